@@ -1,0 +1,92 @@
+"""ctypes binding of libgeom_hip.so (the C ABI declared in include/geom_hip.h).
+
+torch is used only for device memory and the current HIP stream; the signatures below are
+plain pointers and sizes.  Loading fails loudly -- there is no fallback implementation.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgeom_hip.so")
+
+FLAG_REF_TAIL_TRUNC = 1
+FLAG_FIX_REGION6 = 2
+ABI_VERSION = 1
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_u = ctypes.c_uint
+_f = ctypes.c_float
+
+# name -> argtypes; every function returns int (0 ok / hipError_t / negative GEOM_E*)
+_SIGNATURES = {
+    "geom_chamfer_nn_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp],
+    "geom_tri_distance_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp],
+    "geom_tri_distance_indexed_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _u, _vp],
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "geometrics_amd: %s is missing -- build it with `python -m geometrics_amd.build` "
+                "(hipcc, gfx950). There is no CPU/PyTorch fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.geom_abi_version.restype = _i
+        L.geom_strerror.restype = ctypes.c_char_p
+        L.geom_strerror.argtypes = [_i]
+        if L.geom_abi_version() != ABI_VERSION:
+            raise RuntimeError("geometrics_amd: libgeom_hip.so ABI %d != binding ABI %d; rebuild"
+                               % (L.geom_abi_version(), ABI_VERSION))
+        for name, args in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = _i
+        _lib = L
+    return _lib
+
+
+def declared_symbols():
+    return ["geom_abi_version", "geom_strerror"] + sorted(_SIGNATURES)
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().geom_strerror(code).decode()
+        raise RuntimeError("%s failed: %s (code %d)" % (what, msg, code))
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require(t, name, dtype, ndim=None, last=None):
+    """Validate what the reference leaves unchecked (chamfer_distance.cpp:15-27): device, dtype,
+    layout.  Returns a contiguous tensor (the reference wrappers call .contiguous() too)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on a HIP device (got %s); geometrics_amd has no CPU path"
+                           % (name, t.device))
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+    if ndim is not None and t.dim() != ndim:
+        raise RuntimeError("%s must be %d-dimensional (got shape %s)" % (name, ndim, tuple(t.shape)))
+    if last is not None and t.shape[-1] != last:
+        raise RuntimeError("%s must have last dimension %d (got shape %s)" % (name, last, tuple(t.shape)))
+    return t.contiguous()
+
+
+def same_device(*tensors):
+    dev = tensors[0].device
+    for t in tensors[1:]:
+        if t.device != dev:
+            raise RuntimeError("all tensors must be on the same device (%s vs %s)" % (dev, t.device))
+    return dev

@@ -1,0 +1,60 @@
+"""Drop-in for the reference package `chamfer_distance` (chamfer_distance/chamfer_distance.py:9-38).
+
+    ChamferDistance()(xyz1, xyz2) -> (idx1, idx2)      int32, non-differentiable
+
+idx1[b,i] = arg-min_j |xyz2[b,j]-xyz1[b,i]|^2, idx2 the other direction.  Differences from the
+reference wrapper: outputs are allocated on the device (no four host allocations + H2D
+copies per call), the launch goes to torch's current stream, inputs are validated and
+launch failures raise instead of printing.  `chamfer_nn` additionally returns the
+squared distances the kernel computes anyway.
+"""
+import torch
+
+from .. import _lib
+
+
+def chamfer_nn(xyz1, xyz2, flags=0):
+    """(dist1 [B,N] f32, idx1 [B,N] i32, dist2 [B,M] f32, idx2 [B,M] i32)."""
+    xyz1 = _lib.require(xyz1.detach(), "xyz1", torch.float32, 3, 3)
+    xyz2 = _lib.require(xyz2.detach(), "xyz2", torch.float32, 3, 3)
+    dev = _lib.same_device(xyz1, xyz2)
+    b, n, _ = xyz1.shape
+    b2, m, _ = xyz2.shape
+    if b != b2:
+        raise RuntimeError("batch sizes differ: %d vs %d" % (b, b2))
+    dist1 = torch.empty(b, n, dtype=torch.float32, device=dev)
+    dist2 = torch.empty(b, m, dtype=torch.float32, device=dev)
+    idx1 = torch.empty(b, n, dtype=torch.int32, device=dev)
+    idx2 = torch.empty(b, m, dtype=torch.int32, device=dev)
+    forward_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2, flags)
+    return dist1, idx1, dist2, idx2
+
+
+def forward_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2, flags=0):
+    """Same call shape as the reference's pybind `cd.forward_cuda` (chamfer_distance.cpp:15-27,36-38):
+    caller-allocated outputs, filled in place."""
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    with torch.cuda.device(xyz1.device):
+        code = _lib.lib().geom_chamfer_nn_f32(
+            b, n, xyz1.data_ptr(), m, xyz2.data_ptr(),
+            dist1.data_ptr(), idx1.data_ptr(), dist2.data_ptr(), idx2.data_ptr(),
+            flags, _lib.stream_ptr())
+    _lib.check(code, "geom_chamfer_nn_f32")
+
+
+class ChamferDistanceFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        _, idx1, _, idx2 = chamfer_nn(xyz1, xyz2)
+        ctx.mark_non_differentiable(idx1, idx2)
+        return idx1, idx2
+
+    @staticmethod
+    def backward(ctx, *grads):  # integer outputs: nothing flows (the reference defines no backward)
+        return None, None
+
+
+class ChamferDistance(torch.nn.Module):
+    def forward(self, xyz1, xyz2):
+        return ChamferDistanceFunction.apply(xyz1, xyz2)

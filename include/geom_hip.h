@@ -1,0 +1,130 @@
+/*
+ * geom_hip.h -- C ABI of libgeom_hip.so: the MI355X (gfx950) implementation of the
+ * GEOMetrics per-step hot path.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions (all entry points)
+ *   - every pointer is a DEVICE pointer unless stated otherwise; the caller
+ *     allocates every output and every workspace (the library never allocates
+ *     or frees device memory, so all calls are hipGraph-capture safe);
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); kernels
+ *     are enqueued on it and the call returns without synchronising;
+ *   - return value: 0 on success, a positive hipError_t if a launch failed,
+ *     a negative GEOM_E* code for a rejected argument.  Nothing is printed.
+ *     (The reference swallows launch errors with printf:
+ *      chamfer_distance/chamfer_distance.cu:70-72, tri_distance/tri_distance.cu:225-227.)
+ *   - layouts are the reference's: contiguous AoS float32 [B,N,3], int32 index
+ *     outputs (chamfer_distance/chamfer_distance.py:16-26, tri_distance/tri_distance.py:22-30).
+ *
+ * Paths in the comments are relative to the reference checkout (EdwardSmith1884/GEOMetrics).
+ */
+#ifndef GEOM_HIP_H
+#define GEOM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEOM_ABI_VERSION 1
+
+/* argument errors */
+#define GEOM_EINVAL   (-1) /* bad size / null pointer */
+#define GEOM_ETOOBIG  (-2) /* a dimension exceeds what the index encoding supports */
+
+/* flags (bit set) */
+#define GEOM_FLAG_REF_TAIL_TRUNC 1u /* reproduce the shipped CUDA kernels' tail truncation:
+                                       chamfer_distance.cu:31-33, tri_distance.cu:129-134 */
+#define GEOM_FLAG_FIX_REGION6    2u /* tri: walk option 6 along CA instead of the reference's AB (tri_distance.cu:180, Q2) */
+
+int geom_abi_version(void);
+/* static string for a code returned by any entry point */
+const char *geom_strerror(int code);
+
+/* ---- Chamfer nearest neighbour, both directions in one launch --------------------
+ * Replaces ChamferDistanceKernelLauncher (chamfer_distance/chamfer_distance.cpp:4-12,
+ * chamfer_distance/chamfer_distance.cu:57-73) as bound by cd.forward_cuda
+ * (chamfer_distance.cpp:15-27,36-38).
+ *   xyz  [b,n,3], xyz2 [b,m,3]
+ *   result  [b,n] / result_i  [b,n]: squared distance / index of the nearest xyz2 point of each xyz point
+ *   result2 [b,m] / result2_i [b,m]: the other direction
+ * Arg-min is the sequential-scan one: first target seeds, strict '<', lowest index wins ties. */
+int geom_chamfer_nn_f32(int b, int n, const float *xyz, int m, const float *xyz2,
+                        float *result, int *result_i, float *result2, int *result2_i,
+                        unsigned flags, void *stream);
+
+/* ---- point -> triangle distance ------------------------------------------------------
+ * Replaces TriDistanceKernelLauncher (tri_distance/tri_distance.cpp:4-13,
+ * tri_distance/tri_distance.cu:213-228) as bound by tri.forward_cuda (tri_distance.cpp:16-30,34-36).
+ *   xyz [b,n,3]; tri1,tri2,tri3 [b,m,3] = corner A,B,C of every face
+ *   dist [b,n] squared distance to the chosen closest point, point [b,n] region code 0..6,
+ *   index [b,n] winning triangle. */
+int geom_tri_distance_f32(int b, int n, const float *xyz, int m,
+                          const float *tri1, const float *tri2, const float *tri3,
+                          float *dist, int *point, int *index, unsigned flags, void *stream);
+
+/* Same result with the corners gathered in-kernel: verts [b,nv,3], faces [nf,3] int64
+ * shared by the batch (what utils.py:467-469 materialises with three index_selects). */
+int geom_tri_distance_indexed_f32(int b, int n, const float *xyz, int nv, const float *verts,
+                                  int nf, const int64_t *faces,
+                                  float *dist, int *point, int *index, unsigned flags, void *stream);
+
+/* ---- differentiable face sampling (utils.py:590-633) -------------------------------------
+ * areas[b,nf] = 0.5*|(v0-v1) x (v1-v2)|, the un-normalised multinomial weights (utils.py:596-602). */
+int geom_face_areas_f32(int b, int nv, const float *verts, int nf, const int64_t *faces,
+                        float *areas, void *stream);
+/* points[b,num,3] = (1-u)*x + (u*(1-v))*y + (u*v)*z with x,y,z the corners of face
+ * choices[b,num] (int64 face ids), u already sqrt'ed (utils.py:615-631). */
+int geom_sample_faces_fwd_f32(int b, int nv, const float *verts, int nf, const int64_t *faces,
+                              int num, const int64_t *choices, const float *u, const float *v,
+                              float *points, void *stream);
+/* grad_verts[b,nv,3] += barycentric weights * grad_points[b,num,3]; grad_verts must be
+ * zero-initialised (or hold a running sum) by the caller; fp32 atomics. */
+int geom_sample_faces_bwd_f32(int b, int nv, int nf, const int64_t *faces,
+                              int num, const int64_t *choices, const float *u, const float *v,
+                              const float *grad_points, float *grad_verts, void *stream);
+
+/* ---- loss stages (utils.py:393-502, 506-587) -------------------------------------------------
+ * Chamfer gather loss.  For every point j of `src` [b,n,3]: e_j = |dst[b, idx[b,j]] - src[b,j]|^2.
+ * sums[0] = sum_j e_j (fp32, deterministic two-level reduction); hits[b] += #(0.57*sqrt(e_j) <= 1e-2)
+ * when hits != NULL (the F1 counters of utils.py:424-431 / 489-496).
+ * scratch: at least geom_reduce_scratch_floats(b*n) floats. */
+int geom_gather_sqdist_fwd_f32(int b, int n, const float *src, int m, const float *dst,
+                               const int *idx, float *sums, int *hits, float *scratch, void *stream);
+/* grad_src[b,j] (+)= coef*(src - dst[idx]) and, when grad_dst != NULL, grad_dst[b,idx] -= same (atomics).
+ * coef is read from the DEVICE scalar coef_dev[0] times coef_host. accumulate!=0 adds into grad_src. */
+int geom_gather_sqdist_bwd_f32(int b, int n, const float *src, int m, const float *dst,
+                               const int *idx, const float *coef_dev, float coef_host,
+                               float *grad_src, int accumulate, float *grad_dst, void *stream);
+
+/* Point-to-surface loss for the winning triangle of each point (calc_point_to_line,
+ * utils.py:506-550 with edge/Plane utils.py:553-587): q = closest point selected by
+ * option[b,j] on triangle index[b,j] of (verts,faces); sums[0] = sum |q - p|^2.
+ * closest[b,n,3] (optional) receives q, weights[b,n,3] (optional) its affine weights on A,B,C. */
+int geom_p2tri_loss_fwd_f32(int b, int n, const float *xyz, int nv, const float *verts,
+                            int nf, const int64_t *faces, const int *option, const int *index,
+                            float *sums, float *closest, float *weights, float *scratch, void *stream);
+/* grad_verts[b, faces[index,k]] += coef * w_k * (q - p)  (closed form of the reference autograd). */
+int geom_p2tri_loss_bwd_f32(int b, int n, const float *xyz, int nv, int nf, const int64_t *faces,
+                            const int *index, const float *closest, const float *weights,
+                            const float *coef_dev, float coef_host, float *grad_verts, void *stream);
+
+int64_t geom_reduce_scratch_floats(int64_t count);
+
+/* ---- 0N-GCN aggregation (layers.py:34-41, 107-116, 143-152) -----------------------------------
+ * out[r,:k] = sum_j val[j]*support[col[j],:k] over CSR row r (rowptr int32 [nv+1], col int32, val f32),
+ * out[r,k:] = support[r,k:], then + bias[c] when bias != NULL.  support/out are [b,nv,c] row-major.
+ * act: 0 none, 1 relu, 2 elu(alpha=1) fused into the epilogue. */
+int geom_zn_gcn_aggregate_fwd_f32(int b, int nv, int c, int k, const int *rowptr, const int *col,
+                                  const float *val, const float *support, const float *bias,
+                                  int act, float *out, void *stream);
+/* grad_support[r,:k] = sum over CSR^T row r of valT*g[colT,:k]; grad_support[r,k:] = g[r,k:], where
+ * g = grad_out * act'(out) when act != 0 (out = the saved forward output). */
+int geom_zn_gcn_aggregate_bwd_f32(int b, int nv, int c, int k, const int *rowptrT, const int *colT,
+                                  const float *valT, const float *grad_out, const float *out,
+                                  int act, float *grad_support, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEOM_HIP_H */

@@ -1,0 +1,315 @@
+/*
+ * geom_oracle.c -- CPU ORACLE for the GEOMetrics hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is a plain-C restatement of the reference algorithms, used as the
+ * checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ * Nothing in the shipped product path (geometrics_amd/) may import, link or
+ * call it.
+ *
+ * Build with:  gcc -O2 -std=c99 -ffp-contract=off -fPIC -shared   (see Makefile)
+ * -ffp-contract=off pins ONE arithmetic: every product and sum below is a
+ * separately rounded IEEE binary32 operation, evaluated left to right exactly
+ * as written.  The HIP kernels are compiled with the same flag and use the
+ * same operation order, which is what makes index / distance parity bit-exact.
+ *
+ * What each function follows (paths relative to the reference checkout):
+ *   oracle_nn_scan        old_GEOMetrics/chamfer_distance/src/my_lib.c:4-26   (nnsearch)
+ *   oracle_nn_tiled       chamfer_distance/chamfer_distance.cu:6-55           (tile=512 kernel,
+ *                          incl. the tail-truncation quirks Q1/Q3 of lines 29-33,47-50)
+ *   oracle_tri_scan       tri_distance/tri_distance.cu:6-91 (helpers), 94-211 (kernel)
+ *   oracle_nn_grad        old_GEOMetrics/chamfer_distance/src/my_lib.c:49-111 (nnd_backward)
+ *
+ * Parity pinning (see DESIGN.md "Oracle"):
+ *   - oracle_nn_scan is pinned against the reference's own nnsearch, compiled
+ *     from the reference source where it lies into oracle/_ref/ (build_ref.sh),
+ *     on random, tie-heavy and ragged inputs (tests/test_oracle_pin.py, and the
+ *     golden vectors in tests/golden/ were emitted by that reference binary).
+ *   - oracle_tri_scan has NO executable reference (the only implementation is
+ *     the CUDA kernel; no nvcc here).  It is a line-for-line restatement and is
+ *     pinned indirectly: the reference's own utils.calc_point_to_line, imported
+ *     from the reference checkout, must reproduce dist for the (index, option)
+ *     it emits (options 0-5; option 6 differs by the reference's Q2 bug).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+/* flag bits shared with include/geom_hip.h */
+#define GEOM_FLAG_REF_TAIL_TRUNC 1u /* reproduce Q1/Q3: last (len&3) targets of every 512-tile skipped */
+#define GEOM_FLAG_FIX_REGION6    2u /* use the correct CA delta for option 6 instead of the reference's AB delta (Q2) */
+
+#define REF_TILE 512 /* chamfer_distance.cu:15, tri_distance.cu:106 */
+
+/* ------------------------------------------------------------------ NN ---- */
+
+/* squared distance in the reference's operation order: (dx*dx + dy*dy) + dz*dz,
+ * dx = target - query   (my_lib.c:13-16, chamfer_distance.cu:35-38) */
+static inline float sqdist3(const float *t, float qx, float qy, float qz)
+{
+    float dx = t[0] - qx;
+    float dy = t[1] - qy;
+    float dz = t[2] - qz;
+    float xx = dx * dx;
+    float yy = dy * dy;
+    float zz = dz * dz;
+    float s = xx + yy;
+    return s + zz;
+}
+
+/* Full sequential scan: first target seeds, strict '<' afterwards, so the lowest
+ * index wins ties and a NaN seed sticks (my_lib.c:11-21).  The reference keeps
+ * `best` in a double; every value it ever holds is a float, so float compares
+ * are value-identical. */
+void oracle_nn_scan(int b, int n, int m, const float *query, const float *target,
+                    float *dist, int *idx)
+{
+    for (int i = 0; i < b; ++i) {
+        const float *T = target + (size_t)i * m * 3;
+        for (int j = 0; j < n; ++j) {
+            const float *q = query + ((size_t)i * n + j) * 3;
+            float best = 0.0f;
+            int arg = 0;
+            for (int k = 0; k < m; ++k) {
+                float d = sqdist3(T + 3 * k, q[0], q[1], q[2]);
+                if (k == 0 || d < best) {
+                    best = d;
+                    arg = k;
+                }
+            }
+            dist[(size_t)i * n + j] = best;
+            idx[(size_t)i * n + j] = arg;
+        }
+    }
+}
+
+/* The shipped CUDA kernel, tile by tile (chamfer_distance.cu:19-52).
+ * flags & GEOM_FLAG_REF_TAIL_TRUNC reproduces `end_ka = end_k - (end_k & 3)`;
+ * without it every target of the tile is a candidate (the legacy kernel's
+ * behaviour, nnd_cuda.cu:110-119). */
+void oracle_nn_tiled(int b, int n, int m, const float *query, const float *target,
+                     float *dist, int *idx, unsigned flags)
+{
+    for (int i = 0; i < b; ++i) {
+        for (int k2 = 0; k2 < m; k2 += REF_TILE) {
+            int len = (m - k2 < REF_TILE) ? (m - k2) : REF_TILE;
+            int scan = (flags & GEOM_FLAG_REF_TAIL_TRUNC) ? len - (len & 3) : len;
+            const float *T = target + ((size_t)i * m + k2) * 3;
+            for (int j = 0; j < n; ++j) {
+                const float *q = query + ((size_t)i * n + j) * 3;
+                float best = 0.0f;
+                int arg = 0;
+                for (int k = 0; k < scan; ++k) {
+                    float d = sqdist3(T + 3 * k, q[0], q[1], q[2]);
+                    if (k == 0 || d < best) {
+                        best = d;
+                        arg = k + k2;
+                    }
+                }
+                size_t o = (size_t)i * n + j;
+                if (k2 == 0 || dist[o] > best) {
+                    dist[o] = best;
+                    idx[o] = arg;
+                }
+            }
+        }
+    }
+}
+
+/* Gradient scatter of the dist-returning Chamfer formulation (my_lib.c:64-108):
+ * g = 2*graddist; gradients accumulate in source order. */
+void oracle_nn_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
+                    const float *graddist1, const float *graddist2,
+                    const int *idx1, const int *idx2, float *gradxyz1, float *gradxyz2)
+{
+    memset(gradxyz1, 0, sizeof(float) * (size_t)b * n * 3);
+    memset(gradxyz2, 0, sizeof(float) * (size_t)b * m * 3);
+    for (int i = 0; i < b; ++i) {
+        for (int pass = 0; pass < 2; ++pass) {
+            const float *A = pass ? xyz2 : xyz1, *B = pass ? xyz1 : xyz2;
+            float *gA = pass ? gradxyz2 : gradxyz1, *gB = pass ? gradxyz1 : gradxyz2;
+            const float *gd = pass ? graddist2 : graddist1;
+            const int *id = pass ? idx2 : idx1;
+            int na = pass ? m : n, nb = pass ? n : m;
+            for (int j = 0; j < na; ++j) {
+                int j2 = id[(size_t)i * na + j];
+                float g = gd[(size_t)i * na + j] * 2;
+                for (int c = 0; c < 3; ++c) {
+                    float diff = A[((size_t)i * na + j) * 3 + c] - B[((size_t)i * nb + j2) * 3 + c];
+                    gA[((size_t)i * na + j) * 3 + c] += g * diff;
+                    gB[((size_t)i * nb + j2) * 3 + c] -= g * diff;
+                }
+            }
+        }
+    }
+}
+
+/* ----------------------------------------------------- point -> triangle --- */
+
+typedef struct { float x, y, z; } v3;
+
+static inline v3 v3_sub(v3 a, v3 b) { v3 r = { a.x - b.x, a.y - b.y, a.z - b.z }; return r; }   /* tri_distance.cu:19-22 */
+static inline v3 v3_add(v3 a, v3 b) { v3 r = { a.x + b.x, a.y + b.y, a.z + b.z }; return r; }   /* :24-27 */
+static inline v3 v3_scale(v3 a, float s) { v3 r = { a.x * s, a.y * s, a.z * s }; return r; }    /* :29-32 */
+static inline v3 v3_cross(v3 a, v3 b)                                                           /* :34-37 */
+{
+    v3 r;
+    float p0 = a.y * b.z, p1 = a.z * b.y;
+    float p2 = a.z * b.x, p3 = a.x * b.z;
+    float p4 = a.x * b.y, p5 = a.y * b.x;
+    r.x = p0 - p1;
+    r.y = p2 - p3;
+    r.z = p4 - p5;
+    return r;
+}
+static inline float v3_dot(v3 a, v3 b)                                                          /* :38-40 */
+{
+    float xx = a.x * b.x, yy = a.y * b.y, zz = a.z * b.z;
+    float s = xx + yy;
+    return s + zz;
+}
+/* Project_Edge, tri_distance.cu:46-52: ((p - A) . D) / |D|^2, a true IEEE division */
+static inline float edge_param(v3 org, v3 dir, v3 p)
+{
+    v3 v = v3_sub(p, org);
+    float len = v3_dot(dir, dir);
+    return v3_dot(v, dir) / len;
+}
+static inline int unit_range(float u) { return (u <= 1.0f && u >= 0.0f); }                      /* in_range :59-66 */
+/* is_above, tri_distance.cu:67-71: sign test against the in-plane edge normal T x D */
+static inline int inner_side(v3 org, v3 dir, v3 trinorm, v3 p)
+{
+    v3 nrm = v3_cross(trinorm, dir);
+    return v3_dot(nrm, v3_sub(p, org)) > 0.0f;
+}
+/* Project_Plane + normalize, tri_distance.cu:76-91.  `1./len` in the reference is
+ * a DOUBLE division whose result is narrowed to float by mul(Vec,float). */
+static inline v3 plane_foot(v3 org, v3 nrm, v3 p)
+{
+    v3 v = v3_sub(p, org);
+    float len = sqrtf(v3_dot(nrm, nrm));
+    float inv = (float)(1.0 / (double)len);
+    v3 unit = v3_scale(nrm, inv);
+    float h = v3_dot(v, unit);
+    return v3_sub(p, v3_scale(unit, h));
+}
+
+/* One (point, triangle) evaluation: decision tree of tri_distance.cu:140-191.
+ * Returns squared distance to the chosen closest point; *opt gets the 0..6 code. */
+static inline float tri_pair(v3 p, v3 A, v3 B, v3 C, unsigned flags, int *opt)
+{
+    v3 dAB = v3_sub(B, A);
+    v3 dBC = v3_sub(C, B);
+    v3 dCA = v3_sub(A, C);
+    v3 nrm = v3_cross(v3_sub(A, B), v3_sub(A, C));
+    float uab = edge_param(A, dAB, p);
+    float uca = edge_param(C, dCA, p);
+    v3 hit;
+    int code;
+    if (uca > 1.0f && uab < 0.0f) {
+        hit = A; code = 1;
+    } else {
+        float ubc = edge_param(B, dBC, p);
+        if (uab > 1.0f && ubc < 0.0f) {
+            hit = B; code = 2;
+        } else if (ubc > 1.0f && uca < 0.0f) {
+            hit = C; code = 3;
+        } else if (unit_range(uab) && !inner_side(A, dAB, nrm, p)) {
+            hit = v3_add(A, v3_scale(dAB, uab)); code = 4;
+        } else if (unit_range(ubc) && !inner_side(B, dBC, nrm, p)) {
+            hit = v3_add(B, v3_scale(dBC, ubc)); code = 5;
+        } else if (unit_range(uca) && !inner_side(C, dCA, nrm, p)) {
+            /* Q2: the reference walks from C along the AB delta (tri_distance.cu:180) */
+            v3 walk = (flags & GEOM_FLAG_FIX_REGION6) ? dCA : dAB;
+            hit = v3_add(C, v3_scale(walk, uca)); code = 6;
+        } else {
+            hit = plane_foot(A, nrm, p); code = 0;
+        }
+    }
+    *opt = code;
+    v3 diff = v3_sub(p, hit);
+    return v3_dot(diff, diff);
+}
+
+/* Arg-min over triangles.  Default: one sequential scan, first triangle seeds,
+ * strict '<' (tri_distance.cu:194-198 inside a tile, :202-206 across tiles are
+ * equivalent to this for non-NaN data).  With GEOM_FLAG_REF_TAIL_TRUNC the
+ * 512-tile structure and its `end_ka` truncation are reproduced literally. */
+void oracle_tri_scan(int b, int n, const float *xyz, int m,
+                     const float *tri1, const float *tri2, const float *tri3,
+                     float *dist, int *point, int *index, unsigned flags)
+{
+    const int tile = (flags & GEOM_FLAG_REF_TAIL_TRUNC) ? REF_TILE : (m > 0 ? m : 1);
+    for (int i = 0; i < b; ++i) {
+        for (int k2 = 0; k2 < m; k2 += tile) {
+            int len = (m - k2 < tile) ? (m - k2) : tile;
+            int scan = (flags & GEOM_FLAG_REF_TAIL_TRUNC) ? len - (len & 3) : len;
+            for (int j = 0; j < n; ++j) {
+                size_t o = (size_t)i * n + j;
+                v3 p = { xyz[o * 3 + 0], xyz[o * 3 + 1], xyz[o * 3 + 2] };
+                float best = 10000.0f; /* tri_distance.cu:127 (dead unless scan == 0) */
+                int best_opt = 0, arg = 0;
+                for (int k = 0; k < scan; ++k) {
+                    size_t t = ((size_t)i * m + k2 + k) * 3;
+                    v3 A = { tri1[t], tri1[t + 1], tri1[t + 2] };
+                    v3 B = { tri2[t], tri2[t + 1], tri2[t + 2] };
+                    v3 C = { tri3[t], tri3[t + 1], tri3[t + 2] };
+                    int code;
+                    float d = tri_pair(p, A, B, C, flags, &code);
+                    if (k == 0 || d < best) {
+                        best = d;
+                        best_opt = code;
+                        arg = k + k2;
+                    }
+                }
+                if (k2 == 0 || dist[o] > best) {
+                    dist[o] = best;
+                    point[o] = best_opt;
+                    index[o] = arg;
+                }
+            }
+        }
+    }
+}
+
+/* Same scan with the triangle corners gathered from verts[b,nv,3] through
+ * faces[nf,3] (int64, shared by the batch) -- what utils.py:467-470 feeds the
+ * kernel after its three index_selects. */
+void oracle_tri_scan_indexed(int b, int n, const float *xyz, int nv, const float *verts,
+                             int nf, const int64_t *faces,
+                             float *dist, int *point, int *index, unsigned flags)
+{
+    for (int i = 0; i < b; ++i) {
+        const float *V = verts + (size_t)i * nv * 3;
+        for (int j = 0; j < n; ++j) {
+            size_t o = (size_t)i * n + j;
+            v3 p = { xyz[o * 3 + 0], xyz[o * 3 + 1], xyz[o * 3 + 2] };
+            float best = 10000.0f;
+            int best_opt = 0, arg = 0;
+            for (int k = 0; k < nf; ++k) {
+                const float *a = V + 3 * faces[3 * (size_t)k + 0];
+                const float *bb = V + 3 * faces[3 * (size_t)k + 1];
+                const float *c = V + 3 * faces[3 * (size_t)k + 2];
+                v3 A = { a[0], a[1], a[2] }, B = { bb[0], bb[1], bb[2] }, C = { c[0], c[1], c[2] };
+                int code;
+                float d = tri_pair(p, A, B, C, flags, &code);
+                if (k == 0 || d < best) {
+                    best = d;
+                    best_opt = code;
+                    arg = k;
+                }
+            }
+            dist[o] = best;
+            point[o] = best_opt;
+            index[o] = arg;
+        }
+    }
+}
+
+/* single pair, exported for unit tests of the decision tree */
+float oracle_tri_pair(const float *p, const float *A, const float *B, const float *C,
+                      unsigned flags, int *opt)
+{
+    v3 pp = { p[0], p[1], p[2] }, a = { A[0], A[1], A[2] }, bb = { B[0], B[1], B[2] }, c = { C[0], C[1], C[2] };
+    return tri_pair(pp, a, bb, c, flags, opt);
+}

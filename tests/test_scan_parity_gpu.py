@@ -1,0 +1,155 @@
+"""-m gpu parity of the two arg-min scans (through the C ABI) against the CPU oracle.
+
+Bar: indices, region codes AND distances bit-exact (integer/index work; the distances are
+produced by the same un-fused fp32 operation sequence on both sides)."""
+import numpy as np
+import pytest
+import torch
+
+from geometrics_amd import meshgen
+from geometrics_amd._lib import FLAG_FIX_REGION6, FLAG_REF_TAIL_TRUNC
+from geometrics_amd.chamfer_distance import ChamferDistance, chamfer_nn
+from geometrics_amd.tri_distance import TriDistance, tri_distance, tri_distance_indexed
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, gpu):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+
+
+def _check_nn(oracle_mod, gpu, a, b, flags=0):
+    d1, i1, d2, i2 = chamfer_nn(_dev(a, gpu), _dev(b, gpu), flags)
+    e1, j1, e2, j2 = oracle_mod.chamfer_nn(a, b, flags)
+    np.testing.assert_array_equal(i1.cpu().numpy(), j1)
+    np.testing.assert_array_equal(i2.cpu().numpy(), j2)
+    np.testing.assert_array_equal(d1.cpu().numpy().view(np.uint32), e1.view(np.uint32))
+    np.testing.assert_array_equal(d2.cpu().numpy().view(np.uint32), e2.view(np.uint32))
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 500, 500), (2, 3000, 3000), (3, 1, 1), (2, 7, 2466), (1, 2466, 5),
+                                   (2, 63, 65), (1, 1025, 1023), (4, 300, 4097)])
+def test_nn_random(oracle_mod, gpu, b, n, m):
+    rng = np.random.default_rng(b * 1000003 + n * 131 + m)
+    a = rng.standard_normal((b, n, 3)).astype(np.float32)
+    c = rng.standard_normal((b, m, 3)).astype(np.float32)
+    _check_nn(oracle_mod, gpu, a, c)
+
+
+def test_nn_ties_lowest_index(oracle_mod, gpu):
+    rng = np.random.default_rng(5)
+    a = rng.integers(-3, 4, (2, 777, 3)).astype(np.float32)       # integer grid: masses of exact ties
+    c = rng.integers(-3, 4, (2, 1300, 3)).astype(np.float32)
+    c[:, 600:900] = c[:, :300]                                      # duplicated targets
+    _check_nn(oracle_mod, gpu, a, c)
+
+
+def test_nn_config_shapes(oracle_mod, gpu):
+    V, F = meshgen.icosphere(4)
+    verts = meshgen.jittered_batch(V, 2)
+    gt = meshgen.gt_cloud(2, 3000)
+    _check_nn(oracle_mod, gpu, gt, verts)      # 3000 vs 2562 (2562 % 4 == 2)
+    _check_nn(oracle_mod, gpu, gt, meshgen.gt_cloud(2, 3000, first=7, cube=True))
+
+
+@pytest.mark.parametrize("m", [4, 5, 6, 7, 511, 512, 513, 516, 2466, 1, 3, 1027])
+def test_nn_reference_tail_truncation(oracle_mod, gpu, m):
+    rng = np.random.default_rng(m)
+    a = rng.standard_normal((2, 130, 3)).astype(np.float32)
+    c = rng.standard_normal((2, m, 3)).astype(np.float32)
+    _check_nn(oracle_mod, gpu, a, c, FLAG_REF_TAIL_TRUNC)
+
+
+def test_nn_nan_and_inf_follow_the_sequential_scan(oracle_mod, gpu):
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal((1, 70, 3)).astype(np.float32)
+    c = rng.standard_normal((1, 300, 3)).astype(np.float32)
+    c[0, 0, 1] = np.nan          # NaN seed sticks
+    a[0, 3, 0] = np.inf          # every distance inf/nan for this query
+    c[0, 17] = np.nan            # NaN later: never chosen
+    d1, i1, d2, i2 = chamfer_nn(_dev(a, gpu), _dev(c, gpu))
+    e1, j1, e2, j2 = oracle_mod.chamfer_nn(a, c)
+    np.testing.assert_array_equal(i1.cpu().numpy(), j1)
+    np.testing.assert_array_equal(i2.cpu().numpy(), j2)
+    np.testing.assert_array_equal(np.isnan(d1.cpu().numpy()), np.isnan(e1))
+
+
+def test_chamfer_module_contract(gpu):
+    x = torch.rand(2, 100, 3, device=gpu, requires_grad=True)
+    y = torch.rand(2, 80, 3, device=gpu)
+    i1, i2 = ChamferDistance()(x, y)
+    assert i1.dtype == torch.int32 and i2.dtype == torch.int32
+    assert i1.shape == (2, 100) and i2.shape == (2, 80)
+    assert not i1.requires_grad and i1.device == x.device
+    with pytest.raises(RuntimeError):
+        ChamferDistance()(x.cpu(), y.cpu())
+    with pytest.raises(RuntimeError):
+        ChamferDistance()(x.double(), y.double())
+
+
+def _mesh_case(b, level, npts, seed=0, cube=False):
+    V, F = meshgen.icosphere(level)
+    verts = meshgen.jittered_batch(V, b, first=seed)
+    pts = meshgen.gt_cloud(b, npts, first=seed, cube=cube)
+    return verts, F, pts
+
+
+def _check_tri(oracle_mod, gpu, pts, verts, F, flags=0):
+    t1, t2, t3 = (np.ascontiguousarray(verts[:, F[:, k]]) for k in range(3))
+    ed, ep, ei = oracle_mod.tri_scan(pts, t1, t2, t3, flags)
+    d, p, i = tri_distance(_dev(pts, gpu), _dev(t1, gpu), _dev(t2, gpu), _dev(t3, gpu), flags)
+    np.testing.assert_array_equal(i.cpu().numpy(), ei)
+    np.testing.assert_array_equal(p.cpu().numpy(), ep)
+    np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), ed.view(np.uint32))
+    d2, p2, i2 = tri_distance_indexed(_dev(pts, gpu), _dev(verts, gpu), _dev(F, gpu), flags)
+    assert torch.equal(i2, i) and torch.equal(p2, p) and torch.equal(d2.view(torch.int32), d.view(torch.int32))
+    return ep
+
+
+def test_tri_config1(oracle_mod, gpu):
+    verts, F, pts = _mesh_case(2, 2, 500)
+    _check_tri(oracle_mod, gpu, pts, verts, F)
+
+
+def test_tri_config3(oracle_mod, gpu):
+    verts, F, pts = _mesh_case(1, 4, 3000)
+    codes = _check_tri(oracle_mod, gpu, pts, verts, F)
+    assert (codes == 0).mean() > 0.5   # interior wins dominate on a closed surface
+
+
+def test_tri_cube_points_and_fix6(oracle_mod, gpu):
+    verts, F, pts = _mesh_case(2, 2, 700, seed=3, cube=True)
+    codes = _check_tri(oracle_mod, gpu, pts, verts, F)
+    assert set(np.unique(codes)) >= {0, 1, 2, 3, 4, 5}
+    _check_tri(oracle_mod, gpu, pts, verts, F, FLAG_FIX_REGION6)
+
+
+@pytest.mark.parametrize("nf", [1, 3, 4, 5, 511, 513, 516, 320])
+def test_tri_ragged_and_truncation(oracle_mod, gpu, nf):
+    verts, F, pts = _mesh_case(2, 3, 130, seed=nf)
+    F = F[:nf]
+    _check_tri(oracle_mod, gpu, pts, verts, F)
+    _check_tri(oracle_mod, gpu, pts, verts, F, FLAG_REF_TAIL_TRUNC)
+
+
+def test_tri_degenerate_triangles(oracle_mod, gpu):
+    verts, F, pts = _mesh_case(1, 2, 200, seed=11)
+    F = F.copy()
+    F[5] = [7, 7, 9]      # zero-length edge -> inf/nan projections
+    F[0] = [3, 3, 3]      # degenerate FIRST triangle: NaN seed semantics
+    F[40] = [1, 2, 2]
+    t1, t2, t3 = (np.ascontiguousarray(verts[:, F[:, k]]) for k in range(3))
+    ed, ep, ei = oracle_mod.tri_scan(pts, t1, t2, t3)
+    d, p, i = tri_distance(_dev(pts, gpu), _dev(t1, gpu), _dev(t2, gpu), _dev(t3, gpu))
+    np.testing.assert_array_equal(i.cpu().numpy(), ei)
+    np.testing.assert_array_equal(p.cpu().numpy(), ep)
+    np.testing.assert_array_equal(np.isnan(d.cpu().numpy()), np.isnan(ed))
+
+
+def test_tri_module_contract(gpu):
+    verts, F, pts = _mesh_case(1, 2, 64)
+    t = [_dev(np.ascontiguousarray(verts[:, F[:, k]]), gpu) for k in range(3)]
+    dist, point, index = TriDistance()(_dev(pts, gpu), *t)
+    assert dist.dtype == torch.float32 and point.dtype == torch.int32 and index.dtype == torch.int32
+    assert dist.shape == (1, 64) and not dist.requires_grad
+    assert int(point.min()) >= 0 and int(point.max()) <= 6 and int(index.max()) < F.shape[0]

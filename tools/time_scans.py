@@ -1,0 +1,37 @@
+"""Dev helper: HIP-event timing of the two arg-min scans at the BASELINE shard (B meshes)."""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+from geometrics_amd import meshgen
+from geometrics_amd.chamfer_distance import chamfer_nn
+from geometrics_amd.tri_distance import tri_distance_indexed
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+dev = torch.device("cuda:0")
+V, F = meshgen.icosphere(4)
+verts = torch.from_numpy(meshgen.jittered_batch(V, B)).to(dev)
+faces = torch.from_numpy(F).to(dev)
+gt = torch.from_numpy(meshgen.gt_cloud(B, 3000)).to(dev)
+pred = torch.from_numpy(meshgen.gt_cloud(B, 3000, first=100)).to(dev)
+
+
+def timeit(fn, iters=50, warm=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3  # us
+
+
+t_nn = timeit(lambda: chamfer_nn(gt, pred))
+t_tri = timeit(lambda: tri_distance_indexed(gt, verts, faces))
+pairs_nn = 2 * B * 3000 * 3000
+pairs_tri = B * 3000 * 5120
+print(f"B={B} nn {t_nn:.1f} us ({pairs_nn / t_nn / 1e6:.2f} Tpair/s)  tri {t_tri:.1f} us ({pairs_tri / t_tri / 1e6:.3f} Tpair/s)")
+print(f"per mesh: nn {t_nn / B:.1f} us  tri {t_tri / B:.1f} us")
