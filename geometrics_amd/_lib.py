@@ -25,7 +25,26 @@ _SIGNATURES = {
     "geom_chamfer_nn_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp],
     "geom_tri_distance_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp],
     "geom_tri_distance_indexed_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _u, _vp],
+    "geom_face_areas_f32": [_i, _i, _vp, _i, _vp, _vp, _vp],
+    "geom_sample_faces_fwd_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "geom_sample_faces_bwd_f32": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "geom_chamfer_grad_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp],
+    "geom_p2tri_loss_fwd_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "geom_p2tri_loss_bwd_f32": [_i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp],
+    "geom_sum_f32": [ctypes.c_int64, _vp, _f, _vp, _vp],
+    "geom_zn_gcn_aggregate_fwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "geom_zn_gcn_aggregate_bwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
 }
+
+
+def call(name, *args):
+    """Invoke an entry point on the current stream of the current device and raise on failure."""
+    code = getattr(lib(), name)(*args, stream_ptr())
+    check(code, name)
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
 
 _lib = None
 

@@ -1,0 +1,329 @@
+// HBM-bound stages around the two scans: face areas, fused gather + barycentric sampling
+// (forward / backward), Chamfer gather-loss gradient, point-to-surface loss (forward /
+// backward) and a deterministic sum.  One thread per point; every operand is read once
+// and every result written once (algorithmic bytes in DESIGN.md "Kernels").
+//
+// Reference stages replaced (all eager PyTorch op chains there):
+//   utils.py:596-602   face areas                     -> face_areas_kernel
+//   utils.py:615-631   gather + barycentric point     -> sample_fwd_kernel / sample_bwd_kernel
+//   utils.py:454-462   NN-pair gather + squared diff  -> chamfer_grad_kernel (forward = the
+//                                                        distances the NN scan already wrote)
+//   utils.py:472-481, 506-587  calc_point_to_line     -> p2tri_fwd_kernel / p2tri_bwd_kernel
+#include "geom_common.h"
+#include "tri_math.h"
+
+namespace {
+
+using geom::V3;
+
+constexpr int PT_THREADS = 256;
+
+__device__ __forceinline__ V3 ld3(const float *p) { return geom::mk(p[0], p[1], p[2]); }
+
+__device__ __forceinline__ void atomic_add3(float *dst, V3 v)
+{
+    atomicAdd(dst + 0, v.x);
+    atomicAdd(dst + 1, v.y);
+    atomicAdd(dst + 2, v.z);
+}
+
+// ---------------------------------------------------------------- face areas ----
+// utils.py:596-602: x = v0 - v1, y = v1 - v2, area = sqrt(a + b + c) / 2 with the three
+// squared cross-product components in the reference's order.
+__global__ __launch_bounds__(PT_THREADS) void face_areas_kernel(int b, int nv, const float *verts, int nf,
+                                                                 const int64_t *faces, float *areas)
+{
+    const int64_t i = (int64_t)blockIdx.x * PT_THREADS + threadIdx.x;
+    if (i >= (int64_t)b * nf) return;
+    const int mesh = (int)(i / nf);
+    const int f = (int)(i - (int64_t)mesh * nf);
+    const float *V = verts + (size_t)mesh * nv * 3;
+    const V3 v0 = ld3(V + 3 * faces[3 * (size_t)f + 0]);
+    const V3 v1 = ld3(V + 3 * faces[3 * (size_t)f + 1]);
+    const V3 v2 = ld3(V + 3 * faces[3 * (size_t)f + 2]);
+    const V3 x = v0 - v1, y = v1 - v2;
+    const float ca = x.y * y.z - x.z * y.y;
+    const float cb = x.z * y.x - x.x * y.z;
+    const float cc = x.x * y.y - x.y * y.x;
+    const float s = (ca * ca + cb * cb) + cc * cc;
+    areas[i] = sqrtf(s) / 2.f;
+}
+
+// -------------------------------------------------------------- face sampling ----
+struct SampleArgs {
+    const float *verts;
+    const int64_t *faces, *choices;
+    const float *u, *v;
+    int b, nv, nf, num;
+};
+
+// points = ((1-u)*x + (u*(1-v))*y) + (u*v)*z   (utils.py:630, torch's evaluation order)
+__global__ __launch_bounds__(PT_THREADS) void sample_fwd_kernel(SampleArgs a, float *points)
+{
+    const int64_t i = (int64_t)blockIdx.x * PT_THREADS + threadIdx.x;
+    if (i >= (int64_t)a.b * a.num) return;
+    const int mesh = (int)(i / a.num);
+    const int64_t f = a.choices[i];
+    const float *V = a.verts + (size_t)mesh * a.nv * 3;
+    const V3 x = ld3(V + 3 * a.faces[3 * f + 0]);
+    const V3 y = ld3(V + 3 * a.faces[3 * f + 1]);
+    const V3 z = ld3(V + 3 * a.faces[3 * f + 2]);
+    const float u = a.u[i], v = a.v[i];
+    const float w0 = 1.f - u;
+    const float w1 = u * (1.f - v);
+    const float w2 = u * v;
+    const V3 p = (x * w0 + y * w1) + z * w2;
+    points[3 * i + 0] = p.x;
+    points[3 * i + 1] = p.y;
+    points[3 * i + 2] = p.z;
+}
+
+__global__ __launch_bounds__(PT_THREADS) void sample_bwd_kernel(SampleArgs a, const float *grad_points,
+                                                                 float *grad_verts)
+{
+    const int64_t i = (int64_t)blockIdx.x * PT_THREADS + threadIdx.x;
+    if (i >= (int64_t)a.b * a.num) return;
+    const int mesh = (int)(i / a.num);
+    const int64_t f = a.choices[i];
+    float *G = grad_verts + (size_t)mesh * a.nv * 3;
+    const V3 g = ld3(grad_points + 3 * i);
+    const float u = a.u[i], v = a.v[i];
+    atomic_add3(G + 3 * a.faces[3 * f + 0], g * (1.f - u));
+    atomic_add3(G + 3 * a.faces[3 * f + 1], g * (u * (1.f - v)));
+    atomic_add3(G + 3 * a.faces[3 * f + 2], g * (u * v));
+}
+
+// ------------------------------------------------------- Chamfer gather loss ----
+// d/dsrc, d/ddst of  sum_j |dst[idx[j]] - src[j]|^2  scaled by coef (utils.py:416-417, 462).
+__global__ __launch_bounds__(PT_THREADS) void chamfer_grad_kernel(int b, int n, const float *src, int m,
+                                                                   const float *dst, const int *idx,
+                                                                   const float *coef_dev, float coef_host,
+                                                                   float *grad_src, int accumulate, float *grad_dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * PT_THREADS + threadIdx.x;
+    if (i >= (int64_t)b * n) return;
+    const int mesh = (int)(i / n);
+    const float coef = 2.f * coef_host * (coef_dev ? coef_dev[0] : 1.f);
+    const size_t t = (size_t)mesh * m + idx[i];
+    const V3 diff = ld3(src + 3 * i) - ld3(dst + 3 * t);
+    const V3 g = diff * coef;
+    if (grad_src) {
+        if (accumulate) {
+            grad_src[3 * i + 0] += g.x;
+            grad_src[3 * i + 1] += g.y;
+            grad_src[3 * i + 2] += g.z;
+        } else {
+            grad_src[3 * i + 0] = g.x;
+            grad_src[3 * i + 1] = g.y;
+            grad_src[3 * i + 2] = g.z;
+        }
+    }
+    if (grad_dst) atomic_add3(grad_dst + 3 * t, g * -1.f);
+}
+
+// -------------------------------------------------- point-to-surface loss ----
+struct P2TArgs {
+    const float *xyz, *verts;
+    const int64_t *faces;
+    const int *option, *index;
+    int b, n, nv, nf;
+};
+
+// Closest point of calc_point_to_line (utils.py:506-550): the SELECTED candidate only,
+// with its affine weights on (A,B,C).  Option 6 walks along CA here (utils.py:543) -- the
+// kernel-side Q2 quirk only influences which triangle won.
+__device__ __forceinline__ V3 closest_on_triangle(V3 p, V3 A, V3 B, V3 C, int opt, V3 &w)
+{
+    if (opt == 1) { w = geom::mk(1.f, 0.f, 0.f); return A; }
+    if (opt == 2) { w = geom::mk(0.f, 1.f, 0.f); return B; }
+    if (opt == 3) { w = geom::mk(0.f, 0.f, 1.f); return C; }
+    if (opt == 4) {
+        const V3 d = B - A;
+        const float t = geom::dot3(p - A, d) / geom::dot3(d, d);
+        w = geom::mk(1.f - t, t, 0.f);
+        return A + d * t;
+    }
+    if (opt == 5) {
+        const V3 d = C - B;
+        const float t = geom::dot3(p - B, d) / geom::dot3(d, d);
+        w = geom::mk(0.f, 1.f - t, t);
+        return B + d * t;
+    }
+    if (opt == 6) {
+        const V3 d = A - C;
+        const float t = geom::dot3(p - C, d) / geom::dot3(d, d);
+        w = geom::mk(t, 0.f, 1.f - t);
+        return C + d * t;
+    }
+    // plane projection (Plane.Project, utils.py:573-587): n = N / sqrt(sum N^2)
+    const V3 N = geom::cross3(A - B, A - C);
+    const float len = sqrtf(geom::dot3(N, N));
+    const V3 n = geom::mk(N.x / len, N.y / len, N.z / len);
+    const float h = geom::dot3(p - A, n);
+    const V3 q = p - n * h;
+    // affine weights of q: q - A = s (B-A) + t (C-A), 2x2 normal equations
+    const V3 e1 = B - A, e2 = C - A, r = q - A;
+    const float a11 = geom::dot3(e1, e1), a12 = geom::dot3(e1, e2), a22 = geom::dot3(e2, e2);
+    const float b1 = geom::dot3(r, e1), b2 = geom::dot3(r, e2);
+    const float det = a11 * a22 - a12 * a12;
+    const float s = (b1 * a22 - b2 * a12) / det;
+    const float t = (b2 * a11 - b1 * a12) / det;
+    w = geom::mk(1.f - s - t, s, t);
+    return q;
+}
+
+__global__ __launch_bounds__(PT_THREADS) void p2tri_fwd_kernel(P2TArgs a, float *sqdist, float *closest,
+                                                                float *weights)
+{
+    const int64_t i = (int64_t)blockIdx.x * PT_THREADS + threadIdx.x;
+    if (i >= (int64_t)a.b * a.n) return;
+    const int mesh = (int)(i / a.n);
+    const float *V = a.verts + (size_t)mesh * a.nv * 3;
+    const int64_t f = a.index[i];
+    const V3 A = ld3(V + 3 * a.faces[3 * f + 0]);
+    const V3 B = ld3(V + 3 * a.faces[3 * f + 1]);
+    const V3 C = ld3(V + 3 * a.faces[3 * f + 2]);
+    const V3 p = ld3(a.xyz + 3 * i);
+    V3 w;
+    const V3 q = closest_on_triangle(p, A, B, C, a.option[i], w);
+    const V3 d = q - p;
+    sqdist[i] = geom::dot3(d, d);
+    if (closest) {
+        closest[3 * i + 0] = q.x;
+        closest[3 * i + 1] = q.y;
+        closest[3 * i + 2] = q.z;
+    }
+    if (weights) {
+        weights[3 * i + 0] = w.x;
+        weights[3 * i + 1] = w.y;
+        weights[3 * i + 2] = w.z;
+    }
+}
+
+// d/dX_k sum |q - p|^2 = 2 w_k (q - p): q is an exact minimiser along every free parameter
+// (edge parameter, plane foot), so the parameter derivatives vanish (envelope theorem); this
+// equals the reference autograd through calc_point_to_line.
+__global__ __launch_bounds__(PT_THREADS) void p2tri_bwd_kernel(int b, int n, const float *xyz, int nv,
+                                                                const int64_t *faces, const int *index,
+                                                                const float *closest, const float *weights,
+                                                                const float *coef_dev, float coef_host,
+                                                                float *grad_verts)
+{
+    const int64_t i = (int64_t)blockIdx.x * PT_THREADS + threadIdx.x;
+    if (i >= (int64_t)b * n) return;
+    const int mesh = (int)(i / n);
+    const float coef = 2.f * coef_host * (coef_dev ? coef_dev[0] : 1.f);
+    const int64_t f = index[i];
+    const V3 g = (ld3(closest + 3 * i) - ld3(xyz + 3 * i)) * coef;
+    const V3 w = ld3(weights + 3 * i);
+    float *G = grad_verts + (size_t)mesh * nv * 3;
+    if (w.x != 0.f) atomic_add3(G + 3 * faces[3 * f + 0], g * w.x);
+    if (w.y != 0.f) atomic_add3(G + 3 * faces[3 * f + 1], g * w.y);
+    if (w.z != 0.f) atomic_add3(G + 3 * faces[3 * f + 2], g * w.z);
+}
+
+// ------------------------------------------------------------ deterministic sum ----
+// One workgroup, fixed traversal and a fixed shuffle/LDS tree: the same input always
+// produces the same bits (the reference's torch.mean has no such guarantee either way).
+constexpr int SUM_THREADS = 1024;
+__global__ __launch_bounds__(SUM_THREADS) void sum_kernel(int64_t n, const float *x, float scale, float *out)
+{
+    __shared__ float partial[SUM_THREADS / GEOM_WAVE];
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += SUM_THREADS) acc += x[i];
+    for (int off = GEOM_WAVE / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, GEOM_WAVE);
+    if ((threadIdx.x & (GEOM_WAVE - 1)) == 0) partial[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x < GEOM_WAVE) {
+        float v = threadIdx.x < SUM_THREADS / GEOM_WAVE ? partial[threadIdx.x] : 0.f;
+        for (int off = GEOM_WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, GEOM_WAVE);
+        if (threadIdx.x == 0) out[0] = v * scale;
+    }
+}
+
+inline dim3 pt_grid(int64_t count) { return dim3((unsigned)((count + PT_THREADS - 1) / PT_THREADS)); }
+
+} // namespace
+
+extern "C" int geom_face_areas_f32(int b, int nv, const float *verts, int nf, const int64_t *faces,
+                                   float *areas, void *stream)
+{
+    if (b < 0 || nv < 0 || nf < 0) return GEOM_EINVAL;
+    if (b == 0 || nf == 0) return 0;
+    if (!verts || !faces || !areas) return GEOM_EINVAL;
+    hipLaunchKernelGGL(face_areas_kernel, pt_grid((int64_t)b * nf), dim3(PT_THREADS), 0,
+                       static_cast<hipStream_t>(stream), b, nv, verts, nf, faces, areas);
+    return geom::launch_status();
+}
+
+extern "C" int geom_sample_faces_fwd_f32(int b, int nv, const float *verts, int nf, const int64_t *faces,
+                                         int num, const int64_t *choices, const float *u, const float *v,
+                                         float *points, void *stream)
+{
+    if (b < 0 || nv < 0 || nf < 0 || num < 0) return GEOM_EINVAL;
+    if (b == 0 || num == 0) return 0;
+    if (!verts || !faces || !choices || !u || !v || !points) return GEOM_EINVAL;
+    SampleArgs a{verts, faces, choices, u, v, b, nv, nf, num};
+    hipLaunchKernelGGL(sample_fwd_kernel, pt_grid((int64_t)b * num), dim3(PT_THREADS), 0,
+                       static_cast<hipStream_t>(stream), a, points);
+    return geom::launch_status();
+}
+
+extern "C" int geom_sample_faces_bwd_f32(int b, int nv, int nf, const int64_t *faces,
+                                         int num, const int64_t *choices, const float *u, const float *v,
+                                         const float *grad_points, float *grad_verts, void *stream)
+{
+    if (b < 0 || nv < 0 || nf < 0 || num < 0) return GEOM_EINVAL;
+    if (b == 0 || num == 0) return 0;
+    if (!faces || !choices || !u || !v || !grad_points || !grad_verts) return GEOM_EINVAL;
+    SampleArgs a{nullptr, faces, choices, u, v, b, nv, nf, num};
+    hipLaunchKernelGGL(sample_bwd_kernel, pt_grid((int64_t)b * num), dim3(PT_THREADS), 0,
+                       static_cast<hipStream_t>(stream), a, grad_points, grad_verts);
+    return geom::launch_status();
+}
+
+extern "C" int geom_chamfer_grad_f32(int b, int n, const float *src, int m, const float *dst,
+                                     const int *idx, const float *coef_dev, float coef_host,
+                                     float *grad_src, int accumulate, float *grad_dst, void *stream)
+{
+    if (b < 0 || n < 0 || m < 0) return GEOM_EINVAL;
+    if (b == 0 || n == 0) return 0;
+    if (!src || !dst || !idx || (!grad_src && !grad_dst)) return GEOM_EINVAL;
+    hipLaunchKernelGGL(chamfer_grad_kernel, pt_grid((int64_t)b * n), dim3(PT_THREADS), 0,
+                       static_cast<hipStream_t>(stream), b, n, src, m, dst, idx, coef_dev, coef_host,
+                       grad_src, accumulate, grad_dst);
+    return geom::launch_status();
+}
+
+extern "C" int geom_p2tri_loss_fwd_f32(int b, int n, const float *xyz, int nv, const float *verts,
+                                       int nf, const int64_t *faces, const int *option, const int *index,
+                                       float *sqdist, float *closest, float *weights, void *stream)
+{
+    if (b < 0 || n < 0 || nv < 0 || nf < 0) return GEOM_EINVAL;
+    if (b == 0 || n == 0) return 0;
+    if (!xyz || !verts || !faces || !option || !index || !sqdist) return GEOM_EINVAL;
+    P2TArgs a{xyz, verts, faces, option, index, b, n, nv, nf};
+    hipLaunchKernelGGL(p2tri_fwd_kernel, pt_grid((int64_t)b * n), dim3(PT_THREADS), 0,
+                       static_cast<hipStream_t>(stream), a, sqdist, closest, weights);
+    return geom::launch_status();
+}
+
+extern "C" int geom_p2tri_loss_bwd_f32(int b, int n, const float *xyz, int nv, int nf, const int64_t *faces,
+                                       const int *index, const float *closest, const float *weights,
+                                       const float *coef_dev, float coef_host, float *grad_verts, void *stream)
+{
+    if (b < 0 || n < 0 || nv < 0 || nf < 0) return GEOM_EINVAL;
+    if (b == 0 || n == 0) return 0;
+    if (!xyz || !faces || !index || !closest || !weights || !grad_verts) return GEOM_EINVAL;
+    hipLaunchKernelGGL(p2tri_bwd_kernel, pt_grid((int64_t)b * n), dim3(PT_THREADS), 0,
+                       static_cast<hipStream_t>(stream), b, n, xyz, nv, faces, index, closest, weights,
+                       coef_dev, coef_host, grad_verts);
+    return geom::launch_status();
+}
+
+extern "C" int geom_sum_f32(int64_t n, const float *x, float scale, float *out, void *stream)
+{
+    if (n < 0 || !out || (n > 0 && !x)) return GEOM_EINVAL;
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(SUM_THREADS), 0, static_cast<hipStream_t>(stream), n, x, scale, out);
+    return geom::launch_status();
+}

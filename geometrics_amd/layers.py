@@ -1,0 +1,209 @@
+"""0N-GCN layers with the reference's class names, constructor signatures, parameter names
+and initialisers (reference layers.py:14-189), so `models.py` and pretrained state_dicts
+(`gcN.weight1`, `gcN.weight`, `gcN.bias`, `weight_Ws.0`, `weight_Bs.0`) work unchanged.
+
+`forward(input, adj, activation)` still receives the DENSE [V,V] adjacency the callers pass
+(models.py:241, GEOMetrics.py:120).  The layer derives CSR and CSR^T from it once (cached on
+the tensor's identity + version) and replaces the reference's dense `adj @ support[..., :k]`,
+`torch.cat` and bias add by one fused HIP kernel (csrc/zn_gcn.hip); the dense feature GEMM
+`input @ W` stays a library GEMM (rocBLAS/hipBLASLt through torch.matmul).
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import Module
+from torch.nn.parameter import Parameter
+
+from . import _lib
+
+_ACT_NONE, _ACT_RELU, _ACT_ELU = 0, 1, 2
+
+
+# --------------------------------------------------------------- CSR cache ----
+class _Csr:
+    __slots__ = ("rowptr", "col", "val", "rowptr_t", "col_t", "val_t", "nv", "nnz")
+
+
+_csr_cache = {}
+_CSR_CACHE_MAX = 16
+
+
+def _to_csr(dense):
+    nz = dense.nonzero()                       # row-major order == CSR order
+    rows, cols = nz[:, 0], nz[:, 1]
+    counts = torch.bincount(rows, minlength=dense.shape[0])
+    rowptr = torch.zeros(dense.shape[0] + 1, dtype=torch.int64, device=dense.device)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    return rowptr.to(torch.int32), cols.to(torch.int32).contiguous(), dense[rows, cols].to(torch.float32).contiguous()
+
+
+def adjacency_csr(adj):
+    """CSR + CSR^T of a dense [V,V] adjacency, cached per (storage, shape, version, device).
+    Building it reads the dense matrix once (one host sync, at first use only)."""
+    if adj.dim() != 2 or adj.shape[0] != adj.shape[1]:
+        raise RuntimeError("adjacency must be a square [V,V] tensor, got %s" % (tuple(adj.shape),))
+    key = (adj.data_ptr(), tuple(adj.shape), adj._version, str(adj.device), adj.dtype)
+    hit = _csr_cache.get(key)
+    if hit is not None:
+        return hit
+    if not adj.is_cuda:
+        raise RuntimeError("adjacency must live on a HIP device; geometrics_amd has no CPU path")
+    with torch.no_grad():
+        c = _Csr()
+        dense = adj.detach()
+        c.rowptr, c.col, c.val = _to_csr(dense)
+        c.rowptr_t, c.col_t, c.val_t = _to_csr(dense.t())
+        c.nv = adj.shape[0]
+        c.nnz = int(c.col.numel())
+    if len(_csr_cache) >= _CSR_CACHE_MAX:
+        _csr_cache.pop(next(iter(_csr_cache)))
+    _csr_cache[key] = c
+    return c
+
+
+# ------------------------------------------------------- fused aggregation ----
+class _ZeroNAggregate(torch.autograd.Function):
+    """out = [A . S[..., :k] | S[..., k:]] + bias  for S [B,V,C] (one kernel, S read once)."""
+
+    @staticmethod
+    def forward(ctx, support, bias, csr, k):
+        s = _lib.require(support, "support", torch.float32, 3)
+        b, nv, c = s.shape
+        if nv != csr.nv:
+            raise RuntimeError("support has %d vertices but the adjacency has %d" % (nv, csr.nv))
+        bias_c = None if bias is None else _lib.require(bias, "bias", torch.float32, 1)
+        out = torch.empty_like(s)
+        with torch.cuda.device(s.device):
+            _lib.call("geom_zn_gcn_aggregate_fwd_f32", b, nv, c, k, csr.rowptr.data_ptr(), csr.col.data_ptr(),
+                      csr.val.data_ptr(), s.data_ptr(), _lib.ptr(bias_c), _ACT_NONE, out.data_ptr())
+        ctx.csr, ctx.k, ctx.has_bias = csr, k, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g = grad_out.contiguous()
+        b, nv, c = g.shape
+        csr = ctx.csr
+        grad_support = None
+        if ctx.needs_input_grad[0]:
+            grad_support = torch.empty_like(g)
+            with torch.cuda.device(g.device):
+                _lib.call("geom_zn_gcn_aggregate_bwd_f32", b, nv, c, ctx.k, csr.rowptr_t.data_ptr(),
+                          csr.col_t.data_ptr(), csr.val_t.data_ptr(), g.data_ptr(), None, _ACT_NONE,
+                          grad_support.data_ptr())
+        grad_bias = g.sum(dim=(0, 1)) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        return grad_support, grad_bias, None, None
+
+
+def zero_n_aggregate(support, adj, bias, k):
+    """Shared tail of every 0N-GCN layer; accepts [V,C] or [B,V,C] support."""
+    csr = adjacency_csr(adj)
+    if support.dim() == 2:
+        return _ZeroNAggregate.apply(support.unsqueeze(0), bias, csr, k).squeeze(0)
+    return _ZeroNAggregate.apply(support, bias, csr, k)
+
+
+def _uniform(t, bound):
+    t.data.uniform_(-bound, bound)
+
+
+# ------------------------------------------------------------------ layers ----
+class _ZeroNBase(Module):
+    """Common body: `split` = denominator of the aggregated column fraction (10 or 3)."""
+    split = 10
+
+    def _weight(self):
+        raise NotImplementedError
+
+    def forward(self, input, adj, activation):
+        w = self._weight()
+        if w.dim() == 3:            # [1,Cin,Cout]: fold the batch into one GEMM instead of B broadcast bmm's
+            w = w.squeeze(0)
+        support = torch.matmul(input, w)
+        out = zero_n_aggregate(support, adj, self.bias, support.shape[-1] // self.split)
+        return activation(out)
+
+
+class ZERON_GCN(_ZeroNBase):
+    """Unbatched layer, first C//10 output channels neighbour-aggregated (reference layers.py:14-41)."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = Parameter(torch.empty(in_features, out_features))
+        if bias:
+            self.bias = Parameter(torch.empty(out_features))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        _uniform(self.weight, 6.0 / math.sqrt(self.weight.size(0) + self.weight.size(1)))
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def _weight(self):
+        return self.weight
+
+
+class BatchZERON_GCN(ZERON_GCN):
+    """Batched [B,V,Cin] input, same parameters and split (reference layers.py:121-152)."""
+
+
+class Batch_Image_ZERON_GCNGCN(_ZeroNBase):
+    """Batched layer with a [1,Cin,Cout] `weight1` and the first C//3 channels aggregated
+    (reference layers.py:84-116; the initialiser's quirk of using size(0)==1 is kept)."""
+    split = 3
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight1 = Parameter(torch.empty(1, in_features, out_features))
+        if bias:
+            self.bias = Parameter(torch.empty(out_features))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        _uniform(self.weight1, 0.3 * 6.0 / math.sqrt(self.weight1.size(1) + self.weight1.size(0)))
+        if self.bias is not None:
+            _uniform(self.bias, 0.1)
+
+    def _weight(self):
+        return self.weight1
+
+
+class _MaxPoolBase(Module):
+    """Aggregate like a 0N-GCN layer (split 10), then max over the vertex axis."""
+
+    def __init__(self, in_features, print_length):
+        super().__init__()
+        self.in_features, self.print_length = in_features, print_length
+        self.weight_Ws = nn.ParameterList([Parameter(torch.empty(in_features, print_length))])
+        self.weight_Bs = nn.ParameterList([Parameter(torch.empty(print_length))])
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        _uniform(self.weight_Bs[0], 6.0 / math.sqrt(self.weight_Bs[0].size(0)))
+        _uniform(self.weight_Ws[0], 6.0 / math.sqrt(self.weight_Ws[0].size(0) + self.weight_Ws[0].size(1)))
+
+    def _pre_activation(self, r_s, adj):
+        support = torch.matmul(r_s, self.weight_Ws[0])
+        return zero_n_aggregate(support, adj, self.weight_Bs[0], support.shape[-1] // 10)
+
+
+class GCNMax(_MaxPoolBase):
+    """Unbatched: max over vertices of activation(v) (reference layers.py:43-79)."""
+
+    def forward(self, r_s, adj, activation):
+        return torch.max(activation(self._pre_activation(r_s, adj)), dim=0)[0]
+
+
+class BatchGCNMax(_MaxPoolBase):
+    """Batched: max over vertices of the PRE-activation values -- the reference computes the
+    activation and then discards it (layers.py:186-187); preserved."""
+
+    def forward(self, r_s, adj, activation):
+        return torch.max(self._pre_activation(r_s, adj), dim=1)[0]

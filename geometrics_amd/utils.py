@@ -1,0 +1,171 @@
+"""Loss / sampling / adjacency helpers with the reference's names and call signatures
+(reference utils.py:95-131, 393-662), running on the HIP kernels of libgeom_hip.so.
+
+What changes underneath (never in results beyond fp32 round-off, NN indices bit-exact):
+  * batch_sample: one fused gather+barycentric kernel and batched random draws instead of
+    ~20 eager ops and a python loop of B multinomials;
+  * the Chamfer term reuses the squared distances the NN scan already computed;
+  * the three [B,F,3] corner gathers feeding tri_dist are done inside the scan kernel;
+  * calc_point_to_line evaluates only the selected candidate (no seven boolean-mask
+    scatters, each of which is a host sync in the reference) and has an analytic backward;
+  * no host synchronisation unless f1=True (the reference syncs on every call through the
+    dead `ratio = dist_1.cpu()/dist_2.cpu()` line, utils.py:482).
+"""
+import torch
+
+from . import ops
+from .chamfer_distance import ChamferDistance, chamfer_nn
+from .tri_distance import TriDistance, tri_distance_indexed
+
+chamfer_dist = ChamferDistance()
+tri_dist = TriDistance()
+
+LOSS_SCALE = 3000.0      # reference utils.py:420, 484
+F1_SCALE = 0.57          # reference utils.py:425-426
+F1_THRESHOLD = 1e-2      # reference utils.py:430-431
+
+
+# ------------------------------------------------------------------ adjacency ----
+def calc_adj(faces):
+    """Dense binary adjacency with self loops (reference utils.py:115-131)."""
+    n = int(faces.max()) + 1
+    adj = torch.eye(n, device=faces.device)
+    a, b, c = faces[:, 0], faces[:, 1], faces[:, 2]
+    rows = torch.cat([a, a, b, b, c, c])
+    cols = torch.cat([b, c, a, c, a, b])
+    adj[rows, cols] = 1
+    return adj
+
+
+def normalize_adj(mx):
+    """D^-1 (A+I): rows sum to 1 (reference utils.py:96-101; a row scaling is bit-identical to
+    the reference's product with a diagonal matrix and skips its V^3 flops)."""
+    r_inv = (1.0 / mx.sum(1)).view(-1)
+    r_inv[r_inv != r_inv] = 0.0
+    return mx * r_inv.unsqueeze(1)
+
+
+def adj_init(faces):
+    """{'adj': normalised, 'adj_orig': binary, 'faces': faces} (reference utils.py:104-113)."""
+    adj_orig = calc_adj(faces)
+    return {"adj": normalize_adj(adj_orig.clone()), "adj_orig": adj_orig, "faces": faces}
+
+
+# ------------------------------------------------------------------- sampling ----
+def batch_sample(verts, faces, num=10000, draws=None):
+    """Area-weighted random surface points [B,num,3], differentiable in verts
+    (reference utils.py:590-633).  `draws=(choices, u, v)` replays pre-drawn randoms
+    (choices [B,num] int64 face ids, u already sqrt'ed) -- used by the parity tests."""
+    if draws is None:
+        draws = ops.draw_samples(verts, faces, num)
+    choices, u, v = draws
+    return ops.SampleFaces.apply(verts, faces, choices.reshape(verts.shape[0], -1),
+                                 u.reshape(verts.shape[0], -1), v.reshape(verts.shape[0], -1))
+
+
+# --------------------------------------------------------------------- losses ----
+def _f_score(sq_to_pred, sq_to_gt, num):
+    """F1 at the reference's scale/threshold (utils.py:424-436, 489-500): recall over gt points,
+    precision over predicted points, both divided by `num`; averaged over the batch.
+    sqrt((.57 d)^2) <= 1e-2 is evaluated from the squared NN distances; one host read."""
+    recall = (torch.sqrt(sq_to_pred) * F1_SCALE <= F1_THRESHOLD).sum(1).double() / float(num)
+    precision = (torch.sqrt(sq_to_gt) * F1_SCALE <= F1_THRESHOLD).sum(1).double() / float(num)
+    f = 2 * (precision * recall) / (precision + recall + 1e-8)
+    return float(f.mean())
+
+
+def batch_point_to_point(pred_vert, adj_info, gt_points, num=1000, f1=False, draws=None):
+    """Two-sided Chamfer loss between sampled surface points and gt (reference utils.py:393-438)."""
+    pred_points = batch_sample(pred_vert, adj_info["faces"], num=num, draws=draws)
+    gt_points = gt_points.contiguous()
+    # idx_p[b,g] = nearest predicted point of each gt point, idx_g[b,s] = nearest gt point of each prediction
+    sq_gt, idx_p, sq_pred, idx_g = chamfer_nn(gt_points, pred_points)
+    n_pred = pred_points.shape[0] * pred_points.shape[1]
+    n_gt = gt_points.shape[0] * gt_points.shape[1]
+    dist_1 = ops.GatherSqDistSum.apply(pred_points, gt_points, idx_g, sq_pred) / n_pred
+    dist_2 = ops.GatherSqDistSum.apply(gt_points, pred_points, idx_p, sq_gt) / n_gt
+    loss = (dist_1 + dist_2) * LOSS_SCALE
+    if f1:
+        return loss, _f_score(sq_gt, sq_pred, num)
+    return loss
+
+
+def batch_point_to_surface(pred_vert, adj_info, gt_points, num=1000, f1=False, draws=None):
+    """Chamfer (prediction -> gt) + point-to-surface (gt -> mesh) loss (reference utils.py:441-502)."""
+    faces = adj_info["faces"]
+    pred_points = batch_sample(pred_vert, faces, num=num, draws=draws)
+    gt_points = gt_points.contiguous()
+    sq_gt, idx_p, sq_pred, idx_g = chamfer_nn(gt_points, pred_points)
+    n_pred = pred_points.shape[0] * pred_points.shape[1]
+    n_gt = gt_points.shape[0] * gt_points.shape[1]
+    dist_1 = ops.GatherSqDistSum.apply(pred_points, gt_points, idx_g, sq_pred) / n_pred
+
+    _, point_options, index = tri_distance_indexed(gt_points, pred_vert, faces)
+    dist_2 = ops.PointToTriangleSum.apply(gt_points, pred_vert, faces, point_options, index) / n_gt
+    loss = (dist_1 + dist_2) * LOSS_SCALE
+    if f1:
+        return loss, _f_score(sq_gt, sq_pred, num)
+    return loss
+
+
+def calc_point_to_line(p, triangles, point_options):
+    """mean |closest(p; a,b,c, option) - p|^2 for per-point triangles (reference utils.py:506-550).
+    p [N,3]; triangles = (a, b, c) each [N,3]; point_options [N] int."""
+    a, b, c = triangles
+    n = p.shape[0]
+    verts = torch.cat([a, b, c], dim=0).unsqueeze(0)                       # [1,3N,3]
+    ar = torch.arange(n, device=p.device, dtype=torch.int64)
+    faces = torch.stack([ar, ar + n, ar + 2 * n], dim=1)                   # triangle i = rows (i, N+i, 2N+i)
+    index = ar.to(torch.int32).unsqueeze(0)
+    option = point_options.reshape(1, n).to(torch.int32).contiguous()
+    total = ops.PointToTriangleSum.apply(p.reshape(1, n, 3), verts, faces, option, index.contiguous())
+    return total / n
+
+
+class edge:
+    """Edge a->b with the reference's accessor names (utils.py:553-570)."""
+
+    def __init__(self, a, b):
+        self.A = a.clone()
+        self.B = b.clone()
+        self.Delta = b - a
+
+    def PointAt(self, t):
+        return self.A + t.unsqueeze(-1) * self.Delta
+
+    def LengthSquared(self):
+        return (self.Delta ** 2).sum(-1)
+
+    def Project(self, p):
+        return ((p - self.A) * self.Delta).sum(-1) / self.LengthSquared()
+
+
+class Plane:
+    """Plane through `point` with unit normal `direction/|direction|` (utils.py:573-587)."""
+
+    def __init__(self, point, direction):
+        self.Point = point.clone()
+        self.Direction = direction / direction.norm(dim=-1, keepdim=True)
+
+    def IsAbove(self, q):
+        return (q * self.Point).sum(-1) <= 0
+
+    def Project(self, point):
+        h = ((point - self.Point) * self.Direction).sum(-1, keepdim=True)
+        return point - h * self.Direction
+
+
+# ---------------------------------------------------- regularisers ("next" rows) ----
+def batch_calc_edge(verts, info):
+    """Mean squared edge length over the three edges of every face (reference utils.py:636-651)."""
+    faces = info["faces"]
+    p1, p2, p3 = (verts[:, faces[:, k]] for k in range(3))
+    return (((p2 - p1) ** 2).sum(-1).mean() + ((p3 - p1) ** 2).sum(-1).mean() + ((p2 - p3) ** 2).sum(-1).mean()) / 3.0
+
+
+def batch_get_lap_info(positions, adj_info):
+    """positions - mean(neighbours) (reference utils.py:654-662)."""
+    orig = adj_info["adj_orig"]
+    neighbour_sum = torch.matmul(orig, positions) - positions
+    degrees = orig.sum(1) - 1
+    return positions - neighbour_sum * (1.0 / degrees).view(-1, 1)

@@ -85,31 +85,36 @@ int geom_sample_faces_bwd_f32(int b, int nv, int nf, const int64_t *faces,
                               const float *grad_points, float *grad_verts, void *stream);
 
 /* ---- loss stages (utils.py:393-502, 506-587) -------------------------------------------------
- * Chamfer gather loss.  For every point j of `src` [b,n,3]: e_j = |dst[b, idx[b,j]] - src[b,j]|^2.
- * sums[0] = sum_j e_j (fp32, deterministic two-level reduction); hits[b] += #(0.57*sqrt(e_j) <= 1e-2)
- * when hits != NULL (the F1 counters of utils.py:424-431 / 489-496).
- * scratch: at least geom_reduce_scratch_floats(b*n) floats. */
-int geom_gather_sqdist_fwd_f32(int b, int n, const float *src, int m, const float *dst,
-                               const int *idx, float *sums, int *hits, float *scratch, void *stream);
-/* grad_src[b,j] (+)= coef*(src - dst[idx]) and, when grad_dst != NULL, grad_dst[b,idx] -= same (atomics).
- * coef is read from the DEVICE scalar coef_dev[0] times coef_host. accumulate!=0 adds into grad_src. */
-int geom_gather_sqdist_bwd_f32(int b, int n, const float *src, int m, const float *dst,
-                               const int *idx, const float *coef_dev, float coef_host,
-                               float *grad_src, int accumulate, float *grad_dst, void *stream);
+ * Forward of the Chamfer gather loss needs no kernel of its own: sum_j |dst[idx[j]] - src[j]|^2
+ * (utils.py:416-417, 462) is the sum of the squared distances geom_chamfer_nn_f32 already wrote.
+ *
+ * Gradient of  coef * sum_j |dst[b, idx[b,j]] - src[b,j]|^2  with coef = coef_host * coef_dev[0]
+ * (coef_dev may be NULL = 1; it is the upstream autograd scalar, kept on the device so no
+ * host sync is needed):
+ *   grad_src[b,j]        = (or +=, when accumulate != 0)  2*coef*(src - dst[idx])   (may be NULL)
+ *   grad_dst[b,idx[b,j]] -= the same, with fp32 atomics; caller zero-initialises      (may be NULL) */
+int geom_chamfer_grad_f32(int b, int n, const float *src, int m, const float *dst,
+                          const int *idx, const float *coef_dev, float coef_host,
+                          float *grad_src, int accumulate, float *grad_dst, void *stream);
 
 /* Point-to-surface loss for the winning triangle of each point (calc_point_to_line,
- * utils.py:506-550 with edge/Plane utils.py:553-587): q = closest point selected by
- * option[b,j] on triangle index[b,j] of (verts,faces); sums[0] = sum |q - p|^2.
- * closest[b,n,3] (optional) receives q, weights[b,n,3] (optional) its affine weights on A,B,C. */
+ * utils.py:506-550 with edge/Plane utils.py:553-587): q = the candidate selected by option[b,j]
+ * on triangle index[b,j] of (verts [b,nv,3], faces [nf,3] int64).
+ *   sqdist[b,n]    = |q - p|^2
+ *   closest[b,n,3] = q                     (optional, needed by the backward)
+ *   weights[b,n,3] = affine weights of q on the corners A,B,C (optional, needed by the backward) */
 int geom_p2tri_loss_fwd_f32(int b, int n, const float *xyz, int nv, const float *verts,
                             int nf, const int64_t *faces, const int *option, const int *index,
-                            float *sums, float *closest, float *weights, float *scratch, void *stream);
-/* grad_verts[b, faces[index,k]] += coef * w_k * (q - p)  (closed form of the reference autograd). */
+                            float *sqdist, float *closest, float *weights, void *stream);
+/* grad_verts[b, faces[index,k]] += 2*coef * w_k * (q - p)  -- the closed form of the reference's
+ * autograd through calc_point_to_line (q minimises over every free parameter, so the
+ * parameter derivatives vanish).  fp32 atomics; caller zero-initialises grad_verts. */
 int geom_p2tri_loss_bwd_f32(int b, int n, const float *xyz, int nv, int nf, const int64_t *faces,
                             const int *index, const float *closest, const float *weights,
                             const float *coef_dev, float coef_host, float *grad_verts, void *stream);
 
-int64_t geom_reduce_scratch_floats(int64_t count);
+/* out[0] = scale * sum(x[0..n)) with a fixed reduction tree (bit-reproducible run to run). */
+int geom_sum_f32(int64_t n, const float *x, float scale, float *out, void *stream);
 
 /* ---- 0N-GCN aggregation (layers.py:34-41, 107-116, 143-152) -----------------------------------
  * out[r,:k] = sum_j val[j]*support[col[j],:k] over CSR row r (rowptr int32 [nv+1], col int32, val f32),

@@ -1,0 +1,261 @@
+"""Generate the golden fixtures in tests/golden/ from the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference); the fixtures it writes are pure
+data (inputs + expected outputs) and are what travels to the GPU box.
+
+How the reference is executed here
+  * python stages (utils.batch_sample / batch_point_to_point / batch_point_to_surface /
+    calc_point_to_line / calc_adj / normalize_adj, every class of layers.py): the
+    reference modules are IMPORTED from /root/reference and run on CPU.  Modules the image
+    lacks or that need nvcc are replaced in sys.modules before the import:
+      torchvision(.transforms/.models)  -> inert placeholders (never called by these functions)
+      chamfer_distance                  -> the reference's own CPU nnsearch (oracle/_ref, built
+                                           from old_GEOMetrics/chamfer_distance/src/my_lib.c:4-26)
+      tri_distance                      -> the C restatement of tri_distance.cu (oracle/)
+    and torch.Tensor.cuda is made the identity.
+  * NN vectors: emitted by that reference nnsearch binary directly.
+  * random draws are captured by wrapping torch.multinomial and Uniform.sample_n, so a
+    fixture holds (inputs, draws) -> outputs.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+warnings.filterwarnings("ignore")
+
+import oracle  # noqa: E402
+from geometrics_amd import meshgen  # noqa: E402
+
+oracle.build()
+assert oracle.have_ref(), "reference nnsearch (oracle/_ref) must be built first"
+
+
+# ----------------------------------------------------------- import the reference ----
+def _placeholder(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _Inert:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, x):
+        return x
+
+
+tv = _placeholder("torchvision")
+tv.transforms = _placeholder("torchvision.transforms", Normalize=_Inert, Compose=_Inert, Resize=_Inert, ToTensor=_Inert)
+tv.models = _placeholder("torchvision.models")
+
+
+class _RefChamfer(torch.nn.Module):
+    def forward(self, xyz1, xyz2):
+        a, b = xyz1.detach().numpy(), xyz2.detach().numpy()
+        _, i1, _, i2 = oracle.chamfer_nn(a, b, use_ref=True)
+        return torch.from_numpy(i1), torch.from_numpy(i2)
+
+
+class _OracleTri(torch.nn.Module):
+    def forward(self, xyz1, tri1, tri2, tri3):
+        d, p, i = oracle.tri_scan(*(t.detach().numpy() for t in (xyz1, tri1, tri2, tri3)))
+        return torch.from_numpy(d), torch.from_numpy(p), torch.from_numpy(i)
+
+
+_placeholder("chamfer_distance", ChamferDistance=_RefChamfer)
+_placeholder("tri_distance", TriDistance=_OracleTri)
+torch.Tensor.cuda = lambda self, *a, **k: self
+sys.path.insert(0, REF)
+import utils as ref_utils  # noqa: E402  (the reference's utils.py)
+import layers as ref_layers  # noqa: E402  (the reference's layers.py)
+
+assert ref_utils.__file__.startswith(REF) and ref_layers.__file__.startswith(REF)
+
+
+class CaptureDraws:
+    """Record (choices, U1, U2) consumed by one reference batch_sample call."""
+
+    def __enter__(self):
+        self.choices, self.uniform = [], []
+        self._m = torch.multinomial
+        self._s = torch.distributions.Uniform.sample_n
+
+        def multinomial(*a, **k):
+            r = self._m(*a, **k)
+            self.choices.append(r.clone())
+            return r
+
+        def sample_n(dist, n):
+            r = self._s(dist, n)
+            self.uniform.append(r.clone())
+            return r
+
+        torch.multinomial = multinomial
+        torch.distributions.Uniform.sample_n = sample_n
+        return self
+
+    def __exit__(self, *exc):
+        torch.multinomial = self._m
+        torch.distributions.Uniform.sample_n = self._s
+
+    def draws(self, batch):
+        choices = torch.stack(self.choices).numpy().astype(np.int64)          # [B,num]
+        u = torch.sqrt(self.uniform[0]).view(batch, -1).numpy()               # post-sqrt, as the kernel takes it
+        v = self.uniform[1].view(batch, -1).numpy()
+        return choices, u, v
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s %6.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def t(a, grad=False):
+    x = torch.from_numpy(np.ascontiguousarray(a))
+    return x.requires_grad_(True) if grad else x
+
+
+# ------------------------------------------------------------------ NN vectors ----
+def nn_case(a, b):
+    _, i1, _, i2 = oracle.chamfer_nn(a, b, use_ref=True)
+    d1, _, d2, _ = oracle.chamfer_nn(a, b, use_ref=True)
+    return dict(xyz1=a, xyz2=b, idx1=i1, idx2=i2, dist1=d1, dist2=d2)
+
+
+def make_nn():
+    V2, F2 = meshgen.icosphere(2)
+    verts = meshgen.jittered_batch(V2, 2)
+    ch, u, v = meshgen.sampling_draws(verts, F2, 500)
+    x, y, z = (np.take_along_axis(verts, F2[ch][..., k][..., None].repeat(3, -1), 1) for k in range(3))
+    pred = ((1 - u)[..., None] * x + (u * (1 - v))[..., None] * y + (u * v)[..., None] * z).astype(np.float32)
+    save("nn_config1", **nn_case(meshgen.gt_cloud(2, 500), pred))           # 162-icosphere samples vs 500 GT
+    rng = np.random.default_rng(7)
+    a = rng.integers(-3, 4, (2, 400, 3)).astype(np.float32)
+    b = rng.integers(-3, 4, (2, 700, 3)).astype(np.float32)
+    b[:, 300:500] = b[:, :200]
+    save("nn_ties", **nn_case(a, b))                                         # integer grid + duplicates
+    for m in (1, 3, 4, 5, 6, 7, 511, 512, 513, 516, 2466):
+        rng = np.random.default_rng(100 + m)
+        save("nn_ragged_m%d" % m, **nn_case(rng.standard_normal((1, 97, 3)).astype(np.float32),
+                                             rng.standard_normal((1, m, 3)).astype(np.float32)))
+    # config 2 (3000 vs 3000): inputs are regenerated from seeds, only the reference outputs are stored
+    gt, pr = meshgen.gt_cloud(2, 3000), meshgen.gt_cloud(2, 3000, first=100)
+    c = nn_case(gt, pr)
+    save("nn_config2_outputs", idx1=c["idx1"], idx2=c["idx2"], dist1=c["dist1"], dist2=c["dist2"],
+         gt_first=np.int64(0), pred_first=np.int64(100), checksum=np.float64(gt.sum() + pr.sum()))
+
+
+# -------------------------------------------------------- sampling + losses ----
+def make_sampling_and_losses():
+    V2, F2 = meshgen.icosphere(2)
+    B, num = 2, 500
+    verts = meshgen.jittered_batch(V2, B)
+    faces = t(F2)
+    gt = meshgen.gt_cloud(B, num)
+    torch.manual_seed(41)
+
+    pv = t(verts, grad=True)
+    with CaptureDraws() as cap:
+        pts = ref_utils.batch_sample(pv, faces, num=num)
+    gp = torch.from_numpy(np.random.default_rng(3).standard_normal((B, num, 3)).astype(np.float32))
+    pts.backward(gp)
+    choices, u, v = cap.draws(B)
+    save("sample_v162", verts=verts, faces=F2, choices=choices, u=u, v=v, points=pts.detach().numpy(),
+         grad_points=gp.numpy(), grad_verts=pv.grad.numpy())
+
+    info = {"faces": faces}
+    for name, fn in (("p2p_v162", ref_utils.batch_point_to_point), ("p2s_v162", ref_utils.batch_point_to_surface)):
+        pv = t(verts, grad=True)
+        with CaptureDraws() as cap:
+            loss, f1 = fn(pv, info, t(gt), num=num, f1=True)
+        loss.backward()
+        choices, u, v = cap.draws(B)
+        save(name, verts=verts, faces=F2, gt=gt, choices=choices, u=u, v=v, loss=np.float32(loss.item()),
+             f1=np.float64(f1), grad_verts=pv.grad.numpy())
+
+    # calc_point_to_line on every option code, incl. ones the scan would not pick
+    rng = np.random.default_rng(11)
+    n = 7 * 40
+    a, b, c = (rng.standard_normal((n, 3)).astype(np.float32) * 0.3 for _ in range(3))
+    p = rng.standard_normal((n, 3)).astype(np.float32) * 0.5
+    opt = np.repeat(np.arange(7, dtype=np.int32), 40)
+    ta, tb, tc = t(a, True), t(b, True), t(c, True)
+    loss = ref_utils.calc_point_to_line(t(p), [ta, tb, tc], t(opt))
+    loss.backward()
+    save("p2line_options", p=p, a=a, b=b, c=c, option=opt, loss=np.float32(loss.item()),
+         grad_a=ta.grad.numpy(), grad_b=tb.grad.numpy(), grad_c=tc.grad.numpy())
+
+    # the restated tri scan vs the reference's own closest-point formulas (pins oracle_tri_scan)
+    V3_, F3 = meshgen.icosphere(3)
+    verts3 = meshgen.jittered_batch(V3_, 1, first=5)
+    pts3 = meshgen.gt_cloud(1, 600, first=5)
+    tri = [np.ascontiguousarray(verts3[:, F3[:, k]]) for k in range(3)]
+    d, code, idx = oracle.tri_scan(pts3, *tri)
+    per_point = []
+    for j in range(pts3.shape[1]):
+        corners = [t(tri[k][0, idx[0, j]][None]) for k in range(3)]
+        per_point.append(ref_utils.calc_point_to_line(t(pts3[0, j][None]), corners, t(code[0, j:j + 1])).item())
+    save("tri_vs_ref_formulas", verts=verts3, faces=F3, points=pts3, dist=d, option=code, index=idx,
+         ref_sqdist=np.asarray(per_point, np.float32))
+
+
+# ---------------------------------------------------------------- adjacency ----
+def make_adjacency():
+    info, feats = ref_utils.load_initial(os.path.join(REF, "482.obj"))
+    faces = info["faces"].numpy()
+    adj = info["adj"].numpy()
+    r, c = np.nonzero(adj)
+    save("adj_482", faces=faces, nnz_rows=r.astype(np.int32), nnz_cols=c.astype(np.int32), nnz_vals=adj[r, c],
+         orig_rowsum=info["adj_orig"].numpy().sum(1).astype(np.float32), verts=feats.numpy())
+    V2, F2 = meshgen.icosphere(2)
+    info = ref_utils.adj_init(t(F2))
+    save("adj_ico162", faces=F2, adj=info["adj"].numpy(), adj_orig=info["adj_orig"].numpy())
+
+
+# ------------------------------------------------------------------- layers ----
+def make_layers():
+    import torch.nn.functional as F
+    V2, F2 = meshgen.icosphere(2)
+    adj = ref_utils.adj_init(t(F2))["adj"]
+    V = V2.shape[0]
+    torch.manual_seed(40)
+    cases = {
+        "ZERON_GCN": (ref_layers.ZERON_GCN(24, 60), (V, 24), F.elu),
+        "BatchZERON_GCN": (ref_layers.BatchZERON_GCN(24, 60), (3, V, 24), F.elu),
+        "Batch_Image_ZERON_GCNGCN": (ref_layers.Batch_Image_ZERON_GCNGCN(33, 48), (2, V, 33), F.relu),
+        "Batch_Image_ZERON_GCNGCN_out3": (ref_layers.Batch_Image_ZERON_GCNGCN(48, 3), (2, V, 48), lambda x: x),
+        "GCNMax": (ref_layers.GCNMax(30, 50), (V, 30), F.elu),
+        "BatchGCNMax": (ref_layers.BatchGCNMax(30, 50), (2, V, 30), F.elu),
+    }
+    for name, (layer, shape, act) in cases.items():
+        x = torch.randn(*shape, requires_grad=True)
+        out = layer(x, adj, act)
+        gout = torch.randn_like(out)
+        out.backward(gout)
+        arrays = dict(x=x.detach().numpy(), out=out.detach().numpy(), grad_out=gout.numpy(), grad_x=x.grad.numpy())
+        for pn, p in layer.named_parameters():
+            arrays["param." + pn] = p.detach().numpy()
+            arrays["grad." + pn] = p.grad.numpy()
+        save("layer_" + name, **arrays)
+    save("layer_adj", adj=adj.numpy())
+
+
+if __name__ == "__main__":
+    make_nn()
+    make_sampling_and_losses()
+    make_adjacency()
+    make_layers()

@@ -1,0 +1,132 @@
+"""CPU: the C-ABI library loads and exports every symbol include/geom_hip.h declares; host
+logic (mesh generator, adjacency, CSR, argument validation) -- no compute calls on a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import bits, golden
+from geometrics_amd import _lib, meshgen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "geom_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(geom_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared()
+    assert len(names) >= 14
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "libgeom_hip.so does not export %s" % n
+    assert sorted(_lib.declared_symbols()) == names, "ctypes table and header disagree"
+    assert _lib.lib().geom_abi_version() == _lib.ABI_VERSION
+
+
+def test_error_strings_and_argument_rejection_without_a_gpu():
+    L = _lib.lib()
+    assert b"invalid" in L.geom_strerror(-1)
+    assert L.geom_strerror(0) == b"success"
+    # negative sizes / null pointers are rejected before any launch
+    assert L.geom_chamfer_nn_f32(-1, 1, None, 1, None, None, None, None, None, 0, None) == -1
+    assert L.geom_chamfer_nn_f32(1, 4, None, 4, None, None, None, None, None, 0, None) == -1
+    assert L.geom_tri_distance_f32(1, 4, None, 0, None, None, None, None, None, None, 0, None) == -1
+    assert L.geom_chamfer_nn_f32(0, 4, None, 4, None, None, None, None, None, 0, None) == 0   # empty batch: no-op
+    assert L.geom_zn_gcn_aggregate_fwd_f32(1, 4, 8, 9, None, None, None, None, None, 0, None, None) == -1  # k > c
+
+
+def test_ops_refuse_cpu_tensors():
+    from geometrics_amd.chamfer_distance import ChamferDistance
+    from geometrics_amd.tri_distance import TriDistance
+    from geometrics_amd import utils, layers
+    x = torch.zeros(1, 4, 3)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        ChamferDistance()(x, x)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        TriDistance()(x, x, x, x)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        utils.batch_sample(x, torch.zeros(2, 3, dtype=torch.int64), 5,
+                           draws=(torch.zeros(1, 5, dtype=torch.int64), torch.zeros(1, 5), torch.zeros(1, 5)))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        layers.ZERON_GCN(4, 20)(torch.zeros(4, 4), torch.eye(4), torch.relu)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgeom_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        _lib.lib()
+
+
+def test_icosphere_sizes_and_winding():
+    for level, (nv, nf, ne) in {2: (162, 320, 480), 4: (2562, 5120, 7680)}.items():
+        V, F = meshgen.icosphere(level)
+        assert V.shape == (nv, 3) and F.shape == (nf, 3) and V.dtype == np.float32 and F.dtype == np.int64
+        edges = {tuple(sorted((f[i], f[(i + 1) % 3]))) for f in F for i in range(3)}
+        assert len(edges) == ne
+        n = np.cross(V[F[:, 1]] - V[F[:, 0]], V[F[:, 2]] - V[F[:, 0]])
+        assert (np.einsum("ij,ij->i", n, V[F].mean(1)) > 0).all()
+        np.testing.assert_allclose(np.linalg.norm(V, axis=1), meshgen.RADIUS, rtol=1e-6)
+
+
+def test_synthetic_inputs_are_deterministic():
+    V, F = meshgen.icosphere(2)
+    a = meshgen.jittered_batch(V, 3)
+    np.testing.assert_array_equal(a[1:], meshgen.jittered_batch(V, 2, first=1))
+    ch, u, v = meshgen.sampling_draws(a, F, 100)
+    assert ch.shape == (3, 100) and ch.max() < F.shape[0] and (u >= 0).all() and (u <= 1).all()
+    np.testing.assert_array_equal(meshgen.gt_cloud(2, 50), meshgen.gt_cloud(2, 50))
+
+
+def test_adjacency_matches_reference_vectors():
+    from geometrics_amd import utils
+    g = golden("adj_ico162")
+    info = utils.adj_init(torch.from_numpy(g["faces"]))
+    np.testing.assert_array_equal(info["adj_orig"].numpy(), g["adj_orig"])
+    np.testing.assert_array_equal(bits(info["adj"].numpy()), bits(g["adj"]))
+    assert info["faces"].dtype == torch.int64
+    g = golden("adj_482")                                # the reference's own template mesh
+    info = utils.adj_init(torch.from_numpy(g["faces"]))
+    r, c = np.nonzero(info["adj"].numpy())
+    np.testing.assert_array_equal(r, g["nnz_rows"])
+    np.testing.assert_array_equal(c, g["nnz_cols"])
+    np.testing.assert_array_equal(bits(info["adj"].numpy()[r, c]), bits(g["nnz_vals"]))
+    assert len(r) == 3362 and info["adj"].shape == (482, 482)
+
+
+def test_csr_builder_on_host():
+    from geometrics_amd import layers, utils
+    g = golden("adj_482")
+    adj = utils.adj_init(torch.from_numpy(g["faces"]))["adj"]
+    rowptr, col, val = layers._to_csr(adj)
+    assert rowptr.dtype == torch.int32 and col.dtype == torch.int32 and val.dtype == torch.float32
+    assert int(rowptr[-1]) == 3362 and int((rowptr[1:] - rowptr[:-1]).max()) == 33     # the two degree-32 poles
+    dense = torch.zeros_like(adj)
+    rows = torch.repeat_interleave(torch.arange(482), (rowptr[1:] - rowptr[:-1]).long())
+    dense[rows, col.long()] = val
+    assert torch.equal(dense, adj)
+    rp_t, col_t, val_t = layers._to_csr(adj.t())
+    dense_t = torch.zeros_like(adj)
+    rows_t = torch.repeat_interleave(torch.arange(482), (rp_t[1:] - rp_t[:-1]).long())
+    dense_t[rows_t, col_t.long()] = val_t
+    assert torch.equal(dense_t, adj.t())
+
+
+def test_layer_parameter_names_and_shapes():
+    from geometrics_amd import layers
+    assert list(dict(layers.ZERON_GCN(7, 20).named_parameters())) == ["weight", "bias"]
+    assert list(dict(layers.BatchZERON_GCN(7, 20).named_parameters())) == ["weight", "bias"]
+    p = dict(layers.Batch_Image_ZERON_GCNGCN(963, 192).named_parameters())
+    assert list(p) == ["weight1", "bias"] and tuple(p["weight1"].shape) == (1, 963, 192)
+    assert float(p["weight1"].abs().max()) <= 0.3 * 6 / (964 ** 0.5) and float(p["bias"].abs().max()) <= 0.1
+    for cls in (layers.GCNMax, layers.BatchGCNMax):
+        assert list(dict(cls(30, 50).named_parameters())) == ["weight_Ws.0", "weight_Bs.0"]
+    assert layers.ZERON_GCN(7, 20, bias=False).bias is None
+    assert float(layers.ZERON_GCN(7, 20).bias.abs().max()) == 0.0

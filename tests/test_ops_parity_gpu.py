@@ -1,0 +1,183 @@
+"""-m gpu parity of the sampling / loss / 0N-GCN stages (through the C ABI and the python
+mirror of the reference interface) against (a) the fixtures the reference itself produced
+and (b) the CPU restatement at the BASELINE sizes.
+
+Tolerances: sampled points bit-exact (same three products and two sums per coordinate);
+losses 1e-5 relative (north-star bar); gradients 1e-4 relative to the gradient scale
+(fp32 atomics / different but equivalent summation order)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import bits, golden
+from geometrics_amd import layers, meshgen, ops, utils
+from oracle import ref_ops
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, gpu, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    return t.requires_grad_(True) if grad else t
+
+
+def close(actual, expected, rtol, scale=None):
+    actual, expected = np.asarray(actual, np.float64), np.asarray(expected, np.float64)
+    scale = np.abs(expected).max() if scale is None else scale
+    assert np.abs(actual - expected).max() <= rtol * max(scale, 1e-30), \
+        "max abs err %g vs tol %g" % (np.abs(actual - expected).max(), rtol * scale)
+
+
+def draws(g, gpu):
+    return dev(g["choices"], gpu), dev(g["u"], gpu), dev(g["v"], gpu)
+
+
+# ------------------------------------------------------------------ sampling ----
+def test_batch_sample_matches_reference_fixture(gpu):
+    g = golden("sample_v162")
+    verts = dev(g["verts"], gpu, grad=True)
+    pts = utils.batch_sample(verts, dev(g["faces"], gpu), num=500, draws=draws(g, gpu))
+    np.testing.assert_array_equal(bits(pts.detach().cpu().numpy()), bits(g["points"]))
+    pts.backward(dev(g["grad_points"], gpu))
+    close(verts.grad.cpu().numpy(), g["grad_verts"], 1e-5)
+
+
+def test_face_areas_and_random_draws(gpu):
+    V, Fc = meshgen.icosphere(4)
+    verts = meshgen.jittered_batch(V, 2)
+    areas = ops.face_areas(dev(verts, gpu), dev(Fc, gpu))
+    ref = ref_ops.face_areas(torch.from_numpy(verts), torch.from_numpy(Fc))
+    np.testing.assert_allclose(areas.cpu().numpy(), ref.numpy(), rtol=1e-6)      # multinomial weights only
+    torch.manual_seed(0)
+    choices, u, v = ops.draw_samples(dev(verts, gpu), dev(Fc, gpu), 200000)
+    assert choices.shape == (2, 200000) and int(choices.max()) < Fc.shape[0] and choices.dtype == torch.int64
+    freq = torch.bincount(choices[0], minlength=Fc.shape[0]).double().cpu() / 200000
+    p = (ref[0] / ref[0].sum()).double()
+    assert float((freq - p).abs().max()) < 4e-4                       # area-weighted
+    assert abs(float((u * u).mean()) - 0.5) < 5e-3 and abs(float(v.mean()) - 0.5) < 5e-3   # u = sqrt(U)
+    pts = utils.batch_sample(dev(verts, gpu), dev(Fc, gpu), num=3000)
+    assert pts.shape == (2, 3000, 3)
+    r = pts.norm(dim=-1)
+    assert float(r.min()) > 0.3 and float(r.max()) < 0.6               # on the jittered sphere
+
+
+# -------------------------------------------------------------------- losses ----
+@pytest.mark.parametrize("name,fn", [("p2p_v162", "batch_point_to_point"), ("p2s_v162", "batch_point_to_surface")])
+def test_losses_match_reference_fixture(gpu, name, fn):
+    g = golden(name)
+    verts = dev(g["verts"], gpu, grad=True)
+    info = {"faces": dev(g["faces"], gpu)}
+    loss, f1 = getattr(utils, fn)(verts, info, dev(g["gt"], gpu), num=500, f1=True, draws=draws(g, gpu))
+    loss.backward()
+    close(loss.item(), g["loss"], 1e-5)
+    assert abs(f1 - float(g["f1"])) < 1e-9
+    close(verts.grad.cpu().numpy(), g["grad_verts"], 1e-4)
+    assert isinstance(f1, float) and loss.dim() == 0
+
+
+def test_calc_point_to_line_all_options(gpu):
+    g = golden("p2line_options")
+    a, b, c = (dev(g[k], gpu, grad=True) for k in "abc")
+    loss = utils.calc_point_to_line(dev(g["p"], gpu), [a, b, c], dev(g["option"], gpu))
+    loss.backward()
+    close(loss.item(), g["loss"], 1e-5)
+    for t, k in ((a, "grad_a"), (b, "grad_b"), (c, "grad_c")):
+        close(t.grad.cpu().numpy(), g[k], 2e-4)
+
+
+@pytest.mark.parametrize("fn", ["point_to_point", "point_to_surface"])
+def test_losses_at_baseline_size(gpu, fn):
+    V, Fc = meshgen.icosphere(4)
+    B, S = 2, 3000
+    verts = meshgen.jittered_batch(V, B)
+    gt = meshgen.gt_cloud(B, S)
+    ch, u, v = meshgen.sampling_draws(verts, Fc, S)
+    cv = torch.from_numpy(verts).requires_grad_(True)
+    ref = getattr(ref_ops, fn)(cv, torch.from_numpy(Fc), torch.from_numpy(gt), torch.from_numpy(ch),
+                               torch.from_numpy(u), torch.from_numpy(v))
+    ref.backward()
+    gv = dev(verts, gpu, grad=True)
+    loss = getattr(utils, "batch_" + fn)(gv, {"faces": dev(Fc, gpu)}, dev(gt, gpu), num=S,
+                                         draws=(dev(ch, gpu), dev(u, gpu), dev(v, gpu)))
+    loss.backward()
+    close(loss.item(), ref.item(), 1e-5)
+    close(gv.grad.cpu().numpy(), cv.grad.numpy(), 1e-4)
+
+
+def test_device_sum_is_reproducible(gpu):
+    x = torch.randn(24000, device=gpu)
+    a, b = ops.device_sum(x), ops.device_sum(x)
+    assert torch.equal(a, b)
+    close(a.item(), x.double().sum().item(), 1e-5, scale=float(x.abs().sum()))
+
+
+# -------------------------------------------------------------------- layers ----
+CASES = {
+    "ZERON_GCN": (layers.ZERON_GCN, (24, 60), F.elu),
+    "BatchZERON_GCN": (layers.BatchZERON_GCN, (24, 60), F.elu),
+    "Batch_Image_ZERON_GCNGCN": (layers.Batch_Image_ZERON_GCNGCN, (33, 48), F.relu),
+    "Batch_Image_ZERON_GCNGCN_out3": (layers.Batch_Image_ZERON_GCNGCN, (48, 3), lambda x: x),
+    "GCNMax": (layers.GCNMax, (30, 50), F.elu),
+    "BatchGCNMax": (layers.BatchGCNMax, (30, 50), F.elu),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_layers_match_reference_fixture(gpu, name):
+    g = golden("layer_" + name)
+    cls, dims, act = CASES[name]
+    layer = cls(*dims).to(gpu)
+    state = {k[len("param."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param.")}
+    layer.load_state_dict(state)                      # reference parameter names load unchanged
+    adj = dev(golden("layer_adj")["adj"], gpu)
+    x = dev(g["x"], gpu, grad=True)
+    out = layer(x, adj, act)
+    out.backward(dev(g["grad_out"], gpu))
+    close(out.detach().cpu().numpy(), g["out"], 1e-5)
+    close(x.grad.cpu().numpy(), g["grad_x"], 1e-4)
+    for pn, p in layer.named_parameters():
+        close(p.grad.cpu().numpy(), g["grad." + pn], 1e-4)
+
+
+def test_config4_stack_at_baseline_size(gpu):
+    """963 -> 192 -> 192 -> 192 on the 2562-vertex adjacency, fwd + bwd, vs the dense restatement."""
+    V, Fc = meshgen.icosphere(4)
+    info = utils.adj_init(dev(Fc, gpu))
+    adj = info["adj"]
+    torch.manual_seed(3041)
+    stack = [layers.Batch_Image_ZERON_GCNGCN(i, o).to(gpu) for i, o in ((963, 192), (192, 192), (192, 192))]
+    x = torch.randn(2, V.shape[0], 963, device=gpu, requires_grad=True)
+    h = x
+    for l in stack:
+        h = l(h, adj, F.elu)          # smooth: a ReLU mask flips on fp32-vs-fp64 knife edges at this size
+    gout = torch.randn_like(h)
+    h.backward(gout)
+    xc = x.detach().cpu().double().requires_grad_(True)
+    adj_c = adj.cpu().double()
+    hc = xc
+    params = []
+    for l in stack:
+        w = l.weight1.detach().cpu().double().requires_grad_(True)
+        b = l.bias.detach().cpu().double().requires_grad_(True)
+        params.append((w, b))
+        hc = ref_ops.zero_n_layer(hc, adj_c, w, b, 3, F.elu)
+    hc.backward(gout.cpu().double())
+    close(h.detach().cpu().numpy(), hc.detach().numpy(), 1e-5)
+    close(x.grad.cpu().numpy(), xc.grad.numpy(), 1e-4)
+    for l, (w, b) in zip(stack, params):
+        close(l.weight1.grad.cpu().numpy(), w.grad.numpy(), 1e-4)
+        close(l.bias.grad.cpu().numpy(), b.grad.numpy(), 1e-4)
+    csr = layers.adjacency_csr(adj)
+    assert csr.nnz == 17922 and layers.adjacency_csr(adj) is csr          # V + 2E, cached
+
+
+def test_gcn_rows_of_degree_32(gpu):
+    g = golden("adj_482")
+    adj = utils.adj_init(dev(g["faces"], gpu))["adj"]
+    layer = layers.BatchZERON_GCN(16, 40).to(gpu)
+    x = torch.randn(3, 482, 16, device=gpu)
+    out = layer(x, adj, lambda t: t)
+    ref = ref_ops.zero_n_layer(x.cpu().double(), adj.cpu().double(), layer.weight.detach().cpu().double(),
+                               layer.bias.detach().cpu().double(), 10, lambda t: t)
+    close(out.detach().cpu().numpy(), ref.numpy(), 1e-5)
