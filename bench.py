@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""Headline benchmark: meshes/sec of the GEOMetrics per-step hot path on MI355X.
+
+One STEP = one pass of the hot path over the rank's shard of synthetic meshes
+(BASELINE.json config 5 sharded: 8 meshes per GPU, 2562 verts / 5120 faces, 3000 sampled
+vs 3000 GT points, 963-dim features):
+    3-layer 0N-GCN (963-192-192-192, fused CSR aggregation) -> vertex positions
+    -> area-weighted face sampling (fresh random draws every step)
+    -> Chamfer NN (both directions) + Chamfer loss
+    -> point-to-triangle scan + point-to-surface loss
+    -> backward to the GCN parameters and input features
+    -> (N>1: one RCCL all-reduce of the flat gradient bucket + the 8-byte loss vector)
+    -> Adam step.
+All inputs are resident in HBM before the timed region.  Weak scaling: per-GPU work fixed.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--meshes-per-gpu 8] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from geometrics_amd import dist as gdist  # noqa: E402
+from geometrics_amd import layers, meshgen, utils  # noqa: E402
+from geometrics_amd.chamfer_distance import chamfer_nn  # noqa: E402
+from geometrics_amd.tri_distance import tri_distance_indexed  # noqa: E402
+
+V_LEVEL, S_PTS, G_PTS, FEAT, HID = 4, 3000, 3000, 963, 192
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector peak == f32 MFMA dense peak
+
+# Algorithmic work per (point, triangle) pair of the tri scan, counted on the hoisted form of the
+# reference decision tree (DESIGN.md "Kernels"): 3 point-corner differences (9), 3 edge
+# projections (15), region compares (12), 3 inner-side tests (18), closest point + squared
+# distance (12), arg-min update (3)  => 69 flop-equivalents per pair.
+TRI_FLOP_PER_PAIR = 69.0
+NN_FLOP_PER_PAIR = 8.0     # 3 sub, 3 mul, 2 add
+
+
+class Workload:
+    def __init__(self, dev, first_mesh, batch, seed=3041):
+        V, Fc = meshgen.icosphere(V_LEVEL)
+        self.batch, self.nv, self.nf = batch, V.shape[0], Fc.shape[0]
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.faces = to(Fc)
+        self.base = to(meshgen.jittered_batch(V, batch, first=first_mesh))
+        self.gt = to(meshgen.gt_cloud(batch, G_PTS, first=first_mesh))
+        self.info = utils.adj_init(self.faces)
+        g = torch.Generator(device="cpu").manual_seed(seed + first_mesh)
+        self.feat = torch.randn(batch, self.nv, FEAT, generator=g).to(dev).requires_grad_(True)
+        torch.manual_seed(seed)                       # identical (replicated) parameters on every rank
+        self.stack = torch.nn.ModuleList(
+            [layers.Batch_Image_ZERON_GCNGCN(i, o) for i, o in ((FEAT, HID), (HID, HID), (HID, HID))]).to(dev)
+        self.bucket = gdist.GradBucket(self.stack.parameters())
+        self.opt = torch.optim.Adam(self.stack.parameters(), lr=1e-4)   # GEOMetrics.py:73 (Adam, lr 1e-4)
+        self.loss_vec = None
+
+    def positions(self):
+        h = self.feat
+        for layer in self.stack:
+            h = layer(h, self.info["adj"], F.relu)
+        return self.base + 0.01 * h[..., :3]
+
+    def step(self):
+        self.bucket.zero_()
+        self.feat.grad = None
+        pos = self.positions()
+        loss = utils.batch_point_to_surface(pos, self.info, self.gt, num=S_PTS)
+        loss.backward()
+        self.bucket.all_reduce_mean_()
+        self.loss_vec = gdist.global_mean_loss(loss.detach() * self.batch, self.batch)
+        self.opt.step()
+        return loss
+
+
+def time_steps(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    gdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    gdist.barrier()
+    return time.perf_counter() - t0
+
+
+def event_time_us(fn, iters=30, warm=5):
+    """Average duration of fn's launches, HIP events on the launch (= torch current) stream."""
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / iters
+
+
+def kernel_rooflines(w):
+    """Launch-level timing of the hot kernels on the step's own tensors."""
+    with torch.no_grad():
+        pos = w.positions().contiguous()
+        pred = utils.batch_sample(pos, w.faces, num=S_PTS)
+        t_tri = event_time_us(lambda: tri_distance_indexed(w.gt, pos, w.faces))
+        t_nn = event_time_us(lambda: chamfer_nn(w.gt, pred))
+        sup = torch.randn(w.batch, w.nv, HID, device=pos.device)
+        csr = layers.adjacency_csr(w.info["adj"])
+        t_agg = event_time_us(lambda: layers._ZeroNAggregate.apply(sup, w.stack[1].bias, csr, HID // 3))
+    b = w.batch
+    tri_pairs = b * G_PTS * w.nf
+    nn_pairs = 2 * b * G_PTS * S_PTS
+    tri_tflops = tri_pairs * TRI_FLOP_PER_PAIR / (t_tri * 1e-6) / 1e12
+    nn_tflops = nn_pairs * NN_FLOP_PER_PAIR / (t_nn * 1e-6) / 1e12
+    # 0N-GCN aggregation: read support + write out (4 B each per element) + CSR (12 B per nnz + 4 B per row)
+    agg_bytes = 2 * b * w.nv * HID * 4 + csr.nnz * 12 + (w.nv + 1) * 4
+    agg_gbs = agg_bytes / (t_agg * 1e-6) / 1e9
+    tri_bytes = b * (G_PTS * 12 + w.nv * 12 + w.nf * 24 + G_PTS * 12)     # points + verts + faces(int64) + 3 outputs
+    roofline = {"kernel": "tri_distance_kernel (point-to-triangle arg-min scan)", "bound": "mfma",
+                "pipe": "fp32 VALU (arg-min scan, not a contraction; on gfx950 the f32 VALU peak equals the dense f32 MFMA peak)",
+                "achieved": round(tri_tflops, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tri_tflops / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                "launch_us": round(t_tri, 1), "pairs_per_launch": tri_pairs, "flop_per_pair": TRI_FLOP_PER_PAIR,
+                "algorithmic_bytes_per_launch": tri_bytes,
+                "hbm_gbs_algorithmic": round(tri_bytes / (t_tri * 1e-6) / 1e9, 2)}
+    others = {
+        "chamfer_nn_kernel": {"bound": "mfma", "pipe": "fp32 VALU", "achieved": round(nn_tflops, 3),
+                              "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(nn_tflops / FP32_PEAK_TFLOPS, 4),
+                              "launch_us": round(t_nn, 1), "pairs_per_launch": nn_pairs, "flop_per_pair": NN_FLOP_PER_PAIR},
+        "zn_aggregate_kernel": {"bound": "hbm", "achieved": round(agg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(agg_gbs / HBM_PEAK_GBS, 4), "launch_us": round(t_agg, 1),
+                                "algorithmic_bytes_per_launch": agg_bytes},
+    }
+    return roofline, others
+
+
+def cpu_baseline(budget_s=12.0):
+    """Reference-side CPU throughput for the part of the path that has a CPU implementation:
+    Chamfer NN (the reference's own nnsearch when oracle/_ref is present) + the C restatement
+    of tri_distance, single thread as shipped, on whole meshes of the same workload."""
+    import oracle
+    oracle.build()
+    V, Fc = meshgen.icosphere(V_LEVEL)
+    use_ref = oracle.have_ref()
+    done, t_nn, t_tri = 0, 0.0, 0.0
+    t_start = time.perf_counter()
+    while done < 2 or (time.perf_counter() - t_start < budget_s and done < 64):
+        verts = meshgen.jittered_batch(V, 1, first=done)
+        gt = meshgen.gt_cloud(1, G_PTS, first=done)
+        pred = meshgen.gt_cloud(1, S_PTS, first=1000 + done)
+        t0 = time.perf_counter()
+        oracle.chamfer_nn(gt, pred, use_ref=use_ref)
+        t1 = time.perf_counter()
+        oracle.tri_scan_indexed(gt, verts, Fc)
+        t2 = time.perf_counter()
+        t_nn += t1 - t0
+        t_tri += t2 - t1
+        done += 1
+    return {"value": round(done / (t_nn + t_tri), 3), "unit": "meshes/s (Chamfer NN both directions + tri_distance only)",
+            "cores": 1, "kind": "reference" if use_ref else "port",
+            "sample": "%d whole meshes of the bench workload (3000x3000 NN both ways, 3000 pts x 5120 faces); "
+                      "NN = %s, tri_distance = C restatement (the reference has no CPU tri_distance)"
+                      % (done, "reference nnsearch (oracle/_ref)" if use_ref else "C restatement of nnsearch"),
+            "chamfer_only_meshes_per_s": round(done / t_nn, 2), "tri_only_meshes_per_s": round(done / t_tri, 3),
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--meshes-per-gpu", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="also print a per-stage event-timed breakdown")
+    args = ap.parse_args()
+
+    rank, world, local = gdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    per_gpu = args.meshes_per_gpu
+    first, count = gdist.shard_range(per_gpu * world, rank, world)
+    w = Workload(dev, first, count)
+    elapsed = time_steps(w.step, args.steps, args.warmup)
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        total_meshes = per_gpu * world * args.steps
+        line = {
+            "metric": "meshes/sec (sample+Chamfer+tri_dist+0N-GCN fwd+bwd), 2562 verts/3000 pts",
+            "value": round(total_meshes / elapsed, 2), "unit": "meshes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 5 shard: %d independent 2562-vert/5120-face meshes per GPU, full "
+                                   "loss (face sampling 3000 pts + Chamfer NN vs 3000 GT pts + tri_distance 3000x5120 + "
+                                   "point-to-surface) on top of a 3-layer 0N-GCN 963-192-192-192, fwd+bwd, flat-bucket "
+                                   "grad all-reduce, Adam step" % per_gpu,
+                       "meshes_per_gpu": per_gpu, "global_batch": per_gpu * world, "parallelism": "dp%d" % world},
+            "final_loss": round(float(w.loss_vec.item()), 6),
+        }
+        roofline, others = kernel_rooflines(w)
+        line["roofline"] = roofline
+        line["other_kernels"] = others
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    gdist.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
