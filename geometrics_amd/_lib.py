@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgeom_hip.so")
 
 FLAG_REF_TAIL_TRUNC = 1
 FLAG_FIX_REGION6 = 2
+FLAG_TRI_BRUTE_FORCE = 4
 ABI_VERSION = 1
 
 _vp = ctypes.c_void_p
@@ -25,6 +26,8 @@ _SIGNATURES = {
     "geom_chamfer_nn_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp],
     "geom_tri_distance_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp],
     "geom_tri_distance_indexed_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _u, _vp],
+    "geom_tri_distance_ws_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp, ctypes.c_size_t, _vp],
+    "geom_tri_distance_indexed_ws_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _u, _vp, ctypes.c_size_t, _vp],
     "geom_face_areas_f32": [_i, _i, _vp, _i, _vp, _vp, _vp],
     "geom_sample_faces_fwd_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_sample_faces_bwd_f32": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -64,6 +67,8 @@ def lib():
         if L.geom_abi_version() != ABI_VERSION:
             raise RuntimeError("geometrics_amd: libgeom_hip.so ABI %d != binding ABI %d; rebuild"
                                % (L.geom_abi_version(), ABI_VERSION))
+        L.geom_tri_distance_workspace_bytes.restype = ctypes.c_size_t
+        L.geom_tri_distance_workspace_bytes.argtypes = [_i, _i]
         for name, args in _SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args
@@ -73,7 +78,7 @@ def lib():
 
 
 def declared_symbols():
-    return ["geom_abi_version", "geom_strerror"] + sorted(_SIGNATURES)
+    return sorted(["geom_abi_version", "geom_strerror", "geom_tri_distance_workspace_bytes"] + list(_SIGNATURES))
 
 
 def check(code, what):

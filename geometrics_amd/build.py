@@ -19,7 +19,7 @@ LIB = os.path.join(LIBDIR, "libgeom_hip.so")
 # -ffp-contract=off: one canonical fp32 arithmetic shared with the CPU oracle (no FMA contraction).
 # Division and sqrt stay correctly rounded (hipcc default; never -ffast-math).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-               "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+               "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def sources():

@@ -144,6 +144,456 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_distance_kernel(TriJob job)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Culled scan (default).  Same result as the brute-force kernel above, bit for bit, at a
+// fraction of the work:
+//
+//   1. every triangle gets a conservative bounding sphere that contains every point the
+//      decision tree can return for it.  With the reference's region-6 quirk the candidate set
+//      is the parallelogram A,B,C,D=B+C-A (region 6 returns C + t*(B-A), t in [0,1], the edge
+//      C->D), so the sphere is centred on the midpoint of BC with radius max(|B-m|,|A-m|);
+//      with GEOM_FLAG_FIX_REGION6 it is the centroid sphere of the triangle.  The radius is
+//      inflated by 2^-10 relative and 2^-12 * coordinate-magnitude absolute margins (>= 100x
+//      the fp32 error of any computed closest point).
+//   2. per query point the workgroup keeps ONE 64-bit word in LDS: (distance bits << 32) |
+//      (triangle << 3 | region), updated with ds_min_u64.  Distances are non-negative, so
+//      unsigned order == lexicographic (distance, triangle) order == the reference's
+//      sequential strict-'<' scan.  It is seeded by a HINT -- each wave evaluates, with the
+//      literal arithmetic, the triangle whose sphere centre is nearest among every
+//      HINT_STRIDE-th triangle -- so from the start it holds the distance of a REAL candidate,
+//      an upper bound on the final minimum shared by all four waves.
+//   3. the scan costs ~11 lane-ops per (point, triangle) pair: |p-c|^2 > (r_eff + s)^2 with
+//      s = sqrt(bound) (+ margins) proves the triangle's literal distance is strictly above
+//      the bound, so it can neither win nor tie.  Survivors (tens per point) are compacted
+//      across the wave (ballot + mbcnt) into an LDS queue of (lane, triangle) items and
+//      evaluated 64 at a time with every lane busy, corners read from the LDS chunk; each
+//      result goes into the query's word with one LDS atomic, which also tightens the bound
+//      every wave culls against.
+//   4. the "first triangle seeds" rule (NaN seed sticks) is applied explicitly at the end.
+//
+// A triangle whose sphere is not trustworthy (non-finite, or nearly degenerate so that its
+// computed plane normal could be garbage) gets r_eff = +inf and is never culled; a query
+// whose bound is still unknown (NaN) culls nothing.
+constexpr int CULL_CHUNK = 512;   // triangles staged per pass: 512 * (16 + 48) B = 32 KiB
+constexpr int CULL_QCAP = 64 + 4 * GEOM_WAVE; // queue slots per wave
+constexpr int HINT_STRIDE = 8;
+constexpr unsigned long long KEY_NONE = ~0ull;
+
+template <bool FIX6>
+__device__ __forceinline__ float4 bounding_sphere(V3 A, V3 B, V3 C)
+{
+    V3 c;
+    float r;
+    if (FIX6) {
+        const float third = 1.f / 3.f;
+        c = geom::mk((A.x + B.x + C.x) * third, (A.y + B.y + C.y) * third, (A.z + B.z + C.z) * third);
+        r = sqrtf(fmaxf(fmaxf(geom::dot3(A - c, A - c), geom::dot3(B - c, B - c)), geom::dot3(C - c, C - c)));
+    } else {
+        c = geom::mk((B.x + C.x) * 0.5f, (B.y + C.y) * 0.5f, (B.z + C.z) * 0.5f);
+        r = sqrtf(fmaxf(fmaxf(geom::dot3(A - c, A - c), geom::dot3(B - c, B - c)), geom::dot3(C - c, C - c)));
+    }
+    const float mag = fabsf(c.x) + fabsf(c.y) + fabsf(c.z) + r;
+    float r_eff = r * (1.f + 0x1p-10f) + 0x1p-12f * mag;
+    // trust test: finite, and sin(angle at A) >= 1/64 so the normal (hence the plane foot) is accurate
+    const V3 ab = B - A, ac = C - A;
+    const V3 n = geom::cross3(ab, ac);
+    const float nn = geom::dot3(n, n);
+    const bool ok = (nn >= 0x1p-12f * geom::dot3(ab, ab) * geom::dot3(ac, ac)) && (nn > 0.f) && (mag < 0x1p60f);
+    if (!ok) r_eff = INFINITY; // also catches NaN (comparisons false)
+    return make_float4(c.x, c.y, c.z, r_eff);
+}
+
+__device__ __forceinline__ unsigned long long pack_key(float d, int k, int opt)
+{
+    return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)((k << 3) | opt);
+}
+
+template <bool INDEXED, bool TRUNC, bool FIX6>
+__global__ __launch_bounds__(TRI_THREADS) void tri_distance_culled_kernel(TriJob job)
+{
+    __shared__ float4 sph[CULL_CHUNK];        // {centre, r_eff}
+    __shared__ float4 cor[CULL_CHUNK][3];     // corners A, B, C of the staged chunk
+    __shared__ unsigned long long qbest[TRI_QUERIES];
+    __shared__ float qp[3][TRI_QUERIES];
+    __shared__ unsigned queue[TRI_WAVES][CULL_QCAP];
+
+    const int mesh = blockIdx.y;
+    const int q0 = blockIdx.x * TRI_QUERIES;
+    const int lane = threadIdx.x & (GEOM_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    const int q = q0 + lane;
+    const bool live = q < job.n;
+    V3 p = geom::mk(0.f, 0.f, 0.f);
+    if (live) p = load3(job.xyz + ((size_t)mesh * job.n + q) * 3);
+    const float p_mag = fabsf(p.x) + fabsf(p.y) + fabsf(p.z);
+    if (wave == 0) {
+        qbest[lane] = KEY_NONE;
+        qp[0][lane] = p.x;
+        qp[1][lane] = p.y;
+        qp[2][lane] = p.z;
+    }
+
+    // ---- hint: nearest of every HINT_STRIDE-th sphere centre, per wave --------------------
+    {
+        float near_c2 = INFINITY;
+        int near_k = wave < job.m ? wave : 0; // any valid triangle is a valid hint
+        const int hints = (job.m + HINT_STRIDE - 1) / HINT_STRIDE;
+        for (int c0 = 0; c0 < hints; c0 += CULL_CHUNK) {
+            const int len = min(CULL_CHUNK, hints - c0);
+            for (int t = threadIdx.x; t < len; t += TRI_THREADS) {
+                V3 A, B, C;
+                fetch_triangle<INDEXED>(job, mesh, (c0 + t) * HINT_STRIDE, A, B, C);
+                sph[t] = bounding_sphere<FIX6>(A, B, C);
+            }
+            __syncthreads();
+            const int per_wave = (len + TRI_WAVES - 1) / TRI_WAVES;
+            const int t_end = min(len, (wave + 1) * per_wave);
+            for (int t = wave * per_wave; t < t_end; ++t) {
+                const float4 rec = sph[t];
+                const float c2 = geom::sqdist3(rec.x, rec.y, rec.z, p.x, p.y, p.z);
+                if (c2 < near_c2) {
+                    near_c2 = c2;
+                    near_k = (c0 + t) * HINT_STRIDE;
+                }
+            }
+            __syncthreads();
+        }
+        if (!(TRUNC && geom::ref_tail_skipped(near_k, job.m))) {
+            V3 A, B, C;
+            fetch_triangle<INDEXED>(job, mesh, near_k, A, B, C);
+            int opt;
+            const float d = geom::tri_pair_literal<FIX6>(p, A, B, C, opt);
+            if (d == d) atomicMin(&qbest[lane], pack_key(d, near_k, opt));
+        }
+        __syncthreads();
+    }
+
+    // culling slack from the current bound (NaN while the query has no candidate: culls nothing)
+    auto slack = [&]() {
+        const float bound = __uint_as_float((unsigned)(qbest[lane] >> 32));
+        return sqrtf(bound) * (1.f + 0x1p-10f) + 0x1p-12f * p_mag;
+    };
+    float s = slack();
+
+    unsigned *my_queue = queue[wave];
+    int qn = 0; // wave-uniform queue length
+
+    // evaluate `count` (<= 64) queued items, one per lane, with the literal arithmetic
+    auto process = [&](int first, int count, int c0) {
+        if (lane < count) {
+            const unsigned item = my_queue[first + lane];
+            const int ql = item >> 26;
+            const int t = item & 0x3ffffff;
+            if (!(TRUNC && geom::ref_tail_skipped(c0 + t, job.m))) {
+                const float4 a = cor[t][0], b = cor[t][1], c = cor[t][2];
+                const V3 pq = geom::mk(qp[0][ql], qp[1][ql], qp[2][ql]);
+                int opt;
+                const float d = geom::tri_pair_literal<FIX6>(pq, geom::mk(a.x, a.y, a.z), geom::mk(b.x, b.y, b.z),
+                                                             geom::mk(c.x, c.y, c.z), opt);
+                if (d == d) atomicMin(&qbest[ql], pack_key(d, c0 + t, opt));
+            }
+        }
+    };
+
+    // ---- culled scan --------------------------------------------------------------------
+    for (int c0 = 0; c0 < job.m; c0 += CULL_CHUNK) {
+        const int len = min(CULL_CHUNK, job.m - c0);
+        for (int t = threadIdx.x; t < len; t += TRI_THREADS) {
+            V3 A, B, C;
+            fetch_triangle<INDEXED>(job, mesh, c0 + t, A, B, C);
+            float4 rec = bounding_sphere<FIX6>(A, B, C);
+            if (TRUNC && geom::ref_tail_skipped(c0 + t, job.m)) rec.x = INFINITY; // culled unless s is inf/NaN
+            sph[t] = rec;
+            cor[t][0] = make_float4(A.x, A.y, A.z, 0.f);
+            cor[t][1] = make_float4(B.x, B.y, B.z, 0.f);
+            cor[t][2] = make_float4(C.x, C.y, C.z, 0.f);
+        }
+        __syncthreads();
+        const int per_wave = (((len + TRI_WAVES - 1) / TRI_WAVES) + 3) & ~3; // multiple of 4
+        const int t_begin = wave * per_wave;
+        const int t_end = min(len, t_begin + per_wave);
+        for (int t = t_begin; t < t_end; t += 4) {
+            bool keep[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 rec = sph[min(t + j, len - 1)];
+                const float c2 = geom::sqdist3(rec.x, rec.y, rec.z, p.x, p.y, p.z);
+                const float reach = rec.w + s;
+                keep[j] = live && (t + j < t_end) && !(c2 > reach * reach);
+            }
+            if (__ballot(keep[0] || keep[1] || keep[2] || keep[3]) != 0ull) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned long long m = __ballot(keep[j]);
+                    if (m != 0ull) {
+                        const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        if (keep[j]) my_queue[pos] = ((unsigned)lane << 26) | (unsigned)(t + j);
+                        qn += __popcll(m);
+                    }
+                }
+                if (qn >= GEOM_WAVE) {
+                    do {
+                        qn -= GEOM_WAVE;
+                        process(qn, GEOM_WAVE, c0);
+                    } while (qn >= GEOM_WAVE);
+                    s = slack();
+                }
+            }
+        }
+        if (qn > 0) { // the corners of this chunk are about to be overwritten: drain
+            process(0, qn, c0);
+            qn = 0;
+            s = slack();
+        }
+        __syncthreads();
+    }
+
+    if (wave == 0 && live) {
+        const unsigned long long word = qbest[lane];
+        float acc_d = __uint_as_float((unsigned)(word >> 32));
+        int acc_k = (int)(unsigned)word;
+        // "k == 0 ||" seed (tri_distance.cu:194): a NaN first distance sticks, and when nothing
+        // finite was found the first triangle's result stands.
+        V3 A, B, C;
+        fetch_triangle<INDEXED>(job, mesh, 0, A, B, C);
+        int opt0;
+        const float d0 = geom::tri_pair_literal<FIX6>(p, A, B, C, opt0);
+        if (d0 != d0 || word == KEY_NONE) {
+            acc_d = d0;
+            acc_k = opt0;
+        }
+        if (TRUNC) {
+            const int last0 = ((job.m - 1) / geom::REF_TILE) * geom::REF_TILE;
+            if (job.m - last0 < 4 && (last0 == 0 || acc_d > 10000.f)) {
+                acc_d = 10000.f;
+                acc_k = 0;
+            }
+        }
+        const size_t o = (size_t)mesh * job.n + q;
+        job.dist[o] = acc_d;
+        job.point[o] = acc_k & 7;
+        job.index[o] = acc_k >> 3;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Workspace variant of the culled scan (what the python operators use).
+//
+// A prep kernel writes, once per (mesh, triangle), the bounding sphere and the three corners
+// into a caller-provided workspace (64 B per triangle).  The scan kernel then never touches
+// faces/verts again and needs no LDS staging and no chunk barriers:
+//   * the sphere records are wave-uniform, so they are fetched with SCALAR loads
+//     (s_load_dwordx4/x16 through the scalar cache) and used as SGPR operands of the VALU
+//     compare -- the CDNA way to broadcast, leaving LDS and VGPRs to the survivor queue;
+//   * 8 waves share 64 query points and split the triangle range 8 ways (3008 waves at the
+//     BASELINE shard of 8 meshes), so one block's serial chain is ~1/8 of the range;
+//   * survivors are compacted into per-wave LDS queues exactly as above, their corners come
+//     from the workspace with one 48-byte gather per item, and the queue only drains at the end.
+constexpr int WS_THREADS = 512;
+constexpr int WS_WAVES = WS_THREADS / GEOM_WAVE; // 8
+constexpr int WS_PAD = 4 * WS_WAVES;             // triangle count is padded to a multiple of this
+
+struct TriWs {
+    float4 *sph; // [b][m_pad]     {centre, r_eff}
+    float4 *cor; // [b][m_pad][3]  corners A, B, C
+    int m_pad;
+};
+
+__host__ __device__ inline int ws_pad(int m) { return (m + WS_PAD - 1) / WS_PAD * WS_PAD; }
+
+template <bool INDEXED, bool TRUNC, bool FIX6>
+__global__ __launch_bounds__(256) void tri_prep_kernel(TriJob job, TriWs ws)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int mesh = blockIdx.y;
+    if (k >= ws.m_pad) return;
+    float4 rec = make_float4(INFINITY, 0.f, 0.f, 0.f); // padding: culled (or dropped by the k < m test)
+    V3 A = geom::mk(0.f, 0.f, 0.f), B = A, C = A;
+    if (k < job.m) {
+        fetch_triangle<INDEXED>(job, mesh, k, A, B, C);
+        rec = bounding_sphere<FIX6>(A, B, C);
+        if (TRUNC && geom::ref_tail_skipped(k, job.m)) rec.x = INFINITY;
+    }
+    const size_t o = (size_t)mesh * ws.m_pad + k;
+    ws.sph[o] = rec;
+    ws.cor[3 * o + 0] = make_float4(A.x, A.y, A.z, 0.f);
+    ws.cor[3 * o + 1] = make_float4(B.x, B.y, B.z, 0.f);
+    ws.cor[3 * o + 2] = make_float4(C.x, C.y, C.z, 0.f);
+}
+
+template <bool TRUNC, bool FIX6>
+__global__ __launch_bounds__(WS_THREADS) void tri_scan_ws_kernel(const float *__restrict__ xyz, int n, int m, int m_pad,
+                                                                  const float4 *__restrict__ sph_all,
+                                                                  const float4 *__restrict__ cor_all,
+                                                                  float *__restrict__ dist, int *__restrict__ point,
+                                                                  int *__restrict__ index)
+{
+    __shared__ unsigned long long qbest[TRI_QUERIES];
+    __shared__ float qp[3][TRI_QUERIES];
+    __shared__ unsigned queue[WS_WAVES][CULL_QCAP];
+
+    const int mesh = blockIdx.y;
+    const int q0 = blockIdx.x * TRI_QUERIES;
+    const int lane = threadIdx.x & (GEOM_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform => scalar addressing
+    const int q = q0 + lane;
+    const bool live = q < n;
+    const float4 *__restrict__ sph = sph_all + (size_t)mesh * m_pad;
+    const float4 *__restrict__ cor = cor_all + (size_t)mesh * m_pad * 3;
+    V3 p = geom::mk(0.f, 0.f, 0.f);
+    if (live) p = load3(xyz + ((size_t)mesh * n + q) * 3);
+    const float p_mag = fabsf(p.x) + fabsf(p.y) + fabsf(p.z);
+    if (wave == 0) {
+        qbest[lane] = KEY_NONE;
+        qp[0][lane] = p.x;
+        qp[1][lane] = p.y;
+        qp[2][lane] = p.z;
+    }
+    __syncthreads();
+
+    // literal evaluation of triangle k for the query held by lane `ql`, merged with one LDS atomic
+    auto evaluate = [&](int ql, int k) {
+        if (k >= m || (TRUNC && geom::ref_tail_skipped(k, m))) return;
+        const float4 a = cor[3 * (size_t)k + 0], b = cor[3 * (size_t)k + 1], c = cor[3 * (size_t)k + 2];
+        const V3 pq = geom::mk(qp[0][ql], qp[1][ql], qp[2][ql]);
+        int opt;
+        const float d = geom::tri_pair_literal<FIX6>(pq, geom::mk(a.x, a.y, a.z), geom::mk(b.x, b.y, b.z),
+                                                     geom::mk(c.x, c.y, c.z), opt);
+        if (d == d) atomicMin(&qbest[ql], pack_key(d, k, opt));
+    };
+
+    // ---- hint: nearest of every HINT_STRIDE-th sphere centre within this wave's share ------
+    {
+        float near_c2 = INFINITY;
+        int near_k = wave < m ? wave : 0;
+        for (int k = wave * HINT_STRIDE; k < m; k += WS_WAVES * HINT_STRIDE) {
+            const float4 rec = sph[k]; // scalar load
+            const float c2 = geom::sqdist3(rec.x, rec.y, rec.z, p.x, p.y, p.z);
+            if (c2 < near_c2) {
+                near_c2 = c2;
+                near_k = k;
+            }
+        }
+        evaluate(lane, near_k);
+        __syncthreads();
+    }
+
+    auto slack = [&]() {
+        const float bound = __uint_as_float((unsigned)(qbest[lane] >> 32)); // NaN until a candidate exists
+        return sqrtf(bound) * (1.f + 0x1p-10f) + 0x1p-12f * p_mag;
+    };
+    float s = slack();
+
+    unsigned *my_queue = queue[wave];
+    int qn = 0; // wave-uniform queue length
+    auto pop_batch = [&](int first, int count) {
+        if (lane < count) {
+            const unsigned item = my_queue[first + lane];
+            evaluate((int)(item >> 26), (int)(item & 0x3ffffffu));
+        }
+    };
+
+    // ---- culled scan over this wave's contiguous share (multiple of 4 triangles) -----------
+    // The records of the NEXT group are requested (scalar loads) before the current group is
+    // tested, so the ~300-cycle scalar-cache latency overlaps the VALU work.
+    const unsigned long long live_mask = __ballot(live);
+    const int per_wave = m_pad / WS_WAVES;
+    const int t_begin = wave * per_wave;
+    const int t_last = t_begin + per_wave - 4;
+    float4 cur[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cur[j] = sph[t_begin + j];
+    for (int t = t_begin; t <= t_last; t += 4) {
+        float4 nxt[4];
+        const int tn = t < t_last ? t + 4 : t; // last group re-reads itself (stays in bounds)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nxt[j] = sph[tn + j];
+        unsigned long long keep[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float c2 = geom::sqdist3(cur[j].x, cur[j].y, cur[j].z, p.x, p.y, p.z);
+            const float reach = cur[j].w + s;
+            keep[j] = __builtin_amdgcn_ballot_w64(!(c2 > reach * reach)) & live_mask;
+        }
+        if ((keep[0] | keep[1] | keep[2] | keep[3]) != 0ull) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned long long mask = keep[j];
+                if (mask != 0ull) {
+                    const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if ((mask >> lane) & 1ull) my_queue[pos] = ((unsigned)lane << 26) | (unsigned)(t + j);
+                    qn += __popcll(mask);
+                }
+            }
+            if (qn >= GEOM_WAVE) {
+                do {
+                    qn -= GEOM_WAVE;
+                    pop_batch(qn, GEOM_WAVE);
+                } while (qn >= GEOM_WAVE);
+                s = slack();
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+    }
+    if (qn > 0) pop_batch(0, qn);
+    __syncthreads();
+
+    if (wave == 0 && live) {
+        const unsigned long long word = qbest[lane];
+        float acc_d = __uint_as_float((unsigned)(word >> 32));
+        int acc_k = (int)(unsigned)word;
+        // "k == 0 ||" seed (tri_distance.cu:194)
+        const float4 a = cor[0], b = cor[1], c = cor[2];
+        int opt0;
+        const float d0 = geom::tri_pair_literal<FIX6>(p, geom::mk(a.x, a.y, a.z), geom::mk(b.x, b.y, b.z),
+                                                      geom::mk(c.x, c.y, c.z), opt0);
+        if (d0 != d0 || word == KEY_NONE) {
+            acc_d = d0;
+            acc_k = opt0;
+        }
+        if (TRUNC) {
+            const int last0 = ((m - 1) / geom::REF_TILE) * geom::REF_TILE;
+            if (m - last0 < 4 && (last0 == 0 || acc_d > 10000.f)) {
+                acc_d = 10000.f;
+                acc_k = 0;
+            }
+        }
+        const size_t o = (size_t)mesh * n + q;
+        dist[o] = acc_d;
+        point[o] = acc_k & 7;
+        index[o] = acc_k >> 3;
+    }
+}
+
+template <bool INDEXED, bool TRUNC, bool FIX6>
+int launch_ws_variant(const TriJob &job, const TriWs &ws, hipStream_t s)
+{
+    hipLaunchKernelGGL((tri_prep_kernel<INDEXED, TRUNC, FIX6>), dim3((ws.m_pad + 255) / 256, job.b), dim3(256), 0, s, job, ws);
+    hipLaunchKernelGGL((tri_scan_ws_kernel<TRUNC, FIX6>), dim3((job.n + TRI_QUERIES - 1) / TRI_QUERIES, job.b),
+                       dim3(WS_THREADS), 0, s, job.xyz, job.n, job.m, ws.m_pad, ws.sph, ws.cor, job.dist, job.point,
+                       job.index);
+    return geom::launch_status();
+}
+
+template <bool INDEXED>
+int launch_tri_ws(const TriJob &job, unsigned flags, void *workspace, size_t ws_bytes, void *stream)
+{
+    const int m_pad = ws_pad(job.m);
+    const size_t need = (size_t)job.b * m_pad * 4 * sizeof(float4);
+    if (!workspace || ws_bytes < need || ((uintptr_t)workspace & 15)) return GEOM_EINVAL;
+    TriWs ws{static_cast<float4 *>(workspace), static_cast<float4 *>(workspace) + (size_t)job.b * m_pad, m_pad};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool trunc = flags & GEOM_FLAG_REF_TAIL_TRUNC, fix6 = flags & GEOM_FLAG_FIX_REGION6;
+    if (trunc && fix6) return launch_ws_variant<INDEXED, true, true>(job, ws, s);
+    if (trunc) return launch_ws_variant<INDEXED, true, false>(job, ws, s);
+    if (fix6) return launch_ws_variant<INDEXED, false, true>(job, ws, s);
+    return launch_ws_variant<INDEXED, false, false>(job, ws, s);
+}
+
 template <bool INDEXED>
 int launch_tri(const TriJob &job, unsigned flags, void *stream)
 {
@@ -151,6 +601,17 @@ int launch_tri(const TriJob &job, unsigned flags, void *stream)
     dim3 block(TRI_THREADS);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool trunc = flags & GEOM_FLAG_REF_TAIL_TRUNC, fix6 = flags & GEOM_FLAG_FIX_REGION6;
+    if (!(flags & GEOM_FLAG_TRI_BRUTE_FORCE)) {
+        if (trunc && fix6)
+            hipLaunchKernelGGL((tri_distance_culled_kernel<INDEXED, true, true>), grid, block, 0, s, job);
+        else if (trunc)
+            hipLaunchKernelGGL((tri_distance_culled_kernel<INDEXED, true, false>), grid, block, 0, s, job);
+        else if (fix6)
+            hipLaunchKernelGGL((tri_distance_culled_kernel<INDEXED, false, true>), grid, block, 0, s, job);
+        else
+            hipLaunchKernelGGL((tri_distance_culled_kernel<INDEXED, false, false>), grid, block, 0, s, job);
+        return geom::launch_status();
+    }
     if (trunc && fix6)
         hipLaunchKernelGGL((tri_distance_kernel<INDEXED, true, true>), grid, block, 0, s, job);
     else if (trunc)
@@ -172,7 +633,7 @@ extern "C" int geom_tri_distance_f32(int b, int n, const float *xyz, int m,
     if (b == 0 || n == 0) return 0;
     if (m == 0) return GEOM_EINVAL;
     if (!xyz || !tri1 || !tri2 || !tri3 || !dist || !point || !index) return GEOM_EINVAL;
-    if (b > 65535 || m >= (1 << 28)) return GEOM_ETOOBIG;
+    if (b > 65535 || m >= (1 << 26)) return GEOM_ETOOBIG;
     TriJob job{xyz, tri1, tri2, tri3, nullptr, nullptr, dist, point, index, b, n, m, 0};
     return launch_tri<false>(job, flags, stream);
 }
@@ -185,7 +646,43 @@ extern "C" int geom_tri_distance_indexed_f32(int b, int n, const float *xyz, int
     if (b == 0 || n == 0) return 0;
     if (nf == 0 || nv == 0) return GEOM_EINVAL;
     if (!xyz || !verts || !faces || !dist || !point || !index) return GEOM_EINVAL;
-    if (b > 65535 || nf >= (1 << 28)) return GEOM_ETOOBIG;
+    if (b > 65535 || nf >= (1 << 26)) return GEOM_ETOOBIG;
     TriJob job{xyz, nullptr, nullptr, nullptr, verts, faces, dist, point, index, b, n, nf, nv};
     return launch_tri<true>(job, flags, stream);
+}
+
+extern "C" size_t geom_tri_distance_workspace_bytes(int b, int m)
+{
+    if (b <= 0 || m <= 0) return 0;
+    return (size_t)b * ws_pad(m) * 4 * sizeof(float4);
+}
+
+extern "C" int geom_tri_distance_ws_f32(int b, int n, const float *xyz, int m,
+                                        const float *tri1, const float *tri2, const float *tri3,
+                                        float *dist, int *point, int *index, unsigned flags,
+                                        void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (b < 0 || n < 0 || m < 0) return GEOM_EINVAL;
+    if (b == 0 || n == 0) return 0;
+    if (m == 0) return GEOM_EINVAL;
+    if (!xyz || !tri1 || !tri2 || !tri3 || !dist || !point || !index) return GEOM_EINVAL;
+    if (b > 65535 || m >= (1 << 26)) return GEOM_ETOOBIG;
+    TriJob job{xyz, tri1, tri2, tri3, nullptr, nullptr, dist, point, index, b, n, m, 0};
+    if (flags & GEOM_FLAG_TRI_BRUTE_FORCE) return launch_tri<false>(job, flags, stream);
+    return launch_tri_ws<false>(job, flags, workspace, workspace_bytes, stream);
+}
+
+extern "C" int geom_tri_distance_indexed_ws_f32(int b, int n, const float *xyz, int nv, const float *verts,
+                                                int nf, const int64_t *faces,
+                                                float *dist, int *point, int *index, unsigned flags,
+                                                void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (b < 0 || n < 0 || nf < 0 || nv < 0) return GEOM_EINVAL;
+    if (b == 0 || n == 0) return 0;
+    if (nf == 0 || nv == 0) return GEOM_EINVAL;
+    if (!xyz || !verts || !faces || !dist || !point || !index) return GEOM_EINVAL;
+    if (b > 65535 || nf >= (1 << 26)) return GEOM_ETOOBIG;
+    TriJob job{xyz, nullptr, nullptr, nullptr, verts, faces, dist, point, index, b, n, nf, nv};
+    if (flags & GEOM_FLAG_TRI_BRUTE_FORCE) return launch_tri<true>(job, flags, stream);
+    return launch_tri_ws<true>(job, flags, workspace, workspace_bytes, stream);
 }

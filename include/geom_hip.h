@@ -20,6 +20,7 @@
 #ifndef GEOM_HIP_H
 #define GEOM_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -36,6 +37,8 @@ extern "C" {
 #define GEOM_FLAG_REF_TAIL_TRUNC 1u /* reproduce the shipped CUDA kernels' tail truncation:
                                        chamfer_distance.cu:31-33, tri_distance.cu:129-134 */
 #define GEOM_FLAG_FIX_REGION6    2u /* tri: walk option 6 along CA instead of the reference's AB (tri_distance.cu:180, Q2) */
+#define GEOM_FLAG_TRI_BRUTE_FORCE 4u /* tri: evaluate the full decision tree for every pair (no sphere culling);
+                                       same result, kept as the in-library cross-check of the culled scan */
 
 int geom_abi_version(void);
 /* static string for a code returned by any entry point */
@@ -68,6 +71,20 @@ int geom_tri_distance_f32(int b, int n, const float *xyz, int m,
 int geom_tri_distance_indexed_f32(int b, int n, const float *xyz, int nv, const float *verts,
                                   int nf, const int64_t *faces,
                                   float *dist, int *point, int *index, unsigned flags, void *stream);
+
+/* Workspace variants (what the python operators call): identical results; the scan reads
+ * per-triangle {bounding sphere, corners} records that a prep kernel writes into `workspace`
+ * (device memory, 16-byte aligned, at least geom_tri_distance_workspace_bytes(b, m) bytes,
+ * contents undefined on entry and exit), which removes all per-block staging work. */
+size_t geom_tri_distance_workspace_bytes(int b, int m);
+int geom_tri_distance_ws_f32(int b, int n, const float *xyz, int m,
+                             const float *tri1, const float *tri2, const float *tri3,
+                             float *dist, int *point, int *index, unsigned flags,
+                             void *workspace, size_t workspace_bytes, void *stream);
+int geom_tri_distance_indexed_ws_f32(int b, int n, const float *xyz, int nv, const float *verts,
+                                     int nf, const int64_t *faces,
+                                     float *dist, int *point, int *index, unsigned flags,
+                                     void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- differentiable face sampling (utils.py:590-633) -------------------------------------
  * areas[b,nf] = 0.5*|(v0-v1) x (v1-v2)|, the un-normalised multinomial weights (utils.py:596-602). */

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from geometrics_amd import meshgen
-from geometrics_amd._lib import FLAG_FIX_REGION6, FLAG_REF_TAIL_TRUNC
+from geometrics_amd._lib import FLAG_FIX_REGION6, FLAG_REF_TAIL_TRUNC, FLAG_TRI_BRUTE_FORCE
 from geometrics_amd.chamfer_distance import ChamferDistance, chamfer_nn
 from geometrics_amd.tri_distance import TriDistance, tri_distance, tri_distance_indexed
 
@@ -103,6 +103,16 @@ def _check_tri(oracle_mod, gpu, pts, verts, F, flags=0):
     np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), ed.view(np.uint32))
     d2, p2, i2 = tri_distance_indexed(_dev(pts, gpu), _dev(verts, gpu), _dev(F, gpu), flags)
     assert torch.equal(i2, i) and torch.equal(p2, p) and torch.equal(d2.view(torch.int32), d.view(torch.int32))
+    # the in-library brute-force scan (every pair through the full decision tree) must agree too
+    d3, p3, i3 = tri_distance_indexed(_dev(pts, gpu), _dev(verts, gpu), _dev(F, gpu), flags | FLAG_TRI_BRUTE_FORCE)
+    assert torch.equal(i3, i) and torch.equal(p3, p) and torch.equal(d3.view(torch.int32), d.view(torch.int32))
+    d4, p4, i4 = tri_distance(_dev(pts, gpu), _dev(t1, gpu), _dev(t2, gpu), _dev(t3, gpu), flags | FLAG_TRI_BRUTE_FORCE)
+    assert torch.equal(i4, i) and torch.equal(p4, p) and torch.equal(d4.view(torch.int32), d.view(torch.int32))
+    # the reference-shaped entry points without a workspace (in-kernel staging) as well
+    d5, p5, i5 = tri_distance(_dev(pts, gpu), _dev(t1, gpu), _dev(t2, gpu), _dev(t3, gpu), flags, use_workspace=False)
+    assert torch.equal(i5, i) and torch.equal(p5, p) and torch.equal(d5.view(torch.int32), d.view(torch.int32))
+    d6, p6, i6 = tri_distance_indexed(_dev(pts, gpu), _dev(verts, gpu), _dev(F, gpu), flags, use_workspace=False)
+    assert torch.equal(i6, i) and torch.equal(p6, p) and torch.equal(d6.view(torch.int32), d.view(torch.int32))
     return ep
 
 
@@ -140,10 +150,50 @@ def test_tri_degenerate_triangles(oracle_mod, gpu):
     F[40] = [1, 2, 2]
     t1, t2, t3 = (np.ascontiguousarray(verts[:, F[:, k]]) for k in range(3))
     ed, ep, ei = oracle_mod.tri_scan(pts, t1, t2, t3)
-    d, p, i = tri_distance(_dev(pts, gpu), _dev(t1, gpu), _dev(t2, gpu), _dev(t3, gpu))
-    np.testing.assert_array_equal(i.cpu().numpy(), ei)
-    np.testing.assert_array_equal(p.cpu().numpy(), ep)
-    np.testing.assert_array_equal(np.isnan(d.cpu().numpy()), np.isnan(ed))
+    for flags in (0, FLAG_TRI_BRUTE_FORCE):
+        d, p, i = tri_distance(_dev(pts, gpu), _dev(t1, gpu), _dev(t2, gpu), _dev(t3, gpu), flags)
+        np.testing.assert_array_equal(i.cpu().numpy(), ei)
+        np.testing.assert_array_equal(p.cpu().numpy(), ep)
+        np.testing.assert_array_equal(np.isnan(d.cpu().numpy()), np.isnan(ed))
+
+
+@pytest.mark.parametrize("case", ["on_vertices", "far_away", "offset_1000", "tiny_scale", "huge_scale", "slivers",
+                                  "duplicate_faces", "points_on_surface", "batch8_baseline"])
+def test_tri_culling_is_exact_under_stress(oracle_mod, gpu, case):
+    """Inputs chosen to break a sloppy culling bound: zero distances, bounds much larger than the
+    mesh, catastrophic-cancellation offsets, extreme scales, near-degenerate triangles, exact ties."""
+    rng = np.random.default_rng(hash(case) % 2 ** 31)
+    verts, F, pts = _mesh_case(2, 3, 400, seed=21)
+    if case == "on_vertices":
+        pts[:, :300] = verts[:, rng.integers(0, verts.shape[1], 300)]
+    elif case == "far_away":
+        pts = pts * 40 + 7
+    elif case == "offset_1000":
+        verts, pts = verts + 1000.0, pts + 1000.0
+    elif case == "tiny_scale":
+        verts, pts = verts * 1e-4, pts * 1e-4
+    elif case == "huge_scale":
+        verts, pts = verts * 1e5, pts * 1e5
+    elif case == "slivers":
+        verts = verts.copy()
+        verts[:, F[::7, 2]] = verts[:, F[::7, 1]] + 1e-6 * rng.standard_normal((2, len(F[::7]), 3)).astype(np.float32)
+    elif case == "duplicate_faces":
+        F = np.concatenate([F, F[:200], F[::-1][:100]])
+    elif case == "points_on_surface":
+        ch, u, v = meshgen.sampling_draws(verts, F, 400)
+        x, y, z = (np.take_along_axis(verts, F[ch][..., k][..., None].repeat(3, -1), 1) for k in range(3))
+        pts = ((1 - u)[..., None] * x + (u * (1 - v))[..., None] * y + (u * v)[..., None] * z).astype(np.float32)
+    elif case == "batch8_baseline":
+        verts, F, pts = _mesh_case(8, 4, 3000, seed=0)
+        d, p, i = tri_distance_indexed(_dev(pts, gpu), _dev(verts, gpu), _dev(F, gpu))
+        d2, p2, i2 = tri_distance_indexed(_dev(pts, gpu), _dev(verts, gpu), _dev(F, gpu), FLAG_TRI_BRUTE_FORCE)
+        assert torch.equal(i2, i) and torch.equal(p2, p) and torch.equal(d2.view(torch.int32), d.view(torch.int32))
+        ed, ep, ei = oracle_mod.tri_scan_indexed(pts[:1], verts[:1], F)
+        np.testing.assert_array_equal(i[:1].cpu().numpy(), ei)
+        return
+    _check_tri(oracle_mod, gpu, np.ascontiguousarray(pts, np.float32), np.ascontiguousarray(verts, np.float32), F)
+    _check_tri(oracle_mod, gpu, np.ascontiguousarray(pts, np.float32), np.ascontiguousarray(verts, np.float32), F,
+               FLAG_FIX_REGION6)
 
 
 def test_tri_module_contract(gpu):
