@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from geometrics_amd import dist as gdist  # noqa: E402
-from geometrics_amd import layers, meshgen, utils  # noqa: E402
+from geometrics_amd import gemm_tuning, layers, meshgen, utils  # noqa: E402
 from geometrics_amd.chamfer_distance import chamfer_nn  # noqa: E402
 from geometrics_amd.tri_distance import tri_distance_indexed  # noqa: E402
 
@@ -61,8 +61,31 @@ class Workload:
         self.stack = torch.nn.ModuleList(
             [layers.Batch_Image_ZERON_GCNGCN(i, o) for i, o in ((FEAT, HID), (HID, HID), (HID, HID))]).to(dev)
         self.bucket = gdist.GradBucket(self.stack.parameters())
-        self.opt = torch.optim.Adam(self.stack.parameters(), lr=1e-4)   # GEOMetrics.py:73 (Adam, lr 1e-4)
+        # GEOMetrics.py:73 (Adam, lr 1e-4); fused + capturable: one kernel, no host sync, graph-safe
+        self.opt = torch.optim.Adam(self.stack.parameters(), lr=1e-4, fused=True, capturable=True)
         self.loss_vec = None
+        self.graph = None
+
+    def capture(self, warm=3):
+        """Record one whole step (fwd + bwd + all-reduce + Adam) into a HIP graph; every launch of
+        the step -- library GEMMs, our C-ABI kernels, RCCL -- replays without python in the loop."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warm):
+                self.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.step()
+        self.graph = graph
+
+    def run(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.step()
 
     def positions(self):
         h = self.feat
@@ -184,6 +207,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--meshes-per-gpu", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch", choices=("graph", "eager"), default="graph",
+                    help="replay the whole step as one HIP graph (default) or launch eagerly from python")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-stage event-timed breakdown")
     args = ap.parse_args()
 
@@ -195,10 +220,21 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    tuned = gemm_tuning.enable()      # pin the measured-fastest library GEMM per shape (no tuning at run time)
     per_gpu = args.meshes_per_gpu
     first, count = gdist.shard_range(per_gpu * world, rank, world)
     w = Workload(dev, first, count)
-    elapsed = time_steps(w.step, args.steps, args.warmup)
+    launch = "eager"
+    if args.launch == "graph":
+        try:
+            w.capture()
+            launch = "hipgraph"
+        except Exception as exc:  # fall back loudly, never silently
+            print("bench.py: HIP graph capture failed (%s: %s); running eager" % (type(exc).__name__, exc),
+                  file=sys.stderr)
+            w.graph = None
+            torch.cuda.synchronize()
+    elapsed = time_steps(w.run, args.steps, args.warmup)
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -215,7 +251,8 @@ def main():
                                    "loss (face sampling 3000 pts + Chamfer NN vs 3000 GT pts + tri_distance 3000x5120 + "
                                    "point-to-surface) on top of a 3-layer 0N-GCN 963-192-192-192, fwd+bwd, flat-bucket "
                                    "grad all-reduce, Adam step" % per_gpu,
-                       "meshes_per_gpu": per_gpu, "global_batch": per_gpu * world, "parallelism": "dp%d" % world},
+                       "meshes_per_gpu": per_gpu, "global_batch": per_gpu * world, "parallelism": "dp%d" % world,
+                       "launch": launch, "gemm_selection": "tunableop file" if tuned else "library default"},
             "final_loss": round(float(w.loss_vec.item()), 6),
         }
         roofline, others = kernel_rooflines(w)

@@ -44,8 +44,8 @@ def all_reduce_sum_(t):
 
 def global_mean_loss(local_loss_sum, local_count):
     """Mean over ALL meshes of per-mesh losses: all-reduce [sum, count] (8 bytes)."""
-    vec = torch.stack([local_loss_sum.reshape(()).float(),
-                       torch.as_tensor(float(local_count), device=local_loss_sum.device)])
+    total = local_loss_sum.reshape(()).float()
+    vec = torch.stack([total, total.new_full((), float(local_count))])   # no host->device copy: graph-capturable
     all_reduce_sum_(vec)
     return vec[0] / vec[1]
 

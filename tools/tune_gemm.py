@@ -1,0 +1,31 @@
+"""Regenerate geometrics_amd/tuning/tunableop_gfx950.csv on an MI355X:
+    python tools/tune_gemm.py gpurun_out/tunableop_gfx950.csv
+Runs PyTorch TunableOp over the GEMM shapes of the 0N-GCN stacks (forward, dW, dX) for the
+shard sizes the benchmarks and tests use."""
+import os
+import sys
+
+out = sys.argv[1]
+os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
+os.environ["PYTORCH_TUNABLEOP_TUNING"] = "1"
+os.environ["PYTORCH_TUNABLEOP_FILENAME"] = out
+import torch  # noqa: E402
+
+torch.cuda.tunable.set_filename(out)
+torch.cuda.tunable.set_max_tuning_duration(60)
+torch.cuda.tunable.set_max_tuning_iterations(40)
+dev = torch.device("cuda:0")
+V = 2562
+layers = [(963, 192), (192, 192), (1155, 192), (192, 3)]
+for meshes in (1, 2, 4, 8, 16):
+    M = meshes * V
+    for cin, cout in layers:
+        x = torch.randn(M, cin, device=dev, requires_grad=True)
+        w = torch.randn(cin, cout, device=dev, requires_grad=True)
+        y = x @ w
+        y.backward(torch.randn_like(y))
+        x3 = torch.randn(meshes, V, cin, device=dev, requires_grad=True)      # the [B,V,C] @ [C,O] path
+        (x3 @ w).sum().backward()
+torch.cuda.synchronize()
+torch.cuda.tunable.write_file()
+print("wrote", out)
