@@ -1,0 +1,37 @@
+"""Overlay module for the reference's `utils.py`.
+
+The drivers do `from utils import *` and rely on every name that module defines or imports
+(data loaders, OBJ parser, camera pooling, re-exported numpy/torch/tqdm/...).  Only the
+hot-path functions are ours; everything else must stay the user's reference code.  So this
+overlay (1) finds the reference's own utils.py further down sys.path, (2) executes it as
+`_reference_utils` -- its `from chamfer_distance import ...` / `from tri_distance import ...`
+lines resolve to the overlay packages, so nothing is JIT-compiled with nvcc -- (3) re-exports
+all of its public names, and (4) overrides the hot-path ones with the HIP implementations.
+No reference source is shipped in this repository.
+"""
+import importlib.util
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _find_reference_utils():
+    for entry in sys.path:
+        cand = os.path.join(entry or os.getcwd(), "utils.py")
+        if os.path.isfile(cand) and os.path.dirname(os.path.abspath(cand)) != _HERE:
+            return cand
+    raise ImportError("overlay/utils.py: no reference utils.py found on sys.path after the overlay directory; "
+                      "run from the reference checkout with PYTHONPATH=<repo>/overlay:<repo>")
+
+
+_spec = importlib.util.spec_from_file_location("_reference_utils", _find_reference_utils())
+_reference_utils = importlib.util.module_from_spec(_spec)
+sys.modules["_reference_utils"] = _reference_utils
+_spec.loader.exec_module(_reference_utils)
+
+globals().update({k: v for k, v in vars(_reference_utils).items() if not k.startswith("__")})
+
+from geometrics_amd.utils import (Plane, adj_init, batch_calc_edge, batch_get_lap_info,  # noqa: E402,F401
+                                  batch_point_to_point, batch_point_to_surface, batch_sample, calc_adj,
+                                  calc_point_to_line, chamfer_dist, edge, normalize_adj, tri_dist)
