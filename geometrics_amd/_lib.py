@@ -35,8 +35,11 @@ _SIGNATURES = {
     "geom_p2tri_loss_fwd_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "geom_p2tri_loss_bwd_f32": [_i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp],
     "geom_sum_f32": [ctypes.c_int64, _vp, _f, _vp, _vp],
+    "geom_sum2_f32": [ctypes.c_int64, _vp, _f, ctypes.c_int64, _vp, _f, _vp, _vp],
+    "geom_sample_chamfer_bwd_f32": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _f, _vp, _vp],
+    "geom_adam_step_f32": [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _vp],
     "geom_zn_gcn_aggregate_fwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
-    "geom_zn_gcn_aggregate_bwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "geom_zn_gcn_aggregate_bwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
 }
 
 
@@ -67,6 +70,8 @@ def lib():
         if L.geom_abi_version() != ABI_VERSION:
             raise RuntimeError("geometrics_amd: libgeom_hip.so ABI %d != binding ABI %d; rebuild"
                                % (L.geom_abi_version(), ABI_VERSION))
+        L.geom_zn_gcn_bwd_scratch_floats.restype = ctypes.c_int64
+        L.geom_zn_gcn_bwd_scratch_floats.argtypes = [_i, _i, _i]
         L.geom_tri_distance_workspace_bytes.restype = ctypes.c_size_t
         L.geom_tri_distance_workspace_bytes.argtypes = [_i, _i]
         for name, args in _SIGNATURES.items():
@@ -78,7 +83,8 @@ def lib():
 
 
 def declared_symbols():
-    return sorted(["geom_abi_version", "geom_strerror", "geom_tri_distance_workspace_bytes"] + list(_SIGNATURES))
+    return sorted(["geom_abi_version", "geom_strerror", "geom_tri_distance_workspace_bytes",
+                   "geom_zn_gcn_bwd_scratch_floats"] + list(_SIGNATURES))
 
 
 def check(code, what):

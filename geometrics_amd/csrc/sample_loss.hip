@@ -93,6 +93,40 @@ __global__ __launch_bounds__(PT_THREADS) void sample_bwd_kernel(SampleArgs a, co
     atomic_add3(G + 3 * a.faces[3 * f + 2], g * (u * v));
 }
 
+// Fused backward of  coef * sum |dst[idx] - src|^2  THROUGH the sampling: the gradient of a sampled
+// point never exists in memory, it is scattered straight into grad_verts with the point's
+// barycentric weights (what autograd does in the reference through utils.py:615-631 + 454-462).
+//   via_nn == 0: thread t is sampled point t;            diff = point[t]  - other[idx[t]]
+//   via_nn == 1: thread t is a point of `other`;         diff = point[si] - other[t],  si = idx[t]
+//                (the second Chamfer direction of batch_point_to_point, utils.py:417)
+__global__ __launch_bounds__(PT_THREADS) void sample_chamfer_bwd_kernel(SampleArgs a, const float *points,
+                                                                         int n_other, const float *other,
+                                                                         const int *idx, int via_nn,
+                                                                         const float *coef_dev, float coef_host,
+                                                                         float *grad_verts)
+{
+    const int count = via_nn ? n_other : a.num;
+    const int64_t i = (int64_t)blockIdx.x * PT_THREADS + threadIdx.x;
+    if (i >= (int64_t)a.b * count) return;
+    const int mesh = (int)(i / count);
+    const float coef = 2.f * coef_host * (coef_dev ? coef_dev[0] : 1.f);
+    int64_t si, oi; // sampled point / other point (flattened over the batch)
+    if (via_nn) {
+        si = (int64_t)mesh * a.num + idx[i];
+        oi = i;
+    } else {
+        si = i;
+        oi = (int64_t)mesh * n_other + idx[i];
+    }
+    const V3 g = (ld3(points + 3 * si) - ld3(other + 3 * oi)) * coef;
+    const int64_t f = a.choices[si];
+    const float u = a.u[si], v = a.v[si];
+    float *G = grad_verts + (size_t)mesh * a.nv * 3;
+    atomic_add3(G + 3 * a.faces[3 * f + 0], g * (1.f - u));
+    atomic_add3(G + 3 * a.faces[3 * f + 1], g * (u * (1.f - v)));
+    atomic_add3(G + 3 * a.faces[3 * f + 2], g * (u * v));
+}
+
 // ------------------------------------------------------- Chamfer gather loss ----
 // d/dsrc, d/ddst of  sum_j |dst[idx[j]] - src[j]|^2  scaled by coef (utils.py:416-417, 462).
 __global__ __launch_bounds__(PT_THREADS) void chamfer_grad_kernel(int b, int n, const float *src, int m,
@@ -241,6 +275,35 @@ __global__ __launch_bounds__(SUM_THREADS) void sum_kernel(int64_t n, const float
     }
 }
 
+// out[0] = s1 * sum(x1) + s2 * sum(x2): the whole  (dist_1 + dist_2) * 3000  of utils.py:420/484
+// in one launch, same fixed reduction tree per segment.
+__global__ __launch_bounds__(SUM_THREADS) void sum2_kernel(int64_t n1, const float *x1, float s1, int64_t n2,
+                                                            const float *x2, float s2, float *out)
+{
+    __shared__ float partial[2][SUM_THREADS / GEOM_WAVE];
+    float a1 = 0.f, a2 = 0.f;
+    for (int64_t i = threadIdx.x; i < n1; i += SUM_THREADS) a1 += x1[i];
+    for (int64_t i = threadIdx.x; i < n2; i += SUM_THREADS) a2 += x2[i];
+    for (int off = GEOM_WAVE / 2; off > 0; off >>= 1) {
+        a1 += __shfl_down(a1, off, GEOM_WAVE);
+        a2 += __shfl_down(a2, off, GEOM_WAVE);
+    }
+    if ((threadIdx.x & (GEOM_WAVE - 1)) == 0) {
+        partial[0][threadIdx.x >> 6] = a1;
+        partial[1][threadIdx.x >> 6] = a2;
+    }
+    __syncthreads();
+    if (threadIdx.x < GEOM_WAVE) {
+        float v1 = threadIdx.x < SUM_THREADS / GEOM_WAVE ? partial[0][threadIdx.x] : 0.f;
+        float v2 = threadIdx.x < SUM_THREADS / GEOM_WAVE ? partial[1][threadIdx.x] : 0.f;
+        for (int off = GEOM_WAVE / 2; off > 0; off >>= 1) {
+            v1 += __shfl_down(v1, off, GEOM_WAVE);
+            v2 += __shfl_down(v2, off, GEOM_WAVE);
+        }
+        if (threadIdx.x == 0) out[0] = v1 * s1 + v2 * s2;
+    }
+}
+
 inline dim3 pt_grid(int64_t count) { return dim3((unsigned)((count + PT_THREADS - 1) / PT_THREADS)); }
 
 } // namespace
@@ -325,5 +388,31 @@ extern "C" int geom_sum_f32(int64_t n, const float *x, float scale, float *out, 
 {
     if (n < 0 || !out || (n > 0 && !x)) return GEOM_EINVAL;
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(SUM_THREADS), 0, static_cast<hipStream_t>(stream), n, x, scale, out);
+    return geom::launch_status();
+}
+
+extern "C" int geom_sample_chamfer_bwd_f32(int b, int nv, int nf, const int64_t *faces, int num,
+                                           const int64_t *choices, const float *u, const float *v,
+                                           const float *points, int n_other, const float *other,
+                                           const int *idx, int via_nn, const float *coef_dev, float coef_host,
+                                           float *grad_verts, void *stream)
+{
+    if (b < 0 || nv < 0 || nf < 0 || num < 0 || n_other < 0) return GEOM_EINVAL;
+    const int count = via_nn ? n_other : num;
+    if (b == 0 || count == 0) return 0;
+    if (!faces || !choices || !u || !v || !points || !other || !idx || !grad_verts) return GEOM_EINVAL;
+    SampleArgs a{nullptr, faces, choices, u, v, b, nv, nf, num};
+    hipLaunchKernelGGL(sample_chamfer_bwd_kernel, pt_grid((int64_t)b * count), dim3(PT_THREADS), 0,
+                       static_cast<hipStream_t>(stream), a, points, n_other, other, idx, via_nn, coef_dev, coef_host,
+                       grad_verts);
+    return geom::launch_status();
+}
+
+extern "C" int geom_sum2_f32(int64_t n1, const float *x1, float scale1, int64_t n2, const float *x2, float scale2,
+                             float *out, void *stream)
+{
+    if (n1 < 0 || n2 < 0 || !out || (n1 > 0 && !x1) || (n2 > 0 && !x2)) return GEOM_EINVAL;
+    hipLaunchKernelGGL(sum2_kernel, dim3(1), dim3(SUM_THREADS), 0, static_cast<hipStream_t>(stream), n1, x1, scale1, n2,
+                       x2, scale2, out);
     return geom::launch_status();
 }

@@ -66,83 +66,192 @@ struct Pack<1> {
     __device__ __forceinline__ float &at(int) { return v; }
 };
 
-template <int VEC, int ACT, bool BACKWARD>
-__global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_kernel(GcnArgs a)
-{
-    const int groups = a.c / VEC;
-    const int64_t tid = (int64_t)blockIdx.x * GCN_THREADS + threadIdx.x;
-    if (tid >= a.rows * groups) return;
-    const int64_t row = tid / groups;
-    const int g = (int)(tid - row * groups);
-    const int c0 = g * VEC;
-    const int64_t mesh_row0 = (row / a.nv) * a.nv; // first row of this mesh
-    const int r = (int)(row - mesh_row0);
+// Thread layout: a block owns `rows_per_block` consecutive rows of ONE mesh; thread t owns column group
+// (t % groups) for rows (t / groups), (t / groups) + rows_in_flight, ...  so that
+//   * a wave reads/writes contiguous runs of a row (coalesced),
+//   * a thread's column group is FIXED, which lets the backward kernel accumulate the bias
+//     gradient (column sums of g) in registers and emit one partial per block -- reduced by a
+//     second tiny kernel in a fixed order (deterministic, no atomics).
+// Neighbour gathers are issued in batches of NB: first all (col, val) pairs of the batch, then
+// all neighbour rows, so a row costs two memory round trips instead of two per neighbour.
+constexpr int GCN_NB = 8;         // neighbours fetched per batch
+constexpr int GCN_BWD_ITERS = 2;  // rows per thread in the backward (halves the bias-gradient partials)
 
-    Pack<VEC> acc;
-    if (c0 < a.k) {
+template <int VEC, int ACT, bool BACKWARD>
+__global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_kernel(GcnArgs a, int groups, int rows_in_flight,
+                                                                    int rows_per_block, float *colsum_partial)
+{
+    extern __shared__ float lds_colsum[]; // [rows_in_flight][c], backward with colsum only
+    const int g = threadIdx.x % groups;
+    const int rl = threadIdx.x / groups;
+    const int c0 = g * VEC;
+    const bool active = rl < rows_in_flight;
+    // grid = (row chunks of one mesh, meshes): no integer division on the row index
+    const int r_begin = blockIdx.x * rows_per_block;
+    const int r_end = min(r_begin + rows_per_block, a.nv);
+    const int64_t mesh_row0 = (int64_t)blockIdx.y * a.nv; // first row of this mesh
+
+    Pack<VEC> colsum;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc.at(i) = 0.f;
-        const int e0 = a.rowptr[r], e1 = a.rowptr[r + 1];
-        for (int e = e0; e < e1; ++e) {
-            const int64_t nb = mesh_row0 + a.col[e];
-            const float w = a.val[e];
-            Pack<VEC> s;
-            s.load(a.x + nb * a.c + c0);
-            if (BACKWARD && ACT != ACT_NONE) {
-                Pack<VEC> o;
-                o.load(a.saved + nb * a.c + c0);
+    for (int i = 0; i < VEC; ++i) colsum.at(i) = 0.f;
+
+    if (active) {
+        for (int r = r_begin + rl; r < r_end; r += rows_in_flight) {
+            const int64_t row = mesh_row0 + r;
+            Pack<VEC> acc, own;
+            if (BACKWARD || c0 >= a.k) { // the thread's own element: pass-through value and/or bias-gradient term
+                own.load(a.x + row * a.c + c0);
+                if (BACKWARD && ACT != ACT_NONE) {
+                    Pack<VEC> o;
+                    o.load(a.saved + row * a.c + c0);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) s.at(i) = act_bwd<ACT>(s.at(i), o.at(i));
+                    for (int i = 0; i < VEC; ++i) own.at(i) = act_bwd<ACT>(own.at(i), o.at(i));
+                }
             }
+            if (c0 < a.k) {
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) acc.at(i) += w * s.at(i);
-        }
-    } else {
-        acc.load(a.x + row * a.c + c0);
-        if (BACKWARD && ACT != ACT_NONE) {
-            Pack<VEC> o;
-            o.load(a.saved + row * a.c + c0);
+                for (int i = 0; i < VEC; ++i) acc.at(i) = 0.f;
+                const int e1 = a.rowptr[r + 1];
+                for (int e = a.rowptr[r]; e < e1; e += GCN_NB) {
+                    int64_t nb[GCN_NB];
+                    float w[GCN_NB];
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) acc.at(i) = act_bwd<ACT>(acc.at(i), o.at(i));
+                    for (int j = 0; j < GCN_NB; ++j) {
+                        const bool in = e + j < e1;
+                        nb[j] = in ? mesh_row0 + a.col[e + j] : row;
+                        w[j] = in ? a.val[e + j] : 0.f;
+                    }
+                    Pack<VEC> sv[GCN_NB], ov[GCN_NB];
+#pragma unroll
+                    for (int j = 0; j < GCN_NB; ++j) {
+                        sv[j].load(a.x + nb[j] * a.c + c0);
+                        if (BACKWARD && ACT != ACT_NONE) ov[j].load(a.saved + nb[j] * a.c + c0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < GCN_NB; ++j) {
+                        if (e + j < e1) { // keep the CSR order of the sum; padded slots contribute nothing
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) {
+                                float v = sv[j].at(i);
+                                if (BACKWARD && ACT != ACT_NONE) v = act_bwd<ACT>(v, ov[j].at(i));
+                                acc.at(i) += w[j] * v;
+                            }
+                        }
+                    }
+                }
+            } else {
+                acc = own;
+            }
+            if (BACKWARD) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) colsum.at(i) += own.at(i);
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    float v = acc.at(i);
+                    if (a.bias) v += a.bias[c0 + i];
+                    acc.at(i) = act_fwd<ACT>(v);
+                }
+            }
+            acc.store(a.y + row * a.c + c0);
         }
     }
-    if (!BACKWARD) {
+
+    if (BACKWARD && colsum_partial) { // block partial of the bias gradient, fixed summation order
+        if (active) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            float v = acc.at(i);
-            if (a.bias) v += a.bias[c0 + i];
-            acc.at(i) = act_fwd<ACT>(v);
+            for (int i = 0; i < VEC; ++i) lds_colsum[rl * a.c + c0 + i] = colsum.at(i);
+        }
+        __syncthreads();
+        if (active && rl == 0) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float t = 0.f;
+                for (int l = 0; l < rows_in_flight; ++l) t += lds_colsum[l * a.c + c0 + i];
+                colsum_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * a.c + c0 + i] = t;
+            }
         }
     }
-    acc.store(a.y + row * a.c + c0);
 }
 
-template <int VEC, bool BACKWARD>
-int launch(const GcnArgs &a, int act, void *stream)
+// grad_bias[c] = sum over blocks of partial[blk][c].  16 columns x 64 block-lanes per workgroup:
+// lane l adds blocks l, l+64, ... (independent loads, pipelined), then the 64 lane sums are added
+// in ascending lane order -- a fixed tree, so the result is bit-reproducible.
+constexpr int CS_COLS = 16, CS_LANES = 64;
+__global__ __launch_bounds__(CS_COLS *CS_LANES) void colsum_final_kernel(int blocks, int c, const float *partial,
+                                                                         float *out)
 {
-    const int64_t threads = a.rows * (a.c / VEC);
-    dim3 grid((unsigned)((threads + GCN_THREADS - 1) / GCN_THREADS)), block(GCN_THREADS);
+    __shared__ float part[CS_LANES][CS_COLS];
+    const int cl = threadIdx.x % CS_COLS, lane = threadIdx.x / CS_COLS;
+    const int col = blockIdx.x * CS_COLS + cl;
+    float t = 0.f;
+    if (col < c)
+        for (int b = lane; b < blocks; b += CS_LANES) t += partial[(size_t)b * c + col];
+    part[lane][cl] = t;
+    __syncthreads();
+    if (lane == 0 && col < c) {
+        float acc = 0.f;
+        for (int l = 0; l < CS_LANES; ++l) acc += part[l][cl];
+        out[col] = acc;
+    }
+}
+
+struct GcnGeometry {
+    int groups, rows_in_flight, rows_per_block;
+    int chunks;     // blocks per mesh (grid.x)
+    int64_t blocks; // chunks * meshes
+};
+
+inline GcnGeometry gcn_geometry(int b, int nv, int c, int vec, bool backward)
+{
+    GcnGeometry g;
+    g.groups = c / vec;
+    g.rows_in_flight = g.groups >= GCN_THREADS ? 1 : GCN_THREADS / g.groups;
+    g.rows_per_block = g.rows_in_flight * (backward ? GCN_BWD_ITERS : 1);
+    g.chunks = (nv + g.rows_per_block - 1) / g.rows_per_block;
+    g.blocks = (int64_t)g.chunks * b;
+    return g;
+}
+
+inline bool gcn_vec4(int c, int k) { return (c % 4 == 0) && (k % 4 == 0); }
+
+template <int VEC, bool BACKWARD>
+int launch(const GcnArgs &a, int act, float *colsum_partial, float *grad_bias, void *stream)
+{
+    const int meshes = (int)(a.rows / a.nv);
+    const GcnGeometry geo = gcn_geometry(meshes, a.nv, a.c, VEC, BACKWARD);
+    if (geo.groups > GCN_THREADS) return GEOM_ETOOBIG; // > 1024 channels (VEC=4): not a 0N-GCN shape
+    if (meshes > 65535 || geo.blocks > 0x7fffffffLL) return GEOM_ETOOBIG;
+    dim3 grid((unsigned)geo.chunks, (unsigned)meshes), block(GCN_THREADS);
+    const size_t lds = (BACKWARD && colsum_partial) ? (size_t)geo.rows_in_flight * a.c * sizeof(float) : 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (act) {
-    case ACT_NONE: hipLaunchKernelGGL((zn_aggregate_kernel<VEC, ACT_NONE, BACKWARD>), grid, block, 0, s, a); break;
-    case ACT_RELU: hipLaunchKernelGGL((zn_aggregate_kernel<VEC, ACT_RELU, BACKWARD>), grid, block, 0, s, a); break;
-    case ACT_ELU: hipLaunchKernelGGL((zn_aggregate_kernel<VEC, ACT_ELU, BACKWARD>), grid, block, 0, s, a); break;
+    case ACT_NONE: hipLaunchKernelGGL((zn_aggregate_kernel<VEC, ACT_NONE, BACKWARD>), grid, block, lds, s, a, geo.groups, geo.rows_in_flight, geo.rows_per_block, colsum_partial); break;
+    case ACT_RELU: hipLaunchKernelGGL((zn_aggregate_kernel<VEC, ACT_RELU, BACKWARD>), grid, block, lds, s, a, geo.groups, geo.rows_in_flight, geo.rows_per_block, colsum_partial); break;
+    case ACT_ELU: hipLaunchKernelGGL((zn_aggregate_kernel<VEC, ACT_ELU, BACKWARD>), grid, block, lds, s, a, geo.groups, geo.rows_in_flight, geo.rows_per_block, colsum_partial); break;
     default: return GEOM_EINVAL;
     }
+    if (BACKWARD && colsum_partial)
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((a.c + CS_COLS - 1) / CS_COLS), dim3(CS_COLS * CS_LANES), 0, s,
+                           (int)geo.blocks, a.c, colsum_partial, grad_bias);
     return geom::launch_status();
 }
 
 template <bool BACKWARD>
-int dispatch(GcnArgs a, int b, int act, void *stream)
+int dispatch(GcnArgs a, int b, int act, float *grad_bias, float *scratch, void *stream)
 {
     if (b < 0 || a.nv < 0 || a.c < 0 || a.k < 0 || a.k > a.c) return GEOM_EINVAL;
     if (b == 0 || a.nv == 0 || a.c == 0) return 0;
     if (!a.rowptr || !a.x || !a.y || (a.k > 0 && (!a.col || !a.val))) return GEOM_EINVAL;
     if (BACKWARD && act != ACT_NONE && !a.saved) return GEOM_EINVAL;
+    if (grad_bias && !scratch) return GEOM_EINVAL;
     a.rows = (int64_t)b * a.nv;
-    const bool vec4 = (a.c % 4 == 0) && (a.k % 4 == 0) && (((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.saved) % 16 == 0);
-    if ((a.rows * (vec4 ? a.c / 4 : a.c) + GCN_THREADS - 1) / GCN_THREADS > 0x7fffffffLL) return GEOM_ETOOBIG;
-    return vec4 ? launch<4, BACKWARD>(a, act, stream) : launch<1, BACKWARD>(a, act, stream);
+    if (gcn_vec4(a.c, a.k) && (((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.saved) % 16 != 0))
+        return GEOM_EINVAL; // row-major fp32 tensors from any allocator are 16-byte aligned; refuse odd views
+    const bool vec4 = gcn_vec4(a.c, a.k);
+    float *partial = grad_bias ? scratch : nullptr;
+    if (!vec4 && a.c > GCN_THREADS) return GEOM_ETOOBIG;
+    return vec4 ? launch<4, BACKWARD>(a, act, partial, grad_bias, stream) : launch<1, BACKWARD>(a, act, partial, grad_bias, stream);
 }
 
 } // namespace
@@ -152,13 +261,23 @@ extern "C" int geom_zn_gcn_aggregate_fwd_f32(int b, int nv, int c, int k, const 
                                              int act, float *out, void *stream)
 {
     GcnArgs a{rowptr, col, val, support, bias, nullptr, out, 0, nv, c, k};
-    return dispatch<false>(a, b, act, stream);
+    return dispatch<false>(a, b, act, nullptr, nullptr, stream);
+}
+
+extern "C" int64_t geom_zn_gcn_bwd_scratch_floats(int b, int nv, int c)
+{
+    if (b <= 0 || nv <= 0 || c <= 0) return 0;
+    // upper bound over both vector widths (k is not known here): the scalar layout has fewer rows per block
+    const int64_t b4 = (c % 4 == 0) ? gcn_geometry(b, nv, c, 4, true).blocks : 0;
+    const int64_t b1 = gcn_geometry(b, nv, c, 1, true).blocks;
+    return (b4 > b1 ? b4 : b1) * c;
 }
 
 extern "C" int geom_zn_gcn_aggregate_bwd_f32(int b, int nv, int c, int k, const int *rowptrT, const int *colT,
                                              const float *valT, const float *grad_out, const float *out,
-                                             int act, float *grad_support, void *stream)
+                                             int act, float *grad_support, float *grad_bias, float *scratch,
+                                             void *stream)
 {
     GcnArgs a{rowptrT, colT, valT, grad_out, nullptr, out, grad_support, 0, nv, c, k};
-    return dispatch<true>(a, b, act, stream);
+    return dispatch<true>(a, b, act, grad_bias, scratch, stream);
 }

@@ -51,27 +51,24 @@ def global_mean_loss(local_loss_sum, local_count):
 
 
 class GradBucket:
-    """One flat fp32 buffer aliasing every parameter's .grad, so the DP gradient average is a
-    single all-reduce (no per-parameter launches, no copies in or out)."""
+    """One flat fp32 buffer for the DP gradient exchange.  Autograd leaves a fresh .grad on every
+    parameter (no accumulate kernels); `pack_all_reduce()` copies them into the flat buffer with
+    one launch, sums it across ranks with ONE all-reduce, and returns per-parameter views of the
+    reduced buffer (the caller applies the 1/world scale inside the optimiser kernel)."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
         ref = self.params[0]
-        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
-        off = 0
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=ref.dtype, device=ref.device)
+        self.views, off = [], 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
 
-    def zero_(self):
-        self.flat.zero_()
-
-    def all_reduce_mean_(self):
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(dist.get_world_size())
-        return self.flat
+    def pack_all_reduce(self):
+        torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
+        all_reduce_sum_(self.flat)
+        return self.views
 
 
 def barrier():

@@ -11,6 +11,7 @@ the tensor's identity + version) and replaces the reference's dense `adj @ suppo
 import math
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 from torch.nn import Module
 from torch.nn.parameter import Parameter
@@ -63,11 +64,22 @@ def adjacency_csr(adj):
 
 
 # ------------------------------------------------------- fused aggregation ----
+def _activation_code(activation):
+    """ReLU / ELU(alpha=1) are folded into the kernel epilogue (and their derivative into the
+    backward read); any other callable is applied by the caller after an un-activated kernel."""
+    if activation is F.relu or activation is torch.relu:
+        return _ACT_RELU
+    if activation is F.elu:
+        return _ACT_ELU
+    return _ACT_NONE
+
+
 class _ZeroNAggregate(torch.autograd.Function):
-    """out = [A . S[..., :k] | S[..., k:]] + bias  for S [B,V,C] (one kernel, S read once)."""
+    """out = act([A . S[..., :k] | S[..., k:]] + bias)  for S [B,V,C]: one kernel, S read once.
+    Backward: grad_S = [A^T . g[..., :k] | g[..., k:]] with g = grad_out * act'(out), again one kernel."""
 
     @staticmethod
-    def forward(ctx, support, bias, csr, k):
+    def forward(ctx, support, bias, csr, k, act):
         s = _lib.require(support, "support", torch.float32, 3)
         b, nv, c = s.shape
         if nv != csr.nv:
@@ -76,32 +88,44 @@ class _ZeroNAggregate(torch.autograd.Function):
         out = torch.empty_like(s)
         with torch.cuda.device(s.device):
             _lib.call("geom_zn_gcn_aggregate_fwd_f32", b, nv, c, k, csr.rowptr.data_ptr(), csr.col.data_ptr(),
-                      csr.val.data_ptr(), s.data_ptr(), _lib.ptr(bias_c), _ACT_NONE, out.data_ptr())
-        ctx.csr, ctx.k, ctx.has_bias = csr, k, bias is not None
+                      csr.val.data_ptr(), s.data_ptr(), _lib.ptr(bias_c), act, out.data_ptr())
+        ctx.csr, ctx.k, ctx.act, ctx.has_bias = csr, k, act, bias is not None
+        if act != _ACT_NONE:
+            ctx.save_for_backward(out)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         g = grad_out.contiguous()
         b, nv, c = g.shape
-        csr = ctx.csr
-        grad_support = None
-        if ctx.needs_input_grad[0]:
-            grad_support = torch.empty_like(g)
-            with torch.cuda.device(g.device):
-                _lib.call("geom_zn_gcn_aggregate_bwd_f32", b, nv, c, ctx.k, csr.rowptr_t.data_ptr(),
-                          csr.col_t.data_ptr(), csr.val_t.data_ptr(), g.data_ptr(), None, _ACT_NONE,
-                          grad_support.data_ptr())
-        grad_bias = g.sum(dim=(0, 1)) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
-        return grad_support, grad_bias, None, None
+        csr, act = ctx.csr, ctx.act
+        out = ctx.saved_tensors[0] if act != _ACT_NONE else None
+        want_bias = ctx.has_bias and ctx.needs_input_grad[1]
+        grad_support = torch.empty_like(g)
+        grad_bias = scratch = None
+        if want_bias:   # column sums of g come out of the same kernel (per-block partials + fixed-order reduce)
+            grad_bias = torch.empty(c, dtype=torch.float32, device=g.device)
+            scratch = torch.empty(_lib.lib().geom_zn_gcn_bwd_scratch_floats(b, nv, c), dtype=torch.float32,
+                                  device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.call("geom_zn_gcn_aggregate_bwd_f32", b, nv, c, ctx.k, csr.rowptr_t.data_ptr(),
+                      csr.col_t.data_ptr(), csr.val_t.data_ptr(), g.data_ptr(), _lib.ptr(out), act,
+                      grad_support.data_ptr(), _lib.ptr(grad_bias), _lib.ptr(scratch))
+        return (grad_support if ctx.needs_input_grad[0] else None), grad_bias, None, None, None
 
 
-def zero_n_aggregate(support, adj, bias, k):
-    """Shared tail of every 0N-GCN layer; accepts [V,C] or [B,V,C] support."""
+def zero_n_aggregate(support, adj, bias, k, activation=None):
+    """Shared tail of every 0N-GCN layer; accepts [V,C] or [B,V,C] support.  Returns the
+    ACTIVATED output when `activation` is given (fused for relu / elu)."""
     csr = adjacency_csr(adj)
+    act = _ACT_NONE if activation is None else _activation_code(activation)
+    s3 = support.unsqueeze(0) if support.dim() == 2 else support
+    out = _ZeroNAggregate.apply(s3, bias, csr, k, act)
     if support.dim() == 2:
-        return _ZeroNAggregate.apply(support.unsqueeze(0), bias, csr, k).squeeze(0)
-    return _ZeroNAggregate.apply(support, bias, csr, k)
+        out = out.squeeze(0)
+    if activation is not None and act == _ACT_NONE:
+        out = activation(out)
+    return out
 
 
 def _uniform(t, bound):
@@ -121,8 +145,7 @@ class _ZeroNBase(Module):
         if w.dim() == 3:            # [1,Cin,Cout]: fold the batch into one GEMM instead of B broadcast bmm's
             w = w.squeeze(0)
         support = torch.matmul(input, w)
-        out = zero_n_aggregate(support, adj, self.bias, support.shape[-1] // self.split)
-        return activation(out)
+        return zero_n_aggregate(support, adj, self.bias, support.shape[-1] // self.split, activation)
 
 
 class ZERON_GCN(_ZeroNBase):
@@ -198,7 +221,8 @@ class GCNMax(_MaxPoolBase):
     """Unbatched: max over vertices of activation(v) (reference layers.py:43-79)."""
 
     def forward(self, r_s, adj, activation):
-        return torch.max(activation(self._pre_activation(r_s, adj)), dim=0)[0]
+        support = torch.matmul(r_s, self.weight_Ws[0])
+        return torch.max(zero_n_aggregate(support, adj, self.weight_Bs[0], support.shape[-1] // 10, activation), dim=0)[0]
 
 
 class BatchGCNMax(_MaxPoolBase):

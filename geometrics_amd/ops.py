@@ -132,6 +132,121 @@ class PointToTriangleSum(torch.autograd.Function):
         return None, grad_verts, None, None, None
 
 
+class SurfaceLoss(torch.autograd.Function):
+    """The whole sampled-surface loss of the reference in one autograd node.
+
+      two_sided=False  batch_point_to_surface (utils.py:441-502):
+            3000 * ( mean_s |gt[nn(s)] - pred_s|^2  +  mean_g |closest_on_mesh(g) - g|^2 )
+      two_sided=True   batch_point_to_point (utils.py:393-438):
+            3000 * ( mean_s |gt[nn(s)] - pred_s|^2  +  mean_g |pred[nn(g)] - g|^2 )
+
+    Forward: sample -> NN (both directions) -> [tri scan -> closest point] -> one two-segment sum.
+    Backward: ONE zero-fill of grad_verts, then every term scatters into it (the gradient of the
+    sampled points is never materialised).  Returns (loss, sq_gt, sq_pred); the squared NN
+    distances feed the F1 score and are not differentiable."""
+
+    @staticmethod
+    def forward(ctx, verts, faces, gt, choices, u, v, two_sided, scale):
+        verts_c = _f32(verts.detach(), "verts", 3, 3)
+        gt_c = _f32(gt.detach(), "gt_points", 3, 3)
+        faces = _lib.require(faces, "faces", torch.int64, 2, 3)
+        b, nv, _ = verts_c.shape
+        choices = _lib.require(choices.reshape(b, -1), "choices", torch.int64, 2)
+        u = _f32(u.reshape(b, -1), "u", 2)
+        v = _f32(v.reshape(b, -1), "v", 2)
+        num, n_gt, nf, dev = choices.shape[1], gt_c.shape[1], faces.shape[0], verts_c.device
+        if gt_c.shape[0] != b:
+            raise RuntimeError("gt_points and verts batch sizes differ")
+        L = _lib.lib()
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        # every buffer is allocated on the calling stream BEFORE the fork below
+        points = torch.empty(b, num, 3, **f32)
+        out = torch.empty((), **f32)
+        sq_gt, sq_pred = torch.empty(b, n_gt, **f32), torch.empty(b, num, **f32)
+        idx_p, idx_g = torch.empty(b, n_gt, **i32), torch.empty(b, num, **i32)
+        if not two_sided:
+            ws_bytes = L.geom_tri_distance_workspace_bytes(b, nf)
+            ws = torch.empty(max(ws_bytes, 16) // 4, **f32)
+            tri_d, option, index = torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, **i32), torch.empty(b, n_gt, **i32)
+            sq, closest, weights = torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, 3, **f32), torch.empty(b, n_gt, 3, **f32)
+        with torch.cuda.device(dev):
+            main = torch.cuda.current_stream()
+            if not two_sided:
+                # the tri branch depends only on (gt, verts): run it beside sampling + NN on a second
+                # stream (a parallel branch of the captured HIP graph); both are far too small to
+                # fill 256 CUs alone at a per-GPU shard of a few meshes
+                side = _side_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    _lib.check(L.geom_tri_distance_indexed_ws_f32(
+                        b, n_gt, gt_c.data_ptr(), nv, verts_c.data_ptr(), nf, faces.data_ptr(), tri_d.data_ptr(),
+                        option.data_ptr(), index.data_ptr(), 0, ws.data_ptr(), ws_bytes, _lib.stream_ptr()),
+                        "geom_tri_distance_indexed_ws_f32")
+                    _lib.call("geom_p2tri_loss_fwd_f32", b, n_gt, gt_c.data_ptr(), nv, verts_c.data_ptr(), nf,
+                              faces.data_ptr(), option.data_ptr(), index.data_ptr(), sq.data_ptr(),
+                              closest.data_ptr(), weights.data_ptr())
+            _lib.call("geom_sample_faces_fwd_f32", b, nv, verts_c.data_ptr(), nf, faces.data_ptr(), num,
+                      choices.data_ptr(), u.data_ptr(), v.data_ptr(), points.data_ptr())
+            _lib.check(L.geom_chamfer_nn_f32(b, n_gt, gt_c.data_ptr(), num, points.data_ptr(), sq_gt.data_ptr(),
+                                             idx_p.data_ptr(), sq_pred.data_ptr(), idx_g.data_ptr(), 0,
+                                             _lib.stream_ptr()), "geom_chamfer_nn_f32")
+            if two_sided:
+                _lib.call("geom_sum2_f32", sq_pred.numel(), sq_pred.data_ptr(), scale / sq_pred.numel(),
+                          sq_gt.numel(), sq_gt.data_ptr(), scale / sq_gt.numel(), out.data_ptr())
+                ctx.save_for_backward(faces, choices, u, v, points, gt_c, idx_g, idx_p)
+            else:
+                main.wait_stream(side)
+                _lib.call("geom_sum2_f32", sq_pred.numel(), sq_pred.data_ptr(), scale / sq_pred.numel(),
+                          sq.numel(), sq.data_ptr(), scale / sq.numel(), out.data_ptr())
+                ctx.save_for_backward(faces, choices, u, v, points, gt_c, idx_g, index, closest, weights)
+        ctx.two_sided, ctx.scale, ctx.nv = two_sided, scale, nv
+        ctx.mark_non_differentiable(sq_gt, sq_pred)
+        return out, sq_gt, sq_pred
+
+    @staticmethod
+    def backward(ctx, grad, _g1, _g2):
+        saved = ctx.saved_tensors
+        faces, choices, u, v, points, gt = saved[:6]
+        b, num, _ = points.shape
+        n_gt, nf, nv = gt.shape[1], faces.shape[0], ctx.nv
+        dev = points.device
+        grad = grad.contiguous()
+        grad_verts = torch.zeros(b, nv, 3, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            main = torch.cuda.current_stream()
+            sample_args = (b, nv, nf, faces.data_ptr(), num, choices.data_ptr(), u.data_ptr(), v.data_ptr(),
+                           points.data_ptr(), n_gt, gt.data_ptr())
+            if not ctx.two_sided:   # both terms scatter (atomics) into the same zeroed buffer, concurrently
+                index, closest, weights = saved[7:10]
+                side = _side_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    _lib.call("geom_p2tri_loss_bwd_f32", b, n_gt, gt.data_ptr(), nv, nf, faces.data_ptr(),
+                              index.data_ptr(), closest.data_ptr(), weights.data_ptr(), grad.data_ptr(),
+                              ctx.scale / (b * n_gt), grad_verts.data_ptr())
+            _lib.call("geom_sample_chamfer_bwd_f32", *sample_args, saved[6].data_ptr(), 0, grad.data_ptr(),
+                      ctx.scale / (b * num), grad_verts.data_ptr())
+            if ctx.two_sided:
+                _lib.call("geom_sample_chamfer_bwd_f32", *sample_args, saved[7].data_ptr(), 1, grad.data_ptr(),
+                          ctx.scale / (b * n_gt), grad_verts.data_ptr())
+            else:
+                main.wait_stream(side)
+        return grad_verts, None, None, None, None, None, None, None
+
+
+_side_streams = {}
+
+
+def _side_stream(dev):
+    """One auxiliary stream per device for the independent branch of the fused loss."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def draw_samples(verts, faces, num, generator=None):
     """The random part of batch_sample (reference utils.py:604-612, 627-628) in three batched
     calls instead of a python loop of B multinomials: choices [B,num] ~ area-weighted with
@@ -142,5 +257,6 @@ def draw_samples(verts, faces, num, generator=None):
     return choices, torch.sqrt(uv[0]), uv[1]
 
 
-__all__ = ["face_areas", "device_sum", "SampleFaces", "GatherSqDistSum", "PointToTriangleSum", "draw_samples",
+__all__ = ["face_areas", "device_sum", "SampleFaces", "GatherSqDistSum", "PointToTriangleSum", "SurfaceLoss",
+           "draw_samples",
            "chamfer_nn", "tri_distance_indexed"]

@@ -74,38 +74,26 @@ def _f_score(sq_to_pred, sq_to_gt, num):
     return float(f.mean())
 
 
-def batch_point_to_point(pred_vert, adj_info, gt_points, num=1000, f1=False, draws=None):
-    """Two-sided Chamfer loss between sampled surface points and gt (reference utils.py:393-438)."""
-    pred_points = batch_sample(pred_vert, adj_info["faces"], num=num, draws=draws)
-    gt_points = gt_points.contiguous()
-    # idx_p[b,g] = nearest predicted point of each gt point, idx_g[b,s] = nearest gt point of each prediction
-    sq_gt, idx_p, sq_pred, idx_g = chamfer_nn(gt_points, pred_points)
-    n_pred = pred_points.shape[0] * pred_points.shape[1]
-    n_gt = gt_points.shape[0] * gt_points.shape[1]
-    dist_1 = ops.GatherSqDistSum.apply(pred_points, gt_points, idx_g, sq_pred) / n_pred
-    dist_2 = ops.GatherSqDistSum.apply(gt_points, pred_points, idx_p, sq_gt) / n_gt
-    loss = (dist_1 + dist_2) * LOSS_SCALE
+def _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, two_sided):
+    faces = adj_info["faces"]
+    if draws is None:
+        draws = ops.draw_samples(pred_vert, faces, num)
+    choices, u, v = draws
+    loss, sq_gt, sq_pred = ops.SurfaceLoss.apply(pred_vert, faces, gt_points, choices, u, v, two_sided, LOSS_SCALE)
     if f1:
         return loss, _f_score(sq_gt, sq_pred, num)
     return loss
+
+
+def batch_point_to_point(pred_vert, adj_info, gt_points, num=1000, f1=False, draws=None):
+    """Two-sided Chamfer loss between sampled surface points and gt (reference utils.py:393-438).
+    One fused autograd node (ops.SurfaceLoss); `draws` replays pre-drawn randoms."""
+    return _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, True)
 
 
 def batch_point_to_surface(pred_vert, adj_info, gt_points, num=1000, f1=False, draws=None):
     """Chamfer (prediction -> gt) + point-to-surface (gt -> mesh) loss (reference utils.py:441-502)."""
-    faces = adj_info["faces"]
-    pred_points = batch_sample(pred_vert, faces, num=num, draws=draws)
-    gt_points = gt_points.contiguous()
-    sq_gt, idx_p, sq_pred, idx_g = chamfer_nn(gt_points, pred_points)
-    n_pred = pred_points.shape[0] * pred_points.shape[1]
-    n_gt = gt_points.shape[0] * gt_points.shape[1]
-    dist_1 = ops.GatherSqDistSum.apply(pred_points, gt_points, idx_g, sq_pred) / n_pred
-
-    _, point_options, index = tri_distance_indexed(gt_points, pred_vert, faces)
-    dist_2 = ops.PointToTriangleSum.apply(gt_points, pred_vert, faces, point_options, index) / n_gt
-    loss = (dist_1 + dist_2) * LOSS_SCALE
-    if f1:
-        return loss, _f_score(sq_gt, sq_pred, num)
-    return loss
+    return _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, False)
 
 
 def calc_point_to_line(p, triangles, point_options):

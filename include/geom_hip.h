@@ -132,6 +132,21 @@ int geom_p2tri_loss_bwd_f32(int b, int n, const float *xyz, int nv, int nf, cons
 
 /* out[0] = scale * sum(x[0..n)) with a fixed reduction tree (bit-reproducible run to run). */
 int geom_sum_f32(int64_t n, const float *x, float scale, float *out, void *stream);
+/* out[0] = scale1*sum(x1) + scale2*sum(x2): the whole (dist_1 + dist_2) * 3000 of utils.py:420/484. */
+int geom_sum2_f32(int64_t n1, const float *x1, float scale1, int64_t n2, const float *x2, float scale2,
+                  float *out, void *stream);
+
+/* Fused backward of the Chamfer term THROUGH the sampling (utils.py:454-462 + 615-631 under autograd):
+ * the gradient 2*coef*(point - other) of a sampled point is scattered straight into grad_verts with
+ * the point's barycentric weights (fp32 atomics, caller zero-initialises), never materialised.
+ *   points [b,num,3] sampled points with their draws (choices,u,v) on faces; other [b,n_other,3].
+ *   via_nn == 0: one thread per sampled point t,  pair (t, idx[b,t])      idx [b,num]      -> into other
+ *   via_nn == 1: one thread per other point t,    pair (idx[b,t], t)      idx [b,n_other]  -> into points */
+int geom_sample_chamfer_bwd_f32(int b, int nv, int nf, const int64_t *faces, int num,
+                                const int64_t *choices, const float *u, const float *v,
+                                const float *points, int n_other, const float *other,
+                                const int *idx, int via_nn, const float *coef_dev, float coef_host,
+                                float *grad_verts, void *stream);
 
 /* ---- 0N-GCN aggregation (layers.py:34-41, 107-116, 143-152) -----------------------------------
  * out[r,:k] = sum_j val[j]*support[col[j],:k] over CSR row r (rowptr int32 [nv+1], col int32, val f32),
@@ -141,10 +156,25 @@ int geom_zn_gcn_aggregate_fwd_f32(int b, int nv, int c, int k, const int *rowptr
                                   const float *val, const float *support, const float *bias,
                                   int act, float *out, void *stream);
 /* grad_support[r,:k] = sum over CSR^T row r of valT*g[colT,:k]; grad_support[r,k:] = g[r,k:], where
- * g = grad_out * act'(out) when act != 0 (out = the saved forward output). */
+ * g = grad_out * act'(out) when act != 0 (out = the saved forward output, may be NULL when act == 0).
+ * grad_bias[c] (optional) = column sums of g, reduced in a fixed order (bit-reproducible); it needs
+ * `scratch` of at least geom_zn_gcn_bwd_scratch_floats(b, nv, c) floats. */
+int64_t geom_zn_gcn_bwd_scratch_floats(int b, int nv, int c);
 int geom_zn_gcn_aggregate_bwd_f32(int b, int nv, int c, int k, const int *rowptrT, const int *colT,
                                   const float *valT, const float *grad_out, const float *out,
-                                  int act, float *grad_support, void *stream);
+                                  int act, float *grad_support, float *grad_bias, float *scratch,
+                                  void *stream);
+
+/* ---- optimiser step for the replicated layer parameters (GEOMetrics.py:73: Adam, lr 1e-4) -----------
+ * torch.optim.Adam's update (no weight decay / amsgrad) for up to GEOM_ADAM_MAX_TENSORS tensors in one
+ * launch.  params/grads/exp_avg/exp_avg_sq/sizes are HOST arrays of `count` device pointers / lengths;
+ * grads are multiplied by grad_scale first (1/world after a SUM all-reduce).  `state` is 3 device
+ * floats {t, beta1^t, beta2^t}, zero-initialised by the caller once and advanced by every call on the
+ * device, so a captured HIP graph replays the correct bias correction. */
+#define GEOM_ADAM_MAX_TENSORS 16
+int geom_adam_step_f32(int count, float *const *params, const float *const *grads, float *const *exp_avg,
+                       float *const *exp_avg_sq, const int64_t *sizes, float lr, float beta1, float beta2,
+                       float eps, float grad_scale, float *state, void *stream);
 
 #ifdef __cplusplus
 }

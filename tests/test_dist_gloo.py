@@ -38,13 +38,12 @@ def _worker(rank, world, port, out):
     first, count = gdist.shard_range(8, rank, world)
     g = torch.Generator().manual_seed(123)
     data = torch.randn(8, 6, generator=g)                  # the "meshes": every rank sees the same global batch
-    bucket.zero_()
     loss = model(data[first:first + count]).pow(2).sum(1).mean()   # mean over the local shard
     loss.backward()
-    for p in model.parameters():                           # .grad still aliases the bucket after backward
-        assert p.grad.data_ptr() >= bucket.flat.data_ptr()
-        assert p.grad.data_ptr() < bucket.flat.data_ptr() + bucket.flat.numel() * 4
-    bucket.all_reduce_mean_()
+    views = bucket.pack_all_reduce()                       # one cat + one all-reduce(SUM)
+    assert [tuple(v.shape) for v in views] == [tuple(p.shape) for p in model.parameters()]
+    assert all(v.data_ptr() >= bucket.flat.data_ptr() for v in views)
+    bucket.flat.div_(world)
     mean_loss = gdist.global_mean_loss(loss.detach() * count, count)
     gdist.barrier()
     if rank == 0:

@@ -1,0 +1,24 @@
+import sys, torch
+sys.path.insert(0, ".")
+from geometrics_amd import layers, meshgen, utils, _lib
+dev = torch.device("cuda:0")
+V, F = meshgen.icosphere(4)
+adj = utils.adj_init(torch.from_numpy(F).to(dev))["adj"]
+csr = layers.adjacency_csr(adj)
+B, C = 8, 192
+sup = torch.randn(B, V.shape[0], C, device=dev); bias = torch.randn(C, device=dev); out = torch.empty_like(sup)
+def run(k, act=0):
+    _lib.call("geom_zn_gcn_aggregate_fwd_f32", B, V.shape[0], C, k, csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.val.data_ptr(), sup.data_ptr(), bias.data_ptr(), act, out.data_ptr())
+def t(fn, it=200):
+    for _ in range(10): fn()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(it): fn()
+    g.replay(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record(); g.replay(); e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / it * 1e3
+print("clone        ", t(lambda: out.copy_(sup)))
+print("add bias     ", t(lambda: torch.add(sup, bias, out=out)))
+for k in (0, 16, 64, 128, 192):
+    print("agg k=%3d    " % k, t(lambda: run(k)), " relu", t(lambda: run(k, 1)))
