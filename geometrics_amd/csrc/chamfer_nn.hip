@@ -6,18 +6,19 @@
 // a global read-modify-write per 512-target tile).
 //
 // Design (written for CDNA4, not translated):
-//   * one workgroup = 4 waves = 64 query points of one (direction, mesh) job; lane <-> query,
+//   * one workgroup = 8 waves = 64 query points of one (direction, mesh) job; lane <-> query,
 //     so every lane of a wave looks at the SAME target at the same time and the target
 //     tile is read from LDS as wave-uniform (broadcast) ds_read_b128s: 3 reads serve
 //     4 targets x 64 queries.
-//   * the 4 waves split each 1024-target LDS chunk four ways, which gives
-//     b * (ceil(n/64)+ceil(m/64)) * 4 waves (>= 3000 at the BASELINE shard of 8 meshes)
+//   * the target set is staged in LDS in sweeps of up to 4096 points (the whole set at the
+//     BASELINE size: one coalesced sweep, one barrier) and the 8 waves split it eight ways, which
+//     gives b * (ceil(n/64)+ceil(m/64)) * 8 waves (6016 at the BASELINE shard of 8 meshes)
 //     instead of the reference's 6 busy blocks per mesh.
 //   * the arg-min keeps only a running minimum per GROUP of 4 targets in the hot loop
 //     (v_min3/v_min + one compare + two selects per 4 pairs instead of a compare and two
 //     selects per pair); the winning group's 4 distances are recomputed once at the end
 //     to recover the exact first-minimum index.
-//   * partial results of the 4 waves are merged lexicographically on (distance, index),
+//   * partial results of the 8 waves are merged lexicographically on (distance, index),
 //     which equals the reference's sequential strict-'<' scan; the "first target seeds"
 //     rule (NaN seed sticks, all-inf keeps index 0) is applied explicitly.
 //   * arithmetic: (dx*dx + dy*dy) + dz*dz with dx = target - query, un-fused
@@ -29,10 +30,10 @@
 
 namespace {
 
-constexpr int NN_THREADS = 256;
-constexpr int NN_WAVES = NN_THREADS / GEOM_WAVE; // 4
+constexpr int NN_THREADS = 512;
+constexpr int NN_WAVES = NN_THREADS / GEOM_WAVE; // 8
 constexpr int NN_QUERIES = GEOM_WAVE;            // queries per workgroup
-constexpr int NN_CHUNK = 1024;                   // targets staged in LDS at a time (multiple of 16)
+constexpr int NN_CHUNK = 4096;                   // targets staged in LDS per sweep (48 KiB; multiple of 4 * NN_WAVES)
 
 struct NNJob {
     const float *xyz1, *xyz2;
@@ -49,16 +50,20 @@ __device__ __forceinline__ float min4(float a, float b, float c, float d)
 template <bool TRUNC>
 __global__ __launch_bounds__(NN_THREADS) void chamfer_nn_kernel(NNJob job)
 {
-    __shared__ float4 tile[NN_CHUNK * 3 / 4]; // 12 KiB: [target][xyz] packed, read 4 targets per 3 float4
+    __shared__ float4 tile[NN_CHUNK * 3 / 4]; // 48 KiB: [target][xyz] packed, read 4 targets per 3 float4
     __shared__ float part_d[NN_WAVES][NN_QUERIES];
     __shared__ int part_i[NN_WAVES][NN_QUERIES];
 
-    const int dir = blockIdx.y / job.b;
-    const int mesh = blockIdx.y - dir * job.b;
+    // (direction, mesh) jobs are pinned to XCDs so a job's target set is fetched into one L2 only
+    const int longer = job.n > job.m ? job.n : job.m;
+    int jobid, qtile;
+    if (!geom::xcd_assign(blockIdx.x, 2 * job.b, (longer + NN_QUERIES - 1) / NN_QUERIES, jobid, qtile)) return;
+    const int dir = jobid / job.b;
+    const int mesh = jobid - dir * job.b;
     const int nq = dir ? job.m : job.n;
     const int nt = dir ? job.n : job.m;
-    const int q0 = blockIdx.x * NN_QUERIES;
-    if (q0 >= nq) return; // grid.x is sized for the longer direction
+    const int q0 = qtile * NN_QUERIES;
+    if (q0 >= nq) return; // tiles are sized for the longer direction
 
     const float *Q = (dir ? job.xyz2 : job.xyz1) + (size_t)mesh * nq * 3;
     const float *T = (dir ? job.xyz1 : job.xyz2) + (size_t)mesh * nt * 3;
@@ -172,10 +177,11 @@ extern "C" int geom_chamfer_nn_f32(int b, int n, const float *xyz, int m, const 
     if (b == 0 || (n == 0 && m == 0)) return 0;
     if (n == 0 || m == 0) return GEOM_EINVAL; // a direction with no targets has no arg-min
     if (!xyz || !xyz2 || !result || !result_i || !result2 || !result2_i) return GEOM_EINVAL;
-    if (2 * (int64_t)b > 65535) return GEOM_ETOOBIG;
     NNJob job{xyz, xyz2, result, result2, result_i, result2_i, b, n, m};
     const int longer = n > m ? n : m;
-    dim3 grid((longer + NN_QUERIES - 1) / NN_QUERIES, 2 * b, 1);
+    const int64_t blocks = (int64_t)geom::NUM_XCD * ((longer + NN_QUERIES - 1) / NN_QUERIES) * ((2 * (int64_t)b + 7) / 8);
+    if (blocks > 0x7fffffffLL) return GEOM_ETOOBIG;
+    dim3 grid(geom::xcd_grid(2 * b, (longer + NN_QUERIES - 1) / NN_QUERIES), 1, 1);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (flags & GEOM_FLAG_REF_TAIL_TRUNC)
         hipLaunchKernelGGL(chamfer_nn_kernel<true>, grid, dim3(NN_THREADS), 0, s, job);

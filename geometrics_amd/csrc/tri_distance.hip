@@ -384,15 +384,18 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_distance_culled_kernel(TriJob
 // A prep kernel writes, once per (mesh, triangle), the bounding sphere and the three corners
 // into a caller-provided workspace (64 B per triangle).  The scan kernel then never touches
 // faces/verts again and needs no LDS staging and no chunk barriers:
-//   * the sphere records are wave-uniform, so they are fetched with SCALAR loads
-//     (s_load_dwordx4/x16 through the scalar cache) and used as SGPR operands of the VALU
-//     compare -- the CDNA way to broadcast, leaving LDS and VGPRs to the survivor queue;
-//   * 8 waves share 64 query points and split the triangle range 8 ways (3008 waves at the
-//     BASELINE shard of 8 meshes), so one block's serial chain is ~1/8 of the range;
+//   * the sphere records (16 B per triangle) are staged into LDS in chunks of 3072 with ONE
+//     coalesced sweep per chunk -- every load of the chunk is in flight together, so a workgroup
+//     pays one memory round trip per chunk -- and read back as wave-uniform ds_read_b128
+//     (LDS broadcast).  (A scalar-load / SGPR-broadcast variant was measured first: with only
+//     1-3 waves per SIMD at the 8-mesh shard its per-record s_load round trips, ~0.3 us each
+//     and barely overlappable, made a workgroup take ~100 us regardless of batch size.)
+//   * 16 waves share 64 query points and split every chunk 16 ways (6016 waves at the BASELINE
+//     shard of 8 meshes), so one block's serial chain is 1/16 of the range (8 waves measured 16 % slower);
 //   * survivors are compacted into per-wave LDS queues exactly as above, their corners come
 //     from the workspace with one 48-byte gather per item, and the queue only drains at the end.
-constexpr int WS_THREADS = 512;
-constexpr int WS_WAVES = WS_THREADS / GEOM_WAVE; // 8
+constexpr int WS_THREADS = 1024;
+constexpr int WS_WAVES = WS_THREADS / GEOM_WAVE; // 16
 constexpr int WS_PAD = 4 * WS_WAVES;             // triangle count is padded to a multiple of this
 
 struct TriWs {
@@ -423,19 +426,23 @@ __global__ __launch_bounds__(256) void tri_prep_kernel(TriJob job, TriWs ws)
     ws.cor[3 * o + 2] = make_float4(C.x, C.y, C.z, 0.f);
 }
 
+constexpr int WS_CHUNK = 3072; // sphere records staged in LDS per pass (48 KiB); multiple of WS_PAD
+
 template <bool TRUNC, bool FIX6>
-__global__ __launch_bounds__(WS_THREADS) void tri_scan_ws_kernel(const float *__restrict__ xyz, int n, int m, int m_pad,
+__global__ __launch_bounds__(WS_THREADS) void tri_scan_ws_kernel(const float *__restrict__ xyz, int b, int n, int m, int m_pad,
                                                                   const float4 *__restrict__ sph_all,
                                                                   const float4 *__restrict__ cor_all,
                                                                   float *__restrict__ dist, int *__restrict__ point,
                                                                   int *__restrict__ index)
 {
+    __shared__ float4 tile[WS_CHUNK];
     __shared__ unsigned long long qbest[TRI_QUERIES];
     __shared__ float qp[3][TRI_QUERIES];
     __shared__ unsigned queue[WS_WAVES][CULL_QCAP];
 
-    const int mesh = blockIdx.y;
-    const int q0 = blockIdx.x * TRI_QUERIES;
+    int mesh, qtile; // all workgroups of a mesh share one XCD (its records stay in that L2)
+    if (!geom::xcd_assign(blockIdx.x, b, (n + TRI_QUERIES - 1) / TRI_QUERIES, mesh, qtile)) return;
+    const int q0 = qtile * TRI_QUERIES;
     const int lane = threadIdx.x & (GEOM_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform => scalar addressing
     const int q = q0 + lane;
@@ -451,30 +458,37 @@ __global__ __launch_bounds__(WS_THREADS) void tri_scan_ws_kernel(const float *__
         qp[1][lane] = p.y;
         qp[2][lane] = p.z;
     }
-    __syncthreads();
 
     // literal evaluation of triangle k for the query held by lane `ql`, merged with one LDS atomic
     auto evaluate = [&](int ql, int k) {
         if (k >= m || (TRUNC && geom::ref_tail_skipped(k, m))) return;
-        const float4 a = cor[3 * (size_t)k + 0], b = cor[3 * (size_t)k + 1], c = cor[3 * (size_t)k + 2];
+        const float4 a = cor[3 * (size_t)k + 0], bq = cor[3 * (size_t)k + 1], c = cor[3 * (size_t)k + 2];
         const V3 pq = geom::mk(qp[0][ql], qp[1][ql], qp[2][ql]);
         int opt;
-        const float d = geom::tri_pair_literal<FIX6>(pq, geom::mk(a.x, a.y, a.z), geom::mk(b.x, b.y, b.z),
+        const float d = geom::tri_pair_literal<FIX6>(pq, geom::mk(a.x, a.y, a.z), geom::mk(bq.x, bq.y, bq.z),
                                                      geom::mk(c.x, c.y, c.z), opt);
         if (d == d) atomicMin(&qbest[ql], pack_key(d, k, opt));
     };
 
-    // ---- hint: nearest of every HINT_STRIDE-th sphere centre within this wave's share ------
+    // ---- hint: every HINT_STRIDE-th sphere record of the whole mesh is staged once (all loads in
+    //      flight together), each wave takes the nearest centre of its share and evaluates it ----
     {
+        const int hints = (m + HINT_STRIDE - 1) / HINT_STRIDE;
         float near_c2 = INFINITY;
         int near_k = wave < m ? wave : 0;
-        for (int k = wave * HINT_STRIDE; k < m; k += WS_WAVES * HINT_STRIDE) {
-            const float4 rec = sph[k]; // scalar load
-            const float c2 = geom::sqdist3(rec.x, rec.y, rec.z, p.x, p.y, p.z);
-            if (c2 < near_c2) {
-                near_c2 = c2;
-                near_k = k;
+        for (int h0 = 0; h0 < hints; h0 += WS_CHUNK) {
+            const int len = min(WS_CHUNK, hints - h0);
+            for (int t = threadIdx.x; t < len; t += WS_THREADS) tile[t] = sph[(size_t)(h0 + t) * HINT_STRIDE];
+            __syncthreads();
+            for (int t = wave; t < len; t += WS_WAVES) {
+                const float4 rec = tile[t];
+                const float c2 = geom::sqdist3(rec.x, rec.y, rec.z, p.x, p.y, p.z);
+                if (c2 < near_c2) {
+                    near_c2 = c2;
+                    near_k = (h0 + t) * HINT_STRIDE;
+                }
             }
+            __syncthreads();
         }
         evaluate(lane, near_k);
         __syncthreads();
@@ -495,49 +509,46 @@ __global__ __launch_bounds__(WS_THREADS) void tri_scan_ws_kernel(const float *__
         }
     };
 
-    // ---- culled scan over this wave's contiguous share (multiple of 4 triangles) -----------
-    // The records of the NEXT group are requested (scalar loads) before the current group is
-    // tested, so the ~300-cycle scalar-cache latency overlaps the VALU work.
+    // ---- culled scan: chunks of sphere records are staged in LDS with one coalesced sweep (every
+    //      load of the chunk in flight at once), then each wave tests its contiguous share of the chunk
+    //      with wave-uniform ds_read_b128 (LDS broadcast) --------------------------------------------
     const unsigned long long live_mask = __ballot(live);
-    const int per_wave = m_pad / WS_WAVES;
-    const int t_begin = wave * per_wave;
-    const int t_last = t_begin + per_wave - 4;
-    float4 cur[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) cur[j] = sph[t_begin + j];
-    for (int t = t_begin; t <= t_last; t += 4) {
-        float4 nxt[4];
-        const int tn = t < t_last ? t + 4 : t; // last group re-reads itself (stays in bounds)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) nxt[j] = sph[tn + j];
-        unsigned long long keep[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float c2 = geom::sqdist3(cur[j].x, cur[j].y, cur[j].z, p.x, p.y, p.z);
-            const float reach = cur[j].w + s;
-            keep[j] = __builtin_amdgcn_ballot_w64(!(c2 > reach * reach)) & live_mask;
-        }
-        if ((keep[0] | keep[1] | keep[2] | keep[3]) != 0ull) {
+    for (int c0 = 0; c0 < m_pad; c0 += WS_CHUNK) {
+        const int len = min(WS_CHUNK, m_pad - c0); // multiple of WS_PAD = 4 * WS_WAVES
+        for (int t = threadIdx.x; t < len; t += WS_THREADS) tile[t] = sph[c0 + t];
+        __syncthreads();
+        const int per_wave = len / WS_WAVES; // multiple of 4
+        const int t_begin = wave * per_wave;
+        for (int t = t_begin; t < t_begin + per_wave; t += 4) {
+            unsigned long long keep[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const unsigned long long mask = keep[j];
-                if (mask != 0ull) {
-                    const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                  __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    if ((mask >> lane) & 1ull) my_queue[pos] = ((unsigned)lane << 26) | (unsigned)(t + j);
-                    qn += __popcll(mask);
+                const float4 rec = tile[t + j];
+                const float c2 = geom::sqdist3(rec.x, rec.y, rec.z, p.x, p.y, p.z);
+                const float reach = rec.w + s;
+                keep[j] = __builtin_amdgcn_ballot_w64(!(c2 > reach * reach)) & live_mask;
+            }
+            if ((keep[0] | keep[1] | keep[2] | keep[3]) != 0ull) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned long long mask = keep[j];
+                    if (mask != 0ull) {
+                        const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        if ((mask >> lane) & 1ull) my_queue[pos] = ((unsigned)lane << 26) | (unsigned)(c0 + t + j);
+                        qn += __popcll(mask);
+                    }
+                }
+                if (qn >= GEOM_WAVE) {
+                    do {
+                        qn -= GEOM_WAVE;
+                        pop_batch(qn, GEOM_WAVE);
+                    } while (qn >= GEOM_WAVE);
+                    s = slack();
                 }
             }
-            if (qn >= GEOM_WAVE) {
-                do {
-                    qn -= GEOM_WAVE;
-                    pop_batch(qn, GEOM_WAVE);
-                } while (qn >= GEOM_WAVE);
-                s = slack();
-            }
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+        __syncthreads(); // the chunk is overwritten next; queued items carry global indices and survive
     }
     if (qn > 0) pop_batch(0, qn);
     __syncthreads();
@@ -547,9 +558,9 @@ __global__ __launch_bounds__(WS_THREADS) void tri_scan_ws_kernel(const float *__
         float acc_d = __uint_as_float((unsigned)(word >> 32));
         int acc_k = (int)(unsigned)word;
         // "k == 0 ||" seed (tri_distance.cu:194)
-        const float4 a = cor[0], b = cor[1], c = cor[2];
+        const float4 a = cor[0], bq = cor[1], c = cor[2];
         int opt0;
-        const float d0 = geom::tri_pair_literal<FIX6>(p, geom::mk(a.x, a.y, a.z), geom::mk(b.x, b.y, b.z),
+        const float d0 = geom::tri_pair_literal<FIX6>(p, geom::mk(a.x, a.y, a.z), geom::mk(bq.x, bq.y, bq.z),
                                                       geom::mk(c.x, c.y, c.z), opt0);
         if (d0 != d0 || word == KEY_NONE) {
             acc_d = d0;
@@ -573,9 +584,9 @@ template <bool INDEXED, bool TRUNC, bool FIX6>
 int launch_ws_variant(const TriJob &job, const TriWs &ws, hipStream_t s)
 {
     hipLaunchKernelGGL((tri_prep_kernel<INDEXED, TRUNC, FIX6>), dim3((ws.m_pad + 255) / 256, job.b), dim3(256), 0, s, job, ws);
-    hipLaunchKernelGGL((tri_scan_ws_kernel<TRUNC, FIX6>), dim3((job.n + TRI_QUERIES - 1) / TRI_QUERIES, job.b),
-                       dim3(WS_THREADS), 0, s, job.xyz, job.n, job.m, ws.m_pad, ws.sph, ws.cor, job.dist, job.point,
-                       job.index);
+    hipLaunchKernelGGL((tri_scan_ws_kernel<TRUNC, FIX6>),
+                       dim3(geom::xcd_grid(job.b, (job.n + TRI_QUERIES - 1) / TRI_QUERIES)), dim3(WS_THREADS), 0, s,
+                       job.xyz, job.b, job.n, job.m, ws.m_pad, ws.sph, ws.cor, job.dist, job.point, job.index);
     return geom::launch_status();
 }
 
