@@ -38,12 +38,14 @@ V_LEVEL, S_PTS, G_PTS, FEAT, HID = 4, 3000, 3000, 963, 192
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector peak == f32 MFMA dense peak
 
-# Algorithmic work per (point, triangle) pair of the tri scan, counted on the hoisted form of the
-# reference decision tree (DESIGN.md "Kernels"): 3 point-corner differences (9), 3 edge
-# projections (15), region compares (12), 3 inner-side tests (18), closest point + squared
-# distance (12), arg-min update (3)  => 69 flop-equivalents per pair.
-TRI_FLOP_PER_PAIR = 69.0
-NN_FLOP_PER_PAIR = 8.0     # 3 sub, 3 mul, 2 add
+# Work per (point, triangle) pair of the culled tri scan: the cull test is
+# 3 sub, 3 mul, 2 add (|p-c|^2), 1 add + 1 mul ((r_eff+s)^2) and 1 compare = 11 fp32 lane-ops, none of
+# them fusable into FMAs.  Survivor evaluation (~40 literal decision trees per point) is NOT counted,
+# so `achieved` is a lower bound of the executed arithmetic.
+TRI_CULL_FLOP_PER_PAIR = 11.0
+TRI_BRUTE_FLOP_PER_PAIR = 69.0   # hoisted count of the full decision tree (what a brute-force scan spends)
+NN_FLOP_PER_PAIR = 8.0           # 3 sub, 3 mul, 2 add
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
 
 
 class Workload:
@@ -124,17 +126,38 @@ def time_steps(fn, steps, warmup):
 
 
 def event_time_us(fn, iters=30, warm=5):
-    """Average duration of fn's launches, HIP events on the launch (= torch current) stream."""
+    """Average duration of fn's launches: `iters` launches are captured into one HIP graph and the
+    replay is bracketed by HIP events on the launch (= torch current) stream, so host launch overhead
+    is excluded and what is measured is kernel time."""
     for _ in range(warm):
         fn()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(iters):
+            fn()
+    graph.replay()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     s.record()
-    for _ in range(iters):
-        fn()
+    graph.replay()
     e.record()
     torch.cuda.synchronize()
     return s.elapsed_time(e) * 1e3 / iters
+
+
+def pmc_traffic_bytes(kernel_prefix):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE are in KiB;
+    calibrated 1:1 on the aggregation kernel's known byte count, see profiles/README.md), or None."""
+    try:
+        with open(PMC_FILE) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    for name, row in table.items():
+        if name.startswith(kernel_prefix):
+            return int((row["FETCH_SIZE_KB_per_launch"] + row["WRITE_SIZE_KB_per_launch"]) * 1024)
+    return None
 
 
 def kernel_rooflines(w):
@@ -142,7 +165,7 @@ def kernel_rooflines(w):
     with torch.no_grad():
         pos = w.positions().contiguous()
         pred = utils.batch_sample(pos, w.faces, num=S_PTS)
-        t_tri = event_time_us(lambda: tri_distance_indexed(w.gt, pos, w.faces))
+        t_tri = event_time_us(lambda: tri_distance_indexed(w.gt, pos, w.faces))       # prep + scan launches
         t_nn = event_time_us(lambda: chamfer_nn(w.gt, pred))
         sup = torch.randn(w.batch, w.nv, HID, device=pos.device)
         csr = layers.adjacency_csr(w.info["adj"])
@@ -150,26 +173,34 @@ def kernel_rooflines(w):
     b = w.batch
     tri_pairs = b * G_PTS * w.nf
     nn_pairs = 2 * b * G_PTS * S_PTS
-    tri_tflops = tri_pairs * TRI_FLOP_PER_PAIR / (t_tri * 1e-6) / 1e12
+    tri_tflops = tri_pairs * TRI_CULL_FLOP_PER_PAIR / (t_tri * 1e-6) / 1e12
     nn_tflops = nn_pairs * NN_FLOP_PER_PAIR / (t_nn * 1e-6) / 1e12
     # 0N-GCN aggregation: read support + write out (4 B each per element) + CSR (12 B per nnz + 4 B per row)
     agg_bytes = 2 * b * w.nv * HID * 4 + csr.nnz * 12 + (w.nv + 1) * 4
     agg_gbs = agg_bytes / (t_agg * 1e-6) / 1e9
     tri_bytes = b * (G_PTS * 12 + w.nv * 12 + w.nf * 24 + G_PTS * 12)     # points + verts + faces(int64) + 3 outputs
-    roofline = {"kernel": "tri_distance_kernel (point-to-triangle arg-min scan)", "bound": "mfma",
-                "pipe": "fp32 VALU (arg-min scan, not a contraction; on gfx950 the f32 VALU peak equals the dense f32 MFMA peak)",
+    roofline = {"kernel": "tri_prep_kernel + tri_scan_ws_kernel (point-to-triangle arg-min scan, culled)",
+                "bound": "mfma",
+                "pipe": "fp32 VALU, un-fused (arg-min scan, not a contraction; on gfx950 the f32 VALU peak equals the "
+                        "dense f32 MFMA peak; code that cannot use FMA tops out at half of it)",
                 "achieved": round(tri_tflops, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tri_tflops / FP32_PEAK_TFLOPS, 4), "traffic": None,
-                "launch_us": round(t_tri, 1), "pairs_per_launch": tri_pairs, "flop_per_pair": TRI_FLOP_PER_PAIR,
+                "frac": round(tri_tflops / FP32_PEAK_TFLOPS, 4), "traffic": pmc_traffic_bytes("tri_scan_ws_kernel"),
+                "launch_us": round(t_tri, 1), "pairs_per_launch": tri_pairs, "flop_per_pair": TRI_CULL_FLOP_PER_PAIR,
                 "algorithmic_bytes_per_launch": tri_bytes,
-                "hbm_gbs_algorithmic": round(tri_bytes / (t_tri * 1e-6) / 1e9, 2)}
+                "hbm_gbs_algorithmic": round(tri_bytes / (t_tri * 1e-6) / 1e9, 2),
+                "brute_force_equivalent_tflops": round(tri_pairs * TRI_BRUTE_FLOP_PER_PAIR / (t_tri * 1e-6) / 1e12, 2),
+                "note": "achieved counts only the 11-op cull test of every pair (lower bound of executed work); "
+                        "brute_force_equivalent is what an un-culled scan would need to sustain for the same time "
+                        "and is not a utilisation"}
     others = {
-        "chamfer_nn_kernel": {"bound": "mfma", "pipe": "fp32 VALU", "achieved": round(nn_tflops, 3),
+        "chamfer_nn_kernel": {"bound": "mfma", "pipe": "fp32 VALU, un-fused", "achieved": round(nn_tflops, 3),
                               "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(nn_tflops / FP32_PEAK_TFLOPS, 4),
-                              "launch_us": round(t_nn, 1), "pairs_per_launch": nn_pairs, "flop_per_pair": NN_FLOP_PER_PAIR},
+                              "launch_us": round(t_nn, 1), "pairs_per_launch": nn_pairs, "flop_per_pair": NN_FLOP_PER_PAIR,
+                              "traffic": pmc_traffic_bytes("chamfer_nn_kernel")},
         "zn_aggregate_kernel": {"bound": "hbm", "achieved": round(agg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(agg_gbs / HBM_PEAK_GBS, 4), "launch_us": round(t_agg, 1),
-                                "algorithmic_bytes_per_launch": agg_bytes},
+                                "algorithmic_bytes_per_launch": agg_bytes,
+                                "traffic": pmc_traffic_bytes("zn_aggregate_kernel<4, 1, false>")},
     }
     return roofline, others
 

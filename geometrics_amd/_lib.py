@@ -15,6 +15,7 @@ FLAG_REF_TAIL_TRUNC = 1
 FLAG_FIX_REGION6 = 2
 FLAG_TRI_BRUTE_FORCE = 4
 ABI_VERSION = 1
+EUNSUPPORTED = -3
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -39,6 +40,8 @@ _SIGNATURES = {
     "geom_sample_chamfer_bwd_f32": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _f, _vp, _vp],
     "geom_adam_step_f32": [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _vp],
     "geom_zn_gcn_aggregate_fwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "geom_zn_gcn_aggregate_ell_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "geom_zn_gcn_aggregate_ell_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "geom_zn_gcn_aggregate_bwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
 }
 

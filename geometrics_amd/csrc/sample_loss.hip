@@ -281,9 +281,20 @@ __global__ __launch_bounds__(SUM_THREADS) void sum2_kernel(int64_t n1, const flo
                                                             const float *x2, float s2, float *out)
 {
     __shared__ float partial[2][SUM_THREADS / GEOM_WAVE];
-    float a1 = 0.f, a2 = 0.f;
-    for (int64_t i = threadIdx.x; i < n1; i += SUM_THREADS) a1 += x1[i];
-    for (int64_t i = threadIdx.x; i < n2; i += SUM_THREADS) a2 += x2[i];
+    // four independent partial sums per segment keep four loads in flight per thread (the loop is a
+    // latency chain otherwise); the association is fixed, so the result stays bit-reproducible
+    float p1[4] = {0.f, 0.f, 0.f, 0.f}, p2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = threadIdx.x; i < n1; i += 4 * SUM_THREADS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i + j * SUM_THREADS < n1) p1[j] += x1[i + j * SUM_THREADS];
+    }
+    for (int64_t i = threadIdx.x; i < n2; i += 4 * SUM_THREADS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i + j * SUM_THREADS < n2) p2[j] += x2[i + j * SUM_THREADS];
+    }
+    float a1 = (p1[0] + p1[1]) + (p1[2] + p1[3]), a2 = (p2[0] + p2[1]) + (p2[2] + p2[3]);
     for (int off = GEOM_WAVE / 2; off > 0; off >>= 1) {
         a1 += __shfl_down(a1, off, GEOM_WAVE);
         a2 += __shfl_down(a2, off, GEOM_WAVE);

@@ -185,8 +185,10 @@ __global__ __launch_bounds__(CS_COLS *CS_LANES) void colsum_final_kernel(int blo
     const int cl = threadIdx.x % CS_COLS, lane = threadIdx.x / CS_COLS;
     const int col = blockIdx.x * CS_COLS + cl;
     float t = 0.f;
-    if (col < c)
+    if (col < c) {
+#pragma unroll 8
         for (int b = lane; b < blocks; b += CS_LANES) t += partial[(size_t)b * c + col];
+    }
     part[lane][cl] = t;
     __syncthreads();
     if (lane == 0 && col < c) {
@@ -237,6 +239,172 @@ int launch(const GcnArgs &a, int act, float *colsum_partial, float *grad_bias, v
     return geom::launch_status();
 }
 
+// ---------------------------------------------------------------------------------------
+// ELL fast path (k % 4 == 0, C == k * (NC + 1) with NC = 2 (split 3) or 9 (split 10), rows of at
+// most W = 8 / 16 neighbours -- every hidden layer of the reference models on a triangle mesh).
+//
+// Thread (row, j) owns the aggregated float4 j of the row AND the NC pass-through float4s
+// j + (k/4)*i of the same row.  Compared with the generic kernel above:
+//   * every lane gathers (no wave where 2/3 of the lanes wait for the gathering third),
+//     b*V*k/4 threads fit the chip in ONE resident round;
+//   * neighbour indices/weights sit at a fixed stride (ELL, -1 padded): no rowptr round trip, the
+//     index loads and the thread's own pass-through loads are issued together, then all W
+//     neighbour rows -- two memory round trips per thread;
+//   * the thread stores NC + 1 float4s; in the backward it also owns the bias-gradient terms of
+//     those columns, reduced per workgroup through LDS (fixed order) into one partial per block.
+struct EllArgs {
+    const int *col;     // [nv][W], -1 = padding
+    const float *val;   // [nv][W]
+    const float *x, *bias, *saved;
+    float *y;
+    int nv, c, k;
+};
+
+template <int ACT, bool BACKWARD, int W, int NC>
+__global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a, int rows_per_block,
+                                                                        float *colsum_partial)
+{
+    extern __shared__ float lds_cs[]; // [rows_per_block][c]
+    const int kg = a.k >> 2;                         // aggregated float4 groups per row
+    const int j = threadIdx.x % kg;
+    const int rl = threadIdx.x / kg;
+    const int r = blockIdx.x * rows_per_block + rl;
+    const bool active = rl < rows_per_block && r < a.nv;
+    const int64_t mesh_row0 = (int64_t)blockIdx.y * a.nv;
+    const int c0 = 4 * j;
+
+    float4 own[NC + 1]; // [0] = own aggregated-slot element (backward only), [1..NC] = pass-through
+#pragma unroll
+    for (int i = 0; i <= NC; ++i) own[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    if (active) {
+        const int64_t row = mesh_row0 + r;
+        const float *xrow = a.x + row * a.c;
+        // round trip 1: indices, weights and the thread's own elements
+        int nb[W];
+        float w[W];
+#pragma unroll
+        for (int n = 0; n < W; n += 4) {
+            const int4 ci = *reinterpret_cast<const int4 *>(a.col + (size_t)r * W + n);
+            const float4 wi = *reinterpret_cast<const float4 *>(a.val + (size_t)r * W + n);
+            nb[n] = ci.x, nb[n + 1] = ci.y, nb[n + 2] = ci.z, nb[n + 3] = ci.w;
+            w[n] = wi.x, w[n + 1] = wi.y, w[n + 2] = wi.z, w[n + 3] = wi.w;
+        }
+#pragma unroll
+        for (int i = BACKWARD ? 0 : 1; i <= NC; ++i) {
+            own[i] = *reinterpret_cast<const float4 *>(xrow + c0 + a.k * i);
+            if (BACKWARD && ACT != ACT_NONE) {
+                const float4 o = *reinterpret_cast<const float4 *>(a.saved + row * a.c + c0 + a.k * i);
+                own[i].x = act_bwd<ACT>(own[i].x, o.x);
+                own[i].y = act_bwd<ACT>(own[i].y, o.y);
+                own[i].z = act_bwd<ACT>(own[i].z, o.z);
+                own[i].w = act_bwd<ACT>(own[i].w, o.w);
+            }
+        }
+        // round trip 2: the neighbour rows of the aggregated slot
+        float4 sv[W], ov[W];
+#pragma unroll
+        for (int n = 0; n < W; ++n) {
+            const int64_t nrow = mesh_row0 + (nb[n] >= 0 ? nb[n] : r);
+            sv[n] = *reinterpret_cast<const float4 *>(a.x + nrow * a.c + c0);
+            if (BACKWARD && ACT != ACT_NONE) ov[n] = *reinterpret_cast<const float4 *>(a.saved + nrow * a.c + c0);
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int n = 0; n < W; ++n) {
+            if (nb[n] >= 0) { // ELL order == CSR order of the row
+                float4 v = sv[n];
+                if (BACKWARD && ACT != ACT_NONE) {
+                    v.x = act_bwd<ACT>(v.x, ov[n].x);
+                    v.y = act_bwd<ACT>(v.y, ov[n].y);
+                    v.z = act_bwd<ACT>(v.z, ov[n].z);
+                    v.w = act_bwd<ACT>(v.w, ov[n].w);
+                }
+                acc.x += w[n] * v.x;
+                acc.y += w[n] * v.y;
+                acc.z += w[n] * v.z;
+                acc.w += w[n] * v.w;
+            }
+        }
+        float *yrow = a.y + row * a.c;
+#pragma unroll
+        for (int i = 0; i <= NC; ++i) {
+            float4 v = i == 0 ? acc : own[i];
+            if (!BACKWARD) {
+                if (a.bias) {
+                    const float4 bb = *reinterpret_cast<const float4 *>(a.bias + c0 + a.k * i);
+                    v.x += bb.x, v.y += bb.y, v.z += bb.z, v.w += bb.w;
+                }
+                v.x = act_fwd<ACT>(v.x), v.y = act_fwd<ACT>(v.y), v.z = act_fwd<ACT>(v.z), v.w = act_fwd<ACT>(v.w);
+            }
+            *reinterpret_cast<float4 *>(yrow + c0 + a.k * i) = v;
+        }
+    }
+
+    if (BACKWARD && colsum_partial) {
+        if (rl < rows_per_block) {
+#pragma unroll
+            for (int i = 0; i <= NC; ++i)
+                *reinterpret_cast<float4 *>(lds_cs + rl * a.c + c0 + a.k * i) = own[i]; // zeros for inactive rows
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < a.c; c += GCN_THREADS) {
+            float t = 0.f;
+            for (int l = 0; l < rows_per_block; ++l) t += lds_cs[l * a.c + c];
+            colsum_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * a.c + c] = t;
+        }
+    }
+}
+
+inline int ell_rows_per_block(int k) { return GCN_THREADS / (k >> 2); }
+inline int ell_nc(int c, int k) { return (k > 0 && k % 4 == 0 && c % k == 0) ? c / k - 1 : -1; }
+inline bool ell_supported(int c, int k, int w)
+{
+    const int nc = ell_nc(c, k);
+    return (nc == 2 || nc == 9) && (w == 8 || w == 16) && (k >> 2) <= GCN_THREADS;
+}
+
+template <int ACT, bool BACKWARD>
+void launch_ell_shape(const EllArgs &a, int w, dim3 grid, size_t lds, hipStream_t s, int rpb, float *partial)
+{
+    const dim3 block(GCN_THREADS);
+    const int nc = ell_nc(a.c, a.k);
+    if (w == 8 && nc == 2) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 8, 2>), grid, block, lds, s, a, rpb, partial);
+    else if (w == 16 && nc == 2) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 16, 2>), grid, block, lds, s, a, rpb, partial);
+    else if (w == 8 && nc == 9) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 8, 9>), grid, block, lds, s, a, rpb, partial);
+    else hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 16, 9>), grid, block, lds, s, a, rpb, partial);
+}
+
+template <bool BACKWARD>
+int dispatch_ell(EllArgs a, int b, int w, int act, float *grad_bias, float *scratch, void *stream)
+{
+    if (b < 0 || a.nv < 0 || a.c < 0 || a.k < 0 || a.k > a.c) return GEOM_EINVAL;
+    if (!ell_supported(a.c, a.k, w)) return GEOM_EUNSUPPORTED;
+    if (b == 0 || a.nv == 0) return 0;
+    if (!a.col || !a.val || !a.x || !a.y) return GEOM_EINVAL;
+    if (BACKWARD && act != ACT_NONE && !a.saved) return GEOM_EINVAL;
+    if (grad_bias && !scratch) return GEOM_EINVAL;
+    if ((((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.saved | (uintptr_t)a.bias | (uintptr_t)a.col | (uintptr_t)a.val) % 16) != 0)
+        return GEOM_EINVAL;
+    if (b > 65535) return GEOM_ETOOBIG;
+    const int rpb = ell_rows_per_block(a.k);
+    const int chunks = (a.nv + rpb - 1) / rpb;
+    float *partial = grad_bias ? scratch : nullptr;
+    const size_t lds = (BACKWARD && partial) ? (size_t)rpb * a.c * sizeof(float) : 0;
+    dim3 grid((unsigned)chunks, (unsigned)b);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (act) {
+    case ACT_NONE: launch_ell_shape<ACT_NONE, BACKWARD>(a, w, grid, lds, s, rpb, partial); break;
+    case ACT_RELU: launch_ell_shape<ACT_RELU, BACKWARD>(a, w, grid, lds, s, rpb, partial); break;
+    case ACT_ELU: launch_ell_shape<ACT_ELU, BACKWARD>(a, w, grid, lds, s, rpb, partial); break;
+    default: return GEOM_EINVAL;
+    }
+    if (BACKWARD && partial)
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((a.c + CS_COLS - 1) / CS_COLS), dim3(CS_COLS * CS_LANES), 0, s,
+                           chunks * b, a.c, partial, grad_bias);
+    return geom::launch_status();
+}
+
 template <bool BACKWARD>
 int dispatch(GcnArgs a, int b, int act, float *grad_bias, float *scratch, void *stream)
 {
@@ -280,4 +448,21 @@ extern "C" int geom_zn_gcn_aggregate_bwd_f32(int b, int nv, int c, int k, const 
 {
     GcnArgs a{rowptrT, colT, valT, grad_out, nullptr, out, grad_support, 0, nv, c, k};
     return dispatch<true>(a, b, act, grad_bias, scratch, stream);
+}
+
+extern "C" int geom_zn_gcn_aggregate_ell_fwd_f32(int b, int nv, int c, int k, int w, const int *ell_col,
+                                                 const float *ell_val, const float *support, const float *bias,
+                                                 int act, float *out, void *stream)
+{
+    EllArgs a{ell_col, ell_val, support, bias, nullptr, out, nv, c, k};
+    return dispatch_ell<false>(a, b, w, act, nullptr, nullptr, stream);
+}
+
+extern "C" int geom_zn_gcn_aggregate_ell_bwd_f32(int b, int nv, int c, int k, int w, const int *ell_colT,
+                                                 const float *ell_valT, const float *grad_out, const float *out,
+                                                 int act, float *grad_support, float *grad_bias, float *scratch,
+                                                 void *stream)
+{
+    EllArgs a{ell_colT, ell_valT, grad_out, nullptr, out, grad_support, nv, c, k};
+    return dispatch_ell<true>(a, b, w, act, grad_bias, scratch, stream);
 }

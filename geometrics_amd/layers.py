@@ -23,7 +23,8 @@ _ACT_NONE, _ACT_RELU, _ACT_ELU = 0, 1, 2
 
 # --------------------------------------------------------------- CSR cache ----
 class _Csr:
-    __slots__ = ("rowptr", "col", "val", "rowptr_t", "col_t", "val_t", "nv", "nnz")
+    __slots__ = ("rowptr", "col", "val", "rowptr_t", "col_t", "val_t", "nv", "nnz",
+                 "ell_w", "ell_col", "ell_val", "ell_col_t", "ell_val_t")
 
 
 _csr_cache = {}
@@ -37,6 +38,19 @@ def _to_csr(dense):
     rowptr = torch.zeros(dense.shape[0] + 1, dtype=torch.int64, device=dense.device)
     rowptr[1:] = torch.cumsum(counts, 0)
     return rowptr.to(torch.int32), cols.to(torch.int32).contiguous(), dense[rows, cols].to(torch.float32).contiguous()
+
+
+def _to_ell(rowptr, col, val, width):
+    """[V][width] neighbour table in CSR order, unused slots col = -1 / val = 0."""
+    nv = rowptr.numel() - 1
+    lens = (rowptr[1:] - rowptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(nv, device=col.device), lens)
+    slot = torch.arange(col.numel(), device=col.device) - rowptr[:-1].long()[rows]
+    ell_col = torch.full((nv, width), -1, dtype=torch.int32, device=col.device)
+    ell_val = torch.zeros((nv, width), dtype=torch.float32, device=col.device)
+    ell_col[rows, slot] = col
+    ell_val[rows, slot] = val
+    return ell_col.contiguous(), ell_val.contiguous()
 
 
 def adjacency_csr(adj):
@@ -57,6 +71,11 @@ def adjacency_csr(adj):
         c.rowptr_t, c.col_t, c.val_t = _to_csr(dense.t())
         c.nv = adj.shape[0]
         c.nnz = int(c.col.numel())
+        longest = int(max((c.rowptr[1:] - c.rowptr[:-1]).max(), (c.rowptr_t[1:] - c.rowptr_t[:-1]).max()))
+        c.ell_w = 8 if longest <= 8 else (16 if longest <= 16 else 0)   # ELL fast path for bounded degrees
+        if c.ell_w:
+            c.ell_col, c.ell_val = _to_ell(c.rowptr, c.col, c.val, c.ell_w)
+            c.ell_col_t, c.ell_val_t = _to_ell(c.rowptr_t, c.col_t, c.val_t, c.ell_w)
     if len(_csr_cache) >= _CSR_CACHE_MAX:
         _csr_cache.pop(next(iter(_csr_cache)))
     _csr_cache[key] = c
@@ -87,8 +106,16 @@ class _ZeroNAggregate(torch.autograd.Function):
         bias_c = None if bias is None else _lib.require(bias, "bias", torch.float32, 1)
         out = torch.empty_like(s)
         with torch.cuda.device(s.device):
-            _lib.call("geom_zn_gcn_aggregate_fwd_f32", b, nv, c, k, csr.rowptr.data_ptr(), csr.col.data_ptr(),
-                      csr.val.data_ptr(), s.data_ptr(), _lib.ptr(bias_c), act, out.data_ptr())
+            code = _lib.EUNSUPPORTED
+            if csr.ell_w:   # bounded-degree mesh: fixed-stride neighbour table, no rowptr round trip
+                code = _lib.lib().geom_zn_gcn_aggregate_ell_fwd_f32(
+                    b, nv, c, k, csr.ell_w, csr.ell_col.data_ptr(), csr.ell_val.data_ptr(), s.data_ptr(),
+                    _lib.ptr(bias_c), act, out.data_ptr(), _lib.stream_ptr())
+            if code == _lib.EUNSUPPORTED:
+                _lib.call("geom_zn_gcn_aggregate_fwd_f32", b, nv, c, k, csr.rowptr.data_ptr(), csr.col.data_ptr(),
+                          csr.val.data_ptr(), s.data_ptr(), _lib.ptr(bias_c), act, out.data_ptr())
+            else:
+                _lib.check(code, "geom_zn_gcn_aggregate_ell_fwd_f32")
         ctx.csr, ctx.k, ctx.act, ctx.has_bias = csr, k, act, bias is not None
         if act != _ACT_NONE:
             ctx.save_for_backward(out)
@@ -108,9 +135,18 @@ class _ZeroNAggregate(torch.autograd.Function):
             scratch = torch.empty(_lib.lib().geom_zn_gcn_bwd_scratch_floats(b, nv, c), dtype=torch.float32,
                                   device=g.device)
         with torch.cuda.device(g.device):
-            _lib.call("geom_zn_gcn_aggregate_bwd_f32", b, nv, c, ctx.k, csr.rowptr_t.data_ptr(),
-                      csr.col_t.data_ptr(), csr.val_t.data_ptr(), g.data_ptr(), _lib.ptr(out), act,
-                      grad_support.data_ptr(), _lib.ptr(grad_bias), _lib.ptr(scratch))
+            code = _lib.EUNSUPPORTED
+            if csr.ell_w:
+                code = _lib.lib().geom_zn_gcn_aggregate_ell_bwd_f32(
+                    b, nv, c, ctx.k, csr.ell_w, csr.ell_col_t.data_ptr(), csr.ell_val_t.data_ptr(), g.data_ptr(),
+                    _lib.ptr(out), act, grad_support.data_ptr(), _lib.ptr(grad_bias), _lib.ptr(scratch),
+                    _lib.stream_ptr())
+            if code == _lib.EUNSUPPORTED:
+                _lib.call("geom_zn_gcn_aggregate_bwd_f32", b, nv, c, ctx.k, csr.rowptr_t.data_ptr(),
+                          csr.col_t.data_ptr(), csr.val_t.data_ptr(), g.data_ptr(), _lib.ptr(out), act,
+                          grad_support.data_ptr(), _lib.ptr(grad_bias), _lib.ptr(scratch))
+            else:
+                _lib.check(code, "geom_zn_gcn_aggregate_ell_bwd_f32")
         return (grad_support if ctx.needs_input_grad[0] else None), grad_bias, None, None, None
 
 

@@ -32,6 +32,7 @@ extern "C" {
 /* argument errors */
 #define GEOM_EINVAL   (-1) /* bad size / null pointer */
 #define GEOM_ETOOBIG  (-2) /* a dimension exceeds what the index encoding supports */
+#define GEOM_EUNSUPPORTED (-3) /* the shape is outside a fast path; call the general entry point instead */
 
 /* flags (bit set) */
 #define GEOM_FLAG_REF_TAIL_TRUNC 1u /* reproduce the shipped CUDA kernels' tail truncation:
@@ -164,6 +165,19 @@ int geom_zn_gcn_aggregate_bwd_f32(int b, int nv, int c, int k, const int *rowptr
                                   const float *valT, const float *grad_out, const float *out,
                                   int act, float *grad_support, float *grad_bias, float *scratch,
                                   void *stream);
+
+/* ELL fast path of the same two operations (identical results: neighbours are summed in the same
+ * order).  ell_col/ell_val are [nv][w] row-major, w = 8 or 16, unused slots col = -1; supported when
+ * k % 4 == 0 and c == 3k (split 3) or c == 10k (split 10) -- every hidden layer of the reference
+ * models on a triangle mesh; anything else returns GEOM_EUNSUPPORTED and the CSR entry points above
+ * apply.  All pointers 16-byte aligned.  Scratch as for the CSR backward. */
+int geom_zn_gcn_aggregate_ell_fwd_f32(int b, int nv, int c, int k, int w, const int *ell_col,
+                                      const float *ell_val, const float *support, const float *bias,
+                                      int act, float *out, void *stream);
+int geom_zn_gcn_aggregate_ell_bwd_f32(int b, int nv, int c, int k, int w, const int *ell_colT,
+                                      const float *ell_valT, const float *grad_out, const float *out,
+                                      int act, float *grad_support, float *grad_bias, float *scratch,
+                                      void *stream);
 
 /* ---- optimiser step for the replicated layer parameters (GEOMetrics.py:73: Adam, lr 1e-4) -----------
  * torch.optim.Adam's update (no weight decay / amsgrad) for up to GEOM_ADAM_MAX_TENSORS tensors in one
