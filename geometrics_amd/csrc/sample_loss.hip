@@ -49,6 +49,69 @@ __global__ __launch_bounds__(PT_THREADS) void face_areas_kernel(int b, int nv, c
     areas[i] = sqrtf(s) / 2.f;
 }
 
+// ------------------------------------------------------------- random draws ----
+// Area-weighted face choice with replacement + the two barycentric uniforms, from pre-generated
+// uniforms (the reference: a python loop of B torch.multinomial calls plus two sample_n calls,
+// utils.py:604-612, 627-628).  One workgroup = one (mesh, 1024-sample chunk): it rebuilds the
+// mesh's face-area CDF in LDS (areas as in face_areas_kernel, block-wide inclusive scan in a fixed
+// order) and every thread inverts it for its sample with a binary search: face = first f with
+// cdf[f] > U0 * total.  Same distribution as multinomial(areas, num, replacement=True); the
+// stream of draws is our own (torch's generator stream is not reproducible across devices either).
+constexpr int DRAW_THREADS = 1024;
+constexpr int DRAW_MAX_FACES = 16384; // 64 KiB of LDS
+
+__global__ __launch_bounds__(DRAW_THREADS) void draw_samples_kernel(int nv, const float *verts, int nf,
+                                                                     const int64_t *faces, int num,
+                                                                     const float *uniforms, int64_t plane,
+                                                                     int64_t *choices, float *u, float *v)
+{
+    __shared__ float cdf[DRAW_MAX_FACES];
+    __shared__ float wave_total[DRAW_THREADS / GEOM_WAVE];
+    const int mesh = blockIdx.y;
+    const float *V = verts + (size_t)mesh * nv * 3;
+    const int per = (nf + DRAW_THREADS - 1) / DRAW_THREADS; // consecutive faces per thread
+    const int f0 = threadIdx.x * per;
+    float run = 0.f;
+    for (int f = f0; f < min(f0 + per, nf); ++f) { // local inclusive sums
+        const V3 v0 = ld3(V + 3 * faces[3 * (size_t)f + 0]);
+        const V3 v1 = ld3(V + 3 * faces[3 * (size_t)f + 1]);
+        const V3 v2 = ld3(V + 3 * faces[3 * (size_t)f + 2]);
+        const V3 x = v0 - v1, y = v1 - v2;
+        const float ca = x.y * y.z - x.z * y.y, cb = x.z * y.x - x.x * y.z, cc = x.x * y.y - x.y * y.x;
+        run += sqrtf((ca * ca + cb * cb) + cc * cc) / 2.f;
+        cdf[f] = run;
+    }
+    // exclusive offset of this thread: wave scan of the thread totals, then scan of the 16 wave totals
+    const int lane = threadIdx.x & (GEOM_WAVE - 1), wave = threadIdx.x >> 6;
+    float incl = run;
+    for (int off = 1; off < GEOM_WAVE; off <<= 1) {
+        const float t = __shfl_up(incl, off, GEOM_WAVE);
+        if (lane >= off) incl += t;
+    }
+    if (lane == GEOM_WAVE - 1) wave_total[wave] = incl;
+    __syncthreads();
+    float base = 0.f;
+    for (int w = 0; w < wave; ++w) base += wave_total[w];
+    const float offset = base + (incl - run);
+    for (int f = f0; f < min(f0 + per, nf); ++f) cdf[f] += offset;
+    __syncthreads();
+    const float total = cdf[nf - 1];
+
+    const int i = blockIdx.x * DRAW_THREADS + threadIdx.x;
+    if (i >= num) return;
+    const int64_t o = (int64_t)mesh * num + i;
+    const float target = uniforms[o] * total;
+    int lo = 0, hi = nf - 1; // first f with cdf[f] > target, clamped to the last face
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] > target) hi = mid;
+        else lo = mid + 1;
+    }
+    choices[o] = lo;
+    u[o] = sqrtf(uniforms[plane + o]);
+    v[o] = uniforms[2 * plane + o];
+}
+
 // -------------------------------------------------------------- face sampling ----
 struct SampleArgs {
     const float *verts;
@@ -425,5 +488,19 @@ extern "C" int geom_sum2_f32(int64_t n1, const float *x1, float scale1, int64_t 
     if (n1 < 0 || n2 < 0 || !out || (n1 > 0 && !x1) || (n2 > 0 && !x2)) return GEOM_EINVAL;
     hipLaunchKernelGGL(sum2_kernel, dim3(1), dim3(SUM_THREADS), 0, static_cast<hipStream_t>(stream), n1, x1, scale1, n2,
                        x2, scale2, out);
+    return geom::launch_status();
+}
+
+extern "C" int geom_draw_samples_f32(int b, int nv, const float *verts, int nf, const int64_t *faces, int num,
+                                     const float *uniforms, int64_t *choices, float *u, float *v, void *stream)
+{
+    if (b < 0 || nv < 0 || nf < 0 || num < 0) return GEOM_EINVAL;
+    if (nf > DRAW_MAX_FACES) return GEOM_EUNSUPPORTED;
+    if (b == 0 || num == 0) return 0;
+    if (nf == 0 || !verts || !faces || !uniforms || !choices || !u || !v) return GEOM_EINVAL;
+    if (b > 65535) return GEOM_ETOOBIG;
+    hipLaunchKernelGGL(draw_samples_kernel, dim3((num + DRAW_THREADS - 1) / DRAW_THREADS, b), dim3(DRAW_THREADS), 0,
+                       static_cast<hipStream_t>(stream), nv, verts, nf, faces, num, uniforms, (int64_t)b * num, choices,
+                       u, v);
     return geom::launch_status();
 }

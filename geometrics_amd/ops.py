@@ -248,13 +248,27 @@ def _side_stream(dev):
 
 
 def draw_samples(verts, faces, num, generator=None):
-    """The random part of batch_sample (reference utils.py:604-612, 627-628) in three batched
-    calls instead of a python loop of B multinomials: choices [B,num] ~ area-weighted with
-    replacement, u = sqrt(U1), v = U2."""
-    areas = face_areas(verts, faces)
-    choices = torch.multinomial(areas, num, True, generator=generator)
-    uv = torch.rand(2, areas.shape[0], num, device=areas.device, generator=generator)
-    return choices, torch.sqrt(uv[0]), uv[1]
+    """The random part of batch_sample (reference utils.py:604-612, 627-628): choices [B,num] ~
+    area-weighted with replacement, u = sqrt(U1), v = U2.  One torch.rand for the uniforms and one
+    kernel (per-mesh face-area CDF in LDS + binary search) instead of a python loop of B multinomials;
+    meshes with more than 16384 faces take the torch.multinomial route."""
+    verts_c = _f32(verts.detach(), "verts", 3, 3)
+    faces = _lib.require(faces, "faces", torch.int64, 2, 3)
+    b, nv, _ = verts_c.shape
+    dev = verts_c.device
+    uniforms = torch.rand(3, b, num, device=dev, generator=generator)
+    choices = torch.empty(b, num, dtype=torch.int64, device=dev)
+    u = torch.empty(b, num, dtype=torch.float32, device=dev)
+    v = torch.empty(b, num, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        code = _lib.lib().geom_draw_samples_f32(b, nv, verts_c.data_ptr(), faces.shape[0], faces.data_ptr(), num,
+                                                uniforms.data_ptr(), choices.data_ptr(), u.data_ptr(), v.data_ptr(),
+                                                _lib.stream_ptr())
+    if code == _lib.EUNSUPPORTED:
+        choices = torch.multinomial(face_areas(verts_c, faces), num, True, generator=generator)
+        return choices, torch.sqrt(uniforms[1]), uniforms[2]
+    _lib.check(code, "geom_draw_samples_f32")
+    return choices, u, v
 
 
 __all__ = ["face_areas", "device_sum", "SampleFaces", "GatherSqDistSum", "PointToTriangleSum", "SurfaceLoss",

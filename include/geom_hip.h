@@ -91,6 +91,12 @@ int geom_tri_distance_indexed_ws_f32(int b, int n, const float *xyz, int nv, con
  * areas[b,nf] = 0.5*|(v0-v1) x (v1-v2)|, the un-normalised multinomial weights (utils.py:596-602). */
 int geom_face_areas_f32(int b, int nv, const float *verts, int nf, const int64_t *faces,
                         float *areas, void *stream);
+/* The random part of batch_sample (utils.py:604-612, 627-628) from caller-supplied uniforms
+ * uniforms[3][b][num] in [0,1):  choices[b,num] = area-weighted face id (inverse CDF of the face areas
+ * at uniforms[0], i.e. multinomial with replacement), u = sqrt(uniforms[1]), v = uniforms[2].
+ * nf <= 16384 (the CDF lives in LDS), otherwise GEOM_EUNSUPPORTED. */
+int geom_draw_samples_f32(int b, int nv, const float *verts, int nf, const int64_t *faces, int num,
+                          const float *uniforms, int64_t *choices, float *u, float *v, void *stream);
 /* points[b,num,3] = (1-u)*x + (u*(1-v))*y + (u*v)*z with x,y,z the corners of face
  * choices[b,num] (int64 face ids), u already sqrt'ed (utils.py:615-631). */
 int geom_sample_faces_fwd_f32(int b, int nv, const float *verts, int nf, const int64_t *faces,
