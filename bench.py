@@ -63,32 +63,13 @@ class Workload:
         self.stack = torch.nn.ModuleList(
             [layers.Batch_Image_ZERON_GCNGCN(i, o) for i, o in ((FEAT, HID), (HID, HID), (HID, HID))]).to(dev)
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-        self.bucket = gdist.GradBucket(self.stack.parameters()) if self.world > 1 else None
+        # flat DP bucket: all gradients + [loss_sum, mesh_count] -> exactly one all-reduce per step
+        self.bucket = gdist.GradBucket(self.stack.parameters(), extra=2) if self.world > 1 else None
+        self.count = torch.full((), float(batch), device=dev)
         # GEOMetrics.py:73 (Adam, lr 1e-4): every parameter tensor in one launch, step count on the device
         self.opt = optim.FusedAdam(self.stack.parameters(), lr=1e-4)
-        self.loss_vec = None
-        self.graph = None
-
-    def capture(self, warm=3):
-        """Record one whole step (fwd + bwd + all-reduce + Adam) into a HIP graph; every launch of
-        the step -- library GEMMs, our C-ABI kernels, RCCL -- replays without python in the loop."""
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warm):
-                self.step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            self.step()
-        self.graph = graph
-
-    def run(self):
-        if self.graph is not None:
-            self.graph.replay()
-        else:
-            self.step()
+        self.loss = None
+        self.graphs = None
 
     def positions(self):
         h = self.feat
@@ -96,20 +77,72 @@ class Workload:
             h = layer(h, self.info["adj"], F.relu)
         return self.base + 0.01 * h[..., :3]
 
-    def step(self):
+    # one step = forward_backward() -> [exchange()] -> update(); captured as HIP graphs by capture()
+    def forward_backward(self):
         self.opt.zero_grad()
         self.feat.grad = None
         pos = self.positions()
-        loss = utils.batch_point_to_surface(pos, self.info, self.gt, num=S_PTS)
-        loss.backward()
+        self.loss = utils.batch_point_to_surface(pos, self.info, self.gt, num=S_PTS)
+        self.loss.backward()
         if self.world > 1:
-            grads = self.bucket.pack_all_reduce()               # one cat + ONE RCCL all-reduce (1.04 MB)
-            self.loss_vec = gdist.global_mean_loss(loss.detach() * self.batch, self.batch)
-            self.opt.step(grads, grad_scale=1.0 / self.world)   # mean over ranks folded into the update
+            self.bucket.pack(self.loss.detach() * self.batch, self.count)
+
+    def exchange(self):
+        if self.world > 1:
+            self.bucket.all_reduce()            # ONE RCCL all-reduce: 259 200 grads + loss sum + count (1.04 MB)
+
+    def update(self):
+        if self.world > 1:
+            self.opt.step(self.bucket.views, grad_scale=1.0 / self.world)   # mean over ranks folded into Adam
         else:
-            self.loss_vec = loss.detach()
             self.opt.step()
-        return loss
+
+    def step(self):
+        self.forward_backward()
+        self.exchange()
+        self.update()
+
+    def mean_loss(self):
+        if self.world > 1:
+            return float(self.bucket.extra[0] / self.bucket.extra[1])
+        return float(self.loss)
+
+    def capture(self, warm=3):
+        """Record the step into HIP graphs so that no python runs between its ~45 launches (library
+        GEMMs, our C-ABI kernels, fused Adam).  N=1: one graph.  N>1: graph A = forward + backward +
+        bucket pack, then the single all-reduce issued eagerly on the same stream, then graph B = Adam
+        -- the collective stays outside the captured region, so nothing depends on RCCL's
+        graph-capture support."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warm):
+                self.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if self.world == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step()
+            self.graphs = (g,)
+        else:
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                self.forward_backward()
+            self.exchange()
+            with torch.cuda.graph(gb, pool=ga.pool()):
+                self.update()
+            self.graphs = (ga, gb)
+
+    def run(self):
+        if self.graphs is None:
+            self.step()
+        elif len(self.graphs) == 1:
+            self.graphs[0].replay()
+        else:
+            self.graphs[0].replay()
+            self.exchange()
+            self.graphs[1].replay()
 
 
 def time_steps(fn, steps, warmup):
@@ -253,7 +286,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % torch.cuda.device_count())   # one rank per GPU (modulo only for 1-GPU tests)
     torch.cuda.set_device(dev)
 
     tuned = gemm_tuning.enable()      # pin the measured-fastest library GEMM per shape (no tuning at run time)
@@ -268,8 +301,10 @@ def main():
         except Exception as exc:  # fall back loudly, never silently
             print("bench.py: HIP graph capture failed (%s: %s); running eager" % (type(exc).__name__, exc),
                   file=sys.stderr)
-            w.graph = None
+            w.graphs = None
             torch.cuda.synchronize()
+            from geometrics_amd import _lib
+            _lib.clear_hip_error()
     elapsed = time_steps(w.run, args.steps, args.warmup)
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
@@ -289,7 +324,7 @@ def main():
                                    "grad all-reduce, Adam step" % per_gpu,
                        "meshes_per_gpu": per_gpu, "global_batch": per_gpu * world, "parallelism": "dp%d" % world,
                        "launch": launch, "gemm_selection": "tunableop file" if tuned else "library default"},
-            "final_loss": round(float(w.loss_vec.item()), 6),
+            "final_loss": round(w.mean_loss(), 6),
         }
         roofline, others = kernel_rooflines(w)
         line["roofline"] = roofline

@@ -97,6 +97,17 @@ def check(code, what):
         raise RuntimeError("%s failed: %s (code %d)" % (what, msg, code))
 
 
+def clear_hip_error():
+    """Fetch-and-reset HIP's sticky last-error (e.g. after an aborted graph capture), so that the next
+    launch check reports only its own failure.  Returns the stale code."""
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+    except OSError:
+        return 0
+    hip.hipGetLastError.restype = _i
+    return hip.hipGetLastError()
+
+
 def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 

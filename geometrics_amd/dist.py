@@ -21,9 +21,10 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # GEOM_DIST_BACKEND is a test hook (e.g. two ranks sharing one GPU over gloo); production = RCCL
+            backend = os.environ.get("GEOM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -51,24 +52,35 @@ def global_mean_loss(local_loss_sum, local_count):
 
 
 class GradBucket:
-    """One flat fp32 buffer for the DP gradient exchange.  Autograd leaves a fresh .grad on every
-    parameter (no accumulate kernels); `pack_all_reduce()` copies them into the flat buffer with
-    one launch, sums it across ranks with ONE all-reduce, and returns per-parameter views of the
-    reduced buffer (the caller applies the 1/world scale inside the optimiser kernel)."""
+    """One flat fp32 buffer for the DP exchange: every parameter gradient plus `extra` trailing scalars
+    (e.g. [loss_sum, mesh_count]), so a step needs exactly ONE all-reduce.  Autograd leaves a fresh
+    .grad on every parameter (no accumulate kernels); `pack()` gathers them with one launch,
+    `all_reduce()` sums the buffer across ranks, `views` are per-parameter views of the reduced buffer
+    (the 1/world scale is applied inside the optimiser kernel)."""
 
-    def __init__(self, params):
+    def __init__(self, params, extra=0):
         self.params = [p for p in params if p.requires_grad]
         ref = self.params[0]
-        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=ref.dtype, device=ref.device)
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel + extra, dtype=ref.dtype, device=ref.device)
         self.views, off = [], 0
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self.extra = self.flat[self.numel:]
 
-    def pack_all_reduce(self):
-        torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
+    def pack(self, *scalars):
+        parts = [p.grad.reshape(-1) for p in self.params] + [s.reshape(1).to(self.flat.dtype) for s in scalars]
+        torch.cat(parts, out=self.flat)
+        return self.flat
+
+    def all_reduce(self):
         all_reduce_sum_(self.flat)
         return self.views
+
+    def pack_all_reduce(self, *scalars):
+        self.pack(*scalars)
+        return self.all_reduce()
 
 
 def barrier():

@@ -34,20 +34,22 @@ def _worker(rank, world, port, out):
     assert (r, w) == (rank, world)
     torch.manual_seed(0)                                   # replicated parameters
     model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
-    bucket = gdist.GradBucket(model.parameters())
+    bucket = gdist.GradBucket(model.parameters(), extra=2)
     first, count = gdist.shard_range(8, rank, world)
     g = torch.Generator().manual_seed(123)
     data = torch.randn(8, 6, generator=g)                  # the "meshes": every rank sees the same global batch
     loss = model(data[first:first + count]).pow(2).sum(1).mean()   # mean over the local shard
     loss.backward()
-    views = bucket.pack_all_reduce()                       # one cat + one all-reduce(SUM)
+    # one cat + ONE all-reduce(SUM) carries the gradients and the [loss_sum, count] tail
+    views = bucket.pack_all_reduce(loss.detach() * count, torch.tensor(float(count)))
     assert [tuple(v.shape) for v in views] == [tuple(p.shape) for p in model.parameters()]
     assert all(v.data_ptr() >= bucket.flat.data_ptr() for v in views)
-    bucket.flat.div_(world)
-    mean_loss = gdist.global_mean_loss(loss.detach() * count, count)
+    mean_loss = bucket.extra[0] / bucket.extra[1]
+    assert float(bucket.extra[1]) == 8.0
+    bucket.flat[:bucket.numel].div_(world)
     gdist.barrier()
     if rank == 0:
-        out.put((bucket.flat.clone(), float(mean_loss)))
+        out.put((bucket.flat[:bucket.numel].clone(), float(mean_loss)))
     dist.destroy_process_group()
 
 
