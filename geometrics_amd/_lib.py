@@ -39,6 +39,9 @@ _SIGNATURES = {
     "geom_sum_f32": [ctypes.c_int64, _vp, _f, _vp, _vp],
     "geom_sum2_f32": [ctypes.c_int64, _vp, _f, ctypes.c_int64, _vp, _f, _vp, _vp],
     "geom_sample_chamfer_bwd_f32": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _f, _vp, _vp],
+    "geom_laplacian_f32": [_i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "geom_edge_sqlen_fwd_f32": [_i, _i, _vp, _i, _vp, _vp, _vp],
+    "geom_edge_sqlen_bwd_f32": [_i, _i, _vp, _i, _vp, _vp, _f, _vp, _vp],
     "geom_adam_step_f32": [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _vp],
     "geom_zn_gcn_aggregate_fwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "geom_zn_gcn_aggregate_ell_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],

@@ -24,7 +24,7 @@ _ACT_NONE, _ACT_RELU, _ACT_ELU = 0, 1, 2
 # --------------------------------------------------------------- CSR cache ----
 class _Csr:
     __slots__ = ("rowptr", "col", "val", "rowptr_t", "col_t", "val_t", "nv", "nnz",
-                 "ell_w", "ell_col", "ell_val", "ell_col_t", "ell_val_t")
+                 "ell_w", "ell_col", "ell_val", "ell_col_t", "ell_val_t", "inv_deg")
 
 
 _csr_cache = {}
@@ -71,6 +71,8 @@ def adjacency_csr(adj):
         c.rowptr_t, c.col_t, c.val_t = _to_csr(dense.t())
         c.nv = adj.shape[0]
         c.nnz = int(c.col.numel())
+        # 1 / (neighbours without the self loop): what batch_get_lap_info divides by on the binary adjacency
+        c.inv_deg = (1.0 / ((c.rowptr[1:] - c.rowptr[:-1]).float() - 1.0)).contiguous()
         longest = int(max((c.rowptr[1:] - c.rowptr[:-1]).max(), (c.rowptr_t[1:] - c.rowptr_t[:-1]).max()))
         c.ell_w = 8 if longest <= 8 else (16 if longest <= 16 else 0)   # ELL fast path for bounded degrees
         if c.ell_w:

@@ -235,6 +235,61 @@ class SurfaceLoss(torch.autograd.Function):
         return grad_verts, None, None, None, None, None, None, None
 
 
+class Laplacian(torch.autograd.Function):
+    """lap = p - mean(neighbours(p)) over the CSR of the binary adjacency (reference
+    batch_get_lap_info, utils.py:654-662, a dense [V,V] @ [B,V,3] there)."""
+
+    @staticmethod
+    def forward(ctx, positions, rowptr, col, inv_deg):
+        x = _f32(positions, "positions", 3, 3)
+        b, nv, _ = x.shape
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.call("geom_laplacian_f32", b, nv, rowptr.data_ptr(), col.data_ptr(), inv_deg.data_ptr(),
+                      x.data_ptr(), 0, out.data_ptr())
+        ctx.save_for_backward(rowptr, col, inv_deg)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        rowptr, col, inv_deg = ctx.saved_tensors
+        g = grad.contiguous()
+        b, nv, _ = g.shape
+        out = torch.empty_like(g)
+        with torch.cuda.device(g.device):
+            _lib.call("geom_laplacian_f32", b, nv, rowptr.data_ptr(), col.data_ptr(), inv_deg.data_ptr(),
+                      g.data_ptr(), 1, out.data_ptr())
+        return out, None, None, None
+
+
+class EdgeSqLenSum(torch.autograd.Function):
+    """sum over meshes and faces of the three squared edge lengths (reference batch_calc_edge,
+    utils.py:636-651, before its means)."""
+
+    @staticmethod
+    def forward(ctx, verts, faces):
+        v = _f32(verts, "verts", 3, 3)
+        faces = _lib.require(faces, "faces", torch.int64, 2, 3)
+        b, nv, _ = v.shape
+        per_face = torch.empty(b, faces.shape[0], dtype=torch.float32, device=v.device)
+        with torch.cuda.device(v.device):
+            _lib.call("geom_edge_sqlen_fwd_f32", b, nv, v.data_ptr(), faces.shape[0], faces.data_ptr(),
+                      per_face.data_ptr())
+        ctx.save_for_backward(v, faces)
+        return device_sum(per_face)
+
+    @staticmethod
+    def backward(ctx, grad):
+        v, faces = ctx.saved_tensors
+        b, nv, _ = v.shape
+        grad = grad.contiguous()
+        grad_verts = torch.zeros_like(v)
+        with torch.cuda.device(v.device):
+            _lib.call("geom_edge_sqlen_bwd_f32", b, nv, v.data_ptr(), faces.shape[0], faces.data_ptr(),
+                      grad.data_ptr(), 1.0, grad_verts.data_ptr())
+        return grad_verts, None
+
+
 _side_streams = {}
 
 
@@ -272,5 +327,6 @@ def draw_samples(verts, faces, num, generator=None):
 
 
 __all__ = ["face_areas", "device_sum", "SampleFaces", "GatherSqDistSum", "PointToTriangleSum", "SurfaceLoss",
+           "Laplacian", "EdgeSqLenSum",
            "draw_samples",
            "chamfer_nn", "tri_distance_indexed"]

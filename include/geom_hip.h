@@ -185,6 +185,20 @@ int geom_zn_gcn_aggregate_ell_bwd_f32(int b, int nv, int c, int k, int w, const 
                                       int act, float *grad_support, float *grad_bias, float *scratch,
                                       void *stream);
 
+/* ---- mesh regularisers (SURVEY 8f "next" row 1; utils.py:636-662, GEOMetrics.py:147-161) ----------------
+ * Laplacian coordinates over the CSR of the BINARY adjacency with self loops (adj_info['adj_orig']):
+ *   transpose == 0:  out[b,v] = x[b,v] - (sum_{j in row v} x[b,j] - x[b,v]) * inv_deg[v]     (batch_get_lap_info)
+ *   transpose != 0:  out[b,v] = g[b,v] - (sum_{j in row v} g[b,j]*inv_deg[j] - g[b,v]*inv_deg[v])   (its adjoint)
+ * x/out [b,nv,3]; inv_deg[v] = 1 / (row length - 1). */
+int geom_laplacian_f32(int b, int nv, const int *rowptr, const int *col, const float *inv_deg,
+                       const float *x, int transpose, float *out, void *stream);
+/* per_face[b,f] = |p2-p1|^2 + |p3-p1|^2 + |p2-p3|^2 (batch_calc_edge = sum / (3*b*nf)); and the gradient of
+ * coef * sum(per_face) scattered into grad_verts (fp32 atomics, caller zero-initialises). */
+int geom_edge_sqlen_fwd_f32(int b, int nv, const float *verts, int nf, const int64_t *faces,
+                            float *per_face, void *stream);
+int geom_edge_sqlen_bwd_f32(int b, int nv, const float *verts, int nf, const int64_t *faces,
+                            const float *coef_dev, float coef_host, float *grad_verts, void *stream);
+
 /* ---- optimiser step for the replicated layer parameters (GEOMetrics.py:73: Adam, lr 1e-4) -----------
  * torch.optim.Adam's update (no weight decay / amsgrad) for up to GEOM_ADAM_MAX_TENSORS tensors in one
  * launch.  params/grads/exp_avg/exp_avg_sq/sizes are HOST arrays of `count` device pointers / lengths;

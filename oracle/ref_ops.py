@@ -139,3 +139,16 @@ def gcn_max(x, adj, weight, bias, activation, batched):
 
 def as_np(t):
     return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def lap_info(positions, adj_orig):
+    """utils.py:654-662: dense neighbour sum minus self, divided by (degree), subtracted from positions."""
+    neighbour_sum = torch.matmul(adj_orig, positions) - positions
+    scaler = (1.0 / (adj_orig.sum(1) - 1)).view(-1, 1)
+    return positions - neighbour_sum * scaler
+
+
+def calc_edge(verts, faces):
+    """utils.py:636-651."""
+    p1, p2, p3 = (verts[:, faces[:, k]] for k in range(3))
+    return (((p2 - p1) ** 2).sum(-1).mean() + ((p3 - p1) ** 2).sum(-1).mean() + ((p2 - p3) ** 2).sum(-1).mean()) / 3.0

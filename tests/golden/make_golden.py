@@ -254,7 +254,27 @@ def make_layers():
     save("layer_adj", adj=adj.numpy())
 
 
+# ------------------------------------------------------------- regularisers ----
+def make_regularisers():
+    V2, F2 = meshgen.icosphere(2)
+    B = 3
+    verts = meshgen.jittered_batch(V2, B, first=9)
+    info = ref_utils.adj_init(t(F2))
+    pv = t(verts, grad=True)
+    lap = ref_utils.batch_get_lap_info(pv, info)
+    g = torch.from_numpy(np.random.default_rng(4).standard_normal(lap.shape).astype(np.float32))
+    lap.backward(g)
+    pe = t(verts, grad=True)
+    edge = ref_utils.batch_calc_edge(pe, info)
+    edge.backward()
+    save("regularisers_v162", verts=verts, faces=F2, lap=lap.detach().numpy(), grad_lap=g.numpy(),
+         grad_verts_lap=pv.grad.numpy(), edge=np.float32(edge.item()), grad_verts_edge=pe.grad.numpy())
+
+
 if __name__ == "__main__":
+    make_regularisers()
+    if "--only-new" in sys.argv:
+        sys.exit(0)
     make_nn()
     make_sampling_and_losses()
     make_adjacency()

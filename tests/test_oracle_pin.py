@@ -162,3 +162,19 @@ def test_layer_restatements(name):
         out = ref_ops.gcn_max(x, adj, torch.from_numpy(g["param.weight_Ws.0"]), torch.from_numpy(g["param.weight_Bs.0"]),
                               LAYER_ACT[name], batched=name.startswith("Batch"))
     np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-5, atol=1e-6)
+
+
+def test_regulariser_restatements():
+    g = golden("regularisers_v162")
+    verts = torch.from_numpy(g["verts"]).requires_grad_(True)
+    faces = torch.from_numpy(g["faces"])
+    adj_orig = ref_ops.calc_adj(faces)
+    lap = ref_ops.lap_info(verts, adj_orig)
+    np.testing.assert_allclose(lap.detach().numpy(), g["lap"], rtol=1e-5, atol=1e-7)
+    lap.backward(torch.from_numpy(g["grad_lap"]))
+    np.testing.assert_allclose(verts.grad.numpy(), g["grad_verts_lap"], rtol=1e-5, atol=1e-6)
+    v2 = torch.from_numpy(g["verts"]).requires_grad_(True)
+    edge = ref_ops.calc_edge(v2, faces)
+    edge.backward()
+    np.testing.assert_allclose(edge.item(), g["edge"], rtol=1e-6)
+    np.testing.assert_allclose(v2.grad.numpy(), g["grad_verts_edge"], rtol=1e-4, atol=1e-8)
