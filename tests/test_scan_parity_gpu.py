@@ -203,3 +203,62 @@ def test_tri_module_contract(gpu):
     assert dist.dtype == torch.float32 and point.dtype == torch.int32 and index.dtype == torch.int32
     assert dist.shape == (1, 64) and not dist.requires_grad
     assert int(point.min()) >= 0 and int(point.max()) <= 6 and int(index.max()) < F.shape[0]
+
+
+def test_size_independent_properties_at_the_config5_shard(gpu):
+    """BASELINE config 5 shard (8 meshes, 3000 vs 3000 points, 5120 faces): properties that need no
+    oracle run -- self-consistency of (distance, index), optimality against random candidates,
+    equivariance under permutation of queries and of targets/triangles, idempotence."""
+    B, N = 8, 3000
+    V, F = meshgen.icosphere(4)
+    verts = _dev(meshgen.jittered_batch(V, B), gpu)
+    faces = _dev(F, gpu)
+    gt = _dev(meshgen.gt_cloud(B, N), gpu)
+    pred = _dev(meshgen.gt_cloud(B, N, first=100), gpu)
+    g = torch.Generator(device="cpu").manual_seed(0)
+
+    d1, i1, d2, i2 = chamfer_nn(gt, pred)
+    # (distance, index) are consistent: the distance is the squared distance to the indexed target
+    picked = torch.gather(pred, 1, i1.long().unsqueeze(-1).expand(-1, -1, 3))
+    assert torch.allclose(((picked - gt) ** 2).sum(-1), d1, rtol=1e-6, atol=0)
+    # optimality: no random other target is closer
+    for _ in range(4):
+        r = torch.randint(0, N, (B, N), generator=g).to(gpu)
+        other = torch.gather(pred, 1, r.unsqueeze(-1).expand(-1, -1, 3))
+        assert bool((((other - gt) ** 2).sum(-1) >= d1 * (1 - 1e-6)).all())
+    # symmetry of the two directions: the pair found from one side bounds the other side's distance
+    assert bool((torch.gather(d2, 1, i1.long()) <= d1).all())
+    # permuting the queries permutes the outputs; permuting the targets relabels the indices
+    perm = torch.stack([torch.randperm(N, generator=g) for _ in range(B)]).to(gpu)
+    gt_p = torch.gather(gt, 1, perm.unsqueeze(-1).expand(-1, -1, 3))
+    d1p, i1p, _, _ = chamfer_nn(gt_p, pred)
+    assert torch.equal(d1p, torch.gather(d1, 1, perm)) and torch.equal(i1p, torch.gather(i1, 1, perm))
+    pred_p = torch.gather(pred, 1, perm.unsqueeze(-1).expand(-1, -1, 3))
+    d1q, i1q, _, _ = chamfer_nn(gt, pred_p)
+    assert torch.equal(d1q, d1)                                  # the minimum does not depend on the order
+    assert torch.equal(torch.gather(perm, 1, i1q.long()), i1.long()) or bool(
+        (torch.gather(pred_p, 1, i1q.long().unsqueeze(-1).expand(-1, -1, 3)) == picked).all())
+    # idempotence / determinism
+    d1r, i1r, d2r, i2r = chamfer_nn(gt, pred)
+    assert torch.equal(d1r, d1) and torch.equal(i1r, i1) and torch.equal(d2r, d2) and torch.equal(i2r, i2)
+
+    dist, option, index = tri_distance_indexed(gt, verts, faces)
+    assert int(index.min()) >= 0 and int(index.max()) < F.shape[0] and int(option.min()) >= 0 and int(option.max()) <= 6
+    # the chosen point is never farther than the nearest corner of the winning triangle
+    corners = verts[torch.arange(B, device=gpu)[:, None, None], faces[index.long()]]          # [B,N,3,3]
+    corner_d = ((corners - gt.unsqueeze(2)) ** 2).sum(-1).min(-1)[0]
+    keep = option != 6                                                                           # Q2: region 6 is off-triangle
+    assert bool((dist[keep] <= corner_d[keep] * (1 + 1e-5) + 1e-12).all())
+    # query permutation equivariance and triangle relabelling invariance of the distance
+    dp, op, ip = tri_distance_indexed(gt_p, verts, faces)
+    assert torch.equal(dp, torch.gather(dist, 1, perm)) and torch.equal(ip, torch.gather(index, 1, perm))
+    fperm = torch.randperm(F.shape[0], generator=g).to(gpu)
+    df, of, jf = tri_distance_indexed(gt, verts, faces[fperm])
+    assert torch.equal(df, dist)
+    # winners on a shared edge / vertex tie bit-exactly between the adjacent triangles, and the tie goes to
+    # the lowest index of the CURRENT order: the distance is order-independent, the label need not be
+    same = fperm[jf.long()] == index.long()
+    assert float(same.float().mean()) > 0.85
+    assert bool(same[option == 0].all())                        # interior winners are unique
+    d_again, o_again, i_again = tri_distance_indexed(gt, verts, faces)
+    assert torch.equal(d_again, dist) and torch.equal(i_again, index) and torch.equal(o_again, option)
