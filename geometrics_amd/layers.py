@@ -9,6 +9,7 @@ the tensor's identity + version) and replaces the reference's dense `adj @ suppo
 `input @ W` stays a library GEMM (rocBLAS/hipBLASLt through torch.matmul).
 """
 import math
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -27,8 +28,7 @@ class _Csr:
                  "ell_w", "ell_col", "ell_val", "ell_col_t", "ell_val_t", "inv_deg")
 
 
-_csr_cache = {}
-_CSR_CACHE_MAX = 16
+_csr_cache = {}   # id(adjacency tensor) -> (weakref, version, _Csr)
 
 
 def _to_csr(dense):
@@ -54,14 +54,16 @@ def _to_ell(rowptr, col, val, width):
 
 
 def adjacency_csr(adj):
-    """CSR + CSR^T of a dense [V,V] adjacency, cached per (storage, shape, version, device).
-    Building it reads the dense matrix once (one host sync, at first use only)."""
+    """CSR + CSR^T (+ ELL tables) of a dense [V,V] adjacency, cached per TENSOR OBJECT and in-place
+    version.  The key is the object's identity guarded by a weak reference -- never the data pointer,
+    which the caching allocator hands to the next adjacency of the same size (auto_encoder.py builds a
+    fresh one per mesh).  Building reads the dense matrix once (one host sync, at first use only)."""
     if adj.dim() != 2 or adj.shape[0] != adj.shape[1]:
         raise RuntimeError("adjacency must be a square [V,V] tensor, got %s" % (tuple(adj.shape),))
-    key = (adj.data_ptr(), tuple(adj.shape), adj._version, str(adj.device), adj.dtype)
+    key = id(adj)
     hit = _csr_cache.get(key)
-    if hit is not None:
-        return hit
+    if hit is not None and hit[0]() is adj and hit[1] == adj._version:
+        return hit[2]
     if not adj.is_cuda:
         raise RuntimeError("adjacency must live on a HIP device; geometrics_amd has no CPU path")
     with torch.no_grad():
@@ -78,9 +80,7 @@ def adjacency_csr(adj):
         if c.ell_w:
             c.ell_col, c.ell_val = _to_ell(c.rowptr, c.col, c.val, c.ell_w)
             c.ell_col_t, c.ell_val_t = _to_ell(c.rowptr_t, c.col_t, c.val_t, c.ell_w)
-    if len(_csr_cache) >= _CSR_CACHE_MAX:
-        _csr_cache.pop(next(iter(_csr_cache)))
-    _csr_cache[key] = c
+    _csr_cache[key] = (weakref.ref(adj, lambda _ref, k=key: _csr_cache.pop(k, None)), adj._version, c)
     return c
 
 

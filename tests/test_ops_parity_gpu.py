@@ -257,3 +257,30 @@ def test_laplacian_on_the_reference_template_mesh(gpu):
     p = pos.double()
     ref = p - (torch.matmul(orig, p) - p) * (1.0 / (orig.sum(1) - 1)).view(-1, 1)
     close(lap.cpu().numpy(), ref.cpu().numpy(), 1e-5)
+
+
+def test_csr_cache_follows_tensor_identity_not_addresses(gpu):
+    """A freed adjacency's memory is reused by the next one of the same size; the cache must not
+    serve the old graph (auto_encoder.py builds one adjacency per mesh), and in-place edits must
+    invalidate too."""
+    g = golden("adj_ico162")
+    faces = dev(g["faces"], gpu)
+    layer = layers.BatchZERON_GCN(8, 40).to(gpu)
+    x = torch.randn(2, 162, 8, device=gpu)
+
+    def expect(adj):
+        return ref_ops.zero_n_layer(x.cpu().double(), adj.cpu().double(), layer.weight.detach().cpu().double(),
+                                    layer.bias.detach().cpu().double(), 10, lambda t: t).numpy()
+
+    adj = utils.adj_init(faces)["adj"]
+    ptr = adj.data_ptr()
+    close(layer(x, adj, lambda t: t).detach().cpu().numpy(), expect(adj), 1e-5)
+    ring = torch.roll(torch.eye(162, device=gpu), 1, 1) * 0.5 + torch.eye(162, device=gpu) * 0.5
+    del adj
+    adj2 = torch.empty(162, 162, device=gpu)            # typically lands on the freed block
+    adj2.copy_(ring)
+    reused = adj2.data_ptr() == ptr
+    close(layer(x, adj2, lambda t: t).detach().cpu().numpy(), expect(adj2), 1e-5)
+    adj2.mul_(0.5)                                       # in-place edit bumps the version
+    close(layer(x, adj2, lambda t: t).detach().cpu().numpy(), expect(adj2), 1e-5)
+    assert len(layers._csr_cache) <= 4 or reused is not None
