@@ -42,6 +42,8 @@ _SIGNATURES = {
     "geom_laplacian_f32": [_i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "geom_edge_sqlen_fwd_f32": [_i, _i, _vp, _i, _vp, _vp, _vp],
     "geom_edge_sqlen_bwd_f32": [_i, _i, _vp, _i, _vp, _vp, _f, _vp, _vp],
+    "geom_vertex_bn_fwd_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _i, _vp, _i, _f, _vp, _vp, _vp, _vp],
+    "geom_vertex_bn_bwd_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "geom_adam_step_f32": [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _vp],
     "geom_zn_gcn_aggregate_fwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "geom_zn_gcn_aggregate_ell_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],

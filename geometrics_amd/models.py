@@ -1,0 +1,129 @@
+"""The mesh deformation block of the reference (models.py:203-297) on the fused HIP kernels:
+same attribute names, constructor and `forward(features, pooled, adj) -> (features, coords)`, and
+the same state_dict keys (`gcN.weight1`, `gcN.bias`, `bnN.weight/bias/running_mean/running_var/
+num_batches_tracked`), so the reference's checkpoints load unchanged.
+
+Per layer pair the reference runs GEMM, dense adjacency product, cat, bias add, a two-pass
+BatchNorm1d(verts), ReLU, add and divide as separate eager ops; here it is GEMM -> one aggregation
+kernel (csrc/zn_gcn.hip) -> one per-vertex BN + ReLU (+ residual average) kernel (csrc/vertex_bn.hip).
+Data-parallel note: like torch's BatchNorm under DDP without SyncBN, statistics are those of the
+LOCAL shard of meshes.
+"""
+import torch
+from torch import nn
+
+from . import _lib
+from .layers import Batch_Image_ZERON_GCNGCN
+
+
+def _identity(x):
+    return x
+
+
+class _VertexBN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, residual, training, momentum, eps, relu, scale):
+        xc = _lib.require(x, "x", torch.float32, 3)
+        b, nv, c = xc.shape
+        dev = xc.device
+        res, res_ld = None, c
+        if residual is not None:
+            res = residual
+            ok = (res.dim() == 3 and res.shape == xc.shape and res.stride(2) == 1 and res.stride(1) >= c
+                  and res.stride(0) == nv * res.stride(1) and res.dtype == torch.float32 and res.is_cuda)
+            if not ok:
+                res = res.contiguous()
+            res_ld = res.stride(1)   # a column slice of a wider row-major tensor is read in place
+        out = torch.empty_like(xc)
+        mean = torch.empty(nv, dtype=torch.float32, device=dev)
+        invstd = torch.empty(nv, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("geom_vertex_bn_fwd_f32", b, nv, c, xc.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
+                      _lib.ptr(running_mean), _lib.ptr(running_var), int(training), float(momentum), float(eps),
+                      int(relu), _lib.ptr(res), res_ld, float(scale), out.data_ptr(), mean.data_ptr(),
+                      invstd.data_ptr())
+        if training:
+            ctx.save_for_backward(xc, weight, bias, mean, invstd)
+        else:
+            inv = torch.rsqrt(running_var + eps)
+            ctx.save_for_backward(xc, weight, bias, running_mean.clone(), inv)
+        ctx.relu, ctx.scale, ctx.has_res, ctx.training = relu, scale, residual is not None, training
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight, bias, mean, invstd = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("backward through the fused vertex BatchNorm is implemented for training mode only")
+        g = grad_out.contiguous()
+        b, nv, c = x.shape
+        grad_x = torch.empty_like(x)
+        grad_res = torch.empty_like(x) if ctx.has_res else None
+        gw = torch.empty(nv, dtype=torch.float32, device=x.device) if weight is not None else None
+        gb = torch.empty(nv, dtype=torch.float32, device=x.device) if bias is not None else None
+        with torch.cuda.device(x.device):
+            _lib.call("geom_vertex_bn_bwd_f32", b, nv, c, x.data_ptr(), g.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
+                      mean.data_ptr(), invstd.data_ptr(), int(ctx.relu), int(ctx.has_res), float(ctx.scale),
+                      grad_x.data_ptr(), _lib.ptr(grad_res), _lib.ptr(gw), _lib.ptr(gb))
+        return grad_x, gw, gb, None, None, grad_res, None, None, None, None, None
+
+
+class VertexBatchNorm(nn.Module):
+    """nn.BatchNorm1d(verts) for [B,V,C] activations with the ReLU and the block's residual average
+    `(residual + relu(bn(x))) / 2` folded into the same kernel.  Parameters and buffers are named as in
+    nn.BatchNorm1d, so `bnN.*` checkpoint entries load unchanged."""
+
+    def __init__(self, verts, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = verts, eps, momentum
+        self.weight = nn.Parameter(torch.ones(verts))
+        self.bias = nn.Parameter(torch.zeros(verts))
+        self.register_buffer("running_mean", torch.zeros(verts))
+        self.register_buffer("running_var", torch.ones(verts))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self._pending_batches = 0   # counted on the host; folded into the buffer when the state is saved
+
+    def forward(self, x, relu=False, residual=None, scale=0.5):
+        b, _, c = x.shape
+        if b * c > 4096 or not x.is_cuda:      # outside the register-resident kernel: library ops, same maths
+            y = nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
+                                         self.training, self.momentum, self.eps)
+            y = torch.relu(y) if relu else y
+            return (residual + y) * scale if residual is not None else y
+        if self.training:
+            self._pending_batches += 1
+        return _VertexBN.apply(x, self.weight, self.bias, self.running_mean, self.running_var, residual,
+                               self.training, self.momentum, self.eps, relu, scale)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        if self._pending_batches:
+            self.num_batches_tracked += self._pending_batches
+            self._pending_batches = 0
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+
+class BatchMeshDeformationBlock(nn.Module):
+    """Reference models.py:203-297: 13 hidden 0N-GCN layers (each followed by BatchNorm1d(verts) + ReLU,
+    a residual average after every pair) and a coordinate head `gc15` (hidden -> output_features)."""
+
+    def __init__(self, input_features, verts, hidden=192, output_features=3):
+        super().__init__()
+        self.hidden = hidden
+        self.gc1 = Batch_Image_ZERON_GCNGCN(input_features, hidden)
+        for i in range(2, 14):
+            setattr(self, "gc%d" % i, Batch_Image_ZERON_GCNGCN(hidden, hidden))
+        self.gc15 = Batch_Image_ZERON_GCNGCN(hidden, output_features)
+        for i in range(1, 15):                       # bn14 exists in the reference (unused) -- kept for the keys
+            setattr(self, "bn%d" % i, VertexBatchNorm(verts))
+
+    def forward(self, features, pooled, adj):
+        full = torch.cat((features, pooled), dim=-1)
+        x = self.bn1(self.gc1(full, adj, _identity), relu=True)
+        feats = self.bn2(self.gc2(x, adj, _identity), relu=True, residual=full[:, :, :self.hidden])
+        for i in (3, 5, 7, 9, 11):
+            x = getattr(self, "bn%d" % i)(getattr(self, "gc%d" % i)(feats, adj, _identity), relu=True)
+            feats = getattr(self, "bn%d" % (i + 1))(getattr(self, "gc%d" % (i + 1))(x, adj, _identity), relu=True,
+                                                    residual=feats)
+        feats = self.bn13(self.gc13(feats, adj, _identity), relu=True, residual=feats)
+        coords = self.gc15(feats, adj, _identity)
+        return feats, coords

@@ -199,6 +199,23 @@ int geom_edge_sqlen_fwd_f32(int b, int nv, const float *verts, int nf, const int
 int geom_edge_sqlen_bwd_f32(int b, int nv, const float *verts, int nf, const int64_t *faces,
                             const float *coef_dev, float coef_host, float *grad_verts, void *stream);
 
+/* ---- per-vertex BatchNorm + ReLU + residual average (SURVEY 8f "next" row 2; models.py:222-297) --------
+ * nn.BatchNorm1d(verts) applied to x [b,nv,c]: one statistic per vertex over its b*c values, then
+ *     out = (residual + act(bn(x))) * scale      (residual == NULL: out = act(bn(x)))
+ * training != 0: batch statistics (biased variance), running stats updated in place with `momentum` and
+ * the unbiased variance, save_mean/save_invstd [nv] written for the backward; training == 0: running stats.
+ * residual may be a column slice of a wider tensor: row stride residual_ld >= c.  b*c <= 4096, else
+ * GEOM_EUNSUPPORTED (callers then use the library ops). */
+int geom_vertex_bn_fwd_f32(int b, int nv, int c, const float *x, const float *weight, const float *bias,
+                           float *running_mean, float *running_var, int training, float momentum, float eps,
+                           int relu, const float *residual, int residual_ld, float scale,
+                           float *out, float *save_mean, float *save_invstd, void *stream);
+/* grad_x, (optional) grad_residual [b,nv,c] = grad_out*scale, grad_weight / grad_bias [nv] (optional). */
+int geom_vertex_bn_bwd_f32(int b, int nv, int c, const float *x, const float *grad_out, const float *weight,
+                           const float *bias, const float *save_mean, const float *save_invstd, int relu,
+                           int has_residual, float scale, float *grad_x, float *grad_residual,
+                           float *grad_weight, float *grad_bias, void *stream);
+
 /* ---- optimiser step for the replicated layer parameters (GEOMetrics.py:73: Adam, lr 1e-4) -----------
  * torch.optim.Adam's update (no weight decay / amsgrad) for up to GEOM_ADAM_MAX_TENSORS tensors in one
  * launch.  params/grads/exp_avg/exp_avg_sq/sizes are HOST arrays of `count` device pointers / lengths;

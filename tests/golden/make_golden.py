@@ -271,7 +271,42 @@ def make_regularisers():
          grad_verts_lap=pv.grad.numpy(), edge=np.float32(edge.item()), grad_verts_edge=pe.grad.numpy())
 
 
+# ------------------------------------------------------------ deformation block ----
+def make_block():
+    import models as ref_models                      # the reference's models.py
+    assert ref_models.__file__.startswith(REF)
+    V2, F2 = meshgen.icosphere(2)
+    adj = ref_utils.adj_init(t(F2))["adj"]
+    torch.manual_seed(44)
+    block = ref_models.BatchMeshDeformationBlock(32, V2.shape[0], hidden=24, output_features=3)
+    block.train()
+    with torch.no_grad():                             # non-trivial BN affine parameters
+        for i in range(1, 14):
+            getattr(block, "bn%d" % i).weight.uniform_(0.5, 1.5)
+            getattr(block, "bn%d" % i).bias.uniform_(-0.2, 0.2)
+    state0 = {k: v.clone() for k, v in block.state_dict().items()}
+    feats = torch.randn(3, V2.shape[0], 3, requires_grad=True)
+    pooled = torch.randn(3, V2.shape[0], 29, requires_grad=True)
+    out_f, coords = block(feats, pooled, adj)
+    gf, gc = torch.randn_like(out_f), torch.randn_like(coords)
+    (out_f * gf).sum().add((coords * gc).sum()).backward()
+    arrays = dict(adj=adj.numpy(), features=feats.detach().numpy(), pooled=pooled.detach().numpy(),
+                  out_features=out_f.detach().numpy(), coords=coords.detach().numpy(), g_features=gf.numpy(),
+                  g_coords=gc.numpy(), grad_features=feats.grad.numpy(), grad_pooled=pooled.grad.numpy())
+    for k, v in state0.items():
+        arrays["state." + k] = v.numpy()
+    for k in ("gc1.weight1", "gc1.bias", "gc7.weight1", "gc15.weight1", "gc15.bias", "bn1.weight", "bn1.bias",
+              "bn13.weight", "bn6.bias"):
+        arrays["grad." + k] = dict(block.named_parameters())[k].grad.numpy()
+    for k in ("bn1.running_mean", "bn1.running_var", "bn13.running_mean", "bn13.running_var"):
+        arrays["after." + k] = block.state_dict()[k].numpy()
+    save("deformation_block_v162", **arrays)
+
+
 if __name__ == "__main__":
+    if "--block" in sys.argv:
+        make_block()
+        sys.exit(0)
     make_regularisers()
     if "--only-new" in sys.argv:
         sys.exit(0)
@@ -279,3 +314,4 @@ if __name__ == "__main__":
     make_sampling_and_losses()
     make_adjacency()
     make_layers()
+    make_block()
