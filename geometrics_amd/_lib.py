@@ -44,6 +44,8 @@ _SIGNATURES = {
     "geom_edge_sqlen_bwd_f32": [_i, _i, _vp, _i, _vp, _vp, _f, _vp, _vp],
     "geom_vertex_bn_fwd_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _i, _vp, _i, _f, _vp, _vp, _vp, _vp],
     "geom_vertex_bn_bwd_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
+    "geom_pool_features_fwd_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "geom_pool_features_bwd_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "geom_adam_step_f32": [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _vp],
     "geom_zn_gcn_aggregate_fwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "geom_zn_gcn_aggregate_ell_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
@@ -79,6 +81,8 @@ def lib():
         if L.geom_abi_version() != ABI_VERSION:
             raise RuntimeError("geometrics_amd: libgeom_hip.so ABI %d != binding ABI %d; rebuild"
                                % (L.geom_abi_version(), ABI_VERSION))
+        L.geom_pool_features_bwd_workspace_bytes.restype = ctypes.c_size_t
+        L.geom_pool_features_bwd_workspace_bytes.argtypes = [_i, _i, _i, _vp]
         L.geom_zn_gcn_bwd_scratch_floats.restype = ctypes.c_int64
         L.geom_zn_gcn_bwd_scratch_floats.argtypes = [_i, _i, _i]
         L.geom_tri_distance_workspace_bytes.restype = ctypes.c_size_t
@@ -93,7 +97,7 @@ def lib():
 
 def declared_symbols():
     return sorted(["geom_abi_version", "geom_strerror", "geom_tri_distance_workspace_bytes",
-                   "geom_zn_gcn_bwd_scratch_floats"] + list(_SIGNATURES))
+                   "geom_zn_gcn_bwd_scratch_floats", "geom_pool_features_bwd_workspace_bytes"] + list(_SIGNATURES))
 
 
 def check(code, what):

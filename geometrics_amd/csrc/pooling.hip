@@ -1,0 +1,379 @@
+// batched_pooling for gfx950: project every vertex into the image and
+// bilinearly pool the encoder's feature maps at that pixel -- the 960 image features of the 963-wide
+// 0N-GCN input.
+//
+// The reference (utils.py:316-389) does this per feature map with ~10 eager ops: a permuted copy of
+// the whole map, four index_selects, eight broadcast products, a cat; ~40 kernels per call, three
+// calls per step.  Here ONE kernel per direction handles all maps:
+//   * a workgroup owns 64 vertices of one mesh; the camera projection is done once per vertex;
+//   * lanes <-> vertices, waves <-> channels: for a channel the 64 lanes read the same [dim x dim]
+//     plane (L1/L2 resident), results go through an LDS tile so that the [B,V,960] output is written
+//     in contiguous 256-byte runs;
+//   * backward, vertices: the output gradient comes in through the same LDS transpose; every (vertex,
+//     channel) accumulates d/d(pixel x,y), chained through clamp, the perspective divide and the camera
+//     matrix to grad_verts in closed form;
+//   * backward, maps: inverted into a gather -- a binning kernel builds texel -> (vertex, weight) lists, then
+//     a wave owns one texel x 64 channels and sums its list with coalesced reads (no float atomics).
+// The reference's interpolation quirk is kept: weights are (ceil - x, x - floor), so a coordinate that
+// is exactly integral (incl. clamped ones) gets all-zero weights (utils.py:346-350, 372-379).
+#include "geom_common.h"
+
+namespace {
+
+constexpr int PL_THREADS = 256;
+constexpr int PL_WAVES = PL_THREADS / GEOM_WAVE;
+constexpr int PL_VERTS = GEOM_WAVE; // vertices per workgroup
+// reference constants (utils.py:321, 329-335)
+constexpr float PL_SCALE = 0.57f, PL_FOCAL = 248.f, PL_HALF = 224.f / 2.0f, PL_NORM = 223.f;
+
+struct PoolArgs {
+    const float *verts, *cam_mat, *cam_pos;
+    const float *blocks[GEOM_POOL_MAX_LEVELS];
+    float *grad_blocks[GEOM_POOL_MAX_LEVELS];
+    int channels[GEOM_POOL_MAX_LEVELS], dims[GEOM_POOL_MAX_LEVELS];
+    int levels, b, nv, ctot;
+};
+
+struct Projection {
+    float X, Y, Z, xs, ys;
+};
+
+__device__ __forceinline__ Projection project(const PoolArgs &a, int mesh, int v)
+{
+    const float *p = a.verts + ((size_t)mesh * a.nv + v) * 3;
+    const float *M = a.cam_mat + (size_t)mesh * 9, *cp = a.cam_pos + (size_t)mesh * 3;
+    const float ax = p[0] * PL_SCALE - cp[0], ay = p[1] * PL_SCALE - cp[1], az = p[2] * PL_SCALE - cp[2];
+    Projection r;
+    r.X = (ax * M[0] + ay * M[1]) + az * M[2];
+    r.Y = (ax * M[3] + ay * M[4]) + az * M[5];
+    r.Z = (ax * M[6] + ay * M[7]) + az * M[8];
+    const float h = (-r.Y) / (-r.Z) * PL_FOCAL + PL_HALF;
+    const float w = r.X / (-r.Z) * PL_FOCAL + PL_HALF;
+    r.xs = h / PL_NORM;
+    r.ys = w / PL_NORM;
+    return r;
+}
+
+struct Texel {
+    int i11, i12, i21, i22;
+    float A, B, G, H; // x2-x, x-x1, y2-y, y-y1
+    bool in_x, in_y;  // clamp passes the gradient
+};
+
+__device__ __forceinline__ Texel texel(float xs, float ys, int dim)
+{
+    const float rx = xs * dim, ry = ys * dim, hi = (float)(dim - 1);
+    const float cx = fminf(fmaxf(rx, 0.f), hi), cy = fminf(fmaxf(ry, 0.f), hi);
+    const float x1 = floorf(cx), x2 = ceilf(cx), y1 = floorf(cy), y2 = ceilf(cy);
+    Texel t;
+    t.A = x2 - cx, t.B = cx - x1, t.G = y2 - cy, t.H = cy - y1;
+    const int ix1 = (int)x1, ix2 = (int)x2, iy1 = (int)y1, iy2 = (int)y2;
+    t.i11 = ix1 * dim + iy1, t.i12 = ix1 * dim + iy2, t.i21 = ix2 * dim + iy1, t.i22 = ix2 * dim + iy2;
+    t.in_x = rx >= 0.f && rx <= hi;
+    t.in_y = ry >= 0.f && ry <= hi;
+    return t;
+}
+
+__global__ __launch_bounds__(PL_THREADS) void pool_fwd_kernel(PoolArgs a, float *out)
+{
+    __shared__ float tile[PL_VERTS][GEOM_WAVE + 1];
+    const int mesh = blockIdx.y, v0 = blockIdx.x * PL_VERTS;
+    const int lane = threadIdx.x & (GEOM_WAVE - 1), wave = threadIdx.x >> 6;
+    const int v = min(v0 + lane, a.nv - 1);
+    const Projection pr = project(a, mesh, v);
+    int off = 0;
+    for (int l = 0; l < a.levels; ++l) {
+        const int dim = a.dims[l], C = a.channels[l];
+        const Texel t = texel(pr.xs, pr.ys, dim);
+        const float *blk = a.blocks[l] + (size_t)mesh * C * dim * dim;
+        for (int cc = 0; cc < C; cc += GEOM_WAVE) {
+            const int nch = min(GEOM_WAVE, C - cc);
+            for (int c = wave; c < nch; c += PL_WAVES) {
+                const float *plane = blk + (size_t)(cc + c) * dim * dim;
+                const float s1 = (t.A * plane[t.i11]) * t.G, s2 = (t.H * plane[t.i12]) * t.A;
+                const float s3 = (t.G * plane[t.i21]) * t.B, s4 = (t.B * plane[t.i22]) * t.H;
+                tile[lane][c] = ((s1 + s2) + s3) + s4;
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < PL_VERTS * nch; i += PL_THREADS) {
+                const int vv = i / nch, ch = i - vv * nch;
+                if (v0 + vv < a.nv) out[((size_t)mesh * a.nv + v0 + vv) * a.ctot + off + cc + ch] = tile[vv][ch];
+            }
+            __syncthreads();
+        }
+        off += C;
+    }
+}
+
+// d loss / d verts: vertex-tiled like the forward (the gradient w.r.t. a vertex sums over all channels)
+__global__ __launch_bounds__(PL_THREADS) void pool_bwd_verts_kernel(PoolArgs a, const float *grad_out, float *grad_verts)
+{
+    __shared__ float tile[PL_VERTS][GEOM_WAVE + 1];
+    __shared__ float part[PL_WAVES][2][PL_VERTS];
+    const int mesh = blockIdx.y, v0 = blockIdx.x * PL_VERTS;
+    const int lane = threadIdx.x & (GEOM_WAVE - 1), wave = threadIdx.x >> 6;
+    const bool live = v0 + lane < a.nv;
+    const int v = min(v0 + lane, a.nv - 1);
+    const Projection pr = project(a, mesh, v);
+    float g_xs = 0.f, g_ys = 0.f; // this wave's share of d loss / d (xs, ys) of the lane's vertex
+    int off = 0;
+    for (int l = 0; l < a.levels; ++l) {
+        const int dim = a.dims[l], C = a.channels[l];
+        const Texel t = texel(pr.xs, pr.ys, dim);
+        const float *blk = a.blocks[l] + (size_t)mesh * C * dim * dim;
+        float gx = 0.f, gy = 0.f;
+        for (int cc = 0; cc < C; cc += GEOM_WAVE) {
+            const int nch = min(GEOM_WAVE, C - cc);
+            for (int i = threadIdx.x; i < PL_VERTS * nch; i += PL_THREADS) {
+                const int vv = i / nch, ch = i - vv * nch;
+                tile[vv][ch] = v0 + vv < a.nv ? grad_out[((size_t)mesh * a.nv + v0 + vv) * a.ctot + off + cc + ch] : 0.f;
+            }
+            __syncthreads();
+            if (live) {
+                for (int c = wave; c < nch; c += PL_WAVES) {
+                    const size_t po = (size_t)(cc + c) * dim * dim;
+                    const float g = tile[lane][c];
+                    const float c11 = blk[po + t.i11], c12 = blk[po + t.i12], c21 = blk[po + t.i21], c22 = blk[po + t.i22];
+                    gx += g * (((-c11 * t.G) - (t.H * c12)) + ((t.G * c21) + (c22 * t.H)));
+                    gy += g * (((-t.A * c11) + (c12 * t.A)) + ((-c21 * t.B) + (t.B * c22)));
+                }
+            }
+            __syncthreads();
+        }
+        if (t.in_x) g_xs += gx * dim;
+        if (t.in_y) g_ys += gy * dim;
+        off += C;
+    }
+    part[wave][0][lane] = g_xs;
+    part[wave][1][lane] = g_ys;
+    __syncthreads();
+    if (wave == 0 && live) {
+        float sx = 0.f, sy = 0.f;
+        for (int w = 0; w < PL_WAVES; ++w) {
+            sx += part[w][0][lane];
+            sy += part[w][1][lane];
+        }
+        // xs = h/223, ys = w/223; h = (-Y)/(-Z)*F + 112, w = X/(-Z)*F + 112
+        const float gh = sx / PL_NORM, gw = sy / PL_NORM;
+        const float d = -pr.Z;
+        const float gX = gw * (PL_FOCAL / d);
+        const float gY = -gh * (PL_FOCAL / d);
+        const float gZ = (gh * ((-pr.Y) * PL_FOCAL) + gw * (pr.X * PL_FOCAL)) / (d * d); // d(.)/dd * dd/dZ, dd/dZ = -1 twice
+        const float *M = a.cam_mat + (size_t)mesh * 9;
+        float *gv = grad_verts + ((size_t)mesh * a.nv + v) * 3;
+        gv[0] = PL_SCALE * ((gX * M[0] + gY * M[3]) + gZ * M[6]);
+        gv[1] = PL_SCALE * ((gX * M[1] + gY * M[4]) + gZ * M[7]);
+        gv[2] = PL_SCALE * ((gX * M[2] + gY * M[5]) + gZ * M[8]);
+    }
+}
+
+// d loss / d maps as a GATHER (no floating-point atomics anywhere).
+//
+// Scattering a vertex's four texel contributions is hostile to this hardware: the maps are as small as
+// 7x7, so global fp32 atomics from 2562 vertices pile up on a few addresses (4.4 ms per call measured),
+// LDS ds_add_f32 costs ~1700 cycles per wave instruction whatever the addresses (2 ms), and wave-private
+// LDS planes with plain adds are a serial walk over the vertices (0.8 ms).  So the scatter is inverted:
+//   1. pool_bin_kernel, one workgroup per (mesh, level): counts the contributions per texel (INTEGER LDS
+//      atomics), scans, and fills texel -> (vertex, weight) lists in the workspace;
+//   2. pool_gather_kernel: a wave owns one texel x 64 channels, lanes <-> channels, and sums
+//      w * grad_out[b, v, c] over the texel's list -- every read is a contiguous 256-byte run of the
+//      gradient row, every output is written exactly once (nothing to zero-initialise).
+// The order inside a list follows the atomic cursor, so the fp32 summation order can differ between runs
+// (as with torch's own index_add backward); contributions with zero weight are dropped.
+constexpr int BIN_THREADS = 256;
+constexpr int BIN_MAX_TEXELS = 4096; // dim <= 64
+
+struct BinSpace {
+    int *offsets;   // per (mesh, level): dim*dim + 1 ints, level-major inside a mesh
+    int *ent_v;     // per (mesh, level): 4*nv vertex ids
+    float *ent_w;   // per (mesh, level): 4*nv weights
+    int off_stride; // ints per mesh in `offsets`
+    int level_off[GEOM_POOL_MAX_LEVELS]; // start of level l inside a mesh's offsets block
+};
+
+__global__ __launch_bounds__(BIN_THREADS) void pool_bin_kernel(PoolArgs a, BinSpace ws)
+{
+    __shared__ int counts[BIN_MAX_TEXELS + 1];
+    __shared__ int wave_sum[BIN_THREADS / GEOM_WAVE];
+    const int l = blockIdx.x, mesh = blockIdx.y;
+    const int dim = a.dims[l], texels = dim * dim;
+    for (int i = threadIdx.x; i <= texels; i += BIN_THREADS) counts[i] = 0;
+    __syncthreads();
+    for (int v = threadIdx.x; v < a.nv; v += BIN_THREADS) {
+        const Projection pr = project(a, mesh, v);
+        const Texel t = texel(pr.xs, pr.ys, dim);
+        if (t.G * t.A != 0.f) atomicAdd(&counts[t.i11], 1);
+        if (t.A * t.H != 0.f) atomicAdd(&counts[t.i12], 1);
+        if (t.B * t.G != 0.f) atomicAdd(&counts[t.i21], 1);
+        if (t.H * t.B != 0.f) atomicAdd(&counts[t.i22], 1);
+    }
+    __syncthreads();
+    // exclusive scan of counts[0..texels): thread owns a contiguous run, wave shuffle scan, wave totals
+    const int per = (texels + BIN_THREADS - 1) / BIN_THREADS;
+    const int i0 = threadIdx.x * per;
+    int run = 0;
+    for (int i = i0; i < min(i0 + per, texels); ++i) run += counts[i];
+    const int lane = threadIdx.x & (GEOM_WAVE - 1), wave = threadIdx.x >> 6;
+    int incl = run;
+    for (int o = 1; o < GEOM_WAVE; o <<= 1) {
+        const int t = __shfl_up(incl, o, GEOM_WAVE);
+        if (lane >= o) incl += t;
+    }
+    if (lane == GEOM_WAVE - 1) wave_sum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wave_sum[w];
+    int excl = base + incl - run;
+    int *offs = ws.offsets + (size_t)mesh * ws.off_stride + ws.level_off[l];
+    for (int i = i0; i < min(i0 + per, texels); ++i) {
+        const int c = counts[i];
+        counts[i] = excl; // becomes the fill cursor
+        offs[i] = excl;
+        excl += c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int w = 0; w < BIN_THREADS / GEOM_WAVE; ++w) total += wave_sum[w];
+        offs[texels] = total;
+    }
+    int *ev = ws.ent_v + ((size_t)mesh * a.levels + l) * 4 * a.nv;
+    float *ew = ws.ent_w + ((size_t)mesh * a.levels + l) * 4 * a.nv;
+    for (int v = threadIdx.x; v < a.nv; v += BIN_THREADS) {
+        const Projection pr = project(a, mesh, v);
+        const Texel t = texel(pr.xs, pr.ys, dim);
+        const float w11 = t.G * t.A, w12 = t.A * t.H, w21 = t.B * t.G, w22 = t.H * t.B;
+        if (w11 != 0.f) { const int p = atomicAdd(&counts[t.i11], 1); ev[p] = v; ew[p] = w11; }
+        if (w12 != 0.f) { const int p = atomicAdd(&counts[t.i12], 1); ev[p] = v; ew[p] = w12; }
+        if (w21 != 0.f) { const int p = atomicAdd(&counts[t.i21], 1); ev[p] = v; ew[p] = w21; }
+        if (w22 != 0.f) { const int p = atomicAdd(&counts[t.i22], 1); ev[p] = v; ew[p] = w22; }
+    }
+}
+
+// tasks per mesh are enumerated level by level: texel-major, then 64-channel chunk
+__global__ __launch_bounds__(PL_THREADS) void pool_gather_kernel(PoolArgs a, BinSpace ws, const float *grad_out,
+                                                                 int tasks_per_mesh)
+{
+    const int lane = threadIdx.x & (GEOM_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int task = blockIdx.x * PL_WAVES + wave;
+    const int mesh = blockIdx.y;
+    if (task >= tasks_per_mesh) return;
+    int l = 0, off = 0;
+    for (;; ++l) {
+        const int n = a.dims[l] * a.dims[l] * ((a.channels[l] + GEOM_WAVE - 1) / GEOM_WAVE);
+        if (task < n) break;
+        task -= n;
+        off += a.channels[l];
+    }
+    if (!a.grad_blocks[l]) return; // wave-uniform
+    const int dim = a.dims[l], C = a.channels[l], texels = dim * dim;
+    const int chunks = (C + GEOM_WAVE - 1) / GEOM_WAVE;
+    const int tx = task / chunks, c = (task - tx * chunks) * GEOM_WAVE + lane;
+    const int *offs = ws.offsets + (size_t)mesh * ws.off_stride + ws.level_off[l];
+    const int *ev = ws.ent_v + ((size_t)mesh * a.levels + l) * 4 * a.nv;
+    const float *ew = ws.ent_w + ((size_t)mesh * a.levels + l) * 4 * a.nv;
+    const int e0 = offs[tx], e1 = offs[tx + 1];
+    const float *g = grad_out + (size_t)mesh * a.nv * a.ctot + off + (c < C ? c : 0);
+    float acc = 0.f;
+    int e = e0;
+    for (; e + 4 <= e1; e += 4) { // four rows in flight
+        const int v0 = ev[e], v1 = ev[e + 1], v2 = ev[e + 2], v3 = ev[e + 3];
+        const float w0 = ew[e], w1 = ew[e + 1], w2 = ew[e + 2], w3 = ew[e + 3];
+        const float g0 = g[(size_t)v0 * a.ctot], g1 = g[(size_t)v1 * a.ctot];
+        const float g2 = g[(size_t)v2 * a.ctot], g3 = g[(size_t)v3 * a.ctot];
+        acc += g0 * w0;
+        acc += g1 * w1;
+        acc += g2 * w2;
+        acc += g3 * w3;
+    }
+    for (; e < e1; ++e) acc += g[(size_t)ev[e] * a.ctot] * ew[e];
+    if (c < C) a.grad_blocks[l][((size_t)mesh * C + c) * texels + tx] = acc;
+}
+
+int fill_args(PoolArgs &a, int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos, int levels,
+              const float *const *blocks, const int *channels, const int *dims)
+{
+    if (b < 0 || nv < 0 || levels < 0 || levels > GEOM_POOL_MAX_LEVELS) return GEOM_EINVAL;
+    if (!verts || !cam_mat || !cam_pos || (levels > 0 && (!blocks || !channels || !dims))) return GEOM_EINVAL;
+    if (b > 65535) return GEOM_ETOOBIG;
+    a.verts = verts, a.cam_mat = cam_mat, a.cam_pos = cam_pos, a.levels = levels, a.b = b, a.nv = nv, a.ctot = 0;
+    for (int l = 0; l < levels; ++l) {
+        if (!blocks[l] || channels[l] <= 0 || dims[l] <= 0) return GEOM_EINVAL;
+        a.blocks[l] = blocks[l], a.grad_blocks[l] = nullptr, a.channels[l] = channels[l], a.dims[l] = dims[l];
+        a.ctot += channels[l];
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" int geom_pool_features_fwd_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos,
+                                          int levels, const float *const *blocks, const int *channels, const int *dims,
+                                          float *out, void *stream)
+{
+    PoolArgs a;
+    if (int rc = fill_args(a, b, nv, verts, cam_mat, cam_pos, levels, blocks, channels, dims)) return rc;
+    if (b == 0 || nv == 0 || levels == 0) return 0;
+    if (!out) return GEOM_EINVAL;
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3((nv + PL_VERTS - 1) / PL_VERTS, b), dim3(PL_THREADS), 0,
+                       static_cast<hipStream_t>(stream), a, out);
+    return geom::launch_status();
+}
+
+static size_t pool_ws_layout(int b, int nv, int levels, const int *dims, BinSpace *ws, void *base)
+{
+    int per_mesh = 0;
+    for (int l = 0; l < levels; ++l) {
+        if (ws) ws->level_off[l] = per_mesh;
+        per_mesh += dims[l] * dims[l] + 1;
+    }
+    const size_t off_bytes = ((size_t)b * per_mesh * sizeof(int) + 15) / 16 * 16;
+    const size_t ent = (size_t)b * levels * 4 * nv;
+    if (ws) {
+        char *p = static_cast<char *>(base);
+        ws->offsets = reinterpret_cast<int *>(p);
+        ws->ent_v = reinterpret_cast<int *>(p + off_bytes);
+        ws->ent_w = reinterpret_cast<float *>(p + off_bytes + ent * sizeof(int));
+        ws->off_stride = per_mesh;
+    }
+    return off_bytes + ent * (sizeof(int) + sizeof(float));
+}
+
+extern "C" size_t geom_pool_features_bwd_workspace_bytes(int b, int nv, int levels, const int *dims)
+{
+    if (b <= 0 || nv <= 0 || levels <= 0 || levels > GEOM_POOL_MAX_LEVELS || !dims) return 0;
+    return pool_ws_layout(b, nv, levels, dims, nullptr, nullptr);
+}
+
+extern "C" int geom_pool_features_bwd_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos,
+                                          int levels, const float *const *blocks, const int *channels, const int *dims,
+                                          const float *grad_out, float *const *grad_blocks, float *grad_verts,
+                                          void *workspace, size_t workspace_bytes, void *stream)
+{
+    PoolArgs a;
+    if (int rc = fill_args(a, b, nv, verts, cam_mat, cam_pos, levels, blocks, channels, dims)) return rc;
+    if (b == 0 || nv == 0 || levels == 0) return 0;
+    if (!grad_out) return GEOM_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    bool any_map = false;
+    int tasks = 0;
+    for (int l = 0; l < levels; ++l) {
+        a.grad_blocks[l] = grad_blocks ? grad_blocks[l] : nullptr;
+        any_map = any_map || a.grad_blocks[l];
+        if (dims[l] * dims[l] > BIN_MAX_TEXELS) return GEOM_EUNSUPPORTED;
+        tasks += dims[l] * dims[l] * ((channels[l] + GEOM_WAVE - 1) / GEOM_WAVE);
+    }
+    if (any_map) {
+        BinSpace ws;
+        const size_t need = pool_ws_layout(b, nv, levels, dims, &ws, workspace);
+        if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return GEOM_EINVAL;
+        hipLaunchKernelGGL(pool_bin_kernel, dim3(levels, b), dim3(BIN_THREADS), 0, s, a, ws);
+        hipLaunchKernelGGL(pool_gather_kernel, dim3((tasks + PL_WAVES - 1) / PL_WAVES, b), dim3(PL_THREADS), 0, s, a, ws,
+                           grad_out, tasks);
+    }
+    if (grad_verts)
+        hipLaunchKernelGGL(pool_bwd_verts_kernel, dim3((nv + PL_VERTS - 1) / PL_VERTS, b), dim3(PL_THREADS), 0, s, a,
+                           grad_out, grad_verts);
+    return geom::launch_status();
+}

@@ -290,6 +290,56 @@ class EdgeSqLenSum(torch.autograd.Function):
         return grad_verts, None
 
 
+class PoolFeatures(torch.autograd.Function):
+    """Bilinear pooling of the image feature maps at the projected vertex positions (reference
+    batched_pooling, utils.py:316-389): one kernel forward, one backward (texel scatters + closed-form
+    chain to the vertex positions)."""
+
+    @staticmethod
+    def forward(ctx, verts, cam_mat, cam_pos, *blocks):
+        import ctypes
+        v = _f32(verts, "verts_pos", 3, 3)
+        cam_mat = _f32(cam_mat, "cam_mat", 3, 3)
+        cam_pos = _f32(cam_pos, "cam_pos", 2, 3)
+        blks = [_f32(b, "block", 4) for b in blocks]
+        b, nv, _ = v.shape
+        for blk in blks:
+            if blk.shape[0] != b or blk.shape[2] != blk.shape[3]:
+                raise RuntimeError("feature maps must be [B, C, dim, dim] with the vertex batch size")
+        n = len(blks)
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in blks])
+        chans = (ctypes.c_int * n)(*[t.shape[1] for t in blks])
+        dims = (ctypes.c_int * n)(*[t.shape[2] for t in blks])
+        out = torch.empty(b, nv, sum(t.shape[1] for t in blks), dtype=torch.float32, device=v.device)
+        with torch.cuda.device(v.device):
+            _lib.call("geom_pool_features_fwd_f32", b, nv, v.data_ptr(), cam_mat.data_ptr(), cam_pos.data_ptr(), n,
+                      ptrs, chans, dims, out.data_ptr())
+        ctx.save_for_backward(v, cam_mat, cam_pos, *blks)
+        ctx.meta = (ptrs, chans, dims, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        import ctypes
+        v, cam_mat, cam_pos = ctx.saved_tensors[:3]
+        blks = ctx.saved_tensors[3:]
+        ptrs, chans, dims, n = ctx.meta
+        g = grad_out.contiguous()
+        b, nv, _ = v.shape
+        need_blocks = [ctx.needs_input_grad[3 + i] for i in range(n)]
+        gblks = [torch.empty_like(t) if need else None for t, need in zip(blks, need_blocks)]
+        gptrs = (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in gblks])
+        gverts = torch.empty_like(v) if ctx.needs_input_grad[0] else None
+        ws, ws_bytes = None, 0
+        if any(need_blocks):   # texel -> (vertex, weight) lists for the gather formulation of the map gradient
+            ws_bytes = _lib.lib().geom_pool_features_bwd_workspace_bytes(b, nv, n, dims)
+            ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=v.device)
+        with torch.cuda.device(v.device):
+            _lib.call("geom_pool_features_bwd_f32", b, nv, v.data_ptr(), cam_mat.data_ptr(), cam_pos.data_ptr(), n,
+                      ptrs, chans, dims, g.data_ptr(), gptrs, _lib.ptr(gverts), _lib.ptr(ws), ws_bytes)
+        return (gverts, None, None) + tuple(gblks)
+
+
 _side_streams = {}
 
 
@@ -327,6 +377,6 @@ def draw_samples(verts, faces, num, generator=None):
 
 
 __all__ = ["face_areas", "device_sum", "SampleFaces", "GatherSqDistSum", "PointToTriangleSum", "SurfaceLoss",
-           "Laplacian", "EdgeSqLenSum",
+           "Laplacian", "EdgeSqLenSum", "PoolFeatures",
            "draw_samples",
            "chamfer_nn", "tri_distance_indexed"]

@@ -216,6 +216,26 @@ int geom_vertex_bn_bwd_f32(int b, int nv, int c, const float *x, const float *gr
                            int has_residual, float scale, float *grad_x, float *grad_residual,
                            float *grad_weight, float *grad_bias, void *stream);
 
+/* ---- image-feature pooling (SURVEY 8f "next" row 3; utils.py:316-389 batched_pooling) -----------------
+ * out[b,v,:] = concat over `levels` feature maps blocks[l] [b, channels[l], dims[l], dims[l]] (NCHW) of the
+ * reference's bilinear pooling at the pixel vertex v projects to: p' = cam_mat[b] . (0.57*verts[b,v] -
+ * cam_pos[b]), h = (-Y)/(-Z)*248 + 112, w = X/(-Z)*248 + 112, (xs, ys) = (h, w)/223, per map clamp(xs*dim,
+ * 0, dim-1) with weights (ceil-x, x-floor) (utils.py:321-350).  blocks/channels/dims (and grad_blocks) are
+ * HOST arrays of `levels` <= GEOM_POOL_MAX_LEVELS entries.  Backward: grad_blocks[l] (entries or the array
+ * may be NULL) and grad_verts [b,nv,3] (may be NULL) are fully overwritten (nothing to zero-initialise).  The
+ * map gradient is computed as a gather over texel -> (vertex, weight) lists built in `workspace` (device,
+ * 16-byte aligned, >= geom_pool_features_bwd_workspace_bytes(...) bytes; may be NULL when no map gradient
+ * is requested); dims[l] <= 64, else GEOM_EUNSUPPORTED. */
+size_t geom_pool_features_bwd_workspace_bytes(int b, int nv, int levels, const int *dims);
+#define GEOM_POOL_MAX_LEVELS 8
+int geom_pool_features_fwd_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos,
+                               int levels, const float *const *blocks, const int *channels, const int *dims,
+                               float *out, void *stream);
+int geom_pool_features_bwd_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos,
+                               int levels, const float *const *blocks, const int *channels, const int *dims,
+                               const float *grad_out, float *const *grad_blocks, float *grad_verts,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- optimiser step for the replicated layer parameters (GEOMetrics.py:73: Adam, lr 1e-4) -----------
  * torch.optim.Adam's update (no weight decay / amsgrad) for up to GEOM_ADAM_MAX_TENSORS tensors in one
  * launch.  params/grads/exp_avg/exp_avg_sq/sizes are HOST arrays of `count` device pointers / lengths;

@@ -32,6 +32,7 @@ _spec.loader.exec_module(_reference_utils)
 
 globals().update({k: v for k, v in vars(_reference_utils).items() if not k.startswith("__")})
 
-from geometrics_amd.utils import (Plane, adj_init, batch_calc_edge, batch_get_lap_info,  # noqa: E402,F401
-                                  batch_point_to_point, batch_point_to_surface, batch_sample, calc_adj,
-                                  calc_point_to_line, chamfer_dist, edge, normalize_adj, tri_dist)
+from geometrics_amd.utils import (Plane, adj_init, batch_calc_edge, batch_camera_info,  # noqa: E402,F401
+                                  batch_get_lap_info, batch_point_to_point, batch_point_to_surface, batch_sample,
+                                  batched_pooling, calc_adj, calc_point_to_line, chamfer_dist, edge, normalize_adj,
+                                  tri_dist)

@@ -303,7 +303,35 @@ def make_block():
     save("deformation_block_v162", **arrays)
 
 
+# --------------------------------------------------------------- image pooling ----
+def make_pooling():
+    torch.cuda.LongTensor = torch.LongTensor          # the reference casts indices with .type(torch.cuda.LongTensor)
+    V2, _ = meshgen.icosphere(2)
+    B = 2
+    rng = np.random.default_rng(17)
+    verts = meshgen.jittered_batch(V2, B, first=3)
+    verts[:, :12] *= 3.0                               # some vertices project outside the image -> clamped
+    info = np.stack([rng.uniform(0, 360, B), rng.uniform(10, 40, B), rng.uniform(0.9, 1.3, B)], 1).astype(np.float32)
+    chans, dims = (4, 8, 8, 16), (56, 28, 14, 7)
+    blocks = [torch.from_numpy(rng.standard_normal((B, c, d, d)).astype(np.float32)).requires_grad_(True)
+              for c, d in zip(chans, dims)]
+    pv = t(verts, grad=True)
+    feats = ref_utils.batched_pooling(blocks, pv, t(info))
+    g = torch.from_numpy(rng.standard_normal(tuple(feats.shape)).astype(np.float32))
+    feats.backward(g)
+    cam_mat, cam_pos = ref_utils.batch_camera_info(t(info))
+    arrays = dict(verts=verts, img_info=info, features=feats.detach().numpy(), grad_out=g.numpy(),
+                  grad_verts=pv.grad.numpy(), cam_mat=cam_mat.numpy(), cam_pos=cam_pos.numpy())
+    for i, blk in enumerate(blocks):
+        arrays["block%d" % i] = blk.detach().numpy()
+        arrays["grad_block%d" % i] = blk.grad.numpy()
+    save("pooling_v162", **arrays)
+
+
 if __name__ == "__main__":
+    if "--pooling" in sys.argv:
+        make_pooling()
+        sys.exit(0)
     if "--block" in sys.argv:
         make_block()
         sys.exit(0)
@@ -315,3 +343,4 @@ if __name__ == "__main__":
     make_adjacency()
     make_layers()
     make_block()
+    make_pooling()

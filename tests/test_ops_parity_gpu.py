@@ -346,3 +346,25 @@ def test_vertex_batchnorm_matches_torch(gpu):
     big = torch.randn(30, 50, 192, device=gpu)                # b*c > 4096: library-op route, same result
     bn.train(), ref.train()
     close(bn(big, relu=True).detach().cpu().numpy(), torch.relu(ref(big)).detach().cpu().numpy(), 1e-5)
+
+
+def test_batched_pooling_matches_reference_fixture(gpu):
+    """camera projection + bilinear pooling of four feature maps, forward and the
+    gradients w.r.t. the maps and the vertex positions, against the reference's own batched_pooling."""
+    g = golden("pooling_v162")
+    cam_mat, cam_pos = utils.batch_camera_info(dev(g["img_info"], gpu))
+    close(cam_mat.cpu().numpy(), g["cam_mat"], 1e-6)
+    close(cam_pos.cpu().numpy(), g["cam_pos"], 1e-6)
+    blocks = [dev(g["block%d" % i], gpu, grad=True) for i in range(4)]
+    verts = dev(g["verts"], gpu, grad=True)
+    feats = utils.batched_pooling(blocks, verts, dev(g["img_info"], gpu))
+    assert feats.shape == (2, 162, 36)
+    # the pixel coordinate is scaled by the map resolution (up to 56), which amplifies the fp32 round-off of
+    # the projection (the reference's own matmul order is BLAS-dependent); the maps here are white noise
+    close(feats.detach().cpu().numpy(), g["features"], 3e-5)
+    feats.backward(dev(g["grad_out"], gpu))
+    for i, blk in enumerate(blocks):
+        close(blk.grad.cpu().numpy(), g["grad_block%d" % i], 3e-5)
+    close(verts.grad.cpu().numpy(), g["grad_verts"], 2e-4)
+    # clamped vertices exist in the fixture (zero position gradient through the clamp) and are reproduced
+    assert (np.abs(g["grad_verts"]).sum(-1) == 0).any()

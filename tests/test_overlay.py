@@ -34,7 +34,9 @@ assert utils._reference_utils.__file__.startswith(REF)
 for n in ("batch_sample", "batch_point_to_point", "batch_point_to_surface", "calc_point_to_line", "adj_init",
           "calc_adj", "normalize_adj", "edge", "Plane", "chamfer_dist", "tri_dist"):
     assert getattr(utils, n) is getattr(gu, n), n
-for n in ("load_initial", "ObjLoader", "Mesh_loader", "Voxel_loader", "batched_pooling", "batch_camera_info"):
+for n in ("batched_pooling", "batch_camera_info", "batch_calc_edge", "batch_get_lap_info"):
+    assert getattr(utils, n) is getattr(gu, n), n
+for n in ("load_initial", "ObjLoader", "Mesh_loader", "Voxel_loader", "render_mesh"):
     assert getattr(utils, n) is getattr(utils._reference_utils, n), n       # untouched reference code
 for n in ("ZERON_GCN", "GCNMax", "Batch_Image_ZERON_GCNGCN", "BatchZERON_GCN", "BatchGCNMax"):
     assert getattr(layers, n) is getattr(gl, n), n
