@@ -238,6 +238,53 @@ def kernel_rooflines(w):
     return roofline, others
 
 
+def component_times(w):
+    """Kernel time of each stage of the step on the step's own tensors (HIP-graph replay + HIP events,
+    microseconds per shard of `batch` meshes).  Stages overlap inside the real step (two streams), so the
+    sum exceeds ms_per_step; this is the per-component view SURVEY 8(d) asks for."""
+    from geometrics_amd import ops
+    out = {}
+    pos = w.positions().detach().contiguous()
+    out["sampling (draws + gather/barycentric)"] = event_time_us(lambda: utils.batch_sample(pos, w.faces, num=S_PTS))
+    pred = utils.batch_sample(pos, w.faces, num=S_PTS)
+    out["chamfer NN, both directions"] = event_time_us(lambda: chamfer_nn(w.gt, pred))
+    out["tri_distance (prep + culled scan)"] = event_time_us(lambda: tri_distance_indexed(w.gt, pos, w.faces))
+    pv = pos.clone().requires_grad_(True)
+
+    def loss_fb():
+        pv.grad = None
+        utils.batch_point_to_surface(pv, w.info, w.gt, num=S_PTS).backward()
+    out["surface loss fwd+bwd (sampling, NN || tri, sums, scatters)"] = event_time_us(loss_fb, iters=10)
+
+    def gcn_fwd():
+        with torch.no_grad():
+            w.positions()
+    out["0N-GCN stack forward (3 GEMM + 3 aggregation)"] = event_time_us(gcn_fwd, iters=10)
+
+    def gcn_fb():
+        w.opt.zero_grad()
+        w.feat.grad = None
+        w.positions().sum().backward()
+    out["0N-GCN stack forward+backward"] = event_time_us(gcn_fb, iters=10)
+    for p in w.stack.parameters():
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    out["Adam (all parameter tensors, one launch)"] = event_time_us(lambda: w.opt.step(), iters=10)
+    w.opt.zero_grad()
+    return {k: round(v, 1) for k, v in out.items()}
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(budget_s=12.0):
     """Reference-side CPU throughput for the part of the path that has a CPU implementation:
     Chamfer NN (the reference's own nnsearch when oracle/_ref is present) + the C restatement
@@ -260,7 +307,21 @@ def cpu_baseline(budget_s=12.0):
         t_nn += t1 - t0
         t_tri += t2 - t1
         done += 1
+    # all-cores figure: one independent mesh per thread (the reference has no threading; ctypes releases the GIL)
+    import concurrent.futures
+    threads = min(os.cpu_count() or 1, 64)
+    def one_mesh(i):
+        verts = meshgen.jittered_batch(V, 1, first=i)
+        gt = meshgen.gt_cloud(1, G_PTS, first=i)
+        pred = meshgen.gt_cloud(1, S_PTS, first=1000 + i)
+        oracle.chamfer_nn(gt, pred, use_ref=use_ref)
+        oracle.tri_scan_indexed(gt, verts, Fc)
+    with concurrent.futures.ThreadPoolExecutor(threads) as ex:
+        t0 = time.perf_counter()
+        list(ex.map(one_mesh, range(threads)))
+        t_all = time.perf_counter() - t0
     return {"value": round(done / (t_nn + t_tri), 3), "unit": "meshes/s (Chamfer NN both directions + tri_distance only)",
+            "all_cores_value": round(threads / t_all, 2), "all_cores_threads": threads, "cpu_model": _cpu_model(),
             "cores": 1, "kind": "port",   # the combined figure is dominated by tri_distance, which only exists as our C port
             "chamfer_kind": "reference" if use_ref else "port",
             "sample": "%d whole meshes of the bench workload (3000x3000 NN both ways, 3000 pts x 5120 faces); "
@@ -330,6 +391,8 @@ def main():
         roofline, others = kernel_rooflines(w)
         line["roofline"] = roofline
         line["other_kernels"] = others
+        if world == 1:
+            line["components_us"] = component_times(w)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
