@@ -86,7 +86,7 @@ def lib():
         L.geom_zn_gcn_bwd_scratch_floats.restype = ctypes.c_int64
         L.geom_zn_gcn_bwd_scratch_floats.argtypes = [_i, _i, _i]
         L.geom_tri_distance_workspace_bytes.restype = ctypes.c_size_t
-        L.geom_tri_distance_workspace_bytes.argtypes = [_i, _i]
+        L.geom_tri_distance_workspace_bytes.argtypes = [_i, _i, _i]
         for name, args in _SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args

@@ -401,7 +401,9 @@ constexpr int WS_PAD = 4 * WS_WAVES;             // triangle count is padded to 
 struct TriWs {
     float4 *sph; // [b][m_pad]     {centre, r_eff}
     float4 *cor; // [b][m_pad][3]  corners A, B, C
+    unsigned long long *keys; // [b][n] merged (distance, triangle, region) words, used when split > 1
     int m_pad;
+    int split;   // workgroups per query tile (each scans 1/split of the triangles)
 };
 
 __host__ __device__ inline int ws_pad(int m) { return (m + WS_PAD - 1) / WS_PAD * WS_PAD; }
@@ -411,6 +413,7 @@ __global__ __launch_bounds__(256) void tri_prep_kernel(TriJob job, TriWs ws)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int mesh = blockIdx.y;
+    if (ws.split > 1 && k < job.n) ws.keys[(size_t)mesh * job.n + k] = KEY_NONE; // merged across workgroups later
     if (k >= ws.m_pad) return;
     float4 rec = make_float4(INFINITY, 0.f, 0.f, 0.f); // padding: culled (or dropped by the k < m test)
     V3 A = geom::mk(0.f, 0.f, 0.f), B = A, C = A;
@@ -433,16 +436,22 @@ __global__ __launch_bounds__(WS_THREADS) void tri_scan_ws_kernel(const float *__
                                                                   const float4 *__restrict__ sph_all,
                                                                   const float4 *__restrict__ cor_all,
                                                                   float *__restrict__ dist, int *__restrict__ point,
-                                                                  int *__restrict__ index)
+                                                                  int *__restrict__ index, int split,
+                                                                  unsigned long long *__restrict__ keys)
 {
     __shared__ float4 tile[WS_CHUNK];
     __shared__ unsigned long long qbest[TRI_QUERIES];
     __shared__ float qp[3][TRI_QUERIES];
     __shared__ unsigned queue[WS_WAVES][CULL_QCAP];
 
-    int mesh, qtile; // all workgroups of a mesh share one XCD (its records stay in that L2)
-    if (!geom::xcd_assign(blockIdx.x, b, (n + TRI_QUERIES - 1) / TRI_QUERIES, mesh, qtile)) return;
+    int mesh, task; // all workgroups of a mesh share one XCD (its records stay in that L2)
+    if (!geom::xcd_assign(blockIdx.x, b, ((n + TRI_QUERIES - 1) / TRI_QUERIES) * split, mesh, task)) return;
+    const int qtile = task / split, part = task - qtile * split; // `split` workgroups share a query tile
     const int q0 = qtile * TRI_QUERIES;
+    // this workgroup's triangle range [r_begin, r_end): 1/split of the padded range, in WS_PAD units
+    const int r_len = ((m_pad / WS_PAD + split - 1) / split) * WS_PAD;
+    const int r_begin = part * r_len, r_end = min(m_pad, r_begin + r_len);
+    if (r_begin >= r_end) return;
     const int lane = threadIdx.x & (GEOM_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform => scalar addressing
     const int q = q0 + lane;
@@ -513,8 +522,8 @@ __global__ __launch_bounds__(WS_THREADS) void tri_scan_ws_kernel(const float *__
     //      load of the chunk in flight at once), then each wave tests its contiguous share of the chunk
     //      with wave-uniform ds_read_b128 (LDS broadcast) --------------------------------------------
     const unsigned long long live_mask = __ballot(live);
-    for (int c0 = 0; c0 < m_pad; c0 += WS_CHUNK) {
-        const int len = min(WS_CHUNK, m_pad - c0); // multiple of WS_PAD = 4 * WS_WAVES
+    for (int c0 = r_begin; c0 < r_end; c0 += WS_CHUNK) {
+        const int len = min(WS_CHUNK, r_end - c0); // multiple of WS_PAD = 4 * WS_WAVES
         for (int t = threadIdx.x; t < len; t += WS_THREADS) tile[t] = sph[c0 + t];
         __syncthreads();
         const int per_wave = len / WS_WAVES; // multiple of 4
@@ -553,6 +562,10 @@ __global__ __launch_bounds__(WS_THREADS) void tri_scan_ws_kernel(const float *__
     if (qn > 0) pop_batch(0, qn);
     __syncthreads();
 
+    if (split > 1) { // partial result: merged across the tile's workgroups, finished by tri_finalize_kernel
+        if (wave == 0 && live && qbest[lane] != KEY_NONE) atomicMin(&keys[(size_t)mesh * n + q], qbest[lane]);
+        return;
+    }
     if (wave == 0 && live) {
         const unsigned long long word = qbest[lane];
         float acc_d = __uint_as_float((unsigned)(word >> 32));
@@ -580,23 +593,83 @@ __global__ __launch_bounds__(WS_THREADS) void tri_scan_ws_kernel(const float *__
     }
 }
 
+// split > 1 only: the merged word of every query -> outputs, with the "first triangle seeds" rule
+template <bool TRUNC, bool FIX6>
+__global__ __launch_bounds__(256) void tri_finalize_kernel(const float *__restrict__ xyz, int n, int m, int m_pad,
+                                                           const float4 *__restrict__ cor_all,
+                                                           const unsigned long long *__restrict__ keys,
+                                                           float *__restrict__ dist, int *__restrict__ point,
+                                                           int *__restrict__ index)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int mesh = blockIdx.y;
+    if (q >= n) return;
+    const size_t o = (size_t)mesh * n + q;
+    const unsigned long long word = keys[o];
+    float acc_d = __uint_as_float((unsigned)(word >> 32));
+    int acc_k = (int)(unsigned)word;
+    const float4 *cor = cor_all + (size_t)mesh * m_pad * 3;
+    const V3 p = load3(xyz + o * 3);
+    const float4 a = cor[0], bq = cor[1], c = cor[2];
+    int opt0;
+    const float d0 = geom::tri_pair_literal<FIX6>(p, geom::mk(a.x, a.y, a.z), geom::mk(bq.x, bq.y, bq.z),
+                                                  geom::mk(c.x, c.y, c.z), opt0);
+    if (d0 != d0 || word == KEY_NONE) { // "k == 0 ||" seed (tri_distance.cu:194)
+        acc_d = d0;
+        acc_k = opt0;
+    }
+    if (TRUNC) {
+        const int last0 = ((m - 1) / geom::REF_TILE) * geom::REF_TILE;
+        if (m - last0 < 4 && (last0 == 0 || acc_d > 10000.f)) {
+            acc_d = 10000.f;
+            acc_k = 0;
+        }
+    }
+    dist[o] = acc_d;
+    point[o] = acc_k & 7;
+    index[o] = acc_k >> 3;
+}
+
 template <bool INDEXED, bool TRUNC, bool FIX6>
 int launch_ws_variant(const TriJob &job, const TriWs &ws, hipStream_t s)
 {
-    hipLaunchKernelGGL((tri_prep_kernel<INDEXED, TRUNC, FIX6>), dim3((ws.m_pad + 255) / 256, job.b), dim3(256), 0, s, job, ws);
-    hipLaunchKernelGGL((tri_scan_ws_kernel<TRUNC, FIX6>),
-                       dim3(geom::xcd_grid(job.b, (job.n + TRI_QUERIES - 1) / TRI_QUERIES)), dim3(WS_THREADS), 0, s,
-                       job.xyz, job.b, job.n, job.m, ws.m_pad, ws.sph, ws.cor, job.dist, job.point, job.index);
+    const int prep_items = ws.split > 1 && job.n > ws.m_pad ? job.n : ws.m_pad;
+    hipLaunchKernelGGL((tri_prep_kernel<INDEXED, TRUNC, FIX6>), dim3((prep_items + 255) / 256, job.b), dim3(256), 0, s, job, ws);
+    const int qtiles = (job.n + TRI_QUERIES - 1) / TRI_QUERIES;
+    hipLaunchKernelGGL((tri_scan_ws_kernel<TRUNC, FIX6>), dim3(geom::xcd_grid(job.b, qtiles * ws.split)), dim3(WS_THREADS),
+                       0, s, job.xyz, job.b, job.n, job.m, ws.m_pad, ws.sph, ws.cor, job.dist, job.point, job.index,
+                       ws.split, ws.keys);
+    if (ws.split > 1)
+        hipLaunchKernelGGL((tri_finalize_kernel<TRUNC, FIX6>), dim3((job.n + 255) / 256, job.b), dim3(256), 0, s, job.xyz,
+                           job.n, job.m, ws.m_pad, ws.cor, ws.keys, job.dist, job.point, job.index);
     return geom::launch_status();
 }
+
+// How many workgroups share a query tile.  A workgroup holds 16 waves and at most two fit a CU.  With
+// fewer query tiles than CUs (1-5 meshes of 3000 points) most of the chip would idle, so the triangle
+// range of a tile is split over up to 4 workgroups (measured: 1 mesh 51 -> 26 us, 3 meshes 72 -> 50 us).
+// Every part repeats the hint phase (~10 us), so from 256 tiles on the split costs more than the better
+// balance returns (8 meshes: 73 us unsplit, 86 us at split 3) and parts stay >= 1024 triangles.
+inline int ws_split(int b, int n, int m_pad)
+{
+    const int64_t tiles = (int64_t)b * ((n + TRI_QUERIES - 1) / TRI_QUERIES);
+    if (tiles <= 0 || tiles >= 256) return 1;
+    int split = (int)((512 + tiles - 1) / tiles);
+    if (split > m_pad / 1024) split = m_pad / 1024;
+    if (split > 4) split = 4;
+    return split < 1 ? 1 : split;
+}
+
+inline size_t ws_bytes_needed(int b, int n, int m_pad) { return (size_t)b * m_pad * 4 * sizeof(float4) + (size_t)b * n * 8; }
 
 template <bool INDEXED>
 int launch_tri_ws(const TriJob &job, unsigned flags, void *workspace, size_t ws_bytes, void *stream)
 {
     const int m_pad = ws_pad(job.m);
-    const size_t need = (size_t)job.b * m_pad * 4 * sizeof(float4);
-    if (!workspace || ws_bytes < need || ((uintptr_t)workspace & 15)) return GEOM_EINVAL;
-    TriWs ws{static_cast<float4 *>(workspace), static_cast<float4 *>(workspace) + (size_t)job.b * m_pad, m_pad};
+    if (!workspace || ws_bytes < ws_bytes_needed(job.b, job.n, m_pad) || ((uintptr_t)workspace & 15)) return GEOM_EINVAL;
+    float4 *base = static_cast<float4 *>(workspace);
+    TriWs ws{base, base + (size_t)job.b * m_pad, reinterpret_cast<unsigned long long *>(base + (size_t)job.b * m_pad * 4),
+             m_pad, ws_split(job.b, job.n, m_pad)};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool trunc = flags & GEOM_FLAG_REF_TAIL_TRUNC, fix6 = flags & GEOM_FLAG_FIX_REGION6;
     if (trunc && fix6) return launch_ws_variant<INDEXED, true, true>(job, ws, s);
@@ -662,10 +735,10 @@ extern "C" int geom_tri_distance_indexed_f32(int b, int n, const float *xyz, int
     return launch_tri<true>(job, flags, stream);
 }
 
-extern "C" size_t geom_tri_distance_workspace_bytes(int b, int m)
+extern "C" size_t geom_tri_distance_workspace_bytes(int b, int n, int m)
 {
-    if (b <= 0 || m <= 0) return 0;
-    return (size_t)b * ws_pad(m) * 4 * sizeof(float4);
+    if (b <= 0 || m <= 0 || n < 0) return 0;
+    return ws_bytes_needed(b, n, ws_pad(m));
 }
 
 extern "C" int geom_tri_distance_ws_f32(int b, int n, const float *xyz, int m,

@@ -166,7 +166,7 @@ class SurfaceLoss(torch.autograd.Function):
         sq_gt, sq_pred = torch.empty(b, n_gt, **f32), torch.empty(b, num, **f32)
         idx_p, idx_g = torch.empty(b, n_gt, **i32), torch.empty(b, num, **i32)
         if not two_sided:
-            ws_bytes = L.geom_tri_distance_workspace_bytes(b, nf)
+            ws_bytes = L.geom_tri_distance_workspace_bytes(b, n_gt, nf)
             ws = torch.empty(max(ws_bytes, 16) // 4, **f32)
             tri_d, option, index = torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, **i32), torch.empty(b, n_gt, **i32)
             sq, closest, weights = torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, 3, **f32), torch.empty(b, n_gt, 3, **f32)

@@ -17,10 +17,10 @@ def _outputs(b, n, dev):
             torch.empty(b, n, dtype=torch.int32, device=dev))
 
 
-def _workspace(b, m, dev):
+def _workspace(b, n, m, dev):
     """Scratch for the per-triangle {sphere, corners} records (64 B per triangle); torch's caching
     allocator makes this free after the first call and keeps it hipGraph-capturable."""
-    nbytes = _lib.lib().geom_tri_distance_workspace_bytes(b, m)
+    nbytes = _lib.lib().geom_tri_distance_workspace_bytes(b, n, m)
     return torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=dev), nbytes
 
 
@@ -30,7 +30,7 @@ def forward_cuda(xyz1, tri1, tri2, tri3, dist, point, index, flags=0, use_worksp
     m = tri1.shape[1]
     with torch.cuda.device(xyz1.device):
         if use_workspace:
-            ws, nbytes = _workspace(b, m, xyz1.device)
+            ws, nbytes = _workspace(b, n, m, xyz1.device)
             code = _lib.lib().geom_tri_distance_ws_f32(
                 b, n, xyz1.data_ptr(), m, tri1.data_ptr(), tri2.data_ptr(), tri3.data_ptr(),
                 dist.data_ptr(), point.data_ptr(), index.data_ptr(), flags, ws.data_ptr(), nbytes,
@@ -67,7 +67,7 @@ def tri_distance_indexed(xyz1, verts, faces, flags=0, use_workspace=True):
     dist, point, index = _outputs(b, n, dev)
     with torch.cuda.device(dev):
         if use_workspace:
-            ws, nbytes = _workspace(b, faces.shape[0], dev)
+            ws, nbytes = _workspace(b, n, faces.shape[0], dev)
             code = _lib.lib().geom_tri_distance_indexed_ws_f32(
                 b, n, xyz1.data_ptr(), verts.shape[1], verts.data_ptr(), faces.shape[0], faces.data_ptr(),
                 dist.data_ptr(), point.data_ptr(), index.data_ptr(), flags, ws.data_ptr(), nbytes,

@@ -75,9 +75,11 @@ int geom_tri_distance_indexed_f32(int b, int n, const float *xyz, int nv, const 
 
 /* Workspace variants (what the python operators call): identical results; the scan reads
  * per-triangle {bounding sphere, corners} records that a prep kernel writes into `workspace`
- * (device memory, 16-byte aligned, at least geom_tri_distance_workspace_bytes(b, m) bytes,
- * contents undefined on entry and exit), which removes all per-block staging work. */
-size_t geom_tri_distance_workspace_bytes(int b, int m);
+ * (device memory, 16-byte aligned, at least geom_tri_distance_workspace_bytes(b, n, m) bytes,
+ * contents undefined on entry and exit), which removes all per-block staging work; with few query
+ * tiles the triangle range of a tile is split over several workgroups whose partial results are
+ * merged through 64-bit atomic-min words that also live in the workspace. */
+size_t geom_tri_distance_workspace_bytes(int b, int n, int m);
 int geom_tri_distance_ws_f32(int b, int n, const float *xyz, int m,
                              const float *tri1, const float *tri2, const float *tri3,
                              float *dist, int *point, int *index, unsigned flags,
