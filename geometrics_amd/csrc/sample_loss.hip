@@ -338,26 +338,37 @@ __global__ __launch_bounds__(SUM_THREADS) void sum_kernel(int64_t n, const float
     }
 }
 
+constexpr int SUM_BATCH = 8;
+__device__ __forceinline__ float thread_sum(int64_t n, const float *x)
+{
+    float acc = 0.f;
+    const bool vec = (((uintptr_t)x) & 15) == 0;
+    const int64_t n4 = vec ? n / 4 : 0;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    for (int64_t base = 0; base < n4; base += (int64_t)SUM_BATCH * SUM_THREADS) {
+        float4 v[SUM_BATCH];
+#pragma unroll
+        for (int j = 0; j < SUM_BATCH; ++j) {
+            const int64_t i = base + threadIdx.x + (int64_t)j * SUM_THREADS;
+            v[j] = i < n4 ? x4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < SUM_BATCH; ++j) acc += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += SUM_THREADS) acc += x[i]; // tail / unaligned input
+    return acc;
+}
+
 // out[0] = s1 * sum(x1) + s2 * sum(x2): the whole  (dist_1 + dist_2) * 3000  of utils.py:420/484
 // in one launch, same fixed reduction tree per segment.
 __global__ __launch_bounds__(SUM_THREADS) void sum2_kernel(int64_t n1, const float *x1, float s1, int64_t n2,
                                                             const float *x2, float s2, float *out)
 {
     __shared__ float partial[2][SUM_THREADS / GEOM_WAVE];
-    // four independent partial sums per segment keep four loads in flight per thread (the loop is a
-    // latency chain otherwise); the association is fixed, so the result stays bit-reproducible
-    float p1[4] = {0.f, 0.f, 0.f, 0.f}, p2[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t i = threadIdx.x; i < n1; i += 4 * SUM_THREADS) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i + j * SUM_THREADS < n1) p1[j] += x1[i + j * SUM_THREADS];
-    }
-    for (int64_t i = threadIdx.x; i < n2; i += 4 * SUM_THREADS) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i + j * SUM_THREADS < n2) p2[j] += x2[i + j * SUM_THREADS];
-    }
-    float a1 = (p1[0] + p1[1]) + (p1[2] + p1[3]), a2 = (p2[0] + p2[1]) + (p2[2] + p2[3]);
+    // One workgroup: the sum is a latency chain unless many loads are in flight.  Each thread issues up to
+    // SUM_BATCH float4 loads per segment back to back (48 000 floats = 12 per thread: one round trip), then
+    // adds them in a fixed order -- the association is static, so the result stays bit-reproducible.
+    float a1 = thread_sum(n1, x1), a2 = thread_sum(n2, x2);
     for (int off = GEOM_WAVE / 2; off > 0; off >>= 1) {
         a1 += __shfl_down(a1, off, GEOM_WAVE);
         a2 += __shfl_down(a2, off, GEOM_WAVE);
