@@ -1,15 +1,22 @@
 // Point-to-triangle arg-min scan for gfx950.
 //
 // Replaces TriDistanceKernel + launcher of the reference (tri_distance/tri_distance.cu:94-211,
-// 213-228).  Same workgroup shape as the Chamfer scan (chamfer_nn.hip): 64 query points per
-// workgroup, lane <-> query, the 4 waves split each LDS chunk of triangles four ways, and
-// the partial (distance, triangle, region) results are merged lexicographically -- equal to
-// the reference's sequential strict-'<' scan, with the "first triangle seeds" rule applied
-// explicitly.  Triangle corners are staged in LDS once per chunk as 3 x float4 records and
-// read wave-uniformly; in the INDEXED variant the corners are gathered from verts through
-// faces while staging, so the three [b,F,3] corner arrays the reference materialises
-// (utils.py:467-469) never exist.
+// 213-228).  Three kernels live here, all with lane <-> query point and 64 queries per workgroup,
+// all producing the reference's sequential strict-'<' arg-min bit for bit (partial results are merged
+// lexicographically on (distance, triangle) and the "first triangle seeds" rule is applied explicitly):
 //
+//   1. tri_distance_kernel            brute force: every (point, triangle) pair through the full decision
+//                                     tree, corners staged in LDS.  Selected by GEOM_FLAG_TRI_BRUTE_FORCE;
+//                                     it is the in-library cross-check of the other two.
+//   2. tri_distance_culled_kernel     culled scan with in-kernel staging from (verts, faces) or the three
+//                                     corner arrays -- what the workspace-free entry points (the exact
+//                                     reference prototypes) run.
+//   3. tri_prep_kernel + tri_scan_ws_kernel (+ tri_finalize_kernel)
+//                                     culled scan over per-triangle records in a caller-provided workspace:
+//                                     the fast path the python operators use.
+//
+// In the INDEXED variants the corners are gathered from verts through faces, so the three [b,F,3] corner
+// arrays the reference materialises (utils.py:467-469) never exist.
 // Arithmetic: tri_math.h (literal operation order of tri_distance.cu:140-191).
 #include "geom_common.h"
 #include "tri_math.h"

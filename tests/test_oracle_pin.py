@@ -178,3 +178,21 @@ def test_regulariser_restatements():
     edge.backward()
     np.testing.assert_allclose(edge.item(), g["edge"], rtol=1e-6)
     np.testing.assert_allclose(v2.grad.numpy(), g["grad_verts_edge"], rtol=1e-4, atol=1e-8)
+
+
+def test_nn_grad_restatement_equals_autograd_of_the_distance_form():
+    """oracle_nn_grad follows the reference's nnd_backward (my_lib.c:49-111): it is the gradient of
+    sum(w1*dist1) + sum(w2*dist2) with the NN indices held fixed."""
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((2, 40, 3)).astype(np.float32)
+    b = rng.standard_normal((2, 55, 3)).astype(np.float32)
+    w1 = rng.standard_normal((2, 40)).astype(np.float32)
+    w2 = rng.standard_normal((2, 55)).astype(np.float32)
+    _, i1, _, i2 = oracle.chamfer_nn(a, b)
+    g1, g2 = oracle.nn_grad(a, b, w1, w2, i1, i2)
+    ta, tb = torch.from_numpy(a).requires_grad_(True), torch.from_numpy(b).requires_grad_(True)
+    d1 = ((ta - torch.gather(tb, 1, torch.from_numpy(i1).long().unsqueeze(-1).expand(-1, -1, 3))) ** 2).sum(-1)
+    d2 = ((tb - torch.gather(ta, 1, torch.from_numpy(i2).long().unsqueeze(-1).expand(-1, -1, 3))) ** 2).sum(-1)
+    ((d1 * torch.from_numpy(w1)).sum() + (d2 * torch.from_numpy(w2)).sum()).backward()
+    np.testing.assert_allclose(g1, ta.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(g2, tb.grad.numpy(), rtol=1e-4, atol=1e-5)

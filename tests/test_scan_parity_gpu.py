@@ -262,3 +262,22 @@ def test_size_independent_properties_at_the_config5_shard(gpu):
     assert bool(same[option == 0].all())                        # interior winners are unique
     d_again, o_again, i_again = tri_distance_indexed(gt, verts, faces)
     assert torch.equal(d_again, dist) and torch.equal(i_again, index) and torch.equal(o_again, option)
+
+
+def test_empty_and_degenerate_shapes(gpu):
+    """Empty batch is a no-op; a direction without targets has no arg-min and is rejected (the reference
+    silently leaves zero-initialised outputs); single points and single triangles work."""
+    e = torch.empty(0, 5, 3, device=gpu)
+    d1, i1, d2, i2 = chamfer_nn(e, torch.empty(0, 7, 3, device=gpu))
+    assert d1.shape == (0, 5) and i2.shape == (0, 7)
+    with pytest.raises(RuntimeError):
+        chamfer_nn(torch.rand(1, 4, 3, device=gpu), torch.empty(1, 0, 3, device=gpu))
+    d, p, i = tri_distance_indexed(torch.empty(0, 3, 3, device=gpu), torch.empty(0, 4, 3, device=gpu),
+                                   torch.zeros(1, 3, dtype=torch.int64, device=gpu))
+    assert d.shape == (0, 3)
+    one = torch.tensor([[[0.2, 0.2, 1.0]]], device=gpu)
+    tri = torch.tensor([[[0., 0., 0.], [1., 0., 0.], [0., 1., 0.]]], device=gpu)
+    d, p, i = tri_distance_indexed(one, tri, torch.tensor([[0, 1, 2]], device=gpu))
+    assert float(d) == 1.0 and int(p) == 0 and int(i) == 0
+    d1, i1, d2, i2 = chamfer_nn(one, tri)
+    assert int(i1) == 0 and int(i2[0, 0]) == 0 and float(d1) == pytest.approx(1.08, rel=1e-6)
