@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from geometrics_amd import dist as gdist  # noqa: E402
-from geometrics_amd import gemm_tuning, layers, meshgen, optim, utils  # noqa: E402
+from geometrics_amd import gemm_tuning, layers, meshgen, ops, optim, utils  # noqa: E402
 from geometrics_amd.chamfer_distance import chamfer_nn  # noqa: E402
 from geometrics_amd.tri_distance import tri_distance_indexed  # noqa: E402
 
@@ -66,6 +66,8 @@ class Workload:
         # flat DP bucket: all gradients + [loss_sum, mesh_count] -> exactly one all-reduce per step
         self.bucket = gdist.GradBucket(self.stack.parameters(), extra=2) if self.world > 1 else None
         self.count = torch.full((), float(batch), device=dev)
+        self.seed_grad = torch.ones((), device=dev)
+        ops.manual_seed(seed + 977 * first_mesh, dev)        # sampler stream: distinct per shard, reproducible
         # GEOMetrics.py:73 (Adam, lr 1e-4): every parameter tensor in one launch, step count on the device
         self.opt = optim.FusedAdam(self.stack.parameters(), lr=1e-4)
         self.loss = None
@@ -75,7 +77,7 @@ class Workload:
         h = self.feat
         for layer in self.stack:
             h = layer(h, self.info["adj"], F.relu)
-        return self.base + 0.01 * h[..., :3]
+        return ops.VertexHead.apply(self.base, h, 0.01)     # base + 0.01 * h[..., :3], one kernel each way
 
     # one step = forward_backward() -> [exchange()] -> update(); captured as HIP graphs by capture()
     def forward_backward(self):
@@ -83,7 +85,7 @@ class Workload:
         self.feat.grad = None
         pos = self.positions()
         self.loss = utils.batch_point_to_surface(pos, self.info, self.gt, num=S_PTS)
-        self.loss.backward()
+        self.loss.backward(self.seed_grad)                  # explicit seed: no ones_like fill launch
         if self.world > 1:
             self.bucket.pack(self.loss.detach() * self.batch, self.count)
 

@@ -60,9 +60,33 @@ __global__ __launch_bounds__(PT_THREADS) void face_areas_kernel(int b, int nv, c
 constexpr int DRAW_THREADS = 1024;
 constexpr int DRAW_MAX_FACES = 16384; // 64 KiB of LDS
 
+// Philox4x32-10 (Salmon et al. 2011): counter-based, so a sample's three uniforms depend only on
+// (seed, stream position, mesh, sample index) -- no generator state to carry, and a captured HIP graph
+// draws fresh numbers on every replay because the stream position lives in device memory.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * ctr.x;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * ctr.z;
+        ctr = make_uint4((unsigned)(p1 >> 32) ^ ctr.y ^ key.x, (unsigned)p1, (unsigned)(p0 >> 32) ^ ctr.w ^ key.y, (unsigned)p0);
+        key.x += 0x9E3779B9u;
+        key.y += 0xBB67AE85u;
+    }
+    return ctr;
+}
+__device__ __forceinline__ float u01(unsigned x) { return (x >> 8) * 0x1p-24f; } // [0,1), 24 random bits
+
+// state[0..1] = seed, state[2..3] = stream position (advanced by draw_tick_kernel after every call)
+__global__ void draw_tick_kernel(unsigned long long *state)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) state[1] += 1ull;
+}
+
 __global__ __launch_bounds__(DRAW_THREADS) void draw_samples_kernel(int nv, const float *verts, int nf,
                                                                      const int64_t *faces, int num,
                                                                      const float *uniforms, int64_t plane,
+                                                                     const unsigned long long *rng_state,
                                                                      int64_t *choices, float *u, float *v)
 {
     __shared__ float cdf[DRAW_MAX_FACES];
@@ -100,7 +124,16 @@ __global__ __launch_bounds__(DRAW_THREADS) void draw_samples_kernel(int nv, cons
     const int i = blockIdx.x * DRAW_THREADS + threadIdx.x;
     if (i >= num) return;
     const int64_t o = (int64_t)mesh * num + i;
-    const float target = uniforms[o] * total;
+    float r0, r1, r2;
+    if (rng_state) { // in-kernel Philox: counter = (sample, mesh, stream position), key = seed
+        const unsigned long long seed = rng_state[0], pos = rng_state[1];
+        const uint4 r = philox4x32_10(make_uint4((unsigned)i, (unsigned)mesh, (unsigned)pos, (unsigned)(pos >> 32)),
+                                      make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+        r0 = u01(r.x), r1 = u01(r.y), r2 = u01(r.z);
+    } else {
+        r0 = uniforms[o], r1 = uniforms[plane + o], r2 = uniforms[2 * plane + o];
+    }
+    const float target = r0 * total;
     int lo = 0, hi = nf - 1; // first f with cdf[f] > target, clamped to the last face
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
@@ -108,8 +141,8 @@ __global__ __launch_bounds__(DRAW_THREADS) void draw_samples_kernel(int nv, cons
         else lo = mid + 1;
     }
     choices[o] = lo;
-    u[o] = sqrtf(uniforms[plane + o]);
-    v[o] = uniforms[2 * plane + o];
+    u[o] = sqrtf(r1);
+    v[o] = r2;
 }
 
 // -------------------------------------------------------------- face sampling ----
@@ -511,7 +544,72 @@ extern "C" int geom_draw_samples_f32(int b, int nv, const float *verts, int nf, 
     if (nf == 0 || !verts || !faces || !uniforms || !choices || !u || !v) return GEOM_EINVAL;
     if (b > 65535) return GEOM_ETOOBIG;
     hipLaunchKernelGGL(draw_samples_kernel, dim3((num + DRAW_THREADS - 1) / DRAW_THREADS, b), dim3(DRAW_THREADS), 0,
-                       static_cast<hipStream_t>(stream), nv, verts, nf, faces, num, uniforms, (int64_t)b * num, choices,
-                       u, v);
+                       static_cast<hipStream_t>(stream), nv, verts, nf, faces, num, uniforms, (int64_t)b * num,
+                       static_cast<const unsigned long long *>(nullptr), choices, u, v);
+    return geom::launch_status();
+}
+
+extern "C" int geom_draw_samples_rng_f32(int b, int nv, const float *verts, int nf, const int64_t *faces, int num,
+                                         uint64_t *rng_state, int64_t *choices, float *u, float *v, void *stream)
+{
+    if (b < 0 || nv < 0 || nf < 0 || num < 0) return GEOM_EINVAL;
+    if (nf > DRAW_MAX_FACES) return GEOM_EUNSUPPORTED;
+    if (b == 0 || num == 0) return 0;
+    if (nf == 0 || !verts || !faces || !rng_state || !choices || !u || !v) return GEOM_EINVAL;
+    if (b > 65535) return GEOM_ETOOBIG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(draw_samples_kernel, dim3((num + DRAW_THREADS - 1) / DRAW_THREADS, b), dim3(DRAW_THREADS), 0, s,
+                       nv, verts, nf, faces, num, static_cast<const float *>(nullptr), (int64_t)b * num,
+                       reinterpret_cast<const unsigned long long *>(rng_state), choices, u, v);
+    hipLaunchKernelGGL(draw_tick_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned long long *>(rng_state));
+    return geom::launch_status();
+}
+
+// ------------------------------------------------------------ vertex head ----
+// pos[b,v,:] = base[b,v,:] + scale * feat[b,v,:3]   and its adjoint  grad_feat = [scale*grad_pos | 0]:
+// the coordinate update of a deformation stage (GEOMetrics.py:121, 126, 131: positions + block output)
+// when the coordinates are the leading channels of a wider feature tensor.
+namespace {
+__global__ __launch_bounds__(PT_THREADS) void vertex_head_fwd_kernel(int64_t rows, int c, const float *base,
+                                                                      const float *feat, float scale, float *pos)
+{
+    const int64_t i = (int64_t)blockIdx.x * PT_THREADS + threadIdx.x;
+    if (i >= rows * 3) return;
+    const int64_t r = i / 3;
+    pos[i] = base[i] + scale * feat[r * c + (i - 3 * r)];
+}
+__global__ __launch_bounds__(PT_THREADS) void vertex_head_bwd_kernel(int64_t rows, int c, const float *grad_pos,
+                                                                      float scale, float *grad_feat)
+{
+    const int64_t i = (int64_t)blockIdx.x * PT_THREADS + threadIdx.x; // one thread per float4 of grad_feat
+    const int c4 = c >> 2;
+    if (i >= rows * c4) return;
+    const int64_t r = i / c4;
+    const int q = (int)(i - r * c4);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q == 0) g = make_float4(scale * grad_pos[3 * r], scale * grad_pos[3 * r + 1], scale * grad_pos[3 * r + 2], 0.f);
+    reinterpret_cast<float4 *>(grad_feat)[i] = g;
+}
+} // namespace
+
+extern "C" int geom_vertex_head_fwd_f32(int64_t rows, int c, const float *base, const float *feat, float scale,
+                                        float *pos, void *stream)
+{
+    if (rows < 0 || c < 3) return GEOM_EINVAL;
+    if (rows == 0) return 0;
+    if (!base || !feat || !pos) return GEOM_EINVAL;
+    hipLaunchKernelGGL(vertex_head_fwd_kernel, pt_grid(rows * 3), dim3(PT_THREADS), 0, static_cast<hipStream_t>(stream),
+                       rows, c, base, feat, scale, pos);
+    return geom::launch_status();
+}
+
+extern "C" int geom_vertex_head_bwd_f32(int64_t rows, int c, const float *grad_pos, float scale, float *grad_feat,
+                                        void *stream)
+{
+    if (rows < 0 || c < 4 || (c & 3)) return GEOM_EINVAL;
+    if (rows == 0) return 0;
+    if (!grad_pos || !grad_feat || ((uintptr_t)grad_feat & 15)) return GEOM_EINVAL;
+    hipLaunchKernelGGL(vertex_head_bwd_kernel, pt_grid(rows * (c >> 2)), dim3(PT_THREADS), 0,
+                       static_cast<hipStream_t>(stream), rows, c, grad_pos, scale, grad_feat);
     return geom::launch_status();
 }

@@ -202,6 +202,7 @@ class SurfaceLoss(torch.autograd.Function):
                 ctx.save_for_backward(faces, choices, u, v, points, gt_c, idx_g, index, closest, weights)
         ctx.two_sided, ctx.scale, ctx.nv = two_sided, scale, nv
         ctx.mark_non_differentiable(sq_gt, sq_pred)
+        ctx.set_materialize_grads(False)    # no zero tensors (two fill launches) for the two distance outputs
         return out, sq_gt, sq_pred
 
     @staticmethod
@@ -352,31 +353,92 @@ def _side_stream(dev):
     return st
 
 
+_rng_states = {}
+
+
+def manual_seed(seed, device=None):
+    """(Re)seed the in-kernel sampler stream of `device` (default: current).  Without a call the stream is
+    seeded from torch's default generator the first time it is used."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    state = torch.tensor([int(seed) & (2 ** 63 - 1), 0], dtype=torch.int64).to(dev)
+    _rng_states[key] = state
+    return state
+
+
+def _rng_state(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _rng_states.get(key)
+    if st is None:
+        st = manual_seed(torch.initial_seed() ^ 0x5DEECE66D, dev)
+    return st
+
+
 def draw_samples(verts, faces, num, generator=None):
     """The random part of batch_sample (reference utils.py:604-612, 627-628): choices [B,num] ~
-    area-weighted with replacement, u = sqrt(U1), v = U2.  One torch.rand for the uniforms and one
-    kernel (per-mesh face-area CDF in LDS + binary search) instead of a python loop of B multinomials;
-    meshes with more than 16384 faces take the torch.multinomial route."""
+    area-weighted with replacement, u = sqrt(U1), v = U2, in ONE kernel: per-mesh face-area CDF in LDS,
+    binary search per sample, uniforms from an in-kernel Philox stream whose position lives on the device
+    (graph replays draw fresh numbers; no generator bookkeeping launches).  With an explicit torch
+    `generator` the uniforms come from torch.rand instead; meshes with more than 16384 faces take the
+    torch.multinomial route."""
     verts_c = _f32(verts.detach(), "verts", 3, 3)
     faces = _lib.require(faces, "faces", torch.int64, 2, 3)
     b, nv, _ = verts_c.shape
     dev = verts_c.device
-    uniforms = torch.rand(3, b, num, device=dev, generator=generator)
     choices = torch.empty(b, num, dtype=torch.int64, device=dev)
     u = torch.empty(b, num, dtype=torch.float32, device=dev)
     v = torch.empty(b, num, dtype=torch.float32, device=dev)
+    uniforms = None
     with torch.cuda.device(dev):
-        code = _lib.lib().geom_draw_samples_f32(b, nv, verts_c.data_ptr(), faces.shape[0], faces.data_ptr(), num,
-                                                uniforms.data_ptr(), choices.data_ptr(), u.data_ptr(), v.data_ptr(),
-                                                _lib.stream_ptr())
+        if generator is None:
+            code = _lib.lib().geom_draw_samples_rng_f32(b, nv, verts_c.data_ptr(), faces.shape[0], faces.data_ptr(), num,
+                                                        _rng_state(dev).data_ptr(), choices.data_ptr(), u.data_ptr(),
+                                                        v.data_ptr(), _lib.stream_ptr())
+        else:
+            uniforms = torch.rand(3, b, num, device=dev, generator=generator)
+            code = _lib.lib().geom_draw_samples_f32(b, nv, verts_c.data_ptr(), faces.shape[0], faces.data_ptr(), num,
+                                                    uniforms.data_ptr(), choices.data_ptr(), u.data_ptr(),
+                                                    v.data_ptr(), _lib.stream_ptr())
     if code == _lib.EUNSUPPORTED:
+        if uniforms is None:
+            uniforms = torch.rand(3, b, num, device=dev)
         choices = torch.multinomial(face_areas(verts_c, faces), num, True, generator=generator)
         return choices, torch.sqrt(uniforms[1]), uniforms[2]
     _lib.check(code, "geom_draw_samples_f32")
     return choices, u, v
 
 
+class VertexHead(torch.autograd.Function):
+    """pos = base + scale * feat[..., :3] in one kernel; the adjoint writes grad_feat = [scale*grad_pos | 0]
+    in one pass (a slice + mul + add costs two launches forward and mul + zero-fill + strided copy backward)."""
+
+    @staticmethod
+    def forward(ctx, base, feat, scale):
+        b_ = _f32(base, "base", 3, 3)
+        f_ = _f32(feat, "feat", 3)
+        if f_.shape[:2] != b_.shape[:2] or f_.shape[2] < 4 or f_.shape[2] % 4:
+            raise RuntimeError("feat must be [B,V,C] with C a multiple of 4 matching base [B,V,3]")
+        pos = torch.empty_like(b_)
+        rows = b_.shape[0] * b_.shape[1]
+        with torch.cuda.device(b_.device):
+            _lib.call("geom_vertex_head_fwd_f32", rows, f_.shape[2], b_.data_ptr(), f_.data_ptr(), float(scale),
+                      pos.data_ptr())
+        ctx.scale, ctx.c = float(scale), f_.shape[2]
+        return pos
+
+    @staticmethod
+    def backward(ctx, grad_pos):
+        g = grad_pos.contiguous()
+        rows = g.shape[0] * g.shape[1]
+        grad_feat = None
+        if ctx.needs_input_grad[1]:
+            grad_feat = torch.empty(g.shape[0], g.shape[1], ctx.c, dtype=torch.float32, device=g.device)
+            with torch.cuda.device(g.device):
+                _lib.call("geom_vertex_head_bwd_f32", rows, ctx.c, g.data_ptr(), ctx.scale, grad_feat.data_ptr())
+        return (g if ctx.needs_input_grad[0] else None), grad_feat, None
+
+
 __all__ = ["face_areas", "device_sum", "SampleFaces", "GatherSqDistSum", "PointToTriangleSum", "SurfaceLoss",
-           "Laplacian", "EdgeSqLenSum", "PoolFeatures",
+           "Laplacian", "EdgeSqLenSum", "PoolFeatures", "VertexHead", "manual_seed",
            "draw_samples",
            "chamfer_nn", "tri_distance_indexed"]

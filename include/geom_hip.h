@@ -99,6 +99,11 @@ int geom_face_areas_f32(int b, int nv, const float *verts, int nf, const int64_t
  * nf <= 16384 (the CDF lives in LDS), otherwise GEOM_EUNSUPPORTED. */
 int geom_draw_samples_f32(int b, int nv, const float *verts, int nf, const int64_t *faces, int num,
                           const float *uniforms, int64_t *choices, float *u, float *v, void *stream);
+/* Same draws from an in-kernel counter-based generator (Philox4x32-10): rng_state = 2 device uint64
+ * {seed, stream position}; the position is advanced on the device after every call, so a captured HIP
+ * graph draws fresh numbers on each replay and no generator bookkeeping is launched. */
+int geom_draw_samples_rng_f32(int b, int nv, const float *verts, int nf, const int64_t *faces, int num,
+                              uint64_t *rng_state, int64_t *choices, float *u, float *v, void *stream);
 /* points[b,num,3] = (1-u)*x + (u*(1-v))*y + (u*v)*z with x,y,z the corners of face
  * choices[b,num] (int64 face ids), u already sqrt'ed (utils.py:615-631). */
 int geom_sample_faces_fwd_f32(int b, int nv, const float *verts, int nf, const int64_t *faces,
@@ -186,6 +191,14 @@ int geom_zn_gcn_aggregate_ell_bwd_f32(int b, int nv, int c, int k, int w, const 
                                       const float *ell_valT, const float *grad_out, const float *out,
                                       int act, float *grad_support, float *grad_bias, float *scratch,
                                       void *stream);
+
+/* Coordinate update of a deformation stage (GEOMetrics.py:121,126,131) when the predicted offsets are the
+ * three leading channels of a wider feature tensor: pos[r,:] = base[r,:] + scale*feat[r,:3] for `rows`
+ * vertices (feat row length c), and its adjoint grad_feat[r,:] = [scale*grad_pos[r,:] | 0 ...] (c % 4 == 0). */
+int geom_vertex_head_fwd_f32(int64_t rows, int c, const float *base, const float *feat, float scale,
+                             float *pos, void *stream);
+int geom_vertex_head_bwd_f32(int64_t rows, int c, const float *grad_pos, float scale, float *grad_feat,
+                             void *stream);
 
 /* ---- mesh regularisers (SURVEY 8f "next" row 1; utils.py:636-662, GEOMetrics.py:147-161) ----------------
  * Laplacian coordinates over the CSR of the BINARY adjacency with self loops (adj_info['adj_orig']):

@@ -368,3 +368,46 @@ def test_batched_pooling_matches_reference_fixture(gpu):
     close(verts.grad.cpu().numpy(), g["grad_verts"], 2e-4)
     # clamped vertices exist in the fixture (zero position gradient through the clamp) and are reproduced
     assert (np.abs(g["grad_verts"]).sum(-1) == 0).any()
+
+
+def test_in_kernel_sampler_stream(gpu):
+    """The Philox stream of the sampler: reproducible after manual_seed, fresh numbers on every call (also
+    when the call is replayed from a HIP graph), uniform u/v, area-weighted faces."""
+    V, Fc = meshgen.icosphere(3)
+    verts, faces = dev(meshgen.jittered_batch(V, 2), gpu), dev(Fc, gpu)
+    ops.manual_seed(123)
+    c1, u1, v1 = ops.draw_samples(verts, faces, 5000)
+    c2, u2, v2 = ops.draw_samples(verts, faces, 5000)
+    assert not torch.equal(c1, c2) and not torch.equal(u1, u2)                  # the stream advances
+    ops.manual_seed(123)
+    c3, u3, v3 = ops.draw_samples(verts, faces, 5000)
+    assert torch.equal(c1, c3) and torch.equal(u1, u3) and torch.equal(v1, v3)  # and is reproducible
+    assert not torch.equal(c1[0], c1[1])                                        # meshes draw independently
+    graph = torch.cuda.CUDAGraph()
+    ops.draw_samples(verts, faces, 5000)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        cg, ug, vg = ops.draw_samples(verts, faces, 5000)
+    graph.replay()
+    first = cg.clone()
+    graph.replay()
+    assert not torch.equal(first, cg)                                           # replays are not frozen
+    big_c, big_u, big_v = ops.draw_samples(verts, faces, 200000)
+    areas = ops.face_areas(verts, faces)[0].double().cpu()
+    freq = torch.bincount(big_c[0], minlength=Fc.shape[0]).double().cpu() / 200000
+    assert float((freq - areas / areas.sum()).abs().max()) < 1e-3
+    assert abs(float((big_u * big_u).mean()) - 0.5) < 5e-3 and abs(float(big_v.mean()) - 0.5) < 5e-3
+    assert float(big_u.min()) >= 0 and float(big_u.max()) < 1 and float(big_v.max()) < 1
+
+
+def test_vertex_head_matches_slice_formulation(gpu):
+    base = torch.randn(3, 50, 3, device=gpu, requires_grad=True)
+    feat = torch.randn(3, 50, 24, device=gpu, requires_grad=True)
+    b2, f2 = base.detach().clone().requires_grad_(True), feat.detach().clone().requires_grad_(True)
+    out = ops.VertexHead.apply(base, feat, 0.01)
+    ref = b2 + 0.01 * f2[..., :3]
+    g = torch.randn_like(out)
+    out.backward(g)
+    ref.backward(g)
+    assert torch.allclose(out, ref, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(base.grad, b2.grad) and torch.allclose(feat.grad, f2.grad, rtol=1e-6, atol=1e-9)
