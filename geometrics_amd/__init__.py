@@ -6,6 +6,7 @@ python operator surface of the reference on top of it:
     geometrics_amd.chamfer_distance.ChamferDistance      (reference chamfer_distance/chamfer_distance.py)
     geometrics_amd.tri_distance.TriDistance              (reference tri_distance/tri_distance.py)
     geometrics_amd.layers.{ZERON_GCN, GCNMax, Batch_Image_ZERON_GCNGCN, BatchZERON_GCN, BatchGCNMax}
+    geometrics_amd.models.{BatchMeshDeformationBlock, MeshEncoder};  geometrics_amd.ragged.RaggedMeshBatch
     geometrics_amd.utils.{batch_sample, batch_point_to_point, batch_point_to_surface, ...}
 
 There is no CPU fallback: every op raises if libgeom_hip.so is missing or a tensor is not

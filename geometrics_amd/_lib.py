@@ -39,6 +39,8 @@ _SIGNATURES = {
     "geom_chamfer_grad_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp],
     "geom_p2tri_loss_fwd_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "geom_p2tri_loss_bwd_f32": [_i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp],
+    "geom_segment_max_fwd_f32": [_i, _vp, ctypes.c_int64, _i, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp],
+    "geom_segment_max_bwd_f32": [_i, _vp, ctypes.c_int64, _i, _vp, _vp, _vp, _vp],
     "geom_sum_f32": [ctypes.c_int64, _vp, _f, _vp, _vp],
     "geom_sum2_f32": [ctypes.c_int64, _vp, _f, ctypes.c_int64, _vp, _f, _vp, _vp],
     "geom_sample_chamfer_bwd_f32": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _f, _vp, _vp],
@@ -86,6 +88,8 @@ def lib():
                                % (L.geom_abi_version(), ABI_VERSION))
         L.geom_pool_features_bwd_workspace_bytes.restype = ctypes.c_size_t
         L.geom_pool_features_bwd_workspace_bytes.argtypes = [_i, _i, _i, _vp]
+        L.geom_segment_max_workspace_bytes.restype = ctypes.c_int64
+        L.geom_segment_max_workspace_bytes.argtypes = [_i, _i, ctypes.c_int64]
         L.geom_zn_gcn_bwd_scratch_floats.restype = ctypes.c_int64
         L.geom_zn_gcn_bwd_scratch_floats.argtypes = [_i, _i, _i]
         L.geom_tri_distance_workspace_bytes.restype = ctypes.c_size_t
@@ -100,7 +104,8 @@ def lib():
 
 def declared_symbols():
     return sorted(["geom_abi_version", "geom_strerror", "geom_tri_distance_workspace_bytes",
-                   "geom_zn_gcn_bwd_scratch_floats", "geom_pool_features_bwd_workspace_bytes"] + list(_SIGNATURES))
+                   "geom_zn_gcn_bwd_scratch_floats", "geom_pool_features_bwd_workspace_bytes",
+                   "geom_segment_max_workspace_bytes"] + list(_SIGNATURES))
 
 
 def check(code, what):

@@ -99,7 +99,9 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_kernel(GcnArgs a, in
         for (int r = r_begin + rl; r < r_end; r += rows_in_flight) {
             const int64_t row = mesh_row0 + r;
             Pack<VEC> acc, own;
-            if (BACKWARD || c0 >= a.k) { // the thread's own element: pass-through value and/or bias-gradient term
+            const bool pass = c0 + VEC > a.k; // the group holds pass-through columns (all of them, or -- when k is not
+                                              // a multiple of VEC -- the tail of the group that straddles column k)
+            if (BACKWARD || pass) { // the thread's own element: pass-through value and/or bias-gradient term
                 own.load(a.x + row * a.c + c0);
                 if (BACKWARD && ACT != ACT_NONE) {
                     Pack<VEC> o;
@@ -138,6 +140,11 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_kernel(GcnArgs a, in
                             }
                         }
                     }
+                }
+                if (pass) { // straddling group: the gathered values of columns >= k are discarded
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i)
+                        if (c0 + i >= a.k) acc.at(i) = own.at(i);
                 }
             } else {
                 acc = own;
@@ -215,7 +222,7 @@ inline GcnGeometry gcn_geometry(int b, int nv, int c, int vec, bool backward)
     return g;
 }
 
-inline bool gcn_vec4(int c, int k) { return (c % 4 == 0) && (k % 4 == 0); }
+inline bool gcn_vec4(int c, int /*k*/) { return c % 4 == 0; } // any k: the group straddling column k is mixed
 
 template <int VEC, bool BACKWARD>
 int launch(const GcnArgs &a, int act, float *colsum_partial, float *grad_bias, void *stream)

@@ -53,11 +53,40 @@ def _to_ell(rowptr, col, val, width):
     return ell_col.contiguous(), ell_val.contiguous()
 
 
+def _finish_csr(c):
+    """Derived tables shared by every construction route: 1/(degree without the self loop) and, for bounded
+    degrees, the fixed-stride ELL neighbour tables of the fast aggregation kernel."""
+    c.nv = int(c.rowptr.numel()) - 1
+    c.nnz = int(c.col.numel())
+    # 1 / (neighbours without the self loop): what batch_get_lap_info divides by on the binary adjacency
+    c.inv_deg = (1.0 / ((c.rowptr[1:] - c.rowptr[:-1]).float() - 1.0)).contiguous()
+    longest = int(max((c.rowptr[1:] - c.rowptr[:-1]).max(), (c.rowptr_t[1:] - c.rowptr_t[:-1]).max())) if c.nv else 0
+    c.ell_w = 8 if longest <= 8 else (16 if longest <= 16 else 0)   # ELL fast path for bounded degrees
+    c.ell_col = c.ell_val = c.ell_col_t = c.ell_val_t = None
+    if c.ell_w:
+        c.ell_col, c.ell_val = _to_ell(c.rowptr, c.col, c.val, c.ell_w)
+        c.ell_col_t, c.ell_val_t = _to_ell(c.rowptr_t, c.col_t, c.val_t, c.ell_w)
+    return c
+
+
+def csr_from_parts(rowptr, col, val, rowptr_t, col_t, val_t):
+    """An adjacency handed over already in CSR (+ CSR^T): int32 rowptr/col, fp32 val, on the device.  The result
+    can be passed wherever a layer takes `adj` (geometrics_amd.ragged builds block-diagonal batches this way)."""
+    c = _Csr()
+    c.rowptr, c.col, c.val, c.rowptr_t, c.col_t, c.val_t = rowptr, col, val, rowptr_t, col_t, val_t
+    with torch.no_grad():
+        return _finish_csr(c)
+
+
 def adjacency_csr(adj):
     """CSR + CSR^T (+ ELL tables) of a dense [V,V] adjacency, cached per TENSOR OBJECT and in-place
     version.  The key is the object's identity guarded by a weak reference -- never the data pointer,
     which the caching allocator hands to the next adjacency of the same size (auto_encoder.py builds a
     fresh one per mesh).  Building reads the dense matrix once (one host sync, at first use only)."""
+    if isinstance(adj, _Csr):
+        return adj
+    if hasattr(adj, "csr") and isinstance(adj.csr, _Csr):     # a RaggedMeshBatch
+        return adj.csr
     if adj.dim() != 2 or adj.shape[0] != adj.shape[1]:
         raise RuntimeError("adjacency must be a square [V,V] tensor, got %s" % (tuple(adj.shape),))
     key = id(adj)
@@ -71,15 +100,7 @@ def adjacency_csr(adj):
         dense = adj.detach()
         c.rowptr, c.col, c.val = _to_csr(dense)
         c.rowptr_t, c.col_t, c.val_t = _to_csr(dense.t())
-        c.nv = adj.shape[0]
-        c.nnz = int(c.col.numel())
-        # 1 / (neighbours without the self loop): what batch_get_lap_info divides by on the binary adjacency
-        c.inv_deg = (1.0 / ((c.rowptr[1:] - c.rowptr[:-1]).float() - 1.0)).contiguous()
-        longest = int(max((c.rowptr[1:] - c.rowptr[:-1]).max(), (c.rowptr_t[1:] - c.rowptr_t[:-1]).max()))
-        c.ell_w = 8 if longest <= 8 else (16 if longest <= 16 else 0)   # ELL fast path for bounded degrees
-        if c.ell_w:
-            c.ell_col, c.ell_val = _to_ell(c.rowptr, c.col, c.val, c.ell_w)
-            c.ell_col_t, c.ell_val_t = _to_ell(c.rowptr_t, c.col_t, c.val_t, c.ell_w)
+        _finish_csr(c)
     _csr_cache[key] = (weakref.ref(adj, lambda _ref, k=key: _csr_cache.pop(k, None)), adj._version, c)
     return c
 
@@ -256,11 +277,16 @@ class _MaxPoolBase(Module):
 
 
 class GCNMax(_MaxPoolBase):
-    """Unbatched: max over vertices of activation(v) (reference layers.py:43-79)."""
+    """Unbatched: max over vertices of activation(v) (reference layers.py:43-79).  Given a RaggedMeshBatch as
+    `adj` (r_s = the concatenated [sum(V), Cin] features) it returns one row per mesh, [B, print_length]."""
 
     def forward(self, r_s, adj, activation):
         support = torch.matmul(r_s, self.weight_Ws[0])
-        return torch.max(zero_n_aggregate(support, adj, self.weight_Bs[0], support.shape[-1] // 10, activation), dim=0)[0]
+        acted = zero_n_aggregate(support, adj, self.weight_Bs[0], support.shape[-1] // 10, activation)
+        if hasattr(adj, "offsets"):
+            from .ops import SegmentMax
+            return SegmentMax.apply(acted, adj.offsets, adj.max_len)
+        return torch.max(acted, dim=0)[0]
 
 
 class BatchGCNMax(_MaxPoolBase):

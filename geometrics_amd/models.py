@@ -10,10 +10,11 @@ Data-parallel note: like torch's BatchNorm under DDP without SyncBN, statistics 
 LOCAL shard of meshes.
 """
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
-from .layers import Batch_Image_ZERON_GCNGCN
+from .layers import Batch_Image_ZERON_GCNGCN, GCNMax, ZERON_GCN
 
 
 def _identity(x):
@@ -127,3 +128,35 @@ class BatchMeshDeformationBlock(nn.Module):
         feats = self.bn13(self.gc13(feats, adj, _identity), relu=True, residual=feats)
         coords = self.gc15(feats, adj, _identity)
         return feats, coords
+
+
+class MeshEncoder(nn.Module):
+    """Reference models.py:299-348: 16 unbatched 0N-GCN layers (3 -> 60 ... -> 300, ELU) and a GCNMax head that
+    max-pools the vertices into the latent vector.  Layer names, widths and state_dict keys are the reference's.
+
+    `forward(positions, adj)` is the reference call for ONE mesh (adj = its dense normalised adjacency, converted
+    to CSR once and cached).  `encode_batch(batch)` takes a geometrics_amd.ragged.RaggedMeshBatch and returns
+    [B, latent] for all meshes at once -- the replacement for the per-mesh python loop of auto_encoder.py:71-76:
+    every layer is one GEMM over sum(V) rows + one aggregation launch on the block-diagonal CSR."""
+
+    _WIDTHS = (("h1", 3, 60), ("h21", 60, 60), ("h22", 60, 60), ("h23", 60, 60), ("h24", 60, 120), ("h3", 120, 120),
+               ("h4", 120, 120), ("h41", 120, 150), ("h5", 150, 200), ("h6", 200, 210), ("h7", 210, 250),
+               ("h8", 250, 300), ("h81", 300, 300), ("h9", 300, 300), ("h10", 300, 300), ("h11", 300, 300))
+
+    def __init__(self, latent_length):
+        super().__init__()
+        for name, cin, cout in self._WIDTHS:
+            setattr(self, name, ZERON_GCN(cin, cout))
+        self.reduce = GCNMax(300, latent_length)
+
+    def _trunk(self, positions, adj):
+        features = positions
+        for name, _, _ in self._WIDTHS:
+            features = getattr(self, name)(features, adj, F.elu)
+        return features
+
+    def forward(self, positions, adj, play=False):
+        return self.reduce(self._trunk(positions, adj), adj, F.elu)
+
+    def encode_batch(self, batch):
+        return self.reduce(self._trunk(batch.verts, batch), batch, F.elu)

@@ -341,6 +341,40 @@ class PoolFeatures(torch.autograd.Function):
         return (gverts, None, None) + tuple(gblks)
 
 
+class SegmentMax(torch.autograd.Function):
+    """Column maximum per mesh of a ragged batch: x [sum(V), C], offsets [B+1] int64 (device) -> [B, C]
+    (GCNMax's `torch.max(i_s, dim=0)[0]`, reference layers.py:78, for every mesh at once).  The gradient goes to
+    the arg-max row only (lowest row on ties), written by a gather -- grad_x needs no zero fill."""
+
+    @staticmethod
+    def forward(ctx, x, offsets, max_len):
+        x_ = _f32(x, "x", 2)
+        offsets = _lib.require(offsets, "offsets", torch.int64, 1)
+        nseg, c = offsets.numel() - 1, x_.shape[1]
+        out = torch.empty(nseg, c, dtype=torch.float32, device=x_.device)
+        arg = torch.empty(nseg, c, dtype=torch.int32, device=x_.device)
+        ws_bytes = _lib.lib().geom_segment_max_workspace_bytes(nseg, c, int(max_len))
+        ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=x_.device)
+        with torch.cuda.device(x_.device):
+            _lib.call("geom_segment_max_fwd_f32", nseg, offsets.data_ptr(), int(max_len), c, x_.data_ptr(),
+                      out.data_ptr(), arg.data_ptr(), ws.data_ptr(), ws_bytes)
+        ctx.save_for_backward(offsets, arg)
+        ctx.rows = x_.shape[0]
+        ctx.mark_non_differentiable(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        offsets, arg = ctx.saved_tensors
+        g = grad_out.contiguous()
+        nseg, c = arg.shape
+        grad_x = torch.empty(ctx.rows, c, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.call("geom_segment_max_bwd_f32", nseg, offsets.data_ptr(), ctx.rows, c, g.data_ptr(), arg.data_ptr(),
+                      grad_x.data_ptr())
+        return grad_x, None, None
+
+
 _side_streams = {}
 
 
@@ -439,6 +473,6 @@ class VertexHead(torch.autograd.Function):
 
 
 __all__ = ["face_areas", "device_sum", "SampleFaces", "GatherSqDistSum", "PointToTriangleSum", "SurfaceLoss",
-           "Laplacian", "EdgeSqLenSum", "PoolFeatures", "VertexHead", "manual_seed",
+           "Laplacian", "EdgeSqLenSum", "PoolFeatures", "VertexHead", "SegmentMax", "manual_seed",
            "draw_samples",
            "chamfer_nn", "tri_distance_indexed"]

@@ -251,6 +251,19 @@ int geom_pool_features_bwd_f32(int b, int nv, const float *verts, const float *c
                                const float *grad_out, float *const *grad_blocks, float *grad_verts,
                                void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- ragged mesh batches (SURVEY 8f "next" row 4; auto_encoder.py:71-76, layers.py:78) ---------------
+ * Meshes of different sizes are concatenated along the vertex axis; segment s owns rows
+ * [offsets[s], offsets[s+1]) of x [offsets[nseg], c] (offsets: nseg+1 device int64).  out[s,col] =
+ * max over the segment's rows (GCNMax's torch.max(..., dim=0)), arg[s,col] = the winning row RELATIVE to
+ * the segment start (lowest row on ties, first NaN wins; -inf / -1 for an empty segment).  max_len = the
+ * longest segment (host-known; sizes the row split).  The backward writes every element of grad_x
+ * [total_rows, c] once: grad_out[s,col] at the arg-max row, 0 elsewhere. */
+int64_t geom_segment_max_workspace_bytes(int nseg, int c, int64_t max_len);
+int geom_segment_max_fwd_f32(int nseg, const int64_t *offsets, int64_t max_len, int c, const float *x,
+                             float *out, int *arg, void *workspace, int64_t workspace_bytes, void *stream);
+int geom_segment_max_bwd_f32(int nseg, const int64_t *offsets, int64_t total_rows, int c,
+                             const float *grad_out, const int *arg, float *grad_x, void *stream);
+
 /* ---- optimiser step for the replicated layer parameters (GEOMetrics.py:73: Adam, lr 1e-4) -----------
  * torch.optim.Adam's update (no weight decay / amsgrad) for up to GEOM_ADAM_MAX_TENSORS tensors in one
  * launch.  params/grads/exp_avg/exp_avg_sq/sizes are HOST arrays of `count` device pointers / lengths;

@@ -152,3 +152,21 @@ def calc_edge(verts, faces):
     """utils.py:636-651."""
     p1, p2, p3 = (verts[:, faces[:, k]] for k in range(3))
     return (((p2 - p1) ** 2).sum(-1).mean() + ((p3 - p1) ** 2).sum(-1).mean() + ((p2 - p3) ** 2).sum(-1).mean()) / 3.0
+
+
+ENCODER_LAYERS = ("h1", "h21", "h22", "h23", "h24", "h3", "h4", "h41", "h5", "h6", "h7", "h8", "h81", "h9", "h10", "h11")
+
+
+def mesh_encoder(params, positions, adj):
+    """models.py:324-348 for one mesh: 16 ELU 0N-GCN layers (split 10), then GCNMax (layers.py:61-79).
+    params: {name: tensor} with the reference's state_dict keys."""
+    elu = torch.nn.functional.elu
+    x = positions
+    for name in ENCODER_LAYERS:
+        x = zero_n_layer(x, adj, params[name + ".weight"], params[name + ".bias"], 10, elu)
+    return gcn_max(x, adj, params["reduce.weight_Ws.0"], params["reduce.weight_Bs.0"], elu, batched=False)
+
+
+def segment_max(x, sizes):
+    """Per-mesh column max of rows concatenated along dim 0 (layers.py:78 applied mesh by mesh)."""
+    return torch.stack([part.max(dim=0)[0] for part in torch.split(x, list(sizes), dim=0)])

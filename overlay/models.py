@@ -1,6 +1,6 @@
 """Overlay module for the reference's `models.py`: everything stays the user's reference code (VGG,
-encoders, decoder) except `BatchMeshDeformationBlock`, which is replaced by the fused-kernel version
-with identical attribute names and state_dict keys (geometrics_amd/models.py).  Same mechanism as
+encoders, decoder) except `BatchMeshDeformationBlock` and `MeshEncoder`, which are replaced by the fused-kernel
+versions with identical attribute names and state_dict keys (geometrics_amd/models.py).  Same mechanism as
 overlay/utils.py: the reference file further down sys.path is executed and its names re-exported."""
 import importlib.util
 import os
@@ -24,4 +24,4 @@ _spec.loader.exec_module(_reference_models)
 
 globals().update({k: v for k, v in vars(_reference_models).items() if not k.startswith("__")})
 
-from geometrics_amd.models import BatchMeshDeformationBlock, VertexBatchNorm  # noqa: E402,F401
+from geometrics_amd.models import BatchMeshDeformationBlock, MeshEncoder, VertexBatchNorm  # noqa: E402,F401

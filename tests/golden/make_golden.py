@@ -328,7 +328,52 @@ def make_pooling():
     save("pooling_v162", **arrays)
 
 
+# ---------------------------------------------------- ragged mesh encoder (8f row 4) ----
+def ragged_meshes():
+    """Three meshes of different sizes and degree patterns: icosphere(1), icosphere(2), and icosphere(1) with one
+    face split at its centroid (a degree-3 vertex next to degree-6/7 ones)."""
+    V1, F1 = meshgen.icosphere(1)
+    V2, F2 = meshgen.icosphere(2)
+    c = V1[F1[0]].mean(0, keepdims=True)
+    V3 = np.concatenate([V1, c]).astype(np.float32)
+    n = V1.shape[0]
+    a, b, d = F1[0]
+    F3 = np.concatenate([F1[1:], np.array([[a, b, n], [b, d, n], [d, a, n]], dtype=F1.dtype)])
+    rng = np.random.default_rng(5)
+    return [(V + 0.02 * rng.standard_normal(V.shape)).astype(np.float32) for V in (V1, V2, V3)], [F1, F2, F3]
+
+
+def make_encoder():
+    """auto_encoder.py:71-76 run literally: the reference MeshEncoder on one mesh at a time with its dense
+    normalised adjacency (utils.py:256-257), latents stacked; gradients of sum(latent * g)."""
+    import models as ref_models
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import fill_parameters
+    assert ref_models.__file__.startswith(REF)
+    verts, faces = ragged_meshes()
+    enc = fill_parameters(ref_models.MeshEncoder(50), 77)
+    pos = [t(v, grad=True) for v in verts]
+    latents = torch.stack([enc(p, ref_utils.normalize_adj(ref_utils.calc_adj(t(f)))) for p, f in zip(pos, faces)])
+    g = torch.from_numpy(np.random.default_rng(6).standard_normal(tuple(latents.shape)).astype(np.float32))
+    (latents * g).sum().backward()
+    arrays = dict(verts=np.concatenate(verts), faces=np.concatenate(faces), sizes=np.array([v.shape[0] for v in verts]),
+                  face_counts=np.array([f.shape[0] for f in faces]), seed=np.array(77), latents=latents.detach().numpy(),
+                  g=g.numpy(), grad_verts=np.concatenate([p.grad.numpy() for p in pos]))
+    params = dict(enc.named_parameters())
+    for k in ("h1.weight", "h1.bias", "h24.weight", "h11.bias", "reduce.weight_Ws.0", "reduce.weight_Bs.0"):
+        arrays["grad." + k] = params[k].grad.numpy()
+    # the same run in float64: how far fp32 summation order alone moves the result
+    enc64 = fill_parameters(ref_models.MeshEncoder(50), 77).double()
+    lat64 = torch.stack([enc64(t(v).double(), ref_utils.normalize_adj(ref_utils.calc_adj(t(f))).double())
+                         for v, f in zip(verts, faces)])
+    arrays["latents_f64"] = lat64.detach().numpy()
+    save("mesh_encoder_ragged", **arrays)
+
+
 if __name__ == "__main__":
+    if "--encoder" in sys.argv:
+        make_encoder()
+        sys.exit(0)
     if "--pooling" in sys.argv:
         make_pooling()
         sys.exit(0)

@@ -16,3 +16,17 @@ def golden_names(prefix):
 
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def fill_parameters(module, seed, gain=2.0):
+    """Deterministic parameter values independent of torch's RNG stream (so a fixture only stores the seed):
+    matrices ~ U(+-gain/sqrt(sum(shape))), vectors ~ U(+-0.1), in sorted-name order."""
+    import zlib
+
+    import torch
+    with torch.no_grad():
+        for name, p in sorted(module.named_parameters()):
+            rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
+            bound = gain / np.sqrt(sum(p.shape)) if p.dim() >= 2 else 0.1
+            p.copy_(torch.from_numpy(rng.uniform(-bound, bound, tuple(p.shape)).astype(np.float32)))
+    return module

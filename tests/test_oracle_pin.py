@@ -196,3 +196,23 @@ def test_nn_grad_restatement_equals_autograd_of_the_distance_form():
     ((d1 * torch.from_numpy(w1)).sum() + (d2 * torch.from_numpy(w2)).sum()).backward()
     np.testing.assert_allclose(g1, ta.grad.numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(g2, tb.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_mesh_encoder_restatement_matches_reference_fixture():
+    """oracle.ref_ops.mesh_encoder (the per-mesh checker of the ragged encoder path) against latents the imported
+    reference MeshEncoder produced (tests/golden/make_golden.py --encoder)."""
+    import torch
+    from geometrics_amd import models
+    from helpers import fill_parameters
+    from oracle import ref_ops
+    fx = golden("mesh_encoder_ragged")
+    enc = fill_parameters(models.MeshEncoder(50), int(fx["seed"]))
+    params = {k: v.detach() for k, v in enc.state_dict().items()}
+    verts = np.split(fx["verts"], np.cumsum(fx["sizes"])[:-1])
+    faces = np.split(fx["faces"], np.cumsum(fx["face_counts"])[:-1])
+    for i, (v, f) in enumerate(zip(verts, faces)):
+        adj = ref_ops.normalize_adj(ref_ops.calc_adj(torch.from_numpy(f)))
+        lat = ref_ops.mesh_encoder(params, torch.from_numpy(v), adj)
+        assert np.allclose(lat.numpy(), fx["latents"][i], rtol=1e-5, atol=1e-6)
+    # fp32 summation-order noise of the 17-layer stack, measured by the reference's own float64 run
+    assert np.abs(fx["latents"] - fx["latents_f64"]).max() < 1e-4 * np.abs(fx["latents_f64"]).max()
