@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgeom_hip.so")
 FLAG_REF_TAIL_TRUNC = 1
 FLAG_FIX_REGION6 = 2
 FLAG_TRI_BRUTE_FORCE = 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 EUNSUPPORTED = -3
 
 _vp = ctypes.c_void_p
@@ -27,8 +27,8 @@ _SIGNATURES = {
     "geom_chamfer_nn_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp],
     "geom_tri_distance_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp],
     "geom_tri_distance_indexed_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _u, _vp],
-    "geom_tri_distance_ws_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp, ctypes.c_size_t, _vp],
-    "geom_tri_distance_indexed_ws_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _u, _vp, ctypes.c_size_t, _vp],
+    "geom_tri_distance_ws_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp, ctypes.c_size_t, _vp],
+    "geom_tri_distance_indexed_ws_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp, ctypes.c_size_t, _vp],
     "geom_face_areas_f32": [_i, _i, _vp, _i, _vp, _vp, _vp],
     "geom_draw_samples_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_draw_samples_rng_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],

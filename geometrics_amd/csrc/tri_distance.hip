@@ -1,7 +1,7 @@
 // Point-to-triangle arg-min scan for gfx950.
 //
 // Replaces TriDistanceKernel + launcher of the reference (tri_distance/tri_distance.cu:94-211,
-// 213-228).  Three kernels live here, all with lane <-> query point and 64 queries per workgroup,
+// 213-228).  Four scans live here, all with 64 query points per workgroup,
 // all producing the reference's sequential strict-'<' arg-min bit for bit (partial results are merged
 // lexicographically on (distance, triangle) and the "first triangle seeds" rule is applied explicitly):
 //
@@ -12,8 +12,12 @@
 //                                     corner arrays -- what the workspace-free entry points (the exact
 //                                     reference prototypes) run.
 //   3. tri_prep_kernel + tri_scan_ws_kernel (+ tri_finalize_kernel)
-//                                     culled scan over per-triangle records in a caller-provided workspace:
-//                                     the fast path the python operators use.
+//                                     culled scan over per-triangle records in a caller-provided workspace
+//                                     (flat: every query tests every triangle sphere).
+//   4. tri_prep_grouped_kernel + tri_scan_grouped_kernel
+//                                     two-level scan over groups of 16 triangles (group sphere -> member
+//                                     spheres -> literal evaluation) when the caller supplies a spatially
+//                                     coherent visiting order: the fast path the python operators use.
 //
 // In the INDEXED variants the corners are gathered from verts through faces, so the three [b,F,3] corner
 // arrays the reference materialises (utils.py:467-469) never exist.
@@ -602,8 +606,8 @@ __global__ __launch_bounds__(WS_THREADS) void tri_scan_ws_kernel(const float *__
 
 // split > 1 only: the merged word of every query -> outputs, with the "first triangle seeds" rule
 template <bool TRUNC, bool FIX6>
-__global__ __launch_bounds__(256) void tri_finalize_kernel(const float *__restrict__ xyz, int n, int m, int m_pad,
-                                                           const float4 *__restrict__ cor_all,
+__global__ __launch_bounds__(256) void tri_finalize_kernel(const float *__restrict__ xyz, int n, int m,
+                                                           const float4 *__restrict__ first_all, size_t first_stride,
                                                            const unsigned long long *__restrict__ keys,
                                                            float *__restrict__ dist, int *__restrict__ point,
                                                            int *__restrict__ index)
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(256) void tri_finalize_kernel(const float *__restri
     const unsigned long long word = keys[o];
     float acc_d = __uint_as_float((unsigned)(word >> 32));
     int acc_k = (int)(unsigned)word;
-    const float4 *cor = cor_all + (size_t)mesh * m_pad * 3;
+    const float4 *cor = first_all + (size_t)mesh * first_stride; // corners of (original) triangle 0
     const V3 p = load3(xyz + o * 3);
     const float4 a = cor[0], bq = cor[1], c = cor[2];
     int opt0;
@@ -648,7 +652,357 @@ int launch_ws_variant(const TriJob &job, const TriWs &ws, hipStream_t s)
                        ws.split, ws.keys);
     if (ws.split > 1)
         hipLaunchKernelGGL((tri_finalize_kernel<TRUNC, FIX6>), dim3((job.n + 255) / 256, job.b), dim3(256), 0, s, job.xyz,
-                           job.n, job.m, ws.m_pad, ws.cor, ws.keys, job.dist, job.point, job.index);
+                           job.n, job.m, ws.cor, (size_t)ws.m_pad * 3, ws.keys, job.dist, job.point, job.index);
+    return geom::launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// Grouped (two-level) scan: the fast path when the caller supplies a spatially coherent triangle
+// order (`order` != null; geometrics_amd.tri_distance derives a Morton order of the face centroids once
+// per face list).  Same result as every kernel above, bit for bit -- the permutation only decides which
+// triangles share a group; keys carry the ORIGINAL triangle index, so ties still go to the lowest one.
+//
+//   prep   slot j holds triangle order[j]: sphere + corners as before (the original index rides in the
+//          spare lane of the first corner), and every GRP = 16 consecutive slots get a GROUP sphere
+//          {c_g, R_g}: c_g = mean of the member centres, R_g = max(|c_i - c_g| + r_eff_i), inflated by the
+//          same margins.  Every point the decision tree can return for a member lies inside it, so
+//              lower bound   d_ref(p, t) >= (|p - c_g| - R_g)^2     for every member t
+//              upper bound   min_t d_ref(p, t) <= (|p - c_g| + R_g)^2
+//          (R_g = inf as soon as one member is untrusted: such a group is never culled, never a seed.)
+//   scan   a workgroup = 64 query points x 16 waves.
+//          A1  lanes <-> queries, group spheres broadcast from LDS (320 records for 5120 triangles
+//              instead of 5120): the smallest upper bound and its group -> per-query seed;
+//          A1' the 16 members of that group are evaluated literally, one thread per (query, member): the
+//              bound every later test uses starts from a real candidate next to the query;
+//          A2  groups again: |p - c_g|^2 > (R_g + s)^2 drops the group, survivors (about ten per query)
+//              are compacted into a per-wave queue of (query, group) items;
+//          B   lanes <-> (item, member), 16 items per step (4 sphere loads per lane in flight together): a
+//              group's member records are 256 contiguous bytes (L2); survivors go to a second queue of
+//              (query, slot) items;
+//          C   literal evaluation 64 items at a time, one ds_min_u64 per result (tightens every wave's s).
+//          Waves take groups in a strided pattern so that spatially sorted queries still spread evenly.
+// Per query this is ~2 x 320 group tests + ~100 member tests + a few tens of literal evaluations instead
+// of 5120 member tests; with an incoherent order the group spheres are useless (every group survives) and
+// the flat kernel above is the better choice -- which is why the hierarchy is opt-in through `order`.
+constexpr int GRP = 16;
+constexpr int HS_THREADS = 1024;
+constexpr int HS_WAVES = HS_THREADS / GEOM_WAVE; // 16
+static_assert(HS_WAVES == GRP, "the seed reduction maps wave w to member lane w");
+constexpr int HS_GCHUNK = 2048;                  // group spheres staged per pass (32 KiB = 32768 triangles)
+constexpr int HS_QA = 16 + 4 * GEOM_WAVE;        // (query, group) items per wave
+constexpr int HS_QB = 2 * GEOM_WAVE;             // (query, slot) items per wave
+constexpr unsigned INF_BITS = 0x7f800000u;
+
+struct TriGws {
+    float4 *sph;   // [b][m_pad]     member spheres, slot order
+    float4 *cor;   // [b][m_pad][3]  corners; cor[3j].w = original triangle index (int bits), -1 = padding
+    float4 *grp;   // [b][m_pad/16]  group spheres
+    float4 *first; // [b][3]         corners of original triangle 0 (the "k == 0 ||" seed)
+    unsigned long long *keys; // [b][n], split > 1 only
+    int m_pad, split;
+};
+
+template <bool INDEXED, bool TRUNC, bool FIX6>
+__global__ __launch_bounds__(256) void tri_prep_grouped_kernel(TriJob job, TriGws ws, const int *__restrict__ order)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int mesh = blockIdx.y;
+    if (ws.split > 1 && j < job.n) ws.keys[(size_t)mesh * job.n + j] = KEY_NONE;
+    if (j >= ws.m_pad) return; // m_pad is a multiple of 64: whole waves leave together
+    int k = -1;
+    if (j < job.m) {
+        k = order[j];
+        if (k < 0 || k >= job.m) k = -1; // not a permutation entry: the slot is dropped
+    }
+    float4 rec = make_float4(INFINITY, 0.f, 0.f, 0.f);
+    V3 A = geom::mk(0.f, 0.f, 0.f), B = A, C = A;
+    bool scanned = false; // takes part in the arg-min
+    if (k >= 0) {
+        fetch_triangle<INDEXED>(job, mesh, k, A, B, C);
+        rec = bounding_sphere<FIX6>(A, B, C);
+        scanned = !(TRUNC && geom::ref_tail_skipped(k, job.m));
+        if (!scanned) rec.x = INFINITY;
+        if (k == 0) {
+            float4 *f = ws.first + (size_t)mesh * 3;
+            f[0] = make_float4(A.x, A.y, A.z, 0.f);
+            f[1] = make_float4(B.x, B.y, B.z, 0.f);
+            f[2] = make_float4(C.x, C.y, C.z, 0.f);
+        }
+    }
+    const size_t o = (size_t)mesh * ws.m_pad + j;
+    ws.sph[o] = rec;
+    ws.cor[3 * o + 0] = make_float4(A.x, A.y, A.z, __int_as_float(k));
+    ws.cor[3 * o + 1] = make_float4(B.x, B.y, B.z, 0.f);
+    ws.cor[3 * o + 2] = make_float4(C.x, C.y, C.z, 0.f);
+
+    // group sphere over the 16 lanes of this group (xor shuffles stay inside an aligned 16-lane block)
+    const bool centred = scanned && (fabsf(rec.x) + fabsf(rec.y) + fabsf(rec.z) < INFINITY); // finite centre
+    float sx = centred ? rec.x : 0.f, sy = centred ? rec.y : 0.f, sz = centred ? rec.z : 0.f, cnt = centred ? 1.f : 0.f;
+    float bad = (scanned && !centred) ? 1.f : 0.f; // a scanned member without a usable sphere
+#pragma unroll
+    for (int d = GRP / 2; d > 0; d >>= 1) {
+        sx += __shfl_xor(sx, d);
+        sy += __shfl_xor(sy, d);
+        sz += __shfl_xor(sz, d);
+        cnt += __shfl_xor(cnt, d);
+        bad += __shfl_xor(bad, d);
+    }
+    float4 g = make_float4(INFINITY, 0.f, 0.f, 0.f); // no scanned member: culled for every finite query
+    float reach = 0.f;
+    if (cnt > 0.f) {
+        const float inv = 1.f / cnt;
+        g = make_float4(sx * inv, sy * inv, sz * inv, 0.f);
+        if (centred) reach = sqrtf(geom::sqdist3(rec.x, rec.y, rec.z, g.x, g.y, g.z)) * (1.f + 0x1p-20f) + rec.w;
+    }
+#pragma unroll
+    for (int d = GRP / 2; d > 0; d >>= 1) reach = fmaxf(reach, __shfl_xor(reach, d));
+    if (cnt > 0.f) {
+        const float mag = fabsf(g.x) + fabsf(g.y) + fabsf(g.z) + reach;
+        g.w = reach * (1.f + 0x1p-10f) + 0x1p-12f * mag;
+    }
+    if (bad > 0.f) g = make_float4(cnt > 0.f ? g.x : 0.f, cnt > 0.f ? g.y : 0.f, cnt > 0.f ? g.z : 0.f, INFINITY);
+    if ((j & (GRP - 1)) == 0) ws.grp[(size_t)mesh * (ws.m_pad / GRP) + j / GRP] = g;
+}
+
+template <bool TRUNC, bool FIX6>
+__global__ __launch_bounds__(HS_THREADS) void tri_scan_grouped_kernel(const float *__restrict__ xyz, int b, int n, int m,
+                                                                       TriGws ws, float *__restrict__ dist,
+                                                                       int *__restrict__ point, int *__restrict__ index)
+{
+    __shared__ float4 gtile[HS_GCHUNK];
+    __shared__ unsigned long long qbest[TRI_QUERIES]; // best evaluated (distance, triangle, region)
+    __shared__ unsigned long long qseed[TRI_QUERIES]; // smallest group upper bound and its group
+    __shared__ unsigned long long seed_part[HS_WAVES][TRI_QUERIES]; // per-wave candidates for it (no LDS atomics)
+    __shared__ unsigned qs[TRI_QUERIES];              // seed slack (float bits, positive: uint order == float order)
+    __shared__ float qp[3][TRI_QUERIES], qmag[TRI_QUERIES];
+    __shared__ unsigned queue_a[HS_WAVES][HS_QA];
+    __shared__ unsigned queue_b[HS_WAVES][HS_QB];
+
+    const int split = ws.split, m_pad = ws.m_pad;
+    int mesh, task;
+    if (!geom::xcd_assign(blockIdx.x, b, ((n + TRI_QUERIES - 1) / TRI_QUERIES) * split, mesh, task)) return;
+    const int qtile = task / split, part = task - qtile * split;
+    const int q0 = qtile * TRI_QUERIES;
+    // this workgroup's group range, in units of 4 groups (m_pad is a multiple of 64)
+    const int groups = m_pad / GRP;
+    const int r_len = ((groups / 4 + split - 1) / split) * 4;
+    const int r_begin = part * r_len, r_end = min(groups, r_begin + r_len);
+    if (r_begin >= r_end) return;
+    const int lane = threadIdx.x & (GEOM_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = q0 + lane;
+    const bool live = q < n;
+    const float4 *__restrict__ sph = ws.sph + (size_t)mesh * m_pad;
+    const float4 *__restrict__ cor = ws.cor + (size_t)mesh * m_pad * 3;
+    const float4 *__restrict__ grp = ws.grp + (size_t)mesh * groups;
+    V3 p = geom::mk(0.f, 0.f, 0.f);
+    if (live) p = load3(xyz + ((size_t)mesh * n + q) * 3);
+    if (wave == 0) {
+        qbest[lane] = KEY_NONE;
+        qseed[lane] = KEY_NONE;
+        qs[lane] = INF_BITS;
+        qp[0][lane] = p.x;
+        qp[1][lane] = p.y;
+        qp[2][lane] = p.z;
+        qmag[lane] = fabsf(p.x) + fabsf(p.y) + fabsf(p.z);
+    }
+
+    // cull slack of query ql: sqrt(best evaluated distance) with margins, or the sphere-derived seed
+    auto slack = [&](int ql) {
+        const float bound = __uint_as_float((unsigned)(qbest[ql] >> 32)); // NaN until a candidate exists
+        const float sb = __builtin_amdgcn_sqrtf(bound) * (1.f + 0x1p-10f) + 0x1p-12f * qmag[ql]; // 1-ulp sqrt, 2^-10 margin
+        return fminf(sb, __uint_as_float(qs[ql])); // fminf drops the NaN; +inf (nothing known) culls nothing
+    };
+    auto evaluate = [&](int ql, int j) {
+        if (j >= m_pad) return;
+        const float4 a = cor[3 * (size_t)j + 0], bq = cor[3 * (size_t)j + 1], c = cor[3 * (size_t)j + 2];
+        const int k = __float_as_int(a.w);
+        if (k < 0 || (TRUNC && geom::ref_tail_skipped(k, m))) return;
+        const V3 pq = geom::mk(qp[0][ql], qp[1][ql], qp[2][ql]);
+        int opt;
+        const float d = geom::tri_pair_literal<FIX6>(pq, geom::mk(a.x, a.y, a.z), geom::mk(bq.x, bq.y, bq.z),
+                                                     geom::mk(c.x, c.y, c.z), opt);
+        if (d == d) {
+            const unsigned long long key = pack_key(d, k, opt);
+            if (key < qbest[ql]) atomicMin(&qbest[ql], key); // most candidates lose against the seed: plain read first
+        }
+    };
+
+    unsigned *qa = queue_a[wave], *qb = queue_b[wave];
+    int na = 0, nb = 0; // wave-uniform queue lengths
+    const unsigned long long live_mask = __ballot(live);
+    auto drain_b = [&](int first, int count) {
+        if (lane < count) {
+            const unsigned item = qb[first + lane];
+            evaluate((int)(item >> 26), (int)(item & 0x3ffffffu));
+        }
+    };
+    // phase B for `count` (<= 16) items of queue A starting at `first`: a lane takes member (lane % 16) of items
+    // lane/16, lane/16 + 4, ...; the four sphere loads of a lane are issued together (one L2 round trip per step)
+    auto members = [&](int first, int count) {
+        const int it = lane >> 4, mem = lane & (GRP - 1);
+        float4 rec[4];
+        int ql[4], slot[4];
+        bool valid[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = r * 4 + it;
+            valid[r] = idx < count;
+            const unsigned item = valid[r] ? qa[first + idx] : 0u;
+            ql[r] = (int)(item >> 26);
+            slot[r] = (int)(item & 0x3ffffffu) * GRP + mem;
+            rec[r] = make_float4(INFINITY, 0.f, 0.f, 0.f);
+            if (valid[r]) rec[r] = sph[slot[r]];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float c2 = geom::sqdist3(rec[r].x, rec[r].y, rec[r].z, qp[0][ql[r]], qp[1][ql[r]], qp[2][ql[r]]);
+            const float reach = rec[r].w + slack(ql[r]);
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(valid[r] && !(c2 > reach * reach));
+            if (mask != 0ull) {
+                const int pos = nb + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if ((mask >> lane) & 1ull) qb[pos] = ((unsigned)ql[r] << 26) | (unsigned)slot[r];
+                nb += __popcll(mask);
+                if (nb >= GEOM_WAVE) {
+                    nb -= GEOM_WAVE;
+                    drain_b(nb, GEOM_WAVE);
+                }
+            }
+        }
+    };
+
+    for (int c0 = r_begin; c0 < r_end; c0 += HS_GCHUNK) {
+        const int len = min(HS_GCHUNK, r_end - c0); // multiple of 4
+        for (int t = threadIdx.x; t < len; t += HS_THREADS) gtile[t] = grp[c0 + t];
+        __syncthreads();
+        const int batches = len / 4;
+
+        // ---- A1: smallest upper bound (|p - c_g| + R_g) over this wave's groups ----
+        {
+            float u_best = INFINITY;
+            int g_best = 0;
+            for (int bi = wave; bi < batches; bi += HS_WAVES) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float4 rec = gtile[bi * 4 + jj];
+                    // raw v_sqrt_f32 (1 ulp): only ranks the groups, and the fallback slack below is inflated by 2^-10
+                    const float u = __builtin_amdgcn_sqrtf(geom::sqdist3(rec.x, rec.y, rec.z, p.x, p.y, p.z)) + rec.w;
+                    if (u < u_best) { // NaN / inf never win
+                        u_best = u;
+                        g_best = c0 + bi * 4 + jj;
+                    }
+                }
+            }
+            seed_part[wave][lane] = (live && u_best < INFINITY)
+                                        ? (((unsigned long long)__float_as_uint(u_best) << 32) | (unsigned)g_best)
+                                        : KEY_NONE;
+        }
+        __syncthreads();
+        // ---- A1': the 16 members of the seed group are evaluated literally, one thread per (query, member):
+        //      the cull bound starts from a REAL candidate next to the query, not from a sphere estimate ----
+        {
+            const int ql = threadIdx.x >> 4, mem = threadIdx.x & (GRP - 1);
+            unsigned long long word = seed_part[mem][ql]; // HS_WAVES == GRP: lane `mem` holds wave `mem`'s candidate
+#pragma unroll
+            for (int d = GRP / 2; d > 0; d >>= 1) {
+                const unsigned long long other = __shfl_xor(word, d);
+                word = other < word ? other : word;
+            }
+            if (mem == 0) qseed[ql] = word;
+            if (word != KEY_NONE) {
+                evaluate(ql, (int)(unsigned)word * GRP + mem);
+                if (mem == 0) { // sphere-derived fallback for a seed group whose evaluations are all NaN
+                    const float s0 = __uint_as_float((unsigned)(word >> 32)) * (1.f + 0x1p-10f) + 0x1p-12f * qmag[ql];
+                    if (s0 < INFINITY) atomicMin(&qs[ql], __float_as_uint(s0));
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- A2 + B + C ----
+        const int seed_g = (int)(unsigned)qseed[lane]; // already evaluated (KEY_NONE -> -1: matches no group)
+        float s = slack(lane);
+        for (int bi = wave; bi < batches; bi += HS_WAVES) {
+            unsigned long long keep[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float4 rec = gtile[bi * 4 + jj];
+                const float c2 = geom::sqdist3(rec.x, rec.y, rec.z, p.x, p.y, p.z);
+                const float reach = rec.w + s;
+                keep[jj] = __builtin_amdgcn_ballot_w64(!(c2 > reach * reach) && (c0 + bi * 4 + jj != seed_g)) & live_mask;
+            }
+            if ((keep[0] | keep[1] | keep[2] | keep[3]) != 0ull) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const unsigned long long mask = keep[jj];
+                    if (mask != 0ull) {
+                        const int pos = na + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        if ((mask >> lane) & 1ull) qa[pos] = ((unsigned)lane << 26) | (unsigned)(c0 + bi * 4 + jj);
+                        na += __popcll(mask);
+                    }
+                }
+                if (na >= 16) {
+                    do {
+                        na -= 16;
+                        members(na, 16);
+                    } while (na >= 16);
+                    s = slack(lane);
+                }
+            }
+        }
+        if (na > 0) { // the chunk's remaining items (their group ids are global, but finishing here keeps s fresh)
+            members(0, na);
+            na = 0;
+        }
+        __syncthreads(); // gtile / qseed are rewritten by the next chunk
+    }
+    if (nb > 0) drain_b(0, nb);
+    __syncthreads();
+
+    if (split > 1) {
+        if (wave == 0 && live && qbest[lane] != KEY_NONE) atomicMin(&ws.keys[(size_t)mesh * n + q], qbest[lane]);
+        return;
+    }
+    if (wave == 0 && live) {
+        const unsigned long long word = qbest[lane];
+        float acc_d = __uint_as_float((unsigned)(word >> 32));
+        int acc_k = (int)(unsigned)word;
+        const float4 *f = ws.first + (size_t)mesh * 3; // "k == 0 ||" seed (tri_distance.cu:194)
+        const float4 a = f[0], bq = f[1], c = f[2];
+        int opt0;
+        const float d0 = geom::tri_pair_literal<FIX6>(p, geom::mk(a.x, a.y, a.z), geom::mk(bq.x, bq.y, bq.z),
+                                                      geom::mk(c.x, c.y, c.z), opt0);
+        if (d0 != d0 || word == KEY_NONE) {
+            acc_d = d0;
+            acc_k = opt0;
+        }
+        if (TRUNC) {
+            const int last0 = ((m - 1) / geom::REF_TILE) * geom::REF_TILE;
+            if (m - last0 < 4 && (last0 == 0 || acc_d > 10000.f)) {
+                acc_d = 10000.f;
+                acc_k = 0;
+            }
+        }
+        const size_t o = (size_t)mesh * n + q;
+        dist[o] = acc_d;
+        point[o] = acc_k & 7;
+        index[o] = acc_k >> 3;
+    }
+}
+
+template <bool INDEXED, bool TRUNC, bool FIX6>
+int launch_grouped_variant(const TriJob &job, const TriGws &ws, const int *order, hipStream_t s)
+{
+    const int prep_items = ws.split > 1 && job.n > ws.m_pad ? job.n : ws.m_pad;
+    hipLaunchKernelGGL((tri_prep_grouped_kernel<INDEXED, TRUNC, FIX6>), dim3((prep_items + 255) / 256, job.b), dim3(256), 0, s,
+                       job, ws, order);
+    const int qtiles = (job.n + TRI_QUERIES - 1) / TRI_QUERIES;
+    hipLaunchKernelGGL((tri_scan_grouped_kernel<TRUNC, FIX6>), dim3(geom::xcd_grid(job.b, qtiles * ws.split)),
+                       dim3(HS_THREADS), 0, s, job.xyz, job.b, job.n, job.m, ws, job.dist, job.point, job.index);
+    if (ws.split > 1)
+        hipLaunchKernelGGL((tri_finalize_kernel<TRUNC, FIX6>), dim3((job.n + 255) / 256, job.b), dim3(256), 0, s, job.xyz,
+                           job.n, job.m, ws.first, (size_t)3, ws.keys, job.dist, job.point, job.index);
     return geom::launch_status();
 }
 
@@ -667,14 +1021,31 @@ inline int ws_split(int b, int n, int m_pad)
     return split < 1 ? 1 : split;
 }
 
-inline size_t ws_bytes_needed(int b, int n, int m_pad) { return (size_t)b * m_pad * 4 * sizeof(float4) + (size_t)b * n * 8; }
+inline size_t ws_bytes_needed(int b, int n, int m_pad)
+{
+    // member spheres + corners, group spheres, triangle-0 corners, merged keys
+    return (size_t)b * m_pad * 4 * sizeof(float4) + (size_t)b * (m_pad / GRP) * sizeof(float4) + (size_t)b * 3 * sizeof(float4) +
+           (size_t)b * n * 8;
+}
 
 template <bool INDEXED>
-int launch_tri_ws(const TriJob &job, unsigned flags, void *workspace, size_t ws_bytes, void *stream)
+int launch_tri_ws(const TriJob &job, const int *order, unsigned flags, void *workspace, size_t ws_bytes, void *stream)
 {
     const int m_pad = ws_pad(job.m);
     if (!workspace || ws_bytes < ws_bytes_needed(job.b, job.n, m_pad) || ((uintptr_t)workspace & 15)) return GEOM_EINVAL;
     float4 *base = static_cast<float4 *>(workspace);
+    if (order) { // coherent order supplied: two-level scan
+        float4 *grp = base + (size_t)job.b * m_pad * 4;
+        float4 *first = grp + (size_t)job.b * (m_pad / GRP);
+        TriGws gws{base, base + (size_t)job.b * m_pad, grp, first, reinterpret_cast<unsigned long long *>(first + (size_t)job.b * 3),
+                   m_pad, ws_split(job.b, job.n, m_pad)};
+        hipStream_t gs = static_cast<hipStream_t>(stream);
+        const bool gtrunc = flags & GEOM_FLAG_REF_TAIL_TRUNC, gfix6 = flags & GEOM_FLAG_FIX_REGION6;
+        if (gtrunc && gfix6) return launch_grouped_variant<INDEXED, true, true>(job, gws, order, gs);
+        if (gtrunc) return launch_grouped_variant<INDEXED, true, false>(job, gws, order, gs);
+        if (gfix6) return launch_grouped_variant<INDEXED, false, true>(job, gws, order, gs);
+        return launch_grouped_variant<INDEXED, false, false>(job, gws, order, gs);
+    }
     TriWs ws{base, base + (size_t)job.b * m_pad, reinterpret_cast<unsigned long long *>(base + (size_t)job.b * m_pad * 4),
              m_pad, ws_split(job.b, job.n, m_pad)};
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -749,7 +1120,7 @@ extern "C" size_t geom_tri_distance_workspace_bytes(int b, int n, int m)
 }
 
 extern "C" int geom_tri_distance_ws_f32(int b, int n, const float *xyz, int m,
-                                        const float *tri1, const float *tri2, const float *tri3,
+                                        const float *tri1, const float *tri2, const float *tri3, const int *order,
                                         float *dist, int *point, int *index, unsigned flags,
                                         void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -760,11 +1131,11 @@ extern "C" int geom_tri_distance_ws_f32(int b, int n, const float *xyz, int m,
     if (b > 65535 || m >= (1 << 26)) return GEOM_ETOOBIG;
     TriJob job{xyz, tri1, tri2, tri3, nullptr, nullptr, dist, point, index, b, n, m, 0};
     if (flags & GEOM_FLAG_TRI_BRUTE_FORCE) return launch_tri<false>(job, flags, stream);
-    return launch_tri_ws<false>(job, flags, workspace, workspace_bytes, stream);
+    return launch_tri_ws<false>(job, order, flags, workspace, workspace_bytes, stream);
 }
 
 extern "C" int geom_tri_distance_indexed_ws_f32(int b, int n, const float *xyz, int nv, const float *verts,
-                                                int nf, const int64_t *faces,
+                                                int nf, const int64_t *faces, const int *order,
                                                 float *dist, int *point, int *index, unsigned flags,
                                                 void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -775,5 +1146,5 @@ extern "C" int geom_tri_distance_indexed_ws_f32(int b, int n, const float *xyz, 
     if (b > 65535 || nf >= (1 << 26)) return GEOM_ETOOBIG;
     TriJob job{xyz, nullptr, nullptr, nullptr, verts, faces, dist, point, index, b, n, nf, nv};
     if (flags & GEOM_FLAG_TRI_BRUTE_FORCE) return launch_tri<true>(job, flags, stream);
-    return launch_tri_ws<true>(job, flags, workspace, workspace_bytes, stream);
+    return launch_tri_ws<true>(job, order, flags, workspace, workspace_bytes, stream);
 }

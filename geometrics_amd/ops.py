@@ -168,6 +168,8 @@ class SurfaceLoss(torch.autograd.Function):
         if not two_sided:
             ws_bytes = L.geom_tri_distance_workspace_bytes(b, n_gt, nf)
             ws = torch.empty(max(ws_bytes, 16) // 4, **f32)
+            from .tri_distance import face_order
+            order = face_order(verts_c, faces)      # cached Morton order of the faces: two-level scan
             tri_d, option, index = torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, **i32), torch.empty(b, n_gt, **i32)
             sq, closest, weights = torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, 3, **f32), torch.empty(b, n_gt, 3, **f32)
         with torch.cuda.device(dev):
@@ -180,7 +182,7 @@ class SurfaceLoss(torch.autograd.Function):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     _lib.check(L.geom_tri_distance_indexed_ws_f32(
-                        b, n_gt, gt_c.data_ptr(), nv, verts_c.data_ptr(), nf, faces.data_ptr(), tri_d.data_ptr(),
+                        b, n_gt, gt_c.data_ptr(), nv, verts_c.data_ptr(), nf, faces.data_ptr(), _lib.ptr(order), tri_d.data_ptr(),
                         option.data_ptr(), index.data_ptr(), 0, ws.data_ptr(), ws_bytes, _lib.stream_ptr()),
                         "geom_tri_distance_indexed_ws_f32")
                     _lib.call("geom_p2tri_loss_fwd_f32", b, n_gt, gt_c.data_ptr(), nv, verts_c.data_ptr(), nf,
@@ -220,7 +222,8 @@ class SurfaceLoss(torch.autograd.Function):
                            points.data_ptr(), n_gt, gt.data_ptr())
             if not ctx.two_sided:   # both terms scatter (atomics) into the same zeroed buffer, concurrently
                 index, closest, weights = saved[7:10]
-                side = _side_stream(dev)
+                import os
+                side = main if os.environ.get("GEOM_SERIAL_BWD") else _side_stream(dev)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     _lib.call("geom_p2tri_loss_bwd_f32", b, n_gt, gt.data_ptr(), nv, nf, faces.data_ptr(),

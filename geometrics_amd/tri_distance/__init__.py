@@ -5,10 +5,87 @@
 dist [B,N] f32 squared distance to the chosen closest point, point [B,N] i32 region code 0..6,
 index [B,N] i32 winning triangle; all non-differentiable like the reference's.
 `tri_distance_indexed` takes (verts, faces) and gathers the corners in-kernel.
+
+`order`: an int32 permutation of the triangles that makes neighbours in the list neighbours in space
+switches the scan to its two-level form (groups of 16 triangles under a group sphere).  It never changes
+the result.  `tri_distance_indexed` derives a k-d tree leaf order of the face centroids once per face list
+(`face_order`, cached on the tensor's identity -- mesh deformation keeps a topology's order coherent);
+`morton_order` is the device-only alternative.
 """
+import weakref
+
 import torch
 
 from .. import _lib
+
+_order_cache = {}   # id(faces) -> (weakref, version, order)
+
+
+def morton_order(centroids):
+    """int32 permutation sorting [M,3] points along a 30-bit Morton (Z-order) curve of their bounding box."""
+    c = torch.nan_to_num(centroids.detach().to(torch.float32), nan=0.0, posinf=0.0, neginf=0.0)
+    lo = c.amin(0)
+    span = (c.amax(0) - lo).clamp_min(1e-30)
+    q = ((c - lo) / span * 1023.0).to(torch.int64).clamp_(0, 1023)
+
+    def spread(x):          # 10 bits -> every third bit
+        x = (x | (x << 16)) & 0x030000FF
+        x = (x | (x << 8)) & 0x0300F00F
+        x = (x | (x << 4)) & 0x030C30C3
+        return (x | (x << 2)) & 0x09249249
+
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    return torch.argsort(code, stable=True).to(torch.int32).contiguous()
+
+
+def kd_order(centroids, leaf=16):
+    """int32 permutation that lists [M,3] points leaf by leaf of a median-split k-d tree (split along the longest
+    axis of the node's bounding box, at a multiple of `leaf`): every run of `leaf` consecutive entries is one compact
+    cell -- the property the two-level scan's groups need.  Measured on the 5120-face BASELINE mesh the group spheres
+    come out 25 % smaller than along a 30-bit Morton curve.  Host-side, once per face list (numpy; one device->host
+    copy)."""
+    import numpy as np
+    c = np.nan_to_num(centroids.detach().to(torch.float32).cpu().numpy(), nan=0.0, posinf=0.0, neginf=0.0)
+    order = np.arange(c.shape[0])
+    nodes = [(0, c.shape[0])]
+    while nodes:
+        nxt = []
+        for a, b in nodes:
+            n = b - a
+            if n <= leaf:
+                continue
+            idx = order[a:b]
+            pts = c[idx]
+            axis = int(np.argmax(pts.max(0) - pts.min(0)))
+            order[a:b] = idx[np.argsort(pts[:, axis], kind="stable")]
+            half = ((n // leaf + 1) // 2) * leaf          # left child: a whole number of leaves
+            nxt += [(a, a + half), (a + half, b)]
+        nodes = nxt
+    return torch.from_numpy(order.astype(np.int32)).to(centroids.device)
+
+
+def face_order(verts, faces):
+    """Coherent visiting order of `faces` [F,3], from the centroids of the first mesh of `verts` [B,V,3] the
+    face list is seen with; cached per faces TENSOR OBJECT and in-place version (same policy as the CSR cache)."""
+    key = id(faces)
+    hit = _order_cache.get(key)
+    if hit is not None and hit[0]() is faces and hit[1] == faces._version:
+        return hit[2]
+    if verts.shape[0] == 0 or faces.shape[0] == 0:
+        return None
+    with torch.no_grad():
+        order = kd_order(verts[0][faces].mean(dim=1))
+    _order_cache[key] = (weakref.ref(faces, lambda _ref, k=key: _order_cache.pop(k, None)), faces._version, order)
+    return order
+
+
+def _order_ptr(order, m, dev):
+    if order is None:
+        return None, None
+    order = _lib.require(order, "order", torch.int32, 1)
+    if order.numel() != m or order.device != dev:
+        raise RuntimeError("order must be an int32 permutation of the %d triangles on %s" % (m, dev))
+    return order, order.data_ptr()
 
 
 def _outputs(b, n, dev):
@@ -24,15 +101,16 @@ def _workspace(b, n, m, dev):
     return torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=dev), nbytes
 
 
-def forward_cuda(xyz1, tri1, tri2, tri3, dist, point, index, flags=0, use_workspace=True):
+def forward_cuda(xyz1, tri1, tri2, tri3, dist, point, index, flags=0, use_workspace=True, order=None):
     """Same call shape as the reference's pybind `tri.forward_cuda` (tri_distance.cpp:16-30,34-36)."""
     b, n, _ = xyz1.shape
     m = tri1.shape[1]
     with torch.cuda.device(xyz1.device):
         if use_workspace:
             ws, nbytes = _workspace(b, n, m, xyz1.device)
+            order, order_ptr = _order_ptr(order, m, xyz1.device)
             code = _lib.lib().geom_tri_distance_ws_f32(
-                b, n, xyz1.data_ptr(), m, tri1.data_ptr(), tri2.data_ptr(), tri3.data_ptr(),
+                b, n, xyz1.data_ptr(), m, tri1.data_ptr(), tri2.data_ptr(), tri3.data_ptr(), order_ptr,
                 dist.data_ptr(), point.data_ptr(), index.data_ptr(), flags, ws.data_ptr(), nbytes,
                 _lib.stream_ptr())
         else:
@@ -42,7 +120,7 @@ def forward_cuda(xyz1, tri1, tri2, tri3, dist, point, index, flags=0, use_worksp
     _lib.check(code, "geom_tri_distance_f32")
 
 
-def tri_distance(xyz1, tri1, tri2, tri3, flags=0, use_workspace=True):
+def tri_distance(xyz1, tri1, tri2, tri3, flags=0, use_workspace=True, order=None):
     xyz1 = _lib.require(xyz1.detach(), "xyz1", torch.float32, 3, 3)
     tris = [_lib.require(t.detach(), "tri%d" % (i + 1), torch.float32, 3, 3) for i, t in enumerate((tri1, tri2, tri3))]
     dev = _lib.same_device(xyz1, *tris)
@@ -51,12 +129,13 @@ def tri_distance(xyz1, tri1, tri2, tri3, flags=0, use_workspace=True):
         if t.shape != tris[0].shape or t.shape[0] != b:
             raise RuntimeError("tri1/tri2/tri3 must share one [B,M,3] shape with xyz1's batch")
     dist, point, index = _outputs(b, n, dev)
-    forward_cuda(xyz1, tris[0], tris[1], tris[2], dist, point, index, flags, use_workspace)
+    forward_cuda(xyz1, tris[0], tris[1], tris[2], dist, point, index, flags, use_workspace, order)
     return dist, point, index
 
 
-def tri_distance_indexed(xyz1, verts, faces, flags=0, use_workspace=True):
-    """Corners gathered in-kernel from verts [B,V,3] through faces [F,3] (int64)."""
+def tri_distance_indexed(xyz1, verts, faces, flags=0, use_workspace=True, order="auto"):
+    """Corners gathered in-kernel from verts [B,V,3] through faces [F,3] (int64).  order: "auto" (cached Morton
+    order of the face centroids -> two-level scan), None (flat scan) or an explicit int32 permutation."""
     xyz1 = _lib.require(xyz1.detach(), "xyz1", torch.float32, 3, 3)
     verts = _lib.require(verts.detach(), "verts", torch.float32, 3, 3)
     faces = _lib.require(faces, "faces", torch.int64, 2, 3)
@@ -68,8 +147,11 @@ def tri_distance_indexed(xyz1, verts, faces, flags=0, use_workspace=True):
     with torch.cuda.device(dev):
         if use_workspace:
             ws, nbytes = _workspace(b, n, faces.shape[0], dev)
+            if isinstance(order, str):
+                order = face_order(verts, faces)
+            order, order_ptr = _order_ptr(order, faces.shape[0], dev)
             code = _lib.lib().geom_tri_distance_indexed_ws_f32(
-                b, n, xyz1.data_ptr(), verts.shape[1], verts.data_ptr(), faces.shape[0], faces.data_ptr(),
+                b, n, xyz1.data_ptr(), verts.shape[1], verts.data_ptr(), faces.shape[0], faces.data_ptr(), order_ptr,
                 dist.data_ptr(), point.data_ptr(), index.data_ptr(), flags, ws.data_ptr(), nbytes,
                 _lib.stream_ptr())
         else:

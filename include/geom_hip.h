@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GEOM_ABI_VERSION 1
+#define GEOM_ABI_VERSION 2
 
 /* argument errors */
 #define GEOM_EINVAL   (-1) /* bad size / null pointer */
@@ -78,14 +78,21 @@ int geom_tri_distance_indexed_f32(int b, int n, const float *xyz, int nv, const 
  * (device memory, 16-byte aligned, at least geom_tri_distance_workspace_bytes(b, n, m) bytes,
  * contents undefined on entry and exit), which removes all per-block staging work; with few query
  * tiles the triangle range of a tile is split over several workgroups whose partial results are
- * merged through 64-bit atomic-min words that also live in the workspace. */
+ * merged through 64-bit atomic-min words that also live in the workspace.
+ *
+ * `order` (device int32 [m], may be NULL) is a permutation of the triangle indices that makes
+ * consecutive entries spatially close (e.g. a Morton order of the centroids; the identity when the
+ * triangle list is already coherent).  When given, triangles are visited in that order in groups of 16
+ * under a group bounding sphere (two-level scan: ~10x fewer sphere tests).  It NEVER changes the result --
+ * `index` is always the original triangle index, ties still go to the lowest one; an incoherent order only
+ * costs time (then pass NULL: flat scan).  Entries outside [0, m) drop their slot. */
 size_t geom_tri_distance_workspace_bytes(int b, int n, int m);
 int geom_tri_distance_ws_f32(int b, int n, const float *xyz, int m,
-                             const float *tri1, const float *tri2, const float *tri3,
+                             const float *tri1, const float *tri2, const float *tri3, const int *order,
                              float *dist, int *point, int *index, unsigned flags,
                              void *workspace, size_t workspace_bytes, void *stream);
 int geom_tri_distance_indexed_ws_f32(int b, int n, const float *xyz, int nv, const float *verts,
-                                     int nf, const int64_t *faces,
+                                     int nf, const int64_t *faces, const int *order,
                                      float *dist, int *point, int *index, unsigned flags,
                                      void *workspace, size_t workspace_bytes, void *stream);
 

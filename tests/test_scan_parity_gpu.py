@@ -9,7 +9,7 @@ import torch
 from geometrics_amd import meshgen
 from geometrics_amd._lib import FLAG_FIX_REGION6, FLAG_REF_TAIL_TRUNC, FLAG_TRI_BRUTE_FORCE
 from geometrics_amd.chamfer_distance import ChamferDistance, chamfer_nn
-from geometrics_amd.tri_distance import TriDistance, tri_distance, tri_distance_indexed
+from geometrics_amd.tri_distance import TriDistance, morton_order, tri_distance, tri_distance_indexed
 
 pytestmark = pytest.mark.gpu
 
@@ -113,6 +113,18 @@ def _check_tri(oracle_mod, gpu, pts, verts, F, flags=0):
     assert torch.equal(i5, i) and torch.equal(p5, p) and torch.equal(d5.view(torch.int32), d.view(torch.int32))
     d6, p6, i6 = tri_distance_indexed(_dev(pts, gpu), _dev(verts, gpu), _dev(F, gpu), flags, use_workspace=False)
     assert torch.equal(i6, i) and torch.equal(p6, p) and torch.equal(d6.view(torch.int32), d.view(torch.int32))
+    # two-level (grouped) scan: the visiting order decides speed only -- a Morton order (what "auto" above used),
+    # no order (flat workspace scan), a random permutation (useless group spheres) and a reversed one all give
+    # the same bits, with `index` in the ORIGINAL numbering
+    nf = F.shape[0]
+    rng = np.random.default_rng(nf)
+    orders = [None, morton_order(_dev(verts[0][F].mean(1), gpu)), _dev(rng.permutation(nf).astype(np.int32), gpu),
+              _dev(np.arange(nf - 1, -1, -1, dtype=np.int32), gpu)]
+    for order in orders:
+        d7, p7, i7 = tri_distance_indexed(_dev(pts, gpu), _dev(verts, gpu), _dev(F, gpu), flags, order=order)
+        assert torch.equal(i7, i) and torch.equal(p7, p) and torch.equal(d7.view(torch.int32), d.view(torch.int32))
+        d8, p8, i8 = tri_distance(_dev(pts, gpu), _dev(t1, gpu), _dev(t2, gpu), _dev(t3, gpu), flags, order=order)
+        assert torch.equal(i8, i) and torch.equal(p8, p) and torch.equal(d8.view(torch.int32), d.view(torch.int32))
     return ep
 
 
@@ -150,8 +162,9 @@ def test_tri_degenerate_triangles(oracle_mod, gpu):
     F[40] = [1, 2, 2]
     t1, t2, t3 = (np.ascontiguousarray(verts[:, F[:, k]]) for k in range(3))
     ed, ep, ei = oracle_mod.tri_scan(pts, t1, t2, t3)
-    for flags in (0, FLAG_TRI_BRUTE_FORCE):
-        d, p, i = tri_distance(_dev(pts, gpu), _dev(t1, gpu), _dev(t2, gpu), _dev(t3, gpu), flags)
+    order = morton_order(_dev(verts[0][F].mean(1), gpu))
+    for flags, ordr in ((0, None), (FLAG_TRI_BRUTE_FORCE, None), (0, order), (0, torch.flip(order, [0]))):
+        d, p, i = tri_distance(_dev(pts, gpu), _dev(t1, gpu), _dev(t2, gpu), _dev(t3, gpu), flags, order=ordr)
         np.testing.assert_array_equal(i.cpu().numpy(), ei)
         np.testing.assert_array_equal(p.cpu().numpy(), ep)
         np.testing.assert_array_equal(np.isnan(d.cpu().numpy()), np.isnan(ed))

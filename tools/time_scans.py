@@ -2,7 +2,8 @@
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from geometrics_amd import meshgen
 from geometrics_amd.chamfer_distance import chamfer_nn
 from geometrics_amd.tri_distance import tri_distance_indexed
@@ -41,3 +42,12 @@ pairs_nn = 2 * B * 3000 * 3000
 pairs_tri = B * 3000 * 5120
 print(f"B={B} nn {t_nn:.1f} us ({pairs_nn / t_nn / 1e6:.2f} Tpair/s)  tri {t_tri:.1f} us ({pairs_tri / t_tri / 1e6:.3f} Tpair/s)")
 print(f"per mesh: nn {t_nn / B:.1f} us  tri {t_tri / B:.1f} us")
+t_flat = timeit(lambda: tri_distance_indexed(gt, verts, faces, order=None))
+perm = torch.randperm(faces.shape[0], device=dev).to(torch.int32)
+t_rand = timeit(lambda: tri_distance_indexed(gt, verts, faces, order=perm), iters=10)
+from geometrics_amd.tri_distance import morton_order
+mort = morton_order(verts[0][faces].mean(dim=1))
+t_mort = timeit(lambda: tri_distance_indexed(gt, verts, faces, order=mort))
+ident = torch.arange(faces.shape[0], device=dev, dtype=torch.int32)
+t_ident = timeit(lambda: tri_distance_indexed(gt, verts, faces, order=ident))
+print(f"tri: grouped/k-d order {t_tri:.1f} us  grouped/Morton {t_mort:.1f} us  grouped/identity order {t_ident:.1f} us  flat {t_flat:.1f} us  grouped/random order {t_rand:.1f} us")
