@@ -140,7 +140,7 @@ class SurfaceLoss(torch.autograd.Function):
       two_sided=True   batch_point_to_point (utils.py:393-438):
             3000 * ( mean_s |gt[nn(s)] - pred_s|^2  +  mean_g |pred[nn(g)] - g|^2 )
 
-    Forward: sample -> NN (both directions) -> [tri scan -> closest point] -> one two-segment sum.
+    Forward: [tri scan -> closest point] -> sample -> NN (both directions) -> one two-segment sum, one stream.
     Backward: ONE zero-fill of grad_verts, then every term scatters into it (the gradient of the
     sampled points is never materialised).  Returns (loss, sq_gt, sq_pred); the squared NN
     distances feed the F1 score and are not differentiable."""
@@ -160,7 +160,6 @@ class SurfaceLoss(torch.autograd.Function):
         L = _lib.lib()
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
-        # every buffer is allocated on the calling stream BEFORE the fork below
         points = torch.empty(b, num, 3, **f32)
         out = torch.empty((), **f32)
         sq_gt, sq_pred = torch.empty(b, n_gt, **f32), torch.empty(b, num, **f32)
@@ -169,25 +168,21 @@ class SurfaceLoss(torch.autograd.Function):
             ws_bytes = L.geom_tri_distance_workspace_bytes(b, n_gt, nf)
             ws = torch.empty(max(ws_bytes, 16) // 4, **f32)
             from .tri_distance import face_order
-            order = face_order(verts_c, faces)      # cached Morton order of the faces: two-level scan
+            order = face_order(verts_c, faces)      # cached k-d leaf order of the faces: two-level scan
             tri_d, option, index = torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, **i32), torch.empty(b, n_gt, **i32)
             sq, closest, weights = torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, 3, **f32), torch.empty(b, n_gt, 3, **f32)
         with torch.cuda.device(dev):
-            main = torch.cuda.current_stream()
             if not two_sided:
-                # the tri branch depends only on (gt, verts): run it beside sampling + NN on a second
-                # stream (a parallel branch of the captured HIP graph); both are far too small to
-                # fill 256 CUs alone at a per-GPU shard of a few meshes
-                side = _side_stream(dev)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    _lib.check(L.geom_tri_distance_indexed_ws_f32(
-                        b, n_gt, gt_c.data_ptr(), nv, verts_c.data_ptr(), nf, faces.data_ptr(), _lib.ptr(order), tri_d.data_ptr(),
-                        option.data_ptr(), index.data_ptr(), 0, ws.data_ptr(), ws_bytes, _lib.stream_ptr()),
-                        "geom_tri_distance_indexed_ws_f32")
-                    _lib.call("geom_p2tri_loss_fwd_f32", b, n_gt, gt_c.data_ptr(), nv, verts_c.data_ptr(), nf,
-                              faces.data_ptr(), option.data_ptr(), index.data_ptr(), sq.data_ptr(),
-                              closest.data_ptr(), weights.data_ptr())
+                # (An earlier version ran this branch beside sampling + NN on a second stream.  Inside a captured graph
+                # every fork/join edge costs 5-10 us of dependency latency, and the two scans then share the CUs' LDS
+                # and issue slots: measured 0.567 ms/step forked vs 0.551 ms/step in line.)
+                _lib.check(L.geom_tri_distance_indexed_ws_f32(
+                    b, n_gt, gt_c.data_ptr(), nv, verts_c.data_ptr(), nf, faces.data_ptr(), _lib.ptr(order), tri_d.data_ptr(),
+                    option.data_ptr(), index.data_ptr(), 0, ws.data_ptr(), ws_bytes, _lib.stream_ptr()),
+                    "geom_tri_distance_indexed_ws_f32")
+                _lib.call("geom_p2tri_loss_fwd_f32", b, n_gt, gt_c.data_ptr(), nv, verts_c.data_ptr(), nf,
+                          faces.data_ptr(), option.data_ptr(), index.data_ptr(), sq.data_ptr(),
+                          closest.data_ptr(), weights.data_ptr())
             _lib.call("geom_sample_faces_fwd_f32", b, nv, verts_c.data_ptr(), nf, faces.data_ptr(), num,
                       choices.data_ptr(), u.data_ptr(), v.data_ptr(), points.data_ptr())
             _lib.check(L.geom_chamfer_nn_f32(b, n_gt, gt_c.data_ptr(), num, points.data_ptr(), sq_gt.data_ptr(),
@@ -198,7 +193,6 @@ class SurfaceLoss(torch.autograd.Function):
                           sq_gt.numel(), sq_gt.data_ptr(), scale / sq_gt.numel(), out.data_ptr())
                 ctx.save_for_backward(faces, choices, u, v, points, gt_c, idx_g, idx_p)
             else:
-                main.wait_stream(side)
                 _lib.call("geom_sum2_f32", sq_pred.numel(), sq_pred.data_ptr(), scale / sq_pred.numel(),
                           sq.numel(), sq.data_ptr(), scale / sq.numel(), out.data_ptr())
                 ctx.save_for_backward(faces, choices, u, v, points, gt_c, idx_g, index, closest, weights)
@@ -217,25 +211,18 @@ class SurfaceLoss(torch.autograd.Function):
         grad = grad.contiguous()
         grad_verts = torch.zeros(b, nv, 3, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            main = torch.cuda.current_stream()
             sample_args = (b, nv, nf, faces.data_ptr(), num, choices.data_ptr(), u.data_ptr(), v.data_ptr(),
                            points.data_ptr(), n_gt, gt.data_ptr())
-            if not ctx.two_sided:   # both terms scatter (atomics) into the same zeroed buffer, concurrently
+            if not ctx.two_sided:   # both terms scatter (atomics) into the same zeroed buffer
                 index, closest, weights = saved[7:10]
-                import os
-                side = main if os.environ.get("GEOM_SERIAL_BWD") else _side_stream(dev)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    _lib.call("geom_p2tri_loss_bwd_f32", b, n_gt, gt.data_ptr(), nv, nf, faces.data_ptr(),
-                              index.data_ptr(), closest.data_ptr(), weights.data_ptr(), grad.data_ptr(),
-                              ctx.scale / (b * n_gt), grad_verts.data_ptr())
+                _lib.call("geom_p2tri_loss_bwd_f32", b, n_gt, gt.data_ptr(), nv, nf, faces.data_ptr(),
+                          index.data_ptr(), closest.data_ptr(), weights.data_ptr(), grad.data_ptr(),
+                          ctx.scale / (b * n_gt), grad_verts.data_ptr())
             _lib.call("geom_sample_chamfer_bwd_f32", *sample_args, saved[6].data_ptr(), 0, grad.data_ptr(),
                       ctx.scale / (b * num), grad_verts.data_ptr())
             if ctx.two_sided:
                 _lib.call("geom_sample_chamfer_bwd_f32", *sample_args, saved[7].data_ptr(), 1, grad.data_ptr(),
                           ctx.scale / (b * n_gt), grad_verts.data_ptr())
-            else:
-                main.wait_stream(side)
         return grad_verts, None, None, None, None, None, None, None
 
 
@@ -376,18 +363,6 @@ class SegmentMax(torch.autograd.Function):
             _lib.call("geom_segment_max_bwd_f32", nseg, offsets.data_ptr(), ctx.rows, c, g.data_ptr(), arg.data_ptr(),
                       grad_x.data_ptr())
         return grad_x, None, None
-
-
-_side_streams = {}
-
-
-def _side_stream(dev):
-    """One auxiliary stream per device for the independent branch of the fused loss."""
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
-    st = _side_streams.get(key)
-    if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=dev)
-    return st
 
 
 _rng_states = {}
