@@ -31,7 +31,8 @@ _SIGNATURES = {
     "geom_tri_distance_indexed_ws_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp, ctypes.c_size_t, _vp],
     "geom_face_areas_f32": [_i, _i, _vp, _i, _vp, _vp, _vp],
     "geom_draw_samples_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
-    "geom_draw_samples_rng_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "geom_draw_samples_rng_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "geom_surface_loss_bwd_f32": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp],
     "geom_vertex_head_fwd_f32": [ctypes.c_int64, _i, _vp, _vp, _f, _vp, _vp],
     "geom_vertex_head_bwd_f32": [ctypes.c_int64, _i, _vp, _f, _vp, _vp],
     "geom_sample_faces_fwd_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],

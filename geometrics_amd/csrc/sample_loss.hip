@@ -77,17 +77,14 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key)
 }
 __device__ __forceinline__ float u01(unsigned x) { return (x >> 8) * 0x1p-24f; } // [0,1), 24 random bits
 
-// state[0..1] = seed, state[2..3] = stream position (advanced by draw_tick_kernel after every call)
-__global__ void draw_tick_kernel(unsigned long long *state)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) state[1] += 1ull;
-}
+// rng_state = {seed, stream position, arrival counter}: the LAST workgroup of a call to finish advances the
+// position (every workgroup has read it by then) and re-arms the counter -- no separate tick launch.
 
 __global__ __launch_bounds__(DRAW_THREADS) void draw_samples_kernel(int nv, const float *verts, int nf,
                                                                      const int64_t *faces, int num,
                                                                      const float *uniforms, int64_t plane,
-                                                                     const unsigned long long *rng_state,
-                                                                     int64_t *choices, float *u, float *v)
+                                                                     unsigned long long *rng_state,
+                                                                     int64_t *choices, float *u, float *v, float *points)
 {
     __shared__ float cdf[DRAW_MAX_FACES];
     __shared__ float wave_total[DRAW_THREADS / GEOM_WAVE];
@@ -122,11 +119,23 @@ __global__ __launch_bounds__(DRAW_THREADS) void draw_samples_kernel(int nv, cons
     const float total = cdf[nf - 1];
 
     const int i = blockIdx.x * DRAW_THREADS + threadIdx.x;
+    unsigned long long seed = 0ull, pos = 0ull;
+    if (rng_state) {
+        seed = rng_state[0];
+        pos = rng_state[1];
+        __syncthreads(); // every thread of this workgroup holds the position before the workgroup reports in
+        if (threadIdx.x == 0) {
+            const unsigned long long groups = (unsigned long long)gridDim.x * gridDim.y;
+            if (atomicAdd(&rng_state[2], 1ull) == groups - 1ull) { // last one in: nobody reads the old position any more
+                rng_state[2] = 0ull;
+                rng_state[1] = pos + 1ull;
+            }
+        }
+    }
     if (i >= num) return;
     const int64_t o = (int64_t)mesh * num + i;
     float r0, r1, r2;
     if (rng_state) { // in-kernel Philox: counter = (sample, mesh, stream position), key = seed
-        const unsigned long long seed = rng_state[0], pos = rng_state[1];
         const uint4 r = philox4x32_10(make_uint4((unsigned)i, (unsigned)mesh, (unsigned)pos, (unsigned)(pos >> 32)),
                                       make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
         r0 = u01(r.x), r1 = u01(r.y), r2 = u01(r.z);
@@ -141,8 +150,21 @@ __global__ __launch_bounds__(DRAW_THREADS) void draw_samples_kernel(int nv, cons
         else lo = mid + 1;
     }
     choices[o] = lo;
-    u[o] = sqrtf(r1);
+    const float su = sqrtf(r1);
+    u[o] = su;
     v[o] = r2;
+    if (points) { // the sampled point itself, same expression as sample_fwd_kernel (utils.py:630)
+        const V3 x = ld3(V + 3 * faces[3 * (size_t)lo + 0]);
+        const V3 y = ld3(V + 3 * faces[3 * (size_t)lo + 1]);
+        const V3 z = ld3(V + 3 * faces[3 * (size_t)lo + 2]);
+        const float w0 = 1.f - su;
+        const float w1 = su * (1.f - r2);
+        const float w2 = su * r2;
+        const V3 pt = (x * w0 + y * w1) + z * w2;
+        points[3 * o + 0] = pt.x;
+        points[3 * o + 1] = pt.y;
+        points[3 * o + 2] = pt.z;
+    }
 }
 
 // -------------------------------------------------------------- face sampling ----
@@ -195,15 +217,11 @@ __global__ __launch_bounds__(PT_THREADS) void sample_bwd_kernel(SampleArgs a, co
 //   via_nn == 0: thread t is sampled point t;            diff = point[t]  - other[idx[t]]
 //   via_nn == 1: thread t is a point of `other`;         diff = point[si] - other[t],  si = idx[t]
 //                (the second Chamfer direction of batch_point_to_point, utils.py:417)
-__global__ __launch_bounds__(PT_THREADS) void sample_chamfer_bwd_kernel(SampleArgs a, const float *points,
-                                                                         int n_other, const float *other,
-                                                                         const int *idx, int via_nn,
-                                                                         const float *coef_dev, float coef_host,
-                                                                         float *grad_verts)
+__device__ __forceinline__ void sample_chamfer_bwd_item(int64_t i, const SampleArgs &a, const float *points, int n_other,
+                                                        const float *other, const int *idx, int via_nn,
+                                                        const float *coef_dev, float coef_host, float *grad_verts)
 {
     const int count = via_nn ? n_other : a.num;
-    const int64_t i = (int64_t)blockIdx.x * PT_THREADS + threadIdx.x;
-    if (i >= (int64_t)a.b * count) return;
     const int mesh = (int)(i / count);
     const float coef = 2.f * coef_host * (coef_dev ? coef_dev[0] : 1.f);
     int64_t si, oi; // sampled point / other point (flattened over the batch)
@@ -222,6 +240,19 @@ __global__ __launch_bounds__(PT_THREADS) void sample_chamfer_bwd_kernel(SampleAr
     atomic_add3(G + 3 * a.faces[3 * f + 1], g * (u * (1.f - v)));
     atomic_add3(G + 3 * a.faces[3 * f + 2], g * (u * v));
 }
+
+__global__ __launch_bounds__(PT_THREADS) void sample_chamfer_bwd_kernel(SampleArgs a, const float *points,
+                                                                         int n_other, const float *other,
+                                                                         const int *idx, int via_nn,
+                                                                         const float *coef_dev, float coef_host,
+                                                                         float *grad_verts)
+{
+    const int count = via_nn ? n_other : a.num;
+    const int64_t i = (int64_t)blockIdx.x * PT_THREADS + threadIdx.x;
+    if (i >= (int64_t)a.b * count) return;
+    sample_chamfer_bwd_item(i, a, points, n_other, other, idx, via_nn, coef_dev, coef_host, grad_verts);
+}
+
 
 // ------------------------------------------------------- Chamfer gather loss ----
 // d/dsrc, d/ddst of  sum_j |dst[idx[j]] - src[j]|^2  scaled by coef (utils.py:416-417, 462).
@@ -333,14 +364,10 @@ __global__ __launch_bounds__(PT_THREADS) void p2tri_fwd_kernel(P2TArgs a, float 
 // d/dX_k sum |q - p|^2 = 2 w_k (q - p): q is an exact minimiser along every free parameter
 // (edge parameter, plane foot), so the parameter derivatives vanish (envelope theorem); this
 // equals the reference autograd through calc_point_to_line.
-__global__ __launch_bounds__(PT_THREADS) void p2tri_bwd_kernel(int b, int n, const float *xyz, int nv,
-                                                                const int64_t *faces, const int *index,
-                                                                const float *closest, const float *weights,
-                                                                const float *coef_dev, float coef_host,
-                                                                float *grad_verts)
+__device__ __forceinline__ void p2tri_bwd_item(int64_t i, int n, const float *xyz, int nv, const int64_t *faces,
+                                               const int *index, const float *closest, const float *weights,
+                                               const float *coef_dev, float coef_host, float *grad_verts)
 {
-    const int64_t i = (int64_t)blockIdx.x * PT_THREADS + threadIdx.x;
-    if (i >= (int64_t)b * n) return;
     const int mesh = (int)(i / n);
     const float coef = 2.f * coef_host * (coef_dev ? coef_dev[0] : 1.f);
     const int64_t f = index[i];
@@ -350,6 +377,43 @@ __global__ __launch_bounds__(PT_THREADS) void p2tri_bwd_kernel(int b, int n, con
     if (w.x != 0.f) atomic_add3(G + 3 * faces[3 * f + 0], g * w.x);
     if (w.y != 0.f) atomic_add3(G + 3 * faces[3 * f + 1], g * w.y);
     if (w.z != 0.f) atomic_add3(G + 3 * faces[3 * f + 2], g * w.z);
+}
+
+__global__ __launch_bounds__(PT_THREADS) void p2tri_bwd_kernel(int b, int n, const float *xyz, int nv,
+                                                                const int64_t *faces, const int *index,
+                                                                const float *closest, const float *weights,
+                                                                const float *coef_dev, float coef_host,
+                                                                float *grad_verts)
+{
+    const int64_t i = (int64_t)blockIdx.x * PT_THREADS + threadIdx.x;
+    if (i >= (int64_t)b * n) return;
+    p2tri_bwd_item(i, n, xyz, nv, faces, index, closest, weights, coef_dev, coef_host, grad_verts);
+}
+
+// Backward of batch_point_to_surface in ONE launch: workgroups [0, split) scatter the Chamfer term of the sampled
+// points, the rest the point-to-triangle term -- both into the same zeroed grad_verts.
+struct SurfaceBwdArgs {
+    SampleArgs sample;
+    const float *points, *gt;
+    const int *idx_g, *index;
+    const float *closest, *weights, *coef_dev;
+    float coef_sample, coef_tri;
+    float *grad_verts;
+    int n_gt;
+    unsigned split;
+};
+__global__ __launch_bounds__(PT_THREADS) void surface_bwd_kernel(SurfaceBwdArgs a)
+{
+    if (blockIdx.x < a.split) {
+        const int64_t i = (int64_t)blockIdx.x * PT_THREADS + threadIdx.x;
+        if (i < (int64_t)a.sample.b * a.sample.num)
+            sample_chamfer_bwd_item(i, a.sample, a.points, a.n_gt, a.gt, a.idx_g, 0, a.coef_dev, a.coef_sample, a.grad_verts);
+    } else {
+        const int64_t i = (int64_t)(blockIdx.x - a.split) * PT_THREADS + threadIdx.x;
+        if (i < (int64_t)a.sample.b * a.n_gt)
+            p2tri_bwd_item(i, a.n_gt, a.gt, a.sample.nv, a.sample.faces, a.index, a.closest, a.weights, a.coef_dev, a.coef_tri,
+                           a.grad_verts);
+    }
 }
 
 // ------------------------------------------------------------ deterministic sum ----
@@ -526,6 +590,27 @@ extern "C" int geom_sample_chamfer_bwd_f32(int b, int nv, int nf, const int64_t 
     return geom::launch_status();
 }
 
+extern "C" int geom_surface_loss_bwd_f32(int b, int nv, int nf, const int64_t *faces, int num, const int64_t *choices,
+                                         const float *u, const float *v, const float *points, int n_gt, const float *gt,
+                                         const int *idx_g, const int *index, const float *closest, const float *weights,
+                                         const float *coef_dev, float coef_sample, float coef_tri, float *grad_verts,
+                                         void *stream)
+{
+    if (b < 0 || nv < 0 || nf < 0 || num < 0 || n_gt < 0) return GEOM_EINVAL;
+    if (b == 0 || (num == 0 && n_gt == 0)) return 0;
+    if (!faces || !grad_verts || (num > 0 && (!choices || !u || !v || !points || !gt || !idx_g || n_gt == 0)) ||
+        (n_gt > 0 && (!gt || !index || !closest || !weights)))
+        return GEOM_EINVAL;
+    const int64_t blocks_s = ((int64_t)b * num + PT_THREADS - 1) / PT_THREADS;
+    const int64_t blocks_t = ((int64_t)b * n_gt + PT_THREADS - 1) / PT_THREADS;
+    if (blocks_s + blocks_t > 0x7fffffffLL) return GEOM_ETOOBIG;
+    SurfaceBwdArgs a{{nullptr, faces, choices, u, v, b, nv, nf, num}, points, gt, idx_g, index, closest, weights, coef_dev,
+                     coef_sample, coef_tri, grad_verts, n_gt, (unsigned)blocks_s};
+    hipLaunchKernelGGL(surface_bwd_kernel, dim3((unsigned)(blocks_s + blocks_t)), dim3(PT_THREADS), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return geom::launch_status();
+}
+
 extern "C" int geom_sum2_f32(int64_t n1, const float *x1, float scale1, int64_t n2, const float *x2, float scale2,
                              float *out, void *stream)
 {
@@ -545,12 +630,13 @@ extern "C" int geom_draw_samples_f32(int b, int nv, const float *verts, int nf, 
     if (b > 65535) return GEOM_ETOOBIG;
     hipLaunchKernelGGL(draw_samples_kernel, dim3((num + DRAW_THREADS - 1) / DRAW_THREADS, b), dim3(DRAW_THREADS), 0,
                        static_cast<hipStream_t>(stream), nv, verts, nf, faces, num, uniforms, (int64_t)b * num,
-                       static_cast<const unsigned long long *>(nullptr), choices, u, v);
+                       static_cast<unsigned long long *>(nullptr), choices, u, v, static_cast<float *>(nullptr));
     return geom::launch_status();
 }
 
 extern "C" int geom_draw_samples_rng_f32(int b, int nv, const float *verts, int nf, const int64_t *faces, int num,
-                                         uint64_t *rng_state, int64_t *choices, float *u, float *v, void *stream)
+                                         uint64_t *rng_state, int64_t *choices, float *u, float *v, float *points,
+                                         void *stream)
 {
     if (b < 0 || nv < 0 || nf < 0 || num < 0) return GEOM_EINVAL;
     if (nf > DRAW_MAX_FACES) return GEOM_EUNSUPPORTED;
@@ -560,8 +646,7 @@ extern "C" int geom_draw_samples_rng_f32(int b, int nv, const float *verts, int 
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(draw_samples_kernel, dim3((num + DRAW_THREADS - 1) / DRAW_THREADS, b), dim3(DRAW_THREADS), 0, s,
                        nv, verts, nf, faces, num, static_cast<const float *>(nullptr), (int64_t)b * num,
-                       reinterpret_cast<const unsigned long long *>(rng_state), choices, u, v);
-    hipLaunchKernelGGL(draw_tick_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned long long *>(rng_state));
+                       reinterpret_cast<unsigned long long *>(rng_state), choices, u, v, points);
     return geom::launch_status();
 }
 

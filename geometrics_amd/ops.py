@@ -146,7 +146,7 @@ class SurfaceLoss(torch.autograd.Function):
     distances feed the F1 score and are not differentiable."""
 
     @staticmethod
-    def forward(ctx, verts, faces, gt, choices, u, v, two_sided, scale):
+    def forward(ctx, verts, faces, gt, choices, u, v, two_sided, scale, points=None):
         verts_c = _f32(verts.detach(), "verts", 3, 3)
         gt_c = _f32(gt.detach(), "gt_points", 3, 3)
         faces = _lib.require(faces, "faces", torch.int64, 2, 3)
@@ -160,7 +160,10 @@ class SurfaceLoss(torch.autograd.Function):
         L = _lib.lib()
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
-        points = torch.empty(b, num, 3, **f32)
+        have_points = points is not None      # drawn and gathered by one kernel (ops.draw_samples(with_points=True))
+        points = _f32(points.detach(), "points", 3, 3) if have_points else torch.empty(b, num, 3, **f32)
+        if points.shape != (b, num, 3):
+            raise RuntimeError("points must be [B,num,3] for the given draws")
         out = torch.empty((), **f32)
         sq_gt, sq_pred = torch.empty(b, n_gt, **f32), torch.empty(b, num, **f32)
         idx_p, idx_g = torch.empty(b, n_gt, **i32), torch.empty(b, num, **i32)
@@ -183,8 +186,9 @@ class SurfaceLoss(torch.autograd.Function):
                 _lib.call("geom_p2tri_loss_fwd_f32", b, n_gt, gt_c.data_ptr(), nv, verts_c.data_ptr(), nf,
                           faces.data_ptr(), option.data_ptr(), index.data_ptr(), sq.data_ptr(),
                           closest.data_ptr(), weights.data_ptr())
-            _lib.call("geom_sample_faces_fwd_f32", b, nv, verts_c.data_ptr(), nf, faces.data_ptr(), num,
-                      choices.data_ptr(), u.data_ptr(), v.data_ptr(), points.data_ptr())
+            if not have_points:
+                _lib.call("geom_sample_faces_fwd_f32", b, nv, verts_c.data_ptr(), nf, faces.data_ptr(), num,
+                          choices.data_ptr(), u.data_ptr(), v.data_ptr(), points.data_ptr())
             _lib.check(L.geom_chamfer_nn_f32(b, n_gt, gt_c.data_ptr(), num, points.data_ptr(), sq_gt.data_ptr(),
                                              idx_p.data_ptr(), sq_pred.data_ptr(), idx_g.data_ptr(), 0,
                                              _lib.stream_ptr()), "geom_chamfer_nn_f32")
@@ -213,17 +217,18 @@ class SurfaceLoss(torch.autograd.Function):
         with torch.cuda.device(dev):
             sample_args = (b, nv, nf, faces.data_ptr(), num, choices.data_ptr(), u.data_ptr(), v.data_ptr(),
                            points.data_ptr(), n_gt, gt.data_ptr())
-            if not ctx.two_sided:   # both terms scatter (atomics) into the same zeroed buffer
+            if not ctx.two_sided:   # both terms scatter (atomics) into the same zeroed buffer, one launch
                 index, closest, weights = saved[7:10]
-                _lib.call("geom_p2tri_loss_bwd_f32", b, n_gt, gt.data_ptr(), nv, nf, faces.data_ptr(),
-                          index.data_ptr(), closest.data_ptr(), weights.data_ptr(), grad.data_ptr(),
+                _lib.call("geom_surface_loss_bwd_f32", b, nv, nf, faces.data_ptr(), num, choices.data_ptr(), u.data_ptr(),
+                          v.data_ptr(), points.data_ptr(), n_gt, gt.data_ptr(), saved[6].data_ptr(), index.data_ptr(),
+                          closest.data_ptr(), weights.data_ptr(), grad.data_ptr(), ctx.scale / (b * num),
                           ctx.scale / (b * n_gt), grad_verts.data_ptr())
-            _lib.call("geom_sample_chamfer_bwd_f32", *sample_args, saved[6].data_ptr(), 0, grad.data_ptr(),
-                      ctx.scale / (b * num), grad_verts.data_ptr())
-            if ctx.two_sided:
+            else:
+                _lib.call("geom_sample_chamfer_bwd_f32", *sample_args, saved[6].data_ptr(), 0, grad.data_ptr(),
+                          ctx.scale / (b * num), grad_verts.data_ptr())
                 _lib.call("geom_sample_chamfer_bwd_f32", *sample_args, saved[7].data_ptr(), 1, grad.data_ptr(),
                           ctx.scale / (b * n_gt), grad_verts.data_ptr())
-        return grad_verts, None, None, None, None, None, None, None
+        return grad_verts, None, None, None, None, None, None, None, None
 
 
 class Laplacian(torch.autograd.Function):
@@ -373,7 +378,7 @@ def manual_seed(seed, device=None):
     seeded from torch's default generator the first time it is used."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
-    state = torch.tensor([int(seed) & (2 ** 63 - 1), 0], dtype=torch.int64).to(dev)
+    state = torch.tensor([int(seed) & (2 ** 63 - 1), 0, 0], dtype=torch.int64).to(dev)   # seed, position, arrivals
     _rng_states[key] = state
     return state
 
@@ -386,13 +391,14 @@ def _rng_state(dev):
     return st
 
 
-def draw_samples(verts, faces, num, generator=None):
+def draw_samples(verts, faces, num, generator=None, with_points=False):
     """The random part of batch_sample (reference utils.py:604-612, 627-628): choices [B,num] ~
     area-weighted with replacement, u = sqrt(U1), v = U2, in ONE kernel: per-mesh face-area CDF in LDS,
     binary search per sample, uniforms from an in-kernel Philox stream whose position lives on the device
     (graph replays draw fresh numbers; no generator bookkeeping launches).  With an explicit torch
     `generator` the uniforms come from torch.rand instead; meshes with more than 16384 faces take the
-    torch.multinomial route."""
+    torch.multinomial route.  with_points=True also returns the sampled points [B,num,3] (or None when the
+    kernel could not produce them), which ops.SurfaceLoss accepts in place of its own gather launch."""
     verts_c = _f32(verts.detach(), "verts", 3, 3)
     faces = _lib.require(faces, "faces", torch.int64, 2, 3)
     b, nv, _ = verts_c.shape
@@ -400,12 +406,14 @@ def draw_samples(verts, faces, num, generator=None):
     choices = torch.empty(b, num, dtype=torch.int64, device=dev)
     u = torch.empty(b, num, dtype=torch.float32, device=dev)
     v = torch.empty(b, num, dtype=torch.float32, device=dev)
-    uniforms = None
+    uniforms = points = None
     with torch.cuda.device(dev):
         if generator is None:
+            if with_points:
+                points = torch.empty(b, num, 3, dtype=torch.float32, device=dev)
             code = _lib.lib().geom_draw_samples_rng_f32(b, nv, verts_c.data_ptr(), faces.shape[0], faces.data_ptr(), num,
                                                         _rng_state(dev).data_ptr(), choices.data_ptr(), u.data_ptr(),
-                                                        v.data_ptr(), _lib.stream_ptr())
+                                                        v.data_ptr(), _lib.ptr(points), _lib.stream_ptr())
         else:
             uniforms = torch.rand(3, b, num, device=dev, generator=generator)
             code = _lib.lib().geom_draw_samples_f32(b, nv, verts_c.data_ptr(), faces.shape[0], faces.data_ptr(), num,
@@ -415,9 +423,10 @@ def draw_samples(verts, faces, num, generator=None):
         if uniforms is None:
             uniforms = torch.rand(3, b, num, device=dev)
         choices = torch.multinomial(face_areas(verts_c, faces), num, True, generator=generator)
-        return choices, torch.sqrt(uniforms[1]), uniforms[2]
+        out = (choices, torch.sqrt(uniforms[1]), uniforms[2])
+        return out + (None,) if with_points else out
     _lib.check(code, "geom_draw_samples_f32")
-    return choices, u, v
+    return (choices, u, v, points) if with_points else (choices, u, v)
 
 
 class VertexHead(torch.autograd.Function):

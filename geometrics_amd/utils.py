@@ -78,10 +78,13 @@ def _f_score(sq_to_pred, sq_to_gt, num):
 
 def _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, two_sided):
     faces = adj_info["faces"]
-    if draws is None:
-        draws = ops.draw_samples(pred_vert, faces, num)
-    choices, u, v = draws
-    loss, sq_gt, sq_pred = ops.SurfaceLoss.apply(pred_vert, faces, gt_points, choices, u, v, two_sided, LOSS_SCALE)
+    points = None
+    if draws is None:   # one kernel draws AND gathers the points; replayed draws go through the separate gather
+        choices, u, v, points = ops.draw_samples(pred_vert, faces, num, with_points=True)
+    else:
+        choices, u, v = draws
+    loss, sq_gt, sq_pred = ops.SurfaceLoss.apply(pred_vert, faces, gt_points, choices, u, v, two_sided, LOSS_SCALE,
+                                                 points)
     if f1:
         return loss, _f_score(sq_gt, sq_pred, num)
     return loss

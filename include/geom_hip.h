@@ -106,11 +106,14 @@ int geom_face_areas_f32(int b, int nv, const float *verts, int nf, const int64_t
  * nf <= 16384 (the CDF lives in LDS), otherwise GEOM_EUNSUPPORTED. */
 int geom_draw_samples_f32(int b, int nv, const float *verts, int nf, const int64_t *faces, int num,
                           const float *uniforms, int64_t *choices, float *u, float *v, void *stream);
-/* Same draws from an in-kernel counter-based generator (Philox4x32-10): rng_state = 2 device uint64
- * {seed, stream position}; the position is advanced on the device after every call, so a captured HIP
- * graph draws fresh numbers on each replay and no generator bookkeeping is launched. */
+/* Same draws from an in-kernel counter-based generator (Philox4x32-10): rng_state = 3 device uint64
+ * {seed, stream position, 0}; the last workgroup of every call advances the position on the device (the third
+ * word is its arrival counter and is 0 between calls), so a captured HIP graph draws fresh numbers on each
+ * replay and no generator bookkeeping is launched.  One stream per rng_state.  points (may be NULL):
+ * [b,num,3], the sampled points themselves -- what geom_sample_faces_fwd_f32 would compute from the draws. */
 int geom_draw_samples_rng_f32(int b, int nv, const float *verts, int nf, const int64_t *faces, int num,
-                              uint64_t *rng_state, int64_t *choices, float *u, float *v, void *stream);
+                              uint64_t *rng_state, int64_t *choices, float *u, float *v, float *points,
+                              void *stream);
 /* points[b,num,3] = (1-u)*x + (u*(1-v))*y + (u*v)*z with x,y,z the corners of face
  * choices[b,num] (int64 face ids), u already sqrt'ed (utils.py:615-631). */
 int geom_sample_faces_fwd_f32(int b, int nv, const float *verts, int nf, const int64_t *faces,
@@ -168,6 +171,15 @@ int geom_sample_chamfer_bwd_f32(int b, int nv, int nf, const int64_t *faces, int
                                 const float *points, int n_other, const float *other,
                                 const int *idx, int via_nn, const float *coef_dev, float coef_host,
                                 float *grad_verts, void *stream);
+/* Backward of batch_point_to_surface (utils.py:441-502) in one launch: the Chamfer term of the sampled points
+ * (idx_g [b,num] = nearest gt point; coefficient coef_sample) and the point-to-triangle term of the gt points
+ * (index/closest/weights from geom_p2tri_loss_fwd_f32; coefficient coef_tri), both scattered into the same
+ * ZEROED grad_verts [b,nv,3]; coef_dev (device scalar, may be NULL) multiplies both. */
+int geom_surface_loss_bwd_f32(int b, int nv, int nf, const int64_t *faces, int num, const int64_t *choices,
+                              const float *u, const float *v, const float *points, int n_gt, const float *gt,
+                              const int *idx_g, const int *index, const float *closest, const float *weights,
+                              const float *coef_dev, float coef_sample, float coef_tri, float *grad_verts,
+                              void *stream);
 
 /* ---- 0N-GCN aggregation (layers.py:34-41, 107-116, 143-152) -----------------------------------
  * out[r,:k] = sum_j val[j]*support[col[j],:k] over CSR row r (rowptr int32 [nv+1], col int32, val f32),

@@ -411,3 +411,25 @@ def test_vertex_head_matches_slice_formulation(gpu):
     ref.backward(g)
     assert torch.allclose(out, ref, rtol=1e-6, atol=1e-7)
     assert torch.allclose(base.grad, b2.grad) and torch.allclose(feat.grad, f2.grad, rtol=1e-6, atol=1e-9)
+
+
+def test_fused_draw_points_and_fused_backward_match_the_separate_kernels(gpu):
+    """utils.batch_point_to_surface with its own draws uses (a) the draw kernel's points output and (b) the one-launch
+    backward; both must give the bits of the separate gather / two-scatter formulation on the same draws."""
+    V, Fc = meshgen.icosphere(3)
+    verts = dev(meshgen.jittered_batch(V, 3), gpu).requires_grad_(True)
+    faces, gt = dev(Fc, gpu), dev(meshgen.gt_cloud(3, 700), gpu)
+    ops.manual_seed(5)
+    choices, u, v, points = ops.draw_samples(verts, faces, 900, with_points=True)
+    assert torch.equal(points, ops.SampleFaces.apply(verts, faces, choices, u, v).detach())
+    loss_a, sq_gt_a, sq_pred_a = ops.SurfaceLoss.apply(verts, faces, gt, choices, u, v, False, 3000.0, points)
+    loss_a.backward()
+    grad_a, verts.grad = verts.grad.clone(), None
+    loss_b, sq_gt_b, sq_pred_b = ops.SurfaceLoss.apply(verts, faces, gt, choices, u, v, False, 3000.0)
+    loss_b.backward()
+    assert torch.equal(loss_a, loss_b) and torch.equal(sq_pred_a, sq_pred_b) and torch.equal(sq_gt_a, sq_gt_b)
+    # atomics: the two backward formulations add the same terms in a different order
+    assert torch.allclose(grad_a, verts.grad, rtol=1e-5, atol=1e-6 * float(grad_a.abs().max()))
+    # the arrival counter of the sampler stream is back to zero and the position advanced by exactly one per call
+    state = ops._rng_state(gpu).cpu()
+    assert int(state[2]) == 0 and int(state[1]) == 1
