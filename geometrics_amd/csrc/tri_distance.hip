@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256) void tri_prep_grouped_kernel(TriJob job, TriGw
 }
 
 template <bool TRUNC, bool FIX6>
-__global__ __launch_bounds__(HS_THREADS, 8) void tri_scan_grouped_kernel(const float *__restrict__ xyz, int b, int n, int m,
+__global__ __launch_bounds__(HS_THREADS) void tri_scan_grouped_kernel(const float *__restrict__ xyz, int b, int n, int m,
                                                                        TriGws ws, float *__restrict__ dist,
                                                                        int *__restrict__ point, int *__restrict__ index)
 {
@@ -778,10 +778,6 @@ __global__ __launch_bounds__(HS_THREADS, 8) void tri_scan_grouped_kernel(const f
     __shared__ unsigned queue_a[HS_WAVES][HS_QA];
     __shared__ unsigned queue_b[HS_WAVES][HS_QB];
 
-    // This scan is a chain of short dependent phases (low VALU load, latency bound); the python operators run it
-    // beside the VALU-heavy Chamfer scan.  Raising the wave priority lets its few instructions issue ahead of the
-    // neighbour's instead of queueing behind them (measured: the pair takes 70 us without).
-    __builtin_amdgcn_s_setprio(3);
     const int split = ws.split, m_pad = ws.m_pad;
     int mesh, task;
     if (!geom::xcd_assign(blockIdx.x, b, ((n + TRI_QUERIES - 1) / TRI_QUERIES) * split, mesh, task)) return;
