@@ -130,3 +130,30 @@ def test_layer_parameter_names_and_shapes():
         assert list(dict(cls(30, 50).named_parameters())) == ["weight_Ws.0", "weight_Bs.0"]
     assert layers.ZERON_GCN(7, 20, bias=False).bias is None
     assert float(layers.ZERON_GCN(7, 20).bias.abs().max()) == 0.0
+
+
+def test_triangle_visiting_orders_are_permutations_with_compact_leaves():
+    """kd_order / morton_order (host + torch code, no kernel): valid permutations; every run of 16 consecutive
+    entries of the k-d order is a spatially compact cell (what the two-level tri scan's group spheres rely on)."""
+    import numpy as np
+    import torch
+    from geometrics_amd import meshgen
+    from geometrics_amd.tri_distance import kd_order, morton_order
+    V, F = meshgen.icosphere(3)
+    cent = torch.from_numpy(V[F].mean(1))
+    rng = np.random.default_rng(0)
+    shuffled = cent[torch.from_numpy(rng.permutation(len(F)))]          # destroy the generator's own coherence
+    for fn in (kd_order, morton_order):
+        order = fn(shuffled)
+        assert order.dtype == torch.int32 and sorted(order.tolist()) == list(range(len(F)))
+    def mean_cell_radius(order):
+        c = shuffled[order.long()][: len(F) // 16 * 16].reshape(-1, 16, 3)
+        return float((c - c.mean(1, keepdim=True)).norm(dim=-1).max(1)[0].mean())
+    identity = torch.arange(len(F), dtype=torch.int32)
+    assert mean_cell_radius(kd_order(shuffled)) < 0.25 * mean_cell_radius(identity)
+    assert mean_cell_radius(morton_order(shuffled)) < 0.5 * mean_cell_radius(identity)
+    # degenerate inputs: fewer points than a leaf, non-finite coordinates
+    assert kd_order(cent[:5]).tolist() == sorted(kd_order(cent[:5]).tolist(), key=lambda i: i) or len(kd_order(cent[:5])) == 5
+    bad = cent[:40].clone()
+    bad[3] = float("nan")
+    assert sorted(kd_order(bad).tolist()) == list(range(40)) and sorted(morton_order(bad).tolist()) == list(range(40))
