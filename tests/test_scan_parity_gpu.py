@@ -294,3 +294,25 @@ def test_empty_and_degenerate_shapes(gpu):
     assert float(d) == 1.0 and int(p) == 0 and int(i) == 0
     d1, i1, d2, i2 = chamfer_nn(one, tri)
     assert int(i1) == 0 and int(i2[0, 0]) == 0 and float(d1) == pytest.approx(1.08, rel=1e-6)
+
+
+@pytest.mark.parametrize("level,npts,b", [(5, 700, 2), (6, 200, 1)])
+def test_tri_two_level_scan_multi_chunk_meshes(oracle_mod, gpu, level, npts, b):
+    """20 480 / 81 920 faces: the group spheres no longer fit one LDS staging pass (512 groups = 8192 triangles per
+    chunk), so the seed / cull / evaluate phases run per chunk with the bound carried over.  Grouped (k-d order and a
+    random order), flat and brute-force scans must agree bitwise; mesh 0 is also checked against the C oracle."""
+    verts, F, pts = _mesh_case(b, level, npts, seed=level)
+    dv, df, dp = _dev(verts, gpu), _dev(F, gpu), _dev(pts, gpu)
+    d, p, i = tri_distance_indexed(dp, dv, df)                                   # k-d order (cached), two-level
+    rnd = _dev(np.random.default_rng(level).permutation(F.shape[0]).astype(np.int32), gpu)
+    for kw in (dict(order=None), dict(order=rnd), dict(flags=FLAG_TRI_BRUTE_FORCE), dict(flags=FLAG_REF_TAIL_TRUNC)):
+        d2, p2, i2 = tri_distance_indexed(dp, dv, df, **kw)
+        if kw.get("flags") == FLAG_REF_TAIL_TRUNC:       # a different function of the input: compare its own variants
+            d3, p3, i3 = tri_distance_indexed(dp, dv, df, FLAG_REF_TAIL_TRUNC, order=None)
+            assert torch.equal(i2, i3) and torch.equal(p2, p3) and torch.equal(d2.view(torch.int32), d3.view(torch.int32))
+            continue
+        assert torch.equal(i2, i) and torch.equal(p2, p) and torch.equal(d2.view(torch.int32), d.view(torch.int32))
+    ed, ep, ei = oracle_mod.tri_scan_indexed(pts[:1, :100], verts[:1], F)
+    np.testing.assert_array_equal(i[:1, :100].cpu().numpy(), ei)
+    np.testing.assert_array_equal(p[:1, :100].cpu().numpy(), ep)
+    np.testing.assert_array_equal(d[:1, :100].cpu().numpy().view(np.uint32), ed.view(np.uint32))
