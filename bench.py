@@ -268,7 +268,7 @@ def kernel_rooflines(w):
 
 def component_times(w):
     """Kernel time of each stage of the step on the step's own tensors (HIP-graph replay + HIP events,
-    microseconds per shard of `batch` meshes).  Stages overlap inside the real step (two streams), so the
+    microseconds per shard of `batch` meshes).  Each stage is timed in isolation (its own launches back to back), so the
     sum exceeds ms_per_step; this is the per-component view SURVEY 8(d) asks for."""
     from geometrics_amd import ops
     out = {}
@@ -282,7 +282,7 @@ def component_times(w):
     def loss_fb():
         pv.grad = None
         utils.batch_point_to_surface(pv, w.info, w.gt, num=S_PTS).backward()
-    out["surface loss fwd+bwd (sampling, NN || tri, sums, scatters)"] = event_time_us(loss_fb, iters=10)
+    out["surface loss fwd+bwd (sampling, tri scan, NN, sums, scatter)"] = event_time_us(loss_fb, iters=10)
 
     def gcn_fwd():
         with torch.no_grad():

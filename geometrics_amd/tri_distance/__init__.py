@@ -134,7 +134,7 @@ def tri_distance(xyz1, tri1, tri2, tri3, flags=0, use_workspace=True, order=None
 
 
 def tri_distance_indexed(xyz1, verts, faces, flags=0, use_workspace=True, order="auto"):
-    """Corners gathered in-kernel from verts [B,V,3] through faces [F,3] (int64).  order: "auto" (cached Morton
+    """Corners gathered in-kernel from verts [B,V,3] through faces [F,3] (int64).  order: "auto" (cached k-d leaf
     order of the face centroids -> two-level scan), None (flat scan) or an explicit int32 permutation."""
     xyz1 = _lib.require(xyz1.detach(), "xyz1", torch.float32, 3, 3)
     verts = _lib.require(verts.detach(), "verts", torch.float32, 3, 3)
