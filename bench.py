@@ -268,8 +268,9 @@ def kernel_rooflines(w):
 
 def component_times(w):
     """Kernel time of each stage of the step on the step's own tensors (HIP-graph replay + HIP events,
-    microseconds per shard of `batch` meshes).  Each stage is timed in isolation (its own launches back to back), so the
-    sum exceeds ms_per_step; this is the per-component view SURVEY 8(d) asks for."""
+    microseconds per shard of `batch` meshes).  Each stage is timed in isolation (its own launches back to back) and some
+    entries nest (stack forward is part of forward+backward), so they do not add up to ms_per_step; this is the
+    per-component view SURVEY 8(d) asks for."""
     from geometrics_amd import ops
     out = {}
     pos = w.positions().detach().contiguous()
