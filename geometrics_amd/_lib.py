@@ -54,8 +54,8 @@ _SIGNATURES = {
     "geom_pool_features_bwd_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "geom_adam_step_f32": [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _vp],
     "geom_zn_gcn_aggregate_fwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
-    "geom_zn_gcn_aggregate_ell_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
-    "geom_zn_gcn_aggregate_ell_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "geom_zn_gcn_aggregate_ell_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "geom_zn_gcn_aggregate_ell_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "geom_zn_gcn_aggregate_bwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
 }
 
@@ -92,6 +92,8 @@ def lib():
         L.geom_segment_max_workspace_bytes.restype = ctypes.c_int64
         L.geom_segment_max_workspace_bytes.argtypes = [_i, _i, ctypes.c_int64]
         L.geom_zn_gcn_bwd_scratch_floats.restype = ctypes.c_int64
+        L.geom_zn_gcn_relu_mask_words.restype = ctypes.c_int64
+        L.geom_zn_gcn_relu_mask_words.argtypes = [_i, _i, _i, _i]
         L.geom_zn_gcn_bwd_scratch_floats.argtypes = [_i, _i, _i]
         L.geom_tri_distance_workspace_bytes.restype = ctypes.c_size_t
         L.geom_tri_distance_workspace_bytes.argtypes = [_i, _i, _i]
@@ -106,7 +108,7 @@ def lib():
 def declared_symbols():
     return sorted(["geom_abi_version", "geom_strerror", "geom_tri_distance_workspace_bytes",
                    "geom_zn_gcn_bwd_scratch_floats", "geom_pool_features_bwd_workspace_bytes",
-                   "geom_segment_max_workspace_bytes"] + list(_SIGNATURES))
+                   "geom_segment_max_workspace_bytes", "geom_zn_gcn_relu_mask_words"] + list(_SIGNATURES))
 
 
 def check(code, what):

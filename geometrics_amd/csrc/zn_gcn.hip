@@ -265,12 +265,17 @@ struct EllArgs {
     const float *x, *bias, *saved;
     float *y;
     int nv, c, k;
+    unsigned short *mask; // ReLU sign bits, one word per thread: bit 4*i + e <-> element e of the thread's float4 i
 };
 
-template <int ACT, bool BACKWARD, int W, int NC>
+// MASK (ReLU, NC == 2 only): the forward also stores the sign of every output element as one bit (12 bits per
+// thread -> 0.66 MB per layer at the BASELINE shard), and the backward takes relu' from those bits instead of
+// re-reading the 15.7 MB forward output: 47 -> 32 MB of traffic for the backward launch.
+template <int ACT, bool BACKWARD, int W, int NC, bool MASK = false>
 __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a, int rows_per_block,
                                                                         float *colsum_partial)
 {
+    static_assert(!MASK || (ACT == ACT_RELU && NC == 2), "the sign mask is the ReLU / split-3 fast path");
     extern __shared__ float lds_cs[]; // [rows_per_block][c]
     const int kg = a.k >> 2;                         // aggregated float4 groups per row
     const int j = threadIdx.x % kg;
@@ -297,10 +302,18 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a
             nb[n] = ci.x, nb[n + 1] = ci.y, nb[n + 2] = ci.z, nb[n + 3] = ci.w;
             w[n] = wi.x, w[n + 1] = wi.y, w[n + 2] = wi.z, w[n + 3] = wi.w;
         }
+        unsigned own_bits = 0u;
+        if (BACKWARD && MASK) own_bits = a.mask[row * kg + j];
 #pragma unroll
         for (int i = BACKWARD ? 0 : 1; i <= NC; ++i) {
             own[i] = *reinterpret_cast<const float4 *>(xrow + c0 + a.k * i);
-            if (BACKWARD && ACT != ACT_NONE) {
+            if (BACKWARD && MASK) {
+                const unsigned m = own_bits >> (4 * i);
+                own[i].x = (m & 1u) ? own[i].x : 0.f;
+                own[i].y = (m & 2u) ? own[i].y : 0.f;
+                own[i].z = (m & 4u) ? own[i].z : 0.f;
+                own[i].w = (m & 8u) ? own[i].w : 0.f;
+            } else if (BACKWARD && ACT != ACT_NONE) {
                 const float4 o = *reinterpret_cast<const float4 *>(a.saved + row * a.c + c0 + a.k * i);
                 own[i].x = act_bwd<ACT>(own[i].x, o.x);
                 own[i].y = act_bwd<ACT>(own[i].y, o.y);
@@ -310,18 +323,25 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a
         }
         // round trip 2: the neighbour rows of the aggregated slot
         float4 sv[W], ov[W];
+        unsigned nbits[W];
 #pragma unroll
         for (int n = 0; n < W; ++n) {
             const int64_t nrow = mesh_row0 + (nb[n] >= 0 ? nb[n] : r);
             sv[n] = *reinterpret_cast<const float4 *>(a.x + nrow * a.c + c0);
-            if (BACKWARD && ACT != ACT_NONE) ov[n] = *reinterpret_cast<const float4 *>(a.saved + nrow * a.c + c0);
+            if (BACKWARD && MASK) nbits[n] = a.mask[nrow * kg + j];
+            else if (BACKWARD && ACT != ACT_NONE) ov[n] = *reinterpret_cast<const float4 *>(a.saved + nrow * a.c + c0);
         }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int n = 0; n < W; ++n) {
             if (nb[n] >= 0) { // ELL order == CSR order of the row
                 float4 v = sv[n];
-                if (BACKWARD && ACT != ACT_NONE) {
+                if (BACKWARD && MASK) {
+                    v.x = (nbits[n] & 1u) ? v.x : 0.f;
+                    v.y = (nbits[n] & 2u) ? v.y : 0.f;
+                    v.z = (nbits[n] & 4u) ? v.z : 0.f;
+                    v.w = (nbits[n] & 8u) ? v.w : 0.f;
+                } else if (BACKWARD && ACT != ACT_NONE) {
                     v.x = act_bwd<ACT>(v.x, ov[n].x);
                     v.y = act_bwd<ACT>(v.y, ov[n].y);
                     v.z = act_bwd<ACT>(v.z, ov[n].z);
@@ -334,6 +354,7 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a
             }
         }
         float *yrow = a.y + row * a.c;
+        unsigned sign_bits = 0u;
 #pragma unroll
         for (int i = 0; i <= NC; ++i) {
             float4 v = i == 0 ? acc : own[i];
@@ -343,9 +364,12 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a
                     v.x += bb.x, v.y += bb.y, v.z += bb.z, v.w += bb.w;
                 }
                 v.x = act_fwd<ACT>(v.x), v.y = act_fwd<ACT>(v.y), v.z = act_fwd<ACT>(v.z), v.w = act_fwd<ACT>(v.w);
+                if (MASK) // out > 0, the predicate relu' is defined by (act_bwd)
+                    sign_bits |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << (4 * i);
             }
             *reinterpret_cast<float4 *>(yrow + c0 + a.k * i) = v;
         }
+        if (!BACKWARD && MASK) a.mask[row * kg + j] = (unsigned short)sign_bits;
     }
 
     if (BACKWARD && colsum_partial) {
@@ -376,6 +400,13 @@ void launch_ell_shape(const EllArgs &a, int w, dim3 grid, size_t lds, hipStream_
 {
     const dim3 block(GCN_THREADS);
     const int nc = ell_nc(a.c, a.k);
+    if constexpr (ACT == ACT_RELU) {
+        if (a.mask && nc == 2) {
+            if (w == 8) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 8, 2, true>), grid, block, lds, s, a, rpb, partial);
+            else hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 16, 2, true>), grid, block, lds, s, a, rpb, partial);
+            return;
+        }
+    }
     if (w == 8 && nc == 2) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 8, 2>), grid, block, lds, s, a, rpb, partial);
     else if (w == 16 && nc == 2) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 16, 2>), grid, block, lds, s, a, rpb, partial);
     else if (w == 8 && nc == 9) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 8, 9>), grid, block, lds, s, a, rpb, partial);
@@ -389,7 +420,8 @@ int dispatch_ell(EllArgs a, int b, int w, int act, float *grad_bias, float *scra
     if (!ell_supported(a.c, a.k, w)) return GEOM_EUNSUPPORTED;
     if (b == 0 || a.nv == 0) return 0;
     if (!a.col || !a.val || !a.x || !a.y) return GEOM_EINVAL;
-    if (BACKWARD && act != ACT_NONE && !a.saved) return GEOM_EINVAL;
+    if (a.mask && !(act == ACT_RELU && ell_nc(a.c, a.k) == 2)) return GEOM_EINVAL; // sign mask: ReLU, split 3 only
+    if (BACKWARD && act != ACT_NONE && !a.saved && !a.mask) return GEOM_EINVAL;
     if (grad_bias && !scratch) return GEOM_EINVAL;
     if ((((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.saved | (uintptr_t)a.bias | (uintptr_t)a.col | (uintptr_t)a.val) % 16) != 0)
         return GEOM_EINVAL;
@@ -459,17 +491,23 @@ extern "C" int geom_zn_gcn_aggregate_bwd_f32(int b, int nv, int c, int k, const 
 
 extern "C" int geom_zn_gcn_aggregate_ell_fwd_f32(int b, int nv, int c, int k, int w, const int *ell_col,
                                                  const float *ell_val, const float *support, const float *bias,
-                                                 int act, float *out, void *stream)
+                                                 int act, float *out, uint16_t *relu_mask, void *stream)
 {
-    EllArgs a{ell_col, ell_val, support, bias, nullptr, out, nv, c, k};
+    EllArgs a{ell_col, ell_val, support, bias, nullptr, out, nv, c, k, relu_mask};
     return dispatch_ell<false>(a, b, w, act, nullptr, nullptr, stream);
+}
+
+extern "C" int64_t geom_zn_gcn_relu_mask_words(int b, int nv, int c, int k)
+{
+    if (b <= 0 || nv <= 0 || ell_nc(c, k) != 2) return 0; // 0: this shape has no mask path
+    return (int64_t)b * nv * (k >> 2);
 }
 
 extern "C" int geom_zn_gcn_aggregate_ell_bwd_f32(int b, int nv, int c, int k, int w, const int *ell_colT,
                                                  const float *ell_valT, const float *grad_out, const float *out,
-                                                 int act, float *grad_support, float *grad_bias, float *scratch,
-                                                 void *stream)
+                                                 const uint16_t *relu_mask, int act, float *grad_support,
+                                                 float *grad_bias, float *scratch, void *stream)
 {
-    EllArgs a{ell_colT, ell_valT, grad_out, nullptr, out, grad_support, nv, c, k};
+    EllArgs a{ell_colT, ell_valT, grad_out, nullptr, out, grad_support, nv, c, k, const_cast<uint16_t *>(relu_mask)};
     return dispatch_ell<true>(a, b, w, act, grad_bias, scratch, stream);
 }

@@ -128,19 +128,30 @@ class _ZeroNAggregate(torch.autograd.Function):
             raise RuntimeError("support has %d vertices but the adjacency has %d" % (nv, csr.nv))
         bias_c = None if bias is None else _lib.require(bias, "bias", torch.float32, 1)
         out = torch.empty_like(s)
+        mask = None
         with torch.cuda.device(s.device):
             code = _lib.EUNSUPPORTED
             if csr.ell_w:   # bounded-degree mesh: fixed-stride neighbour table, no rowptr round trip
+                if act == _ACT_RELU and support.requires_grad:
+                    # one sign bit per output element: the backward takes relu' from it instead of re-reading `out`
+                    words = _lib.lib().geom_zn_gcn_relu_mask_words(b, nv, c, k)
+                    if words:
+                        mask = torch.empty(words, dtype=torch.int16, device=s.device)
                 code = _lib.lib().geom_zn_gcn_aggregate_ell_fwd_f32(
                     b, nv, c, k, csr.ell_w, csr.ell_col.data_ptr(), csr.ell_val.data_ptr(), s.data_ptr(),
-                    _lib.ptr(bias_c), act, out.data_ptr(), _lib.stream_ptr())
+                    _lib.ptr(bias_c), act, out.data_ptr(), _lib.ptr(mask), _lib.stream_ptr())
+                if code == _lib.EUNSUPPORTED:
+                    mask = None
             if code == _lib.EUNSUPPORTED:
                 _lib.call("geom_zn_gcn_aggregate_fwd_f32", b, nv, c, k, csr.rowptr.data_ptr(), csr.col.data_ptr(),
                           csr.val.data_ptr(), s.data_ptr(), _lib.ptr(bias_c), act, out.data_ptr())
             else:
                 _lib.check(code, "geom_zn_gcn_aggregate_ell_fwd_f32")
         ctx.csr, ctx.k, ctx.act, ctx.has_bias = csr, k, act, bias is not None
-        if act != _ACT_NONE:
+        ctx.masked = mask is not None
+        if mask is not None:
+            ctx.save_for_backward(mask)
+        elif act != _ACT_NONE:
             ctx.save_for_backward(out)
         return out
 
@@ -149,7 +160,8 @@ class _ZeroNAggregate(torch.autograd.Function):
         g = grad_out.contiguous()
         b, nv, c = g.shape
         csr, act = ctx.csr, ctx.act
-        out = ctx.saved_tensors[0] if act != _ACT_NONE else None
+        mask = ctx.saved_tensors[0] if ctx.masked else None
+        out = ctx.saved_tensors[0] if (act != _ACT_NONE and not ctx.masked) else None
         want_bias = ctx.has_bias and ctx.needs_input_grad[1]
         grad_support = torch.empty_like(g)
         grad_bias = scratch = None
@@ -162,7 +174,7 @@ class _ZeroNAggregate(torch.autograd.Function):
             if csr.ell_w:
                 code = _lib.lib().geom_zn_gcn_aggregate_ell_bwd_f32(
                     b, nv, c, ctx.k, csr.ell_w, csr.ell_col_t.data_ptr(), csr.ell_val_t.data_ptr(), g.data_ptr(),
-                    _lib.ptr(out), act, grad_support.data_ptr(), _lib.ptr(grad_bias), _lib.ptr(scratch),
+                    _lib.ptr(out), _lib.ptr(mask), act, grad_support.data_ptr(), _lib.ptr(grad_bias), _lib.ptr(scratch),
                     _lib.stream_ptr())
             if code == _lib.EUNSUPPORTED:
                 _lib.call("geom_zn_gcn_aggregate_bwd_f32", b, nv, c, ctx.k, csr.rowptr_t.data_ptr(),

@@ -202,14 +202,18 @@ int geom_zn_gcn_aggregate_bwd_f32(int b, int nv, int c, int k, const int *rowptr
  * order).  ell_col/ell_val are [nv][w] row-major, w = 8 or 16, unused slots col = -1; supported when
  * k % 4 == 0 and c == 3k (split 3) or c == 10k (split 10) -- every hidden layer of the reference
  * models on a triangle mesh; anything else returns GEOM_EUNSUPPORTED and the CSR entry points above
- * apply.  All pointers 16-byte aligned.  Scratch as for the CSR backward. */
+ * apply.  All pointers 16-byte aligned.  Scratch as for the CSR backward.
+ * relu_mask (may be NULL; act == ReLU and c == 3k only, else GEOM_EINVAL): geom_zn_gcn_relu_mask_words(b,nv,c,k)
+ * uint16 words.  The forward stores the sign of every output element in it (one bit each); a backward that is
+ * given the mask takes relu' from it and does not read `out` (which may then be NULL): 1/3 less traffic. */
+int64_t geom_zn_gcn_relu_mask_words(int b, int nv, int c, int k);
 int geom_zn_gcn_aggregate_ell_fwd_f32(int b, int nv, int c, int k, int w, const int *ell_col,
                                       const float *ell_val, const float *support, const float *bias,
-                                      int act, float *out, void *stream);
+                                      int act, float *out, uint16_t *relu_mask, void *stream);
 int geom_zn_gcn_aggregate_ell_bwd_f32(int b, int nv, int c, int k, int w, const int *ell_colT,
                                       const float *ell_valT, const float *grad_out, const float *out,
-                                      int act, float *grad_support, float *grad_bias, float *scratch,
-                                      void *stream);
+                                      const uint16_t *relu_mask, int act, float *grad_support,
+                                      float *grad_bias, float *scratch, void *stream);
 
 /* Coordinate update of a deformation stage (GEOMetrics.py:121,126,131) when the predicted offsets are the
  * three leading channels of a wider feature tensor: pos[r,:] = base[r,:] + scale*feat[r,:3] for `rows`

@@ -433,3 +433,48 @@ def test_fused_draw_points_and_fused_backward_match_the_separate_kernels(gpu):
     # the arrival counter of the sampler stream is back to zero and the position advanced by exactly one per call
     state = ops._rng_state(gpu).cpu()
     assert int(state[2]) == 0 and int(state[1]) == 1
+
+
+def test_relu_sign_mask_backward_equals_the_output_based_one(gpu):
+    """ELL aggregation, ReLU, split 3: the backward that takes relu' from the 1-bit-per-element mask written by the
+    forward must give the bits of the backward that re-reads the forward output (and the layer must use it)."""
+    from geometrics_amd import _lib as L
+    V, Fc = meshgen.icosphere(3)
+    adj = utils.adj_init(dev(Fc, gpu))["adj"]
+    csr = layers.adjacency_csr(adj)
+    B, C, k, nv = 3, 48, 16, V.shape[0]
+    torch.manual_seed(1)
+    sup, bias, g = torch.randn(B, nv, C, device=gpu), torch.randn(C, device=gpu), torch.randn(B, nv, C, device=gpu)
+    out = torch.empty_like(sup)
+    words = L.lib().geom_zn_gcn_relu_mask_words(B, nv, C, k)
+    assert words == B * nv * (k // 4) and L.lib().geom_zn_gcn_relu_mask_words(B, nv, 40, 4) == 0
+    mask = torch.zeros(words, dtype=torch.int16, device=gpu)
+    L.call("geom_zn_gcn_aggregate_ell_fwd_f32", B, nv, C, k, csr.ell_w, csr.ell_col.data_ptr(), csr.ell_val.data_ptr(),
+           sup.data_ptr(), bias.data_ptr(), 1, out.data_ptr(), mask.data_ptr())
+    bits = (mask.view(B, nv, k // 4, 1).int() >> torch.arange(12, device=gpu).int()) & 1       # [B,nv,k/4,12]
+    expect = (out > 0).view(B, nv, 3, k // 4, 4).permute(0, 1, 3, 2, 4).reshape(B, nv, k // 4, 12).int()
+    assert torch.equal(bits, expect)
+    scr = torch.empty(L.lib().geom_zn_gcn_bwd_scratch_floats(B, nv, C), device=gpu)
+    res = []
+    for use_mask in (False, True):
+        gs, gb = torch.empty_like(sup), torch.empty(C, device=gpu)
+        L.call("geom_zn_gcn_aggregate_ell_bwd_f32", B, nv, C, k, csr.ell_w, csr.ell_col_t.data_ptr(),
+               csr.ell_val_t.data_ptr(), g.data_ptr(), None if use_mask else out.data_ptr(),
+               mask.data_ptr() if use_mask else None, 1, gs.data_ptr(), gb.data_ptr(), scr.data_ptr())
+        res.append((gs, gb))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    # the mask is a ReLU / split-3 facility: anything else is refused
+    assert L.lib().geom_zn_gcn_aggregate_ell_fwd_f32(B, nv, C, k, csr.ell_w, csr.ell_col.data_ptr(), csr.ell_val.data_ptr(),
+                                                     sup.data_ptr(), bias.data_ptr(), 2, out.data_ptr(), mask.data_ptr(),
+                                                     L.stream_ptr()) == -1
+    # autograd path: a ReLU layer saves the mask, not the output
+    layer = layers.Batch_Image_ZERON_GCNGCN(20, C).to(gpu)
+    x = torch.randn(B, nv, 20, device=gpu, requires_grad=True)
+    y = layer(x, adj, torch.relu)
+    saved = y.grad_fn.saved_tensors
+    assert len(saved) == 1 and saved[0].dtype == torch.int16
+    y.backward(g)
+    x2 = x.detach().clone().requires_grad_(True)
+    ref = torch.relu(torch.cat((adj @ (x2 @ layer.weight1[0])[..., :k], (x2 @ layer.weight1[0])[..., k:]), -1) + layer.bias)
+    ref.backward(g)
+    assert torch.allclose(x.grad, x2.grad, rtol=1e-4, atol=1e-5)
