@@ -43,7 +43,7 @@ _SIGNATURES = {
     "geom_segment_max_fwd_f32": [_i, _vp, ctypes.c_int64, _i, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp],
     "geom_segment_max_bwd_f32": [_i, _vp, ctypes.c_int64, _i, _vp, _vp, _vp, _vp],
     "geom_sum_f32": [ctypes.c_int64, _vp, _f, _vp, _vp],
-    "geom_sum2_f32": [ctypes.c_int64, _vp, _f, ctypes.c_int64, _vp, _f, _vp, _vp],
+    "geom_sum2_f32": [ctypes.c_int64, _vp, _f, ctypes.c_int64, _vp, _f, _vp, _vp, ctypes.c_int64, _vp],
     "geom_sample_chamfer_bwd_f32": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _f, _vp, _vp],
     "geom_laplacian_f32": [_i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "geom_edge_sqlen_fwd_f32": [_i, _i, _vp, _i, _vp, _vp, _vp],

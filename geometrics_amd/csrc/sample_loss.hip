@@ -459,9 +459,13 @@ __device__ __forceinline__ float thread_sum(int64_t n, const float *x)
 // out[0] = s1 * sum(x1) + s2 * sum(x2): the whole  (dist_1 + dist_2) * 3000  of utils.py:420/484
 // in one launch, same fixed reduction tree per segment.
 __global__ __launch_bounds__(SUM_THREADS) void sum2_kernel(int64_t n1, const float *x1, float s1, int64_t n2,
-                                                            const float *x2, float s2, float *out)
+                                                            const float *x2, float s2, float *out, float *clear,
+                                                            int64_t clear_count)
 {
     __shared__ float partial[2][SUM_THREADS / GEOM_WAVE];
+    // optional side job: zero the buffer the backward will accumulate into (saves the backward a fill launch --
+    // about 5 us inside a captured graph, where this workgroup's stores are free)
+    for (int64_t i = threadIdx.x; i < clear_count; i += SUM_THREADS) clear[i] = 0.f;
     // One workgroup: the sum is a latency chain unless many loads are in flight.  Each thread issues up to
     // SUM_BATCH float4 loads per segment back to back (48 000 floats = 12 per thread: one round trip), then
     // adds them in a fixed order -- the association is static, so the result stays bit-reproducible.
@@ -612,11 +616,12 @@ extern "C" int geom_surface_loss_bwd_f32(int b, int nv, int nf, const int64_t *f
 }
 
 extern "C" int geom_sum2_f32(int64_t n1, const float *x1, float scale1, int64_t n2, const float *x2, float scale2,
-                             float *out, void *stream)
+                             float *out, float *clear, int64_t clear_count, void *stream)
 {
     if (n1 < 0 || n2 < 0 || !out || (n1 > 0 && !x1) || (n2 > 0 && !x2)) return GEOM_EINVAL;
+    if (clear_count < 0 || (clear_count > 0 && !clear)) return GEOM_EINVAL;
     hipLaunchKernelGGL(sum2_kernel, dim3(1), dim3(SUM_THREADS), 0, static_cast<hipStream_t>(stream), n1, x1, scale1, n2,
-                       x2, scale2, out);
+                       x2, scale2, out, clear, clear_count);
     return geom::launch_status();
 }
 

@@ -132,6 +132,9 @@ class PointToTriangleSum(torch.autograd.Function):
         return None, grad_verts, None, None, None
 
 
+_CLEAR_IN_FORWARD_MAX = 1 << 18   # floats (1 MiB): beyond this a separate fill kernel is the faster way to zero
+
+
 class SurfaceLoss(torch.autograd.Function):
     """The whole sampled-surface loss of the reference in one autograd node.
 
@@ -192,14 +195,21 @@ class SurfaceLoss(torch.autograd.Function):
             _lib.check(L.geom_chamfer_nn_f32(b, n_gt, gt_c.data_ptr(), num, points.data_ptr(), sq_gt.data_ptr(),
                                              idx_p.data_ptr(), sq_pred.data_ptr(), idx_g.data_ptr(), 0,
                                              _lib.stream_ptr()), "geom_chamfer_nn_f32")
+            # the loss reduction is one workgroup; it also zeroes the buffer the backward scatters into, which spares
+            # the backward a fill launch (used once: a second backward through the same node allocates its own)
+            grad_buf = None
+            if ctx.needs_input_grad[0] and b * nv * 3 <= _CLEAR_IN_FORWARD_MAX:
+                grad_buf = torch.empty(b, nv, 3, **f32)
+            clear = (_lib.ptr(grad_buf), 0 if grad_buf is None else grad_buf.numel())
             if two_sided:
                 _lib.call("geom_sum2_f32", sq_pred.numel(), sq_pred.data_ptr(), scale / sq_pred.numel(),
-                          sq_gt.numel(), sq_gt.data_ptr(), scale / sq_gt.numel(), out.data_ptr())
+                          sq_gt.numel(), sq_gt.data_ptr(), scale / sq_gt.numel(), out.data_ptr(), *clear)
                 ctx.save_for_backward(faces, choices, u, v, points, gt_c, idx_g, idx_p)
             else:
                 _lib.call("geom_sum2_f32", sq_pred.numel(), sq_pred.data_ptr(), scale / sq_pred.numel(),
-                          sq.numel(), sq.data_ptr(), scale / sq.numel(), out.data_ptr())
+                          sq.numel(), sq.data_ptr(), scale / sq.numel(), out.data_ptr(), *clear)
                 ctx.save_for_backward(faces, choices, u, v, points, gt_c, idx_g, index, closest, weights)
+            ctx.grad_buf = grad_buf
         ctx.two_sided, ctx.scale, ctx.nv = two_sided, scale, nv
         ctx.mark_non_differentiable(sq_gt, sq_pred)
         ctx.set_materialize_grads(False)    # no zero tensors (two fill launches) for the two distance outputs
@@ -213,7 +223,9 @@ class SurfaceLoss(torch.autograd.Function):
         n_gt, nf, nv = gt.shape[1], faces.shape[0], ctx.nv
         dev = points.device
         grad = grad.contiguous()
-        grad_verts = torch.zeros(b, nv, 3, dtype=torch.float32, device=dev)
+        grad_verts, ctx.grad_buf = ctx.grad_buf, None     # zeroed by the forward's reduction launch
+        if grad_verts is None:
+            grad_verts = torch.zeros(b, nv, 3, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             sample_args = (b, nv, nf, faces.data_ptr(), num, choices.data_ptr(), u.data_ptr(), v.data_ptr(),
                            points.data_ptr(), n_gt, gt.data_ptr())

@@ -156,9 +156,11 @@ int geom_p2tri_loss_bwd_f32(int b, int n, const float *xyz, int nv, int nf, cons
 
 /* out[0] = scale * sum(x[0..n)) with a fixed reduction tree (bit-reproducible run to run). */
 int geom_sum_f32(int64_t n, const float *x, float scale, float *out, void *stream);
-/* out[0] = scale1*sum(x1) + scale2*sum(x2): the whole (dist_1 + dist_2) * 3000 of utils.py:420/484. */
+/* out[0] = scale1*sum(x1) + scale2*sum(x2): the whole (dist_1 + dist_2) * 3000 of utils.py:420/484.
+ * clear/clear_count (may be NULL/0): floats the same launch sets to zero -- the buffer the backward scatters
+ * into, so that it needs no fill launch of its own (one workgroup: meant for a few hundred KB). */
 int geom_sum2_f32(int64_t n1, const float *x1, float scale1, int64_t n2, const float *x2, float scale2,
-                  float *out, void *stream);
+                  float *out, float *clear, int64_t clear_count, void *stream);
 
 /* Fused backward of the Chamfer term THROUGH the sampling (utils.py:454-462 + 615-631 under autograd):
  * the gradient 2*coef*(point - other) of a sampled point is scattered straight into grad_verts with
