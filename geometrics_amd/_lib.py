@@ -32,6 +32,8 @@ _SIGNATURES = {
     "geom_face_areas_f32": [_i, _i, _vp, _i, _vp, _vp, _vp],
     "geom_draw_samples_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_draw_samples_rng_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "geom_surface_loss_bwd_gather_f32": [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                         _f, _f, _vp, _vp, _vp, _vp],
     "geom_surface_loss_bwd_f32": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp],
     "geom_vertex_head_fwd_f32": [ctypes.c_int64, _i, _vp, _vp, _f, _vp, _vp],
     "geom_vertex_head_bwd_f32": [ctypes.c_int64, _i, _vp, _f, _vp, _vp],
@@ -92,6 +94,10 @@ def lib():
         L.geom_segment_max_workspace_bytes.restype = ctypes.c_int64
         L.geom_segment_max_workspace_bytes.argtypes = [_i, _i, ctypes.c_int64]
         L.geom_zn_gcn_bwd_scratch_floats.restype = ctypes.c_int64
+        L.geom_surface_bin_count_words.restype = ctypes.c_int64
+        L.geom_surface_bin_count_words.argtypes = [_i, _i]
+        L.geom_surface_bin_list_words.restype = ctypes.c_int64
+        L.geom_surface_bin_list_words.argtypes = [_i, _i, _i, _i]
         L.geom_zn_gcn_relu_mask_words.restype = ctypes.c_int64
         L.geom_zn_gcn_relu_mask_words.argtypes = [_i, _i, _i, _i]
         L.geom_zn_gcn_bwd_scratch_floats.argtypes = [_i, _i, _i]
@@ -108,7 +114,8 @@ def lib():
 def declared_symbols():
     return sorted(["geom_abi_version", "geom_strerror", "geom_tri_distance_workspace_bytes",
                    "geom_zn_gcn_bwd_scratch_floats", "geom_pool_features_bwd_workspace_bytes",
-                   "geom_segment_max_workspace_bytes", "geom_zn_gcn_relu_mask_words"] + list(_SIGNATURES))
+                   "geom_segment_max_workspace_bytes", "geom_zn_gcn_relu_mask_words",
+                   "geom_surface_bin_count_words", "geom_surface_bin_list_words"] + list(_SIGNATURES))
 
 
 def check(code, what):

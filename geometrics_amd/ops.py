@@ -132,7 +132,30 @@ class PointToTriangleSum(torch.autograd.Function):
         return None, grad_verts, None, None, None
 
 
-_CLEAR_IN_FORWARD_MAX = 1 << 18   # floats (1 MiB): beyond this a separate fill kernel is the faster way to zero
+_CLEAR_IN_FORWARD_MAX = 1 << 18   # words (1 MiB): beyond this a separate fill kernel is the faster way to zero
+
+_vf_cache = {}   # id(faces) -> (weakref, version, nv, vf_ptr, vf_item)
+
+
+def vertex_faces(faces, nv):
+    """Static CSR vertex -> incident (face << 2 | corner), ascending per vertex: what the gather backward walks.
+    Built once per faces TENSOR OBJECT / in-place version / vertex count (same caching policy as the adjacency CSR)."""
+    import weakref
+    key = id(faces)
+    hit = _vf_cache.get(key)
+    if hit is not None and hit[0]() is faces and hit[1] == faces._version and hit[2] == nv:
+        return hit[3], hit[4]
+    with torch.no_grad():
+        flat = faces.reshape(-1)
+        if flat.numel() and (int(flat.min()) < 0 or int(flat.max()) >= nv):
+            raise RuntimeError("faces refer to vertices outside [0, %d)" % nv)
+        order = torch.argsort(flat, stable=True)                      # position p = 3*face + corner
+        vf_item = (((order // 3) << 2) | (order % 3)).to(torch.int32).contiguous()
+        vf_ptr = torch.zeros(nv + 1, dtype=torch.int64, device=faces.device)
+        vf_ptr[1:] = torch.cumsum(torch.bincount(flat, minlength=nv), 0)
+        vf_ptr = vf_ptr.to(torch.int32).contiguous()
+    _vf_cache[key] = (weakref.ref(faces, lambda _ref, k=key: _vf_cache.pop(k, None)), faces._version, nv, vf_ptr, vf_item)
+    return vf_ptr, vf_item
 
 
 class SurfaceLoss(torch.autograd.Function):
@@ -144,8 +167,9 @@ class SurfaceLoss(torch.autograd.Function):
             3000 * ( mean_s |gt[nn(s)] - pred_s|^2  +  mean_g |pred[nn(g)] - g|^2 )
 
     Forward: [tri scan -> closest point] -> sample -> NN (both directions) -> one two-segment sum, one stream.
-    Backward: ONE zero-fill of grad_verts, then every term scatters into it (the gradient of the
-    sampled points is never materialised).  Returns (loss, sq_gt, sq_pred); the squared NN
+    Backward: a gather -- the points are binned by face (integer atomics) and every vertex sums the points on its
+    incident faces in a fixed order: no float atomics, no zero-fill, bit-reproducible (csrc/surface_gather.hip); the
+    gradient of the sampled points is never materialised.  Returns (loss, sq_gt, sq_pred); the squared NN
     distances feed the F1 score and are not differentiable."""
 
     @staticmethod
@@ -195,12 +219,12 @@ class SurfaceLoss(torch.autograd.Function):
             _lib.check(L.geom_chamfer_nn_f32(b, n_gt, gt_c.data_ptr(), num, points.data_ptr(), sq_gt.data_ptr(),
                                              idx_p.data_ptr(), sq_pred.data_ptr(), idx_g.data_ptr(), 0,
                                              _lib.stream_ptr()), "geom_chamfer_nn_f32")
-            # the loss reduction is one workgroup; it also zeroes the buffer the backward scatters into, which spares
-            # the backward a fill launch (used once: a second backward through the same node allocates its own)
-            grad_buf = None
-            if ctx.needs_input_grad[0] and b * nv * 3 <= _CLEAR_IN_FORWARD_MAX:
-                grad_buf = torch.empty(b, nv, 3, **f32)
-            clear = (_lib.ptr(grad_buf), 0 if grad_buf is None else grad_buf.numel())
+            # the loss reduction is one workgroup; it also zeroes the per-face point counters of the backward's binning
+            # pass, which spares the backward a fill launch (used once: a second backward allocates its own)
+            bins = None
+            if ctx.needs_input_grad[0] and b * nf <= _CLEAR_IN_FORWARD_MAX:
+                bins = torch.empty(L.geom_surface_bin_count_words(b, nf), dtype=torch.int32, device=dev)
+            clear = (_lib.ptr(bins), 0 if bins is None else bins.numel())     # int32 zero == float zero bits
             if two_sided:
                 _lib.call("geom_sum2_f32", sq_pred.numel(), sq_pred.data_ptr(), scale / sq_pred.numel(),
                           sq_gt.numel(), sq_gt.data_ptr(), scale / sq_gt.numel(), out.data_ptr(), *clear)
@@ -209,7 +233,7 @@ class SurfaceLoss(torch.autograd.Function):
                 _lib.call("geom_sum2_f32", sq_pred.numel(), sq_pred.data_ptr(), scale / sq_pred.numel(),
                           sq.numel(), sq.data_ptr(), scale / sq.numel(), out.data_ptr(), *clear)
                 ctx.save_for_backward(faces, choices, u, v, points, gt_c, idx_g, index, closest, weights)
-            ctx.grad_buf = grad_buf
+            ctx.bins = bins
         ctx.two_sided, ctx.scale, ctx.nv = two_sided, scale, nv
         ctx.mark_non_differentiable(sq_gt, sq_pred)
         ctx.set_materialize_grads(False)    # no zero tensors (two fill launches) for the two distance outputs
@@ -223,23 +247,22 @@ class SurfaceLoss(torch.autograd.Function):
         n_gt, nf, nv = gt.shape[1], faces.shape[0], ctx.nv
         dev = points.device
         grad = grad.contiguous()
-        grad_verts, ctx.grad_buf = ctx.grad_buf, None     # zeroed by the forward's reduction launch
-        if grad_verts is None:
-            grad_verts = torch.zeros(b, nv, 3, dtype=torch.float32, device=dev)
+        counts, ctx.bins = ctx.bins, None                 # zeroed by the forward's reduction launch
+        if counts is None:
+            counts = torch.zeros(_lib.lib().geom_surface_bin_count_words(b, nf), dtype=torch.int32, device=dev)
+        vf_ptr, vf_item = vertex_faces(faces, nv)
+        lists = torch.empty(_lib.lib().geom_surface_bin_list_words(b, nf, num, n_gt), dtype=torch.int32, device=dev)
+        grad_verts = torch.empty(b, nv, 3, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            sample_args = (b, nv, nf, faces.data_ptr(), num, choices.data_ptr(), u.data_ptr(), v.data_ptr(),
-                           points.data_ptr(), n_gt, gt.data_ptr())
-            if not ctx.two_sided:   # both terms scatter (atomics) into the same zeroed buffer, one launch
-                index, closest, weights = saved[7:10]
-                _lib.call("geom_surface_loss_bwd_f32", b, nv, nf, faces.data_ptr(), num, choices.data_ptr(), u.data_ptr(),
-                          v.data_ptr(), points.data_ptr(), n_gt, gt.data_ptr(), saved[6].data_ptr(), index.data_ptr(),
-                          closest.data_ptr(), weights.data_ptr(), grad.data_ptr(), ctx.scale / (b * num),
-                          ctx.scale / (b * n_gt), grad_verts.data_ptr())
+            if ctx.two_sided:
+                idx_p, index, closest, weights, coef_other = saved[7], None, None, None, ctx.scale / (b * n_gt)
             else:
-                _lib.call("geom_sample_chamfer_bwd_f32", *sample_args, saved[6].data_ptr(), 0, grad.data_ptr(),
-                          ctx.scale / (b * num), grad_verts.data_ptr())
-                _lib.call("geom_sample_chamfer_bwd_f32", *sample_args, saved[7].data_ptr(), 1, grad.data_ptr(),
-                          ctx.scale / (b * n_gt), grad_verts.data_ptr())
+                idx_p, (index, closest, weights), coef_other = None, saved[7:10], ctx.scale / (b * n_gt)
+            _lib.call("geom_surface_loss_bwd_gather_f32", b, nv, nf, vf_ptr.data_ptr(), vf_item.data_ptr(), num,
+                      choices.data_ptr(), u.data_ptr(), v.data_ptr(), points.data_ptr(), n_gt, gt.data_ptr(),
+                      saved[6].data_ptr(), _lib.ptr(idx_p), _lib.ptr(index), _lib.ptr(closest), _lib.ptr(weights),
+                      grad.data_ptr(), ctx.scale / (b * num), coef_other, counts.data_ptr(), lists.data_ptr(),
+                      grad_verts.data_ptr())
         return grad_verts, None, None, None, None, None, None, None, None
 
 

@@ -182,6 +182,23 @@ int geom_surface_loss_bwd_f32(int b, int nv, int nf, const int64_t *faces, int n
                               const int *idx_g, const int *index, const float *closest, const float *weights,
                               const float *coef_dev, float coef_sample, float coef_tri, float *grad_verts,
                               void *stream);
+/* The same backward (and that of batch_point_to_point) as a GATHER: no float atomics, no zero-fill of grad_verts,
+ * bit-reproducible.  vf_ptr [nv+1] / vf_item [3*nf] = static CSR vertex -> incident (face << 2 | corner), ascending
+ * per vertex.  Exactly one of idx_p ([b,n_gt] nearest sampled point of each gt point: the two-sided Chamfer term)
+ * and index (+ closest, weights: the point-to-triangle term) may be given, or neither (sampled-point term only).
+ * counts: geom_surface_bin_count_words(b, nf) int32, MUST BE ZERO on entry (left holding the per-face point counts);
+ * lists: geom_surface_bin_list_words(b, nf, num, n_gt) int32 scratch, 16-byte aligned (16 slots per face, a per-mesh
+ * overflow list and two float4 records per point; faces
+ * beyond both are summed by an ordered scan of the mesh's points -- exact in every case).  Every element of
+ * grad_verts [b,nv,3] is written. */
+int64_t geom_surface_bin_count_words(int b, int nf);
+int64_t geom_surface_bin_list_words(int b, int nf, int num, int n_gt);
+int geom_surface_loss_bwd_gather_f32(int b, int nv, int nf, const int *vf_ptr, const int *vf_item, int num,
+                                     const int64_t *choices, const float *u, const float *v, const float *points,
+                                     int n_gt, const float *gt, const int *idx_g, const int *idx_p, const int *index,
+                                     const float *closest, const float *weights, const float *coef_dev,
+                                     float coef_sample, float coef_other, int *counts, int *lists, float *grad_verts,
+                                     void *stream);
 
 /* ---- 0N-GCN aggregation (layers.py:34-41, 107-116, 143-152) -----------------------------------
  * out[r,:k] = sum_j val[j]*support[col[j],:k] over CSR row r (rowptr int32 [nv+1], col int32, val f32),

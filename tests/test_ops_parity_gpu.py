@@ -478,3 +478,50 @@ def test_relu_sign_mask_backward_equals_the_output_based_one(gpu):
     ref = torch.relu(torch.cat((adj @ (x2 @ layer.weight1[0])[..., :k], (x2 @ layer.weight1[0])[..., k:]), -1) + layer.bias)
     ref.backward(g)
     assert torch.allclose(x.grad, x2.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("two_sided", [False, True])
+@pytest.mark.parametrize("crowded", [0.0, 0.05, 0.9])
+def test_gather_backward_matches_the_atomic_scatter_and_is_reproducible(gpu, two_sided, crowded):
+    """The surface-loss backward (bin by face + per-vertex gather) against the scatter kernels it replaced, called
+    through the C ABI on a zeroed buffer.  crowded = share of the samples moved onto 3 faces: 0.05 overflows the
+    8-slot lists into the per-mesh overflow list (ordered extraction), 0.9 makes the ordered scan of all points the
+    cheaper route.  Two runs of the gather give identical bits (fixed summation order)."""
+    from geometrics_amd import _lib as L
+    V, Fc = meshgen.icosphere(2)
+    B, num, n_gt = 2, 600, 500
+    verts = dev(meshgen.jittered_batch(V, B), gpu).requires_grad_(True)
+    faces, gt = dev(Fc, gpu), dev(meshgen.gt_cloud(B, n_gt), gpu)
+    ops.manual_seed(11)
+    choices, u, v = ops.draw_samples(verts, faces, num)
+    if crowded:
+        choices = torch.where(torch.rand(B, num, device=gpu) < crowded, choices % 3, choices)
+    grads = []
+    for _ in range(2):
+        verts.grad = None
+        loss, _, _ = ops.SurfaceLoss.apply(verts, faces, gt, choices, u, v, two_sided, 3000.0)
+        loss.backward()
+        grads.append(verts.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    # the scatter formulation on the same saved quantities
+    outs = ops.SurfaceLoss.apply(verts, faces, gt, choices, u, v, two_sided, 3000.0)
+    saved = outs[0].grad_fn.saved_tensors
+    points, idx_g = saved[4], saved[6]
+    ref = torch.zeros(B, V.shape[0], 3, device=gpu)
+    one = torch.ones((), device=gpu)
+    args = (B, V.shape[0], Fc.shape[0], faces.data_ptr(), num, choices.data_ptr(), u.data_ptr(), v.data_ptr(),
+            points.data_ptr(), n_gt, gt.data_ptr())
+    L.call("geom_sample_chamfer_bwd_f32", *args, idx_g.data_ptr(), 0, one.data_ptr(), 3000.0 / (B * num), ref.data_ptr())
+    if two_sided:
+        L.call("geom_sample_chamfer_bwd_f32", *args, saved[7].data_ptr(), 1, one.data_ptr(), 3000.0 / (B * n_gt),
+               ref.data_ptr())
+    else:
+        index, closest, weights = saved[7:10]
+        L.call("geom_p2tri_loss_bwd_f32", B, n_gt, gt.data_ptr(), V.shape[0], Fc.shape[0], faces.data_ptr(), index.data_ptr(),
+               closest.data_ptr(), weights.data_ptr(), one.data_ptr(), 3000.0 / (B * n_gt), ref.data_ptr())
+    assert torch.allclose(grads[0], ref, rtol=2e-5, atol=2e-6 * float(ref.abs().max()))
+    # vertex -> incident faces table: every (face, corner) exactly once, under its vertex
+    vf_ptr, vf_item = ops.vertex_faces(faces, V.shape[0])
+    owner = torch.repeat_interleave(torch.arange(V.shape[0], device=gpu), (vf_ptr[1:] - vf_ptr[:-1]).long())
+    assert torch.equal(faces[(vf_item >> 2).long(), (vf_item & 3).long()], owner)
+    assert sorted((vf_item.long() >> 2) * 3 + (vf_item.long() & 3)) == list(range(3 * Fc.shape[0]))
