@@ -28,6 +28,7 @@ _SIGNATURES = {
     "geom_tri_distance_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp],
     "geom_tri_distance_indexed_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _u, _vp],
     "geom_tri_distance_ws_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp, ctypes.c_size_t, _vp],
+    "geom_tri_surface_fwd_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp, ctypes.c_size_t, _vp],
     "geom_tri_distance_indexed_ws_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp, ctypes.c_size_t, _vp],
     "geom_face_areas_f32": [_i, _i, _vp, _i, _vp, _vp, _vp],
     "geom_draw_samples_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],

@@ -290,49 +290,6 @@ struct P2TArgs {
     int b, n, nv, nf;
 };
 
-// Closest point of calc_point_to_line (utils.py:506-550): the SELECTED candidate only,
-// with its affine weights on (A,B,C).  Option 6 walks along CA here (utils.py:543) -- the
-// kernel-side Q2 quirk only influences which triangle won.
-__device__ __forceinline__ V3 closest_on_triangle(V3 p, V3 A, V3 B, V3 C, int opt, V3 &w)
-{
-    if (opt == 1) { w = geom::mk(1.f, 0.f, 0.f); return A; }
-    if (opt == 2) { w = geom::mk(0.f, 1.f, 0.f); return B; }
-    if (opt == 3) { w = geom::mk(0.f, 0.f, 1.f); return C; }
-    if (opt == 4) {
-        const V3 d = B - A;
-        const float t = geom::dot3(p - A, d) / geom::dot3(d, d);
-        w = geom::mk(1.f - t, t, 0.f);
-        return A + d * t;
-    }
-    if (opt == 5) {
-        const V3 d = C - B;
-        const float t = geom::dot3(p - B, d) / geom::dot3(d, d);
-        w = geom::mk(0.f, 1.f - t, t);
-        return B + d * t;
-    }
-    if (opt == 6) {
-        const V3 d = A - C;
-        const float t = geom::dot3(p - C, d) / geom::dot3(d, d);
-        w = geom::mk(t, 0.f, 1.f - t);
-        return C + d * t;
-    }
-    // plane projection (Plane.Project, utils.py:573-587): n = N / sqrt(sum N^2)
-    const V3 N = geom::cross3(A - B, A - C);
-    const float len = sqrtf(geom::dot3(N, N));
-    const V3 n = geom::mk(N.x / len, N.y / len, N.z / len);
-    const float h = geom::dot3(p - A, n);
-    const V3 q = p - n * h;
-    // affine weights of q: q - A = s (B-A) + t (C-A), 2x2 normal equations
-    const V3 e1 = B - A, e2 = C - A, r = q - A;
-    const float a11 = geom::dot3(e1, e1), a12 = geom::dot3(e1, e2), a22 = geom::dot3(e2, e2);
-    const float b1 = geom::dot3(r, e1), b2 = geom::dot3(r, e2);
-    const float det = a11 * a22 - a12 * a12;
-    const float s = (b1 * a22 - b2 * a12) / det;
-    const float t = (b2 * a11 - b1 * a12) / det;
-    w = geom::mk(1.f - s - t, s, t);
-    return q;
-}
-
 __global__ __launch_bounds__(PT_THREADS) void p2tri_fwd_kernel(P2TArgs a, float *sqdist, float *closest,
                                                                 float *weights)
 {
@@ -346,7 +303,7 @@ __global__ __launch_bounds__(PT_THREADS) void p2tri_fwd_kernel(P2TArgs a, float 
     const V3 C = ld3(V + 3 * a.faces[3 * f + 2]);
     const V3 p = ld3(a.xyz + 3 * i);
     V3 w;
-    const V3 q = closest_on_triangle(p, A, B, C, a.option[i], w);
+    const V3 q = geom::closest_on_triangle(p, A, B, C, a.option[i], w);
     const V3 d = q - p;
     sqdist[i] = geom::dot3(d, d);
     if (closest) {

@@ -693,6 +693,15 @@ constexpr int HS_QA = 16 + 4 * GEOM_WAVE;        // (query, group) items per wav
 constexpr int HS_QB = 2 * GEOM_WAVE;             // (query, slot) items per wave
 constexpr unsigned INF_BITS = 0x7f800000u;
 
+// optional epilogue of the grouped scan: the point-to-surface quantities of the winning triangle (what
+// geom_p2tri_loss_fwd_f32 computes in a launch of its own), INDEXED jobs only
+struct SurfaceOut {
+    const float *verts;
+    const int64_t *faces;
+    int nv;
+    float *sqdist, *closest, *weights; // [b,n], [b,n,3], [b,n,3]; sqdist == null: no epilogue
+};
+
 struct TriGws {
     float4 *sph;   // [b][m_pad]     member spheres, slot order
     float4 *cor;   // [b][m_pad][3]  corners; cor[3j].w = original triangle index (int bits), -1 = padding
@@ -767,7 +776,8 @@ __global__ __launch_bounds__(256) void tri_prep_grouped_kernel(TriJob job, TriGw
 template <bool TRUNC, bool FIX6>
 __global__ __launch_bounds__(HS_THREADS) void tri_scan_grouped_kernel(const float *__restrict__ xyz, int b, int n, int m,
                                                                        TriGws ws, float *__restrict__ dist,
-                                                                       int *__restrict__ point, int *__restrict__ index)
+                                                                       int *__restrict__ point, int *__restrict__ index,
+                                                                       SurfaceOut surf)
 {
     __shared__ float4 gtile[HS_GCHUNK];
     __shared__ unsigned long long qbest[TRI_QUERIES]; // best evaluated (distance, triangle, region)
@@ -988,18 +998,32 @@ __global__ __launch_bounds__(HS_THREADS) void tri_scan_grouped_kernel(const floa
         dist[o] = acc_d;
         point[o] = acc_k & 7;
         index[o] = acc_k >> 3;
+        if (surf.sqdist) { // point-to-surface epilogue (calc_point_to_line on the winner, utils.py:506-550)
+            const float *V = surf.verts + (size_t)mesh * surf.nv * 3;
+            const int64_t f = acc_k >> 3;
+            const V3 A = load3(V + 3 * surf.faces[3 * f + 0]);
+            const V3 B = load3(V + 3 * surf.faces[3 * f + 1]);
+            const V3 C = load3(V + 3 * surf.faces[3 * f + 2]);
+            V3 w;
+            const V3 hit = geom::closest_on_triangle(p, A, B, C, acc_k & 7, w);
+            const V3 d = hit - p;
+            surf.sqdist[o] = geom::dot3(d, d);
+            surf.closest[3 * o + 0] = hit.x, surf.closest[3 * o + 1] = hit.y, surf.closest[3 * o + 2] = hit.z;
+            surf.weights[3 * o + 0] = w.x, surf.weights[3 * o + 1] = w.y, surf.weights[3 * o + 2] = w.z;
+        }
     }
 }
 
 template <bool INDEXED, bool TRUNC, bool FIX6>
-int launch_grouped_variant(const TriJob &job, const TriGws &ws, const int *order, hipStream_t s)
+int launch_grouped_variant(const TriJob &job, const TriGws &ws, const int *order, hipStream_t s, const SurfaceOut &surf)
 {
     const int prep_items = ws.split > 1 && job.n > ws.m_pad ? job.n : ws.m_pad;
     hipLaunchKernelGGL((tri_prep_grouped_kernel<INDEXED, TRUNC, FIX6>), dim3((prep_items + 255) / 256, job.b), dim3(256), 0, s,
                        job, ws, order);
     const int qtiles = (job.n + TRI_QUERIES - 1) / TRI_QUERIES;
     hipLaunchKernelGGL((tri_scan_grouped_kernel<TRUNC, FIX6>), dim3(geom::xcd_grid(job.b, qtiles * ws.split)),
-                       dim3(HS_THREADS), 0, s, job.xyz, job.b, job.n, job.m, ws, job.dist, job.point, job.index);
+                       dim3(HS_THREADS), 0, s, job.xyz, job.b, job.n, job.m, ws, job.dist, job.point, job.index,
+                       ws.split > 1 ? SurfaceOut{nullptr, nullptr, 0, nullptr, nullptr, nullptr} : surf);
     if (ws.split > 1)
         hipLaunchKernelGGL((tri_finalize_kernel<TRUNC, FIX6>), dim3((job.n + 255) / 256, job.b), dim3(256), 0, s, job.xyz,
                            job.n, job.m, ws.first, (size_t)3, ws.keys, job.dist, job.point, job.index);
@@ -1028,9 +1052,12 @@ inline size_t ws_bytes_needed(int b, int n, int m_pad)
            (size_t)b * n * 8;
 }
 
+// *fused = whether the scan wrote the point-to-surface outputs itself (else the caller launches the separate kernel)
 template <bool INDEXED>
-int launch_tri_ws(const TriJob &job, const int *order, unsigned flags, void *workspace, size_t ws_bytes, void *stream)
+int launch_tri_ws(const TriJob &job, const int *order, unsigned flags, void *workspace, size_t ws_bytes, void *stream,
+                  const SurfaceOut &surf = SurfaceOut{nullptr, nullptr, 0, nullptr, nullptr, nullptr}, bool *fused = nullptr)
 {
+    if (fused) *fused = false;
     const int m_pad = ws_pad(job.m);
     if (!workspace || ws_bytes < ws_bytes_needed(job.b, job.n, m_pad) || ((uintptr_t)workspace & 15)) return GEOM_EINVAL;
     float4 *base = static_cast<float4 *>(workspace);
@@ -1041,10 +1068,11 @@ int launch_tri_ws(const TriJob &job, const int *order, unsigned flags, void *wor
                    m_pad, ws_split(job.b, job.n, m_pad)};
         hipStream_t gs = static_cast<hipStream_t>(stream);
         const bool gtrunc = flags & GEOM_FLAG_REF_TAIL_TRUNC, gfix6 = flags & GEOM_FLAG_FIX_REGION6;
-        if (gtrunc && gfix6) return launch_grouped_variant<INDEXED, true, true>(job, gws, order, gs);
-        if (gtrunc) return launch_grouped_variant<INDEXED, true, false>(job, gws, order, gs);
-        if (gfix6) return launch_grouped_variant<INDEXED, false, true>(job, gws, order, gs);
-        return launch_grouped_variant<INDEXED, false, false>(job, gws, order, gs);
+        if (fused) *fused = gws.split == 1 && surf.sqdist != nullptr;
+        if (gtrunc && gfix6) return launch_grouped_variant<INDEXED, true, true>(job, gws, order, gs, surf);
+        if (gtrunc) return launch_grouped_variant<INDEXED, true, false>(job, gws, order, gs, surf);
+        if (gfix6) return launch_grouped_variant<INDEXED, false, true>(job, gws, order, gs, surf);
+        return launch_grouped_variant<INDEXED, false, false>(job, gws, order, gs, surf);
     }
     TriWs ws{base, base + (size_t)job.b * m_pad, reinterpret_cast<unsigned long long *>(base + (size_t)job.b * m_pad * 4),
              m_pad, ws_split(job.b, job.n, m_pad)};
@@ -1147,4 +1175,26 @@ extern "C" int geom_tri_distance_indexed_ws_f32(int b, int n, const float *xyz, 
     TriJob job{xyz, nullptr, nullptr, nullptr, verts, faces, dist, point, index, b, n, nf, nv};
     if (flags & GEOM_FLAG_TRI_BRUTE_FORCE) return launch_tri<true>(job, flags, stream);
     return launch_tri_ws<true>(job, order, flags, workspace, workspace_bytes, stream);
+}
+
+// tri_distance + the point-to-surface quantities of the winner in one call: the two-level scan writes them from its
+// epilogue; the other scans (no order, brute force, split query tiles) are followed by the separate kernel.
+extern "C" int geom_tri_surface_fwd_f32(int b, int n, const float *xyz, int nv, const float *verts, int nf,
+                                        const int64_t *faces, const int *order, float *dist, int *point, int *index,
+                                        float *sqdist, float *closest, float *weights, unsigned flags, void *workspace,
+                                        size_t workspace_bytes, void *stream)
+{
+    if (b < 0 || n < 0 || nf < 0 || nv < 0) return GEOM_EINVAL;
+    if (b == 0 || n == 0) return 0;
+    if (nf == 0 || nv == 0) return GEOM_EINVAL;
+    if (!xyz || !verts || !faces || !dist || !point || !index || !sqdist || !closest || !weights) return GEOM_EINVAL;
+    if (b > 65535 || nf >= (1 << 26)) return GEOM_ETOOBIG;
+    TriJob job{xyz, nullptr, nullptr, nullptr, verts, faces, dist, point, index, b, n, nf, nv};
+    bool fused = false;
+    int rc;
+    if (flags & GEOM_FLAG_TRI_BRUTE_FORCE) rc = launch_tri<true>(job, flags, stream);
+    else rc = launch_tri_ws<true>(job, order, flags, workspace, workspace_bytes, stream,
+                                  SurfaceOut{verts, faces, nv, sqdist, closest, weights}, &fused);
+    if (rc != 0 || fused) return rc;
+    return geom_p2tri_loss_fwd_f32(b, n, xyz, nv, verts, nf, faces, point, index, sqdist, closest, weights, stream);
 }

@@ -206,13 +206,12 @@ class SurfaceLoss(torch.autograd.Function):
                 # (An earlier version ran this branch beside sampling + NN on a second stream.  Inside a captured graph
                 # every fork/join edge costs 5-10 us of dependency latency, and the two scans then share the CUs' LDS
                 # and issue slots: measured 0.567 ms/step forked vs 0.551 ms/step in line.)
-                _lib.check(L.geom_tri_distance_indexed_ws_f32(
+                # tri scan + the closest point / weights / squared distance of the winner, one call (one launch with
+                # the two-level scan)
+                _lib.check(L.geom_tri_surface_fwd_f32(
                     b, n_gt, gt_c.data_ptr(), nv, verts_c.data_ptr(), nf, faces.data_ptr(), _lib.ptr(order), tri_d.data_ptr(),
-                    option.data_ptr(), index.data_ptr(), 0, ws.data_ptr(), ws_bytes, _lib.stream_ptr()),
-                    "geom_tri_distance_indexed_ws_f32")
-                _lib.call("geom_p2tri_loss_fwd_f32", b, n_gt, gt_c.data_ptr(), nv, verts_c.data_ptr(), nf,
-                          faces.data_ptr(), option.data_ptr(), index.data_ptr(), sq.data_ptr(),
-                          closest.data_ptr(), weights.data_ptr())
+                    option.data_ptr(), index.data_ptr(), sq.data_ptr(), closest.data_ptr(), weights.data_ptr(), 0,
+                    ws.data_ptr(), ws_bytes, _lib.stream_ptr()), "geom_tri_surface_fwd_f32")
             if not have_points:
                 _lib.call("geom_sample_faces_fwd_f32", b, nv, verts_c.data_ptr(), nf, faces.data_ptr(), num,
                           choices.data_ptr(), u.data_ptr(), v.data_ptr(), points.data_ptr())

@@ -96,6 +96,14 @@ int geom_tri_distance_indexed_ws_f32(int b, int n, const float *xyz, int nv, con
                                      float *dist, int *point, int *index, unsigned flags,
                                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* geom_tri_distance_indexed_ws_f32 followed by geom_p2tri_loss_fwd_f32 on its result (the gt-side half of
+ * batch_point_to_surface, utils.py:464-481) as ONE call: with a coherent `order` the two-level scan writes sqdist /
+ * closest / weights from its own epilogue and no second launch happens. */
+int geom_tri_surface_fwd_f32(int b, int n, const float *xyz, int nv, const float *verts, int nf,
+                             const int64_t *faces, const int *order, float *dist, int *point, int *index,
+                             float *sqdist, float *closest, float *weights, unsigned flags, void *workspace,
+                             size_t workspace_bytes, void *stream);
+
 /* ---- differentiable face sampling (utils.py:590-633) -------------------------------------
  * areas[b,nf] = 0.5*|(v0-v1) x (v1-v2)|, the un-normalised multinomial weights (utils.py:596-602). */
 int geom_face_areas_f32(int b, int nv, const float *verts, int nf, const int64_t *faces,

@@ -525,3 +525,36 @@ def test_gather_backward_matches_the_atomic_scatter_and_is_reproducible(gpu, two
     owner = torch.repeat_interleave(torch.arange(V.shape[0], device=gpu), (vf_ptr[1:] - vf_ptr[:-1]).long())
     assert torch.equal(faces[(vf_item >> 2).long(), (vf_item & 3).long()], owner)
     assert sorted((vf_item.long() >> 2) * 3 + (vf_item.long() & 3)) == list(range(3 * Fc.shape[0]))
+
+
+def test_tri_surface_fused_call_equals_scan_plus_point_to_triangle(gpu):
+    """geom_tri_surface_fwd_f32 (scan epilogue writes sqdist / closest / weights) against the two separate entry
+    points, for the two-level scan (fused), the flat scan, the brute-force scan and a single mesh (split query tiles:
+    the epilogue is replaced by the separate kernel) -- bitwise."""
+    from geometrics_amd import _lib as L
+    from geometrics_amd.tri_distance import face_order
+    V, Fc = meshgen.icosphere(3)
+    faces = dev(Fc, gpu)
+    for B, n in ((3, 700), (1, 300)):
+        verts, pts = dev(meshgen.jittered_batch(V, B), gpu), dev(meshgen.gt_cloud(B, n), gpu)
+        order = face_order(verts, faces)
+        ws_bytes = L.lib().geom_tri_distance_workspace_bytes(B, n, Fc.shape[0])
+        ws = torch.empty(ws_bytes // 4 + 4, device=gpu)
+        f32 = dict(dtype=torch.float32, device=gpu)
+        i32 = dict(dtype=torch.int32, device=gpu)
+        d0, p0, i0 = torch.empty(B, n, **f32), torch.empty(B, n, **i32), torch.empty(B, n, **i32)
+        L.check(L.lib().geom_tri_distance_indexed_ws_f32(B, n, pts.data_ptr(), V.shape[0], verts.data_ptr(), Fc.shape[0],
+                                                         faces.data_ptr(), order.data_ptr(), d0.data_ptr(), p0.data_ptr(),
+                                                         i0.data_ptr(), 0, ws.data_ptr(), ws_bytes, L.stream_ptr()), "scan")
+        s0, c0, w0 = torch.empty(B, n, **f32), torch.empty(B, n, 3, **f32), torch.empty(B, n, 3, **f32)
+        L.call("geom_p2tri_loss_fwd_f32", B, n, pts.data_ptr(), V.shape[0], verts.data_ptr(), Fc.shape[0], faces.data_ptr(),
+               p0.data_ptr(), i0.data_ptr(), s0.data_ptr(), c0.data_ptr(), w0.data_ptr())
+        for order_ptr, flags in ((order.data_ptr(), 0), (None, 0), (order.data_ptr(), 4)):
+            d, p, i = torch.empty(B, n, **f32), torch.empty(B, n, **i32), torch.empty(B, n, **i32)
+            s, c, w = torch.empty(B, n, **f32), torch.empty(B, n, 3, **f32), torch.empty(B, n, 3, **f32)
+            L.check(L.lib().geom_tri_surface_fwd_f32(B, n, pts.data_ptr(), V.shape[0], verts.data_ptr(), Fc.shape[0],
+                                                     faces.data_ptr(), order_ptr, d.data_ptr(), p.data_ptr(), i.data_ptr(),
+                                                     s.data_ptr(), c.data_ptr(), w.data_ptr(), flags, ws.data_ptr(), ws_bytes,
+                                                     L.stream_ptr()), "fused")
+            for got, want in ((d, d0), (p, p0), (i, i0), (s, s0), (c, c0), (w, w0)):
+                assert torch.equal(got.view(torch.int32), want.view(torch.int32))
