@@ -226,6 +226,8 @@ def kernel_rooflines(w):
     agg_bytes = 2 * b * w.nv * HID * 4 + csr.nnz * 12 + (w.nv + 1) * 4
     agg_gbs = agg_bytes / (t_agg * 1e-6) / 1e9
     tri_bytes = b * (G_PTS * 12 + w.nv * 12 + w.nf * 24 + G_PTS * 12)     # points + verts + faces(int64) + 3 outputs
+    # (inside the loss the scan's epilogue also writes the point-to-surface record of every point, 28 B each; the
+    # PMC traffic figure comes from that fused launch)
     # algorithmic work of the point-to-triangle scan = every (point, triangle) pair at 60 flop (hoisted
     # count of the reference's decision tree).  The two-level scan EXECUTES a small fraction of it (group spheres,
     # then member spheres, then a few tens of literal evaluations per point), so the algorithmic rate can exceed the
@@ -254,10 +256,10 @@ def kernel_rooflines(w):
                         "hierarchy skips ~95 % of the pair evaluations, hence frac > 1 is not a utilisation -- see "
                         "`executed`.  flat_scan_us = the one-level culled scan (order=None) on the same inputs"}
     others = {
-        "chamfer_nn_kernel": {"bound": "mfma", "pipe": "fp32 VALU, un-fused", "achieved": round(nn_tflops, 3),
+        "chamfer_nn_scalar_kernel": {"bound": "mfma", "pipe": "fp32 VALU, un-fused (brute force: algorithmic == executed pairs)", "achieved": round(nn_tflops, 3),
                               "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(nn_tflops / FP32_PEAK_TFLOPS, 4),
                               "launch_us": round(t_nn, 1), "pairs_per_launch": nn_pairs, "flop_per_pair": NN_FLOP_PER_PAIR,
-                              "traffic": pmc_traffic_bytes("chamfer_nn_kernel")},
+                              "traffic": pmc_traffic_bytes("chamfer_nn_scalar_kernel")},
         "zn_aggregate_kernel": {"bound": "hbm", "achieved": round(agg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(agg_gbs / HBM_PEAK_GBS, 4), "launch_us": round(t_agg, 1),
                                 "algorithmic_bytes_per_launch": agg_bytes,
