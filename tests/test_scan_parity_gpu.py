@@ -316,3 +316,30 @@ def test_tri_two_level_scan_multi_chunk_meshes(oracle_mod, gpu, level, npts, b):
     np.testing.assert_array_equal(i[:1, :100].cpu().numpy(), ei)
     np.testing.assert_array_equal(p[:1, :100].cpu().numpy(), ep)
     np.testing.assert_array_equal(d[:1, :100].cpu().numpy().view(np.uint32), ed.view(np.uint32))
+
+
+def test_large_point_sets_are_exact(gpu):
+    """Sizes far beyond the configs (65 536 queries x 100 000 targets; 100 000 points x 5120 faces): the NN result is
+    checked against a chunked torch evaluation of the SAME un-fused arithmetic -- distances bitwise, index = the first
+    target attaining the minimum -- and the tri scans (two-level, flat, brute force) against each other."""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    a = (torch.rand(1, 65536, 3, generator=g) - 0.5).to(gpu)
+    b = (torch.rand(1, 100000, 3, generator=g) - 0.5).to(gpu)
+    b[0, 70000:70050] = b[0, 10:60]                                  # exact duplicates: ties go to the lower index
+    d1, i1, d2, i2 = chamfer_nn(a, b)
+    for q, t, d, i in ((a[0], b[0], d1[0], i1[0]), (b[0], a[0], d2[0], i2[0])):
+        for s in range(0, q.shape[0], 8192):
+            qq = q[s:s + 8192]
+            dx, dy, dz = (t[None, :, k] - qq[:, None, k] for k in range(3))
+            dist = (dx * dx + dy * dy) + dz * dz                     # same operation order, elementwise = un-fused
+            best = dist.min(dim=1)[0]
+            first = (dist == best[:, None]).float().argmax(dim=1)
+            assert torch.equal(best.view(torch.int32), d[s:s + 8192].view(torch.int32))
+            assert torch.equal(first.int(), i[s:s + 8192])
+    V, F = meshgen.icosphere(4)
+    verts, faces = _dev(meshgen.jittered_batch(V, 1), gpu), _dev(F, gpu)
+    pts = (torch.rand(1, 100000, 3, generator=g) - 0.5).to(gpu)
+    ref = tri_distance_indexed(pts, verts, faces, FLAG_TRI_BRUTE_FORCE)
+    for kw in (dict(), dict(order=None)):
+        got = tri_distance_indexed(pts, verts, faces, **kw)
+        assert all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(got, ref))
