@@ -685,9 +685,10 @@ int launch_ws_variant(const TriJob &job, const TriWs &ws, hipStream_t s)
 // of 5120 member tests; with an incoherent order the group spheres are useless (every group survives) and
 // the flat kernel above is the better choice -- which is why the hierarchy is opt-in through `order`.
 constexpr int GRP = 16;
-constexpr int HS_THREADS = 1024;
-constexpr int HS_WAVES = HS_THREADS / GEOM_WAVE; // 16
-static_assert(HS_WAVES == GRP, "the seed reduction maps wave w to member lane w");
+// Waves per workgroup is a template parameter: launching a wave costs ~1.5 ns chip-wide, so at the 8-mesh shard 376
+// workgroups x 16 waves spend ~9 us just starting; 8 waves per workgroup measured 35.7 us against 44.7 (4 waves: 45.0).
+// With few query tiles (one mesh) the longer per-wave chains of 8 waves cost more than the launch saves (24.5 vs 22.5 us).
+constexpr int HS_MAX_WAVES = 16;
 constexpr int HS_GCHUNK = 512;                   // group spheres staged per pass (8 KiB = 8192 triangles); LDS is shared with co-running kernels
 constexpr int HS_QA = 16 + 4 * GEOM_WAVE;        // (query, group) items per wave
 constexpr int HS_QB = 2 * GEOM_WAVE;             // (query, slot) items per wave
@@ -773,12 +774,14 @@ __global__ __launch_bounds__(256) void tri_prep_grouped_kernel(TriJob job, TriGw
     if ((j & (GRP - 1)) == 0) ws.grp[(size_t)mesh * (ws.m_pad / GRP) + j / GRP] = g;
 }
 
-template <bool TRUNC, bool FIX6>
-__global__ __launch_bounds__(HS_THREADS) void tri_scan_grouped_kernel(const float *__restrict__ xyz, int b, int n, int m,
+template <bool TRUNC, bool FIX6, int HS_WAVES>
+__global__ __launch_bounds__(HS_WAVES * GEOM_WAVE) void tri_scan_grouped_kernel(const float *__restrict__ xyz, int b, int n, int m,
                                                                        TriGws ws, float *__restrict__ dist,
                                                                        int *__restrict__ point, int *__restrict__ index,
                                                                        SurfaceOut surf)
 {
+    static_assert(HS_WAVES <= GRP, "the seed reduction maps wave w to member lane w");
+    constexpr int HS_THREADS = HS_WAVES * GEOM_WAVE;
     __shared__ float4 gtile[HS_GCHUNK];
     __shared__ unsigned long long qbest[TRI_QUERIES]; // best evaluated (distance, triangle, region)
     __shared__ unsigned long long qseed[TRI_QUERIES]; // smallest group upper bound and its group
@@ -910,9 +913,9 @@ __global__ __launch_bounds__(HS_THREADS) void tri_scan_grouped_kernel(const floa
         __syncthreads();
         // ---- A1': the 16 members of the seed group are evaluated literally, one thread per (query, member):
         //      the cull bound starts from a REAL candidate next to the query, not from a sphere estimate ----
-        {
-            const int ql = threadIdx.x >> 4, mem = threadIdx.x & (GRP - 1);
-            unsigned long long word = seed_part[mem][ql]; // HS_WAVES == GRP: lane `mem` holds wave `mem`'s candidate
+        for (int t = threadIdx.x; t < TRI_QUERIES * GRP; t += HS_THREADS) { // wave-aligned: whole 16-lane groups
+            const int ql = t >> 4, mem = t & (GRP - 1);
+            unsigned long long word = mem < HS_WAVES ? seed_part[mem][ql] : KEY_NONE; // lane `mem` holds wave `mem`'s candidate
 #pragma unroll
             for (int d = GRP / 2; d > 0; d >>= 1) {
                 const unsigned long long other = __shfl_xor(word, d);
@@ -1021,9 +1024,14 @@ int launch_grouped_variant(const TriJob &job, const TriGws &ws, const int *order
     hipLaunchKernelGGL((tri_prep_grouped_kernel<INDEXED, TRUNC, FIX6>), dim3((prep_items + 255) / 256, job.b), dim3(256), 0, s,
                        job, ws, order);
     const int qtiles = (job.n + TRI_QUERIES - 1) / TRI_QUERIES;
-    hipLaunchKernelGGL((tri_scan_grouped_kernel<TRUNC, FIX6>), dim3(geom::xcd_grid(job.b, qtiles * ws.split)),
-                       dim3(HS_THREADS), 0, s, job.xyz, job.b, job.n, job.m, ws, job.dist, job.point, job.index,
-                       ws.split > 1 ? SurfaceOut{nullptr, nullptr, 0, nullptr, nullptr, nullptr} : surf);
+    const SurfaceOut so = ws.split > 1 ? SurfaceOut{nullptr, nullptr, 0, nullptr, nullptr, nullptr} : surf;
+    const dim3 grid(geom::xcd_grid(job.b, qtiles * ws.split));
+    if ((int64_t)job.b * qtiles * ws.split >= 256) // enough workgroups to fill the chip: fewer, longer-lived waves
+        hipLaunchKernelGGL((tri_scan_grouped_kernel<TRUNC, FIX6, 8>), grid, dim3(8 * GEOM_WAVE), 0, s, job.xyz, job.b, job.n,
+                           job.m, ws, job.dist, job.point, job.index, so);
+    else
+        hipLaunchKernelGGL((tri_scan_grouped_kernel<TRUNC, FIX6, HS_MAX_WAVES>), grid, dim3(HS_MAX_WAVES * GEOM_WAVE), 0, s,
+                           job.xyz, job.b, job.n, job.m, ws, job.dist, job.point, job.index, so);
     if (ws.split > 1)
         hipLaunchKernelGGL((tri_finalize_kernel<TRUNC, FIX6>), dim3((job.n + 255) / 256, job.b), dim3(256), 0, s, job.xyz,
                            job.n, job.m, ws.first, (size_t)3, ws.keys, job.dist, job.point, job.index);
