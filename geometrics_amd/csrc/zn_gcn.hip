@@ -272,7 +272,7 @@ struct EllArgs {
 // thread -> 0.66 MB per layer at the BASELINE shard), and the backward takes relu' from those bits instead of
 // re-reading the 15.7 MB forward output: 47 -> 32 MB of traffic for the backward launch.
 template <int ACT, bool BACKWARD, int W, int NC, bool MASK = false>
-__global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a, int rows_per_block,
+__global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a, int rows_per_block, int iters,
                                                                         float *colsum_partial)
 {
     static_assert(!MASK || (ACT == ACT_RELU && NC == 2), "the sign mask is the ReLU / split-3 fast path");
@@ -280,11 +280,16 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a
     const int kg = a.k >> 2;                         // aggregated float4 groups per row
     const int j = threadIdx.x % kg;
     const int rl = threadIdx.x / kg;
-    const int r = blockIdx.x * rows_per_block + rl;
-    const bool active = rl < rows_per_block && r < a.nv;
     const int64_t mesh_row0 = (int64_t)blockIdx.y * a.nv;
     const int c0 = 4 * j;
+    // `iters` consecutive row tiles per workgroup (the backward uses 2: half the bias-gradient partials to reduce)
+    float4 csum[NC + 1]; // bias-gradient terms of this thread's columns over its rows (backward)
+#pragma unroll
+    for (int i = 0; i <= NC; ++i) csum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    for (int it = 0; it < iters; ++it) {
+    const int r = (blockIdx.x * iters + it) * rows_per_block + rl;
+    const bool active = rl < rows_per_block && r < a.nv;
     float4 own[NC + 1]; // [0] = own aggregated-slot element (backward only), [1..NC] = pass-through
 #pragma unroll
     for (int i = 0; i <= NC; ++i) own[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -371,12 +376,18 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a
         }
         if (!BACKWARD && MASK) a.mask[row * kg + j] = (unsigned short)sign_bits;
     }
+    if (BACKWARD) {
+#pragma unroll
+        for (int i = 0; i <= NC; ++i)
+            csum[i].x += own[i].x, csum[i].y += own[i].y, csum[i].z += own[i].z, csum[i].w += own[i].w;
+    }
+    } // row tiles
 
     if (BACKWARD && colsum_partial) {
         if (rl < rows_per_block) {
 #pragma unroll
             for (int i = 0; i <= NC; ++i)
-                *reinterpret_cast<float4 *>(lds_cs + rl * a.c + c0 + a.k * i) = own[i]; // zeros for inactive rows
+                *reinterpret_cast<float4 *>(lds_cs + rl * a.c + c0 + a.k * i) = csum[i]; // zeros for inactive rows
         }
         __syncthreads();
         for (int c = threadIdx.x; c < a.c; c += GCN_THREADS) {
@@ -396,21 +407,21 @@ inline bool ell_supported(int c, int k, int w)
 }
 
 template <int ACT, bool BACKWARD>
-void launch_ell_shape(const EllArgs &a, int w, dim3 grid, size_t lds, hipStream_t s, int rpb, float *partial)
+void launch_ell_shape(const EllArgs &a, int w, dim3 grid, size_t lds, hipStream_t s, int rpb, int iters, float *partial)
 {
     const dim3 block(GCN_THREADS);
     const int nc = ell_nc(a.c, a.k);
     if constexpr (ACT == ACT_RELU) {
         if (a.mask && nc == 2) {
-            if (w == 8) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 8, 2, true>), grid, block, lds, s, a, rpb, partial);
-            else hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 16, 2, true>), grid, block, lds, s, a, rpb, partial);
+            if (w == 8) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 8, 2, true>), grid, block, lds, s, a, rpb, iters, partial);
+            else hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 16, 2, true>), grid, block, lds, s, a, rpb, iters, partial);
             return;
         }
     }
-    if (w == 8 && nc == 2) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 8, 2>), grid, block, lds, s, a, rpb, partial);
-    else if (w == 16 && nc == 2) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 16, 2>), grid, block, lds, s, a, rpb, partial);
-    else if (w == 8 && nc == 9) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 8, 9>), grid, block, lds, s, a, rpb, partial);
-    else hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 16, 9>), grid, block, lds, s, a, rpb, partial);
+    if (w == 8 && nc == 2) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 8, 2>), grid, block, lds, s, a, rpb, iters, partial);
+    else if (w == 16 && nc == 2) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 16, 2>), grid, block, lds, s, a, rpb, iters, partial);
+    else if (w == 8 && nc == 9) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 8, 9>), grid, block, lds, s, a, rpb, iters, partial);
+    else hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 16, 9>), grid, block, lds, s, a, rpb, iters, partial);
 }
 
 template <bool BACKWARD>
@@ -427,15 +438,18 @@ int dispatch_ell(EllArgs a, int b, int w, int act, float *grad_bias, float *scra
         return GEOM_EINVAL;
     if (b > 65535) return GEOM_ETOOBIG;
     const int rpb = ell_rows_per_block(a.k);
-    const int chunks = (a.nv + rpb - 1) / rpb;
+    // row tiles per workgroup (measured at the BASELINE shard, us: forward 8.1 / 8.4 / 9.2 / 11.1 for 1-4 tiles --
+    // one row per thread keeps the most loads in flight; backward incl. the bias reduction 14.6 / 12.8 / 13.7 / 14.8)
+    const int iters = BACKWARD ? 2 : 1;
+    const int chunks = (a.nv + rpb * iters - 1) / (rpb * iters);
     float *partial = grad_bias ? scratch : nullptr;
     const size_t lds = (BACKWARD && partial) ? (size_t)rpb * a.c * sizeof(float) : 0;
     dim3 grid((unsigned)chunks, (unsigned)b);
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (act) {
-    case ACT_NONE: launch_ell_shape<ACT_NONE, BACKWARD>(a, w, grid, lds, s, rpb, partial); break;
-    case ACT_RELU: launch_ell_shape<ACT_RELU, BACKWARD>(a, w, grid, lds, s, rpb, partial); break;
-    case ACT_ELU: launch_ell_shape<ACT_ELU, BACKWARD>(a, w, grid, lds, s, rpb, partial); break;
+    case ACT_NONE: launch_ell_shape<ACT_NONE, BACKWARD>(a, w, grid, lds, s, rpb, iters, partial); break;
+    case ACT_RELU: launch_ell_shape<ACT_RELU, BACKWARD>(a, w, grid, lds, s, rpb, iters, partial); break;
+    case ACT_ELU: launch_ell_shape<ACT_ELU, BACKWARD>(a, w, grid, lds, s, rpb, iters, partial); break;
     default: return GEOM_EINVAL;
     }
     if (BACKWARD && partial)
