@@ -26,6 +26,7 @@ def enable(filename=TUNING_FILE):
     tun.tuning_enable(False)            # never tune here: only replay recorded selections
     tun.record_untuned_enable(False)
     try:
+        tun.write_file_on_exit(False)   # read-only use: N ranks must not rewrite the shared file when they exit
         tun.set_filename(filename)
         return bool(tun.read_file(filename))
     except Exception:                   # malformed / incompatible file: keep the default heuristic
