@@ -11,6 +11,7 @@ library-version mismatch, silently falls back to the default heuristic -- result
 either way (both are fp32 GEMMs), only the speed differs.
 """
 import os
+import tempfile
 
 import torch
 
@@ -26,8 +27,9 @@ def enable(filename=TUNING_FILE):
     tun.tuning_enable(False)            # never tune here: only replay recorded selections
     tun.record_untuned_enable(False)
     try:
-        tun.write_file_on_exit(False)   # read-only use: N ranks must not rewrite the shared file when they exit
-        tun.set_filename(filename)
+        # read-only use of the shipped file: whatever TunableOp writes when the process exits goes to a private
+        # scratch path, so N ranks never rewrite the shared selections concurrently
+        tun.set_filename(os.path.join(tempfile.gettempdir(), "geom_tunableop_%d.csv" % os.getpid()))
         return bool(tun.read_file(filename))
     except Exception:                   # malformed / incompatible file: keep the default heuristic
         tun.enable(False)
