@@ -3,11 +3,13 @@
 Every function launches on torch's current stream, allocates its outputs with torch and
 never synchronises with the host, so a whole training step can be captured in a HIP graph.
 """
+import weakref
+
 import torch
 
 from . import _lib
 from .chamfer_distance import chamfer_nn
-from .tri_distance import tri_distance_indexed
+from .tri_distance import face_order, tri_distance_indexed
 
 
 def _f32(t, name, ndim, last=None):
@@ -140,7 +142,6 @@ _vf_cache = {}   # id(faces) -> (weakref, version, nv, vf_ptr, vf_item)
 def vertex_faces(faces, nv):
     """Static CSR vertex -> incident (face << 2 | corner), ascending per vertex: what the gather backward walks.
     Built once per faces TENSOR OBJECT / in-place version / vertex count (same caching policy as the adjacency CSR)."""
-    import weakref
     key = id(faces)
     hit = _vf_cache.get(key)
     if hit is not None and hit[0]() is faces and hit[1] == faces._version and hit[2] == nv:
@@ -197,7 +198,6 @@ class SurfaceLoss(torch.autograd.Function):
         if not two_sided:
             ws_bytes = L.geom_tri_distance_workspace_bytes(b, n_gt, nf)
             ws = torch.empty(max(ws_bytes, 16) // 4, **f32)
-            from .tri_distance import face_order
             order = face_order(verts_c, faces)      # cached k-d leaf order of the faces: two-level scan
             tri_d, option, index = torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, **i32), torch.empty(b, n_gt, **i32)
             sq, closest, weights = torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, 3, **f32), torch.empty(b, n_gt, 3, **f32)

@@ -1,7 +1,6 @@
 """CPU: pin the oracle against the golden vectors the REFERENCE produced
 (tests/golden/make_golden.py) and, when it is present, against the reference's own
 nnsearch binary (oracle/_ref)."""
-import os
 
 import numpy as np
 import pytest

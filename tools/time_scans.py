@@ -1,6 +1,5 @@
 """Dev helper: HIP-event timing of the two arg-min scans at the BASELINE shard (B meshes)."""
 import sys
-import numpy as np
 import torch
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
