@@ -213,6 +213,51 @@ def make_sampling_and_losses():
          ref_sqdist=np.asarray(per_point, np.float32))
 
 
+# --------------------------------- independent pin of the tri scan (legacy Eberly regions) ----
+def legacy_point_to_line():
+    """The reference's OTHER point-to-triangle implementation: old_GEOMetrics/utils.py:734-1026 `point_to_line`
+    (Eberly's region formulation, vectorised over all (point, face) pairs; returns the MEAN over points of the
+    per-point minimum squared distance).  The legacy module as a whole does not import under python 3, so the
+    function is compiled from the reference file where it lies, by line range (same recipe as
+    oracle/build_ref.sh); nothing of it is written to the repo."""
+    path = os.path.join(REF, "old_GEOMetrics", "utils.py")
+    with open(path) as f:
+        lines = f.readlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith("def point_to_line("))
+    end = next(i for i in range(start + 1, len(lines)) if lines[i].startswith("def "))
+    assert (start + 1, end) == (734, 1027), (start + 1, end)
+    scope = {"torch": torch, "np": np}
+    exec(compile("".join(lines[start:end]), path, "exec"), scope)
+    return scope["point_to_line"]
+
+
+def true_min_sqdist(fn, verts, faces, points):
+    """Per-point minimum squared distance to the mesh from the legacy function, in float64, one point per call (a
+    call returns the mean over its points, so one point per call isolates that point's minimum)."""
+    v, f = torch.from_numpy(verts.astype(np.float64)), torch.from_numpy(faces.astype(np.int64))
+    pts = torch.from_numpy(points.astype(np.float64))
+    return np.array([float(fn(v, f, pts[j:j + 1])) for j in range(pts.shape[0])])
+
+
+def make_tri_true():
+    """tri_true_*.npz: what the arg-min of tri_distance.cu has to agree with -- the exact point-to-mesh squared
+    distance of every query point, from an implementation that shares no code or structure with the kernel."""
+    fn = legacy_point_to_line()
+    V2, F2 = meshgen.icosphere(2)
+    V4, F4 = meshgen.icosphere(4)
+    cases = {
+        # BASELINE config 1 (2 meshes), config 3 (mesh 0 of the bench workload), uniform-cube stress points
+        "tri_true_config1": (meshgen.jittered_batch(V2, 2), F2, meshgen.gt_cloud(2, 500), dict(level=2, batch=2, num=500, cube=0)),
+        "tri_true_config3": (meshgen.jittered_batch(V4, 1), F4, meshgen.gt_cloud(1, 3000), dict(level=4, batch=1, num=3000, cube=0)),
+        "tri_true_cube": (meshgen.jittered_batch(V2, 2, first=3), F2, meshgen.gt_cloud(2, 400, first=3, cube=True),
+                          dict(level=2, batch=2, num=400, cube=1, first=3)),
+    }
+    for name, (verts, faces, pts, meta) in cases.items():
+        true = np.stack([true_min_sqdist(fn, verts[b], faces, pts[b]) for b in range(verts.shape[0])])
+        save(name, true_sqdist=true, checksum=np.float64(verts.astype(np.float64).sum() + pts.astype(np.float64).sum()),
+             **{k: np.int64(v) for k, v in meta.items()})
+
+
 # ---------------------------------------------------------------- adjacency ----
 def make_adjacency():
     info, feats = ref_utils.load_initial(os.path.join(REF, "482.obj"))
@@ -380,6 +425,9 @@ if __name__ == "__main__":
     if "--block" in sys.argv:
         make_block()
         sys.exit(0)
+    if "--tri-true" in sys.argv:
+        make_tri_true()
+        sys.exit(0)
     make_regularisers()
     if "--only-new" in sys.argv:
         sys.exit(0)
@@ -389,3 +437,4 @@ if __name__ == "__main__":
     make_layers()
     make_block()
     make_pooling()
+    make_tri_true()

@@ -8,7 +8,7 @@ import torch
 
 import oracle
 from oracle import ref_ops
-from helpers import bits, golden, golden_names
+from helpers import bits, golden, golden_names, tri_true_case
 from geometrics_amd import meshgen
 
 NN_CASES = [n for n in golden_names("nn_") if n != "nn_config2_outputs"]
@@ -87,6 +87,31 @@ def test_tri_scan_agrees_with_reference_closest_point_formulas():
     # true distance sanity: the chosen point is never farther than the nearest corner
     corner = np.min([((g["points"][0][:, None] - t[0][None]) ** 2).sum(-1).min(1) for t in tri], axis=0)
     assert (d[0][ok] <= corner[ok] * (1 + 1e-5) + 1e-12).all()
+
+
+@pytest.mark.parametrize("name", ["tri_true_config1", "tri_true_config3", "tri_true_cube"])
+def test_tri_scan_pinned_by_the_legacy_eberly_implementation(name):
+    """Independent pin of the decision tree AND the arg-min of oracle_tri_scan: the reference's legacy
+    `point_to_line` (old_GEOMetrics/utils.py:734-1026, Eberly's region formulation -- no code or structure in common
+    with tri_distance.cu) gives the exact point-to-mesh squared distance of every query (float64, fixture made by
+    tests/golden/make_golden.py --tri-true).  With the region-6 delta corrected the scan must reproduce it for EVERY
+    point: a wrong region classification, a wrong candidate formula or a wrong arg-min would all show up as a
+    larger distance.  In the reference's quirk mode (region 6 walks along AB, tri_distance.cu:180) the result can
+    only be >= the true distance, and is the same wherever the same triangle wins outside region 6."""
+    verts, faces, pts, true = tri_true_case(name)
+    d6, o6, i6 = oracle.tri_scan_indexed(pts, verts, faces, oracle.FLAG_FIX_REGION6)
+    assert (np.abs(d6 - true) <= 1e-5 * true + 1e-9).all()
+    assert (o6 == 6).sum() > 10                      # region 6 really occurs in the corrected mode
+    dq, oq, iq = oracle.tri_scan_indexed(pts, verts, faces)
+    assert (dq >= true * (1 - 1e-5) - 1e-9).all()
+    same = (oq != 6) & (iq == i6)
+    assert same.sum() > 0.8 * same.size
+    np.testing.assert_array_equal(bits(dq[same]), bits(d6[same]))
+    # the direct (pre-gathered corners) entry point is the same scan
+    tri = [np.ascontiguousarray(verts[:, faces[:, k]]) for k in range(3)]
+    d2, o2, i2 = oracle.tri_scan(pts, *tri, oracle.FLAG_FIX_REGION6)
+    np.testing.assert_array_equal(bits(d2), bits(d6))
+    np.testing.assert_array_equal(i2, i6)
 
 
 def test_tri_pair_option_codes():

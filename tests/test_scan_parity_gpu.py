@@ -343,3 +343,23 @@ def test_large_point_sets_are_exact(gpu):
     for kw in (dict(), dict(order=None)):
         got = tri_distance_indexed(pts, verts, faces, **kw)
         assert all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(got, ref))
+
+
+@pytest.mark.parametrize("name", ["tri_true_config1", "tri_true_config3", "tri_true_cube"])
+@pytest.mark.parametrize("scan", ["grouped", "flat", "culled", "brute"])
+def test_tri_fix6_distances_equal_the_legacy_eberly_truth(gpu, name, scan):
+    """The HIP scans against the reference's legacy Eberly point_to_line DIRECTLY (not via the oracle): with the
+    region-6 delta corrected every distance is the exact point-to-mesh squared distance (fixture:
+    tests/golden/tri_true_*.npz, float64 from old_GEOMetrics/utils.py:734-1026); in the reference's quirk mode it is
+    never below it."""
+    from helpers import tri_true_case
+    verts, faces, pts, true = tri_true_case(name)
+    kw = {"grouped": dict(order="auto"), "flat": dict(order=None), "culled": dict(use_workspace=False),
+          "brute": dict(use_workspace=False)}[scan]
+    extra = FLAG_TRI_BRUTE_FORCE if scan == "brute" else 0
+    d6, o6, i6 = tri_distance_indexed(_dev(pts, gpu), _dev(verts, gpu), _dev(faces, gpu), FLAG_FIX_REGION6 | extra, **kw)
+    d6 = d6.cpu().numpy().astype(np.float64)
+    assert (np.abs(d6 - true) <= 1e-5 * true + 1e-9).all()
+    assert int((o6 == 6).sum()) > 10
+    dq, oq, iq = tri_distance_indexed(_dev(pts, gpu), _dev(verts, gpu), _dev(faces, gpu), extra, **kw)
+    assert (dq.cpu().numpy() >= true * (1 - 1e-5) - 1e-9).all()
