@@ -14,8 +14,10 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgeom_hip.so")
 FLAG_REF_TAIL_TRUNC = 1
 FLAG_FIX_REGION6 = 2
 FLAG_TRI_BRUTE_FORCE = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 EUNSUPPORTED = -3
+ADAM_MAX_TENSORS = 16
+ADAM_STATE_WORDS = 72
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -55,7 +57,7 @@ _SIGNATURES = {
     "geom_vertex_bn_bwd_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "geom_pool_features_fwd_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_pool_features_bwd_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
-    "geom_adam_step_f32": [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _vp],
+    "geom_adam_step_f32": [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _i, _vp],
     "geom_zn_gcn_aggregate_fwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "geom_zn_gcn_aggregate_ell_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "geom_zn_gcn_aggregate_ell_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],

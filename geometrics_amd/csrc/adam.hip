@@ -1,9 +1,17 @@
 // Multi-tensor Adam for the replicated 0N-GCN parameters (the optimiser the reference drivers use:
-// GEOMetrics.py:73, optim.Adam(lr=1e-4)).  One launch for every parameter tensor, the step
-// counter and the running beta powers live in device memory (updated by a 1-thread tick kernel),
-// so the whole update is HIP-graph replayable with no host scalars baked in.  (Folding the tick into the update
-// kernel through a last-workgroup-arrives counter was measured twice: with the 6144-workgroup grid the same-address
-// atomics serialise to 50 us; with a 66-workgroup grid the update itself slows to 8-9 us -- no better than 4.6 + 4.5.)
+// GEOMetrics.py:73, optim.Adam(lr=1e-4)).  ONE launch for up to GEOM_ADAM_MAX_TENSORS parameter tensors; the step
+// counter and the running beta powers live in device memory, so the update is HIP-graph replayable with no host
+// scalars baked in.
+//
+// Who advances the step state?  Every workgroup reads {t, b1^t, b2^t} at its start and derives the bias corrections
+// of step t+1 from it; the state may only change after the LAST workgroup has read it.  Round 1 used a 1-thread tick
+// kernel in front (a 4.6 us launch floor per step); a single last-arriver counter was measured and rejected (6144
+// same-address atomics serialise to ~50 us).  Here arrivals go through a two-level tree: workgroup w arrives at
+// leaf counter w % 64, the last arriver of a leaf arrives at the root, the last arriver of the root writes the new
+// state and re-arms the counters -- at most ceil(N/64) + 64 same-address atomics on any word (~1 us for the bench's
+// 254 workgroups), all off the critical path except the final hop.  `advance` = 0 skips the protocol: that is how an
+// optimiser with more than 16 tensors issues several launches that all use the bias corrections of ONE step (only
+// the last launch advances).
 // Update rule = torch.optim.Adam (no weight decay, no amsgrad):
 //   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
 //   p -= lr / (1-b1^t) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
@@ -11,42 +19,92 @@
 
 namespace {
 
+constexpr int ADAM_LEAVES = 64;
+static_assert(GEOM_ADAM_STATE_WORDS >= 4 + ADAM_LEAVES, "state layout: {t, b1^t, b2^t, root, leaf[64]}");
+
 struct AdamTensors {
     float *p[GEOM_ADAM_MAX_TENSORS];
     const float *g[GEOM_ADAM_MAX_TENSORS];
     float *m[GEOM_ADAM_MAX_TENSORS];
     float *v[GEOM_ADAM_MAX_TENSORS];
     int64_t n[GEOM_ADAM_MAX_TENSORS];
+    int first_block[GEOM_ADAM_MAX_TENSORS + 1]; // workgroups [first_block[i], first_block[i+1]) own tensor i
     int count;
 };
 
-// state[0] = t (as float), state[1] = b1^t, state[2] = b2^t
-__global__ void adam_tick_kernel(float b1, float b2, float *state)
+__device__ __forceinline__ void adam_update(float &p, float g, float &m, float &v, float b1, float b2, float eps,
+                                            float grad_scale, float step_size, float bc2_sqrt)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const bool first = state[0] == 0.f;
-        state[0] += 1.f;
-        state[1] = first ? b1 : state[1] * b1;
-        state[2] = first ? b2 : state[2] * b2;
-    }
+    const float gi = g * grad_scale;
+    const float mi = b1 * m + (1.f - b1) * gi;
+    const float vi = b2 * v + (1.f - b2) * gi * gi;
+    m = mi;
+    v = vi;
+    p -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
 }
 
+// state: [0] t (float), [1] b1^t, [2] b2^t, [3] root arrivals, [4..67] leaf arrivals (uint words)
 __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float lr, float b1, float b2, float eps,
-                                                   float grad_scale, const float *state)
+                                                   float grad_scale, float *state, int advance)
 {
-    const int which = blockIdx.y;
-    const float bc1 = 1.f - state[1];
-    const float bc2_sqrt = sqrtf(1.f - state[2]);
+    // the tensor this workgroup works on (at most 16 entries: a short uniform scan)
+    int which = 0;
+    while (which + 1 < t.count && (int)blockIdx.x >= t.first_block[which + 1]) ++which;
+    const int local = blockIdx.x - t.first_block[which];
+
+    const float t_old = state[0];
+    const float b1t = t_old == 0.f ? b1 : state[1] * b1;
+    const float b2t = t_old == 0.f ? b2 : state[2] * b2;
+    const float bc1 = 1.f - b1t;
+    const float bc2_sqrt = sqrtf(1.f - b2t);
     const float step_size = lr / bc1;
+
     float *p = t.p[which], *m = t.m[which], *v = t.v[which];
     const float *g = t.g[which];
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < t.n[which]; i += (int64_t)gridDim.x * 256) {
-        const float gi = g[i] * grad_scale;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    const int64_t n = t.n[which];
+    const int64_t base = ((int64_t)local * 256 + threadIdx.x) * 4;
+    const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    if (base + 4 <= n && vec) {
+        float4 pp = *reinterpret_cast<float4 *>(p + base);
+        const float4 gg = *reinterpret_cast<const float4 *>(g + base);
+        float4 mm = *reinterpret_cast<float4 *>(m + base);
+        float4 vv = *reinterpret_cast<float4 *>(v + base);
+        adam_update(pp.x, gg.x, mm.x, vv.x, b1, b2, eps, grad_scale, step_size, bc2_sqrt);
+        adam_update(pp.y, gg.y, mm.y, vv.y, b1, b2, eps, grad_scale, step_size, bc2_sqrt);
+        adam_update(pp.z, gg.z, mm.z, vv.z, b1, b2, eps, grad_scale, step_size, bc2_sqrt);
+        adam_update(pp.w, gg.w, mm.w, vv.w, b1, b2, eps, grad_scale, step_size, bc2_sqrt);
+        *reinterpret_cast<float4 *>(m + base) = mm;
+        *reinterpret_cast<float4 *>(v + base) = vv;
+        *reinterpret_cast<float4 *>(p + base) = pp;
+    } else {
+        for (int64_t i = base; i < n && i < base + 4; ++i) {
+            float pi = p[i], mi = m[i], vi = v[i];
+            adam_update(pi, g[i], mi, vi, b1, b2, eps, grad_scale, step_size, bc2_sqrt);
+            m[i] = mi;
+            v[i] = vi;
+            p[i] = pi;
+        }
+    }
+
+    if (!advance) return;
+    // arrival tree: this workgroup has read the state (its value is in registers above); the release orders that
+    // read before the arrival, so the state is rewritten only after every workgroup has taken its copy
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned *cnt = reinterpret_cast<unsigned *>(state) + 3;
+        const unsigned nblk = gridDim.x;
+        const unsigned leaf = blockIdx.x % ADAM_LEAVES;
+        const unsigned leaf_total = (nblk - leaf + ADAM_LEAVES - 1) / ADAM_LEAVES; // workgroups mapped to this leaf
+        const unsigned leaves = nblk < ADAM_LEAVES ? nblk : ADAM_LEAVES;
+        if (__hip_atomic_fetch_add(cnt + 1 + leaf, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == leaf_total - 1) {
+            __hip_atomic_store(cnt + 1 + leaf, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == leaves - 1) {
+                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                state[0] = t_old + 1.f;
+                state[1] = b1t;
+                state[2] = b2t;
+            }
+        }
     }
 }
 
@@ -54,13 +112,13 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float lr, floa
 
 extern "C" int geom_adam_step_f32(int count, float *const *params, const float *const *grads, float *const *exp_avg,
                                   float *const *exp_avg_sq, const int64_t *sizes, float lr, float beta1, float beta2,
-                                  float eps, float grad_scale, float *state, void *stream)
+                                  float eps, float grad_scale, float *state, int advance, void *stream)
 {
     if (count < 0 || count > GEOM_ADAM_MAX_TENSORS) return GEOM_ETOOBIG;
     if (count == 0) return 0;
     if (!params || !grads || !exp_avg || !exp_avg_sq || !sizes || !state) return GEOM_EINVAL;
     AdamTensors t;
-    int64_t longest = 0;
+    int64_t blocks = 0;
     for (int i = 0; i < count; ++i) {
         if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || sizes[i] < 0) return GEOM_EINVAL;
         t.p[i] = params[i];
@@ -68,15 +126,15 @@ extern "C" int geom_adam_step_f32(int count, float *const *params, const float *
         t.m[i] = exp_avg[i];
         t.v[i] = exp_avg_sq[i];
         t.n[i] = sizes[i];
-        if (sizes[i] > longest) longest = sizes[i];
+        t.first_block[i] = (int)blocks;
+        blocks += (sizes[i] + 1023) / 1024; // 256 threads x 4 elements
+        if (blocks > 0x3fffffff) return GEOM_ETOOBIG;
     }
+    t.first_block[count] = (int)blocks;
     t.count = count;
+    if (blocks == 0) blocks = 1; // only empty tensors: one workgroup still advances the state
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, beta1, beta2, state);
-    int64_t blocks = (longest + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks, count), dim3(256), 0, s, t, lr, beta1, beta2, eps, grad_scale,
-                       state);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, t, lr, beta1, beta2, eps, grad_scale, state,
+                       advance);
     return geom::launch_status();
 }

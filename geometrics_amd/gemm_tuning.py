@@ -10,7 +10,10 @@ run at use time (no warm-up cost, HIP-graph safe); a shape that is not in the fi
 library-version mismatch, silently falls back to the default heuristic -- results are identical
 either way (both are fp32 GEMMs), only the speed differs.
 """
+import atexit
 import os
+import shutil
+import sys
 import tempfile
 
 import torch
@@ -27,13 +30,24 @@ def enable(filename=TUNING_FILE):
     tun.tuning_enable(False)            # never tune here: only replay recorded selections
     tun.record_untuned_enable(False)
     try:
-        # read-only use of the shipped file: whatever TunableOp writes when the process exits goes to a private
-        # scratch path, so N ranks never rewrite the shared selections concurrently
-        tun.set_filename(os.path.join(tempfile.gettempdir(), "geom_tunableop_%d.csv" % os.getpid()))
-        return bool(tun.read_file(filename))
-    except Exception:                   # malformed / incompatible file: keep the default heuristic
+        # read-only use of the shipped file: nothing is written back at exit, and the filename TunableOp holds
+        # points into a private 0700 scratch directory (removed at exit), so N ranks never rewrite the shared
+        # selections and no predictable path in a shared tmp dir is ever opened for writing
+        scratch = tempfile.mkdtemp(prefix="geom_tunableop_")
+        atexit.register(shutil.rmtree, scratch, True)
+        tun.set_filename(os.path.join(scratch, "selections.csv"))
+        if hasattr(tun, "write_file_on_exit"):
+            tun.write_file_on_exit(False)
+        ok = bool(tun.read_file(filename))
+    except Exception as exc:            # malformed / incompatible file: keep the default heuristic, and say so
+        print("geometrics_amd.gemm_tuning: could not load %s (%s: %s); library default GEMM selection in use"
+              % (filename, type(exc).__name__, exc), file=sys.stderr)
         tun.enable(False)
         return False
+    if not ok:
+        print("geometrics_amd.gemm_tuning: %s was not accepted by TunableOp (library version mismatch?); "
+              "library default GEMM selection in use" % filename, file=sys.stderr)
+    return ok
 
 
 def disable():

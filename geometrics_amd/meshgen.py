@@ -38,6 +38,37 @@ def icosphere(level):
     return V, F
 
 
+def uv_sphere(rings=15, segments=32):
+    """Latitude/longitude sphere with two poles: rings*segments + 2 vertices, 2*segments*rings faces, outward
+    winding.  The default 15 x 32 has the SIZE and the degree extremes of the reference's training template
+    `482.obj` (GEOMetrics.py:44: 482 vertices, 960 faces, two poles with 32 neighbours -> adjacency rows of 33
+    entries beside rows of 5-9); its interior rows all have 7 entries where 482.obj mixes 6-10."""
+    v = [(0.0, 1.0, 0.0)]
+    for r in range(1, rings + 1):
+        th = np.pi * r / (rings + 1)
+        for s in range(segments):
+            ph = 2.0 * np.pi * s / segments
+            v.append((np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)))
+    v.append((0.0, -1.0, 0.0))
+    south = len(v) - 1
+    ring = lambda r, s: 1 + r * segments + (s % segments)
+    f = []
+    for s in range(segments):
+        f.append((0, ring(0, s + 1), ring(0, s)))
+        f.append((south, ring(rings - 1, s), ring(rings - 1, s + 1)))
+    for r in range(rings - 1):
+        for s in range(segments):
+            a, b, c, d = ring(r, s), ring(r, s + 1), ring(r + 1, s), ring(r + 1, s + 1)
+            f += [(a, b, d), (a, d, c)]
+    V = (np.asarray(v, np.float64) * RADIUS).astype(np.float32)
+    F = np.asarray(f, np.int64)
+    # outward winding check: normal . centroid > 0 for every face
+    n = np.cross(V[F[:, 1]] - V[F[:, 0]], V[F[:, 2]] - V[F[:, 0]])
+    flip = (n * V[F].mean(1)).sum(1) < 0
+    F[flip] = F[flip][:, ::-1]
+    return V, F
+
+
 def jittered_batch(verts, batch, first=0, sigma=0.02, seed=41):
     """Per-mesh Gaussian vertex jitter, seed 41+b (41 = the reference's default --seed)."""
     out = np.empty((batch,) + verts.shape, np.float32)

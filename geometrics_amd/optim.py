@@ -1,6 +1,8 @@
-"""Adam for the replicated 0N-GCN parameters on top of geom_adam_step_f32: every parameter tensor
-in one launch, step counter on the device (HIP-graph replayable).  Same update as
-torch.optim.Adam(lr, betas, eps) without weight decay / amsgrad (what GEOMetrics.py:73 uses)."""
+"""Adam for the replicated 0N-GCN parameters on top of geom_adam_step_f32: up to 16 parameter tensors per
+launch, step counter on the device and advanced inside the kernel (HIP-graph replayable, no tick launch).  Same
+update as torch.optim.Adam(lr, betas, eps) without weight decay / amsgrad (what GEOMetrics.py:73 uses).  Any number
+of tensors: they are issued in chunks of 16 that all use the bias corrections of the same step -- only the last
+chunk advances the state."""
 import ctypes
 
 import torch
@@ -11,33 +13,45 @@ from . import _lib
 class FusedAdam:
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
         self.params = [p for p in params if p.requires_grad]
-        if len(self.params) > 16:
-            raise RuntimeError("FusedAdam handles at most 16 parameter tensors per group")
+        if not self.params:
+            raise RuntimeError("FusedAdam got no trainable parameters")
         for p in self.params:
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                 raise RuntimeError("FusedAdam needs contiguous fp32 parameters on a HIP device")
         self.lr, self.betas, self.eps = lr, betas, eps
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
-        self.state = torch.zeros(3, dtype=torch.float32, device=self.params[0].device)
-        n = len(self.params)
-        self._sizes = (ctypes.c_int64 * n)(*[p.numel() for p in self.params])
-        self._ptr_array = ctypes.c_void_p * n
+        self.state = torch.zeros(_lib.ADAM_STATE_WORDS, dtype=torch.float32, device=self.params[0].device)
 
-    def _ptrs(self, tensors):
-        return self._ptr_array(*[t.data_ptr() for t in tensors])
+    @staticmethod
+    def _ptrs(tensors):
+        return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    @property
+    def step_count(self):
+        """Steps taken so far (one host read)."""
+        return int(self.state[0].item())
 
     def zero_grad(self):
         for p in self.params:
             p.grad = None
 
     def step(self, grads=None, grad_scale=1.0):
-        """grads: tensors to read instead of p.grad (e.g. views of an all-reduced flat bucket)."""
+        """grads: tensors to read instead of p.grad (e.g. views of an all-reduced flat bucket).  A parameter whose
+        gradient is None is left untouched, as torch.optim.Adam does (the reference block's bn14 is never used)."""
         if grads is None:
             grads = [p.grad for p in self.params]
-        grads = [g.contiguous() for g in grads]
+        live = [i for i, g in enumerate(grads) if g is not None]
+        if not live:
+            return
+        grads = [None if g is None else g.contiguous() for g in grads]
+        m = _lib.ADAM_MAX_TENSORS
         with torch.cuda.device(self.params[0].device):
-            _lib.call("geom_adam_step_f32", len(self.params), self._ptrs([p.data for p in self.params]),
-                      self._ptrs(grads), self._ptrs(self.exp_avg), self._ptrs(self.exp_avg_sq), self._sizes,
-                      float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(grad_scale),
-                      self.state.data_ptr())
+            for c0 in range(0, len(live), m):
+                chunk = live[c0:c0 + m]
+                pick = lambda seq: self._ptrs([seq[i] for i in chunk])
+                sizes = (ctypes.c_int64 * len(chunk))(*[self.params[i].numel() for i in chunk])
+                _lib.call("geom_adam_step_f32", len(chunk), pick([p.data for p in self.params]), pick(grads),
+                          pick(self.exp_avg), pick(self.exp_avg_sq), sizes, float(self.lr), float(self.betas[0]),
+                          float(self.betas[1]), float(self.eps), float(grad_scale), self.state.data_ptr(),
+                          int(c0 + m >= len(live)))       # only the last chunk advances the device-side step state

@@ -162,6 +162,8 @@ def batch_get_lap_info(positions, adj_info):
     and a thread per vertex walks its row."""
     from .layers import adjacency_csr
     csr = adjacency_csr(adj_info["adj_orig"])
+    if positions.dim() == 2:      # the template mesh itself, [V,3] (GEOMetrics.py:156): the reference's matmul broadcasts
+        return ops.Laplacian.apply(positions.unsqueeze(0), csr.rowptr, csr.col, csr.inv_deg).squeeze(0)
     return ops.Laplacian.apply(positions, csr.rowptr, csr.col, csr.inv_deg)
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GEOM_ABI_VERSION 2
+#define GEOM_ABI_VERSION 3
 
 /* argument errors */
 #define GEOM_EINVAL   (-1) /* bad size / null pointer */
@@ -315,15 +315,20 @@ int geom_segment_max_bwd_f32(int nseg, const int64_t *offsets, int64_t total_row
                              const float *grad_out, const int *arg, float *grad_x, void *stream);
 
 /* ---- optimiser step for the replicated layer parameters (GEOMetrics.py:73: Adam, lr 1e-4) -----------
- * torch.optim.Adam's update (no weight decay / amsgrad) for up to GEOM_ADAM_MAX_TENSORS tensors in one
+ * torch.optim.Adam's update (no weight decay / amsgrad) for up to GEOM_ADAM_MAX_TENSORS tensors in ONE
  * launch.  params/grads/exp_avg/exp_avg_sq/sizes are HOST arrays of `count` device pointers / lengths;
- * grads are multiplied by grad_scale first (1/world after a SUM all-reduce).  `state` is 3 device
- * floats {t, beta1^t, beta2^t}, zero-initialised by the caller once and advanced by every call on the
- * device, so a captured HIP graph replays the correct bias correction. */
+ * grads are multiplied by grad_scale first (1/world after a SUM all-reduce).  `state` is
+ * GEOM_ADAM_STATE_WORDS 4-byte device words, zero-initialised by the caller once: {t, beta1^t, beta2^t}
+ * as floats followed by the arrival counters of the in-kernel step advance.  Every call applies the bias
+ * corrections of step t+1; with advance != 0 the last workgroup to finish moves the state to t+1 (so a
+ * captured HIP graph replays the correct correction, with no separate tick launch).  An optimiser holding
+ * more than GEOM_ADAM_MAX_TENSORS tensors issues several calls on one stream for one step: advance = 0 on
+ * all but the last. */
 #define GEOM_ADAM_MAX_TENSORS 16
+#define GEOM_ADAM_STATE_WORDS 72
 int geom_adam_step_f32(int count, float *const *params, const float *const *grads, float *const *exp_avg,
                        float *const *exp_avg_sq, const int64_t *sizes, float lr, float beta1, float beta2,
-                       float eps, float grad_scale, float *state, void *stream);
+                       float eps, float grad_scale, float *state, int advance, void *stream);
 
 #ifdef __cplusplus
 }

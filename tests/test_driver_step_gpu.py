@@ -1,0 +1,132 @@
+"""-m gpu: one GEOMetrics.py-shaped training step and one validation step with the DRIVER'S OWN CALL SHAPES
+(GEOMetrics.py:100-175 and 196-225) on the geometrics_amd operators, at the reference's training size: a 482-vertex /
+960-face template with two 32-neighbour poles, batch of feature maps 64x56^2 .. 512x7^2, three deformation blocks
+(963 / 1155 / 1155 -> 192 x 13 -> 3), 3000 sampled vs 3000 gt points, Adam over every parameter tensor.
+
+What the driver passes that unit tests of the operators do not: a 2-D [V,3] `initial_positions` into
+batch_get_lap_info, `.unsqueeze(0).expand(...)` (stride-0) position batches, `.clone()`d positions, `gt_samples[:, :2466]`
+(a non-contiguous slice) in validation, eval-mode blocks under no_grad, and an optimiser holding hundreds of tensors.
+The loss terms are checked against the CPU restatement (oracle.ref_ops) on the positions the blocks produced."""
+import numpy as np
+import pytest
+import torch
+
+import oracle  # noqa: F401
+from oracle import ref_ops
+from geometrics_amd import meshgen, models, ops, optim, utils
+
+pytestmark = pytest.mark.gpu
+
+B, SAMPLES = 2, 3000
+
+
+def _setup(gpu, seed=41):
+    torch.manual_seed(seed)
+    V, F = meshgen.uv_sphere()
+    faces = torch.from_numpy(F).to(gpu)
+    adj_info = utils.adj_init(faces)
+    initial_positions = torch.from_numpy(V).to(gpu)                         # 2-D, as load_initial returns it
+    blocks = [models.BatchMeshDeformationBlock(c, V.shape[0]).to(gpu) for c in (963, 1155, 1155)]
+    maps = [[torch.randn(B, c, d, d, device=gpu, requires_grad=True) for c, d in ((64, 56), (128, 28), (256, 14), (512, 7))]
+            for _ in range(3)]                                               # what the three VGG encoders return
+    img_info = torch.tensor([[30.0, 25.0, 1.1], [200.0, 15.0, 1.0]], device=gpu)
+    gt = torch.from_numpy(meshgen.gt_cloud(B, SAMPLES)).to(gpu)
+    return V, F, adj_info, initial_positions, blocks, maps, img_info, gt
+
+
+def _predict(adj_info, initial_positions, blocks, maps, img_info):
+    """GEOMetrics.py:110-131, line for line."""
+    num_verts = initial_positions.shape[0]
+    modelA, modelB, modelC = blocks
+    initial_positions_batch = initial_positions.unsqueeze(0).expand(B, num_verts, 3)
+    vertex_features = utils.batched_pooling(maps[0], initial_positions_batch, img_info.clone())
+    vertex_features, vertex_positions_1 = modelA(initial_positions_batch, vertex_features, adj_info["adj"])
+    vertex_positions_1 = initial_positions_batch + vertex_positions_1
+    vertex_features = torch.cat((vertex_features, utils.batched_pooling(maps[1], vertex_positions_1.clone(), img_info.clone())), dim=-1)
+    vertex_features, vertex_positions_2 = modelB(vertex_positions_1.clone(), vertex_features, adj_info["adj"])
+    vertex_positions_2 = vertex_positions_2 + vertex_positions_1
+    vertex_features = torch.cat((vertex_features, utils.batched_pooling(maps[2], vertex_positions_2.clone(), img_info.clone())), dim=-1)
+    _, vertex_positions_3 = modelC(vertex_positions_2.clone(), vertex_features, adj_info["adj"])
+    vertex_positions_3 = vertex_positions_3 + vertex_positions_2
+    return vertex_positions_1, vertex_positions_2, vertex_positions_3
+
+
+def test_training_step_with_the_drivers_call_shapes(gpu):
+    V, F, adj_info, initial_positions, blocks, maps, img_info, gt_samples = _setup(gpu)
+    for m in blocks:
+        m.train()
+    params = [p for m in blocks for p in m.parameters()]
+    assert len(params) > 150                                                 # far beyond one Adam launch's 16 tensors
+    optimizer = optim.FusedAdam(params, lr=1e-4)
+    draws = [tuple(torch.from_numpy(a).to(gpu) for a in meshgen.sampling_draws(np.zeros((B,) + V.shape, np.float32) + V, F,
+                                                                              SAMPLES, first=10 * i)) for i in range(3)]
+    losses = []
+    for it in range(2):
+        optimizer.zero_grad()
+        p1, p2, p3 = _predict(adj_info, initial_positions, blocks, maps, img_info)
+        # GEOMetrics.py:134-139 (draws replayed so that the CPU restatement sees the same samples)
+        s1 = utils.batch_point_to_surface(p1.clone(), adj_info, gt_samples, num=SAMPLES, draws=draws[0])
+        s2 = utils.batch_point_to_surface(p2.clone(), adj_info, gt_samples, num=SAMPLES, draws=draws[1])
+        s3, f1 = utils.batch_point_to_surface(p3.clone(), adj_info, gt_samples, num=SAMPLES, f1=True, draws=draws[2])
+        surface_loss = s1 * .2 + s2 * .2 + s3 * 2
+        # GEOMetrics.py:147-150
+        edge_loss = utils.batch_calc_edge(p1.clone(), adj_info) * 300
+        edge_loss += utils.batch_calc_edge(p2.clone(), adj_info) * 300
+        edge_loss += utils.batch_calc_edge(p3.clone(), adj_info) * 300
+        # GEOMetrics.py:156-161: the first call hands the 2-D template to batch_get_lap_info
+        lap = utils.batch_get_lap_info
+        lap_loss_1 = torch.mean(torch.sum((lap(initial_positions, adj_info) - lap(p1, adj_info)) ** 2, 2)) * 1500
+        lap_loss_2 = torch.mean(torch.sum((lap(p1, adj_info) - lap(p2, adj_info)) ** 2, 2)) * 1500
+        lap_loss_2 += torch.mean(torch.sum((p1 - p2) ** 2, 2)) * 100
+        lap_loss_3 = torch.mean(torch.sum((lap(p2, adj_info) - lap(p3, adj_info)) ** 2, 2)) * 1500
+        lap_loss_3 += torch.mean(torch.sum((p2 - p3) ** 2, 2)) * 100
+        lap_loss = .2 * (lap_loss_1 * .3 + lap_loss_2 + lap_loss_3)
+        loss = edge_loss + surface_loss + lap_loss
+        if it == 0:     # every term against the CPU restatement, on the positions the blocks produced
+            faces_c, gt_c = torch.from_numpy(F), gt_samples.cpu()
+            adj_orig = ref_ops.calc_adj(faces_c)
+            pc = [p.detach().cpu() for p in (p1, p2, p3)]
+            dc = [tuple(t.cpu() for t in d) for d in draws]
+            ref_s = [ref_ops.point_to_surface(pc[i], faces_c, gt_c, *dc[i]) for i in range(3)]
+            for ours, ref in zip((s1, s2, s3), ref_s):
+                assert abs(ours.item() - ref.item()) <= 1e-4 * abs(ref.item())
+            ref_edge = sum(ref_ops.calc_edge(p, faces_c) for p in pc) * 300
+            assert abs(edge_loss.item() - ref_edge.item()) <= 1e-5 * abs(ref_edge.item())
+            li = lambda p: ref_ops.lap_info(p, adj_orig)
+            r1 = torch.mean(torch.sum((li(initial_positions.cpu()) - li(pc[0])) ** 2, 2)) * 1500
+            assert abs(lap_loss_1.item() - r1.item()) <= 1e-4 * abs(r1.item()) + 1e-7
+            assert 0.0 <= f1 <= 1.0
+        loss.backward()
+        unused = [p for p in params if p.grad is None]
+        assert len(unused) == 6          # bn14.weight / bn14.bias of each block: never called by the reference either
+        for p in params:
+            assert p.grad is None or torch.isfinite(p.grad).all()
+        for group in maps:
+            for m in group:
+                assert m.grad is not None and torch.isfinite(m.grad).all()
+        optimizer.step()
+        losses.append(loss.item())
+    assert np.isfinite(losses).all()
+    assert optimizer.step_count == 2
+
+
+def test_validation_step_with_the_drivers_call_shapes(gpu):
+    """GEOMetrics.py:196-225: eval-mode blocks under no_grad, batch 1 semantics aside, and the sliced gt cloud."""
+    V, F, adj_info, initial_positions, blocks, maps, img_info, gt_samples = _setup(gpu, seed=42)
+    for m in blocks:
+        m.eval()
+    with torch.no_grad():
+        _, _, p3 = _predict(adj_info, initial_positions, blocks, maps, img_info)
+        sliced = gt_samples[:, :2466]
+        assert not sliced.is_contiguous()
+        ch, u, v = (torch.from_numpy(a).to(gpu) for a in meshgen.sampling_draws(p3.cpu().numpy(), F, 2466))
+        loss, f1 = utils.batch_point_to_point(p3, adj_info, sliced, num=2466, f1=True, draws=(ch, u, v))
+        ref, ref_f1 = ref_ops.point_to_point(p3.cpu(), torch.from_numpy(F), sliced.cpu().contiguous(), ch.cpu(), u.cpu(), v.cpu(),
+                                             f1=True)
+    assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    assert abs(f1 - ref_f1) < 1e-9
+    # and with fresh in-kernel draws, as the driver calls it
+    with torch.no_grad():
+        ops.manual_seed(7, gpu)
+        loss2, f1b = utils.batch_point_to_point(p3, adj_info, sliced, num=2466, f1=True)
+    assert np.isfinite(loss2.item()) and abs(loss2.item() - loss.item()) < 0.5 * abs(loss.item())

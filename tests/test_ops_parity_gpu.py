@@ -210,6 +210,45 @@ def test_fused_adam_matches_torch_adam(gpu):
         close(p.detach().cpu().numpy(), r.detach().cpu().numpy(), 2e-6)
 
 
+def test_fused_adam_many_tensors_and_graph_replay(gpu):
+    """More than 16 tensors (a deformation block has 56, GEOMetrics.py:73 hands Adam hundreds): chunks of 16 share the
+    bias corrections of ONE step (only the last chunk advances the device-side state), odd sizes take the scalar tail,
+    and a captured step replays with the state advancing on the device."""
+    from geometrics_amd import optim
+    torch.manual_seed(6)
+    shapes = [(1, 1155, 192), (192,)] + [(192, 192), (192,)] * 12 + [(192, 3), (3,)] + [(7, 5), (1,), (1023,), (1025,)] * 3
+    assert len(shapes) > 32
+    ours = [torch.randn(*s, device=gpu).requires_grad_(True) for s in shapes]
+    ref = [p.detach().clone().requires_grad_(True) for p in ours]
+    opt = optim.FusedAdam(ours, lr=1e-3)
+    ropt = torch.optim.Adam(ref, lr=1e-3)
+    grads = [torch.randn(*s, device=gpu) for s in shapes]
+    for p, r, g in zip(ours, ref, grads):
+        p.grad, r.grad = g.clone(), g.clone()
+    for step in range(3):
+        opt.step()
+        ropt.step()
+    assert opt.step_count == 3
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        opt.step()
+        ropt.step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        opt.step()
+    ropt.step()
+    for _ in range(4):
+        graph.replay()
+        ropt.step()
+    torch.cuda.synchronize()
+    assert opt.step_count == 9
+    assert int(opt.state.view(torch.int32)[3:].abs().sum()) == 0      # arrival counters re-armed
+    for p, r in zip(ours, ref):
+        close(p.detach().cpu().numpy(), r.detach().cpu().numpy(), 5e-6)
+
+
 def test_surface_loss_is_graph_capturable_and_stream_safe(gpu):
     """The fused loss forks a second stream; replaying it from a HIP graph must give the eager value."""
     g = golden("p2s_v162")
