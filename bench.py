@@ -57,8 +57,9 @@ class Workload:
         self.base = to(meshgen.jittered_batch(V, batch, first=first_mesh))
         self.gt = to(meshgen.gt_cloud(batch, G_PTS, first=first_mesh))
         self.info = utils.adj_init(self.faces)
-        g = torch.Generator(device="cpu").manual_seed(seed + first_mesh)
-        self.feat = torch.randn(batch, self.nv, FEAT, generator=g).to(dev).requires_grad_(True)
+        # per-mesh seeds (global mesh index): a shard holds exactly the rows the whole-batch job would hold
+        self.feat = torch.stack([torch.randn(self.nv, FEAT, generator=torch.Generator(device="cpu").manual_seed(seed + first_mesh + i))
+                                 for i in range(batch)]).to(dev).requires_grad_(True)
         torch.manual_seed(seed)                       # identical (replicated) parameters on every rank
         self.stack = torch.nn.ModuleList(
             [layers.Batch_Image_ZERON_GCNGCN(i, o) for i, o in ((FEAT, HID), (HID, HID), (HID, HID))]).to(dev)
@@ -67,7 +68,7 @@ class Workload:
         self.bucket = gdist.GradBucket(self.stack.parameters(), extra=2) if self.world > 1 else None
         self.count = torch.full((), float(batch), device=dev)
         self.seed_grad = torch.ones((), device=dev)
-        ops.manual_seed(seed + 977 * first_mesh, dev)        # sampler stream: distinct per shard, reproducible
+        self.rng = ops.manual_seed(seed, dev, mesh_offset=first_mesh)   # sampler keyed on the GLOBAL mesh index: N shards draw what one process would
         # GEOMetrics.py:73 (Adam, lr 1e-4): every parameter tensor in one launch, step count on the device
         self.opt = optim.FusedAdam(self.stack.parameters(), lr=1e-4)
         self.loss = None

@@ -77,8 +77,10 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key)
 }
 __device__ __forceinline__ float u01(unsigned x) { return (x >> 8) * 0x1p-24f; } // [0,1), 24 random bits
 
-// rng_state = {seed, stream position, arrival counter}: the LAST workgroup of a call to finish advances the
-// position (every workgroup has read it by then) and re-arms the counter -- no separate tick launch.
+// rng_state = {seed, stream position, arrival counter, first GLOBAL mesh index of this shard}: the LAST workgroup of
+// a call to finish advances the position (every workgroup has read it by then) and re-arms the counter -- no separate
+// tick launch.  The counter is keyed on the global mesh index, so data-parallel ranks that share a seed draw exactly
+// what one process holding the whole batch would draw (and never the same samples for different meshes).
 
 __global__ __launch_bounds__(DRAW_THREADS) void draw_samples_kernel(int nv, const float *verts, int nf,
                                                                      const int64_t *faces, int num,
@@ -119,10 +121,11 @@ __global__ __launch_bounds__(DRAW_THREADS) void draw_samples_kernel(int nv, cons
     const float total = cdf[nf - 1];
 
     const int i = blockIdx.x * DRAW_THREADS + threadIdx.x;
-    unsigned long long seed = 0ull, pos = 0ull;
+    unsigned long long seed = 0ull, pos = 0ull, mesh0 = 0ull;
     if (rng_state) {
         seed = rng_state[0];
         pos = rng_state[1];
+        mesh0 = rng_state[3];
         __syncthreads(); // every thread of this workgroup holds the position before the workgroup reports in
         if (threadIdx.x == 0) {
             const unsigned long long groups = (unsigned long long)gridDim.x * gridDim.y;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(DRAW_THREADS) void draw_samples_kernel(int nv, cons
     const int64_t o = (int64_t)mesh * num + i;
     float r0, r1, r2;
     if (rng_state) { // in-kernel Philox: counter = (sample, mesh, stream position), key = seed
-        const uint4 r = philox4x32_10(make_uint4((unsigned)i, (unsigned)mesh, (unsigned)pos, (unsigned)(pos >> 32)),
+        const uint4 r = philox4x32_10(make_uint4((unsigned)i, (unsigned)(mesh0 + mesh), (unsigned)pos, (unsigned)(pos >> 32)),
                                       make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
         r0 = u01(r.x), r1 = u01(r.y), r2 = u01(r.z);
     } else {

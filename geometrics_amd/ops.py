@@ -407,21 +407,36 @@ class SegmentMax(torch.autograd.Function):
 _rng_states = {}
 
 
-def manual_seed(seed, device=None):
-    """(Re)seed the in-kernel sampler stream of `device` (default: current).  Without a call the stream is
-    seeded from torch's default generator the first time it is used."""
+def manual_seed(seed, device=None, mesh_offset=0):
+    """(Re)seed the in-kernel sampler stream of `device` (default: current).  `mesh_offset` = the global index of
+    the first mesh this process holds: the generator is keyed on (seed, stream position, global mesh index, sample),
+    so data-parallel ranks that pass the same seed and their shard's offset draw exactly what one process holding the
+    whole batch would draw.  Without a call the stream is seeded from torch's default generator the first time it is
+    used, with a rank-distinct offset under torch.distributed.  One sampler stream per device: calls that draw
+    from it must be issued on one HIP stream at a time (the position is advanced inside the kernel)."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
-    state = torch.tensor([int(seed) & (2 ** 63 - 1), 0, 0], dtype=torch.int64).to(dev)   # seed, position, arrivals
+    state = torch.tensor([int(seed) & (2 ** 63 - 1), 0, 0, int(mesh_offset)], dtype=torch.int64).to(dev)   # seed, position, arrivals, first mesh
     _rng_states[key] = state
     return state
+
+
+def set_rng_state(state, device=None):
+    """Make `state` (a tensor manual_seed returned) the sampler stream of `device`: lets one process alternate
+    between several independent streams (e.g. two shards stepped in turn)."""
+    dev = state.device if device is None else torch.device(device)
+    _rng_states[dev.index if dev.index is not None else torch.cuda.current_device()] = state
 
 
 def _rng_state(dev):
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     st = _rng_states.get(key)
     if st is None:
-        st = manual_seed(torch.initial_seed() ^ 0x5DEECE66D, dev)
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        # ranks seeded alike (the reference seeds 41 everywhere) must not draw the same samples for different meshes
+        st = manual_seed(torch.initial_seed() ^ 0x5DEECE66D, dev, mesh_offset=rank << 24)
     return st
 
 
@@ -494,6 +509,6 @@ class VertexHead(torch.autograd.Function):
 
 
 __all__ = ["face_areas", "device_sum", "SampleFaces", "GatherSqDistSum", "PointToTriangleSum", "SurfaceLoss",
-           "Laplacian", "EdgeSqLenSum", "PoolFeatures", "VertexHead", "SegmentMax", "manual_seed",
+           "Laplacian", "EdgeSqLenSum", "PoolFeatures", "VertexHead", "SegmentMax", "manual_seed", "set_rng_state",
            "draw_samples",
            "chamfer_nn", "tri_distance_indexed"]

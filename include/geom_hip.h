@@ -114,10 +114,13 @@ int geom_face_areas_f32(int b, int nv, const float *verts, int nf, const int64_t
  * nf <= 16384 (the CDF lives in LDS), otherwise GEOM_EUNSUPPORTED. */
 int geom_draw_samples_f32(int b, int nv, const float *verts, int nf, const int64_t *faces, int num,
                           const float *uniforms, int64_t *choices, float *u, float *v, void *stream);
-/* Same draws from an in-kernel counter-based generator (Philox4x32-10): rng_state = 3 device uint64
- * {seed, stream position, 0}; the last workgroup of every call advances the position on the device (the third
- * word is its arrival counter and is 0 between calls), so a captured HIP graph draws fresh numbers on each
- * replay and no generator bookkeeping is launched.  One stream per rng_state.  points (may be NULL):
+/* Same draws from an in-kernel counter-based generator (Philox4x32-10): rng_state = 4 device uint64
+ * {seed, stream position, 0, first global mesh index}; the last workgroup of every call advances the position on
+ * the device (the third word is its arrival counter and is 0 between calls), so a captured HIP graph draws fresh
+ * numbers on each replay and no generator bookkeeping is launched.  A sample's uniforms are a function of (seed,
+ * position, first global mesh index + mesh, sample): data-parallel shards that share a seed reproduce the draws of
+ * one process holding the whole batch.  One HIP stream per rng_state (the position/arrival words are not
+ * safe under concurrent calls).  points (may be NULL):
  * [b,num,3], the sampled points themselves -- what geom_sample_faces_fwd_f32 would compute from the draws. */
 int geom_draw_samples_rng_f32(int b, int nv, const float *verts, int nf, const int64_t *faces, int num,
                               uint64_t *rng_state, int64_t *choices, float *u, float *v, float *points,

@@ -172,6 +172,36 @@ def test_config4_stack_at_baseline_size(gpu):
     assert csr.nnz == 17922 and layers.adjacency_csr(adj) is csr          # V + 2E, cached
 
 
+def test_relu_sign_mask_path_at_the_bench_configuration(gpu):
+    """The exact kernel configuration bench.py runs -- Batch_Image_ZERON_GCNGCN with F.relu at B=8, V=2562, C=192,
+    k=64: ELL forward that also stores the sign mask, backward that takes relu' from the mask -- against the float64
+    dense restatement (oracle.ref_ops.zero_n_layer, reference layers.py:107-116).  ReLU is not continuous in its
+    derivative: output elements whose float64 pre-activation lies within round-off of zero are left out of the forward
+    comparison and get a zero upstream gradient, so both sides differentiate through the same branch."""
+    V, Fc = meshgen.icosphere(4)
+    adj = utils.adj_init(dev(Fc, gpu))["adj"]
+    torch.manual_seed(77)
+    for cin in (963, 192):
+        layer = layers.Batch_Image_ZERON_GCNGCN(cin, 192).to(gpu)
+        x = torch.randn(8, V.shape[0], cin, device=gpu, requires_grad=True)
+        out = layer(x, adj, F.relu)
+        xc = x.detach().cpu().double().requires_grad_(True)
+        w = layer.weight1.detach().cpu().double().requires_grad_(True)
+        b = layer.bias.detach().cpu().double().requires_grad_(True)
+        pre = ref_ops.zero_n_layer(xc, adj.cpu().double(), w, b, 3, lambda t: t)
+        knife = pre.detach().abs() < 1e-5 * float(pre.detach().abs().max())
+        assert 0 < int(knife.sum()) < 1e-3 * knife.numel()
+        ref = torch.relu(pre)
+        o = out.detach().cpu().double()
+        assert float(((o - ref.detach()).abs() * (~knife)).max()) <= 1e-5 * float(ref.detach().abs().max())
+        gout = torch.randn(out.shape, dtype=torch.float64) * (~knife)
+        out.backward(gout.float().to(gpu))
+        ref.backward(gout)
+        close(x.grad.cpu().numpy(), xc.grad.numpy(), 1e-4)
+        close(layer.weight1.grad.cpu().numpy(), w.grad.numpy(), 1e-4)
+        close(layer.bias.grad.cpu().numpy(), b.grad.numpy(), 1e-4)
+
+
 def test_gcn_rows_of_degree_32(gpu):
     g = golden("adj_482")
     adj = utils.adj_init(dev(g["faces"], gpu))["adj"]
