@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgeom_hip.so")
 FLAG_REF_TAIL_TRUNC = 1
 FLAG_FIX_REGION6 = 2
 FLAG_TRI_BRUTE_FORCE = 4
+FLAG_NN_FMA = 8
 ABI_VERSION = 3
 EUNSUPPORTED = -3
 ADAM_MAX_TENSORS = 16

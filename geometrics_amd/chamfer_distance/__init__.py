@@ -13,8 +13,29 @@ import torch
 from .. import _lib
 
 
-def chamfer_nn(xyz1, xyz2, flags=0):
+_arithmetic_flags = 0
+
+
+def set_arithmetic(mode):
+    """Canonical arithmetic of the squared distance in every NN scan issued without explicit flags:
+    "unfused" (default) = (dx*dx + dy*dy) + dz*dz, bit-identical to the reference's CPU nnsearch as shipped;
+    "fma" = fma(dz, dz, fma(dx, dx, dy*dy)), bit-identical to the same source built with FMA contraction (what
+    gcc -mfma -ffp-contract=fast and nvcc's default produce).  Indices agree between the two except on ties within
+    one rounding; distances differ by round-off (<= 1e-7 relative)."""
+    global _arithmetic_flags
+    if mode not in ("unfused", "fma"):
+        raise ValueError("arithmetic must be 'unfused' or 'fma'")
+    _arithmetic_flags = _lib.FLAG_NN_FMA if mode == "fma" else 0
+
+
+def default_flags():
+    return _arithmetic_flags
+
+
+def chamfer_nn(xyz1, xyz2, flags=None):
     """(dist1 [B,N] f32, idx1 [B,N] i32, dist2 [B,M] f32, idx2 [B,M] i32)."""
+    if flags is None:
+        flags = _arithmetic_flags
     xyz1 = _lib.require(xyz1.detach(), "xyz1", torch.float32, 3, 3)
     xyz2 = _lib.require(xyz2.detach(), "xyz2", torch.float32, 3, 3)
     dev = _lib.same_device(xyz1, xyz2)

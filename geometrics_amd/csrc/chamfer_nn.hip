@@ -186,6 +186,14 @@ constexpr int NNS_GROUP = 16;
 constexpr int NNS_WAVES = 8;  // measured at the BASELINE shard: 4 waves 32.3 us, 8 waves 30.6 us, 16 waves 37.5 us
 constexpr int NNS_THREADS = NNS_WAVES * GEOM_WAVE;
 
+template <bool FMA>
+__device__ __forceinline__ float nn_sqdist(float tx, float ty, float tz, float qx, float qy, float qz)
+{
+    return FMA ? geom::sqdist3_fma(tx, ty, tz, qx, qy, qz) : geom::sqdist3(tx, ty, tz, qx, qy, qz);
+}
+
+// FMA = the contracted arithmetic of GEOM_FLAG_NN_FMA (6 lane-ops per pair instead of 8)
+template <bool FMA>
 __global__ __launch_bounds__(NNS_THREADS) void chamfer_nn_scalar_kernel(NNJob job)
 {
     __shared__ float part_d[NNS_WAVES][NN_QUERIES];
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(NNS_THREADS) void chamfer_nn_scalar_kernel(NNJob jo
         for (int i = 0; i < 3 * NNS_GROUP; ++i) t[i] = tp[i];
         float d[NNS_GROUP];
 #pragma unroll
-        for (int k = 0; k < NNS_GROUP; ++k) d[k] = geom::sqdist3(t[3 * k], t[3 * k + 1], t[3 * k + 2], qx, qy, qz);
+        for (int k = 0; k < NNS_GROUP; ++k) d[k] = nn_sqdist<FMA>(t[3 * k], t[3 * k + 1], t[3 * k + 2], qx, qy, qz);
         float m8 = INFINITY;
 #pragma unroll
         for (int k = 0; k < NNS_GROUP; k += 4) m8 = fminf(m8, min4(d[k], d[k + 1], d[k + 2], d[k + 3])); // NaNs drop out
@@ -248,13 +256,13 @@ __global__ __launch_bounds__(NNS_THREADS) void chamfer_nn_scalar_kernel(NNJob jo
 #pragma unroll
         for (int j = NNS_GROUP - 1; j >= 0; --j) {
             const int k = k0 + j;
-            const float dd = geom::sqdist3(T[3 * k + 0], T[3 * k + 1], T[3 * k + 2], qx, qy, qz);
+            const float dd = nn_sqdist<FMA>(T[3 * k + 0], T[3 * k + 1], T[3 * k + 2], qx, qy, qz);
             if (dd == best) best_idx = k;
         }
     }
     if (wave == NNS_WAVES - 1) { // ragged tail (nt % 8 targets), after every group in index order
         for (int k = groups * NNS_GROUP; k < nt; ++k) {
-            const float dd = geom::sqdist3(T[3 * k + 0], T[3 * k + 1], T[3 * k + 2], qx, qy, qz);
+            const float dd = nn_sqdist<FMA>(T[3 * k + 0], T[3 * k + 1], T[3 * k + 2], qx, qy, qz);
             if (dd < best) {
                 best = dd;
                 best_idx = k;
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(NNS_THREADS) void chamfer_nn_scalar_kernel(NNJob jo
                 acc_i = ii;
             }
         }
-        const float d_first = geom::sqdist3(T[0], T[1], T[2], qx, qy, qz);
+        const float d_first = nn_sqdist<FMA>(T[0], T[1], T[2], qx, qy, qz);
         if (d_first != d_first || acc_i == INT_MAX) { // NaN seed sticks; nothing finite keeps the seed
             acc_d = d_first;
             acc_i = 0;
@@ -303,9 +311,12 @@ extern "C" int geom_chamfer_nn_f32(int b, int n, const float *xyz, int m, const 
     if (blocks > 0x7fffffffLL) return GEOM_ETOOBIG;
     dim3 grid(geom::xcd_grid(2 * b, (longer + NN_QUERIES - 1) / NN_QUERIES), 1, 1);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((flags & GEOM_FLAG_REF_TAIL_TRUNC) && (flags & GEOM_FLAG_NN_FMA)) return GEOM_EINVAL; // one arithmetic per quirk mode
     if (flags & GEOM_FLAG_REF_TAIL_TRUNC)
         hipLaunchKernelGGL(chamfer_nn_kernel<true>, grid, dim3(NN_THREADS), 0, s, job);
+    else if (flags & GEOM_FLAG_NN_FMA)
+        hipLaunchKernelGGL(chamfer_nn_scalar_kernel<true>, grid, dim3(NNS_THREADS), 0, s, job);
     else
-        hipLaunchKernelGGL(chamfer_nn_scalar_kernel, grid, dim3(NNS_THREADS), 0, s, job);
+        hipLaunchKernelGGL(chamfer_nn_scalar_kernel<false>, grid, dim3(NNS_THREADS), 0, s, job);
     return geom::launch_status();
 }

@@ -29,6 +29,17 @@ __device__ __forceinline__ float sqdist3(float tx, float ty, float tz, float qx,
     return s + zz;
 }
 
+// The other admissible canonical form (GEOM_FLAG_NN_FMA): what a contracting compiler makes of the same source line
+// -- fma(dz, dz, fma(dx, dx, dy*dy)), bit-identical to the reference's nnsearch built with gcc -mfma
+// -ffp-contract=fast (oracle/_ref/libref_nnsearch_fma.so).  Explicit fmaf: the file is compiled -ffp-contract=off.
+__device__ __forceinline__ float sqdist3_fma(float tx, float ty, float tz, float qx, float qy, float qz)
+{
+    const float dx = tx - qx;
+    const float dy = ty - qy;
+    const float dz = tz - qz;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+}
+
 // lexicographic (distance, index) "is b better than a": what a strict-'<'
 // first-wins sequential scan reduces to when partial scans are merged.
 __device__ __forceinline__ bool lex_less(float bd, int bi, float ad, int ai)

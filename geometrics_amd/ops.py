@@ -8,6 +8,7 @@ import weakref
 import torch
 
 from . import _lib
+from . import chamfer_distance as _chamfer
 from .chamfer_distance import chamfer_nn
 from .tri_distance import face_order, tri_distance_indexed
 
@@ -216,8 +217,8 @@ class SurfaceLoss(torch.autograd.Function):
                 _lib.call("geom_sample_faces_fwd_f32", b, nv, verts_c.data_ptr(), nf, faces.data_ptr(), num,
                           choices.data_ptr(), u.data_ptr(), v.data_ptr(), points.data_ptr())
             _lib.check(L.geom_chamfer_nn_f32(b, n_gt, gt_c.data_ptr(), num, points.data_ptr(), sq_gt.data_ptr(),
-                                             idx_p.data_ptr(), sq_pred.data_ptr(), idx_g.data_ptr(), 0,
-                                             _lib.stream_ptr()), "geom_chamfer_nn_f32")
+                                             idx_p.data_ptr(), sq_pred.data_ptr(), idx_g.data_ptr(),
+                                             _chamfer.default_flags(), _lib.stream_ptr()), "geom_chamfer_nn_f32")
             # the loss reduction is one workgroup; it also zeroes the per-face point counters of the backward's binning
             # pass, which spares the backward a fill launch (used once: a second backward allocates its own)
             bins = None

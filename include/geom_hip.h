@@ -40,6 +40,10 @@ extern "C" {
 #define GEOM_FLAG_FIX_REGION6    2u /* tri: walk option 6 along CA instead of the reference's AB (tri_distance.cu:180, Q2) */
 #define GEOM_FLAG_TRI_BRUTE_FORCE 4u /* tri: evaluate the full decision tree for every pair (no sphere culling);
                                        same result, kept as the in-library cross-check of the culled scan */
+#define GEOM_FLAG_NN_FMA 8u          /* chamfer: the FMA-contracted distance fma(dz,dz,fma(dx,dx,dy*dy)) -- what a contracting
+                                      * compiler (gcc -mfma -ffp-contract=fast; nvcc by default) makes of the reference's source
+                                      * line.  Second pinned arithmetic: bit-identical to the reference nnsearch built
+                                      * that way; distances differ from the default un-fused form by <= 1 ulp-level round-off */
 
 int geom_abi_version(void);
 /* static string for a code returned by any entry point */

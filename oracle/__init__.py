@@ -22,6 +22,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 FLAG_REF_TAIL_TRUNC = 1
 FLAG_FIX_REGION6 = 2
+FLAG_NN_FMA = 8
 
 _f32p = ctypes.POINTER(ctypes.c_float)
 _i32p = ctypes.POINTER(ctypes.c_int)
@@ -35,13 +36,14 @@ def build(force=False):
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference"):
-        ref = os.path.join(_HERE, "_ref", "libref_nnsearch.so")
+        ref = os.path.join(_HERE, "_ref", "libref_nnsearch_fma.so")     # the second product of build_ref.sh
         if force or not os.path.exists(ref):
             subprocess.check_call(["sh", os.path.join(_HERE, "build_ref.sh")], stdout=subprocess.DEVNULL)
 
 
 _lib = None
 _ref = None
+_ref_fma = None
 
 
 def lib():
@@ -50,6 +52,7 @@ def lib():
         build()
         L = ctypes.CDLL(os.path.join(_HERE, "liboracle.so"))
         L.oracle_nn_scan.argtypes = [ctypes.c_int] * 3 + [_f32p, _f32p, _f32p, _i32p]
+        L.oracle_nn_scan_fma.argtypes = [ctypes.c_int] * 3 + [_f32p, _f32p, _f32p, _i32p]
         L.oracle_nn_tiled.argtypes = [ctypes.c_int] * 3 + [_f32p, _f32p, _f32p, _i32p, ctypes.c_uint]
         L.oracle_nn_grad.argtypes = [ctypes.c_int] * 3 + [_f32p] * 4 + [_i32p] * 2 + [_f32p] * 2
         L.oracle_tri_scan.argtypes = [ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_int,
@@ -79,6 +82,28 @@ def ref():
     return _ref
 
 
+def have_ref_fma():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_nnsearch_fma.so")) and _host_has_fma()
+
+
+def _host_has_fma():
+    try:
+        with open("/proc/cpuinfo") as f:
+            return " fma " in f.read().replace("\n", " ")
+    except OSError:
+        return False
+
+
+def ref_fma():
+    """The reference's nnsearch built with -mfma -ffp-contract=fast (needs an FMA-capable host CPU)."""
+    global _ref_fma
+    if _ref_fma is None:
+        R = ctypes.CDLL(os.path.join(_HERE, "_ref", "libref_nnsearch_fma.so"))
+        R.nnsearch.argtypes = [ctypes.c_int] * 3 + [_f32p, _f32p, _f32p, _i32p]
+        _ref_fma = R
+    return _ref_fma
+
+
 def _f(a):
     a = np.ascontiguousarray(a, dtype=np.float32)
     return a, a.ctypes.data_as(_f32p)
@@ -104,13 +129,27 @@ def nn_tiled(query, target, flags=0):
     return _one_way(lib().oracle_nn_tiled, query, target, flags)
 
 
+def nn_scan_fma(query, target):
+    """nn_scan in the FMA-contracted arithmetic (GEOM_FLAG_NN_FMA)."""
+    return _one_way(lib().oracle_nn_scan_fma, query, target)
+
+
 def ref_nnsearch(query, target):
     return _one_way(ref().nnsearch, query, target)
 
 
+def ref_nnsearch_fma(query, target):
+    return _one_way(ref_fma().nnsearch, query, target)
+
+
 def chamfer_nn(xyz1, xyz2, flags=0, use_ref=False):
     """Both directions, argument order of ChamferDistance.forward: (dist1, idx1, dist2, idx2)."""
-    one = ref_nnsearch if use_ref else (nn_scan if flags == 0 else (lambda q, t: nn_tiled(q, t, flags)))
+    if flags & FLAG_NN_FMA:
+        if flags & ~FLAG_NN_FMA:
+            raise ValueError("FLAG_NN_FMA does not combine with the tiled-kernel quirk flags")
+        one = ref_nnsearch_fma if use_ref else nn_scan_fma
+    else:
+        one = ref_nnsearch if use_ref else (nn_scan if flags == 0 else (lambda q, t: nn_tiled(q, t, flags)))
     d1, i1 = one(xyz1, xyz2)
     d2, i2 = one(xyz2, xyz1)
     return d1, i1, d2, i2

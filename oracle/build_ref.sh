@@ -24,3 +24,8 @@ mkdir -p "$HERE/_ref"
 sed -n '/^void nnsearch(/,/^}/p' "$SRC" \
   | gcc -O2 -std=c99 -ffp-contract=off -fPIC -shared -x c - -o "$HERE/_ref/libref_nnsearch.so"
 echo "built $HERE/_ref/libref_nnsearch.so"
+# The same source text with FMA contraction allowed: gcc emits vmulss(dy,dy), vfmadd(dx,dx,.),
+# vfmadd(dz,dz,.) = fma(dz,dz,fma(dx,dx,dy*dy)) -- the arithmetic of GEOM_FLAG_NN_FMA.
+sed -n '/^void nnsearch(/,/^}/p' "$SRC" \
+  | gcc -O2 -std=c99 -mfma -ffp-contract=fast -fPIC -shared -x c - -o "$HERE/_ref/libref_nnsearch_fma.so"
+echo "built $HERE/_ref/libref_nnsearch_fma.so"

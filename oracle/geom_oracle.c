@@ -14,6 +14,8 @@
  *
  * What each function follows (paths relative to the reference checkout):
  *   oracle_nn_scan        old_GEOMetrics/chamfer_distance/src/my_lib.c:4-26   (nnsearch)
+ *   oracle_nn_scan_fma    the same scan in the FMA-contracted arithmetic (what `gcc -mfma -ffp-contract=fast`
+ *                          and nvcc's default make of that source line)
  *   oracle_nn_tiled       chamfer_distance/chamfer_distance.cu:6-55           (tile=512 kernel,
  *                          incl. the tail-truncation quirks Q1/Q3 of lines 29-33,47-50)
  *   oracle_tri_scan       tri_distance/tri_distance.cu:6-91 (helpers), 94-211 (kernel)
@@ -24,11 +26,23 @@
  *     from the reference source where it lies into oracle/_ref/ (build_ref.sh),
  *     on random, tie-heavy and ragged inputs (tests/test_oracle_pin.py, and the
  *     golden vectors in tests/golden/ were emitted by that reference binary).
- *   - oracle_tri_scan has NO executable reference (the only implementation is
- *     the CUDA kernel; no nvcc here).  It is a line-for-line restatement and is
- *     pinned indirectly: the reference's own utils.calc_point_to_line, imported
- *     from the reference checkout, must reproduce dist for the (index, option)
- *     it emits (options 0-5; option 6 differs by the reference's Q2 bug).
+ *   - oracle_nn_scan_fma is pinned the same way against _ref/libref_nnsearch_fma.so,
+ *     the SAME reference source text built with -mfma -ffp-contract=fast.
+ *   - oracle_tri_scan has no executable reference of the kernel itself (CUDA
+ *     only; no nvcc here).  It is a line-for-line restatement, pinned by the
+ *     reference's two OTHER point-to-triangle implementations:
+ *       (i)  utils.calc_point_to_line (utils.py:506-550), imported from the
+ *            reference checkout, reproduces dist for the (index, option) the
+ *            scan emits (options 0-5; option 6 differs by the reference's Q2 bug);
+ *       (ii) the legacy Eberly-region point_to_line
+ *            (old_GEOMetrics/utils.py:734-1026), compiled from the reference file
+ *            where it lies and run in float64, gives the exact point-to-mesh
+ *            squared distance of every query: with GEOM_FLAG_FIX_REGION6 the
+ *            scan equals it for EVERY point (1e-5 rel + 1e-9 abs), which pins
+ *            the region classification, the candidate formulas and the arg-min;
+ *            in quirk mode the scan is never below it and equal wherever the
+ *            same triangle wins outside region 6 (tests/golden/tri_true_*.npz,
+ *            tests/test_oracle_pin.py).
  */
 #include <math.h>
 #include <stddef.h>
@@ -38,6 +52,7 @@
 /* flag bits shared with include/geom_hip.h */
 #define GEOM_FLAG_REF_TAIL_TRUNC 1u /* reproduce Q1/Q3: last (len&3) targets of every 512-tile skipped */
 #define GEOM_FLAG_FIX_REGION6    2u /* use the correct CA delta for option 6 instead of the reference's AB delta (Q2) */
+#define GEOM_FLAG_NN_FMA         8u /* Chamfer scan: the FMA-contracted arithmetic fma(dz,dz,fma(dx,dx,dy*dy)) (Q4) */
 
 #define REF_TILE 512 /* chamfer_distance.cu:15, tri_distance.cu:106 */
 
@@ -55,6 +70,43 @@ static inline float sqdist3(const float *t, float qx, float qy, float qz)
     float zz = dz * dz;
     float s = xx + yy;
     return s + zz;
+}
+
+/* The OTHER admissible canonical form: what a contracting compiler makes of the same source line --
+ * gcc -mfma -ffp-contract=fast turns my_lib.c:13-16 into vmulss(dy,dy); vfmadd(dx,dx,.); vfmadd(dz,dz,.), i.e.
+ * fma(dz, dz, fma(dx, dx, dy*dy)) (checked in the disassembly and bit for bit against that build,
+ * _ref/libref_nnsearch_fma.so from oracle/build_ref.sh; LLVM-based compilers, nvcc included, fold a*a + b*b the
+ * same way: the left product is fused, the right one stays a multiply).  fmaf() is exact
+ * fused multiply-add whether or not the host has the instruction. */
+static inline float sqdist3_fma(const float *t, float qx, float qy, float qz)
+{
+    float dx = t[0] - qx;
+    float dy = t[1] - qy;
+    float dz = t[2] - qz;
+    return fmaf(dz, dz, fmaf(dx, dx, dy * dy));
+}
+
+/* oracle_nn_scan with the FMA-contracted distance (GEOM_FLAG_NN_FMA) */
+void oracle_nn_scan_fma(int b, int n, int m, const float *query, const float *target,
+                        float *dist, int *idx)
+{
+    for (int i = 0; i < b; ++i) {
+        const float *T = target + (size_t)i * m * 3;
+        for (int j = 0; j < n; ++j) {
+            const float *q = query + ((size_t)i * n + j) * 3;
+            float best = 0.0f;
+            int arg = 0;
+            for (int k = 0; k < m; ++k) {
+                float d = sqdist3_fma(T + 3 * k, q[0], q[1], q[2]);
+                if (k == 0 || d < best) {
+                    best = d;
+                    arg = k;
+                }
+            }
+            dist[(size_t)i * n + j] = best;
+            idx[(size_t)i * n + j] = arg;
+        }
+    }
 }
 
 /* Full sequential scan: first target seeds, strict '<' afterwards, so the lowest

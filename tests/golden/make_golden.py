@@ -159,6 +159,23 @@ def make_nn():
          gt_first=np.int64(0), pred_first=np.int64(100), checksum=np.float64(gt.sum() + pr.sum()))
 
 
+def make_nn_fma():
+    """The second pinned arithmetic (GEOM_FLAG_NN_FMA): outputs of the SAME reference nnsearch source built with
+    -mfma -ffp-contract=fast (oracle/_ref/libref_nnsearch_fma.so) on the inputs of every nn_* fixture."""
+    assert oracle.have_ref_fma(), "needs oracle/_ref/libref_nnsearch_fma.so and an FMA-capable host"
+    out = {}
+    for name in sorted(n[:-4] for n in os.listdir(HERE) if n.startswith("nn_") and n.endswith(".npz")):
+        g = dict(np.load(os.path.join(HERE, name + ".npz")))
+        if name == "nn_config2_outputs":
+            a, b = meshgen.gt_cloud(2, 3000, first=int(g["gt_first"])), meshgen.gt_cloud(2, 3000, first=int(g["pred_first"]))
+        else:
+            a, b = g["xyz1"], g["xyz2"]
+        d1, i1, d2, i2 = oracle.chamfer_nn(a, b, oracle.FLAG_NN_FMA, use_ref=True)
+        for k, v in (("idx1", i1), ("idx2", i2), ("dist1", d1), ("dist2", d2)):
+            out[name + "." + k] = v
+    save("nnfma_outputs", **out)
+
+
 # -------------------------------------------------------- sampling + losses ----
 def make_sampling_and_losses():
     V2, F2 = meshgen.icosphere(2)
@@ -425,6 +442,9 @@ if __name__ == "__main__":
     if "--block" in sys.argv:
         make_block()
         sys.exit(0)
+    if "--nn-fma" in sys.argv:
+        make_nn_fma()
+        sys.exit(0)
     if "--tri-true" in sys.argv:
         make_tri_true()
         sys.exit(0)
@@ -432,6 +452,7 @@ if __name__ == "__main__":
     if "--only-new" in sys.argv:
         sys.exit(0)
     make_nn()
+    make_nn_fma()
     make_sampling_and_losses()
     make_adjacency()
     make_layers()

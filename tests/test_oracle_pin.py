@@ -52,6 +52,44 @@ def test_nn_scan_equals_live_reference_binary(seed):
     np.testing.assert_array_equal(bits(d), bits(dr))
 
 
+def _nn_case_inputs(name):
+    g = golden(name)
+    if name == "nn_config2_outputs":
+        return (meshgen.gt_cloud(2, 3000, first=int(g["gt_first"])), meshgen.gt_cloud(2, 3000, first=int(g["pred_first"]))), g
+    return (g["xyz1"], g["xyz2"]), g
+
+
+@pytest.mark.parametrize("name", NN_CASES + ["nn_config2_outputs"])
+def test_nn_fma_arithmetic_matches_the_fma_built_reference_vectors(name):
+    """GEOM_FLAG_NN_FMA, the second pinned arithmetic: oracle_nn_scan_fma against the outputs of the
+    reference's nnsearch built with -mfma -ffp-contract=fast (tests/golden/nnfma_outputs.npz), bit for bit; and the
+    index-equality property between the two arithmetics on every NN fixture (ties on the integer grid are exact in
+    both; random clouds never put two candidates within one rounding of each other)."""
+    (a, b), g = _nn_case_inputs(name)
+    fx = golden("nnfma_outputs")
+    d1, i1, d2, i2 = oracle.chamfer_nn(a, b, oracle.FLAG_NN_FMA)
+    np.testing.assert_array_equal(i1, fx[name + ".idx1"])
+    np.testing.assert_array_equal(i2, fx[name + ".idx2"])
+    np.testing.assert_array_equal(bits(d1), bits(fx[name + ".dist1"]))
+    np.testing.assert_array_equal(bits(d2), bits(fx[name + ".dist2"]))
+    np.testing.assert_array_equal(i1, g["idx1"])            # same winners as the un-fused reference
+    np.testing.assert_array_equal(i2, g["idx2"])
+    np.testing.assert_allclose(d1, g["dist1"], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.skipif(not oracle.have_ref_fma(), reason="oracle/_ref FMA build (or an FMA-capable host) not available")
+@pytest.mark.parametrize("seed", range(4))
+def test_nn_fma_scan_equals_live_fma_built_reference_binary(seed):
+    rng = np.random.default_rng(40 + seed)
+    n, m = int(rng.integers(1, 700)), int(rng.integers(1, 700))
+    a = rng.standard_normal((2, n, 3)).astype(np.float32)
+    b = (rng.integers(-2, 3, (2, m, 3)) if seed % 2 else rng.standard_normal((2, m, 3))).astype(np.float32)
+    d, i = oracle.nn_scan_fma(a, b)
+    dr, ir = oracle.ref_nnsearch_fma(a, b)
+    np.testing.assert_array_equal(i, ir)
+    np.testing.assert_array_equal(bits(d), bits(dr))
+
+
 def test_tail_truncation_quirks():
     rng = np.random.default_rng(0)
     a = rng.standard_normal((1, 50, 3)).astype(np.float32)

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from geometrics_amd import meshgen
-from geometrics_amd._lib import FLAG_FIX_REGION6, FLAG_REF_TAIL_TRUNC, FLAG_TRI_BRUTE_FORCE
+from geometrics_amd._lib import FLAG_FIX_REGION6, FLAG_NN_FMA, FLAG_REF_TAIL_TRUNC, FLAG_TRI_BRUTE_FORCE
 from geometrics_amd.chamfer_distance import ChamferDistance, chamfer_nn
 from geometrics_amd.tri_distance import TriDistance, morton_order, tri_distance, tri_distance_indexed
 
@@ -72,6 +72,52 @@ def test_nn_nan_and_inf_follow_the_sequential_scan(oracle_mod, gpu):
     np.testing.assert_array_equal(i1.cpu().numpy(), j1)
     np.testing.assert_array_equal(i2.cpu().numpy(), j2)
     np.testing.assert_array_equal(np.isnan(d1.cpu().numpy()), np.isnan(e1))
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 500, 500), (2, 3000, 3000), (3, 1, 1), (2, 7, 2466), (2, 63, 65), (4, 300, 4097)])
+def test_nn_fma_arithmetic_random(oracle_mod, gpu, b, n, m):
+    """GEOM_FLAG_NN_FMA: the HIP scan in the contracted arithmetic against oracle_nn_scan_fma (itself bit-identical to
+    the reference nnsearch built with FMA contraction), indices and distances bit for bit."""
+    rng = np.random.default_rng(b * 7 + n * 31 + m)
+    a = rng.standard_normal((b, n, 3)).astype(np.float32)
+    c = rng.standard_normal((b, m, 3)).astype(np.float32)
+    _check_nn(oracle_mod, gpu, a, c, FLAG_NN_FMA)
+
+
+def test_nn_fma_reference_vectors_and_mode_switch(oracle_mod, gpu):
+    from helpers import golden, golden_names
+    from geometrics_amd import chamfer_distance
+    fx = golden("nnfma_outputs")
+    for name in golden_names("nn_"):
+        if name == "nn_config2_outputs":
+            g = golden(name)
+            a, c = meshgen.gt_cloud(2, 3000, first=int(g["gt_first"])), meshgen.gt_cloud(2, 3000, first=int(g["pred_first"]))
+        else:
+            g = golden(name)
+            a, c = g["xyz1"], g["xyz2"]
+        d1, i1, d2, i2 = chamfer_nn(_dev(a, gpu), _dev(c, gpu), FLAG_NN_FMA)
+        np.testing.assert_array_equal(i1.cpu().numpy(), fx[name + ".idx1"])
+        np.testing.assert_array_equal(i2.cpu().numpy(), fx[name + ".idx2"])
+        np.testing.assert_array_equal(d1.cpu().numpy().view(np.uint32), fx[name + ".dist1"].view(np.uint32))
+        np.testing.assert_array_equal(i1.cpu().numpy(), g["idx1"])       # and the un-fused reference's winners
+    # NaN / inf rules are those of the sequential scan in this arithmetic too
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal((1, 70, 3)).astype(np.float32)
+    c = rng.standard_normal((1, 300, 3)).astype(np.float32)
+    c[0, 0, 1], a[0, 3, 0], c[0, 17] = np.nan, np.inf, np.nan
+    d1, i1, d2, i2 = chamfer_nn(_dev(a, gpu), _dev(c, gpu), FLAG_NN_FMA)
+    e1, j1, e2, j2 = oracle_mod.chamfer_nn(a, c, FLAG_NN_FMA)
+    np.testing.assert_array_equal(i1.cpu().numpy(), j1)
+    np.testing.assert_array_equal(i2.cpu().numpy(), j2)
+    # the package-wide switch routes flag-less calls (ChamferDistance, the fused loss) to the FMA kernel
+    chamfer_distance.set_arithmetic("fma")
+    try:
+        d3, i3, _, _ = chamfer_nn(_dev(fx_a := golden("nn_config1")["xyz1"], gpu), _dev(golden("nn_config1")["xyz2"], gpu))
+        np.testing.assert_array_equal(d3.cpu().numpy().view(np.uint32), fx["nn_config1.dist1"].view(np.uint32))
+    finally:
+        chamfer_distance.set_arithmetic("unfused")
+    with pytest.raises(RuntimeError):
+        chamfer_nn(_dev(a, gpu), _dev(c, gpu), FLAG_NN_FMA | FLAG_REF_TAIL_TRUNC)
 
 
 def test_chamfer_module_contract(gpu):

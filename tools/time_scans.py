@@ -37,6 +37,8 @@ def timeit(fn, iters=40, warm=5):
 
 t_nn = timeit(lambda: chamfer_nn(gt, pred))
 t_tri = timeit(lambda: tri_distance_indexed(gt, verts, faces))
+t_nn_fma = timeit(lambda: chamfer_nn(gt, pred, 8))
+print(f"nn fma mode {t_nn_fma:.1f} us")
 pairs_nn = 2 * B * 3000 * 3000
 pairs_tri = B * 3000 * 5120
 print(f"B={B} nn {t_nn:.1f} us ({pairs_nn / t_nn / 1e6:.2f} Tpair/s)  tri {t_tri:.1f} us ({pairs_tri / t_tri / 1e6:.3f} Tpair/s)")
