@@ -306,6 +306,60 @@ def component_times(w):
     return {k: round(v, 1) for k, v in out.items()}
 
 
+def training_shape_times(dev, batch=16):
+    """The shape the reference really trains at (GEOMetrics.py:25,44,50,66-68): batch 16, a 482-vertex / 960-face
+    template with two 32-neighbour poles (meshgen.uv_sphere: same size and degree extremes as 482.obj), 3000 sampled
+    vs 3000 gt points, one deformation block 1155 -> 192 x 13 -> 3 (14 0N-GCN layers + 13 vertex BatchNorms).  One
+    "training-shape step" = block forward -> positions -> batch_point_to_surface -> backward -> Adam (56 tensors);
+    HIP-graph replay bracketed by HIP events.  Reported beside the headline, not instead of it."""
+    from geometrics_amd import models
+    V, Fc = meshgen.uv_sphere()
+    nv = V.shape[0]
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    faces = to(Fc)
+    info = utils.adj_init(faces)
+    base = to(meshgen.jittered_batch(V, batch, first=500))
+    gt = to(meshgen.gt_cloud(batch, G_PTS, first=500))
+    torch.manual_seed(3041)
+    block = models.BatchMeshDeformationBlock(1155, nv).to(dev).train()
+    feats = torch.randn(batch, nv, 3, device=dev, requires_grad=True)
+    pooled = torch.randn(batch, nv, 1152, device=dev, requires_grad=True)
+    params = list(block.parameters())
+    opt = optim.FusedAdam(params, lr=1e-4)
+    csr = layers.adjacency_csr(info["adj"])
+
+    def step():
+        opt.zero_grad()
+        feats.grad = pooled.grad = None
+        f, coords = block(feats, pooled, info["adj"])
+        loss = utils.batch_point_to_surface(base + coords, info, gt, num=S_PTS)
+        loss.backward()
+        opt.step()
+
+    def block_only():
+        opt.zero_grad()
+        feats.grad = pooled.grad = None
+        f, coords = block(feats, pooled, info["adj"])
+        (f.sum() + coords.sum()).backward()
+
+    pos = base.clone().requires_grad_(True)
+
+    def loss_only():
+        pos.grad = None
+        utils.batch_point_to_surface(pos, info, gt, num=S_PTS).backward()
+
+    t_step = event_time_us(step, iters=5, warm=3)
+    t_block = event_time_us(block_only, iters=5, warm=2)
+    t_loss = event_time_us(loss_only, iters=10, warm=2)
+    return {"workload": "reference training shape: batch %d, %d vertices / %d faces (rows of up to %d adjacency entries), "
+                        "deformation block 1155-192x13-3 fwd+bwd + surface loss (3000 vs 3000 points) + Adam"
+                        % (batch, nv, Fc.shape[0], int((csr.rowptr[1:] - csr.rowptr[:-1]).max())),
+            "step_us": round(t_step, 1), "meshes_per_s": round(batch / (t_step * 1e-6), 1),
+            "deformation_block_fwd_bwd_us": round(t_block, 1), "surface_loss_fwd_bwd_us": round(t_loss, 1),
+            "aggregation_kernel": "ELL table width %d%s" % (csr.ell_w, " + CSR tail for the long rows" if csr.over else "")
+                                  if csr.ell_w else "generic CSR"}
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -429,6 +483,7 @@ def main():
             line["other_kernels"] = others
         if world == 1 and not args.steps_only:
             line["components_us"] = component_times(w)
+            line["reference_training_shape"] = training_shape_times(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

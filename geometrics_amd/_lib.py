@@ -39,6 +39,9 @@ _SIGNATURES = {
     "geom_surface_loss_bwd_gather_f32": [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                          _f, _f, _vp, _vp, _vp, _vp],
     "geom_surface_loss_bwd_f32": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp],
+    "geom_surface_finalize_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i,
+                                  _vp, _vp, _vp],
+    "geom_surface_gather_f32": [_i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "geom_vertex_head_fwd_f32": [ctypes.c_int64, _i, _vp, _vp, _f, _vp, _vp],
     "geom_vertex_head_bwd_f32": [ctypes.c_int64, _i, _vp, _f, _vp, _vp],
     "geom_sample_faces_fwd_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
@@ -60,8 +63,8 @@ _SIGNATURES = {
     "geom_pool_features_bwd_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "geom_adam_step_f32": [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _i, _vp],
     "geom_zn_gcn_aggregate_fwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
-    "geom_zn_gcn_aggregate_ell_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
-    "geom_zn_gcn_aggregate_ell_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "geom_zn_gcn_aggregate_ell_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "geom_zn_gcn_aggregate_ell_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "geom_zn_gcn_aggregate_bwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
 }
 
@@ -102,6 +105,8 @@ def lib():
         L.geom_surface_bin_count_words.argtypes = [_i, _i]
         L.geom_surface_bin_list_words.restype = ctypes.c_int64
         L.geom_surface_bin_list_words.argtypes = [_i, _i, _i, _i]
+        L.geom_surface_order_words.restype = ctypes.c_int64
+        L.geom_surface_order_words.argtypes = [_i, _i, _i, _i]
         L.geom_zn_gcn_relu_mask_words.restype = ctypes.c_int64
         L.geom_zn_gcn_relu_mask_words.argtypes = [_i, _i, _i, _i]
         L.geom_zn_gcn_bwd_scratch_floats.argtypes = [_i, _i, _i]
@@ -119,7 +124,7 @@ def declared_symbols():
     return sorted(["geom_abi_version", "geom_strerror", "geom_tri_distance_workspace_bytes",
                    "geom_zn_gcn_bwd_scratch_floats", "geom_pool_features_bwd_workspace_bytes",
                    "geom_segment_max_workspace_bytes", "geom_zn_gcn_relu_mask_words",
-                   "geom_surface_bin_count_words", "geom_surface_bin_list_words"] + list(_SIGNATURES))
+                   "geom_surface_bin_count_words", "geom_surface_bin_list_words", "geom_surface_order_words"] + list(_SIGNATURES))
 
 
 def check(code, what):

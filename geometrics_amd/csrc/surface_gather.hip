@@ -4,18 +4,22 @@
 //
 // The scatter formulation (sample_loss.hip: one thread per point, nine fp32 atomics into a zeroed grad_verts) costs
 // 26 us for 432 000 atomics at the BASELINE shard, needs a zero-fill, and adds in arrival order, so the last bits of
-// the gradient change from run to run.  Here:
+// the gradient change from run to run.  Here the points are counting-sorted by face:
 //   bin     one thread per point: its gradient vector (point - partner) * coefficient and its three corner weights are
 //           computed here, fully parallel and coalesced, and stored as two float4 records; slot =
-//           atomicAdd(count[mesh][face], 1) (integer, 48 000 of them, almost no contention) and the point's id goes
-//           into a BIN_CAP-slot list of that face;
-//   gather  eight lanes per (mesh, vertex), one incident (face, corner) each -- a static CSR built once per face
-//           list: read the face's list, take its ids in ascending order and accumulate their gradients with this
-//           corner's barycentric weight; the lanes' partial sums are folded in lane order.  Points beyond a face's slots go to a per-mesh overflow list; a face that has some is
-//           summed by repeatedly extracting the next-larger id from (its list + the overflow list), or -- when that
-//           would cost more -- by an ordered scan of all the mesh's points.  Either way: exact, and in id order.
+//           atomicAdd(count[mesh][face], 1) (integer, almost no contention) is remembered per point;
+//   order   one workgroup per mesh, everything in LDS: exclusive scan of the face counts -> offsets; every point id is
+//           dropped at offset[face] + slot; every face's segment is then put in ASCENDING ID ORDER (arrival order is
+//           not reproducible, id order is) by ranking every id against its segment.  Any distribution is handled
+//           exactly -- 1.2 points per face on the 5120-face
+//           BASELINE mesh, 6 on average and dozens on the large faces of the reference's 960-face training template
+//           (the first version kept 16 slots per face plus an overflow list and fell back to scanning all of a mesh's
+//           points per (face, corner): 691 us per call at that shape, 20 us here);
+//   gather  eight lanes per (mesh, vertex), one incident (face, corner) each from a static CSR built once per face
+//           list: walk the face's segment, eight records in flight, accumulate with this corner's barycentric weight;
+//           the lanes' partial sums are folded in lane order.
 // grad_verts is written once per element (no zero-fill, no float atomics) and is bit-reproducible.
-// The per-face counters must be zero on entry (the forward's reduction launch clears them, see geom_sum2_f32).
+// The per-face counters must be zero on entry; the order pass leaves them zero again.
 #include "geom_common.h"
 #include "tri_math.h"
 
@@ -24,9 +28,10 @@ namespace {
 using geom::V3;
 
 constexpr int SGA_THREADS = 256;
-constexpr int BIN_CAP = 16;
-constexpr int VTX_LANES = 8;  // lanes that share a vertex in the gather: one incident face each, then an ordered fold
-constexpr int OVERFLOW_CAP = 2048; // per mesh
+constexpr int ORD_THREADS = 1024;
+constexpr int ORD_WAVES = ORD_THREADS / GEOM_WAVE;
+constexpr int VTX_LANES = 8;    // lanes that share a vertex in the gather: one incident face each, then an ordered fold
+constexpr size_t ORD_LDS_LIMIT = 150 * 1024;
 
 enum { OTHER_NONE = 0, OTHER_NN = 1, OTHER_TRI = 2 };
 
@@ -41,28 +46,23 @@ struct GatherArgs {
     const float *closest, *weights; // [b,n_gt,3] (OTHER_TRI)
     const float *coef_dev;
     float coef_sample, coef_other;
-    int b, nv, nf, num, n_gt, other;
-    int *counts; // [b,nf] points per face, then [b] overflow entries per mesh
-    int *lists;  // [b,nf,BIN_CAP] point ids, then [b,OVERFLOW_CAP,2] (face, id) pairs, then the point records
-    float4 *rec; // [b, num + n_gt, 2]: {gradient vector, skip-zero-weights flag}, {w0, w1, w2, -}
+    int b, nv, nf, num, n_gt, other, per; // per = points per mesh that take part (num [+ n_gt])
+    int *counts; // [b,nf]     points per face (zero on entry, zero again after the order pass)
+    int *off;    // [b,nf+1]   exclusive offsets of the face segments
+    int *slot;   // [b,per]    arrival rank of the point inside its face
+    int *pface;  // [b,per]    face of the point, -1 = none
+    int *seg;    // [b,per]    point ids, face by face, ascending inside a face
+    float4 *rec; // [b,per,2]  {gradient vector, skip-zero-weights flag}, {w0, w1, w2, -}
     float *grad_verts;
 };
 
 __device__ __forceinline__ V3 ld3(const float *p) { return geom::mk(p[0], p[1], p[2]); }
 
-// face a gt point contributes to
-__device__ __forceinline__ int64_t other_face(const GatherArgs &a, int mesh, int g)
-{
-    const int64_t o = (int64_t)mesh * a.n_gt + g;
-    return a.other == OTHER_NN ? a.choices[(int64_t)mesh * a.num + a.idx_p[o]] : (int64_t)a.index[o];
-}
-
 __global__ __launch_bounds__(SGA_THREADS) void surface_bin_kernel(GatherArgs a)
 {
-    const int per = a.num + (a.other != OTHER_NONE ? a.n_gt : 0);
     const int64_t i = (int64_t)blockIdx.x * SGA_THREADS + threadIdx.x;
-    if (i >= (int64_t)a.b * per) return;
-    const int mesh = (int)(i / per), id = (int)(i - (int64_t)mesh * per);
+    if (i >= (int64_t)a.b * a.per) return;
+    const int mesh = (int)(i / a.per), id = (int)(i - (int64_t)mesh * a.per);
     const float scale = 2.f * (a.coef_dev ? a.coef_dev[0] : 1.f);
     // the point's gradient vector and corner weights, exactly as the scatter kernels form them
     int64_t f, sp = -1;
@@ -92,118 +92,97 @@ __global__ __launch_bounds__(SGA_THREADS) void surface_bin_kernel(GatherArgs a)
     }
     a.rec[2 * i + 0] = make_float4(g.x, g.y, g.z, skip_zero);
     a.rec[2 * i + 1] = w;
-    if (f < 0 || f >= a.nf) return; // not a face of this mesh: contributes nowhere (the scatter would have faulted)
-    const int64_t bin = (int64_t)mesh * a.nf + f;
-    const int slot = atomicAdd(&a.counts[bin], 1);
-    if (slot < BIN_CAP) {
-        a.lists[bin * BIN_CAP + slot] = id;
-    } else {
-        const int k = atomicAdd(&a.counts[(int64_t)a.b * a.nf + mesh], 1);
-        if (k < OVERFLOW_CAP) {
-            int *ov = a.lists + (int64_t)a.b * a.nf * BIN_CAP + ((int64_t)mesh * OVERFLOW_CAP + k) * 2;
-            ov[0] = (int)f;
-            ov[1] = id;
-        }
+    const bool on_mesh = f >= 0 && f < a.nf; // else: contributes nowhere (the scatter would have faulted)
+    a.pface[i] = on_mesh ? (int)f : -1;
+    if (on_mesh) a.slot[i] = atomicAdd(&a.counts[(int64_t)mesh * a.nf + f], 1);
+}
+
+// One workgroup per mesh.  LDS: off[nf+1] | seg[per] | wave totals.
+__global__ __launch_bounds__(ORD_THREADS) void surface_order_kernel(GatherArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) int ord_lds[];
+    int *off = ord_lds;
+    int *seg = off + (a.nf + 1);
+    int *wave_total = seg + a.per;   // [ORD_WAVES]
+    const int mesh = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & (GEOM_WAVE - 1), wave = tid >> 6;
+    int *counts = a.counts + (int64_t)mesh * a.nf;
+
+    // ---- exclusive scan of the face counts (consecutive faces per thread), counters re-armed on the way ----
+    const int chunk = (a.nf + ORD_THREADS - 1) / ORD_THREADS;
+    const int f0 = min(a.nf, tid * chunk), f1 = min(a.nf, f0 + chunk);
+    int run = 0;
+    for (int f = f0; f < f1; ++f) {
+        const int c = counts[f];
+        counts[f] = 0;
+        off[f] = run; // local exclusive prefix, completed below
+        run += c;
+    }
+    int incl = run;
+    for (int d = 1; d < GEOM_WAVE; d <<= 1) {
+        const int t = __shfl_up(incl, d, GEOM_WAVE);
+        if (lane >= d) incl += t;
+    }
+    if (lane == GEOM_WAVE - 1) wave_total[wave] = incl;
+    __syncthreads();
+    int base = incl - run;
+    for (int w = 0; w < wave; ++w) base += wave_total[w];
+    for (int f = f0; f < f1; ++f) off[f] += base;
+    if (tid == ORD_THREADS - 1) off[a.nf] = base + run;
+    __syncthreads();
+    int *g_off = a.off + (int64_t)mesh * (a.nf + 1);
+    for (int f = tid; f <= a.nf; f += ORD_THREADS) g_off[f] = off[f];
+
+    // ---- every point id at offset[face] + arrival slot ----
+    const int64_t p0 = (int64_t)mesh * a.per;
+    for (int i = tid; i < a.per; i += ORD_THREADS) {
+        const int f = a.pface[p0 + i];
+        if (f >= 0) seg[off[f] + a.slot[p0 + i]] = i;
+    }
+    __syncthreads();
+
+    // ---- ascending ids inside every face.  One thread per POINT: its rank among the ids of its face's segment (ids
+    //      are distinct, so the ranks are a permutation) is where it goes.  The segment is read from LDS with
+    //      independent loads -- no dependent chain, whatever the segment length (an insertion sort per face was
+    //      measured first: 42 us for the order pass, all of it LDS latency in the sort's inner loop). ----
+    int *g_seg = a.seg + p0;
+    for (int i = tid; i < a.per; i += ORD_THREADS) {
+        const int f = a.pface[p0 + i];
+        if (f < 0) continue;
+        const int s0 = off[f], n = off[f + 1] - s0;
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += seg[s0 + j] < i ? 1 : 0;
+        g_seg[s0 + rank] = i;
     }
 }
 
-// gradient contribution of point `id` of `mesh` to corner c of its face, from the records of the bin pass
+// gradient contribution of a point to corner c of its face, from the records of the bin pass
 __device__ __forceinline__ V3 apply_record(float4 g, float4 w, int c)
 {
     const float wc = c == 0 ? w.x : (c == 1 ? w.y : w.z);
     if (g.w != 0.f && wc == 0.f) return geom::mk(0.f, 0.f, 0.f);
     return geom::mk(g.x, g.y, g.z) * wc;
 }
-__device__ __forceinline__ V3 contribution(const GatherArgs &a, int mesh, int id, int c)
-{
-    const int64_t i = (int64_t)mesh * (a.num + (a.other != OTHER_NONE ? a.n_gt : 0)) + id;
-    return apply_record(a.rec[2 * i], a.rec[2 * i + 1], c);
-}
-
-__device__ __forceinline__ void order2(int &x, int &y)
-{
-    const int lo = min(x, y), hi = max(x, y);
-    x = lo;
-    y = hi;
-}
 
 // sum of the contributions of the points on face f to its corner c, in ascending point-id order
 __device__ __forceinline__ V3 face_sum(const GatherArgs &a, int mesh, int f, int c)
 {
     V3 acc = geom::mk(0.f, 0.f, 0.f);
-    const int64_t bin = (int64_t)mesh * a.nf + f;
-    const int n = a.counts[bin];
-    if (n == 0) return acc;
-    const int *list = a.lists + bin * BIN_CAP;
-    const int64_t per = a.num + (a.other != OTHER_NONE ? a.n_gt : 0);
-    const float4 *rec = a.rec + 2 * (int64_t)mesh * per;
-    if (n <= 4) { // the usual case (1.2 points per face on average): ids, 4-element network, records in one round trip
-        int id[4];
+    const int *off = a.off + (int64_t)mesh * (a.nf + 1);
+    const int s0 = off[f], n = off[f + 1] - s0;
+    const int *ids = a.seg + (int64_t)mesh * a.per + s0;
+    const float4 *rec = a.rec + 2 * (int64_t)mesh * a.per;
+    for (int h = 0; h < n; h += 8) { // eight records in flight per round trip
+        int id[8];
+        float4 g[8], w[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) id[k] = k < n ? list[k] : INT_MAX;
-        order2(id[0], id[1]), order2(id[2], id[3]), order2(id[0], id[2]), order2(id[1], id[3]), order2(id[1], id[2]);
-        float4 g[4], w[4];
+        for (int k = 0; k < 8; ++k) id[k] = h + k < n ? ids[h + k] : 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k < n) g[k] = rec[2 * id[k]], w[k] = rec[2 * id[k] + 1];
+        for (int k = 0; k < 8; ++k)
+            if (h + k < n) g[k] = rec[2 * id[k]], w[k] = rec[2 * id[k] + 1];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k < n) acc = acc + apply_record(g[k], w[k], c);
-        return acc;
-    }
-    if (n <= BIN_CAP) { // up to 16 points: Batcher's odd-even merge network on registers, records eight at a time
-        int id[BIN_CAP];
-#pragma unroll
-        for (int k = 0; k < BIN_CAP; ++k) id[k] = k < n ? list[k] : INT_MAX;
-#pragma unroll
-        for (int p = 1; p < BIN_CAP; p <<= 1)
-#pragma unroll
-            for (int k = p; k >= 1; k >>= 1)
-#pragma unroll
-                for (int j = k % p; j <= BIN_CAP - 1 - k; j += 2 * k)
-#pragma unroll
-                    for (int i = 0; i < (k < BIN_CAP - j - k ? k : BIN_CAP - j - k); ++i)
-                        if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) order2(id[i + j], id[i + j + k]);
-#pragma unroll
-        for (int h = 0; h < BIN_CAP; h += 8) {
-            if (h >= n) break;
-            float4 g[8], w[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (h + k < n) g[k] = rec[2 * id[h + k]], w[k] = rec[2 * id[h + k] + 1];
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (h + k < n) acc = acc + apply_record(g[k], w[k], c);
-        }
-        return acc;
-    }
-    const int n_ov = a.counts[(int64_t)a.b * a.nf + mesh];
-    const int *ov = a.lists + (int64_t)a.b * a.nf * BIN_CAP + (int64_t)mesh * OVERFLOW_CAP * 2;
-    if (n_ov <= OVERFLOW_CAP && (int64_t)n * (BIN_CAP + n_ov) <= per) {
-        // repeatedly take the next-larger id among the face's slots (+ the mesh's overflow entries when the face
-        // has more points than slots): the arrival order in the lists is not reproducible, the id order is
-        const int listed = BIN_CAP;
-        int last = -1;
-        for (int t = 0; t < n; ++t) {
-            int best = INT_MAX;
-            for (int k = 0; k < listed; ++k) {
-                const int id = list[k];
-                if (id > last && id < best) best = id;
-            }
-            for (int k = 0; k < n_ov; ++k)
-                if (ov[2 * k] == f) {
-                    const int id = ov[2 * k + 1];
-                    if (id > last && id < best) best = id;
-                }
-            acc = acc + contribution(a, mesh, best, c);
-            last = best;
-        }
-    } else { // crowded mesh: one ordered pass over all of its points is cheaper (and needs no lists)
-        for (int s = 0; s < a.num; ++s)
-            if (a.choices[(int64_t)mesh * a.num + s] == f) acc = acc + contribution(a, mesh, s, c);
-        if (a.other != OTHER_NONE)
-            for (int g = 0; g < a.n_gt; ++g)
-                if (other_face(a, mesh, g) == f) acc = acc + contribution(a, mesh, a.num + g, c);
+        for (int k = 0; k < 8; ++k)
+            if (h + k < n) acc = acc + apply_record(g[k], w[k], c);
     }
     return acc;
 }
@@ -241,15 +220,268 @@ __global__ __launch_bounds__(SGA_THREADS) void surface_gather_kernel(GatherArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Forward-side FINALIZE: one launch after the two scans that (a) reduces the loss, (b) prepares the backward.
+//
+// One workgroup per mesh (1024 threads), everything that is shared in LDS:
+//   * every thread takes its points (ids tid, tid + 1024, ...), forms their gradient records -- (point - partner) *
+//     coefficient and the three corner weights, two float4 per point -- and counts them into their face with an LDS
+//     atomic, remembering the arrival slot;
+//   * exclusive scan of the face counts -> offsets; ids dropped at offset + slot; every id is then ranked against its
+//     face's segment (LDS, independent loads) and written to its ASCENDING place: the order the gather adds in is a
+//     function of the data only, never of timing;
+//   * one more workgroup reduces the two loss sums (fixed tree) meanwhile.
+// The backward is then ONE launch (surface_vertex_gather_kernel).  Compared with binning in the backward (bin ->
+// order -> gather, plus a one-workgroup loss reduction in the forward) this removes two launches and every global atomic.
+struct FinalizeArgs {
+    const int64_t *choices;
+    const float *u, *v, *points, *gt;
+    const int *idx_g, *idx_p, *index;
+    const float *closest, *weights;
+    const float *sq_sample, *sq_other; // [b,num], [b,n_gt]: the squared distances the loss sums
+    float scale_sample, scale_other;   // loss = scale_sample * sum(sq_sample) + scale_other * sum(sq_other)
+    float coef_sample, coef_other;     // gradient coefficients of the two kinds of points (without 2 * upstream grad)
+    int b, nf, num, n_gt, other, per, want_order;
+    int *off, *seg, *pface, *slot;
+    float4 *rec;
+    float *loss;
+};
+
+constexpr int FIN_ITEMS = 8; // points per thread kept in registers (per <= 8192); beyond: through the pface / slot scratch
+
+__device__ __forceinline__ float block_sum_1024(float v, float *lds16, int tid)
+{
+    for (int d = GEOM_WAVE / 2; d > 0; d >>= 1) v += __shfl_down(v, d, GEOM_WAVE);
+    __syncthreads();
+    if ((tid & (GEOM_WAVE - 1)) == 0) lds16[tid >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (tid < GEOM_WAVE) {
+        t = tid < ORD_WAVES ? lds16[tid] : 0.f;
+        for (int d = GEOM_WAVE / 2; d > 0; d >>= 1) t += __shfl_down(t, d, GEOM_WAVE);
+    }
+    return t; // valid in thread 0
+}
+
+template <bool REGS>
+__global__ __launch_bounds__(ORD_THREADS) void surface_finalize_kernel(FinalizeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) int ord_lds[];
+    int *off = ord_lds;                       // [nf+1]: counts, then offsets
+    int *seg = off + (a.nf + 1);              // [per]
+    int *wave_total = seg + (a.want_order ? a.per : 0);
+    float *fsum = reinterpret_cast<float *>(wave_total + ORD_WAVES);
+    const int mesh = a.want_order ? blockIdx.x : a.b, tid = threadIdx.x; // without ordering the grid is the loss workgroup alone
+    const int lane = tid & (GEOM_WAVE - 1), wave = tid >> 6;
+
+    // ---- the extra workgroup (blockIdx.x == b) reduces the loss while the others order their meshes: float4 loads, all
+    //      of a thread's loads in flight together, then a fixed tree -- no cross-workgroup hand-off at all ----
+    if (mesh == a.b) {
+        auto thread_sum = [&](const float *x, int64_t n) {
+            float acc = 0.f;
+            const bool vec = (((uintptr_t)x) & 15) == 0;
+            const int64_t n4 = vec ? n / 4 : 0;
+            const float4 *x4 = reinterpret_cast<const float4 *>(x);
+            for (int64_t base = 0; base < n4; base += (int64_t)8 * ORD_THREADS) {
+                float4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int64_t i = base + tid + (int64_t)k * ORD_THREADS;
+                    v[k] = i < n4 ? x4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+            }
+            for (int64_t i = 4 * n4 + tid; i < n; i += ORD_THREADS) acc += x[i];
+            return acc;
+        };
+        float s1 = thread_sum(a.sq_sample, (int64_t)a.b * a.num), s2 = thread_sum(a.sq_other, (int64_t)a.b * a.n_gt);
+        s1 = block_sum_1024(s1, fsum, tid);
+        s2 = block_sum_1024(s2, fsum + ORD_WAVES, tid);
+        if (tid == 0) a.loss[0] = s1 * a.scale_sample + s2 * a.scale_other;
+        return;
+    }
+
+    if (a.want_order) {
+        for (int f = tid; f <= a.nf; f += ORD_THREADS) off[f] = 0;
+        __syncthreads();
+        const int64_t p0 = (int64_t)mesh * a.per;
+        // record of point `id` -> global, its face counted in LDS; returns the face (-1: none) and the arrival slot
+        auto bin_point = [&](int id, int &fi, int &sl) {
+            int64_t f, sp = -1;
+            V3 g;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            float skip_zero = 0.f;
+            if (id < a.num) {
+                sp = (int64_t)mesh * a.num + id;
+                f = a.choices[sp];
+                g = (ld3(a.points + 3 * sp) - ld3(a.gt + 3 * ((int64_t)mesh * a.n_gt + a.idx_g[sp]))) * a.coef_sample;
+            } else {
+                const int64_t o = (int64_t)mesh * a.n_gt + (id - a.num);
+                if (a.other == OTHER_TRI) {
+                    f = a.index[o];
+                    g = (ld3(a.closest + 3 * o) - ld3(a.gt + 3 * o)) * a.coef_other;
+                    w = make_float4(a.weights[3 * o], a.weights[3 * o + 1], a.weights[3 * o + 2], 0.f);
+                    skip_zero = 1.f; // the scatter does not touch a corner whose weight is exactly zero
+                } else {
+                    sp = (int64_t)mesh * a.num + a.idx_p[o];
+                    f = a.choices[sp];
+                    g = (ld3(a.points + 3 * sp) - ld3(a.gt + 3 * o)) * a.coef_other;
+                }
+            }
+            if (sp >= 0) {
+                const float u = a.u[sp], v = a.v[sp];
+                w = make_float4(1.f - u, u * (1.f - v), u * v, 0.f);
+            }
+            a.rec[2 * (p0 + id) + 0] = make_float4(g.x, g.y, g.z, skip_zero);
+            a.rec[2 * (p0 + id) + 1] = w;
+            const bool on_mesh = f >= 0 && f < a.nf; // else: contributes nowhere
+            fi = on_mesh ? (int)f : -1;
+            sl = on_mesh ? atomicAdd(&off[fi], 1) : 0; // LDS atomic: arrival slot inside the face
+        };
+        int my_f[FIN_ITEMS], my_slot[FIN_ITEMS];
+        if (REGS) {
+#pragma unroll
+            for (int it = 0; it < FIN_ITEMS; ++it) {
+                const int id = tid + it * ORD_THREADS;
+                my_f[it] = -1, my_slot[it] = 0;
+                if (id < a.per) bin_point(id, my_f[it], my_slot[it]);
+            }
+        } else {
+            for (int id = tid; id < a.per; id += ORD_THREADS) {
+                int fi, sl;
+                bin_point(id, fi, sl);
+                a.pface[p0 + id] = fi;
+                a.slot[p0 + id] = sl;
+            }
+        }
+        __syncthreads();
+        // ---- exclusive scan of the counts (consecutive faces per thread) ----
+        const int chunk = (a.nf + ORD_THREADS - 1) / ORD_THREADS;
+        const int f0 = min(a.nf, tid * chunk), f1 = min(a.nf, f0 + chunk);
+        int run = 0;
+        for (int f = f0; f < f1; ++f) {
+            const int c = off[f];
+            off[f] = run;
+            run += c;
+        }
+        int incl = run;
+        for (int d = 1; d < GEOM_WAVE; d <<= 1) {
+            const int t = __shfl_up(incl, d, GEOM_WAVE);
+            if (lane >= d) incl += t;
+        }
+        if (lane == GEOM_WAVE - 1) wave_total[wave] = incl;
+        __syncthreads();
+        int base = incl - run;
+        for (int w = 0; w < wave; ++w) base += wave_total[w];
+        for (int f = f0; f < f1; ++f) off[f] += base;
+        if (tid == ORD_THREADS - 1) off[a.nf] = base + run;
+        __syncthreads();
+        int *g_off = a.off + (int64_t)mesh * (a.nf + 1);
+        for (int f = tid; f <= a.nf; f += ORD_THREADS) g_off[f] = off[f];
+        // ---- ids at offset + slot, then ranked into ascending order ----
+        if (REGS) {
+#pragma unroll
+            for (int it = 0; it < FIN_ITEMS; ++it)
+                if (my_f[it] >= 0) seg[off[my_f[it]] + my_slot[it]] = tid + it * ORD_THREADS;
+        } else {
+            for (int id = tid; id < a.per; id += ORD_THREADS) {
+                const int f = a.pface[p0 + id];
+                if (f >= 0) seg[off[f] + a.slot[p0 + id]] = id;
+            }
+        }
+        __syncthreads();
+        int *g_seg = a.seg + p0;
+        auto place = [&](int id, int f) {
+            const int s0 = off[f], n = off[f + 1] - s0;
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += seg[s0 + j] < id ? 1 : 0;
+            g_seg[s0 + rank] = id;
+        };
+        if (REGS) {
+#pragma unroll
+            for (int it = 0; it < FIN_ITEMS; ++it)
+                if (my_f[it] >= 0) place(tid + it * ORD_THREADS, my_f[it]);
+        } else {
+            for (int id = tid; id < a.per; id += ORD_THREADS) {
+                const int f = a.pface[p0 + id];
+                if (f >= 0) place(id, f);
+            }
+        }
+    }
+
+}
+
+struct VGatherArgs {
+    const int *vf_ptr, *vf_item;
+    const int *off, *seg;
+    const float4 *rec;
+    const float *grad; // upstream gradient of the loss (device scalar), may be null (= 1)
+    float *grad_verts;
+    int nv, nf, per;
+};
+
+// The backward: eight lanes per (mesh, vertex), one incident (face, corner) each; a face's segment is walked in its
+// stored (ascending id) order, eight records in flight; lanes folded in lane order; result scaled by 2 * upstream.
+__global__ __launch_bounds__(SGA_THREADS) void surface_vertex_gather_kernel(VGatherArgs a)
+{
+    const int t = blockIdx.x * SGA_THREADS + threadIdx.x;
+    const int vtx = t / VTX_LANES, j = t % VTX_LANES;
+    const int mesh = blockIdx.y;
+    const bool live = vtx < a.nv;
+    V3 acc = geom::mk(0.f, 0.f, 0.f);
+    if (live) {
+        const int *off = a.off + (int64_t)mesh * (a.nf + 1);
+        const int *seg = a.seg + (int64_t)mesh * a.per;
+        const float4 *rec = a.rec + 2 * (int64_t)mesh * a.per;
+        const int e1 = a.vf_ptr[vtx + 1];
+        for (int e = a.vf_ptr[vtx] + j; e < e1; e += VTX_LANES) {
+            const int item = a.vf_item[e];
+            const int f = item >> 2, c = item & 3;
+            const int s0 = off[f], n = off[f + 1] - s0;
+            for (int h = 0; h < n; h += 8) {
+                int id[8];
+                float4 g[8], w[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) id[k] = h + k < n ? seg[s0 + h + k] : 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (h + k < n) g[k] = rec[2 * id[k]], w[k] = rec[2 * id[k] + 1];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (h + k < n) acc = acc + apply_record(g[k], w[k], c);
+            }
+        }
+    }
+    V3 total = acc;
+#pragma unroll
+    for (int k = 1; k < VTX_LANES; ++k) {
+        const V3 other = geom::mk(__shfl_down(acc.x, k, VTX_LANES), __shfl_down(acc.y, k, VTX_LANES),
+                                  __shfl_down(acc.z, k, VTX_LANES));
+        total = total + other;
+    }
+    if (live && j == 0) {
+        const float s = 2.f * (a.grad ? a.grad[0] : 1.f);
+        float *G = a.grad_verts + ((int64_t)mesh * a.nv + vtx) * 3;
+        G[0] = total.x * s;
+        G[1] = total.y * s;
+        G[2] = total.z * s;
+    }
+}
+
+inline size_t order_lds_bytes(int nf, int per) { return ((size_t)nf + 1 + per + ORD_WAVES + 4) * sizeof(int); }
+
 } // namespace
 
-// ints needed behind `counts` / `lists` for a batch of b meshes of nf faces
-extern "C" int64_t geom_surface_bin_count_words(int b, int nf) { return b <= 0 || nf < 0 ? 0 : (int64_t)b * nf + b; }
-// (rounded up to a multiple of 4 so that the float4 point records behind the lists stay 16-byte aligned)
-static inline int64_t list_words(int b, int nf) { return (((int64_t)b * nf * BIN_CAP + (int64_t)b * OVERFLOW_CAP * 2) + 3) & ~3ll; }
+// int32 words behind `counts` (zero on entry) and `lists` (scratch) for a batch of b meshes of nf faces
+extern "C" int64_t geom_surface_bin_count_words(int b, int nf) { return b <= 0 || nf < 0 ? 0 : (int64_t)b * nf; }
+// off [b,nf+1] | slot, pface, seg [b,per] each (rounded up so that the float4 point records behind stay 16-byte aligned)
+static inline int64_t list_words(int b, int nf, int64_t per) { return (((int64_t)b * (nf + 1) + 3 * (int64_t)b * per) + 3) & ~3ll; }
 extern "C" int64_t geom_surface_bin_list_words(int b, int nf, int num, int n_gt)
 {
-    return b <= 0 || nf < 0 || num < 0 || n_gt < 0 ? 0 : list_words(b, nf) + (int64_t)b * (num + n_gt) * 8;
+    if (b <= 0 || nf < 0 || num < 0 || n_gt < 0) return 0;
+    const int64_t per = (int64_t)num + n_gt;
+    return list_words(b, nf, per) + (int64_t)b * per * 8;
 }
 
 extern "C" int geom_surface_loss_bwd_gather_f32(int b, int nv, int nf, const int *vf_ptr, const int *vf_item, int num,
@@ -268,15 +500,108 @@ extern "C" int geom_surface_loss_bwd_gather_f32(int b, int nv, int nf, const int
     if (idx_p && (!gt || num == 0)) return GEOM_EINVAL;
     if (b > 65535) return GEOM_ETOOBIG;
     if ((uintptr_t)lists & 15) return GEOM_EINVAL;
+    const int other = idx_p ? OTHER_NN : (index ? OTHER_TRI : OTHER_NONE);
+    const int64_t per64 = (int64_t)num + (other != OTHER_NONE ? n_gt : 0);
+    if (per64 > 0x3fffffff) return GEOM_ETOOBIG;
+    const int per = (int)per64;
+    // the order pass keeps a mesh's offsets and ids in LDS: beyond that the caller uses the scatter formulation
+    if (order_lds_bytes(nf, per) > ORD_LDS_LIMIT) return GEOM_EUNSUPPORTED;
+    // scratch layout sized for (num + n_gt) points per mesh whatever `other` is
+    const int64_t cap = (int64_t)num + n_gt;
+    int *off = lists;
+    int *slot = off + (int64_t)b * (nf + 1);
+    int *pface = slot + (int64_t)b * cap;
+    int *seg = pface + (int64_t)b * cap;
     GatherArgs a{vf_ptr, vf_item, choices, u, v, points, gt, idx_g, idx_p, index, closest, weights, coef_dev, coef_sample,
-                 coef_other, b, nv, nf, num, n_gt, idx_p ? OTHER_NN : (index ? OTHER_TRI : OTHER_NONE), counts, lists,
-                 reinterpret_cast<float4 *>(lists + list_words(b, nf)), grad_verts};
+                 coef_other, b, nv, nf, num, n_gt, other, per, counts, off, slot, pface, seg,
+                 reinterpret_cast<float4 *>(lists + list_words(b, nf, cap)), grad_verts};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int64_t items = (int64_t)b * (num + (a.other != OTHER_NONE ? n_gt : 0));
+    const int64_t items = (int64_t)b * per;
     if ((items + SGA_THREADS - 1) / SGA_THREADS > 0x7fffffffLL) return GEOM_ETOOBIG;
     if (items > 0)
         hipLaunchKernelGGL(surface_bin_kernel, dim3((unsigned)((items + SGA_THREADS - 1) / SGA_THREADS)), dim3(SGA_THREADS), 0, s, a);
+    static const hipError_t lds_opt_in = hipFuncSetAttribute(reinterpret_cast<const void *>(surface_order_kernel),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ORD_LDS_LIMIT);
+    (void)lds_opt_in; // more than 64 KiB of dynamic LDS needs the opt-in; a refusal shows up as a launch error below
+    hipLaunchKernelGGL(surface_order_kernel, dim3(b), dim3(ORD_THREADS), order_lds_bytes(nf, per), s, a);
     hipLaunchKernelGGL(surface_gather_kernel, dim3(((int64_t)nv * VTX_LANES + SGA_THREADS - 1) / SGA_THREADS, b),
                        dim3(SGA_THREADS), 0, s, a);
+    return geom::launch_status();
+}
+
+// ---- forward-side finalize + single-launch backward --------------------------------------------------------------
+// scratch layout (int32 words): off[b,nf+1] | seg[b,cap] | pface[b,cap] | slot[b,cap] | pad to 4 | rec[b,cap,2] float4 |
+// with cap = num + n_gt
+static inline int64_t fin_ints(int b, int nf, int64_t cap) { return (((int64_t)b * (nf + 1) + 3 * (int64_t)b * cap) + 3) & ~3ll; }
+extern "C" int64_t geom_surface_order_words(int b, int nf, int num, int n_gt)
+{
+    if (b <= 0 || nf < 0 || num < 0 || n_gt < 0) return 0;
+    const int64_t cap = (int64_t)num + n_gt;
+    return fin_ints(b, nf, cap) + (int64_t)b * cap * 8;
+}
+
+extern "C" int geom_surface_finalize_f32(int b, int nf, int num, const int64_t *choices, const float *u, const float *v,
+                                         const float *points, int n_gt, const float *gt, const int *idx_g,
+                                         const int *idx_p, const int *index, const float *closest, const float *weights,
+                                         const float *sq_sample, const float *sq_other, float scale_sample,
+                                         float scale_other, float coef_sample, float coef_other, int want_order,
+                                         int *order, float *loss, void *stream)
+{
+    if (b < 0 || nf < 0 || num < 0 || n_gt < 0) return GEOM_EINVAL;
+    if (!loss || !order || ((uintptr_t)order & 15)) return GEOM_EINVAL;
+    if (b == 0) return 0;
+    if ((num > 0 && !sq_sample) || (n_gt > 0 && !sq_other)) return GEOM_EINVAL;
+    if (idx_p && index) return GEOM_EINVAL;
+    if (b > 65535) return GEOM_ETOOBIG;
+    const int other = idx_p ? OTHER_NN : (index ? OTHER_TRI : OTHER_NONE);
+    const int64_t per64 = (int64_t)num + (other != OTHER_NONE ? n_gt : 0);
+    if (per64 > 0x3fffffff) return GEOM_ETOOBIG;
+    const int per = (int)per64;
+    if (want_order) {
+        if (num > 0 && (!choices || !u || !v || !points || !gt || !idx_g || n_gt == 0)) return GEOM_EINVAL;
+        if (index && (!closest || !weights || !gt)) return GEOM_EINVAL;
+        if (order_lds_bytes(nf, per) > ORD_LDS_LIMIT) return GEOM_EUNSUPPORTED;
+    }
+    const int64_t cap = (int64_t)num + n_gt;
+    int *off = order;
+    int *seg = off + (int64_t)b * (nf + 1);
+    int *pface = seg + (int64_t)b * cap;
+    int *slot = pface + (int64_t)b * cap;
+    float4 *rec = reinterpret_cast<float4 *>(order + fin_ints(b, nf, cap));
+    FinalizeArgs a{choices, u, v, points, gt, idx_g, idx_p, index, closest, weights, sq_sample, sq_other, scale_sample,
+                   scale_other, coef_sample, coef_other, b, nf, num, n_gt, other, per, want_order ? 1 : 0, off, seg, pface,
+                   slot, rec, loss};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t lds = want_order ? order_lds_bytes(nf, per) + 2 * ORD_WAVES * sizeof(float)
+                                  : ((size_t)nf + 1 + ORD_WAVES + 4) * sizeof(int) + 2 * ORD_WAVES * sizeof(float);
+    if (per <= FIN_ITEMS * ORD_THREADS) {
+        static const hipError_t opt_in = hipFuncSetAttribute(reinterpret_cast<const void *>(surface_finalize_kernel<true>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ORD_LDS_LIMIT + 1024);
+        (void)opt_in;
+        hipLaunchKernelGGL(surface_finalize_kernel<true>, dim3(want_order ? b + 1 : 1), dim3(ORD_THREADS), lds, s, a);
+    } else {
+        static const hipError_t opt_in = hipFuncSetAttribute(reinterpret_cast<const void *>(surface_finalize_kernel<false>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ORD_LDS_LIMIT + 1024);
+        (void)opt_in;
+        hipLaunchKernelGGL(surface_finalize_kernel<false>, dim3(want_order ? b + 1 : 1), dim3(ORD_THREADS), lds, s, a);
+    }
+    return geom::launch_status();
+}
+
+extern "C" int geom_surface_gather_f32(int b, int nv, int nf, const int *vf_ptr, const int *vf_item, int num, int n_gt,
+                                       int has_other, const int *order, const float *grad, float *grad_verts, void *stream)
+{
+    if (b < 0 || nv < 0 || nf < 0 || num < 0 || n_gt < 0) return GEOM_EINVAL;
+    if (b == 0 || nv == 0) return 0;
+    if (!vf_ptr || !vf_item || !order || !grad_verts || ((uintptr_t)order & 15)) return GEOM_EINVAL;
+    if (b > 65535) return GEOM_ETOOBIG;
+    const int64_t cap = (int64_t)num + n_gt;
+    const int per = num + (has_other ? n_gt : 0);
+    const int *off = order;
+    const int *seg = off + (int64_t)b * (nf + 1);
+    const float4 *rec = reinterpret_cast<const float4 *>(order + fin_ints(b, nf, cap));
+    VGatherArgs a{vf_ptr, vf_item, off, seg, rec, grad, grad_verts, nv, nf, per};
+    hipLaunchKernelGGL(surface_vertex_gather_kernel, dim3(((int64_t)nv * VTX_LANES + SGA_THREADS - 1) / SGA_THREADS, b),
+                       dim3(SGA_THREADS), 0, static_cast<hipStream_t>(stream), a);
     return geom::launch_status();
 }

@@ -247,8 +247,10 @@ int launch(const GcnArgs &a, int act, float *colsum_partial, float *grad_bias, v
 }
 
 // ---------------------------------------------------------------------------------------
-// ELL fast path (k % 4 == 0, C == k * (NC + 1) with NC = 2 (split 3) or 9 (split 10), rows of at
-// most W = 8 / 16 neighbours -- every hidden layer of the reference models on a triangle mesh).
+// ELL fast path (k % 4 == 0, C == k * (NC + 1) with NC = 2 (split 3) or 9 (split 10); the first W = 8 / 16
+// entries of every row in a fixed-stride table, the few longer rows -- the two 33-entry poles of the reference's
+// training template 482.obj -- continue in a short CSR tail: every hidden layer of the reference models on a
+// triangle mesh).
 //
 // Thread (row, j) owns the aggregated float4 j of the row AND the NC pass-through float4s
 // j + (k/4)*i of the same row.  Compared with the generic kernel above:
@@ -266,6 +268,10 @@ struct EllArgs {
     float *y;
     int nv, c, k;
     unsigned short *mask; // ReLU sign bits, one word per thread: bit 4*i + e <-> element e of the thread's float4 i
+    // rows longer than W (the 33-entry poles of the reference's 482.obj): entries W.. of every row in CSR form,
+    // summed after the table slots, i.e. still in CSR order.  over_ptr == null: no row is longer than W.
+    const int *over_ptr, *over_col;
+    const float *over_val;
 };
 
 // MASK (ReLU, NC == 2 only): the forward also stores the sign of every output element as one bit (12 bits per
@@ -358,6 +364,30 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a
                 acc.w += w[n] * v.w;
             }
         }
+        if (a.over_ptr) { // the row's entries beyond the table width (wave-divergent only at the few long rows)
+            for (int e = a.over_ptr[r]; e < a.over_ptr[r + 1]; ++e) {
+                const int64_t nrow = mesh_row0 + a.over_col[e];
+                const float wv = a.over_val[e];
+                float4 v = *reinterpret_cast<const float4 *>(a.x + nrow * a.c + c0);
+                if (BACKWARD && MASK) {
+                    const unsigned m = a.mask[nrow * kg + j];
+                    v.x = (m & 1u) ? v.x : 0.f;
+                    v.y = (m & 2u) ? v.y : 0.f;
+                    v.z = (m & 4u) ? v.z : 0.f;
+                    v.w = (m & 8u) ? v.w : 0.f;
+                } else if (BACKWARD && ACT != ACT_NONE) {
+                    const float4 o = *reinterpret_cast<const float4 *>(a.saved + nrow * a.c + c0);
+                    v.x = act_bwd<ACT>(v.x, o.x);
+                    v.y = act_bwd<ACT>(v.y, o.y);
+                    v.z = act_bwd<ACT>(v.z, o.z);
+                    v.w = act_bwd<ACT>(v.w, o.w);
+                }
+                acc.x += wv * v.x;
+                acc.y += wv * v.y;
+                acc.z += wv * v.z;
+                acc.w += wv * v.w;
+            }
+        }
         float *yrow = a.y + row * a.c;
         unsigned sign_bits = 0u;
 #pragma unroll
@@ -434,6 +464,7 @@ int dispatch_ell(EllArgs a, int b, int w, int act, float *grad_bias, float *scra
     if (a.mask && !(act == ACT_RELU && ell_nc(a.c, a.k) == 2)) return GEOM_EINVAL; // sign mask: ReLU, split 3 only
     if (BACKWARD && act != ACT_NONE && !a.saved && !a.mask) return GEOM_EINVAL;
     if (grad_bias && !scratch) return GEOM_EINVAL;
+    if (a.over_ptr && (!a.over_col || !a.over_val)) return GEOM_EINVAL;
     if ((((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.saved | (uintptr_t)a.bias | (uintptr_t)a.col | (uintptr_t)a.val) % 16) != 0)
         return GEOM_EINVAL;
     if (b > 65535) return GEOM_ETOOBIG;
@@ -504,10 +535,11 @@ extern "C" int geom_zn_gcn_aggregate_bwd_f32(int b, int nv, int c, int k, const 
 }
 
 extern "C" int geom_zn_gcn_aggregate_ell_fwd_f32(int b, int nv, int c, int k, int w, const int *ell_col,
-                                                 const float *ell_val, const float *support, const float *bias,
+                                                 const float *ell_val, const int *over_ptr, const int *over_col,
+                                                 const float *over_val, const float *support, const float *bias,
                                                  int act, float *out, uint16_t *relu_mask, void *stream)
 {
-    EllArgs a{ell_col, ell_val, support, bias, nullptr, out, nv, c, k, relu_mask};
+    EllArgs a{ell_col, ell_val, support, bias, nullptr, out, nv, c, k, relu_mask, over_ptr, over_col, over_val};
     return dispatch_ell<false>(a, b, w, act, nullptr, nullptr, stream);
 }
 
@@ -518,10 +550,12 @@ extern "C" int64_t geom_zn_gcn_relu_mask_words(int b, int nv, int c, int k)
 }
 
 extern "C" int geom_zn_gcn_aggregate_ell_bwd_f32(int b, int nv, int c, int k, int w, const int *ell_colT,
-                                                 const float *ell_valT, const float *grad_out, const float *out,
+                                                 const float *ell_valT, const int *over_ptrT, const int *over_colT,
+                                                 const float *over_valT, const float *grad_out, const float *out,
                                                  const uint16_t *relu_mask, int act, float *grad_support,
                                                  float *grad_bias, float *scratch, void *stream)
 {
-    EllArgs a{ell_colT, ell_valT, grad_out, nullptr, out, grad_support, nv, c, k, const_cast<uint16_t *>(relu_mask)};
+    EllArgs a{ell_colT, ell_valT, grad_out, nullptr, out, grad_support, nv, c, k, const_cast<uint16_t *>(relu_mask),
+              over_ptrT, over_colT, over_valT};
     return dispatch_ell<true>(a, b, w, act, grad_bias, scratch, stream);
 }

@@ -25,7 +25,7 @@ _ACT_NONE, _ACT_RELU, _ACT_ELU = 0, 1, 2
 # --------------------------------------------------------------- CSR cache ----
 class _Csr:
     __slots__ = ("rowptr", "col", "val", "rowptr_t", "col_t", "val_t", "nv", "nnz",
-                 "ell_w", "ell_col", "ell_val", "ell_col_t", "ell_val_t", "inv_deg")
+                 "ell_w", "ell_col", "ell_val", "ell_col_t", "ell_val_t", "inv_deg", "over", "over_t")
 
 
 _csr_cache = {}   # id(adjacency tensor) -> (weakref, version, _Csr)
@@ -41,16 +41,34 @@ def _to_csr(dense):
 
 
 def _to_ell(rowptr, col, val, width):
-    """[V][width] neighbour table in CSR order, unused slots col = -1 / val = 0."""
+    """[V][width] neighbour table holding the first `width` entries of every CSR row (unused slots col = -1 /
+    val = 0) + the CSR tail (over_ptr, over_col, over_val) of the rows that are longer, or None when none is."""
     nv = rowptr.numel() - 1
     lens = (rowptr[1:] - rowptr[:-1]).long()
     rows = torch.repeat_interleave(torch.arange(nv, device=col.device), lens)
     slot = torch.arange(col.numel(), device=col.device) - rowptr[:-1].long()[rows]
     ell_col = torch.full((nv, width), -1, dtype=torch.int32, device=col.device)
     ell_val = torch.zeros((nv, width), dtype=torch.float32, device=col.device)
-    ell_col[rows, slot] = col
-    ell_val[rows, slot] = val
-    return ell_col.contiguous(), ell_val.contiguous()
+    head = slot < width
+    ell_col[rows[head], slot[head]] = col[head]
+    ell_val[rows[head], slot[head]] = val[head]
+    over = None
+    if not bool(head.all()):
+        over_ptr = torch.zeros(nv + 1, dtype=torch.int64, device=col.device)
+        over_ptr[1:] = torch.cumsum((lens - width).clamp_min(0), 0)
+        over = (over_ptr.to(torch.int32).contiguous(), col[~head].contiguous(), val[~head].contiguous())
+    return ell_col.contiguous(), ell_val.contiguous(), over
+
+
+def _ell_width(lens_a, lens_b):
+    """Table width of the fast kernel: the smallest of 8 / 16 that leaves at most 5 % of the rows (of either
+    orientation) with a CSR tail -- an icosphere (rows of 6-7) gets 8 and no tail, the reference's 482.obj (rows of
+    5-9 and two poles of 33) gets 8 with a 10-row tail; 0 = irregular degrees, generic CSR kernel."""
+    n = max(int(lens_a.numel()), 1)
+    for w in (8, 16):
+        if max(int((lens_a > w).sum()), int((lens_b > w).sum())) <= 0.05 * n:
+            return w
+    return 0
 
 
 def _finish_csr(c):
@@ -60,12 +78,11 @@ def _finish_csr(c):
     c.nnz = int(c.col.numel())
     # 1 / (neighbours without the self loop): what batch_get_lap_info divides by on the binary adjacency
     c.inv_deg = (1.0 / ((c.rowptr[1:] - c.rowptr[:-1]).float() - 1.0)).contiguous()
-    longest = int(max((c.rowptr[1:] - c.rowptr[:-1]).max(), (c.rowptr_t[1:] - c.rowptr_t[:-1]).max())) if c.nv else 0
-    c.ell_w = 8 if longest <= 8 else (16 if longest <= 16 else 0)   # ELL fast path for bounded degrees
-    c.ell_col = c.ell_val = c.ell_col_t = c.ell_val_t = None
+    c.ell_w = _ell_width(c.rowptr[1:] - c.rowptr[:-1], c.rowptr_t[1:] - c.rowptr_t[:-1]) if c.nv else 0
+    c.ell_col = c.ell_val = c.ell_col_t = c.ell_val_t = c.over = c.over_t = None
     if c.ell_w:
-        c.ell_col, c.ell_val = _to_ell(c.rowptr, c.col, c.val, c.ell_w)
-        c.ell_col_t, c.ell_val_t = _to_ell(c.rowptr_t, c.col_t, c.val_t, c.ell_w)
+        c.ell_col, c.ell_val, c.over = _to_ell(c.rowptr, c.col, c.val, c.ell_w)
+        c.ell_col_t, c.ell_val_t, c.over_t = _to_ell(c.rowptr_t, c.col_t, c.val_t, c.ell_w)
     return c
 
 
@@ -137,8 +154,10 @@ class _ZeroNAggregate(torch.autograd.Function):
                     words = _lib.lib().geom_zn_gcn_relu_mask_words(b, nv, c, k)
                     if words:
                         mask = torch.empty(words, dtype=torch.int16, device=s.device)
+                over = csr.over or (None, None, None)
                 code = _lib.lib().geom_zn_gcn_aggregate_ell_fwd_f32(
-                    b, nv, c, k, csr.ell_w, csr.ell_col.data_ptr(), csr.ell_val.data_ptr(), s.data_ptr(),
+                    b, nv, c, k, csr.ell_w, csr.ell_col.data_ptr(), csr.ell_val.data_ptr(), _lib.ptr(over[0]),
+                    _lib.ptr(over[1]), _lib.ptr(over[2]), s.data_ptr(),
                     _lib.ptr(bias_c), act, out.data_ptr(), _lib.ptr(mask), _lib.stream_ptr())
                 if code == _lib.EUNSUPPORTED:
                     mask = None
@@ -172,8 +191,10 @@ class _ZeroNAggregate(torch.autograd.Function):
         with torch.cuda.device(g.device):
             code = _lib.EUNSUPPORTED
             if csr.ell_w:
+                over = csr.over_t or (None, None, None)
                 code = _lib.lib().geom_zn_gcn_aggregate_ell_bwd_f32(
-                    b, nv, c, ctx.k, csr.ell_w, csr.ell_col_t.data_ptr(), csr.ell_val_t.data_ptr(), g.data_ptr(),
+                    b, nv, c, ctx.k, csr.ell_w, csr.ell_col_t.data_ptr(), csr.ell_val_t.data_ptr(), _lib.ptr(over[0]),
+                    _lib.ptr(over[1]), _lib.ptr(over[2]), g.data_ptr(),
                     _lib.ptr(out), _lib.ptr(mask), act, grad_support.data_ptr(), _lib.ptr(grad_bias), _lib.ptr(scratch),
                     _lib.stream_ptr())
             if code == _lib.EUNSUPPORTED:

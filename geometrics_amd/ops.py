@@ -135,8 +135,6 @@ class PointToTriangleSum(torch.autograd.Function):
         return None, grad_verts, None, None, None
 
 
-_CLEAR_IN_FORWARD_MAX = 1 << 18   # words (1 MiB): beyond this a separate fill kernel is the faster way to zero
-
 _vf_cache = {}   # id(faces) -> (weakref, version, nv, vf_ptr, vf_item)
 
 
@@ -219,21 +217,27 @@ class SurfaceLoss(torch.autograd.Function):
             _lib.check(L.geom_chamfer_nn_f32(b, n_gt, gt_c.data_ptr(), num, points.data_ptr(), sq_gt.data_ptr(),
                                              idx_p.data_ptr(), sq_pred.data_ptr(), idx_g.data_ptr(),
                                              _chamfer.default_flags(), _lib.stream_ptr()), "geom_chamfer_nn_f32")
-            # the loss reduction is one workgroup; it also zeroes the per-face point counters of the backward's binning
-            # pass, which spares the backward a fill launch (used once: a second backward allocates its own)
-            bins = None
-            if ctx.needs_input_grad[0] and b * nf <= _CLEAR_IN_FORWARD_MAX:
-                bins = torch.empty(L.geom_surface_bin_count_words(b, nf), dtype=torch.int32, device=dev)
-            clear = (_lib.ptr(bins), 0 if bins is None else bins.numel())     # int32 zero == float zero bits
+            # finalize: the loss reduction AND, when a gradient is wanted, the backward's preparation (gradient record per
+            # point, points counting-sorted by face in ascending id order) in one launch; the backward is then a
+            # single gather launch
+            want = bool(ctx.needs_input_grad[0])
+            order = torch.empty(L.geom_surface_order_words(b, nf, num, n_gt), dtype=torch.int32, device=dev)
+            other_sq = sq_gt if two_sided else sq
+            args = (b, nf, num, choices.data_ptr(), u.data_ptr(), v.data_ptr(), points.data_ptr(), n_gt, gt_c.data_ptr(),
+                    idx_g.data_ptr(), idx_p.data_ptr() if two_sided else None, None if two_sided else index.data_ptr(),
+                    None if two_sided else closest.data_ptr(), None if two_sided else weights.data_ptr(),
+                    sq_pred.data_ptr(), other_sq.data_ptr(), scale / sq_pred.numel(), scale / other_sq.numel(),
+                    scale / (b * num), scale / (b * n_gt))
+            code = L.geom_surface_finalize_f32(*args, int(want), order.data_ptr(), out.data_ptr(), _lib.stream_ptr())
+            if code == _lib.EUNSUPPORTED:       # too many faces + points for the in-LDS ordering: loss only, scatter backward
+                want = False
+                code = L.geom_surface_finalize_f32(*args, 0, order.data_ptr(), out.data_ptr(), _lib.stream_ptr())
+            _lib.check(code, "geom_surface_finalize_f32")
+            ctx.order = order if want else None
             if two_sided:
-                _lib.call("geom_sum2_f32", sq_pred.numel(), sq_pred.data_ptr(), scale / sq_pred.numel(),
-                          sq_gt.numel(), sq_gt.data_ptr(), scale / sq_gt.numel(), out.data_ptr(), *clear)
                 ctx.save_for_backward(faces, choices, u, v, points, gt_c, idx_g, idx_p)
             else:
-                _lib.call("geom_sum2_f32", sq_pred.numel(), sq_pred.data_ptr(), scale / sq_pred.numel(),
-                          sq.numel(), sq.data_ptr(), scale / sq.numel(), out.data_ptr(), *clear)
                 ctx.save_for_backward(faces, choices, u, v, points, gt_c, idx_g, index, closest, weights)
-            ctx.bins = bins
         ctx.two_sided, ctx.scale, ctx.nv = two_sided, scale, nv
         ctx.mark_non_differentiable(sq_gt, sq_pred)
         ctx.set_materialize_grads(False)    # no zero tensors (two fill launches) for the two distance outputs
@@ -247,22 +251,27 @@ class SurfaceLoss(torch.autograd.Function):
         n_gt, nf, nv = gt.shape[1], faces.shape[0], ctx.nv
         dev = points.device
         grad = grad.contiguous()
-        counts, ctx.bins = ctx.bins, None                 # zeroed by the forward's reduction launch
-        if counts is None:
-            counts = torch.zeros(_lib.lib().geom_surface_bin_count_words(b, nf), dtype=torch.int32, device=dev)
-        vf_ptr, vf_item = vertex_faces(faces, nv)
-        lists = torch.empty(_lib.lib().geom_surface_bin_list_words(b, nf, num, n_gt), dtype=torch.int32, device=dev)
-        grad_verts = torch.empty(b, nv, 3, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            if ctx.two_sided:
-                idx_p, index, closest, weights, coef_other = saved[7], None, None, None, ctx.scale / (b * n_gt)
+            if ctx.order is not None:           # prepared by the forward's finalize launch: one gather, no atomics
+                vf_ptr, vf_item = vertex_faces(faces, nv)
+                grad_verts = torch.empty(b, nv, 3, dtype=torch.float32, device=dev)
+                _lib.call("geom_surface_gather_f32", b, nv, nf, vf_ptr.data_ptr(), vf_item.data_ptr(), num, n_gt, 1,
+                          ctx.order.data_ptr(), grad.data_ptr(), grad_verts.data_ptr())
             else:
-                idx_p, (index, closest, weights), coef_other = None, saved[7:10], ctx.scale / (b * n_gt)
-            _lib.call("geom_surface_loss_bwd_gather_f32", b, nv, nf, vf_ptr.data_ptr(), vf_item.data_ptr(), num,
-                      choices.data_ptr(), u.data_ptr(), v.data_ptr(), points.data_ptr(), n_gt, gt.data_ptr(),
-                      saved[6].data_ptr(), _lib.ptr(idx_p), _lib.ptr(index), _lib.ptr(closest), _lib.ptr(weights),
-                      grad.data_ptr(), ctx.scale / (b * num), coef_other, counts.data_ptr(), lists.data_ptr(),
-                      grad_verts.data_ptr())
+                # a mesh whose faces + points do not fit the ordering pass's LDS (> ~38 000 together): scatter formulation
+                # (fp32 atomics into a zeroed gradient; same values up to summation order)
+                grad_verts = torch.zeros(b, nv, 3, dtype=torch.float32, device=dev)
+                if ctx.two_sided:
+                    for other_idx, via_nn, coef in ((saved[6], 0, ctx.scale / (b * num)), (saved[7], 1, ctx.scale / (b * n_gt))):
+                        _lib.call("geom_sample_chamfer_bwd_f32", b, nv, nf, faces.data_ptr(), num, choices.data_ptr(),
+                                  u.data_ptr(), v.data_ptr(), points.data_ptr(), n_gt, gt.data_ptr(), other_idx.data_ptr(),
+                                  via_nn, grad.data_ptr(), coef, grad_verts.data_ptr())
+                else:
+                    index, closest, weights = saved[7:10]
+                    _lib.call("geom_surface_loss_bwd_f32", b, nv, nf, faces.data_ptr(), num, choices.data_ptr(),
+                              u.data_ptr(), v.data_ptr(), points.data_ptr(), n_gt, gt.data_ptr(), saved[6].data_ptr(),
+                              index.data_ptr(), closest.data_ptr(), weights.data_ptr(), grad.data_ptr(),
+                              ctx.scale / (b * num), ctx.scale / (b * n_gt), grad_verts.data_ptr())
         return grad_verts, None, None, None, None, None, None, None, None
 
 

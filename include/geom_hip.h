@@ -201,11 +201,12 @@ int geom_surface_loss_bwd_f32(int b, int nv, int nf, const int64_t *faces, int n
  * bit-reproducible.  vf_ptr [nv+1] / vf_item [3*nf] = static CSR vertex -> incident (face << 2 | corner), ascending
  * per vertex.  Exactly one of idx_p ([b,n_gt] nearest sampled point of each gt point: the two-sided Chamfer term)
  * and index (+ closest, weights: the point-to-triangle term) may be given, or neither (sampled-point term only).
- * counts: geom_surface_bin_count_words(b, nf) int32, MUST BE ZERO on entry (left holding the per-face point counts);
- * lists: geom_surface_bin_list_words(b, nf, num, n_gt) int32 scratch, 16-byte aligned (16 slots per face, a per-mesh
- * overflow list and two float4 records per point; faces
- * beyond both are summed by an ordered scan of the mesh's points -- exact in every case).  Every element of
- * grad_verts [b,nv,3] is written. */
+ * counts: geom_surface_bin_count_words(b, nf) int32, MUST BE ZERO on entry and is left zero again;
+ * lists: geom_surface_bin_list_words(b, nf, num, n_gt) int32 scratch, 16-byte aligned (face offsets, per-point slot /
+ * face / ordered id lists and two float4 records per point: the points are counting-sorted by face and every
+ * face's points summed in ascending id order -- exact for any distribution of points over faces).  Returns
+ * GEOM_EUNSUPPORTED when nf + num + n_gt exceeds what one workgroup can order in LDS (~38 000): use the scatter
+ * entry points then.  Every element of grad_verts [b,nv,3] is written. */
 int64_t geom_surface_bin_count_words(int b, int nf);
 int64_t geom_surface_bin_list_words(int b, int nf, int num, int n_gt);
 int geom_surface_loss_bwd_gather_f32(int b, int nv, int nf, const int *vf_ptr, const int *vf_item, int num,
@@ -236,16 +237,21 @@ int geom_zn_gcn_aggregate_bwd_f32(int b, int nv, int c, int k, const int *rowptr
  * order).  ell_col/ell_val are [nv][w] row-major, w = 8 or 16, unused slots col = -1; supported when
  * k % 4 == 0 and c == 3k (split 3) or c == 10k (split 10) -- every hidden layer of the reference
  * models on a triangle mesh; anything else returns GEOM_EUNSUPPORTED and the CSR entry points above
- * apply.  All pointers 16-byte aligned.  Scratch as for the CSR backward.
+ * apply.  Rows longer than w (the 33-entry poles of the reference's 482.obj, GEOMetrics.py:44) keep their first w
+ * entries in the table and continue in a CSR tail: over_ptr int32 [nv+1], over_col / over_val = entries w.. of
+ * every row in row order (all three NULL when no row is longer than w).  All pointers 16-byte aligned.  Scratch as
+ * for the CSR backward.
  * relu_mask (may be NULL; act == ReLU and c == 3k only, else GEOM_EINVAL): geom_zn_gcn_relu_mask_words(b,nv,c,k)
  * uint16 words.  The forward stores the sign of every output element in it (one bit each); a backward that is
  * given the mask takes relu' from it and does not read `out` (which may then be NULL): 1/3 less traffic. */
 int64_t geom_zn_gcn_relu_mask_words(int b, int nv, int c, int k);
 int geom_zn_gcn_aggregate_ell_fwd_f32(int b, int nv, int c, int k, int w, const int *ell_col,
-                                      const float *ell_val, const float *support, const float *bias,
+                                      const float *ell_val, const int *over_ptr, const int *over_col,
+                                      const float *over_val, const float *support, const float *bias,
                                       int act, float *out, uint16_t *relu_mask, void *stream);
 int geom_zn_gcn_aggregate_ell_bwd_f32(int b, int nv, int c, int k, int w, const int *ell_colT,
-                                      const float *ell_valT, const float *grad_out, const float *out,
+                                      const float *ell_valT, const int *over_ptrT, const int *over_colT,
+                                      const float *over_valT, const float *grad_out, const float *out,
                                       const uint16_t *relu_mask, int act, float *grad_support,
                                       float *grad_bias, float *scratch, void *stream);
 
@@ -307,6 +313,29 @@ int geom_pool_features_bwd_f32(int b, int nv, const float *verts, const float *c
                                int levels, const float *const *blocks, const int *channels, const int *dims,
                                const float *grad_out, float *const *grad_blocks, float *grad_verts,
                                void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- surface loss: forward-side finalize + single-launch backward ------------------------------------------
+ * geom_surface_finalize_f32 runs once after the two scans of batch_point_to_surface / batch_point_to_point
+ * (utils.py:393-502).  It (a) writes the scalar loss = scale_sample * sum(sq_sample[b,num]) + scale_other *
+ * sum(sq_other[b,n_gt]) (one workgroup, fixed tree: bit-reproducible) and, when want_order,
+ * (b) prepares the backward in `order` (geom_surface_order_words(b, nf, num, n_gt) int32 words, 16-byte aligned,
+ * uninitialised scratch that must stay alive until the backward).  Every sampled point (face choices[b,num], draws u / v,
+ * partner gt[idx_g]) and every gt point -- partner of the sampled point idx_p[b,n_gt] (two-sided Chamfer) or of the
+ * closest point on triangle index[b,n_gt] with corner weights (point-to-surface); give one of idx_p / index or neither
+ * -- gets a gradient record (point - partner) * coef_{sample,other} + corner weights, and the points are
+ * counting-sorted by face with ascending ids inside a face.  One workgroup per mesh, counts / offsets / ids in LDS:
+ * GEOM_EUNSUPPORTED when nf + num + n_gt exceeds ~38 000 (call again with want_order = 0 and use the scatter
+ * backward).  geom_surface_gather_f32 is then the whole backward: grad_verts[b,nv,3] = 2 * grad[0] * sum over the
+ * points on the vertex's incident faces (vf_ptr / vf_item: static CSR vertex -> (face << 2 | corner)), every element
+ * written once, no float atomics, bit-reproducible.  has_other = whether idx_p or index was given to the finalize. */
+int64_t geom_surface_order_words(int b, int nf, int num, int n_gt);
+int geom_surface_finalize_f32(int b, int nf, int num, const int64_t *choices, const float *u, const float *v,
+                              const float *points, int n_gt, const float *gt, const int *idx_g, const int *idx_p,
+                              const int *index, const float *closest, const float *weights, const float *sq_sample,
+                              const float *sq_other, float scale_sample, float scale_other, float coef_sample,
+                              float coef_other, int want_order, int *order, float *loss, void *stream);
+int geom_surface_gather_f32(int b, int nv, int nf, const int *vf_ptr, const int *vf_item, int num, int n_gt,
+                            int has_other, const int *order, const float *grad, float *grad_verts, void *stream);
 
 /* ---- ragged mesh batches (SURVEY 8f "next" row 4; auto_encoder.py:71-76, layers.py:78) ---------------
  * Meshes of different sizes are concatenated along the vertex axis; segment s owns rows

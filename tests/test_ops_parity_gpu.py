@@ -202,6 +202,55 @@ def test_relu_sign_mask_path_at_the_bench_configuration(gpu):
         close(layer.bias.grad.cpu().numpy(), b.grad.numpy(), 1e-4)
 
 
+@pytest.mark.parametrize("mesh", ["482.obj", "uv_sphere"])
+@pytest.mark.parametrize("act", [F.relu, F.elu])
+def test_long_rows_take_the_ell_kernel_with_a_csr_tail(gpu, mesh, act):
+    """The reference's own training template (GEOMetrics.py:44: 482.obj, two poles with 32 neighbours -> rows of 33
+    entries next to rows of 5-9) must run on the fast table kernel: table width 8 + a CSR tail for the few longer rows.
+    Checked against the generic CSR kernel (same summation order -> same bits) and the float64 dense restatement."""
+    from geometrics_amd import _lib as L
+    if mesh == "482.obj":
+        faces = dev(golden("adj_482")["faces"], gpu)
+    else:
+        faces = dev(meshgen.uv_sphere()[1], gpu)
+    adj = utils.adj_init(faces)["adj"]
+    csr = layers.adjacency_csr(adj)
+    assert csr.ell_w == 8 and csr.over is not None and csr.over_t is not None
+    lens = (csr.rowptr[1:] - csr.rowptr[:-1])
+    assert int(lens.max()) == 33 and int(csr.over[0][-1]) == int((lens - 8).clamp_min(0).sum())
+    B, nv, C, k = 4, 482, 192, 64
+    torch.manual_seed(9)
+    layer = layers.Batch_Image_ZERON_GCNGCN(40, C).to(gpu)
+    x = torch.randn(B, nv, 40, device=gpu, requires_grad=True)
+    out = layer(x, adj, act)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    # generic CSR kernel on the same support: identical bits (same neighbour order)
+    sup = torch.matmul(x.detach(), layer.weight1.detach().squeeze(0))
+    ref = torch.empty_like(sup)
+    code = 1 if act is F.relu else 2
+    L.call("geom_zn_gcn_aggregate_fwd_f32", B, nv, C, k, csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.val.data_ptr(),
+           sup.data_ptr(), layer.bias.data_ptr(), code, ref.data_ptr())
+    assert torch.equal(out.detach(), ref)
+    gs_ref, gb_ref = torch.empty_like(sup), torch.empty(C, device=gpu)
+    scr = torch.empty(L.lib().geom_zn_gcn_bwd_scratch_floats(B, nv, C), device=gpu)
+    L.call("geom_zn_gcn_aggregate_bwd_f32", B, nv, C, k, csr.rowptr_t.data_ptr(), csr.col_t.data_ptr(), csr.val_t.data_ptr(),
+           gout.data_ptr(), ref.data_ptr(), code, gs_ref.data_ptr(), gb_ref.data_ptr(), scr.data_ptr())
+    close(layer.bias.grad.cpu().numpy(), gb_ref.cpu().numpy(), 1e-5)
+    gx_ref = torch.matmul(gs_ref, layer.weight1.detach().squeeze(0).t())
+    close(x.grad.cpu().numpy(), gx_ref.cpu().numpy(), 1e-5)
+    # float64 dense restatement (reference layers.py:107-116), smooth activation only (no knife edges)
+    if act is F.elu:
+        xc = x.detach().cpu().double().requires_grad_(True)
+        w = layer.weight1.detach().cpu().double().requires_grad_(True)
+        bb = layer.bias.detach().cpu().double().requires_grad_(True)
+        oc = ref_ops.zero_n_layer(xc, adj.cpu().double(), w, bb, 3, F.elu)
+        oc.backward(gout.cpu().double())
+        close(out.detach().cpu().numpy(), oc.detach().numpy(), 1e-5)
+        close(x.grad.cpu().numpy(), xc.grad.numpy(), 1e-4)
+        close(layer.weight1.grad.cpu().numpy(), w.grad.numpy(), 1e-4)
+
+
 def test_gcn_rows_of_degree_32(gpu):
     g = golden("adj_482")
     adj = utils.adj_init(dev(g["faces"], gpu))["adj"]
@@ -518,7 +567,7 @@ def test_relu_sign_mask_backward_equals_the_output_based_one(gpu):
     assert words == B * nv * (k // 4) and L.lib().geom_zn_gcn_relu_mask_words(B, nv, 40, 4) == 0
     mask = torch.zeros(words, dtype=torch.int16, device=gpu)
     L.call("geom_zn_gcn_aggregate_ell_fwd_f32", B, nv, C, k, csr.ell_w, csr.ell_col.data_ptr(), csr.ell_val.data_ptr(),
-           sup.data_ptr(), bias.data_ptr(), 1, out.data_ptr(), mask.data_ptr())
+           None, None, None, sup.data_ptr(), bias.data_ptr(), 1, out.data_ptr(), mask.data_ptr())
     bits = (mask.view(B, nv, k // 4, 1).int() >> torch.arange(12, device=gpu).int()) & 1       # [B,nv,k/4,12]
     expect = (out > 0).view(B, nv, 3, k // 4, 4).permute(0, 1, 3, 2, 4).reshape(B, nv, k // 4, 12).int()
     assert torch.equal(bits, expect)
@@ -527,13 +576,13 @@ def test_relu_sign_mask_backward_equals_the_output_based_one(gpu):
     for use_mask in (False, True):
         gs, gb = torch.empty_like(sup), torch.empty(C, device=gpu)
         L.call("geom_zn_gcn_aggregate_ell_bwd_f32", B, nv, C, k, csr.ell_w, csr.ell_col_t.data_ptr(),
-               csr.ell_val_t.data_ptr(), g.data_ptr(), None if use_mask else out.data_ptr(),
+               csr.ell_val_t.data_ptr(), None, None, None, g.data_ptr(), None if use_mask else out.data_ptr(),
                mask.data_ptr() if use_mask else None, 1, gs.data_ptr(), gb.data_ptr(), scr.data_ptr())
         res.append((gs, gb))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     # the mask is a ReLU / split-3 facility: anything else is refused
     assert L.lib().geom_zn_gcn_aggregate_ell_fwd_f32(B, nv, C, k, csr.ell_w, csr.ell_col.data_ptr(), csr.ell_val.data_ptr(),
-                                                     sup.data_ptr(), bias.data_ptr(), 2, out.data_ptr(), mask.data_ptr(),
+                                                     None, None, None, sup.data_ptr(), bias.data_ptr(), 2, out.data_ptr(), mask.data_ptr(),
                                                      L.stream_ptr()) == -1
     # autograd path: a ReLU layer saves the mask, not the output
     layer = layers.Batch_Image_ZERON_GCNGCN(20, C).to(gpu)
@@ -552,9 +601,9 @@ def test_relu_sign_mask_backward_equals_the_output_based_one(gpu):
 @pytest.mark.parametrize("crowded", [0.0, 0.05, 0.9])
 def test_gather_backward_matches_the_atomic_scatter_and_is_reproducible(gpu, two_sided, crowded):
     """The surface-loss backward (bin by face + per-vertex gather) against the scatter kernels it replaced, called
-    through the C ABI on a zeroed buffer.  crowded = share of the samples moved onto 3 faces: 0.05 overflows the
-    8-slot lists into the per-mesh overflow list (ordered extraction), 0.9 makes the ordered scan of all points the
-    cheaper route.  Two runs of the gather give identical bits (fixed summation order)."""
+    through the C ABI on a zeroed buffer.  crowded = share of the samples moved onto 3 faces: 0.05 gives segments of
+    a few dozen points (insertion-sorted by one thread), 0.9 segments of ~180 (wave-wide rank sort).  Two runs of the
+    gather give identical bits (fixed summation order)."""
     from geometrics_amd import _lib as L
     V, Fc = meshgen.icosphere(2)
     B, num, n_gt = 2, 600, 500
@@ -593,6 +642,35 @@ def test_gather_backward_matches_the_atomic_scatter_and_is_reproducible(gpu, two
     owner = torch.repeat_interleave(torch.arange(V.shape[0], device=gpu), (vf_ptr[1:] - vf_ptr[:-1]).long())
     assert torch.equal(faces[(vf_item >> 2).long(), (vf_item & 3).long()], owner)
     assert sorted((vf_item.long() >> 2) * 3 + (vf_item.long() & 3)) == list(range(3 * Fc.shape[0]))
+
+
+def test_gather_backward_at_the_reference_training_shape(gpu):
+    """482 vertices / 960 faces with 3000 + 3000 points per mesh (GEOMetrics.py:25,44): ~6 points per face on average,
+    dozens on the large faces, 32 incident faces at the poles -- the distribution that made the first (16 slots per
+    face) binning fall back to scanning every point.  Against the atomic scatter, and bit-reproducible."""
+    from geometrics_amd import _lib as L
+    V, Fc = meshgen.uv_sphere()
+    B, num = 4, 3000
+    verts = dev(meshgen.jittered_batch(V, B, first=70), gpu).requires_grad_(True)
+    faces, gt = dev(Fc, gpu), dev(meshgen.gt_cloud(B, num, first=70), gpu)
+    ops.manual_seed(3)
+    choices, u, v = ops.draw_samples(verts, faces, num)
+    assert int(torch.bincount(choices[0], minlength=Fc.shape[0]).max()) >= 10
+    grads = []
+    for _ in range(2):
+        verts.grad = None
+        loss, _, _ = ops.SurfaceLoss.apply(verts, faces, gt, choices, u, v, False, 3000.0)
+        loss.backward()
+        grads.append(verts.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    outs = ops.SurfaceLoss.apply(verts, faces, gt, choices, u, v, False, 3000.0)
+    saved = outs[0].grad_fn.saved_tensors
+    ref = torch.zeros(B, V.shape[0], 3, device=gpu)
+    one = torch.ones((), device=gpu)
+    L.call("geom_surface_loss_bwd_f32", B, V.shape[0], Fc.shape[0], faces.data_ptr(), num, choices.data_ptr(), u.data_ptr(),
+           v.data_ptr(), saved[4].data_ptr(), num, gt.data_ptr(), saved[6].data_ptr(), saved[7].data_ptr(),
+           saved[8].data_ptr(), saved[9].data_ptr(), one.data_ptr(), 3000.0 / (B * num), 3000.0 / (B * num), ref.data_ptr())
+    assert torch.allclose(grads[0], ref, rtol=2e-5, atol=2e-6 * float(ref.abs().max()))
 
 
 def test_tri_surface_fused_call_equals_scan_plus_point_to_triangle(gpu):

@@ -10,14 +10,14 @@ sup = torch.randn(B, V.shape[0], C, device=dev); bias = torch.randn(C, device=de
 def run(k, act=0):
     _lib.call("geom_zn_gcn_aggregate_fwd_f32", B, V.shape[0], C, k, csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.val.data_ptr(), sup.data_ptr(), bias.data_ptr(), act, out.data_ptr())
 def run_ell(k, act=0):
-    _lib.call("geom_zn_gcn_aggregate_ell_fwd_f32", B, V.shape[0], C, k, csr.ell_w, csr.ell_col.data_ptr(), csr.ell_val.data_ptr(), sup.data_ptr(), bias.data_ptr(), act, out.data_ptr(), mask.data_ptr() if (act == 1 and use_mask[0]) else None)
+    _lib.call("geom_zn_gcn_aggregate_ell_fwd_f32", B, V.shape[0], C, k, csr.ell_w, csr.ell_col.data_ptr(), csr.ell_val.data_ptr(), None, None, None, sup.data_ptr(), bias.data_ptr(), act, out.data_ptr(), mask.data_ptr() if (act == 1 and use_mask[0]) else None)
 mask = torch.empty(_lib.lib().geom_zn_gcn_relu_mask_words(B, V.shape[0], C, 64), dtype=torch.int16, device=dev)
 use_mask = [False]
 gout = torch.randn_like(sup); gsup = torch.empty_like(sup); gb = torch.empty(C, device=dev)
 scr = torch.empty(_lib.lib().geom_zn_gcn_bwd_scratch_floats(B, V.shape[0], C), device=dev)
 def bwd(ell, act=1):
     if ell:
-        _lib.call("geom_zn_gcn_aggregate_ell_bwd_f32", B, V.shape[0], C, 64, csr.ell_w, csr.ell_col_t.data_ptr(), csr.ell_val_t.data_ptr(), gout.data_ptr(), out.data_ptr(), mask.data_ptr() if use_mask[0] else None, act, gsup.data_ptr(), gb.data_ptr(), scr.data_ptr())
+        _lib.call("geom_zn_gcn_aggregate_ell_bwd_f32", B, V.shape[0], C, 64, csr.ell_w, csr.ell_col_t.data_ptr(), csr.ell_val_t.data_ptr(), None, None, None, gout.data_ptr(), out.data_ptr(), mask.data_ptr() if use_mask[0] else None, act, gsup.data_ptr(), gb.data_ptr(), scr.data_ptr())
     else:
         _lib.call("geom_zn_gcn_aggregate_bwd_f32", B, V.shape[0], C, 64, csr.rowptr_t.data_ptr(), csr.col_t.data_ptr(), csr.val_t.data_ptr(), gout.data_ptr(), out.data_ptr(), act, gsup.data_ptr(), gb.data_ptr(), scr.data_ptr())
 def t(fn, it=200):
