@@ -40,7 +40,9 @@ _SIGNATURES = {
                                          _f, _f, _vp, _vp, _vp, _vp],
     "geom_surface_loss_bwd_f32": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp],
     "geom_surface_finalize_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i,
-                                  _vp, _vp, _vp],
+                                  _i, _vp, _vp, _vp],
+    "geom_surface_scan_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                              _vp, _vp, _f, _f, _vp, _u, _vp, ctypes.c_size_t, _vp, _vp],
     "geom_surface_gather_f32": [_i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "geom_vertex_head_fwd_f32": [ctypes.c_int64, _i, _vp, _vp, _f, _vp, _vp],
     "geom_vertex_head_bwd_f32": [ctypes.c_int64, _i, _vp, _f, _vp, _vp],

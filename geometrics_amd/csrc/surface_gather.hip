@@ -22,6 +22,7 @@
 // The per-face counters must be zero on entry; the order pass leaves them zero again.
 #include "geom_common.h"
 #include "tri_math.h"
+#include "surface_layout.h"
 
 namespace {
 
@@ -241,7 +242,7 @@ struct FinalizeArgs {
     const float *sq_sample, *sq_other; // [b,num], [b,n_gt]: the squared distances the loss sums
     float scale_sample, scale_other;   // loss = scale_sample * sum(sq_sample) + scale_other * sum(sq_other)
     float coef_sample, coef_other;     // gradient coefficients of the two kinds of points (without 2 * upstream grad)
-    int b, nf, num, n_gt, other, per, want_order;
+    int b, nf, num, n_gt, other, per, want_order, records_ready;
     int *off, *seg, *pface, *slot;
     float4 *rec;
     float *loss;
@@ -309,32 +310,40 @@ __global__ __launch_bounds__(ORD_THREADS) void surface_finalize_kernel(FinalizeA
         // record of point `id` -> global, its face counted in LDS; returns the face (-1: none) and the arrival slot
         auto bin_point = [&](int id, int &fi, int &sl) {
             int64_t f, sp = -1;
-            V3 g;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            float skip_zero = 0.f;
-            if (id < a.num) {
-                sp = (int64_t)mesh * a.num + id;
-                f = a.choices[sp];
-                g = (ld3(a.points + 3 * sp) - ld3(a.gt + 3 * ((int64_t)mesh * a.n_gt + a.idx_g[sp]))) * a.coef_sample;
-            } else {
-                const int64_t o = (int64_t)mesh * a.n_gt + (id - a.num);
-                if (a.other == OTHER_TRI) {
-                    f = a.index[o];
-                    g = (ld3(a.closest + 3 * o) - ld3(a.gt + 3 * o)) * a.coef_other;
-                    w = make_float4(a.weights[3 * o], a.weights[3 * o + 1], a.weights[3 * o + 2], 0.f);
-                    skip_zero = 1.f; // the scatter does not touch a corner whose weight is exactly zero
-                } else {
-                    sp = (int64_t)mesh * a.num + a.idx_p[o];
-                    f = a.choices[sp];
-                    g = (ld3(a.points + 3 * sp) - ld3(a.gt + 3 * o)) * a.coef_other;
+            if (a.records_ready) { // the fused scan already wrote the record: only the face is needed here
+                if (id < a.num) f = a.choices[(int64_t)mesh * a.num + id];
+                else {
+                    const int64_t o = (int64_t)mesh * a.n_gt + (id - a.num);
+                    f = a.other == OTHER_TRI ? (int64_t)a.index[o] : a.choices[(int64_t)mesh * a.num + a.idx_p[o]];
                 }
+            } else {
+                V3 g;
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                float skip_zero = 0.f;
+                if (id < a.num) {
+                    sp = (int64_t)mesh * a.num + id;
+                    f = a.choices[sp];
+                    g = (ld3(a.points + 3 * sp) - ld3(a.gt + 3 * ((int64_t)mesh * a.n_gt + a.idx_g[sp]))) * a.coef_sample;
+                } else {
+                    const int64_t o = (int64_t)mesh * a.n_gt + (id - a.num);
+                    if (a.other == OTHER_TRI) {
+                        f = a.index[o];
+                        g = (ld3(a.closest + 3 * o) - ld3(a.gt + 3 * o)) * a.coef_other;
+                        w = make_float4(a.weights[3 * o], a.weights[3 * o + 1], a.weights[3 * o + 2], 0.f);
+                        skip_zero = 1.f; // the scatter does not touch a corner whose weight is exactly zero
+                    } else {
+                        sp = (int64_t)mesh * a.num + a.idx_p[o];
+                        f = a.choices[sp];
+                        g = (ld3(a.points + 3 * sp) - ld3(a.gt + 3 * o)) * a.coef_other;
+                    }
+                }
+                if (sp >= 0) {
+                    const float u = a.u[sp], v = a.v[sp];
+                    w = make_float4(1.f - u, u * (1.f - v), u * v, 0.f);
+                }
+                a.rec[2 * (p0 + id) + 0] = make_float4(g.x, g.y, g.z, skip_zero);
+                a.rec[2 * (p0 + id) + 1] = w;
             }
-            if (sp >= 0) {
-                const float u = a.u[sp], v = a.v[sp];
-                w = make_float4(1.f - u, u * (1.f - v), u * v, 0.f);
-            }
-            a.rec[2 * (p0 + id) + 0] = make_float4(g.x, g.y, g.z, skip_zero);
-            a.rec[2 * (p0 + id) + 1] = w;
             const bool on_mesh = f >= 0 && f < a.nf; // else: contributes nowhere
             fi = on_mesh ? (int)f : -1;
             sl = on_mesh ? atomicAdd(&off[fi], 1) : 0; // LDS atomic: arrival slot inside the face
@@ -532,12 +541,11 @@ extern "C" int geom_surface_loss_bwd_gather_f32(int b, int nv, int nf, const int
 // ---- forward-side finalize + single-launch backward --------------------------------------------------------------
 // scratch layout (int32 words): off[b,nf+1] | seg[b,cap] | pface[b,cap] | slot[b,cap] | pad to 4 | rec[b,cap,2] float4 |
 // with cap = num + n_gt
-static inline int64_t fin_ints(int b, int nf, int64_t cap) { return (((int64_t)b * (nf + 1) + 3 * (int64_t)b * cap) + 3) & ~3ll; }
 extern "C" int64_t geom_surface_order_words(int b, int nf, int num, int n_gt)
 {
     if (b <= 0 || nf < 0 || num < 0 || n_gt < 0) return 0;
     const int64_t cap = (int64_t)num + n_gt;
-    return fin_ints(b, nf, cap) + (int64_t)b * cap * 8;
+    return geom_surface_order_ints(b, nf, cap) + (int64_t)b * cap * 8;
 }
 
 extern "C" int geom_surface_finalize_f32(int b, int nf, int num, const int64_t *choices, const float *u, const float *v,
@@ -545,7 +553,7 @@ extern "C" int geom_surface_finalize_f32(int b, int nf, int num, const int64_t *
                                          const int *idx_p, const int *index, const float *closest, const float *weights,
                                          const float *sq_sample, const float *sq_other, float scale_sample,
                                          float scale_other, float coef_sample, float coef_other, int want_order,
-                                         int *order, float *loss, void *stream)
+                                         int records_ready, int *order, float *loss, void *stream)
 {
     if (b < 0 || nf < 0 || num < 0 || n_gt < 0) return GEOM_EINVAL;
     if (!loss || !order || ((uintptr_t)order & 15)) return GEOM_EINVAL;
@@ -567,9 +575,9 @@ extern "C" int geom_surface_finalize_f32(int b, int nf, int num, const int64_t *
     int *seg = off + (int64_t)b * (nf + 1);
     int *pface = seg + (int64_t)b * cap;
     int *slot = pface + (int64_t)b * cap;
-    float4 *rec = reinterpret_cast<float4 *>(order + fin_ints(b, nf, cap));
+    float4 *rec = reinterpret_cast<float4 *>(order + geom_surface_order_ints(b, nf, cap));
     FinalizeArgs a{choices, u, v, points, gt, idx_g, idx_p, index, closest, weights, sq_sample, sq_other, scale_sample,
-                   scale_other, coef_sample, coef_other, b, nf, num, n_gt, other, per, want_order ? 1 : 0, off, seg, pface,
+                   scale_other, coef_sample, coef_other, b, nf, num, n_gt, other, per, want_order ? 1 : 0, records_ready ? 1 : 0, off, seg, pface,
                    slot, rec, loss};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t lds = want_order ? order_lds_bytes(nf, per) + 2 * ORD_WAVES * sizeof(float)
@@ -599,7 +607,7 @@ extern "C" int geom_surface_gather_f32(int b, int nv, int nf, const int *vf_ptr,
     const int per = num + (has_other ? n_gt : 0);
     const int *off = order;
     const int *seg = off + (int64_t)b * (nf + 1);
-    const float4 *rec = reinterpret_cast<const float4 *>(order + fin_ints(b, nf, cap));
+    const float4 *rec = reinterpret_cast<const float4 *>(order + geom_surface_order_ints(b, nf, cap));
     VGatherArgs a{vf_ptr, vf_item, off, seg, rec, grad, grad_verts, nv, nf, per};
     hipLaunchKernelGGL(surface_vertex_gather_kernel, dim3(((int64_t)nv * VTX_LANES + SGA_THREADS - 1) / SGA_THREADS, b),
                        dim3(SGA_THREADS), 0, static_cast<hipStream_t>(stream), a);

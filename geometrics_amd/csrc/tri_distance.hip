@@ -24,6 +24,8 @@
 // Arithmetic: tri_math.h (literal operation order of tri_distance.cu:140-191).
 #include "geom_common.h"
 #include "tri_math.h"
+#include "nn_scan.h"
+#include "surface_layout.h"
 
 namespace {
 
@@ -701,7 +703,12 @@ struct SurfaceOut {
     const int64_t *faces;
     int nv;
     float *sqdist, *closest, *weights; // [b,n], [b,n,3], [b,n,3]; sqdist == null: no epilogue
+    // gradient record of the gt point for the surface-loss backward (csrc/surface_gather.hip), rec == null: none
+    float4 *rec;      // [b][per][2], the gt points follow the `rec_first` sampled points of their mesh
+    float coef;
+    int per, rec_first;
 };
+constexpr SurfaceOut NO_SURFACE{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f, 0, 0};
 
 struct TriGws {
     float4 *sph;   // [b][m_pad]     member spheres, slot order
@@ -775,10 +782,9 @@ __global__ __launch_bounds__(256) void tri_prep_grouped_kernel(TriJob job, TriGw
 }
 
 template <bool TRUNC, bool FIX6, int HS_WAVES>
-__global__ __launch_bounds__(HS_WAVES * GEOM_WAVE) void tri_scan_grouped_kernel(const float *__restrict__ xyz, int b, int n, int m,
-                                                                       TriGws ws, float *__restrict__ dist,
-                                                                       int *__restrict__ point, int *__restrict__ index,
-                                                                       SurfaceOut surf)
+__device__ __forceinline__ void tri_scan_grouped_body(int bid, const float *__restrict__ xyz, int b, int n, int m,
+                                                      const TriGws &ws, float *__restrict__ dist, int *__restrict__ point,
+                                                      int *__restrict__ index, const SurfaceOut &surf)
 {
     static_assert(HS_WAVES <= GRP, "the seed reduction maps wave w to member lane w");
     constexpr int HS_THREADS = HS_WAVES * GEOM_WAVE;
@@ -793,7 +799,7 @@ __global__ __launch_bounds__(HS_WAVES * GEOM_WAVE) void tri_scan_grouped_kernel(
 
     const int split = ws.split, m_pad = ws.m_pad;
     int mesh, task;
-    if (!geom::xcd_assign(blockIdx.x, b, ((n + TRI_QUERIES - 1) / TRI_QUERIES) * split, mesh, task)) return;
+    if (!geom::xcd_assign(bid, b, ((n + TRI_QUERIES - 1) / TRI_QUERIES) * split, mesh, task)) return;
     const int qtile = task / split, part = task - qtile * split;
     const int q0 = qtile * TRI_QUERIES;
     // this workgroup's group range, in units of 4 groups (m_pad is a multiple of 64)
@@ -1013,8 +1019,40 @@ __global__ __launch_bounds__(HS_WAVES * GEOM_WAVE) void tri_scan_grouped_kernel(
             surf.sqdist[o] = geom::dot3(d, d);
             surf.closest[3 * o + 0] = hit.x, surf.closest[3 * o + 1] = hit.y, surf.closest[3 * o + 2] = hit.z;
             surf.weights[3 * o + 0] = w.x, surf.weights[3 * o + 1] = w.y, surf.weights[3 * o + 2] = w.z;
+            if (surf.rec) { // backward record: (closest - p) * coef, corner weights; flag: zero weights are skipped
+                float4 *r = surf.rec + 2 * ((size_t)mesh * surf.per + surf.rec_first + q);
+                r[0] = make_float4(d.x * surf.coef, d.y * surf.coef, d.z * surf.coef, 1.f);
+                r[1] = make_float4(w.x, w.y, w.z, 0.f);
+            }
         }
     }
+}
+
+template <bool TRUNC, bool FIX6, int HS_WAVES>
+__global__ __launch_bounds__(HS_WAVES * GEOM_WAVE) void tri_scan_grouped_kernel(const float *__restrict__ xyz, int b, int n, int m,
+                                                                       TriGws ws, float *__restrict__ dist,
+                                                                       int *__restrict__ point, int *__restrict__ index,
+                                                                       SurfaceOut surf)
+{
+    tri_scan_grouped_body<TRUNC, FIX6, HS_WAVES>(blockIdx.x, xyz, b, n, m, ws, dist, point, index, surf);
+}
+
+// ---------------------------------------------------------------------------------------
+// The fused surface scan: the point-to-triangle tiles of the two-level scan AND the Chamfer NN jobs of both
+// directions in ONE launch (BASELINE.json north_star: "point-to-triangle projection fused into the same tile pass").
+// A heterogeneous grid: workgroups [0, tri_blocks) run a tri tile, the rest an NN tile.  The two bodies are
+// complementary -- the tri tile is a chain of short dependent phases (VALU 24 % busy, 27 KB of LDS), the NN tile is
+// pure VALU issue (4 KB of LDS) -- so sharing the CUs hides the former's latency under the latter's arithmetic instead
+// of running them back to back.  Tri tiles come first in the grid: they are the long ones.
+template <bool FIX6, bool FMA>
+__global__ __launch_bounds__(8 * GEOM_WAVE) void surface_scan_kernel(const float *__restrict__ xyz, int b, int n, int m, TriGws ws,
+                                                                      float *__restrict__ dist, int *__restrict__ point,
+                                                                      int *__restrict__ index, SurfaceOut surf, NNJob job,
+                                                                      NNRecords rr, int tri_blocks)
+{
+    static_assert(NNS_THREADS == 8 * GEOM_WAVE, "both bodies are written for 8-wave workgroups");
+    if ((int)blockIdx.x < tri_blocks) tri_scan_grouped_body<false, FIX6, 8>(blockIdx.x, xyz, b, n, m, ws, dist, point, index, surf);
+    else nn_scalar_body<FMA>(job, blockIdx.x - tri_blocks, rr);
 }
 
 template <bool INDEXED, bool TRUNC, bool FIX6>
@@ -1024,7 +1062,7 @@ int launch_grouped_variant(const TriJob &job, const TriGws &ws, const int *order
     hipLaunchKernelGGL((tri_prep_grouped_kernel<INDEXED, TRUNC, FIX6>), dim3((prep_items + 255) / 256, job.b), dim3(256), 0, s,
                        job, ws, order);
     const int qtiles = (job.n + TRI_QUERIES - 1) / TRI_QUERIES;
-    const SurfaceOut so = ws.split > 1 ? SurfaceOut{nullptr, nullptr, 0, nullptr, nullptr, nullptr} : surf;
+    const SurfaceOut so = ws.split > 1 ? NO_SURFACE : surf;
     const dim3 grid(geom::xcd_grid(job.b, qtiles * ws.split));
     if ((int64_t)job.b * qtiles * ws.split >= 256) // enough workgroups to fill the chip: fewer, longer-lived waves
         hipLaunchKernelGGL((tri_scan_grouped_kernel<TRUNC, FIX6, 8>), grid, dim3(8 * GEOM_WAVE), 0, s, job.xyz, job.b, job.n,
@@ -1063,7 +1101,7 @@ inline size_t ws_bytes_needed(int b, int n, int m_pad)
 // *fused = whether the scan wrote the point-to-surface outputs itself (else the caller launches the separate kernel)
 template <bool INDEXED>
 int launch_tri_ws(const TriJob &job, const int *order, unsigned flags, void *workspace, size_t ws_bytes, void *stream,
-                  const SurfaceOut &surf = SurfaceOut{nullptr, nullptr, 0, nullptr, nullptr, nullptr}, bool *fused = nullptr)
+                  const SurfaceOut &surf = NO_SURFACE, bool *fused = nullptr)
 {
     if (fused) *fused = false;
     const int m_pad = ws_pad(job.m);
@@ -1205,4 +1243,94 @@ extern "C" int geom_tri_surface_fwd_f32(int b, int n, const float *xyz, int nv, 
                                   SurfaceOut{verts, faces, nv, sqdist, closest, weights}, &fused);
     if (rc != 0 || fused) return rc;
     return geom_p2tri_loss_fwd_f32(b, n, xyz, nv, verts, nf, faces, point, index, sqdist, closest, weights, stream);
+}
+
+namespace {
+template <bool FMA>
+__global__ __launch_bounds__(NNS_THREADS) void nn_records_kernel(NNJob job, NNRecords rr) { nn_scalar_body<FMA>(job, blockIdx.x, rr); }
+} // namespace
+
+// The two arg-min scans of the surface loss in one call (utils.py:451 + 470: chamfer_dist, then tri_dist on the gathered
+// corners).  gt [b,n_gt,3] against the sampled points [b,num,3]: NN both ways (sq_gt / idx_p for the gt points, sq_pred /
+// idx_g for the sampled points, as geom_chamfer_nn_f32(gt, points)); and, when verts != NULL, gt against the mesh
+// (tri_dist / option / index + the point-to-surface quantities sq / closest / weights, as geom_tri_surface_fwd_f32).
+// With a coherent triangle order, the default arithmetic flags and enough query tiles to fill the chip both scans run
+// as ONE heterogeneous launch after the triangle-record prep; otherwise as the separate launches.  order_scratch (may be
+// NULL): the finalize scratch of geom_surface_finalize_f32 -- the scans then also write every point's gradient record
+// into it (u, v: the sampled points' draws; coef_*: the two gradient coefficients); *records_written tells the caller
+// whether they did (the split / brute-force / truncation variants leave them to the finalize pass).
+extern "C" int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, const float *points, float *sq_gt,
+                                     int *idx_p, float *sq_pred, int *idx_g, int nv, const float *verts, int nf,
+                                     const int64_t *faces, const int *tri_order, float *tri_dist, int *option, int *index,
+                                     float *sq, float *closest, float *weights, const float *u, const float *v,
+                                     float coef_sample, float coef_other, int *order_scratch, unsigned flags,
+                                     void *workspace, size_t workspace_bytes, int *records_written, void *stream)
+{
+    if (records_written) *records_written = 0;
+    if (b < 0 || n_gt < 0 || num < 0 || nf < 0 || nv < 0) return GEOM_EINVAL;
+    if (b == 0) return 0;
+    if (n_gt == 0 || num == 0) return GEOM_EINVAL;
+    if (!gt || !points || !sq_gt || !idx_p || !sq_pred || !idx_g) return GEOM_EINVAL;
+    const bool tri = verts != nullptr;
+    if (tri && (!faces || !tri_dist || !option || !index || !sq || !closest || !weights || nf == 0 || nv == 0)) return GEOM_EINVAL;
+    if (order_scratch && (!u || !v || ((uintptr_t)order_scratch & 15))) return GEOM_EINVAL;
+    if (b > 65535 || nf >= (1 << 26)) return GEOM_ETOOBIG;
+    const unsigned nn_flags = flags & (GEOM_FLAG_REF_TAIL_TRUNC | GEOM_FLAG_NN_FMA);
+    const unsigned tri_flags = flags & (GEOM_FLAG_REF_TAIL_TRUNC | GEOM_FLAG_FIX_REGION6 | GEOM_FLAG_TRI_BRUTE_FORCE);
+    if ((nn_flags & GEOM_FLAG_REF_TAIL_TRUNC) && (nn_flags & GEOM_FLAG_NN_FMA)) return GEOM_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t cap = (int64_t)num + n_gt;
+    float4 *rec = order_scratch ? reinterpret_cast<float4 *>(order_scratch + geom_surface_order_ints(b, nf, cap)) : nullptr;
+    NNJob job{gt, points, sq_gt, sq_pred, idx_p, idx_g, b, n_gt, num};
+    const int longer = n_gt > num ? n_gt : num;
+    const int nn_tiles = (longer + NN_QUERIES - 1) / NN_QUERIES;
+    if ((int64_t)geom::NUM_XCD * nn_tiles * ((2 * (int64_t)b + 7) / 8) > 0x3fffffffLL) return GEOM_ETOOBIG;
+    const unsigned nn_blocks = geom::xcd_grid(2 * b, nn_tiles);
+    const bool fma = nn_flags & GEOM_FLAG_NN_FMA;
+    // records of the NN side: the sampled points always; the gt points through their nearest sample only without a tri scan
+    NNRecords rr{rec, u, v, coef_sample, coef_other, (int)(tri ? cap : cap), tri ? 0 : 1};
+
+    if (tri) {
+        const int m_pad = ws_pad(nf);
+        const int split = ws_split(b, n_gt, m_pad);
+        const bool fusable = tri_order && !(tri_flags & (GEOM_FLAG_REF_TAIL_TRUNC | GEOM_FLAG_TRI_BRUTE_FORCE)) &&
+                             !(nn_flags & GEOM_FLAG_REF_TAIL_TRUNC) && split == 1 &&
+                             (int64_t)b * ((n_gt + TRI_QUERIES - 1) / TRI_QUERIES) >= 256;
+        if (fusable) {
+            if (!workspace || workspace_bytes < ws_bytes_needed(b, n_gt, m_pad) || ((uintptr_t)workspace & 15)) return GEOM_EINVAL;
+            float4 *base = static_cast<float4 *>(workspace);
+            float4 *grp = base + (size_t)b * m_pad * 4;
+            float4 *first = grp + (size_t)b * (m_pad / GRP);
+            TriGws gws{base, base + (size_t)b * m_pad, grp, first, reinterpret_cast<unsigned long long *>(first + (size_t)b * 3), m_pad, 1};
+            TriJob tj{gt, nullptr, nullptr, nullptr, verts, faces, tri_dist, option, index, b, n_gt, nf, nv};
+            const bool fix6 = tri_flags & GEOM_FLAG_FIX_REGION6;
+            if (fix6) hipLaunchKernelGGL((tri_prep_grouped_kernel<true, false, true>), dim3((m_pad + 255) / 256, b), dim3(256), 0, s, tj, gws, tri_order);
+            else hipLaunchKernelGGL((tri_prep_grouped_kernel<true, false, false>), dim3((m_pad + 255) / 256, b), dim3(256), 0, s, tj, gws, tri_order);
+            const int qtiles = (n_gt + TRI_QUERIES - 1) / TRI_QUERIES;
+            const unsigned tri_blocks = geom::xcd_grid(b, qtiles);
+            SurfaceOut so{verts, faces, nv, sq, closest, weights, rec, coef_other, (int)cap, num};
+            const dim3 grid(tri_blocks + nn_blocks), block(8 * GEOM_WAVE);
+#define GEOM_LAUNCH_SCAN(F6, FM)                                                                                                \
+    hipLaunchKernelGGL((surface_scan_kernel<F6, FM>), grid, block, 0, s, gt, b, n_gt, nf, gws, tri_dist, option, index, so, job, rr, \
+                       (int)tri_blocks)
+            if (fix6 && fma) GEOM_LAUNCH_SCAN(true, true);
+            else if (fix6) GEOM_LAUNCH_SCAN(true, false);
+            else if (fma) GEOM_LAUNCH_SCAN(false, true);
+            else GEOM_LAUNCH_SCAN(false, false);
+#undef GEOM_LAUNCH_SCAN
+            if (records_written) *records_written = rec != nullptr;
+            return geom::launch_status();
+        }
+        // the other tri variants: separate launches, records left to the finalize pass
+        const int rc = geom_tri_surface_fwd_f32(b, n_gt, gt, nv, verts, nf, faces, tri_order, tri_dist, option, index, sq, closest,
+                                                weights, tri_flags, workspace, workspace_bytes, stream);
+        if (rc != 0) return rc;
+        return geom_chamfer_nn_f32(b, n_gt, gt, num, points, sq_gt, idx_p, sq_pred, idx_g, nn_flags, stream);
+    }
+    // no tri scan (batch_point_to_point): the NN launch writes both kinds of records
+    if (nn_flags & GEOM_FLAG_REF_TAIL_TRUNC) return geom_chamfer_nn_f32(b, n_gt, gt, num, points, sq_gt, idx_p, sq_pred, idx_g, nn_flags, stream);
+    if (fma) hipLaunchKernelGGL(nn_records_kernel<true>, dim3(nn_blocks), dim3(NNS_THREADS), 0, s, job, rr);
+    else hipLaunchKernelGGL(nn_records_kernel<false>, dim3(nn_blocks), dim3(NNS_THREADS), 0, s, job, rr);
+    if (records_written) *records_written = rec != nullptr;
+    return geom::launch_status();
 }

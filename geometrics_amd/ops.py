@@ -3,6 +3,7 @@
 Every function launches on torch's current stream, allocates its outputs with torch and
 never synchronises with the host, so a whole training step can be captured in a HIP graph.
 """
+import ctypes
 import weakref
 
 import torch
@@ -197,41 +198,46 @@ class SurfaceLoss(torch.autograd.Function):
         if not two_sided:
             ws_bytes = L.geom_tri_distance_workspace_bytes(b, n_gt, nf)
             ws = torch.empty(max(ws_bytes, 16) // 4, **f32)
-            order = face_order(verts_c, faces)      # cached k-d leaf order of the faces: two-level scan
+            tri_order = face_order(verts_c, faces)      # cached k-d leaf order of the faces: two-level scan
             tri_d, option, index = torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, **i32), torch.empty(b, n_gt, **i32)
             sq, closest, weights = torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, 3, **f32), torch.empty(b, n_gt, 3, **f32)
         with torch.cuda.device(dev):
-            if not two_sided:
-                # (An earlier version ran this branch beside sampling + NN on a second stream.  Inside a captured graph
-                # every fork/join edge costs 5-10 us of dependency latency, and the two scans then share the CUs' LDS
-                # and issue slots: measured 0.567 ms/step forked vs 0.551 ms/step in line.)
-                # tri scan + the closest point / weights / squared distance of the winner, one call (one launch with
-                # the two-level scan)
-                _lib.check(L.geom_tri_surface_fwd_f32(
-                    b, n_gt, gt_c.data_ptr(), nv, verts_c.data_ptr(), nf, faces.data_ptr(), _lib.ptr(order), tri_d.data_ptr(),
-                    option.data_ptr(), index.data_ptr(), sq.data_ptr(), closest.data_ptr(), weights.data_ptr(), 0,
-                    ws.data_ptr(), ws_bytes, _lib.stream_ptr()), "geom_tri_surface_fwd_f32")
             if not have_points:
                 _lib.call("geom_sample_faces_fwd_f32", b, nv, verts_c.data_ptr(), nf, faces.data_ptr(), num,
                           choices.data_ptr(), u.data_ptr(), v.data_ptr(), points.data_ptr())
-            _lib.check(L.geom_chamfer_nn_f32(b, n_gt, gt_c.data_ptr(), num, points.data_ptr(), sq_gt.data_ptr(),
-                                             idx_p.data_ptr(), sq_pred.data_ptr(), idx_g.data_ptr(),
-                                             _chamfer.default_flags(), _lib.stream_ptr()), "geom_chamfer_nn_f32")
-            # finalize: the loss reduction AND, when a gradient is wanted, the backward's preparation (gradient record per
-            # point, points counting-sorted by face in ascending id order) in one launch; the backward is then a
-            # single gather launch
+            # Both arg-min scans -- Chamfer NN in both directions and (one-sided loss) the point-to-triangle scan with
+            # the closest point / weights / squared distance of the winner -- in ONE call: one heterogeneous launch
+            # behind the triangle-record prep.  (Round 1 ran them back to back: two streams inside a captured graph cost
+            # 5-10 us per fork/join edge.)  When a gradient is wanted the scans also write every point's gradient record
+            # into the backward scratch.
             want = bool(ctx.needs_input_grad[0])
             order = torch.empty(L.geom_surface_order_words(b, nf, num, n_gt), dtype=torch.int32, device=dev)
+            coef_s, coef_o = scale / (b * num), scale / (b * n_gt)
+            wrote = ctypes.c_int(0)
+            flags = _chamfer.default_flags()
+            if two_sided:
+                tri_args = (nv, None, nf, None, None, None, None, None, None, None, None)    # nf still sizes the scratch layout
+                ws_ptr, ws_len = None, 0
+            else:
+                tri_args = (nv, verts_c.data_ptr(), nf, faces.data_ptr(), _lib.ptr(tri_order), tri_d.data_ptr(),
+                            option.data_ptr(), index.data_ptr(), sq.data_ptr(), closest.data_ptr(), weights.data_ptr())
+                ws_ptr, ws_len = ws.data_ptr(), ws_bytes
+            _lib.check(L.geom_surface_scan_f32(
+                b, n_gt, gt_c.data_ptr(), num, points.data_ptr(), sq_gt.data_ptr(), idx_p.data_ptr(), sq_pred.data_ptr(),
+                idx_g.data_ptr(), *tri_args, u.data_ptr(), v.data_ptr(), coef_s, coef_o, order.data_ptr() if want else None,
+                flags, ws_ptr, ws_len, ctypes.byref(wrote), _lib.stream_ptr()), "geom_surface_scan_f32")
+            # finalize: the loss reduction AND, when a gradient is wanted, the backward's preparation (points counting-sorted
+            # by face in ascending id order; the records too when the scans could not write them) in one launch; the
+            # backward is then a single gather launch
             other_sq = sq_gt if two_sided else sq
             args = (b, nf, num, choices.data_ptr(), u.data_ptr(), v.data_ptr(), points.data_ptr(), n_gt, gt_c.data_ptr(),
                     idx_g.data_ptr(), idx_p.data_ptr() if two_sided else None, None if two_sided else index.data_ptr(),
                     None if two_sided else closest.data_ptr(), None if two_sided else weights.data_ptr(),
-                    sq_pred.data_ptr(), other_sq.data_ptr(), scale / sq_pred.numel(), scale / other_sq.numel(),
-                    scale / (b * num), scale / (b * n_gt))
-            code = L.geom_surface_finalize_f32(*args, int(want), order.data_ptr(), out.data_ptr(), _lib.stream_ptr())
+                    sq_pred.data_ptr(), other_sq.data_ptr(), scale / sq_pred.numel(), scale / other_sq.numel(), coef_s, coef_o)
+            code = L.geom_surface_finalize_f32(*args, int(want), wrote.value, order.data_ptr(), out.data_ptr(), _lib.stream_ptr())
             if code == _lib.EUNSUPPORTED:       # too many faces + points for the in-LDS ordering: loss only, scatter backward
                 want = False
-                code = L.geom_surface_finalize_f32(*args, 0, order.data_ptr(), out.data_ptr(), _lib.stream_ptr())
+                code = L.geom_surface_finalize_f32(*args, 0, 0, order.data_ptr(), out.data_ptr(), _lib.stream_ptr())
             _lib.check(code, "geom_surface_finalize_f32")
             ctx.order = order if want else None
             if two_sided:

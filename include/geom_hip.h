@@ -314,6 +314,25 @@ int geom_pool_features_bwd_f32(int b, int nv, const float *verts, const float *c
                                const float *grad_out, float *const *grad_blocks, float *grad_verts,
                                void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- the two arg-min scans of the surface loss in one call (utils.py:451 + 470) ----------------------------------
+ * gt [b,n_gt,3] against the sampled points [b,num,3]: nearest neighbours both ways, exactly geom_chamfer_nn_f32(gt,
+ * points) -> (sq_gt, idx_p) for the gt points, (sq_pred, idx_g) for the sampled points; and, when verts != NULL, gt
+ * against the mesh, exactly geom_tri_surface_fwd_f32 -> tri_dist / option / index + sq / closest / weights.  With a
+ * coherent tri_order, default tri flags and at least 256 query tiles both scans run as ONE heterogeneous launch
+ * (workgroups [0, tri tiles) scan triangles, the rest scan points) behind the triangle-record prep; otherwise as the
+ * separate launches -- same results either way.  flags: GEOM_FLAG_FIX_REGION6 / _TRI_BRUTE_FORCE / _REF_TAIL_TRUNC /
+ * _NN_FMA as for the separate entry points.  workspace: as geom_tri_distance_workspace_bytes(b, n_gt, nf).
+ * order_scratch (may be NULL): the `order` buffer of geom_surface_finalize_f32; the scans then also write every
+ * point's gradient record into it (u, v [b,num]: the draws of the sampled points; coef_sample / coef_other as for the
+ * finalize) and *records_written = 1; the variants that cannot (split query tiles, brute force, tail truncation)
+ * leave *records_written = 0 and the finalize pass forms the records itself. */
+int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, const float *points, float *sq_gt, int *idx_p,
+                          float *sq_pred, int *idx_g, int nv, const float *verts, int nf, const int64_t *faces,
+                          const int *tri_order, float *tri_dist, int *option, int *index, float *sq, float *closest,
+                          float *weights, const float *u, const float *v, float coef_sample, float coef_other,
+                          int *order_scratch, unsigned flags, void *workspace, size_t workspace_bytes,
+                          int *records_written, void *stream);
+
 /* ---- surface loss: forward-side finalize + single-launch backward ------------------------------------------
  * geom_surface_finalize_f32 runs once after the two scans of batch_point_to_surface / batch_point_to_point
  * (utils.py:393-502).  It (a) writes the scalar loss = scale_sample * sum(sq_sample[b,num]) + scale_other *
@@ -327,13 +346,15 @@ int geom_pool_features_bwd_f32(int b, int nv, const float *verts, const float *c
  * GEOM_EUNSUPPORTED when nf + num + n_gt exceeds ~38 000 (call again with want_order = 0 and use the scatter
  * backward).  geom_surface_gather_f32 is then the whole backward: grad_verts[b,nv,3] = 2 * grad[0] * sum over the
  * points on the vertex's incident faces (vf_ptr / vf_item: static CSR vertex -> (face << 2 | corner)), every element
- * written once, no float atomics, bit-reproducible.  has_other = whether idx_p or index was given to the finalize. */
+ * written once, no float atomics, bit-reproducible.  has_other = whether idx_p or index was given to the finalize.
+ * records_ready != 0: the gradient records were already written into `order` by geom_surface_scan_f32. */
 int64_t geom_surface_order_words(int b, int nf, int num, int n_gt);
 int geom_surface_finalize_f32(int b, int nf, int num, const int64_t *choices, const float *u, const float *v,
                               const float *points, int n_gt, const float *gt, const int *idx_g, const int *idx_p,
                               const int *index, const float *closest, const float *weights, const float *sq_sample,
                               const float *sq_other, float scale_sample, float scale_other, float coef_sample,
-                              float coef_other, int want_order, int *order, float *loss, void *stream);
+                              float coef_other, int want_order, int records_ready, int *order, float *loss,
+                              void *stream);
 int geom_surface_gather_f32(int b, int nv, int nf, const int *vf_ptr, const int *vf_item, int num, int n_gt,
                             int has_other, const int *order, const float *grad, float *grad_verts, void *stream);
 

@@ -673,6 +673,69 @@ def test_gather_backward_at_the_reference_training_shape(gpu):
     assert torch.allclose(grads[0], ref, rtol=2e-5, atol=2e-6 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("two_sided", [False, True])
+@pytest.mark.parametrize("fma", [False, True])
+def test_fused_surface_scan_equals_the_separate_scans_and_its_records_those_of_the_finalize_pass(gpu, two_sided, fma):
+    """geom_surface_scan_f32 at the BASELINE shard (8 meshes: one heterogeneous launch for the tri tiles and the NN
+    tiles) against geom_chamfer_nn_f32 + geom_tri_surface_fwd_f32, bit for bit; and the gradient records its epilogues
+    write against the ones the finalize pass forms from the saved tensors -- same `order` scratch, same gradient."""
+    import ctypes
+    from geometrics_amd import _lib as L
+    from geometrics_amd.chamfer_distance import chamfer_nn
+    from geometrics_amd.tri_distance import face_order, tri_distance_indexed
+    lib = L.lib()
+    V, Fc = meshgen.icosphere(4)
+    B, num, n_gt = 8, 3000, 3000
+    verts, faces, gt = dev(meshgen.jittered_batch(V, B), gpu), dev(Fc, gpu), dev(meshgen.gt_cloud(B, n_gt), gpu)
+    ops.manual_seed(21)
+    choices, u, v, points = ops.draw_samples(verts, faces, num, with_points=True)
+    nv, nf = V.shape[0], Fc.shape[0]
+    flags = L.FLAG_NN_FMA if fma else 0
+    f32, i32 = dict(dtype=torch.float32, device=gpu), dict(dtype=torch.int32, device=gpu)
+    order_tri = face_order(verts, faces)
+    ws_bytes = lib.geom_tri_distance_workspace_bytes(B, n_gt, nf)
+    coef_s, coef_o = 3000.0 / (B * num), 3000.0 / (B * n_gt)
+
+    def run(with_records):
+        o = dict(sq_gt=torch.empty(B, n_gt, **f32), idx_p=torch.empty(B, n_gt, **i32), sq_pred=torch.empty(B, num, **f32),
+                 idx_g=torch.empty(B, num, **i32), tri_d=torch.empty(B, n_gt, **f32), option=torch.empty(B, n_gt, **i32),
+                 index=torch.empty(B, n_gt, **i32), sq=torch.empty(B, n_gt, **f32), closest=torch.empty(B, n_gt, 3, **f32),
+                 weights=torch.empty(B, n_gt, 3, **f32), ws=torch.empty(ws_bytes // 4, **f32),
+                 order=torch.zeros(lib.geom_surface_order_words(B, nf, num, n_gt), **i32), loss=torch.empty((), **f32))
+        wrote = ctypes.c_int(-1)
+        tri = (nv, None, nf, None, None, None, None, None, None, None, None) if two_sided else \
+              (nv, verts.data_ptr(), nf, faces.data_ptr(), order_tri.data_ptr(), o["tri_d"].data_ptr(), o["option"].data_ptr(),
+               o["index"].data_ptr(), o["sq"].data_ptr(), o["closest"].data_ptr(), o["weights"].data_ptr())
+        L.check(lib.geom_surface_scan_f32(B, n_gt, gt.data_ptr(), num, points.data_ptr(), o["sq_gt"].data_ptr(),
+                                          o["idx_p"].data_ptr(), o["sq_pred"].data_ptr(), o["idx_g"].data_ptr(), *tri,
+                                          u.data_ptr(), v.data_ptr(), coef_s, coef_o,
+                                          o["order"].data_ptr() if with_records else None, flags, o["ws"].data_ptr(), ws_bytes,
+                                          ctypes.byref(wrote), L.stream_ptr()), "geom_surface_scan_f32")
+        assert wrote.value == int(with_records)
+        other = o["sq_gt"] if two_sided else o["sq"]
+        L.call("geom_surface_finalize_f32", B, nf, num, choices.data_ptr(), u.data_ptr(), v.data_ptr(), points.data_ptr(), n_gt,
+               gt.data_ptr(), o["idx_g"].data_ptr(), o["idx_p"].data_ptr() if two_sided else None,
+               None if two_sided else o["index"].data_ptr(), None if two_sided else o["closest"].data_ptr(),
+               None if two_sided else o["weights"].data_ptr(), o["sq_pred"].data_ptr(), other.data_ptr(), coef_s, coef_o, coef_s,
+               coef_o, 1, wrote.value, o["order"].data_ptr(), o["loss"].data_ptr())
+        vf_ptr, vf_item = ops.vertex_faces(faces, nv)
+        o["grad"] = torch.empty(B, nv, 3, **f32)
+        L.call("geom_surface_gather_f32", B, nv, nf, vf_ptr.data_ptr(), vf_item.data_ptr(), num, n_gt, 1, o["order"].data_ptr(),
+               None, o["grad"].data_ptr())
+        return o
+
+    a, c = run(True), run(False)
+    for k in ("sq_gt", "idx_p", "sq_pred", "idx_g", "loss", "grad") + (() if two_sided else ("tri_d", "option", "index", "sq", "closest", "weights")):
+        assert torch.equal(a[k], c[k]), k
+    assert torch.equal(a["order"], c["order"])           # offsets, ordered ids AND records, word for word
+    # the separate entry points
+    d1, i1, d2, i2 = chamfer_nn(gt, points, flags)
+    assert torch.equal(a["sq_gt"], d1) and torch.equal(a["idx_p"], i1) and torch.equal(a["sq_pred"], d2) and torch.equal(a["idx_g"], i2)
+    if not two_sided:
+        dt, pt, it = tri_distance_indexed(gt, verts, faces)
+        assert torch.equal(a["tri_d"], dt) and torch.equal(a["option"], pt) and torch.equal(a["index"], it)
+
+
 def test_tri_surface_fused_call_equals_scan_plus_point_to_triangle(gpu):
     """geom_tri_surface_fwd_f32 (scan epilogue writes sqdist / closest / weights) against the two separate entry
     points, for the two-level scan (fused), the flat scan, the brute-force scan and a single mesh (split query tiles:
