@@ -1044,6 +1044,12 @@ __global__ __launch_bounds__(HS_WAVES * GEOM_WAVE) void tri_scan_grouped_kernel(
 // complementary -- the tri tile is a chain of short dependent phases (VALU 24 % busy, 27 KB of LDS), the NN tile is
 // pure VALU issue (4 KB of LDS) -- so sharing the CUs hides the former's latency under the latter's arithmetic instead
 // of running them back to back.  Tri tiles come first in the grid: they are the long ones.
+// Measured alternatives (8-mesh shard, us incl. the 5 us prep launch; separate launches: 66.7): tri tiles first 56.9,
+// NN tiles first 64.9, interleaved 8:16 70.3 -- the launch lasts as long as its last TRI tile (a 31 us chain), so all of
+// them have to start at once; s_setprio(3) on the tri waves: no change (they are not starved of issue slots); an 80-VGPR
+// build (3 workgroups per CU instead of 2, 13 registers spilled): 55.3.  PMC of this launch: 32.0 M VALU instructions
+// = 40 T lane-ops/s, 0.51 of the 78.6 T spec issue rate and 0.78 of the 51.5 T the chip sustains on un-packed v_fma_f32
+// (MI355X_MICROARCH.md: 103 TFLOP/s measured) -- the fused launch is VALU-issue bound, what is left is instruction count.
 template <bool FIX6, bool FMA>
 __global__ __launch_bounds__(8 * GEOM_WAVE) void surface_scan_kernel(const float *__restrict__ xyz, int b, int n, int m, TriGws ws,
                                                                       float *__restrict__ dist, int *__restrict__ point,

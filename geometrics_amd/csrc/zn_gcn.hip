@@ -272,6 +272,7 @@ struct EllArgs {
     // summed after the table slots, i.e. still in CSR order.  over_ptr == null: no row is longer than W.
     const int *over_ptr, *over_col;
     const float *over_val;
+    int b, chunks; // meshes, workgroups per mesh (filled in by the dispatcher)
 };
 
 // MASK (ReLU, NC == 2 only): the forward also stores the sign of every output element as one bit (12 bits per
@@ -286,7 +287,11 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a
     const int kg = a.k >> 2;                         // aggregated float4 groups per row
     const int j = threadIdx.x % kg;
     const int rl = threadIdx.x / kg;
-    const int64_t mesh_row0 = (int64_t)blockIdx.y * a.nv;
+    // a mesh's workgroups share one XCD (geom::xcd_assign): the neighbour rows every thread gathers -- each row of the
+    // k-slice is read by ~7 workgroups -- then hit that XCD's L2 instead of being fetched into all eight
+    int mesh_i, chunk_i;
+    if (!geom::xcd_assign(blockIdx.x, a.b, a.chunks, mesh_i, chunk_i)) return;
+    const int64_t mesh_row0 = (int64_t)mesh_i * a.nv;
     const int c0 = 4 * j;
     // `iters` consecutive row tiles per workgroup (the backward uses 2: half the bias-gradient partials to reduce)
     float4 csum[NC + 1]; // bias-gradient terms of this thread's columns over its rows (backward)
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a
     for (int i = 0; i <= NC; ++i) csum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     for (int it = 0; it < iters; ++it) {
-    const int r = (blockIdx.x * iters + it) * rows_per_block + rl;
+    const int r = (chunk_i * iters + it) * rows_per_block + rl;
     const bool active = rl < rows_per_block && r < a.nv;
     float4 own[NC + 1]; // [0] = own aggregated-slot element (backward only), [1..NC] = pass-through
 #pragma unroll
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a
         for (int c = threadIdx.x; c < a.c; c += GCN_THREADS) {
             float t = 0.f;
             for (int l = 0; l < rows_per_block; ++l) t += lds_cs[l * a.c + c];
-            colsum_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * a.c + c] = t;
+            colsum_partial[((size_t)mesh_i * a.chunks + chunk_i) * a.c + c] = t;
         }
     }
 }
@@ -475,7 +480,9 @@ int dispatch_ell(EllArgs a, int b, int w, int act, float *grad_bias, float *scra
     const int chunks = (a.nv + rpb * iters - 1) / (rpb * iters);
     float *partial = grad_bias ? scratch : nullptr;
     const size_t lds = (BACKWARD && partial) ? (size_t)rpb * a.c * sizeof(float) : 0;
-    dim3 grid((unsigned)chunks, (unsigned)b);
+    a.b = b;
+    a.chunks = chunks;
+    dim3 grid(geom::xcd_grid(b, chunks));
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (act) {
     case ACT_NONE: launch_ell_shape<ACT_NONE, BACKWARD>(a, w, grid, lds, s, rpb, iters, partial); break;

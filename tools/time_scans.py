@@ -52,3 +52,33 @@ t_mort = timeit(lambda: tri_distance_indexed(gt, verts, faces, order=mort))
 ident = torch.arange(faces.shape[0], device=dev, dtype=torch.int32)
 t_ident = timeit(lambda: tri_distance_indexed(gt, verts, faces, order=ident))
 print(f"tri: grouped/k-d order {t_tri:.1f} us  grouped/Morton {t_mort:.1f} us  grouped/identity order {t_ident:.1f} us  flat {t_flat:.1f} us  grouped/random order {t_rand:.1f} us")
+
+# ---- the fused surface scan (NN tiles + tri tiles in one launch) ----
+import ctypes
+from geometrics_amd import _lib as L, ops
+from geometrics_amd.tri_distance import face_order
+lib = L.lib()
+nv, nf, num, n_gt = V.shape[0], F.shape[0], 3000, 3000
+f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
+o = [torch.empty(B, n_gt, **f32), torch.empty(B, n_gt, **i32), torch.empty(B, num, **f32), torch.empty(B, num, **i32),
+     torch.empty(B, n_gt, **f32), torch.empty(B, n_gt, **i32), torch.empty(B, n_gt, **i32), torch.empty(B, n_gt, **f32),
+     torch.empty(B, n_gt, 3, **f32), torch.empty(B, n_gt, 3, **f32)]
+ws_bytes = lib.geom_tri_distance_workspace_bytes(B, n_gt, nf)
+ws = torch.empty(ws_bytes // 4, **f32)
+order = torch.empty(lib.geom_surface_order_words(B, nf, num, n_gt), **i32)
+uu, vv = torch.rand(B, num, device=dev), torch.rand(B, num, device=dev)
+tri_order = face_order(verts, faces)
+wrote = ctypes.c_int(0)
+
+
+def fused(flags=0, records=True):
+    L.check(lib.geom_surface_scan_f32(B, n_gt, gt.data_ptr(), num, pred.data_ptr(), o[0].data_ptr(), o[1].data_ptr(),
+                                      o[2].data_ptr(), o[3].data_ptr(), nv, verts.data_ptr(), nf, faces.data_ptr(),
+                                      tri_order.data_ptr(), o[4].data_ptr(), o[5].data_ptr(), o[6].data_ptr(), o[7].data_ptr(),
+                                      o[8].data_ptr(), o[9].data_ptr(), uu.data_ptr(), vv.data_ptr(), 1.0, 1.0,
+                                      order.data_ptr() if records else None, flags, ws.data_ptr(), ws_bytes,
+                                      ctypes.byref(wrote), L.stream_ptr()), "scan")
+
+
+print(f"fused scan (prep + NN/tri launch): {timeit(fused):.1f} us   without records {timeit(lambda: fused(0, False)):.1f} us   "
+      f"FMA NN {timeit(lambda: fused(8)):.1f} us")

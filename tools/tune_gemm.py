@@ -1,7 +1,8 @@
 """Regenerate geometrics_amd/tuning/tunableop_gfx950.csv on an MI355X:
-    python tools/tune_gemm.py gpurun_out/tunableop_gfx950.csv
+    python tools/tune_gemm.py gpurun_out/tunableop_gfx950.csv [V ...]
 Runs PyTorch TunableOp over the GEMM shapes of the 0N-GCN stacks (forward, dW, dX) for the
-shard sizes the benchmarks and tests use."""
+shard sizes the benchmarks and tests use: V = 2562 (BASELINE icosphere) and 482 (the reference's training template,
+GEOMetrics.py:44) by default.  tools/merge_tuning.py folds a partial result into the shipped file."""
 import os
 import sys
 
@@ -15,9 +16,9 @@ torch.cuda.tunable.set_filename(out)
 torch.cuda.tunable.set_max_tuning_duration(60)
 torch.cuda.tunable.set_max_tuning_iterations(40)
 dev = torch.device("cuda:0")
-V = 2562
+verts = [int(a) for a in sys.argv[2:]] or [2562, 482]
 layers = [(963, 192), (192, 192), (1155, 192), (192, 3)]
-for meshes in (1, 2, 4, 8, 16):
+for V, meshes in [(V, m) for V in verts for m in (1, 2, 4, 8, 16)]:
     M = meshes * V
     for cin, cout in layers:
         x = torch.randn(M, cin, device=dev, requires_grad=True)
@@ -27,5 +28,5 @@ for meshes in (1, 2, 4, 8, 16):
         x3 = torch.randn(meshes, V, cin, device=dev, requires_grad=True)      # the [B,V,C] @ [C,O] path
         (x3 @ w).sum().backward()
 torch.cuda.synchronize()
-torch.cuda.tunable.write_file()
+getattr(torch.cuda.tunable, "write_file", lambda: None)()     # older builds write at exit only
 print("wrote", out)
