@@ -38,14 +38,15 @@ V_LEVEL, S_PTS, G_PTS, FEAT, HID = 4, 3000, 3000, 963, 192
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector peak == f32 MFMA dense peak
 
-# Work per (point, triangle) pair of the culled tri scan: the cull test is
-# 3 sub, 3 mul, 2 add (|p-c|^2), 1 add + 1 mul ((r_eff+s)^2) and 1 compare = 11 fp32 lane-ops, none of
-# them fusable into FMAs.  Survivor evaluation (~40 literal decision trees per point) is NOT counted,
-# so `achieved` is a lower bound of the executed arithmetic.
+# Roofline constants (MI355X_MICROARCH.md).  The two arg-min scans are fp32-VALU work written WITHOUT fused multiply-adds
+# (the pinned reference arithmetic): every executed lane-op carries one flop, so their issue ceiling is half of the
+# 157.3 TFLOP/s FMA peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s.  The guide's own measurement of
+# un-packed v_fma_f32 is 103 TFLOP/s = 51.5 T lane-ops/s: what the chip sustains in practice.
+VALU_ISSUE_TERA_LANE_OPS = FP32_PEAK_TFLOPS / 2.0
+VALU_MEASURED_TERA_LANE_OPS = 103.0 / 2.0
 TRI_ALGO_FLOP_PER_PAIR = 60.0    # hoisted op count of the reference's decision tree per (point, triangle)
-VALU_ISSUE_TERA_LANE_OPS = 78.6  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz: what un-fused fp32 code can issue
 NN_FLOP_PER_PAIR = 8.0           # 3 sub, 3 mul, 2 add
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_counters.json")
 
 
 class Workload:
@@ -182,90 +183,161 @@ def event_time_us(fn, iters=30, warm=5):
     return s.elapsed_time(e) * 1e3 / iters
 
 
+_pmc_cache = None
+
+
+def pmc_table():
+    """Per-kernel rocprofv3 counters committed under profiles/ (tools/pmc_traffic.sh), or {} when the file is missing or
+    was collected for OTHER kernel sources: it is stamped with the digest of geometrics_amd/csrc + include, and a
+    mismatch means the kernels changed since -- stale counters are never reported."""
+    global _pmc_cache
+    if _pmc_cache is None:
+        _pmc_cache = {}
+        try:
+            with open(PMC_FILE) as f:
+                table = json.load(f)
+            from geometrics_amd import build as hip_build
+            if table.get("_meta", {}).get("source_sha256") == hip_build.source_digest():
+                _pmc_cache = table
+        except (OSError, ValueError):
+            pass
+    return _pmc_cache
+
+
+def pmc_row(kernel_prefix):
+    for name, row in pmc_table().items():
+        if name.startswith(kernel_prefix):
+            return row
+    return None
+
+
 def pmc_traffic_bytes(kernel_prefix):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE are in KiB;
-    calibrated 1:1 on the aggregation kernel's known byte count, see profiles/README.md), or None."""
-    try:
-        with open(PMC_FILE) as f:
-            table = json.load(f)
-    except (OSError, ValueError):
+    """HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, KiB; calibrated 1:1 on the aggregation kernel's known byte
+    count, profiles/README.md), or None without valid counters."""
+    row = pmc_row(kernel_prefix)
+    if row is None or "FETCH_SIZE_KB_per_launch" not in row:
         return None
-    for name, row in table.items():
-        if name.startswith(kernel_prefix):
-            return int((row["FETCH_SIZE_KB_per_launch"] + row["WRITE_SIZE_KB_per_launch"]) * 1024)
-    return None
+    return int((row["FETCH_SIZE_KB_per_launch"] + row["WRITE_SIZE_KB_per_launch"]) * 1024)
 
 
-def pmc_field(kernel_prefix, field):
-    try:
-        with open(PMC_FILE) as f:
-            table = json.load(f)
-    except (OSError, ValueError):
+def valu_rate(kernel_prefix, launch_us):
+    """Executed fp32-VALU work of a kernel: SQ_INSTS_VALU (wave instructions, PMC) x 64 lanes / launch time."""
+    row = pmc_row(kernel_prefix)
+    if row is None or "SQ_INSTS_VALU_per_launch" not in row:
         return None
-    for name, row in table.items():
-        if name.startswith(kernel_prefix):
-            return row.get(field)
-    return None
+    lane_ops = row["SQ_INSTS_VALU_per_launch"] * 64
+    rate = lane_ops / (launch_us * 1e-6) / 1e12
+    return {"valu_instructions_per_launch": int(row["SQ_INSTS_VALU_per_launch"]), "lane_ops_per_launch": int(lane_ops),
+            "tera_lane_ops_per_s": round(rate, 2), "frac_of_spec_issue_rate": round(rate / VALU_ISSUE_TERA_LANE_OPS, 4),
+            "frac_of_measured_vfma_rate": round(rate / VALU_MEASURED_TERA_LANE_OPS, 4)}
+
+
+def fused_scan_call(w, pos, pred, flags=0, share=None):
+    """geom_surface_scan_f32 on the step's own tensors (outputs allocated once): prep launch + the fused NN / tri launch.
+    share = an earlier call object whose buffers (incl. the prepared tri workspace) are reused."""
+    import ctypes
+    from geometrics_amd import _lib as L
+    from geometrics_amd.tri_distance import face_order
+    lib = L.lib()
+    b, n_gt, num, nv, nf, dev = w.batch, G_PTS, S_PTS, w.nv, w.nf, pos.device
+    f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
+    ws_bytes = lib.geom_tri_distance_workspace_bytes(b, n_gt, nf)
+    if share is not None:
+        o, ws, order, u, v, tri_order = share.keep
+    else:
+        o = [torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, **i32), torch.empty(b, num, **f32), torch.empty(b, num, **i32),
+             torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, **i32), torch.empty(b, n_gt, **i32), torch.empty(b, n_gt, **f32),
+             torch.empty(b, n_gt, 3, **f32), torch.empty(b, n_gt, 3, **f32)]
+        ws = torch.empty(ws_bytes // 4, **f32)
+        order = torch.empty(lib.geom_surface_order_words(b, nf, num, n_gt), **i32)
+        u, v = torch.rand(b, num, device=dev), torch.rand(b, num, device=dev)
+        tri_order = face_order(pos, w.faces)
+    wrote = ctypes.c_int(0)
+
+    def call():
+        L.check(lib.geom_surface_scan_f32(b, n_gt, w.gt.data_ptr(), num, pred.data_ptr(), o[0].data_ptr(), o[1].data_ptr(),
+                                          o[2].data_ptr(), o[3].data_ptr(), nv, pos.data_ptr(), nf, w.faces.data_ptr(),
+                                          tri_order.data_ptr(), o[4].data_ptr(), o[5].data_ptr(), o[6].data_ptr(),
+                                          o[7].data_ptr(), o[8].data_ptr(), o[9].data_ptr(), u.data_ptr(), v.data_ptr(), 1.0, 1.0,
+                                          order.data_ptr(), flags, ws.data_ptr(), ws_bytes, ctypes.byref(wrote),
+                                          L.stream_ptr()), "geom_surface_scan_f32")
+    call.keep = (o, ws, order, u, v, tri_order)
+    return call
 
 
 def kernel_rooflines(w):
-    """Launch-level timing of the hot kernels on the step's own tensors."""
+    """Launch-level timing of the hot kernels on the step's own tensors (HIP-graph replay bracketed by HIP events on the
+    launch stream), combined with the committed PMC counters when they belong to these kernel sources."""
+    from geometrics_amd import _lib
     with torch.no_grad():
         pos = w.positions().contiguous()
         pred = utils.batch_sample(pos, w.faces, num=S_PTS)
-        t_tri = event_time_us(lambda: tri_distance_indexed(w.gt, pos, w.faces))       # prep + scan launches
+        scan = fused_scan_call(w, pos, pred)
+        t_scan_all = event_time_us(scan)                                              # prep + fused launch
+        scan()                                                                        # workspace now holds this mesh's records
+        t_scan = event_time_us(fused_scan_call(w, pos, pred, _lib.FLAG_TRI_WS_READY, share=scan))   # the fused launch alone
+        t_prep_tri = event_time_us(lambda: tri_distance_indexed(w.gt, pos, w.faces))  # prep + tri-only scan
         t_tri_flat = event_time_us(lambda: tri_distance_indexed(w.gt, pos, w.faces, order=None))
-        t_nn = event_time_us(lambda: chamfer_nn(w.gt, pred))
+        t_nn = event_time_us(lambda: chamfer_nn(w.gt, pred, 0))
+        t_nn_fma = event_time_us(lambda: chamfer_nn(w.gt, pred, _lib.FLAG_NN_FMA))
+        t_scan_fma = event_time_us(fused_scan_call(w, pos, pred, _lib.FLAG_NN_FMA))
         sup = torch.randn(w.batch, w.nv, HID, device=pos.device)
         csr = layers.adjacency_csr(w.info["adj"])
         t_agg = event_time_us(lambda: layers._ZeroNAggregate.apply(sup, w.stack[1].bias, csr, HID // 3, 1))
     b = w.batch
     tri_pairs = b * G_PTS * w.nf
     nn_pairs = 2 * b * G_PTS * S_PTS
+    prep_row = pmc_row("tri_prep_grouped_kernel")
+    algo_flops = tri_pairs * TRI_ALGO_FLOP_PER_PAIR + nn_pairs * NN_FLOP_PER_PAIR
+    executed = valu_rate("surface_scan_kernel", t_scan)
+    scan_bytes = b * (G_PTS * 12 + w.nv * 12 + w.nf * 24 + G_PTS * 12) + b * (G_PTS + S_PTS) * (12 + 8)
+    if executed is not None:
+        achieved, frac = executed["tera_lane_ops_per_s"], executed["frac_of_spec_issue_rate"]
+        basis = "executed"
+    else:   # no valid counters for these sources: the brute-force-equivalent NN rate is still an executed rate (no culling there)
+        achieved, frac, basis = None, None, "unavailable (profiles/r02_pmc_counters.json is stale for these kernel sources)"
+    roofline = {
+        "kernel": "surface_scan_kernel: Chamfer NN tiles (both directions) + point-to-triangle tiles (two-level culled scan) in "
+                  "one heterogeneous launch",
+        "bound": "mfma",
+        "pipe": "fp32 VALU, un-fused arithmetic (arg-min scans, not contractions): one flop per executed lane-op, so the "
+                "issue ceiling is 157.3 / 2 = 78.6 TFLOP/s (256 CU x 4 SIMD x 32 lanes x 2.4 GHz); the dense f32 MFMA peak "
+                "equals the f32 FMA vector peak on gfx950",
+        "achieved": achieved, "peak": VALU_ISSUE_TERA_LANE_OPS, "unit": "TFLOP/s", "frac": frac, "basis": basis,
+        "traffic": pmc_traffic_bytes("surface_scan_kernel"),
+        "launch_us": round(t_scan, 1), "call_us_with_prep_launch": round(t_scan_all, 1),
+        "executed": executed,
+        "algorithmic": {"pairs_per_launch": {"tri": tri_pairs, "nn": nn_pairs},
+                        "flop_per_pair": {"tri": TRI_ALGO_FLOP_PER_PAIR, "nn": NN_FLOP_PER_PAIR},
+                        "brute_force_equivalent_tflops": round(algo_flops / (t_scan * 1e-6) / 1e12, 1),
+                        "algorithmic_speedup_vs_brute_force": round(algo_flops / (executed["lane_ops_per_launch"]), 2) if executed else None,
+                        "bytes_per_launch": scan_bytes, "hbm_gbs_algorithmic": round(scan_bytes / (t_scan * 1e-6) / 1e9, 1),
+                        "note": "SURVEY 8(d) figures: every (point, triangle) pair at 60 flop + every (point, point) pair at 8 "
+                                "flop.  The tri tiles cull ~95 % of their pairs (proven bit-exact against brute force), so this "
+                                "rate is not a utilisation; `achieved` / `frac` are the EXECUTED work (SQ_INSTS_VALU x 64 lanes)"},
+        "separate_launches_us": {"chamfer_nn": round(t_nn, 1), "tri_prep_plus_scan": round(t_prep_tri, 1),
+                                 "tri_flat_scan": round(t_tri_flat, 1)},
+        "fma_arithmetic_us": {"chamfer_nn (GEOM_FLAG_NN_FMA)": round(t_nn_fma, 1), "fused call": round(t_scan_fma, 1)},
+        "note": "executed.frac_of_measured_vfma_rate relates the same rate to the 103 TFLOP/s the guide measures for un-packed "
+                "v_fma_f32 (51.5 T lane-ops/s): the practical issue ceiling"}
+    nn_exec = valu_rate("chamfer_nn_scalar_kernel", t_nn)
     nn_tflops = nn_pairs * NN_FLOP_PER_PAIR / (t_nn * 1e-6) / 1e12
-    # 0N-GCN aggregation: read support + write out (4 B each per element) + CSR (12 B per nnz + 4 B per row)
     agg_bytes = 2 * b * w.nv * HID * 4 + csr.nnz * 12 + (w.nv + 1) * 4
     agg_gbs = agg_bytes / (t_agg * 1e-6) / 1e9
-    tri_bytes = b * (G_PTS * 12 + w.nv * 12 + w.nf * 24 + G_PTS * 12)     # points + verts + faces(int64) + 3 outputs
-    # (inside the loss the scan's epilogue also writes the point-to-surface record of every point, 28 B each; the
-    # PMC traffic figure comes from that fused launch)
-    # SURVEY 8(d): algorithmic work of the point-to-triangle scan = every (point, triangle) pair at 60 flop (hoisted
-    # count of the reference's decision tree).  The two-level scan EXECUTES a small fraction of it (group spheres,
-    # then member spheres, then a few tens of literal evaluations per point), so the algorithmic rate can exceed the
-    # hardware peak; `executed` is what the VALUs really issued (SQ_INSTS_VALU x 64 lanes, PMC pass in profiles/).
-    tri_algo_tflops = tri_pairs * TRI_ALGO_FLOP_PER_PAIR / (t_tri * 1e-6) / 1e12
-    valu = pmc_field("tri_scan_grouped_kernel", "SQ_INSTS_VALU_per_launch")
-    executed = None
-    if valu is not None:
-        lane_ops = valu * 64
-        executed = {"valu_instructions_per_launch": int(valu), "lane_ops_per_launch": int(lane_ops),
-                    "tera_lane_ops_per_s": round(lane_ops / (t_tri * 1e-6) / 1e12, 2),
-                    "frac_of_valu_issue_rate": round(lane_ops / (t_tri * 1e-6) / 1e12 / VALU_ISSUE_TERA_LANE_OPS, 4),
-                    "note": "un-fused fp32 code issues at most 78.6 T lane-ops/s (256 CU x 4 SIMD x 32 lanes x 2.4 GHz)"}
-    roofline = {"kernel": "tri_prep_grouped_kernel + tri_scan_grouped_kernel (point-to-triangle arg-min, two-level scan)",
-                "bound": "mfma",
-                "pipe": "fp32 VALU, un-fused (arg-min scan, not a contraction; on gfx950 the f32 VALU peak equals the "
-                        "dense f32 MFMA peak; the kernel itself is latency bound: a chain of short dependent phases)",
-                "achieved": round(tri_algo_tflops, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tri_algo_tflops / FP32_PEAK_TFLOPS, 4), "traffic": pmc_traffic_bytes("tri_scan_grouped_kernel"),
-                "launch_us": round(t_tri, 1), "pairs_per_launch": tri_pairs, "flop_per_pair": TRI_ALGO_FLOP_PER_PAIR,
-                "algorithmic_bytes_per_launch": tri_bytes,
-                "hbm_gbs_algorithmic": round(tri_bytes / (t_tri * 1e-6) / 1e9, 2),
-                "executed": executed,
-                "flat_scan_us": round(t_tri_flat, 1),
-                "note": "achieved = algorithmic flops of the brute-force formulation (SURVEY 8d) / launch time; the "
-                        "hierarchy skips ~95 % of the pair evaluations, hence frac > 1 is not a utilisation -- see "
-                        "`executed`.  flat_scan_us = the one-level culled scan (order=None) on the same inputs"}
     others = {
-        "chamfer_nn_scalar_kernel": {"bound": "mfma", "pipe": "fp32 VALU, un-fused (brute force: algorithmic == executed pairs)", "achieved": round(nn_tflops, 3),
-                              "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(nn_tflops / FP32_PEAK_TFLOPS, 4),
-                              "launch_us": round(t_nn, 1), "pairs_per_launch": nn_pairs, "flop_per_pair": NN_FLOP_PER_PAIR,
-                              "traffic": pmc_traffic_bytes("chamfer_nn_scalar_kernel")},
-        "zn_aggregate_kernel": {"bound": "hbm", "achieved": round(agg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(agg_gbs / HBM_PEAK_GBS, 4), "launch_us": round(t_agg, 1),
-                                "algorithmic_bytes_per_launch": agg_bytes,
-                                "traffic": pmc_traffic_bytes("zn_aggregate_ell_kernel<1, false")},
+        "chamfer_nn_scalar_kernel (stand-alone launch)": {
+            "bound": "mfma", "pipe": "fp32 VALU, un-fused (brute force: algorithmic == executed pairs)",
+            "achieved": round(nn_tflops, 2), "peak": VALU_ISSUE_TERA_LANE_OPS, "unit": "TFLOP/s",
+            "frac": round(nn_tflops / VALU_ISSUE_TERA_LANE_OPS, 4), "launch_us": round(t_nn, 1), "executed": nn_exec,
+            "traffic": pmc_traffic_bytes("chamfer_nn_scalar_kernel")},
+        "zn_aggregate_ell_kernel (forward, sign mask)": {
+            "bound": "hbm", "achieved": round(agg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(agg_gbs / HBM_PEAK_GBS, 4), "launch_us": round(t_agg, 1), "algorithmic_bytes_per_launch": agg_bytes,
+            "traffic": pmc_traffic_bytes("zn_aggregate_ell_kernel<1, false"),
+            "note": "timed back to back on one buffer pair: reads are served from the 256 MiB infinity cache"},
     }
+    if prep_row is not None:
+        roofline["prep_launch"] = {"kernel": "tri_prep_grouped_kernel", "valu_instructions_per_launch": int(prep_row.get("SQ_INSTS_VALU_per_launch", 0))}
     return roofline, others
 
 

@@ -15,6 +15,7 @@ FLAG_REF_TAIL_TRUNC = 1
 FLAG_FIX_REGION6 = 2
 FLAG_TRI_BRUTE_FORCE = 4
 FLAG_NN_FMA = 8
+FLAG_TRI_WS_READY = 16
 ABI_VERSION = 3
 EUNSUPPORTED = -3
 ADAM_MAX_TENSORS = 16

@@ -26,6 +26,18 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_digest():
+    """sha256 over every kernel source and header the library is built from (names + contents): what a committed
+    profile / counter file is stamped with, so that stale counters are recognised (bench.py, tools/pmc_traffic_json.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True

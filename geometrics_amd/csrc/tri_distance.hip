@@ -1310,7 +1310,8 @@ extern "C" int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, 
             TriGws gws{base, base + (size_t)b * m_pad, grp, first, reinterpret_cast<unsigned long long *>(first + (size_t)b * 3), m_pad, 1};
             TriJob tj{gt, nullptr, nullptr, nullptr, verts, faces, tri_dist, option, index, b, n_gt, nf, nv};
             const bool fix6 = tri_flags & GEOM_FLAG_FIX_REGION6;
-            if (fix6) hipLaunchKernelGGL((tri_prep_grouped_kernel<true, false, true>), dim3((m_pad + 255) / 256, b), dim3(256), 0, s, tj, gws, tri_order);
+            if (flags & GEOM_FLAG_TRI_WS_READY) {} // records of an earlier call on the same mesh: no prep launch
+            else if (fix6) hipLaunchKernelGGL((tri_prep_grouped_kernel<true, false, true>), dim3((m_pad + 255) / 256, b), dim3(256), 0, s, tj, gws, tri_order);
             else hipLaunchKernelGGL((tri_prep_grouped_kernel<true, false, false>), dim3((m_pad + 255) / 256, b), dim3(256), 0, s, tj, gws, tri_order);
             const int qtiles = (n_gt + TRI_QUERIES - 1) / TRI_QUERIES;
             const unsigned tri_blocks = geom::xcd_grid(b, qtiles);

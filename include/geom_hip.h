@@ -45,6 +45,9 @@ extern "C" {
                                       * line.  Second pinned arithmetic: bit-identical to the reference nnsearch built
                                       * that way; distances differ from the default un-fused form by <= 1 ulp-level round-off */
 
+#define GEOM_FLAG_TRI_WS_READY 16u    /* geom_surface_scan_f32: `workspace` still holds the triangle records a previous call
+                                      * wrote for the SAME verts / faces / order / flags: the prep launch is skipped */
+
 int geom_abi_version(void);
 /* static string for a code returned by any entry point */
 const char *geom_strerror(int code);

@@ -40,11 +40,18 @@ def main(src, dst):
         row = {"launches": len(fetch[k]["FETCH_SIZE"]), "FETCH_SIZE_KB_per_launch": round(sum(f) / len(f), 1),
                "WRITE_SIZE_KB_per_launch": round(sum(w) / len(w), 1)}
         row.update(meta[k])
-        for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES"):
+        for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU",
+                  "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES"):
             vals = valu.get(k, {}).get(c)
             if vals:
                 row[c + "_per_launch"] = round(sum(vals) / len(vals), 1)
         table[k[:60]] = row
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from geometrics_amd import build as hip_build
+    table["_meta"] = {"source_sha256": hip_build.source_digest(),
+                      "note": "counters are valid for exactly these kernel sources (geometrics_amd.build.source_digest); "
+                              "bench.py ignores the file when the digest differs",
+                      "command": "bash tools/pmc_traffic.sh && python tools/pmc_traffic_json.py gpurun_out/pmc <this file>"}
     with open(dst, "w") as fh:
         json.dump(table, fh, indent=1, sort_keys=True)
     print("wrote", dst, len(table), "kernels")
