@@ -15,6 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgeom_hip.so")
+SHIM = os.path.join(LIBDIR, "geom_torch_shim.so")       # pybind `forward_cuda` entry points on top of the C ABI
+SHIM_SRC = os.path.join(CSRC, "torch_shim.cpp")
 
 # -ffp-contract=off: one canonical fp32 arithmetic shared with the CPU oracle (no FMA contraction).
 # Division and sqrt stay correctly rounded (hipcc default; never -ffast-math).
@@ -46,7 +48,35 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_shim(force=False, verbose=False):
+    """The compiled pybind module with the reference's `forward_cuda` call shapes (chamfer_distance.cpp:36-38,
+    tri_distance.cpp:34-36): host-only C++ (g++) against the torch headers, linked to libgeom_hip.so."""
+    if not force and os.path.exists(SHIM) and os.path.getmtime(SHIM) >= max(os.path.getmtime(SHIM_SRC), os.path.getmtime(LIB)):
+        return SHIM
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    tlib = ce.library_paths()[0]
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=geom_torch_shim", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+           "-I", INCLUDE, "-I", sysconfig.get_paths()["include"], "-I", "/opt/rocm/include"]
+    for inc in ce.include_paths():
+        cmd += ["-I", inc]
+    cmd += [SHIM_SRC, "-o", SHIM, "-L", LIBDIR, "-lgeom_hip", "-L", tlib, "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10",
+            "-lc10_hip", "-ltorch_python", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SHIM
+
+
 def build(force=False, verbose=False):
+    lib = build_lib(force, verbose)
+    build_shim(force, verbose)
+    return lib
+
+
+def build_lib(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -1,0 +1,80 @@
+// The compiled entry points the reference's python wrappers bind: pybind functions with the call shape of
+//   cd.forward_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2)            chamfer_distance/chamfer_distance.cpp:15-27, 36-38
+//   tri.forward_cuda(xyz1, tri1, tri2, tri3, dist, point, index)     tri_distance/tri_distance.cpp:16-30, 34-36
+// on top of the C ABI of libgeom_hip.so.  Caller-allocated outputs are filled in place; unlike the reference glue the
+// tensors are validated (device, dtype, contiguity, shapes), the launch goes to torch's CURRENT stream of the input's
+// device, and a failed launch raises instead of printing.  Host code only (no kernels): built with g++ against the
+// torch headers by geometrics_amd/build.py; geometrics_amd.chamfer_distance / .tri_distance use the ctypes binding by
+// default and these functions are what a maintainer of the reference would call from the unmodified wrappers
+// (INTEGRATION.md section 3).
+#include <torch/extension.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+
+#include "geom_hip.h"
+
+namespace {
+
+void check_points(const at::Tensor &t, const char *name, at::ScalarType dtype, int64_t dims, int64_t last)
+{
+    TORCH_CHECK(t.is_cuda(), name, " must live on a HIP device (geometrics_amd has no CPU path)");
+    TORCH_CHECK(t.scalar_type() == dtype, name, " has the wrong dtype");
+    TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");
+    TORCH_CHECK(t.dim() == dims, name, " must be ", dims, "-dimensional");
+    TORCH_CHECK(last < 0 || t.size(-1) == last, name, " must have last dimension ", last);
+}
+
+void raise_on(int code, const char *what)
+{
+    TORCH_CHECK(code == 0, what, " failed: ", geom_strerror(code), " (code ", code, ")");
+}
+
+void chamfer_forward_cuda(at::Tensor xyz1, at::Tensor xyz2, at::Tensor dist1, at::Tensor dist2, at::Tensor idx1,
+                          at::Tensor idx2, int64_t flags)
+{
+    check_points(xyz1, "xyz1", at::kFloat, 3, 3);
+    check_points(xyz2, "xyz2", at::kFloat, 3, 3);
+    const int64_t b = xyz1.size(0), n = xyz1.size(1), m = xyz2.size(1);
+    TORCH_CHECK(xyz2.size(0) == b, "batch sizes differ");
+    check_points(dist1, "dist1", at::kFloat, 2, n);
+    check_points(dist2, "dist2", at::kFloat, 2, m);
+    check_points(idx1, "idx1", at::kInt, 2, n);
+    check_points(idx2, "idx2", at::kInt, 2, m);
+    TORCH_CHECK(dist1.size(0) == b && dist2.size(0) == b && idx1.size(0) == b && idx2.size(0) == b, "output batch sizes differ");
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(xyz1.device());   // PyTorch-ROCm tensors carry device type "cuda"
+    raise_on(geom_chamfer_nn_f32((int)b, (int)n, xyz1.data_ptr<float>(), (int)m, xyz2.data_ptr<float>(), dist1.data_ptr<float>(),
+                                 idx1.data_ptr<int>(), dist2.data_ptr<float>(), idx2.data_ptr<int>(), (unsigned)flags,
+                                 c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
+             "geom_chamfer_nn_f32");
+}
+
+void tri_forward_cuda(at::Tensor xyz1, at::Tensor tri1, at::Tensor tri2, at::Tensor tri3, at::Tensor dist, at::Tensor point,
+                      at::Tensor index, int64_t flags)
+{
+    check_points(xyz1, "xyz1", at::kFloat, 3, 3);
+    check_points(tri1, "tri1", at::kFloat, 3, 3);
+    check_points(tri2, "tri2", at::kFloat, 3, 3);
+    check_points(tri3, "tri3", at::kFloat, 3, 3);
+    const int64_t b = xyz1.size(0), n = xyz1.size(1), m = tri1.size(1);
+    TORCH_CHECK(tri1.sizes() == tri2.sizes() && tri1.sizes() == tri3.sizes() && tri1.size(0) == b,
+                "tri1 / tri2 / tri3 must share one [B,M,3] shape with xyz1's batch");
+    check_points(dist, "dist", at::kFloat, 2, n);
+    check_points(point, "point", at::kInt, 2, n);
+    check_points(index, "index", at::kInt, 2, n);
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(xyz1.device());   // PyTorch-ROCm tensors carry device type "cuda"
+    // workspace-free culled scan: the exact prototype of the reference launcher (tri_distance.cpp:4-13)
+    raise_on(geom_tri_distance_f32((int)b, (int)n, xyz1.data_ptr<float>(), (int)m, tri1.data_ptr<float>(), tri2.data_ptr<float>(),
+                                   tri3.data_ptr<float>(), dist.data_ptr<float>(), point.data_ptr<int>(), index.data_ptr<int>(),
+                                   (unsigned)flags, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
+             "geom_tri_distance_f32");
+}
+
+} // namespace
+
+PYBIND11_MODULE(geom_torch_shim, m)
+{
+    m.def("chamfer_forward_cuda", &chamfer_forward_cuda, "chamfer_distance.cpp:36-38 forward_cuda on libgeom_hip.so",
+          py::arg("xyz1"), py::arg("xyz2"), py::arg("dist1"), py::arg("dist2"), py::arg("idx1"), py::arg("idx2"), py::arg("flags") = 0);
+    m.def("tri_forward_cuda", &tri_forward_cuda, "tri_distance.cpp:34-36 forward_cuda on libgeom_hip.so", py::arg("xyz1"),
+          py::arg("tri1"), py::arg("tri2"), py::arg("tri3"), py::arg("dist"), py::arg("point"), py::arg("index"), py::arg("flags") = 0);
+}

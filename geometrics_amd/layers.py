@@ -209,6 +209,13 @@ class _ZeroNAggregate(torch.autograd.Function):
 def zero_n_aggregate(support, adj, bias, k, activation=None):
     """Shared tail of every 0N-GCN layer; accepts [V,C] or [B,V,C] support.  Returns the
     ACTIVATED output when `activation` is given (fused for relu / elu)."""
+    if torch.is_tensor(adj) and adj.dim() == 3:
+        # one dense adjacency PER MESH ([B,V,V]): what the reference's torch.matmul(adj, support[..., :k]) also accepts
+        # (layers.py:111, 146).  Not a shape the reference drivers produce; served by the same dense product.
+        out = torch.cat((torch.matmul(adj, support[..., :k]), support[..., k:]), dim=-1)
+        if bias is not None:
+            out = out + bias
+        return out if activation is None else activation(out)
     csr = adjacency_csr(adj)
     act = _ACT_NONE if activation is None else _activation_code(activation)
     s3 = support.unsqueeze(0) if support.dim() == 2 else support

@@ -86,7 +86,12 @@ class VertexBatchNorm(nn.Module):
 
     def forward(self, x, relu=False, residual=None, scale=0.5):
         b, _, c = x.shape
-        if b * c > 4096 or not x.is_cuda:      # outside the register-resident kernel: library ops, same maths
+        # library ops (same maths) outside the register-resident kernel, and for gradients through an eval()'d block
+        # (frozen-BN fine-tuning): the fused backward is written for batch statistics
+        eval_grad = not self.training and torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)
+        if b * c > 4096 or not x.is_cuda or eval_grad:
+            if self.training:
+                self._pending_batches += 1      # nn.BatchNorm1d's num_batches_tracked, folded in when the state is saved
             y = nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
                                          self.training, self.momentum, self.eps)
             y = torch.relu(y) if relu else y

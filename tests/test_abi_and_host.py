@@ -157,3 +157,18 @@ def test_triangle_visiting_orders_are_permutations_with_compact_leaves():
     bad = cent[:40].clone()
     bad[3] = float("nan")
     assert sorted(kd_order(bad).tolist()) == list(range(40)) and sorted(morton_order(bad).tolist()) == list(range(40))
+
+
+def test_compiled_forward_cuda_shim_loads_and_validates():
+    """The pybind module with the reference's `forward_cuda` call shapes (chamfer_distance.cpp:36-38,
+    tri_distance.cpp:34-36): built, importable without a GPU, and it refuses CPU tensors instead of faulting."""
+    import torch
+    from geometrics_amd import _shim
+    m = _shim.module()
+    assert "chamfer_distance.cpp" in m.chamfer_forward_cuda.__doc__ and "tri_distance.cpp" in m.tri_forward_cuda.__doc__
+    z = torch.zeros(1, 2, 3)
+    i = torch.zeros(1, 2, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        _shim.cd.forward_cuda(z, z, torch.zeros(1, 2), torch.zeros(1, 2), i, i)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        _shim.tri.forward_cuda(z, z, z, z, torch.zeros(1, 2), i, i)

@@ -251,6 +251,37 @@ def test_long_rows_take_the_ell_kernel_with_a_csr_tail(gpu, mesh, act):
         close(layer.weight1.grad.cpu().numpy(), w.grad.numpy(), 1e-4)
 
 
+def test_vertex_bn_eval_mode_gradients_and_batched_adjacency(gpu):
+    """Two call patterns nn.BatchNorm1d / torch.matmul accept and the fused kernels do not cover natively: gradients
+    through an eval()'d block (frozen-BN fine-tuning) and a per-mesh [B,V,V] adjacency; both take the library route and
+    must match the plain torch formulation."""
+    from geometrics_amd import models
+    V, Fc = meshgen.icosphere(2)
+    nv = V.shape[0]
+    adj = utils.adj_init(dev(Fc, gpu))["adj"]
+    torch.manual_seed(2)
+    bn = models.VertexBatchNorm(nv).to(gpu)
+    ref = torch.nn.BatchNorm1d(nv).to(gpu)
+    x = torch.randn(3, nv, 16, device=gpu)
+    bn.train(), ref.train()
+    for _ in range(2):                                  # running statistics from the fused training kernel
+        bn(x * 1.5 + 0.3), ref(x * 1.5 + 0.3)
+    bn.eval(), ref.eval()
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = bn(xa, relu=True), torch.relu(ref(xb))
+    g = torch.randn_like(ya)
+    ya.backward(g), yb.backward(g)
+    close(ya.detach().cpu().numpy(), yb.detach().cpu().numpy(), 1e-5)
+    close(xa.grad.cpu().numpy(), xb.grad.cpu().numpy(), 1e-5)
+    assert int(bn.state_dict()["num_batches_tracked"]) == 2
+    big = models.VertexBatchNorm(nv).to(gpu).train()    # outside the register-resident kernel: batches are still counted
+    big(torch.randn(40, nv, 192, device=gpu))
+    assert int(big.state_dict()["num_batches_tracked"]) == 1
+    layer = layers.BatchZERON_GCN(16, 40).to(gpu)
+    out = layer(x, adj.unsqueeze(0).expand(3, nv, nv).contiguous(), F.elu)
+    close(out.detach().cpu().numpy(), layer(x, adj, F.elu).detach().cpu().numpy(), 1e-5)
+
+
 def test_gcn_rows_of_degree_32(gpu):
     g = golden("adj_482")
     adj = utils.adj_init(dev(g["faces"], gpu))["adj"]

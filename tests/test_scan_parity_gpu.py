@@ -409,3 +409,30 @@ def test_tri_fix6_distances_equal_the_legacy_eberly_truth(gpu, name, scan):
     assert int((o6 == 6).sum()) > 10
     dq, oq, iq = tri_distance_indexed(_dev(pts, gpu), _dev(verts, gpu), _dev(faces, gpu), extra, **kw)
     assert (dq.cpu().numpy() >= true * (1 - 1e-5) - 1e-9).all()
+
+
+def test_compiled_forward_cuda_entry_points_equal_the_ctypes_binding(oracle_mod, gpu):
+    """cd.forward_cuda / tri.forward_cuda (the compiled pybind shim with the reference's call shapes) write exactly what
+    the ctypes-bound operators return; config-1 size, oracle-checked."""
+    from geometrics_amd import _shim
+    V, F = meshgen.icosphere(2)
+    verts, gt = meshgen.jittered_batch(V, 2), meshgen.gt_cloud(2, 500)
+    pred = meshgen.gt_cloud(2, 500, first=9)
+    a, c = _dev(gt, gpu), _dev(pred, gpu)
+    d1, d2 = torch.empty(2, 500, device=gpu), torch.empty(2, 500, device=gpu)
+    i1, i2 = torch.empty(2, 500, dtype=torch.int32, device=gpu), torch.empty(2, 500, dtype=torch.int32, device=gpu)
+    assert _shim.cd.forward_cuda(a, c, d1, d2, i1, i2) is None
+    e1, j1, e2, j2 = oracle_mod.chamfer_nn(gt, pred)
+    np.testing.assert_array_equal(i1.cpu().numpy(), j1)
+    np.testing.assert_array_equal(i2.cpu().numpy(), j2)
+    np.testing.assert_array_equal(d1.cpu().numpy().view(np.uint32), e1.view(np.uint32))
+    tri = [_dev(np.ascontiguousarray(verts[:, F[:, k]]), gpu) for k in range(3)]
+    dist, point, index = torch.empty(2, 500, device=gpu), torch.empty(2, 500, dtype=torch.int32, device=gpu), \
+        torch.empty(2, 500, dtype=torch.int32, device=gpu)
+    assert _shim.tri.forward_cuda(a, *tri, dist, point, index) is None
+    et, ept, eit = oracle_mod.tri_scan(gt, *(np.ascontiguousarray(verts[:, F[:, k]]) for k in range(3)))
+    np.testing.assert_array_equal(index.cpu().numpy(), eit)
+    np.testing.assert_array_equal(point.cpu().numpy(), ept)
+    np.testing.assert_array_equal(dist.cpu().numpy().view(np.uint32), et.view(np.uint32))
+    with pytest.raises(RuntimeError):
+        _shim.cd.forward_cuda(a.double(), c, d1, d2, i1, i2)
