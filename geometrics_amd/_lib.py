@@ -42,6 +42,7 @@ _SIGNATURES = {
     "geom_surface_loss_bwd_f32": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp],
     "geom_surface_finalize_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i,
                                   _i, _vp, _vp, _vp],
+    "geom_surface_prepare_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _u, _vp, ctypes.c_size_t, _vp, _vp],
     "geom_surface_scan_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp, _f, _f, _vp, _u, _vp, ctypes.c_size_t, _vp, _vp],
     "geom_surface_gather_f32": [_i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],

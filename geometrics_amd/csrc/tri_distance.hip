@@ -26,6 +26,7 @@
 #include "tri_math.h"
 #include "nn_scan.h"
 #include "surface_layout.h"
+#include "draw_body.h"
 
 namespace {
 
@@ -719,11 +720,11 @@ struct TriGws {
     int m_pad, split;
 };
 
+// j = visiting slot, mesh = which mesh (whole waves share a mesh and 64 consecutive slots)
 template <bool INDEXED, bool TRUNC, bool FIX6>
-__global__ __launch_bounds__(256) void tri_prep_grouped_kernel(TriJob job, TriGws ws, const int *__restrict__ order)
+__device__ __forceinline__ void tri_prep_grouped_body(const TriJob &job, const TriGws &ws, const int *__restrict__ order, int j,
+                                                      int mesh)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int mesh = blockIdx.y;
     if (ws.split > 1 && j < job.n) ws.keys[(size_t)mesh * job.n + j] = KEY_NONE;
     if (j >= ws.m_pad) return; // m_pad is a multiple of 64: whole waves leave together
     int k = -1;
@@ -779,6 +780,31 @@ __global__ __launch_bounds__(256) void tri_prep_grouped_kernel(TriJob job, TriGw
     }
     if (bad > 0.f) g = make_float4(cnt > 0.f ? g.x : 0.f, cnt > 0.f ? g.y : 0.f, cnt > 0.f ? g.z : 0.f, INFINITY);
     if ((j & (GRP - 1)) == 0) ws.grp[(size_t)mesh * (ws.m_pad / GRP) + j / GRP] = g;
+}
+
+template <bool INDEXED, bool TRUNC, bool FIX6>
+__global__ __launch_bounds__(256) void tri_prep_grouped_kernel(TriJob job, TriGws ws, const int *__restrict__ order)
+{
+    tri_prep_grouped_body<INDEXED, TRUNC, FIX6>(job, ws, order, blockIdx.x * 256 + threadIdx.x, blockIdx.y);
+}
+
+// The per-step PREPARATION of the surface loss in one launch: everything that depends only on the vertex positions --
+// the random face draws (+ the sampled points) of batch_sample and the triangle records / group spheres of the
+// two-level scan.  Workgroups [0, draw_blocks) run a draw chunk, the rest 1024 triangle slots each.
+template <bool FIX6>
+__global__ __launch_bounds__(DRAW_THREADS) void surface_prepare_kernel(int draw_blocks, int draw_chunks, int nv, const float *verts,
+                                                                        int nf, const int64_t *faces, int num,
+                                                                        unsigned long long *rng_state, int64_t *choices, float *u,
+                                                                        float *v, float *points, TriJob job, TriGws ws,
+                                                                        const int *__restrict__ order, int prep_chunks)
+{
+    if ((int)blockIdx.x < draw_blocks) {
+        draw_samples_body(blockIdx.x % draw_chunks, blockIdx.x / draw_chunks, (unsigned long long)draw_blocks, nv, verts, nf,
+                          faces, num, nullptr, 0, rng_state, choices, u, v, points);
+    } else {
+        const int pid = blockIdx.x - draw_blocks;
+        tri_prep_grouped_body<true, false, FIX6>(job, ws, order, (pid % prep_chunks) * DRAW_THREADS + threadIdx.x, pid / prep_chunks);
+    }
 }
 
 template <bool TRUNC, bool FIX6, int HS_WAVES>
@@ -1339,5 +1365,47 @@ extern "C" int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, 
     if (fma) hipLaunchKernelGGL(nn_records_kernel<true>, dim3(nn_blocks), dim3(NNS_THREADS), 0, s, job, rr);
     else hipLaunchKernelGGL(nn_records_kernel<false>, dim3(nn_blocks), dim3(NNS_THREADS), 0, s, job, rr);
     if (records_written) *records_written = rec != nullptr;
+    return geom::launch_status();
+}
+
+// Draws + sampled points of batch_sample (exactly geom_draw_samples_rng_f32) and, when the surface scan of the same
+// step will run fused (same conditions as in geom_surface_scan_f32: coherent tri_order, no truncation / brute-force
+// flags, >= 256 query tiles of n_gt points), the triangle records of that scan -- in ONE launch; *prepared = 1 then and
+// the scan is called with GEOM_FLAG_TRI_WS_READY.  Otherwise only the draws are made (*prepared = 0).
+extern "C" int geom_surface_prepare_f32(int b, int nv, const float *verts, int nf, const int64_t *faces, int num,
+                                        uint64_t *rng_state, int64_t *choices, float *u, float *v, float *points, int n_gt,
+                                        const int *tri_order, unsigned flags, void *workspace, size_t workspace_bytes,
+                                        int *prepared, void *stream)
+{
+    if (prepared) *prepared = 0;
+    if (b < 0 || nv < 0 || nf < 0 || num < 0 || n_gt < 0) return GEOM_EINVAL;
+    if (nf > DRAW_MAX_FACES) return GEOM_EUNSUPPORTED;
+    if (b == 0 || num == 0) return 0;
+    if (nf == 0 || !verts || !faces || !rng_state || !choices || !u || !v) return GEOM_EINVAL;
+    if (b > 65535) return GEOM_ETOOBIG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int draw_chunks = (num + DRAW_THREADS - 1) / DRAW_THREADS;
+    const int m_pad = ws_pad(nf);
+    const bool fusable = tri_order && workspace && n_gt > 0 &&
+                         !(flags & (GEOM_FLAG_REF_TAIL_TRUNC | GEOM_FLAG_TRI_BRUTE_FORCE)) && ws_split(b, n_gt, m_pad) == 1 &&
+                         (int64_t)b * ((n_gt + TRI_QUERIES - 1) / TRI_QUERIES) >= 256;
+    if (!fusable) return geom_draw_samples_rng_f32(b, nv, verts, nf, faces, num, rng_state, choices, u, v, points, stream);
+    if (workspace_bytes < ws_bytes_needed(b, n_gt, m_pad) || ((uintptr_t)workspace & 15)) return GEOM_EINVAL;
+    float4 *base = static_cast<float4 *>(workspace);
+    float4 *grp = base + (size_t)b * m_pad * 4;
+    float4 *first = grp + (size_t)b * (m_pad / GRP);
+    TriGws gws{base, base + (size_t)b * m_pad, grp, first, reinterpret_cast<unsigned long long *>(first + (size_t)b * 3), m_pad, 1};
+    TriJob tj{nullptr, nullptr, nullptr, nullptr, verts, faces, nullptr, nullptr, nullptr, b, n_gt, nf, nv};
+    const int prep_chunks = (m_pad + DRAW_THREADS - 1) / DRAW_THREADS;
+    const int draw_blocks = draw_chunks * b;
+    const dim3 grid(draw_blocks + prep_chunks * b), block(DRAW_THREADS);
+    unsigned long long *st = reinterpret_cast<unsigned long long *>(rng_state);
+    if (flags & GEOM_FLAG_FIX_REGION6)
+        hipLaunchKernelGGL(surface_prepare_kernel<true>, grid, block, 0, s, draw_blocks, draw_chunks, nv, verts, nf, faces, num, st,
+                           choices, u, v, points, tj, gws, tri_order, prep_chunks);
+    else
+        hipLaunchKernelGGL(surface_prepare_kernel<false>, grid, block, 0, s, draw_blocks, draw_chunks, nv, verts, nf, faces, num, st,
+                           choices, u, v, points, tj, gws, tri_order, prep_chunks);
+    if (prepared) *prepared = 1;
     return geom::launch_status();
 }

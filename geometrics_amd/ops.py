@@ -174,7 +174,7 @@ class SurfaceLoss(torch.autograd.Function):
     distances feed the F1 score and are not differentiable."""
 
     @staticmethod
-    def forward(ctx, verts, faces, gt, choices, u, v, two_sided, scale, points=None):
+    def forward(ctx, verts, faces, gt, choices, u, v, two_sided, scale, points=None, tri_ws=None):
         verts_c = _f32(verts.detach(), "verts", 3, 3)
         gt_c = _f32(gt.detach(), "gt_points", 3, 3)
         faces = _lib.require(faces, "faces", torch.int64, 2, 3)
@@ -197,7 +197,10 @@ class SurfaceLoss(torch.autograd.Function):
         idx_p, idx_g = torch.empty(b, n_gt, **i32), torch.empty(b, num, **i32)
         if not two_sided:
             ws_bytes = L.geom_tri_distance_workspace_bytes(b, n_gt, nf)
-            ws = torch.empty(max(ws_bytes, 16) // 4, **f32)
+            ws_ready = tri_ws is not None and have_points      # written by the draw launch (ops.draw_samples(prepare_scan_for=...))
+            if ws_ready and (tri_ws.numel() * 4 < ws_bytes or tri_ws.device != dev):
+                raise RuntimeError("tri_ws does not belong to this mesh batch / query count")
+            ws = tri_ws if ws_ready else torch.empty(max(ws_bytes, 16) // 4, **f32)
             tri_order = face_order(verts_c, faces)      # cached k-d leaf order of the faces: two-level scan
             tri_d, option, index = torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, **i32), torch.empty(b, n_gt, **i32)
             sq, closest, weights = torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, 3, **f32), torch.empty(b, n_gt, 3, **f32)
@@ -215,6 +218,8 @@ class SurfaceLoss(torch.autograd.Function):
             coef_s, coef_o = scale / (b * num), scale / (b * n_gt)
             wrote = ctypes.c_int(0)
             flags = _chamfer.default_flags()
+            if not two_sided and ws_ready:
+                flags |= _lib.FLAG_TRI_WS_READY
             if two_sided:
                 tri_args = (nv, None, nf, None, None, None, None, None, None, None, None)    # nf still sizes the scratch layout
                 ws_ptr, ws_len = None, 0
@@ -278,7 +283,7 @@ class SurfaceLoss(torch.autograd.Function):
                               u.data_ptr(), v.data_ptr(), points.data_ptr(), n_gt, gt.data_ptr(), saved[6].data_ptr(),
                               index.data_ptr(), closest.data_ptr(), weights.data_ptr(), grad.data_ptr(),
                               ctx.scale / (b * num), ctx.scale / (b * n_gt), grad_verts.data_ptr())
-        return grad_verts, None, None, None, None, None, None, None, None
+        return grad_verts, None, None, None, None, None, None, None, None, None
 
 
 class Laplacian(torch.autograd.Function):
@@ -456,14 +461,17 @@ def _rng_state(dev):
     return st
 
 
-def draw_samples(verts, faces, num, generator=None, with_points=False):
+def draw_samples(verts, faces, num, generator=None, with_points=False, prepare_scan_for=None):
     """The random part of batch_sample (reference utils.py:604-612, 627-628): choices [B,num] ~
     area-weighted with replacement, u = sqrt(U1), v = U2, in ONE kernel: per-mesh face-area CDF in LDS,
     binary search per sample, uniforms from an in-kernel Philox stream whose position lives on the device
     (graph replays draw fresh numbers; no generator bookkeeping launches).  With an explicit torch
     `generator` the uniforms come from torch.rand instead; meshes with more than 16384 faces take the
     torch.multinomial route.  with_points=True also returns the sampled points [B,num,3] (or None when the
-    kernel could not produce them), which ops.SurfaceLoss accepts in place of its own gather launch."""
+    kernel could not produce them), which ops.SurfaceLoss accepts in place of its own gather launch.
+    prepare_scan_for = n_gt (with with_points=True): the same launch also writes the triangle records of the surface scan
+    of n_gt query points per mesh; a fifth return value is then the prepared workspace tensor (or None when the scan
+    will not take the fused route), to be handed to ops.SurfaceLoss as `tri_ws`."""
     verts_c = _f32(verts.detach(), "verts", 3, 3)
     faces = _lib.require(faces, "faces", torch.int64, 2, 3)
     b, nv, _ = verts_c.shape
@@ -476,9 +484,21 @@ def draw_samples(verts, faces, num, generator=None, with_points=False):
         if generator is None:
             if with_points:
                 points = torch.empty(b, num, 3, dtype=torch.float32, device=dev)
-            code = _lib.lib().geom_draw_samples_rng_f32(b, nv, verts_c.data_ptr(), faces.shape[0], faces.data_ptr(), num,
-                                                        _rng_state(dev).data_ptr(), choices.data_ptr(), u.data_ptr(),
-                                                        v.data_ptr(), _lib.ptr(points), _lib.stream_ptr())
+            if with_points and prepare_scan_for:
+                n_gt, nf = int(prepare_scan_for), faces.shape[0]
+                ws_bytes = _lib.lib().geom_tri_distance_workspace_bytes(b, n_gt, nf)
+                tri_ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device=dev)
+                prepared = ctypes.c_int(0)
+                code = _lib.lib().geom_surface_prepare_f32(
+                    b, nv, verts_c.data_ptr(), nf, faces.data_ptr(), num, _rng_state(dev).data_ptr(), choices.data_ptr(),
+                    u.data_ptr(), v.data_ptr(), points.data_ptr(), n_gt, _lib.ptr(face_order(verts_c, faces)), 0,
+                    tri_ws.data_ptr(), ws_bytes, ctypes.byref(prepared), _lib.stream_ptr())
+                if code == 0:
+                    return choices, u, v, points, (tri_ws if prepared.value else None)
+            else:
+                code = _lib.lib().geom_draw_samples_rng_f32(b, nv, verts_c.data_ptr(), faces.shape[0], faces.data_ptr(), num,
+                                                            _rng_state(dev).data_ptr(), choices.data_ptr(), u.data_ptr(),
+                                                            v.data_ptr(), _lib.ptr(points), _lib.stream_ptr())
         else:
             uniforms = torch.rand(3, b, num, device=dev, generator=generator)
             code = _lib.lib().geom_draw_samples_f32(b, nv, verts_c.data_ptr(), faces.shape[0], faces.data_ptr(), num,
@@ -489,9 +509,13 @@ def draw_samples(verts, faces, num, generator=None, with_points=False):
             uniforms = torch.rand(3, b, num, device=dev)
         choices = torch.multinomial(face_areas(verts_c, faces), num, True, generator=generator)
         out = (choices, torch.sqrt(uniforms[1]), uniforms[2])
-        return out + (None,) if with_points else out
+        if with_points:
+            out = out + ((None, None) if prepare_scan_for else (None,))
+        return out
     _lib.check(code, "geom_draw_samples_f32")
-    return (choices, u, v, points) if with_points else (choices, u, v)
+    if with_points:
+        return (choices, u, v, points, None) if prepare_scan_for else (choices, u, v, points)
+    return choices, u, v
 
 
 class VertexHead(torch.autograd.Function):

@@ -78,13 +78,18 @@ def _f_score(sq_to_pred, sq_to_gt, num):
 
 def _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, two_sided):
     faces = adj_info["faces"]
-    points = None
-    if draws is None:   # one kernel draws AND gathers the points; replayed draws go through the separate gather
-        choices, u, v, points = ops.draw_samples(pred_vert, faces, num, with_points=True)
+    points = tri_ws = None
+    if draws is None:   # one kernel draws AND gathers the points (and, for the one-sided loss, prepares the triangle
+        #                 records of the scan: both depend only on the vertex positions); replayed draws: separate gather
+        if two_sided:
+            choices, u, v, points = ops.draw_samples(pred_vert, faces, num, with_points=True)
+        else:
+            choices, u, v, points, tri_ws = ops.draw_samples(pred_vert, faces, num, with_points=True,
+                                                             prepare_scan_for=gt_points.shape[1])
     else:
         choices, u, v = draws
     loss, sq_gt, sq_pred = ops.SurfaceLoss.apply(pred_vert, faces, gt_points, choices, u, v, two_sided, LOSS_SCALE,
-                                                 points)
+                                                 points, tri_ws)
     if f1:
         return loss, _f_score(sq_gt, sq_pred, num)
     return loss

@@ -317,6 +317,17 @@ int geom_pool_features_bwd_f32(int b, int nv, const float *verts, const float *c
                                const float *grad_out, float *const *grad_blocks, float *grad_verts,
                                void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- per-step preparation of the surface loss in one launch ------------------------------------------------------
+ * Everything that depends only on the vertex positions: the random face draws (+ sampled points) of batch_sample,
+ * exactly geom_draw_samples_rng_f32, AND -- when the scan of the same step will take the fused route (coherent
+ * tri_order, no truncation / brute-force flag, >= 256 query tiles of n_gt points) -- the triangle records of
+ * geom_surface_scan_f32 in `workspace` (geom_tri_distance_workspace_bytes(b, n_gt, nf)).  *prepared = 1 then: pass
+ * GEOM_FLAG_TRI_WS_READY and the same workspace to the scan.  Otherwise only the draws are made (*prepared = 0). */
+int geom_surface_prepare_f32(int b, int nv, const float *verts, int nf, const int64_t *faces, int num,
+                             uint64_t *rng_state, int64_t *choices, float *u, float *v, float *points, int n_gt,
+                             const int *tri_order, unsigned flags, void *workspace, size_t workspace_bytes,
+                             int *prepared, void *stream);
+
 /* ---- the two arg-min scans of the surface loss in one call (utils.py:451 + 470) ----------------------------------
  * gt [b,n_gt,3] against the sampled points [b,num,3]: nearest neighbours both ways, exactly geom_chamfer_nn_f32(gt,
  * points) -> (sq_gt, idx_p) for the gt points, (sq_pred, idx_g) for the sampled points; and, when verts != NULL, gt

@@ -767,6 +767,43 @@ def test_fused_surface_scan_equals_the_separate_scans_and_its_records_those_of_t
         assert torch.equal(a["tri_d"], dt) and torch.equal(a["option"], pt) and torch.equal(a["index"], it)
 
 
+def test_prepare_launch_equals_draw_plus_prep(gpu):
+    """geom_surface_prepare_f32 (draws + sampled points + the triangle records of the scan in ONE launch) against the
+    separate draw launch and the scan's own prep launch: same random stream, same samples, and a loss / gradient that do
+    not depend on which launch wrote the workspace."""
+    V, Fc = meshgen.icosphere(4)
+    B, num = 8, 3000
+    verts = dev(meshgen.jittered_batch(V, B), gpu).requires_grad_(True)
+    faces, gt = dev(Fc, gpu), dev(meshgen.gt_cloud(B, num), gpu)
+    ops.manual_seed(31)
+    a = ops.draw_samples(verts, faces, num, with_points=True)
+    ops.manual_seed(31)
+    b = ops.draw_samples(verts, faces, num, with_points=True, prepare_scan_for=num)
+    assert len(b) == 5 and b[4] is not None
+    for x, y in zip(a, b[:4]):
+        assert torch.equal(x, y)
+    res = []
+    for tri_ws in (None, b[4]):
+        verts.grad = None
+        loss, sq_gt, sq_pred = ops.SurfaceLoss.apply(verts, faces, gt, b[0], b[1], b[2], False, 3000.0, b[3], tri_ws)
+        loss.backward()
+        res.append((loss.detach().clone(), sq_gt.clone(), sq_pred.clone(), verts.grad.clone()))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    # a single mesh does not take the fused route: draws only, no workspace
+    c = ops.draw_samples(verts[:1].detach(), faces, num, with_points=True, prepare_scan_for=num)
+    assert c[4] is None and c[3] is not None
+    # and the whole helper still matches the CPU restatement through the prepared path
+    ops.manual_seed(5)
+    ch, u, v, pts, ws = ops.draw_samples(verts.detach(), faces, num, with_points=True, prepare_scan_for=num)
+    loss = ops.SurfaceLoss.apply(verts.detach(), faces, gt, ch, u, v, False, 3000.0, pts, ws)[0]
+    ref = ref_ops.point_to_surface(verts.detach().cpu()[:2], torch.from_numpy(Fc), gt.cpu()[:2], ch.cpu()[:2], u.cpu()[:2], v.cpu()[:2])
+    part = ops.SurfaceLoss.apply(verts.detach()[:2].contiguous(), faces, gt[:2].contiguous(), ch[:2].contiguous(), u[:2].contiguous(),
+                                 v[:2].contiguous(), False, 3000.0)[0]
+    assert abs(part.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    assert torch.isfinite(loss)
+
+
 def test_tri_surface_fused_call_equals_scan_plus_point_to_triangle(gpu):
     """geom_tri_surface_fwd_f32 (scan epilogue writes sqdist / closest / weights) against the two separate entry
     points, for the two-level scan (fused), the flat scan, the brute-force scan and a single mesh (split query tiles:
