@@ -46,7 +46,9 @@ __device__ __forceinline__ void draw_samples_body(int chunk, int mesh, unsigned 
     const int per = (nf + DRAW_THREADS - 1) / DRAW_THREADS; // consecutive faces per thread
     const int f0 = threadIdx.x * per;
     float run = 0.f;
-    for (int f = f0; f < min(f0 + per, nf); ++f) { // local inclusive sums
+    const int f1 = min(f0 + per, nf);
+#pragma unroll 4
+    for (int f = f0; f < f1; ++f) { // local inclusive sums
         const geom::V3 v0 = draw_ld3(V + 3 * faces[3 * (size_t)f + 0]);
         const geom::V3 v1 = draw_ld3(V + 3 * faces[3 * (size_t)f + 1]);
         const geom::V3 v2 = draw_ld3(V + 3 * faces[3 * (size_t)f + 2]);
