@@ -111,6 +111,75 @@ __global__ __launch_bounds__(BN_THREADS) void vertex_bn_fwd_kernel(BnArgs a)
     }
 }
 
+// Vector path (c % 4 == 0, b <= 4 * (256 / (c/4)) rows -- every hidden layer of the deformation block): thread
+// (r0, q) owns float4 column group q of rows r0, r0 + R, r0 + 2R, r0 + 3R (R = 256 / (c/4) rows per pass), so the
+// vertex's B rows arrive as 16-byte loads of contiguous 4c-byte runs, with no per-element division, and the residual
+// is fetched in the SAME round trip as x instead of after the statistics (the scalar kernel above: 19 us per launch at
+// the reference's training shape B = 16, V = 482, C = 192 for 18 MB of traffic).
+constexpr int BN_VEC_ITERS = 4;
+
+__global__ __launch_bounds__(BN_THREADS) void vertex_bn_fwd_vec_kernel(BnArgs a)
+{
+    __shared__ float lds[2 * BN_THREADS / GEOM_WAVE];
+    const int v = blockIdx.x;
+    const int c4 = a.c >> 2, rows = BN_THREADS / c4;
+    const int r0 = threadIdx.x / c4, q = threadIdx.x - r0 * c4;
+    const bool lane_on = r0 < rows;
+    const int n = a.b * a.c;
+    float4 xv[BN_VEC_ITERS], rv[BN_VEC_ITERS];
+    float s = 0.f, dummy = 0.f;
+#pragma unroll
+    for (int i = 0; i < BN_VEC_ITERS; ++i) {
+        const int bi = r0 + i * rows;
+        xv[i] = rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane_on && bi < a.b) {
+            xv[i] = *reinterpret_cast<const float4 *>(a.x + ((size_t)bi * a.nv + v) * a.c + 4 * q);
+            if (a.res) rv[i] = *reinterpret_cast<const float4 *>(a.res + ((size_t)bi * a.nv + v) * a.res_ld + 4 * q);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < BN_VEC_ITERS; ++i) s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w); // absent rows hold zeros
+    float mean, invstd;
+    if (a.training) {
+        block_sum2(s, dummy, lds);
+        mean = s / n;
+        float qq = 0.f;
+#pragma unroll
+        for (int i = 0; i < BN_VEC_ITERS; ++i)
+            if (lane_on && r0 + i * rows < a.b) {
+                const float d0 = xv[i].x - mean, d1 = xv[i].y - mean, d2 = xv[i].z - mean, d3 = xv[i].w - mean;
+                qq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        dummy = 0.f;
+        block_sum2(qq, dummy, lds);
+        const float var = qq / n; // biased, as used for normalisation
+        invstd = 1.f / sqrtf(var + a.eps);
+        if (threadIdx.x == 0) {
+            a.save_mean[v] = mean;
+            a.save_invstd[v] = invstd;
+            if (a.run_mean) a.run_mean[v] = (1.f - a.momentum) * a.run_mean[v] + a.momentum * mean;
+            if (a.run_var) a.run_var[v] = (1.f - a.momentum) * a.run_var[v] + a.momentum * (n > 1 ? qq / (n - 1) : var);
+        }
+    } else {
+        mean = a.run_mean[v];
+        invstd = 1.f / sqrtf(a.run_var[v] + a.eps);
+    }
+    const float g = a.weight ? a.weight[v] : 1.f, be = a.bias ? a.bias[v] : 0.f;
+    auto finish = [&](float x, float r) {
+        float y = (x - mean) * invstd * g + be;
+        if (a.relu) y = y > 0.f ? y : 0.f;
+        if (a.res) y = (r + y) * a.scale;
+        return y;
+    };
+#pragma unroll
+    for (int i = 0; i < BN_VEC_ITERS; ++i) {
+        const int bi = r0 + i * rows;
+        if (lane_on && bi < a.b)
+            *reinterpret_cast<float4 *>(a.out + ((size_t)bi * a.nv + v) * a.c + 4 * q) =
+                make_float4(finish(xv[i].x, rv[i].x), finish(xv[i].y, rv[i].y), finish(xv[i].z, rv[i].z), finish(xv[i].w, rv[i].w));
+    }
+}
+
 struct BnBwdArgs {
     const float *x, *grad_out, *weight, *bias, *save_mean, *save_invstd;
     float *grad_x, *grad_res, *grad_weight, *grad_bias; // grad_res [b,nv,c] optional
@@ -163,6 +232,68 @@ __global__ __launch_bounds__(BN_THREADS) void vertex_bn_bwd_kernel(BnBwdArgs a)
     }
 }
 
+__global__ __launch_bounds__(BN_THREADS) void vertex_bn_bwd_vec_kernel(BnBwdArgs a)
+{
+    __shared__ float lds[2 * BN_THREADS / GEOM_WAVE];
+    const int v = blockIdx.x;
+    const int c4 = a.c >> 2, rows = BN_THREADS / c4;
+    const int r0 = threadIdx.x / c4, q = threadIdx.x - r0 * c4;
+    const bool lane_on = r0 < rows;
+    const int n = a.b * a.c;
+    const float mean = a.save_mean[v], invstd = a.save_invstd[v];
+    const float g = a.weight ? a.weight[v] : 1.f, be = a.bias ? a.bias[v] : 0.f;
+    float4 xh[BN_VEC_ITERS], gy[BN_VEC_ITERS];
+    float sum_g = 0.f, sum_gx = 0.f;
+#pragma unroll
+    for (int i = 0; i < BN_VEC_ITERS; ++i) { // both operands of every row in one round trip
+        const int bi = r0 + i * rows;
+        xh[i] = gy[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane_on && bi < a.b) {
+            const size_t o = ((size_t)bi * a.nv + v) * a.c + 4 * q;
+            xh[i] = *reinterpret_cast<const float4 *>(a.x + o);
+            gy[i] = *reinterpret_cast<const float4 *>(a.grad_out + o);
+        }
+    }
+    auto one = [&](float &x, float &go) {
+        x = (x - mean) * invstd;
+        if (a.has_res) go *= a.scale;
+        const float pass = go;
+        if (a.relu && !(x * g + be > 0.f)) go = 0.f;
+        sum_g += go;
+        sum_gx += go * x;
+        return pass;
+    };
+#pragma unroll
+    for (int i = 0; i < BN_VEC_ITERS; ++i) {
+        const int bi = r0 + i * rows;
+        if (lane_on && bi < a.b) {
+            const float4 r = make_float4(one(xh[i].x, gy[i].x), one(xh[i].y, gy[i].y), one(xh[i].z, gy[i].z), one(xh[i].w, gy[i].w));
+            if (a.has_res && a.grad_res) *reinterpret_cast<float4 *>(a.grad_res + ((size_t)bi * a.nv + v) * a.c + 4 * q) = r;
+        }
+    }
+    block_sum2(sum_g, sum_gx, lds);
+    if (threadIdx.x == 0) {
+        if (a.grad_bias) a.grad_bias[v] = sum_g;
+        if (a.grad_weight) a.grad_weight[v] = sum_gx;
+    }
+    const float k = g * invstd, mg = sum_g / n, mgx = sum_gx / n;
+#pragma unroll
+    for (int i = 0; i < BN_VEC_ITERS; ++i) {
+        const int bi = r0 + i * rows;
+        if (lane_on && bi < a.b)
+            *reinterpret_cast<float4 *>(a.grad_x + ((size_t)bi * a.nv + v) * a.c + 4 * q) =
+                make_float4(k * (gy[i].x - mg - xh[i].x * mgx), k * (gy[i].y - mg - xh[i].y * mgx),
+                            k * (gy[i].z - mg - xh[i].z * mgx), k * (gy[i].w - mg - xh[i].w * mgx));
+    }
+}
+
+inline bool bn_vec_ok(int b, int c, uintptr_t ptr_bits, int extra_ld)
+{
+    if (c % 4 != 0 || c / 4 > BN_THREADS || (ptr_bits & 15) || (extra_ld & 3)) return false;
+    const int rows = BN_THREADS / (c / 4);
+    return b <= BN_VEC_ITERS * rows;
+}
+
 } // namespace
 
 extern "C" int geom_vertex_bn_fwd_f32(int b, int nv, int c, const float *x, const float *weight, const float *bias,
@@ -178,7 +309,10 @@ extern "C" int geom_vertex_bn_fwd_f32(int b, int nv, int c, const float *x, cons
     if (residual && residual_ld < c) return GEOM_EINVAL;
     BnArgs a{x, weight, bias, residual, out, running_mean, running_var, save_mean, save_invstd,
              b, nv, c, residual_ld, eps, momentum, residual ? scale : 1.f, relu, training};
-    hipLaunchKernelGGL(vertex_bn_fwd_kernel, dim3(nv), dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    if (bn_vec_ok(b, c, (uintptr_t)x | (uintptr_t)out | (uintptr_t)residual, residual ? residual_ld : 0))
+        hipLaunchKernelGGL(vertex_bn_fwd_vec_kernel, dim3(nv), dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(vertex_bn_fwd_kernel, dim3(nv), dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), a);
     return geom::launch_status();
 }
 
@@ -193,6 +327,9 @@ extern "C" int geom_vertex_bn_bwd_f32(int b, int nv, int c, const float *x, cons
     if (!x || !grad_out || !save_mean || !save_invstd || !grad_x) return GEOM_EINVAL;
     BnBwdArgs a{x, grad_out, weight, bias, save_mean, save_invstd, grad_x, grad_residual, grad_weight, grad_bias,
                 b, nv, c, has_residual ? scale : 1.f, relu, has_residual};
-    hipLaunchKernelGGL(vertex_bn_bwd_kernel, dim3(nv), dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    if (bn_vec_ok(b, c, (uintptr_t)x | (uintptr_t)grad_out | (uintptr_t)grad_x | (uintptr_t)grad_residual, 0))
+        hipLaunchKernelGGL(vertex_bn_bwd_vec_kernel, dim3(nv), dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(vertex_bn_bwd_kernel, dim3(nv), dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), a);
     return geom::launch_status();
 }

@@ -13,12 +13,13 @@ os.environ["PYTORCH_TUNABLEOP_FILENAME"] = out
 import torch  # noqa: E402
 
 torch.cuda.tunable.set_filename(out)
-torch.cuda.tunable.set_max_tuning_duration(60)
-torch.cuda.tunable.set_max_tuning_iterations(40)
+torch.cuda.tunable.set_max_tuning_duration(int(os.environ.get("GEOM_TUNE_MS", "60")))
+torch.cuda.tunable.set_max_tuning_iterations(int(os.environ.get("GEOM_TUNE_ITERS", "40")))
 dev = torch.device("cuda:0")
 verts = [int(a) for a in sys.argv[2:]] or [2562, 482]
 layers = [(963, 192), (192, 192), (1155, 192), (192, 3)]
-for V, meshes in [(V, m) for V in verts for m in (1, 2, 4, 8, 16)]:
+batches = [int(m) for m in os.environ.get("GEOM_TUNE_MESHES", "1,2,4,8,16").split(",")]
+for V, meshes in [(V, m) for V in verts for m in batches]:
     M = meshes * V
     for cin, cout in layers:
         x = torch.randn(M, cin, device=dev, requires_grad=True)
