@@ -172,3 +172,33 @@ def test_compiled_forward_cuda_shim_loads_and_validates():
         _shim.cd.forward_cuda(z, z, torch.zeros(1, 2), torch.zeros(1, 2), i, i)
     with pytest.raises(RuntimeError, match="HIP device"):
         _shim.tri.forward_cuda(z, z, z, z, torch.zeros(1, 2), i, i)
+
+
+def test_new_entry_points_reject_bad_arguments_without_a_gpu():
+    """The round-2 entry points (fused scan, prepare, finalize, gather, Adam with in-kernel step advance): sizes and
+    pointers are validated before any launch, empty batches are no-ops."""
+    L = _lib.lib()
+    one = ctypes.c_int(7)
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.addressof(buf)
+    p16 = (p + 15) & ~15
+    # geom_surface_scan_f32(b, n_gt, gt, num, points, sq_gt, idx_p, sq_pred, idx_g, nv, verts, nf, faces, order, ... )
+    scan = lambda b, n_gt, num, gt: L.geom_surface_scan_f32(b, n_gt, gt, num, None, None, None, None, None, 0, None, 0, None, None,
+                                                            None, None, None, None, None, None, None, None, 1.0, 1.0, None, 0, None,
+                                                            0, ctypes.byref(one), None)
+    assert scan(-1, 4, 4, None) == -1 and scan(1, 0, 4, None) == -1 and scan(1, 4, 4, None) == -1
+    assert scan(0, 4, 4, None) == 0 and one.value == 0            # empty batch; *records_written cleared
+    assert L.geom_surface_prepare_f32(1, 4, None, 4, None, 8, None, None, None, None, None, 8, None, 0, None, 0, None, None) == -1
+    assert L.geom_surface_prepare_f32(0, 4, None, 4, None, 8, None, None, None, None, None, 8, None, 0, None, 0, None, None) == 0
+    assert L.geom_surface_prepare_f32(1, 4, None, 20000, None, 8, None, None, None, None, None, 8, None, 0, None, 0, None, None) \
+        == _lib.EUNSUPPORTED                                       # the face-area CDF lives in LDS: <= 16384 faces
+    fin = lambda b, order, loss: L.geom_surface_finalize_f32(b, 8, 4, None, None, None, None, 4, None, None, None, None, None, None,
+                                                             p, p, 1.0, 1.0, 1.0, 1.0, 0, 0, order, loss, None)
+    assert fin(1, None, p) == -1 and fin(1, p16, None) == -1 and fin(-1, p16, p) == -1 and fin(0, p16, p) == 0
+    assert L.geom_surface_order_words(2, 10, 5, 7) == ((2 * 11 + 3 * 2 * 12 + 3) // 4 * 4) + 2 * 12 * 8
+    assert L.geom_surface_gather_f32(1, 4, 8, None, None, 4, 4, 1, None, None, None, None) == -1
+    assert L.geom_surface_gather_f32(0, 4, 8, None, None, 4, 4, 1, None, None, None, None) == 0
+    assert L.geom_adam_step_f32(17, None, None, None, None, None, 1e-3, .9, .999, 1e-8, 1.0, None, 1, None) == -2   # > 16 tensors per launch
+    assert L.geom_adam_step_f32(1, None, None, None, None, None, 1e-3, .9, .999, 1e-8, 1.0, None, 1, None) == -1
+    assert L.geom_adam_step_f32(0, None, None, None, None, None, 1e-3, .9, .999, 1e-8, 1.0, None, 1, None) == 0
+    assert L.geom_chamfer_nn_f32(1, 4, p, 4, p, p, p, p, p, _lib.FLAG_NN_FMA | _lib.FLAG_REF_TAIL_TRUNC, None) == -1
