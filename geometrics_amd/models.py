@@ -6,8 +6,9 @@ num_batches_tracked`), so the reference's checkpoints load unchanged.
 Per layer pair the reference runs GEMM, dense adjacency product, cat, bias add, a two-pass
 BatchNorm1d(verts), ReLU, add and divide as separate eager ops; here it is GEMM -> one aggregation
 kernel (csrc/zn_gcn.hip) -> one per-vertex BN + ReLU (+ residual average) kernel (csrc/vertex_bn.hip).
-Data-parallel note: like torch's BatchNorm under DDP without SyncBN, statistics are those of the
-LOCAL shard of meshes.
+Data-parallel note: under torch.distributed with more than one rank the BatchNorm statistics are those of the GLOBAL
+batch (per-vertex sums all-reduced, `_SyncVertexBN`), i.e. N shards normalise exactly as the single-GPU reference does
+over its whole batch; `VertexBatchNorm.sync_across_ranks = False` restores local-shard statistics on the fused kernel.
 """
 import torch
 import torch.nn.functional as F
@@ -69,6 +70,45 @@ class _VertexBN(torch.autograd.Function):
         return grad_x, gw, gb, None, None, grad_res, None, None, None, None, None
 
 
+class _SyncVertexBN(torch.autograd.Function):
+    """nn.BatchNorm1d(verts) over the GLOBAL batch of a data-parallel job: the per-vertex sums of x and x^2 (forward) and
+    of g and g*x_hat (backward) are all-reduced across the ranks, so N shards of B/N meshes normalise exactly as ONE
+    process holding all B meshes -- the reference's semantics (it is single-GPU: models.py:237-297 sees the whole
+    batch).  Plain torch ops + two small all-reduces ([V, 2] floats each way); used only when a process group with more
+    than one rank is active."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        import torch.distributed as dist
+        local = torch.stack((x.sum(dim=(0, 2)), (x * x).sum(dim=(0, 2))), dim=1)          # [V, 2]
+        count = torch.tensor([x.shape[0] * x.shape[2]], dtype=x.dtype, device=x.device)
+        packed = torch.cat((local.reshape(-1), count))
+        dist.all_reduce(packed)
+        n = packed[-1]
+        tot = packed[:-1].view(-1, 2)
+        mean = tot[:, 0] / n
+        var = (tot[:, 1] / n - mean * mean).clamp_min(0.0)                                  # biased, as used for normalisation
+        invstd = torch.rsqrt(var + eps)
+        with torch.no_grad():
+            running_mean.mul_(1 - momentum).add_(momentum * mean)
+            running_var.mul_(1 - momentum).add_(momentum * var * (n / (n - 1).clamp_min(1.0)))
+        xhat = (x - mean.view(1, -1, 1)) * invstd.view(1, -1, 1)
+        ctx.save_for_backward(xhat, weight, invstd, n)
+        return xhat * weight.view(1, -1, 1) + bias.view(1, -1, 1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        import torch.distributed as dist
+        xhat, weight, invstd, n = ctx.saved_tensors
+        local = torch.stack((grad_out.sum(dim=(0, 2)), (grad_out * xhat).sum(dim=(0, 2))), dim=1)
+        grad_weight, grad_bias = local[:, 1].clone(), local[:, 0].clone()                  # local shard: DDP-style, reduced with the other gradients
+        tot = local.clone()
+        dist.all_reduce(tot)
+        mg, mgx = (tot[:, 0] / n).view(1, -1, 1), (tot[:, 1] / n).view(1, -1, 1)
+        grad_x = (weight * invstd).view(1, -1, 1) * (grad_out - mg - xhat * mgx)
+        return grad_x, grad_weight, grad_bias, None, None, None, None
+
+
 class VertexBatchNorm(nn.Module):
     """nn.BatchNorm1d(verts) for [B,V,C] activations with the ReLU and the block's residual average
     `(residual + relu(bn(x))) / 2` folded into the same kernel.  Parameters and buffers are named as in
@@ -84,8 +124,17 @@ class VertexBatchNorm(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self._pending_batches = 0   # counted on the host; folded into the buffer when the state is saved
 
+    sync_across_ranks = True   # under torch.distributed with > 1 rank: statistics of the GLOBAL batch (the reference is
+    #                            single-GPU and normalises over the whole batch); False = local-shard statistics, fused kernel
+
     def forward(self, x, relu=False, residual=None, scale=0.5):
         b, _, c = x.shape
+        if self.training and self.sync_across_ranks and torch.distributed.is_available() \
+                and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            self._pending_batches += 1
+            y = _SyncVertexBN.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum, self.eps)
+            y = torch.relu(y) if relu else y
+            return (residual + y) * scale if residual is not None else y
         # library ops (same maths) outside the register-resident kernel, and for gradients through an eval()'d block
         # (frozen-BN fine-tuning): the fused backward is written for batch statistics
         eval_grad = not self.training and torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)

@@ -81,3 +81,63 @@ def test_single_process_helpers_are_noops():
     assert gdist.all_reduce_sum_(t) is t
     assert float(gdist.global_mean_loss(torch.tensor(6.0), 3)) == 2.0
     gdist.barrier()
+
+
+# ------------------------------------------------- BatchNorm(verts) under data parallelism: global-batch statistics ----
+def _bn_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    gdist.init_from_env(backend="gloo")
+    from geometrics_amd import models
+    torch.manual_seed(3)
+    bn = models.VertexBatchNorm(11)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.3, 0.3)
+    g = torch.Generator().manual_seed(9)
+    x_all, go_all, res_all = (torch.randn(6, 11, 5, generator=g) for _ in range(3))
+    first, count = gdist.shard_range(6, rank, world)
+    x = x_all[first:first + count].clone().requires_grad_(True)
+    res = res_all[first:first + count].clone().requires_grad_(True)
+    y = bn(x, relu=True, residual=res)                      # CPU tensors + 2 ranks: only the synchronised path can serve this
+    y.backward(go_all[first:first + count])
+    gw, gb = bn.weight.grad.clone(), bn.bias.grad.clone()
+    dist.all_reduce(gw), dist.all_reduce(gb)                # what the flat gradient bucket does for every parameter
+    gdist.barrier()
+    out.put((rank, y.detach(), x.grad, res.grad, gw, gb, bn.running_mean.clone(), bn.running_var.clone(),
+             int(bn.state_dict()["num_batches_tracked"])))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_vertex_batchnorm_uses_global_batch_statistics_across_ranks():
+    """Two ranks with 3 meshes each must normalise exactly as ONE process with all 6 (the reference is single-GPU:
+    BatchNorm1d(verts) sees the whole batch, models.py:237-297): outputs, input / residual gradients, parameter
+    gradients (summed over ranks) and running statistics against torch.nn.BatchNorm1d on the full batch."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_worker, args=(r, 2, port, out), daemon=True) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([out.get(timeout=90) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    torch.manual_seed(3)
+    ref = torch.nn.BatchNorm1d(11)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5)
+        ref.bias.uniform_(-0.3, 0.3)
+    g = torch.Generator().manual_seed(9)
+    x_all, go_all, res_all = (torch.randn(6, 11, 5, generator=g) for _ in range(3))
+    x, res = x_all.clone().requires_grad_(True), res_all.clone().requires_grad_(True)
+    y = (res + torch.relu(ref(x))) * 0.5
+    y.backward(go_all)
+    y2 = torch.cat([got[0][1], got[1][1]])
+    assert torch.allclose(y2, y.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(torch.cat([got[0][2], got[1][2]]), x.grad, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(torch.cat([got[0][3], got[1][3]]), res.grad, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(got[0][4], ref.weight.grad, rtol=1e-4, atol=1e-6) and torch.allclose(got[0][5], ref.bias.grad, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(got[0][6], ref.running_mean, rtol=1e-5, atol=1e-7) and torch.allclose(got[0][7], ref.running_var, rtol=1e-5, atol=1e-6)
+    assert got[0][8] == 1
