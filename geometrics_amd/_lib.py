@@ -16,7 +16,7 @@ FLAG_FIX_REGION6 = 2
 FLAG_TRI_BRUTE_FORCE = 4
 FLAG_NN_FMA = 8
 FLAG_TRI_WS_READY = 16
-ABI_VERSION = 3
+ABI_VERSION = 4
 EUNSUPPORTED = -3
 ADAM_MAX_TENSORS = 16
 ADAM_STATE_WORDS = 72
@@ -62,7 +62,7 @@ _SIGNATURES = {
     "geom_edge_sqlen_fwd_f32": [_i, _i, _vp, _i, _vp, _vp, _vp],
     "geom_edge_sqlen_bwd_f32": [_i, _i, _vp, _i, _vp, _vp, _f, _vp, _vp],
     "geom_vertex_bn_fwd_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _i, _vp, _i, _f, _vp, _vp, _vp, _vp],
-    "geom_vertex_bn_bwd_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
+    "geom_vertex_bn_bwd_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "geom_pool_features_fwd_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_pool_features_bwd_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "geom_adam_step_f32": [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _i, _vp],

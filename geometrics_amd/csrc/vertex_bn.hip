@@ -126,6 +126,12 @@ __global__ __launch_bounds__(BN_THREADS) void vertex_bn_fwd_vec_kernel(BnArgs a)
     const int r0 = threadIdx.x / c4, q = threadIdx.x - r0 * c4;
     const bool lane_on = r0 < rows;
     const int n = a.b * a.c;
+    // the vertex's parameters and running statistics are requested up front, in the round trip of the rows: read where
+    // they are used they add a dependent trip after the reductions (the launch is a latency chain, not a bandwidth job)
+    const float g = a.weight ? a.weight[v] : 1.f, be = a.bias ? a.bias[v] : 0.f;
+    const bool updates = a.training && threadIdx.x == 0;
+    const float old_mean = (updates && a.run_mean) ? a.run_mean[v] : 0.f;
+    const float old_var = (updates && a.run_var) ? a.run_var[v] : 0.f;
     float4 xv[BN_VEC_ITERS], rv[BN_VEC_ITERS];
     float s = 0.f, dummy = 0.f;
 #pragma unroll
@@ -157,14 +163,13 @@ __global__ __launch_bounds__(BN_THREADS) void vertex_bn_fwd_vec_kernel(BnArgs a)
         if (threadIdx.x == 0) {
             a.save_mean[v] = mean;
             a.save_invstd[v] = invstd;
-            if (a.run_mean) a.run_mean[v] = (1.f - a.momentum) * a.run_mean[v] + a.momentum * mean;
-            if (a.run_var) a.run_var[v] = (1.f - a.momentum) * a.run_var[v] + a.momentum * (n > 1 ? qq / (n - 1) : var);
+            if (a.run_mean) a.run_mean[v] = (1.f - a.momentum) * old_mean + a.momentum * mean;
+            if (a.run_var) a.run_var[v] = (1.f - a.momentum) * old_var + a.momentum * (n > 1 ? qq / (n - 1) : var);
         }
     } else {
         mean = a.run_mean[v];
         invstd = 1.f / sqrtf(a.run_var[v] + a.eps);
     }
-    const float g = a.weight ? a.weight[v] : 1.f, be = a.bias ? a.bias[v] : 0.f;
     auto finish = [&](float x, float r) {
         float y = (x - mean) * invstd * g + be;
         if (a.relu) y = y > 0.f ? y : 0.f;
@@ -181,7 +186,8 @@ __global__ __launch_bounds__(BN_THREADS) void vertex_bn_fwd_vec_kernel(BnArgs a)
 }
 
 struct BnBwdArgs {
-    const float *x, *grad_out, *weight, *bias, *save_mean, *save_invstd;
+    const float *x, *grad_out, *grad_out2, *weight, *bias, *save_mean, *save_invstd; // grad_out2: optional second upstream
+    //   gradient of the same output (it fed a layer AND a residual average): summed on the fly, one add as autograd's
     float *grad_x, *grad_res, *grad_weight, *grad_bias; // grad_res [b,nv,c] optional
     int b, nv, c;
     float scale;
@@ -206,6 +212,7 @@ __global__ __launch_bounds__(BN_THREADS) void vertex_bn_bwd_kernel(BnBwdArgs a)
             const size_t o = ((size_t)bi * a.nv + v) * a.c + ci;
             xh[i] = (a.x[o] - mean) * invstd;
             float go = a.grad_out[o];
+            if (a.grad_out2) go += a.grad_out2[o];
             if (a.has_res) {
                 go *= a.scale;
                 if (a.grad_res) a.grad_res[o] = go;
@@ -242,17 +249,22 @@ __global__ __launch_bounds__(BN_THREADS) void vertex_bn_bwd_vec_kernel(BnBwdArgs
     const int n = a.b * a.c;
     const float mean = a.save_mean[v], invstd = a.save_invstd[v];
     const float g = a.weight ? a.weight[v] : 1.f, be = a.bias ? a.bias[v] : 0.f;
-    float4 xh[BN_VEC_ITERS], gy[BN_VEC_ITERS];
+    float4 xh[BN_VEC_ITERS], gy[BN_VEC_ITERS], g2[BN_VEC_ITERS];
     float sum_g = 0.f, sum_gx = 0.f;
 #pragma unroll
-    for (int i = 0; i < BN_VEC_ITERS; ++i) { // both operands of every row in one round trip
+    for (int i = 0; i < BN_VEC_ITERS; ++i) { // all operands of every row in one round trip
         const int bi = r0 + i * rows;
-        xh[i] = gy[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        xh[i] = gy[i] = g2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (lane_on && bi < a.b) {
             const size_t o = ((size_t)bi * a.nv + v) * a.c + 4 * q;
             xh[i] = *reinterpret_cast<const float4 *>(a.x + o);
             gy[i] = *reinterpret_cast<const float4 *>(a.grad_out + o);
+            if (a.grad_out2) g2[i] = *reinterpret_cast<const float4 *>(a.grad_out2 + o);
         }
+    }
+    if (a.grad_out2) {
+#pragma unroll
+        for (int i = 0; i < BN_VEC_ITERS; ++i) gy[i].x += g2[i].x, gy[i].y += g2[i].y, gy[i].z += g2[i].z, gy[i].w += g2[i].w;
     }
     auto one = [&](float &x, float &go) {
         x = (x - mean) * invstd;
@@ -319,15 +331,15 @@ extern "C" int geom_vertex_bn_fwd_f32(int b, int nv, int c, const float *x, cons
 extern "C" int geom_vertex_bn_bwd_f32(int b, int nv, int c, const float *x, const float *grad_out, const float *weight,
                                       const float *bias, const float *save_mean, const float *save_invstd, int relu,
                                       int has_residual, float scale, float *grad_x, float *grad_residual,
-                                      float *grad_weight, float *grad_bias, void *stream)
+                                      float *grad_weight, float *grad_bias, const float *grad_out2, void *stream)
 {
     if (b < 0 || nv < 0 || c < 0) return GEOM_EINVAL;
     if ((int64_t)b * c > BN_THREADS * BN_MAX_PER_THREAD) return GEOM_EUNSUPPORTED;
     if (b == 0 || nv == 0 || c == 0) return 0;
     if (!x || !grad_out || !save_mean || !save_invstd || !grad_x) return GEOM_EINVAL;
-    BnBwdArgs a{x, grad_out, weight, bias, save_mean, save_invstd, grad_x, grad_residual, grad_weight, grad_bias,
+    BnBwdArgs a{x, grad_out, grad_out2, weight, bias, save_mean, save_invstd, grad_x, grad_residual, grad_weight, grad_bias,
                 b, nv, c, has_residual ? scale : 1.f, relu, has_residual};
-    if (bn_vec_ok(b, c, (uintptr_t)x | (uintptr_t)grad_out | (uintptr_t)grad_x | (uintptr_t)grad_residual, 0))
+    if (bn_vec_ok(b, c, (uintptr_t)x | (uintptr_t)grad_out | (uintptr_t)grad_out2 | (uintptr_t)grad_x | (uintptr_t)grad_residual, 0))
         hipLaunchKernelGGL(vertex_bn_bwd_vec_kernel, dim3(nv), dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), a);
     else
         hipLaunchKernelGGL(vertex_bn_bwd_kernel, dim3(nv), dim3(BN_THREADS), 0, static_cast<hipStream_t>(stream), a);

@@ -318,6 +318,9 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a
             nb[n] = ci.x, nb[n + 1] = ci.y, nb[n + 2] = ci.z, nb[n + 3] = ci.w;
             w[n] = wi.x, w[n + 1] = wi.y, w[n + 2] = wi.z, w[n + 3] = wi.w;
         }
+        constexpr int TAIL = (ACT == ACT_NONE && NC == 2) ? 16 : 8; // entries of a long row per round (below)
+        int e0 = 0, e1 = 0; // the row's entries beyond the table width, in the CSR tail
+        if (a.over_ptr) e0 = a.over_ptr[r], e1 = a.over_ptr[r + 1];
         unsigned own_bits = 0u;
         if (BACKWARD && MASK) own_bits = a.mask[row * kg + j];
 #pragma unroll
@@ -347,6 +350,16 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a
             if (BACKWARD && MASK) nbits[n] = a.mask[nrow * kg + j];
             else if (BACKWARD && ACT != ACT_NONE) ov[n] = *reinterpret_cast<const float4 *>(a.saved + nrow * a.c + c0);
         }
+        int tcol[TAIL];
+        float tval[TAIL];
+        if (e0 < e1) { // a long row: the indices of its first TAIL extra entries travel with the neighbour rows
+#pragma unroll
+            for (int t = 0; t < TAIL; ++t) {
+                const int ee = e0 + t < e1 ? e0 + t : e1 - 1;
+                tcol[t] = a.over_col[ee];
+                tval[t] = a.over_val[ee];
+            }
+        }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int n = 0; n < W; ++n) {
@@ -369,28 +382,50 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a
                 acc.w += w[n] * v.w;
             }
         }
-        if (a.over_ptr) { // the row's entries beyond the table width (wave-divergent only at the few long rows)
-            for (int e = a.over_ptr[r]; e < a.over_ptr[r + 1]; ++e) {
-                const int64_t nrow = mesh_row0 + a.over_col[e];
-                const float wv = a.over_val[e];
-                float4 v = *reinterpret_cast<const float4 *>(a.x + nrow * a.c + c0);
-                if (BACKWARD && MASK) {
-                    const unsigned m = a.mask[nrow * kg + j];
-                    v.x = (m & 1u) ? v.x : 0.f;
-                    v.y = (m & 2u) ? v.y : 0.f;
-                    v.z = (m & 4u) ? v.z : 0.f;
-                    v.w = (m & 8u) ? v.w : 0.f;
-                } else if (BACKWARD && ACT != ACT_NONE) {
-                    const float4 o = *reinterpret_cast<const float4 *>(a.saved + nrow * a.c + c0);
-                    v.x = act_bwd<ACT>(v.x, o.x);
-                    v.y = act_bwd<ACT>(v.y, o.y);
-                    v.z = act_bwd<ACT>(v.z, o.z);
-                    v.w = act_bwd<ACT>(v.w, o.w);
+        // the row's entries beyond the table width (wave-divergent only at the few long rows).  TAIL entries per round:
+        // their rows in one round trip, the NEXT round's indices requested meanwhile (one entry at a time the 25 extra
+        // entries of a 482.obj pole cost 50 dependent round trips, and the two pole rows set the launch time)
+        for (int e = e0; e < e1; e += TAIL) {
+            int64_t nrow[TAIL];
+            float wv[TAIL];
+            float4 tv[TAIL], to[TAIL];
+            unsigned tb[TAIL];
+#pragma unroll
+            for (int t = 0; t < TAIL; ++t) {
+                nrow[t] = mesh_row0 + tcol[t];
+                wv[t] = tval[t];
+                tv[t] = *reinterpret_cast<const float4 *>(a.x + nrow[t] * a.c + c0);
+                if (BACKWARD && MASK) tb[t] = a.mask[nrow[t] * kg + j];
+                else if (BACKWARD && ACT != ACT_NONE) to[t] = *reinterpret_cast<const float4 *>(a.saved + nrow[t] * a.c + c0);
+            }
+            if (e + TAIL < e1) {
+#pragma unroll
+                for (int t = 0; t < TAIL; ++t) {
+                    const int ee = e + TAIL + t < e1 ? e + TAIL + t : e1 - 1;
+                    tcol[t] = a.over_col[ee];
+                    tval[t] = a.over_val[ee];
                 }
-                acc.x += wv * v.x;
-                acc.y += wv * v.y;
-                acc.z += wv * v.z;
-                acc.w += wv * v.w;
+            }
+#pragma unroll
+            for (int t = 0; t < TAIL; ++t) {
+                if (e + t < e1) { // still in CSR order
+                    float4 v = tv[t];
+                    if (BACKWARD && MASK) {
+                        v.x = (tb[t] & 1u) ? v.x : 0.f;
+                        v.y = (tb[t] & 2u) ? v.y : 0.f;
+                        v.z = (tb[t] & 4u) ? v.z : 0.f;
+                        v.w = (tb[t] & 8u) ? v.w : 0.f;
+                    } else if (BACKWARD && ACT != ACT_NONE) {
+                        v.x = act_bwd<ACT>(v.x, to[t].x);
+                        v.y = act_bwd<ACT>(v.y, to[t].y);
+                        v.z = act_bwd<ACT>(v.z, to[t].z);
+                        v.w = act_bwd<ACT>(v.w, to[t].w);
+                    }
+                    acc.x += wv[t] * v.x;
+                    acc.y += wv[t] * v.y;
+                    acc.z += wv[t] * v.z;
+                    acc.w += wv[t] * v.w;
+                }
             }
         }
         float *yrow = a.y + row * a.c;

@@ -133,6 +133,63 @@ def _activation_code(activation):
     return _ACT_NONE
 
 
+def aggregate_forward(s, bias_c, csr, k, act, out, want_mask=False):
+    """Launch out = act([A . s[..., :k] | s[..., k:]] + bias) on contiguous fp32 [B,V,C] tensors: the fixed-stride table
+    kernel when the adjacency has one (bounded degrees; long rows continue in its CSR tail), the generic CSR kernel
+    otherwise.  Returns the ReLU sign mask when one was asked for and written."""
+    b, nv, c = s.shape
+    mask = None
+    with torch.cuda.device(s.device):
+        code = _lib.EUNSUPPORTED
+        if csr.ell_w:   # bounded-degree mesh: fixed-stride neighbour table, no rowptr round trip
+            if want_mask and act == _ACT_RELU:
+                # one sign bit per output element: the backward takes relu' from it instead of re-reading `out`
+                words = _lib.lib().geom_zn_gcn_relu_mask_words(b, nv, c, k)
+                if words:
+                    mask = torch.empty(words, dtype=torch.int16, device=s.device)
+            over = csr.over or (None, None, None)
+            code = _lib.lib().geom_zn_gcn_aggregate_ell_fwd_f32(
+                b, nv, c, k, csr.ell_w, csr.ell_col.data_ptr(), csr.ell_val.data_ptr(), _lib.ptr(over[0]),
+                _lib.ptr(over[1]), _lib.ptr(over[2]), s.data_ptr(),
+                _lib.ptr(bias_c), act, out.data_ptr(), _lib.ptr(mask), _lib.stream_ptr())
+            if code == _lib.EUNSUPPORTED:
+                mask = None
+        if code == _lib.EUNSUPPORTED:
+            _lib.call("geom_zn_gcn_aggregate_fwd_f32", b, nv, c, k, csr.rowptr.data_ptr(), csr.col.data_ptr(),
+                      csr.val.data_ptr(), s.data_ptr(), _lib.ptr(bias_c), act, out.data_ptr())
+        else:
+            _lib.check(code, "geom_zn_gcn_aggregate_ell_fwd_f32")
+    return mask
+
+
+def aggregate_backward(g, csr, k, act, out, mask, want_bias):
+    """grad_support = [A^T . g'[..., :k] | g'[..., k:]] with g' = g * act'(out) (relu' from the sign mask when there is
+    one), and the bias gradient = column sums of g' out of the same launch (+ a fixed-order reduction)."""
+    b, nv, c = g.shape
+    grad_support = torch.empty_like(g)
+    grad_bias = scratch = None
+    if want_bias:   # column sums of g come out of the same kernel (per-block partials + fixed-order reduce)
+        grad_bias = torch.empty(c, dtype=torch.float32, device=g.device)
+        scratch = torch.empty(_lib.lib().geom_zn_gcn_bwd_scratch_floats(b, nv, c), dtype=torch.float32,
+                              device=g.device)
+    with torch.cuda.device(g.device):
+        code = _lib.EUNSUPPORTED
+        if csr.ell_w:
+            over = csr.over_t or (None, None, None)
+            code = _lib.lib().geom_zn_gcn_aggregate_ell_bwd_f32(
+                b, nv, c, k, csr.ell_w, csr.ell_col_t.data_ptr(), csr.ell_val_t.data_ptr(), _lib.ptr(over[0]),
+                _lib.ptr(over[1]), _lib.ptr(over[2]), g.data_ptr(),
+                _lib.ptr(out), _lib.ptr(mask), act, grad_support.data_ptr(), _lib.ptr(grad_bias), _lib.ptr(scratch),
+                _lib.stream_ptr())
+        if code == _lib.EUNSUPPORTED:
+            _lib.call("geom_zn_gcn_aggregate_bwd_f32", b, nv, c, k, csr.rowptr_t.data_ptr(),
+                      csr.col_t.data_ptr(), csr.val_t.data_ptr(), g.data_ptr(), _lib.ptr(out), act,
+                      grad_support.data_ptr(), _lib.ptr(grad_bias), _lib.ptr(scratch))
+        else:
+            _lib.check(code, "geom_zn_gcn_aggregate_ell_bwd_f32")
+    return grad_support, grad_bias
+
+
 class _ZeroNAggregate(torch.autograd.Function):
     """out = act([A . S[..., :k] | S[..., k:]] + bias)  for S [B,V,C]: one kernel, S read once.
     Backward: grad_S = [A^T . g[..., :k] | g[..., k:]] with g = grad_out * act'(out), again one kernel."""
@@ -140,32 +197,11 @@ class _ZeroNAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, support, bias, csr, k, act):
         s = _lib.require(support, "support", torch.float32, 3)
-        b, nv, c = s.shape
-        if nv != csr.nv:
-            raise RuntimeError("support has %d vertices but the adjacency has %d" % (nv, csr.nv))
+        if s.shape[1] != csr.nv:
+            raise RuntimeError("support has %d vertices but the adjacency has %d" % (s.shape[1], csr.nv))
         bias_c = None if bias is None else _lib.require(bias, "bias", torch.float32, 1)
         out = torch.empty_like(s)
-        mask = None
-        with torch.cuda.device(s.device):
-            code = _lib.EUNSUPPORTED
-            if csr.ell_w:   # bounded-degree mesh: fixed-stride neighbour table, no rowptr round trip
-                if act == _ACT_RELU and support.requires_grad:
-                    # one sign bit per output element: the backward takes relu' from it instead of re-reading `out`
-                    words = _lib.lib().geom_zn_gcn_relu_mask_words(b, nv, c, k)
-                    if words:
-                        mask = torch.empty(words, dtype=torch.int16, device=s.device)
-                over = csr.over or (None, None, None)
-                code = _lib.lib().geom_zn_gcn_aggregate_ell_fwd_f32(
-                    b, nv, c, k, csr.ell_w, csr.ell_col.data_ptr(), csr.ell_val.data_ptr(), _lib.ptr(over[0]),
-                    _lib.ptr(over[1]), _lib.ptr(over[2]), s.data_ptr(),
-                    _lib.ptr(bias_c), act, out.data_ptr(), _lib.ptr(mask), _lib.stream_ptr())
-                if code == _lib.EUNSUPPORTED:
-                    mask = None
-            if code == _lib.EUNSUPPORTED:
-                _lib.call("geom_zn_gcn_aggregate_fwd_f32", b, nv, c, k, csr.rowptr.data_ptr(), csr.col.data_ptr(),
-                          csr.val.data_ptr(), s.data_ptr(), _lib.ptr(bias_c), act, out.data_ptr())
-            else:
-                _lib.check(code, "geom_zn_gcn_aggregate_ell_fwd_f32")
+        mask = aggregate_forward(s, bias_c, csr, k, act, out, want_mask=support.requires_grad)
         ctx.csr, ctx.k, ctx.act, ctx.has_bias = csr, k, act, bias is not None
         ctx.masked = mask is not None
         if mask is not None:
@@ -177,32 +213,11 @@ class _ZeroNAggregate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         g = grad_out.contiguous()
-        b, nv, c = g.shape
-        csr, act = ctx.csr, ctx.act
+        act = ctx.act
         mask = ctx.saved_tensors[0] if ctx.masked else None
         out = ctx.saved_tensors[0] if (act != _ACT_NONE and not ctx.masked) else None
-        want_bias = ctx.has_bias and ctx.needs_input_grad[1]
-        grad_support = torch.empty_like(g)
-        grad_bias = scratch = None
-        if want_bias:   # column sums of g come out of the same kernel (per-block partials + fixed-order reduce)
-            grad_bias = torch.empty(c, dtype=torch.float32, device=g.device)
-            scratch = torch.empty(_lib.lib().geom_zn_gcn_bwd_scratch_floats(b, nv, c), dtype=torch.float32,
-                                  device=g.device)
-        with torch.cuda.device(g.device):
-            code = _lib.EUNSUPPORTED
-            if csr.ell_w:
-                over = csr.over_t or (None, None, None)
-                code = _lib.lib().geom_zn_gcn_aggregate_ell_bwd_f32(
-                    b, nv, c, ctx.k, csr.ell_w, csr.ell_col_t.data_ptr(), csr.ell_val_t.data_ptr(), _lib.ptr(over[0]),
-                    _lib.ptr(over[1]), _lib.ptr(over[2]), g.data_ptr(),
-                    _lib.ptr(out), _lib.ptr(mask), act, grad_support.data_ptr(), _lib.ptr(grad_bias), _lib.ptr(scratch),
-                    _lib.stream_ptr())
-            if code == _lib.EUNSUPPORTED:
-                _lib.call("geom_zn_gcn_aggregate_bwd_f32", b, nv, c, ctx.k, csr.rowptr_t.data_ptr(),
-                          csr.col_t.data_ptr(), csr.val_t.data_ptr(), g.data_ptr(), _lib.ptr(out), act,
-                          grad_support.data_ptr(), _lib.ptr(grad_bias), _lib.ptr(scratch))
-            else:
-                _lib.check(code, "geom_zn_gcn_aggregate_ell_bwd_f32")
+        grad_support, grad_bias = aggregate_backward(g, ctx.csr, ctx.k, act, out, mask,
+                                                     ctx.has_bias and ctx.needs_input_grad[1])
         return (grad_support if ctx.needs_input_grad[0] else None), grad_bias, None, None, None
 
 

@@ -6,6 +6,10 @@ num_batches_tracked`), so the reference's checkpoints load unchanged.
 Per layer pair the reference runs GEMM, dense adjacency product, cat, bias add, a two-pass
 BatchNorm1d(verts), ReLU, add and divide as separate eager ops; here it is GEMM -> one aggregation
 kernel (csrc/zn_gcn.hip) -> one per-vertex BN + ReLU (+ residual average) kernel (csrc/vertex_bn.hip).
+A BatchNorm output that feeds the next layer AND a later residual average is handed out as two tensor objects over
+the same memory (`tap`), so that its two upstream gradients meet inside the BN backward kernel instead of in a separate
+accumulation pass; the block input's leading columns (the first residual) are tapped the same way (`_InputTap`).
+(Measured and rejected: aggregation + BatchNorm in ONE launch -- DESIGN section 9.)
 Data-parallel note: under torch.distributed with more than one rank the BatchNorm statistics are those of the GLOBAL
 batch (per-vertex sums all-reduced, `_SyncVertexBN`), i.e. N shards normalise exactly as the single-GPU reference does
 over its whole batch; `VertexBatchNorm.sync_across_ranks = False` restores local-shard statistics on the fused kernel.
@@ -24,18 +28,11 @@ def _identity(x):
 
 class _VertexBN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, residual, training, momentum, eps, relu, scale):
+    def forward(ctx, x, weight, bias, running_mean, running_var, residual, training, momentum, eps, relu, scale, tap=False):
         xc = _lib.require(x, "x", torch.float32, 3)
         b, nv, c = xc.shape
         dev = xc.device
-        res, res_ld = None, c
-        if residual is not None:
-            res = residual
-            ok = (res.dim() == 3 and res.shape == xc.shape and res.stride(2) == 1 and res.stride(1) >= c
-                  and res.stride(0) == nv * res.stride(1) and res.dtype == torch.float32 and res.is_cuda)
-            if not ok:
-                res = res.contiguous()
-            res_ld = res.stride(1)   # a column slice of a wider row-major tensor is read in place
+        res, res_ld = _residual_operand(residual, xc)   # a column slice of a wider row-major tensor is read in place
         out = torch.empty_like(xc)
         mean = torch.empty(nv, dtype=torch.float32, device=dev)
         invstd = torch.empty(nv, dtype=torch.float32, device=dev)
@@ -50,14 +47,17 @@ class _VertexBN(torch.autograd.Function):
             inv = torch.rsqrt(running_var + eps)
             ctx.save_for_backward(xc, weight, bias, running_mean.clone(), inv)
         ctx.relu, ctx.scale, ctx.has_res, ctx.training = relu, scale, residual is not None, training
-        return out
+        # tap: the output twice (two tensor objects over the same memory) -- the caller gives one to the next layer and one
+        # to the residual average two layers on; their gradients are summed inside the backward kernel
+        return (out, _alias(out)) if tap else out
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, *grads):
         x, weight, bias, mean, invstd = ctx.saved_tensors
         if not ctx.training:
             raise RuntimeError("backward through the fused vertex BatchNorm is implemented for training mode only")
-        g = grad_out.contiguous()
+        given = [t.contiguous() for t in grads if t is not None]
+        g, g2 = given[0], (given[1] if len(given) > 1 else None)
         b, nv, c = x.shape
         grad_x = torch.empty_like(x)
         grad_res = torch.empty_like(x) if ctx.has_res else None
@@ -66,8 +66,58 @@ class _VertexBN(torch.autograd.Function):
         with torch.cuda.device(x.device):
             _lib.call("geom_vertex_bn_bwd_f32", b, nv, c, x.data_ptr(), g.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
                       mean.data_ptr(), invstd.data_ptr(), int(ctx.relu), int(ctx.has_res), float(ctx.scale),
-                      grad_x.data_ptr(), _lib.ptr(grad_res), _lib.ptr(gw), _lib.ptr(gb))
-        return grad_x, gw, gb, None, None, grad_res, None, None, None, None, None
+                      grad_x.data_ptr(), _lib.ptr(grad_res), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(g2))
+        return grad_x, gw, gb, None, None, grad_res, None, None, None, None, None, None
+
+
+def _residual_operand(residual, like):
+    """The residual as the kernels read it: in place when it is a [B,V,C] fp32 tensor or a column slice of a wider
+    row-major one (row stride = its leading dimension), a contiguous copy otherwise.  Returns (tensor, row stride)."""
+    if residual is None:
+        return None, like.shape[2]
+    res = residual
+    nv, c = like.shape[1], like.shape[2]
+    ok = (res.dim() == 3 and res.shape == like.shape and res.stride(2) == 1 and res.stride(1) >= c
+          and res.stride(0) == nv * res.stride(1) and res.dtype == torch.float32 and res.is_cuda)
+    if not ok:
+        res = res.contiguous()
+    return res, res.stride(1)
+
+
+def _alias(t):
+    """A second tensor object over t's memory (no view relation, no copy): the other handle of a tapped output."""
+    return torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage(), t.storage_offset(), t.size(), t.stride())
+
+
+class _InputTap(torch.autograd.Function):
+    """full = cat(features, pooled) and, as a second output, a contiguous copy of its leading `width` columns -- the
+    residual of the block's first layer pair (models.py:252: `features[:, :, :self.hidden]`).  As two autograd ops the
+    slice's gradient comes back as a zero-filled tensor of the full width (35.6 MB at the training shape) that is then
+    added to the first layer's input gradient; here the narrow gradient is added into the two input gradients directly."""
+
+    @staticmethod
+    def forward(ctx, features, pooled, width):
+        full = torch.cat((features, pooled), dim=-1)
+        if width > full.shape[-1]:
+            raise RuntimeError("the block input has %d columns, fewer than the %d hidden ones" % (full.shape[-1], width))
+        ctx.nf, ctx.width = features.shape[-1], width
+        ctx.shapes = (features.shape, pooled.shape)
+        return full, full[..., :width].contiguous()
+
+    @staticmethod
+    def backward(ctx, g_full, g_res):
+        nf, width = ctx.nf, ctx.width
+        lead = min(nf, width)
+        gf = gp = None
+        if ctx.needs_input_grad[0]:
+            gf = g_full[..., :nf].clone() if g_full is not None else g_res.new_zeros(ctx.shapes[0])
+            if g_res is not None and lead:
+                gf[..., :lead] += g_res[..., :lead]
+        if ctx.needs_input_grad[1]:
+            gp = g_full[..., nf:].contiguous() if g_full is not None else g_res.new_zeros(ctx.shapes[1])
+            if g_res is not None and width > nf:
+                gp[..., :width - nf] += g_res[..., nf:width]
+        return gf, gp, None
 
 
 class _SyncVertexBN(torch.autograd.Function):
@@ -127,28 +177,38 @@ class VertexBatchNorm(nn.Module):
     sync_across_ranks = True   # under torch.distributed with > 1 rank: statistics of the GLOBAL batch (the reference is
     #                            single-GPU and normalises over the whole batch); False = local-shard statistics, fused kernel
 
-    def forward(self, x, relu=False, residual=None, scale=0.5):
+    def _synchronised(self):
+        return (self.training and self.sync_across_ranks and torch.distributed.is_available()
+                and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1)
+
+    MAX_VALUES_PER_VERTEX = 4096   # b * c held in the registers of one workgroup (csrc/vertex_bn.hip)
+
+    def fused_kernel_serves(self, x):
+        """True when the register-resident HIP kernels serve this call: device tensors with b*c <= 4096 values per
+        vertex, local statistics, and not a gradient through an eval()'d block (the fused backward is written for batch
+        statistics; frozen-BN fine-tuning takes the library ops)."""
         b, _, c = x.shape
-        if self.training and self.sync_across_ranks and torch.distributed.is_available() \
-                and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            self._pending_batches += 1
-            y = _SyncVertexBN.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum, self.eps)
-            y = torch.relu(y) if relu else y
-            return (residual + y) * scale if residual is not None else y
-        # library ops (same maths) outside the register-resident kernel, and for gradients through an eval()'d block
-        # (frozen-BN fine-tuning): the fused backward is written for batch statistics
         eval_grad = not self.training and torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)
-        if b * c > 4096 or not x.is_cuda or eval_grad:
+        return x.is_cuda and b * c <= self.MAX_VALUES_PER_VERTEX and not eval_grad and not self._synchronised()
+
+    def forward(self, x, relu=False, residual=None, scale=0.5, tap=False):
+        """tap=True returns the result twice: on the HIP kernel two tensor objects over the same memory whose gradients
+        are added inside the backward kernel (give one to each consumer); on the library routes the same tensor twice."""
+        if self._synchronised() or not self.fused_kernel_serves(x):
             if self.training:
                 self._pending_batches += 1      # nn.BatchNorm1d's num_batches_tracked, folded in when the state is saved
-            y = nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
-                                         self.training, self.momentum, self.eps)
+            if self._synchronised():
+                y = _SyncVertexBN.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum, self.eps)
+            else:                               # library ops, same maths
+                y = nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
+                                             self.training, self.momentum, self.eps)
             y = torch.relu(y) if relu else y
-            return (residual + y) * scale if residual is not None else y
+            y = (residual + y) * scale if residual is not None else y
+            return (y, y) if tap else y
         if self.training:
             self._pending_batches += 1
         return _VertexBN.apply(x, self.weight, self.bias, self.running_mean, self.running_var, residual,
-                               self.training, self.momentum, self.eps, relu, scale)
+                               self.training, self.momentum, self.eps, relu, scale, tap)
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         if self._pending_batches:
@@ -171,17 +231,20 @@ class BatchMeshDeformationBlock(nn.Module):
         for i in range(1, 15):                       # bn14 exists in the reference (unused) -- kept for the keys
             setattr(self, "bn%d" % i, VertexBatchNorm(verts))
 
+    def _layer(self, i, x, adj, residual=None, tap=False):
+        """gc_i -> bn_i -> ReLU (-> residual average); tap: see VertexBatchNorm.forward."""
+        return getattr(self, "bn%d" % i)(getattr(self, "gc%d" % i)(x, adj, _identity), relu=True, residual=residual, tap=tap)
+
     def forward(self, features, pooled, adj):
-        full = torch.cat((features, pooled), dim=-1)
-        x = self.bn1(self.gc1(full, adj, _identity), relu=True)
-        feats = self.bn2(self.gc2(x, adj, _identity), relu=True, residual=full[:, :, :self.hidden])
+        full, lead = _InputTap.apply(features, pooled, self.hidden)
+        x = self._layer(1, full, adj)
+        feats, feats_r = self._layer(2, x, adj, residual=lead, tap=True)
         for i in (3, 5, 7, 9, 11):
-            x = getattr(self, "bn%d" % i)(getattr(self, "gc%d" % i)(feats, adj, _identity), relu=True)
-            feats = getattr(self, "bn%d" % (i + 1))(getattr(self, "gc%d" % (i + 1))(x, adj, _identity), relu=True,
-                                                    residual=feats)
-        feats = self.bn13(self.gc13(feats, adj, _identity), relu=True, residual=feats)
+            x = self._layer(i, feats, adj)
+            feats, feats_r = self._layer(i + 1, x, adj, residual=feats_r, tap=True)
+        feats, feats_r = self._layer(13, feats, adj, residual=feats_r, tap=True)
         coords = self.gc15(feats, adj, _identity)
-        return feats, coords
+        return feats_r, coords
 
 
 class MeshEncoder(nn.Module):

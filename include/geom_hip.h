@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GEOM_ABI_VERSION 3
+#define GEOM_ABI_VERSION 4
 
 /* argument errors */
 #define GEOM_EINVAL   (-1) /* bad size / null pointer */
@@ -291,11 +291,14 @@ int geom_vertex_bn_fwd_f32(int b, int nv, int c, const float *x, const float *we
                            float *running_mean, float *running_var, int training, float momentum, float eps,
                            int relu, const float *residual, int residual_ld, float scale,
                            float *out, float *save_mean, float *save_invstd, void *stream);
-/* grad_x, (optional) grad_residual [b,nv,c] = grad_out*scale, grad_weight / grad_bias [nv] (optional). */
+/* grad_x, (optional) grad_residual [b,nv,c] = grad_out*scale, grad_weight / grad_bias [nv] (optional).
+ * grad_out2 (may be NULL): a second upstream gradient of the same output -- in the deformation block every second
+ * BatchNorm output feeds the next layer AND a later residual average (models.py:249-287) -- added to grad_out on the
+ * fly (one fp32 add per element, as autograd's own accumulation would do in a separate pass). */
 int geom_vertex_bn_bwd_f32(int b, int nv, int c, const float *x, const float *grad_out, const float *weight,
                            const float *bias, const float *save_mean, const float *save_invstd, int relu,
                            int has_residual, float scale, float *grad_x, float *grad_residual,
-                           float *grad_weight, float *grad_bias, void *stream);
+                           float *grad_weight, float *grad_bias, const float *grad_out2, void *stream);
 
 /* ---- image-feature pooling (SURVEY 8f "next" row 3; utils.py:316-389 batched_pooling) -----------------
  * out[b,v,:] = concat over `levels` feature maps blocks[l] [b, channels[l], dims[l], dims[l]] (NCHW) of the

@@ -467,6 +467,92 @@ def test_deformation_block_matches_reference_fixture(gpu):
     assert torch.isfinite(e_f).all()
 
 
+@pytest.mark.parametrize("mesh", ["uv_sphere_482", "icosphere_162", "irregular"])
+def test_tapped_layer_output_sums_its_two_gradients_in_the_batchnorm_backward(gpu, mesh):
+    """A BatchNorm output that feeds the next layer AND a later residual average is handed out as two tensor objects over
+    the same memory (`tap`); their two upstream gradients are added inside `geom_vertex_bn_bwd_f32` (grad_out2) instead of
+    by autograd's accumulation pass.  Against the untapped layer given the pre-added gradient: outputs, running
+    statistics and every gradient BIT for bit (one fp32 add either way) -- at the reference's training shape (16 x 482
+    vertices, two 33-entry pole rows -> table + CSR tail in the aggregation), on a pole-free mesh (scalar BN kernel: 48
+    columns x 5 rows), and on an adjacency with irregular degrees (generic aggregation kernel)."""
+    import copy
+    from geometrics_amd import meshgen, models
+    torch.manual_seed(11)
+    if mesh == "irregular":
+        nv, batch, hidden = 40, 3, 24
+        a = (torch.rand(nv, nv) < 0.5).float()
+        a = ((a + a.t()) > 0).float()
+        a.fill_diagonal_(1.0)
+        adj = (a / a.sum(1, keepdim=True)).to(gpu)
+        assert layers.adjacency_csr(adj).ell_w == 0
+    else:
+        V, Fc = meshgen.uv_sphere() if mesh == "uv_sphere_482" else meshgen.icosphere(2)
+        nv, batch, hidden = V.shape[0], (16 if mesh == "uv_sphere_482" else 5), (192 if mesh == "uv_sphere_482" else 48)
+        adj = utils.adj_init(torch.from_numpy(Fc).to(gpu))["adj"]
+        csr = layers.adjacency_csr(adj)
+        assert csr.ell_w == 8 and bool(csr.over) == (mesh == "uv_sphere_482")
+    block = models.BatchMeshDeformationBlock(hidden + 7, nv, hidden=hidden).to(gpu).train()
+    with torch.no_grad():
+        block.bn4.weight.uniform_(0.5, 1.5), block.bn4.bias.uniform_(-0.3, 0.3)
+    twin = copy.deepcopy(block)
+    x = torch.randn(batch, nv, hidden, device=gpu)
+    res = torch.randn(batch, nv, hidden, device=gpu)
+    g_a, g_b = torch.randn_like(x), torch.randn_like(x)
+
+    x1, r1 = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    y, y_again = block._layer(4, x1, adj, residual=r1, tap=True)
+    assert y.data_ptr() == y_again.data_ptr() and y is not y_again and type(y.grad_fn).__name__ == "_VertexBNBackward"
+    ((y * g_a).sum() + (y_again * g_b).sum()).backward()
+
+    x2, r2 = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    z = twin.bn4(twin.gc4(x2, adj, models._identity), relu=True, residual=r2)
+    z.backward(g_a + g_b)
+
+    assert torch.equal(y, z)
+    assert torch.equal(x1.grad, x2.grad) and torch.equal(r1.grad, r2.grad)
+    for (name, p), (_, q) in zip(block.named_parameters(), twin.named_parameters()):
+        if name.startswith(("gc4.", "bn4.")):
+            assert torch.equal(p.grad, q.grad), name
+    assert torch.equal(block.bn4.running_mean, twin.bn4.running_mean) and torch.equal(block.bn4.running_var, twin.bn4.running_var)
+    assert int(block.state_dict()["bn4.num_batches_tracked"]) == 1
+    # only ONE of the two handles used downstream
+    x3 = x.clone().requires_grad_(True)
+    block._layer(3, x3, adj, tap=True)[1].backward(g_a)
+    x4 = x.clone().requires_grad_(True)
+    twin.bn3(twin.gc3(x4, adj, models._identity), relu=True).backward(g_a)
+    assert torch.equal(x3.grad, x4.grad) and torch.equal(block.gc3.bias.grad, twin.gc3.bias.grad)
+    # library route (b*c > 4096 values per vertex): the same tensor twice, autograd adds
+    big = torch.randn(4096 // hidden + 1, nv, hidden, device=gpu, requires_grad=True)
+    o1, o2 = block._layer(5, big, adj, tap=True)
+    assert o1 is o2
+
+
+def test_block_input_tap_equals_cat_and_slice(gpu):
+    """models._InputTap (cat + the leading columns as a contiguous second output, narrow gradient added in place) against
+    torch.cat + a slice: same values, same gradients, for 3 + 1152 columns / 192 hidden and for a feature part WIDER than
+    the hidden width."""
+    from geometrics_amd import models
+    torch.manual_seed(5)
+    for nf, npool, width in ((3, 1152, 192), (40, 30, 24), (3, 21, 24)):
+        f = torch.randn(4, 37, nf, device=gpu)
+        p = torch.randn(4, 37, npool, device=gpu)
+        ga, gb = torch.randn(4, 37, nf + npool, device=gpu), torch.randn(4, 37, width, device=gpu)
+        f1, p1 = f.clone().requires_grad_(True), p.clone().requires_grad_(True)
+        full, lead = models._InputTap.apply(f1, p1, width)
+        assert lead.is_contiguous()
+        ((full * ga).sum() + (lead * gb).sum()).backward()
+        f2, p2 = f.clone().requires_grad_(True), p.clone().requires_grad_(True)
+        full2 = torch.cat((f2, p2), dim=-1)
+        ((full2 * ga).sum() + (full2[..., :width] * gb).sum()).backward()
+        assert torch.equal(full, full2) and torch.equal(lead, full2[..., :width])
+        assert torch.equal(f1.grad, f2.grad) and torch.equal(p1.grad, p2.grad)
+        f3 = f.clone().requires_grad_(True)                   # only the narrow output used, only one input differentiable
+        models._InputTap.apply(f3, p, width)[1].backward(gb)
+        exp = torch.zeros_like(f)
+        exp[..., :min(nf, width)] = gb[..., :min(nf, width)]
+        assert torch.equal(f3.grad, exp)
+
+
 def test_vertex_batchnorm_matches_torch(gpu):
     from geometrics_amd import models
     torch.manual_seed(2)
