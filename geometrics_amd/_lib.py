@@ -18,7 +18,7 @@ FLAG_NN_FMA = 8
 FLAG_TRI_WS_READY = 16
 ABI_VERSION = 4
 EUNSUPPORTED = -3
-ADAM_MAX_TENSORS = 16
+ADAM_MAX_TENSORS = 64
 ADAM_STATE_WORDS = 72
 
 _vp = ctypes.c_void_p

@@ -10,7 +10,7 @@
 // leaf counter w % 64, the last arriver of a leaf arrives at the root, the last arriver of the root writes the new
 // state and re-arms the counters -- at most ceil(N/64) + 64 same-address atomics on any word (~1 us for the bench's
 // 254 workgroups), all off the critical path except the final hop.  `advance` = 0 skips the protocol: that is how an
-// optimiser with more than 16 tensors issues several launches that all use the bias corrections of ONE step (only
+// optimiser with more than 64 tensors issues several launches that all use the bias corrections of ONE step (only
 // the last launch advances).
 // Update rule = torch.optim.Adam (no weight decay, no amsgrad):
 //   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
@@ -47,9 +47,15 @@ __device__ __forceinline__ void adam_update(float &p, float g, float &m, float &
 __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float lr, float b1, float b2, float eps,
                                                    float grad_scale, float *state, int advance)
 {
-    // the tensor this workgroup works on (at most 16 entries: a short uniform scan)
-    int which = 0;
-    while (which + 1 < t.count && (int)blockIdx.x >= t.first_block[which + 1]) ++which;
+    // the tensor this workgroup works on: the last i with first_block[i] <= blockIdx.x (uniform binary search, <= 6 steps;
+    // empty tensors own no workgroup and are skipped by it)
+    int lo = 0, hi = t.count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)blockIdx.x >= t.first_block[mid]) lo = mid;
+        else hi = mid - 1;
+    }
+    const int which = lo;
     const int local = blockIdx.x - t.first_block[which];
 
     const float t_old = state[0];

@@ -1,7 +1,7 @@
-"""Adam for the replicated 0N-GCN parameters on top of geom_adam_step_f32: up to 16 parameter tensors per
+"""Adam for the replicated 0N-GCN parameters on top of geom_adam_step_f32: up to 64 parameter tensors per
 launch, step counter on the device and advanced inside the kernel (HIP-graph replayable, no tick launch).  Same
 update as torch.optim.Adam(lr, betas, eps) without weight decay / amsgrad (what GEOMetrics.py:73 uses).  Any number
-of tensors: they are issued in chunks of 16 that all use the bias corrections of the same step -- only the last
+of tensors: they are issued in chunks of 64 that all use the bias corrections of the same step -- only the last
 chunk advances the state."""
 import ctypes
 

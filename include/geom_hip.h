@@ -398,7 +398,7 @@ int geom_segment_max_bwd_f32(int nseg, const int64_t *offsets, int64_t total_row
  * captured HIP graph replays the correct correction, with no separate tick launch).  An optimiser holding
  * more than GEOM_ADAM_MAX_TENSORS tensors issues several calls on one stream for one step: advance = 0 on
  * all but the last. */
-#define GEOM_ADAM_MAX_TENSORS 16
+#define GEOM_ADAM_MAX_TENSORS 64
 #define GEOM_ADAM_STATE_WORDS 72
 int geom_adam_step_f32(int count, float *const *params, const float *const *grads, float *const *exp_avg,
                        float *const *exp_avg_sq, const int64_t *sizes, float lr, float beta1, float beta2,

@@ -198,7 +198,7 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.geom_surface_order_words(2, 10, 5, 7) == ((2 * 11 + 3 * 2 * 12 + 3) // 4 * 4) + 2 * 12 * 8
     assert L.geom_surface_gather_f32(1, 4, 8, None, None, 4, 4, 1, None, None, None, None) == -1
     assert L.geom_surface_gather_f32(0, 4, 8, None, None, 4, 4, 1, None, None, None, None) == 0
-    assert L.geom_adam_step_f32(17, None, None, None, None, None, 1e-3, .9, .999, 1e-8, 1.0, None, 1, None) == -2   # > 16 tensors per launch
+    assert L.geom_adam_step_f32(_lib.ADAM_MAX_TENSORS + 1, None, None, None, None, None, 1e-3, .9, .999, 1e-8, 1.0, None, 1, None) == -2   # > 64 tensors per launch
     assert L.geom_adam_step_f32(1, None, None, None, None, None, 1e-3, .9, .999, 1e-8, 1.0, None, 1, None) == -1
     assert L.geom_adam_step_f32(0, None, None, None, None, None, 1e-3, .9, .999, 1e-8, 1.0, None, 1, None) == 0
     assert L.geom_chamfer_nn_f32(1, 4, p, 4, p, p, p, p, p, _lib.FLAG_NN_FMA | _lib.FLAG_REF_TAIL_TRUNC, None) == -1

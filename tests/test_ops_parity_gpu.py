@@ -321,13 +321,13 @@ def test_fused_adam_matches_torch_adam(gpu):
 
 
 def test_fused_adam_many_tensors_and_graph_replay(gpu):
-    """More than 16 tensors (a deformation block has 56, GEOMetrics.py:73 hands Adam hundreds): chunks of 16 share the
+    """More than 64 tensors (a deformation block has 56, GEOMetrics.py:73 hands Adam hundreds): chunks of 64 share the
     bias corrections of ONE step (only the last chunk advances the device-side state), odd sizes take the scalar tail,
     and a captured step replays with the state advancing on the device."""
-    from geometrics_amd import optim
+    from geometrics_amd import _lib, optim
     torch.manual_seed(6)
-    shapes = [(1, 1155, 192), (192,)] + [(192, 192), (192,)] * 12 + [(192, 3), (3,)] + [(7, 5), (1,), (1023,), (1025,)] * 3
-    assert len(shapes) > 32
+    shapes = [(1, 1155, 192), (192,)] + [(192, 192), (192,)] * 12 + [(192, 3), (3,)] + [(7, 5), (1,), (1023,), (1025,)] * 10
+    assert len(shapes) > _lib.ADAM_MAX_TENSORS
     ours = [torch.randn(*s, device=gpu).requires_grad_(True) for s in shapes]
     ref = [p.detach().clone().requires_grad_(True) for p in ours]
     opt = optim.FusedAdam(ours, lr=1e-3)
