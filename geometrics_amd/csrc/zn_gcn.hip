@@ -205,6 +205,37 @@ __global__ __launch_bounds__(CS_COLS *CS_LANES) void colsum_final_kernel(int blo
     }
 }
 
+// The same reduction for several pending bias gradients in ONE launch (blockIdx.y = job): a backward pass through N
+// layers leaves N sets of partials, and N separate 4.7 us launches are 5 % of the reference's training-shape step.
+struct ColsumJobs {
+    const float *partial[GEOM_COLSUM_MAX_JOBS];
+    float *out[GEOM_COLSUM_MAX_JOBS];
+    int blocks[GEOM_COLSUM_MAX_JOBS], c[GEOM_COLSUM_MAX_JOBS];
+};
+
+__global__ __launch_bounds__(CS_COLS *CS_LANES) void colsum_batch_kernel(ColsumJobs jobs)
+{
+    __shared__ float part[CS_LANES][CS_COLS];
+    const int job = blockIdx.y;
+    const int blocks = jobs.blocks[job], c = jobs.c[job];
+    if ((int)blockIdx.x * CS_COLS >= c) return; // a job narrower than the widest one
+    const float *partial = jobs.partial[job];
+    const int cl = threadIdx.x % CS_COLS, lane = threadIdx.x / CS_COLS;
+    const int col = blockIdx.x * CS_COLS + cl;
+    float t = 0.f;
+    if (col < c) {
+#pragma unroll 8
+        for (int b = lane; b < blocks; b += CS_LANES) t += partial[(size_t)b * c + col];
+    }
+    part[lane][cl] = t;
+    __syncthreads();
+    if (lane == 0 && col < c) {
+        float acc = 0.f;
+        for (int l = 0; l < CS_LANES; ++l) acc += part[l][cl];
+        jobs.out[job][col] = acc;
+    }
+}
+
 struct GcnGeometry {
     int groups, rows_in_flight, rows_per_block;
     int chunks;     // blocks per mesh (grid.x)
@@ -240,7 +271,7 @@ int launch(const GcnArgs &a, int act, float *colsum_partial, float *grad_bias, v
     case ACT_ELU: hipLaunchKernelGGL((zn_aggregate_kernel<VEC, ACT_ELU, BACKWARD>), grid, block, lds, s, a, geo.groups, geo.rows_in_flight, geo.rows_per_block, colsum_partial); break;
     default: return GEOM_EINVAL;
     }
-    if (BACKWARD && colsum_partial)
+    if (BACKWARD && colsum_partial && grad_bias) // grad_bias == null: partials only (geom_colsum_batch_f32 finishes them)
         hipLaunchKernelGGL(colsum_final_kernel, dim3((a.c + CS_COLS - 1) / CS_COLS), dim3(CS_COLS * CS_LANES), 0, s,
                            (int)geo.blocks, a.c, colsum_partial, grad_bias);
     return geom::launch_status();
@@ -513,7 +544,7 @@ int dispatch_ell(EllArgs a, int b, int w, int act, float *grad_bias, float *scra
     // one row per thread keeps the most loads in flight; backward incl. the bias reduction 14.6 / 12.8 / 13.7 / 14.8)
     const int iters = BACKWARD ? 2 : 1;
     const int chunks = (a.nv + rpb * iters - 1) / (rpb * iters);
-    float *partial = grad_bias ? scratch : nullptr;
+    float *partial = scratch; // with grad_bias == null the partials stay un-reduced (geom_colsum_batch_f32 finishes them)
     const size_t lds = (BACKWARD && partial) ? (size_t)rpb * a.c * sizeof(float) : 0;
     a.b = b;
     a.chunks = chunks;
@@ -525,7 +556,7 @@ int dispatch_ell(EllArgs a, int b, int w, int act, float *grad_bias, float *scra
     case ACT_ELU: launch_ell_shape<ACT_ELU, BACKWARD>(a, w, grid, lds, s, rpb, iters, partial); break;
     default: return GEOM_EINVAL;
     }
-    if (BACKWARD && partial)
+    if (BACKWARD && partial && grad_bias)
         hipLaunchKernelGGL(colsum_final_kernel, dim3((a.c + CS_COLS - 1) / CS_COLS), dim3(CS_COLS * CS_LANES), 0, s,
                            chunks * b, a.c, partial, grad_bias);
     return geom::launch_status();
@@ -543,7 +574,7 @@ int dispatch(GcnArgs a, int b, int act, float *grad_bias, float *scratch, void *
     if (gcn_vec4(a.c, a.k) && (((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.saved) % 16 != 0))
         return GEOM_EINVAL; // row-major fp32 tensors from any allocator are 16-byte aligned; refuse odd views
     const bool vec4 = gcn_vec4(a.c, a.k);
-    float *partial = grad_bias ? scratch : nullptr;
+    float *partial = scratch;
     if (!vec4 && a.c > GCN_THREADS) return GEOM_ETOOBIG;
     return vec4 ? launch<4, BACKWARD>(a, act, partial, grad_bias, stream) : launch<1, BACKWARD>(a, act, partial, grad_bias, stream);
 }
@@ -565,6 +596,37 @@ extern "C" int64_t geom_zn_gcn_bwd_scratch_floats(int b, int nv, int c)
     const int64_t b4 = (c % 4 == 0) ? gcn_geometry(b, nv, c, 4, true).blocks : 0;
     const int64_t b1 = gcn_geometry(b, nv, c, 1, true).blocks;
     return (b4 > b1 ? b4 : b1) * c;
+}
+
+// Rows of per-workgroup partial column sums the backward launches write into `scratch` for this shape: ell_w = the table
+// width of the geom_zn_gcn_aggregate_ell_bwd_f32 call (8 / 16), 0 = geom_zn_gcn_aggregate_bwd_f32.  0: unsupported shape.
+extern "C" int64_t geom_zn_gcn_bwd_partial_rows(int b, int nv, int c, int k, int ell_w)
+{
+    if (b <= 0 || nv <= 0 || c <= 0 || k < 0 || k > c) return 0;
+    if (ell_w) {
+        if (!ell_supported(c, k, ell_w)) return 0;
+        const int per = ell_rows_per_block(k) * 2; // two row tiles per workgroup in the backward
+        return (int64_t)((nv + per - 1) / per) * b;
+    }
+    return gcn_geometry(b, nv, c, gcn_vec4(c, k) ? 4 : 1, true).blocks;
+}
+
+extern "C" int geom_colsum_batch_f32(int count, const float *const *partials, const int *rows, const int *cols,
+                                     float *const *outs, void *stream)
+{
+    if (count < 0 || count > GEOM_COLSUM_MAX_JOBS) return GEOM_ETOOBIG;
+    if (count == 0) return 0;
+    if (!partials || !rows || !cols || !outs) return GEOM_EINVAL;
+    ColsumJobs jobs;
+    int widest = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!partials[i] || !outs[i] || rows[i] < 0 || cols[i] <= 0) return GEOM_EINVAL;
+        jobs.partial[i] = partials[i], jobs.out[i] = outs[i], jobs.blocks[i] = rows[i], jobs.c[i] = cols[i];
+        widest = cols[i] > widest ? cols[i] : widest;
+    }
+    hipLaunchKernelGGL(colsum_batch_kernel, dim3((widest + CS_COLS - 1) / CS_COLS, count), dim3(CS_COLS * CS_LANES), 0,
+                       static_cast<hipStream_t>(stream), jobs);
+    return geom::launch_status();
 }
 
 extern "C" int geom_zn_gcn_aggregate_bwd_f32(int b, int nv, int c, int k, const int *rowptrT, const int *colT,

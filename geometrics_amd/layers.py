@@ -8,6 +8,7 @@ the tensor's identity + version) and replaces the reference's dense `adj @ suppo
 `torch.cat` and bias add by one fused HIP kernel (csrc/zn_gcn.hip); the dense feature GEMM
 `input @ W` stays a library GEMM (rocBLAS/hipBLASLt through torch.matmul).
 """
+import ctypes
 import math
 import weakref
 
@@ -162,31 +163,93 @@ def aggregate_forward(s, bias_c, csr, k, act, out, want_mask=False):
     return mask
 
 
-def aggregate_backward(g, csr, k, act, out, mask, want_bias):
+# ---- bias gradients of a whole backward pass finished in ONE launch -----------------------------------------------
+# The aggregation backward leaves per-workgroup partial column sums; reducing them is a launch-floor kernel (4.7 us) per
+# layer -- 14 of them in a deformation block.  Inside an autograd backward pass the reduction is postponed instead: the
+# partials are queued, and a callback at the END of the pass (the engine's queue_callback, what DDP uses for its own
+# finalisation) reduces all of them with one geom_colsum_batch_f32 launch on the stream they were produced on.  The
+# bias gradient handed to autograd is therefore complete when backward() returns, but not while the pass is running;
+# a pass in which something could read it earlier -- an existing .grad to accumulate into, a hook on the bias -- takes
+# the immediate reduction, and so does every call outside an engine-run pass.
+defer_bias_gradients = True
+_pending_colsums = {}     # autograd graph-task id -> [(partials, rows, cols, out alias, stream)]
+
+
+def _alias(t):
+    """A second tensor object over t's memory (no view relation): keeps the storage alive without being a reference to
+    the tensor itself, so that autograd still finds the gradient unshared and stores it instead of cloning it."""
+    return torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage(), t.storage_offset(), t.size(), t.stride())
+
+
+def _may_defer(bias):
+    if not defer_bias_gradients or bias is None or not hasattr(torch._C, "_current_graph_task_id"):
+        return False
+    if torch._C._current_graph_task_id() < 0 or torch.is_grad_enabled():      # not an engine pass / double backward
+        return False
+    return (bias.grad is None and not bias._backward_hooks and not getattr(bias, "_post_accumulate_grad_hooks", None)
+            and bias.is_leaf)
+
+
+def _flush_colsums(task):
+    jobs = _pending_colsums.pop(task, [])
+    by_stream = {}
+    for job in jobs:
+        by_stream.setdefault(job[4], []).append(job)
+    for stream, group in by_stream.items():
+        with torch.cuda.device(stream.device):
+            for c0 in range(0, len(group), _lib.COLSUM_MAX_JOBS):
+                chunk = group[c0:c0 + _lib.COLSUM_MAX_JOBS]
+                n = len(chunk)
+                _lib.check(_lib.lib().geom_colsum_batch_f32(
+                    n, (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in chunk]), (ctypes.c_int * n)(*[j[1] for j in chunk]),
+                    (ctypes.c_int * n)(*[j[2] for j in chunk]), (ctypes.c_void_p * n)(*[j[3].data_ptr() for j in chunk]),
+                    stream.cuda_stream), "geom_colsum_batch_f32")
+
+
+def _queue_colsum(partials, rows, cols, out):
+    task = torch._C._current_graph_task_id()
+    jobs = _pending_colsums.get(task)
+    if jobs is None:
+        for stale in [t for t in _pending_colsums if t < task - 64]:      # passes that died of an exception
+            del _pending_colsums[stale]
+        jobs = _pending_colsums[task] = []
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_colsums(task))
+    jobs.append((partials, rows, cols, _alias(out), torch.cuda.current_stream(out.device)))
+
+
+def aggregate_backward(g, csr, k, act, out, mask, want_bias, bias=None):
     """grad_support = [A^T . g'[..., :k] | g'[..., k:]] with g' = g * act'(out) (relu' from the sign mask when there is
-    one), and the bias gradient = column sums of g' out of the same launch (+ a fixed-order reduction)."""
+    one), and the bias gradient = column sums of g' out of the same launch (+ a fixed-order reduction: at once, or -- given
+    the bias parameter, inside a backward pass -- batched at the end of the pass, see above)."""
     b, nv, c = g.shape
     grad_support = torch.empty_like(g)
     grad_bias = scratch = None
+    defer = False
     if want_bias:   # column sums of g come out of the same kernel (per-block partials + fixed-order reduce)
         grad_bias = torch.empty(c, dtype=torch.float32, device=g.device)
         scratch = torch.empty(_lib.lib().geom_zn_gcn_bwd_scratch_floats(b, nv, c), dtype=torch.float32,
                               device=g.device)
+        defer = _may_defer(bias)
+    now = None if defer else grad_bias
     with torch.cuda.device(g.device):
         code = _lib.EUNSUPPORTED
-        if csr.ell_w:
+        ell_w = csr.ell_w
+        if ell_w:
             over = csr.over_t or (None, None, None)
             code = _lib.lib().geom_zn_gcn_aggregate_ell_bwd_f32(
-                b, nv, c, k, csr.ell_w, csr.ell_col_t.data_ptr(), csr.ell_val_t.data_ptr(), _lib.ptr(over[0]),
+                b, nv, c, k, ell_w, csr.ell_col_t.data_ptr(), csr.ell_val_t.data_ptr(), _lib.ptr(over[0]),
                 _lib.ptr(over[1]), _lib.ptr(over[2]), g.data_ptr(),
-                _lib.ptr(out), _lib.ptr(mask), act, grad_support.data_ptr(), _lib.ptr(grad_bias), _lib.ptr(scratch),
+                _lib.ptr(out), _lib.ptr(mask), act, grad_support.data_ptr(), _lib.ptr(now), _lib.ptr(scratch),
                 _lib.stream_ptr())
         if code == _lib.EUNSUPPORTED:
+            ell_w = 0
             _lib.call("geom_zn_gcn_aggregate_bwd_f32", b, nv, c, k, csr.rowptr_t.data_ptr(),
                       csr.col_t.data_ptr(), csr.val_t.data_ptr(), g.data_ptr(), _lib.ptr(out), act,
-                      grad_support.data_ptr(), _lib.ptr(grad_bias), _lib.ptr(scratch))
+                      grad_support.data_ptr(), _lib.ptr(now), _lib.ptr(scratch))
         else:
             _lib.check(code, "geom_zn_gcn_aggregate_ell_bwd_f32")
+    if defer:
+        _queue_colsum(scratch, int(_lib.lib().geom_zn_gcn_bwd_partial_rows(b, nv, c, k, ell_w)), c, grad_bias)
     return grad_support, grad_bias
 
 
@@ -203,6 +266,7 @@ class _ZeroNAggregate(torch.autograd.Function):
         out = torch.empty_like(s)
         mask = aggregate_forward(s, bias_c, csr, k, act, out, want_mask=support.requires_grad)
         ctx.csr, ctx.k, ctx.act, ctx.has_bias = csr, k, act, bias is not None
+        ctx.bias_ref = None if bias is None else weakref.ref(bias)
         ctx.masked = mask is not None
         if mask is not None:
             ctx.save_for_backward(mask)
@@ -217,7 +281,8 @@ class _ZeroNAggregate(torch.autograd.Function):
         mask = ctx.saved_tensors[0] if ctx.masked else None
         out = ctx.saved_tensors[0] if (act != _ACT_NONE and not ctx.masked) else None
         grad_support, grad_bias = aggregate_backward(g, ctx.csr, ctx.k, act, out, mask,
-                                                     ctx.has_bias and ctx.needs_input_grad[1])
+                                                     ctx.has_bias and ctx.needs_input_grad[1],
+                                                     ctx.bias_ref() if ctx.bias_ref is not None else None)
         return (grad_support if ctx.needs_input_grad[0] else None), grad_bias, None, None, None
 
 

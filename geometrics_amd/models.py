@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
-from .layers import Batch_Image_ZERON_GCNGCN, GCNMax, ZERON_GCN
+from .layers import Batch_Image_ZERON_GCNGCN, GCNMax, ZERON_GCN, _alias
 
 
 def _identity(x):
@@ -82,11 +82,6 @@ def _residual_operand(residual, like):
     if not ok:
         res = res.contiguous()
     return res, res.stride(1)
-
-
-def _alias(t):
-    """A second tensor object over t's memory (no view relation, no copy): the other handle of a tapped output."""
-    return torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage(), t.storage_offset(), t.size(), t.stride())
 
 
 class _InputTap(torch.autograd.Function):

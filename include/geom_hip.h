@@ -229,8 +229,19 @@ int geom_zn_gcn_aggregate_fwd_f32(int b, int nv, int c, int k, const int *rowptr
 /* grad_support[r,:k] = sum over CSR^T row r of valT*g[colT,:k]; grad_support[r,k:] = g[r,k:], where
  * g = grad_out * act'(out) when act != 0 (out = the saved forward output, may be NULL when act == 0).
  * grad_bias[c] (optional) = column sums of g, reduced in a fixed order (bit-reproducible); it needs
- * `scratch` of at least geom_zn_gcn_bwd_scratch_floats(b, nv, c) floats. */
+ * `scratch` of at least geom_zn_gcn_bwd_scratch_floats(b, nv, c) floats.
+ * scratch != NULL with grad_bias == NULL: the launch leaves its per-workgroup partial column sums in scratch --
+ * geom_zn_gcn_bwd_partial_rows(...) rows of c floats -- and the caller finishes them later with geom_colsum_batch_f32
+ * (same fixed-order reduction, same bits), ONE launch for the pending bias gradients of a whole backward pass
+ * instead of one per layer. */
 int64_t geom_zn_gcn_bwd_scratch_floats(int b, int nv, int c);
+/* ell_w = the table width passed to geom_zn_gcn_aggregate_ell_bwd_f32 (8 / 16); 0 = geom_zn_gcn_aggregate_bwd_f32. */
+int64_t geom_zn_gcn_bwd_partial_rows(int b, int nv, int c, int k, int ell_w);
+/* outs[i][0..cols[i]) = column sums of partials[i] (rows[i] x cols[i], row-major), i < count <= GEOM_COLSUM_MAX_JOBS;
+ * the pointer / size arrays are HOST arrays. */
+#define GEOM_COLSUM_MAX_JOBS 32
+int geom_colsum_batch_f32(int count, const float *const *partials, const int *rows, const int *cols,
+                          float *const *outs, void *stream);
 int geom_zn_gcn_aggregate_bwd_f32(int b, int nv, int c, int k, const int *rowptrT, const int *colT,
                                   const float *valT, const float *grad_out, const float *out,
                                   int act, float *grad_support, float *grad_bias, float *scratch,

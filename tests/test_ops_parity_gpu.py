@@ -527,6 +527,89 @@ def test_tapped_layer_output_sums_its_two_gradients_in_the_batchnorm_backward(gp
     assert o1 is o2
 
 
+def test_bias_gradients_of_a_backward_pass_are_finished_in_one_batched_launch(gpu):
+    """Inside an autograd pass the per-layer bias-gradient reductions are queued and finished by ONE
+    geom_colsum_batch_f32 launch at the end of the pass (layers.defer_bias_gradients): same bits as the immediate
+    reduction, complete when backward() returns, nothing left pending; a bias with an existing .grad (accumulation) or a
+    hook takes the immediate path; torch.autograd.grad sees finished values; and a captured pass replays."""
+    from geometrics_amd import meshgen
+    torch.manual_seed(21)
+    V, Fc = meshgen.uv_sphere()
+    adj = utils.adj_init(torch.from_numpy(Fc).to(gpu))["adj"]
+    stack = [layers.Batch_Image_ZERON_GCNGCN(40, 48), layers.Batch_Image_ZERON_GCNGCN(48, 48), layers.BatchZERON_GCN(48, 40)]
+    stack = torch.nn.ModuleList(stack).to(gpu)
+    x = torch.randn(5, V.shape[0], 40, device=gpu)
+    g_out = torch.randn(5, V.shape[0], 40, device=gpu)
+
+    def run(defer, prepare=None):
+        layers.defer_bias_gradients = defer
+        try:
+            for p in stack.parameters():
+                p.grad = None
+            if prepare:
+                prepare()
+            h = x
+            for i, layer in enumerate(stack):
+                h = layer(h, adj, F.relu if i < 2 else None)
+            h.backward(g_out)
+            assert not layers._pending_colsums
+            return [layer.bias.grad.clone() for layer in stack], [layer._weight().grad.clone() for layer in stack]
+        finally:
+            layers.defer_bias_gradients = True
+
+    now_b, now_w = run(False)
+    later_b, later_w = run(True)
+    for a, b in zip(now_b + now_w, later_b + later_w):
+        assert torch.equal(a, b)
+    close(later_b[2].cpu().numpy(), g_out.sum((0, 1)).cpu().numpy(), 1e-4)       # last layer, no activation: plain column sums
+
+    def existing_grads():                                  # accumulation into an existing .grad reads the gradient at once
+        for layer in stack:
+            layer.bias.grad = torch.ones_like(layer.bias)
+    acc_b, _ = run(True, existing_grads)
+    for a, b in zip(acc_b, now_b):
+        assert torch.equal(a, b + 1.0)
+    seen = []
+    hook = stack[1].bias.register_hook(lambda gr: seen.append(gr.clone()))       # a hook reads it inside the pass
+    hook_b, _ = run(True)
+    hook.remove()
+    assert torch.equal(seen[0], now_b[1]) and all(torch.equal(a, b) for a, b in zip(hook_b, now_b))
+    # torch.autograd.grad: captured gradients are finished when the call returns
+    h = x
+    for i, layer in enumerate(stack):
+        h = layer(h, adj, F.relu if i < 2 else None)
+    got = torch.autograd.grad(h, [layer.bias for layer in stack], g_out)
+    assert all(torch.equal(a, b) for a, b in zip(got, now_b)) and not layers._pending_colsums
+    # HIP-graph capture of forward + backward: the batched launch is part of the graph
+    for p in stack.parameters():
+        p.grad = None
+    static_x = x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            for p in stack.parameters():
+                p.grad = None
+            h = static_x
+            for i, layer in enumerate(stack):
+                h = layer(h, adj, F.relu if i < 2 else None)
+            h.backward(g_out)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    for p in stack.parameters():
+        p.grad = None
+    with torch.cuda.graph(graph):
+        h = static_x
+        for i, layer in enumerate(stack):
+            h = layer(h, adj, F.relu if i < 2 else None)
+        h.backward(g_out)
+    static_x.mul_(2.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    close(stack[2].bias.grad.cpu().numpy(), g_out.sum((0, 1)).cpu().numpy(), 1e-4)
+    assert not torch.equal(stack[0].bias.grad, now_b[0]) and torch.isfinite(stack[0].bias.grad).all()
+
+
 def test_block_input_tap_equals_cat_and_slice(gpu):
     """models._InputTap (cat + the leading columns as a contiguous second output, narrow gradient added in place) against
     torch.cat + a slice: same values, same gradients, for 3 + 1152 columns / 192 hidden and for a feature part WIDER than
