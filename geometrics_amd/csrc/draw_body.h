@@ -43,6 +43,14 @@ __device__ __forceinline__ void draw_samples_body(int chunk, int mesh, unsigned 
     __shared__ float cdf[DRAW_MAX_FACES];
     __shared__ float wave_total[DRAW_THREADS / GEOM_WAVE];
     const float *V = verts + (size_t)mesh * nv * 3;
+    // the random stream's state is requested first: read after the CDF it would add a dependent round trip to a launch
+    // that is a chain of them (face ids -> corners -> scan -> search -> face ids -> corners -> store)
+    unsigned long long seed = 0ull, pos = 0ull, mesh0 = 0ull;
+    if (rng_state) {
+        seed = rng_state[0];
+        pos = rng_state[1];
+        mesh0 = rng_state[3];
+    }
     const int per = (nf + DRAW_THREADS - 1) / DRAW_THREADS; // consecutive faces per thread
     const int f0 = threadIdx.x * per;
     float run = 0.f;
@@ -74,11 +82,7 @@ __device__ __forceinline__ void draw_samples_body(int chunk, int mesh, unsigned 
     const float total = cdf[nf - 1];
 
     const int i = chunk * DRAW_THREADS + threadIdx.x;
-    unsigned long long seed = 0ull, pos = 0ull, mesh0 = 0ull;
     if (rng_state) {
-        seed = rng_state[0];
-        pos = rng_state[1];
-        mesh0 = rng_state[3];
         __syncthreads(); // every thread of this workgroup holds the position before the workgroup reports in
         if (threadIdx.x == 0) {
             if (atomicAdd(&rng_state[2], 1ull) == groups - 1ull) { // last one in: nobody reads the old position any more
