@@ -9,7 +9,7 @@ kernel (csrc/zn_gcn.hip) -> one per-vertex BN + ReLU (+ residual average) kernel
 A BatchNorm output that feeds the next layer AND a later residual average is handed out as two tensor objects over
 the same memory (`tap`), so that its two upstream gradients meet inside the BN backward kernel instead of in a separate
 accumulation pass; the block input's leading columns (the first residual) are tapped the same way (`_InputTap`).
-(Measured and rejected: aggregation + BatchNorm in ONE launch -- DESIGN section 9.)
+(Measured and rejected: aggregation + BatchNorm in ONE launch -- DESIGN section 4.)
 Data-parallel note: under torch.distributed with more than one rank the BatchNorm statistics are those of the GLOBAL
 batch (per-vertex sums all-reduced, `_SyncVertexBN`), i.e. N shards normalise exactly as the single-GPU reference does
 over its whole batch; `VertexBatchNorm.sync_across_ranks = False` restores local-shard statistics on the fused kernel.
