@@ -169,10 +169,28 @@ def aggregate_forward(s, bias_c, csr, k, act, out, want_mask=False):
 # partials are queued, and a callback at the END of the pass (the engine's queue_callback, what DDP uses for its own
 # finalisation) reduces all of them with one geom_colsum_batch_f32 launch on the stream they were produced on.  The
 # bias gradient handed to autograd is therefore complete when backward() returns, but not while the pass is running;
-# a pass in which something could read it earlier -- an existing .grad to accumulate into, a hook on the bias -- takes
-# the immediate reduction, and so does every call outside an engine-run pass.
+# a pass in which something could read it earlier -- an existing .grad to accumulate into, a hook on the bias, a bias that
+# receives gradients from more than one node (the engine adds them on arrival) -- takes the immediate reduction, and so
+# does every call outside an engine-run pass.
 defer_bias_gradients = True
 _pending_colsums = {}     # autograd graph-task id -> [(partials, rows, cols, out alias, stream)]
+# bias parameter -> the live autograd nodes that produce a gradient for it.  A bias shared by two layers (or a layer applied
+# twice) gets its gradients ADDED by the engine inside the pass, which reads them on arrival: more than one live node means
+# immediate reduction for all of them.  Nodes leave the set when their graph is freed.
+_bias_users = {}          # id(bias) -> (weak reference to the bias, WeakSet of nodes); keyed by identity, tensors do not compare
+
+
+def _register_bias_user(bias, node):
+    key = id(bias)
+    entry = _bias_users.get(key)
+    if entry is None or entry[0]() is not bias:
+        entry = _bias_users[key] = (weakref.ref(bias, lambda _ref, k=key: _bias_users.pop(k, None)), weakref.WeakSet())
+    entry[1].add(node)
+
+
+def _bias_user_count(bias):
+    entry = _bias_users.get(id(bias))
+    return len(entry[1]) if entry is not None and entry[0]() is bias else 0
 
 
 def _alias(t):
@@ -185,6 +203,8 @@ def _may_defer(bias):
     if not defer_bias_gradients or bias is None or not hasattr(torch._C, "_current_graph_task_id"):
         return False
     if torch._C._current_graph_task_id() < 0 or torch.is_grad_enabled():      # not an engine pass / double backward
+        return False
+    if _bias_user_count(bias) > 1:      # another node of a live graph feeds the same parameter
         return False
     return (bias.grad is None and not bias._backward_hooks and not getattr(bias, "_post_accumulate_grad_hooks", None)
             and bias.is_leaf)
@@ -267,6 +287,8 @@ class _ZeroNAggregate(torch.autograd.Function):
         mask = aggregate_forward(s, bias_c, csr, k, act, out, want_mask=support.requires_grad)
         ctx.csr, ctx.k, ctx.act, ctx.has_bias = csr, k, act, bias is not None
         ctx.bias_ref = None if bias is None else weakref.ref(bias)
+        if bias is not None and ctx.needs_input_grad[1]:
+            _register_bias_user(bias, ctx)
         ctx.masked = mask is not None
         if mask is not None:
             ctx.save_for_backward(mask)

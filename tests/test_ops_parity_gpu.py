@@ -574,6 +574,23 @@ def test_bias_gradients_of_a_backward_pass_are_finished_in_one_batched_launch(gp
     hook_b, _ = run(True)
     hook.remove()
     assert torch.equal(seen[0], now_b[1]) and all(torch.equal(a, b) for a, b in zip(hook_b, now_b))
+    # a bias shared by two layers: the engine adds the two gradients inside the pass, so neither may be postponed
+    tied = layers.Batch_Image_ZERON_GCNGCN(48, 48).to(gpu)
+    tied.bias = stack[1].bias
+    def tied_pass(defer):
+        layers.defer_bias_gradients = defer
+        try:
+            for p_ in list(stack.parameters()) + [tied.weight1]:
+                p_.grad = None
+            h = stack[0](x, adj, F.relu)
+            h = tied(stack[1](h, adj, F.relu), adj, F.relu)
+            stack[2](h, adj, None).backward(g_out)
+            assert not layers._pending_colsums
+            return stack[1].bias.grad.clone()
+        finally:
+            layers.defer_bias_gradients = True
+    assert torch.equal(tied_pass(False), tied_pass(True))
+    del tied
     # torch.autograd.grad: captured gradients are finished when the call returns
     h = x
     for i, layer in enumerate(stack):
