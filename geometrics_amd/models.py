@@ -19,6 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
+from . import layers as _layers
 from .layers import Batch_Image_ZERON_GCNGCN, GCNMax, ZERON_GCN, _alias
 
 
@@ -33,7 +34,7 @@ class _VertexBN(torch.autograd.Function):
         b, nv, c = xc.shape
         dev = xc.device
         res, res_ld = _residual_operand(residual, xc)   # a column slice of a wider row-major tensor is read in place
-        out = torch.empty_like(xc)
+        out = _layers._new_like(xc, "normalised", _layers._slabs)   # a slot of the pass's stacked buffers when batching is on
         mean = torch.empty(nv, dtype=torch.float32, device=dev)
         invstd = torch.empty(nv, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
@@ -231,14 +232,15 @@ class BatchMeshDeformationBlock(nn.Module):
         return getattr(self, "bn%d" % i)(getattr(self, "gc%d" % i)(x, adj, _identity), relu=True, residual=residual, tap=tap)
 
     def forward(self, features, pooled, adj):
-        full, lead = _InputTap.apply(features, pooled, self.hidden)
-        x = self._layer(1, full, adj)
-        feats, feats_r = self._layer(2, x, adj, residual=lead, tap=True)
-        for i in (3, 5, 7, 9, 11):
-            x = self._layer(i, feats, adj)
-            feats, feats_r = self._layer(i + 1, x, adj, residual=feats_r, tap=True)
-        feats, feats_r = self._layer(13, feats, adj, residual=feats_r, tap=True)
-        coords = self.gc15(feats, adj, _identity)
+        with _layers.weight_gradient_batching(depth=14):   # the twelve equal hidden layers: one batched weight-gradient product
+            full, lead = _InputTap.apply(features, pooled, self.hidden)
+            x = self._layer(1, full, adj)
+            feats, feats_r = self._layer(2, x, adj, residual=lead, tap=True)
+            for i in (3, 5, 7, 9, 11):
+                x = self._layer(i, feats, adj)
+                feats, feats_r = self._layer(i + 1, x, adj, residual=feats_r, tap=True)
+            feats, feats_r = self._layer(13, feats, adj, residual=feats_r, tap=True)
+            coords = self.gc15(feats, adj, _identity)
         return feats_r, coords
 
 

@@ -627,6 +627,74 @@ def test_bias_gradients_of_a_backward_pass_are_finished_in_one_batched_launch(gp
     assert not torch.equal(stack[0].bias.grad, now_b[0]) and torch.isfinite(stack[0].bias.grad).all()
 
 
+def test_weight_gradients_of_equal_layers_come_from_one_batched_product(gpu):
+    """Inside layers.weight_gradient_batching() the weight gradients of a stack are postponed to the end of the backward
+    pass and runs of equal layers are issued as ONE strided-batched product over stacked activation / gradient buffers:
+    same values as the per-layer products up to the library kernel's summation order, every other gradient and the
+    outputs bit-identical; the operands of the run really sit at a regular pitch; an existing .grad (accumulation) takes
+    the immediate product; the deformation block uses it by itself."""
+    from geometrics_amd import meshgen, models
+    torch.manual_seed(31)
+    V, Fc = meshgen.uv_sphere()
+    adj = utils.adj_init(torch.from_numpy(Fc).to(gpu))["adj"]
+    widths = ((40, 48), (48, 48), (48, 48), (48, 48), (48, 40))
+    stack = torch.nn.ModuleList([layers.Batch_Image_ZERON_GCNGCN(i, o) for i, o in widths]).to(gpu)
+    x = torch.randn(6, V.shape[0], 40, device=gpu, requires_grad=True)
+    g_out = torch.randn(6, V.shape[0], 40, device=gpu)
+
+    def run(batched, prepare=None):
+        for p in stack.parameters():
+            p.grad = None
+        x.grad = None
+        if prepare:
+            prepare()
+        ctxm = layers.weight_gradient_batching() if batched else contextlib.nullcontext()
+        with ctxm:
+            h = x
+            for i, layer in enumerate(stack):
+                h = layer(h, adj, F.relu if i < 4 else None)
+        h.backward(g_out)
+        assert not layers._pending_dense and not layers._pending_colsums
+        return (h.detach().clone(), x.grad.clone(), [l.weight1.grad.clone() for l in stack], [l.bias.grad.clone() for l in stack])
+
+    import contextlib
+    seen = []
+    real_bmm = torch.bmm
+    def spy(a, b, out=None):
+        seen.append((tuple(a.shape), tuple(a.stride()), tuple(b.stride())))
+        return real_bmm(a, b, out=out)
+    plain = run(False)
+    torch.bmm = spy
+    try:
+        batched = run(True)
+    finally:
+        torch.bmm = real_bmm
+    assert seen == [((3, 48, 6 * V.shape[0]), seen[0][1], seen[0][2])] and seen[0][1][0] > 0 and seen[0][2][0] > 0   # ONE product for the three 48 x 48 layers
+    assert torch.equal(plain[0], batched[0]) and torch.equal(plain[1], batched[1])
+    for a, b in zip(plain[3], batched[3]):
+        assert torch.equal(a, b)
+    for a, b in zip(plain[2], batched[2]):
+        assert a.shape == b.shape
+        close(b.cpu().numpy(), a.cpu().numpy(), 2e-5)
+    def existing():
+        stack[2].weight1.grad = torch.ones_like(stack[2].weight1)
+    acc = run(True, existing)
+    close(acc[2][2].cpu().numpy(), (plain[2][2] + 1.0).cpu().numpy(), 2e-5)
+    close(acc[2][1].cpu().numpy(), plain[2][1].cpu().numpy(), 2e-5)
+    # the deformation block batches its twelve hidden layers without being asked
+    block = models.BatchMeshDeformationBlock(60, V.shape[0], hidden=48).to(gpu).train()
+    feats, pooled = torch.randn(4, V.shape[0], 3, device=gpu, requires_grad=True), torch.randn(4, V.shape[0], 57, device=gpu, requires_grad=True)
+    seen.clear()
+    torch.bmm = spy
+    try:
+        f, coords = block(feats, pooled, adj)
+        (f.sum() + coords.sum()).backward()
+    finally:
+        torch.bmm = real_bmm
+    assert len(seen) == 1 and seen[0][0][0] == 12
+    assert all(torch.isfinite(p.grad).all() for n, p in block.named_parameters() if not n.startswith("bn14"))
+
+
 def test_block_input_tap_equals_cat_and_slice(gpu):
     """models._InputTap (cat + the leading columns as a contiguous second output, narrow gradient added in place) against
     torch.cat + a slice: same values, same gradients, for 3 + 1152 columns / 192 hidden and for a feature part WIDER than
