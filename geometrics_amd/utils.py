@@ -16,8 +16,8 @@ import math
 import torch
 
 from . import ops
-from .chamfer_distance import ChamferDistance, chamfer_nn
-from .tri_distance import TriDistance, tri_distance_indexed
+from .chamfer_distance import ChamferDistance
+from .tri_distance import TriDistance
 
 chamfer_dist = ChamferDistance()
 tri_dist = TriDistance()

@@ -1,6 +1,6 @@
 """Dev helper: the 12 same-shape weight-gradient products of a deformation block as ONE strided-batched product
 (TunableOp-tuned) against 12 separate ones."""
-import os, sys
+import os
 os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
 os.environ["PYTORCH_TUNABLEOP_TUNING"] = "1"
 os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", "/tmp/dw_batched_tunableop.csv")

@@ -1,6 +1,6 @@
 """Dev helper: the weight-gradient product in its two equivalent forms, both TunableOp-tuned:
    dW = X^T . G   ([Cin x rows] . [rows x Cout], what autograd issues)   vs   dW^T = G^T . X   ([Cout x rows] . [rows x Cin])."""
-import os, sys
+import os
 os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
 os.environ["PYTORCH_TUNABLEOP_TUNING"] = "1"
 os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", "/tmp/dw_forms_tunableop.csv")
