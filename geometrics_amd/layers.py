@@ -172,7 +172,7 @@ def aggregate_forward(s, bias_c, csr, k, act, out, want_mask=False):
 # a pass in which something could read it earlier -- an existing .grad to accumulate into, a hook on the bias, a bias that
 # receives gradients from more than one node (the engine adds them on arrival) -- takes the immediate reduction, and so
 # does every call outside an engine-run pass.
-defer_bias_gradients = True
+defer_parameter_gradients = True      # False: every bias / weight gradient is reduced where it is produced
 _pending_colsums = {}     # autograd graph-task id -> [(partials, rows, cols, out alias, stream)]
 # bias parameter -> the live autograd nodes that produce a gradient for it.  A bias shared by two layers (or a layer applied
 # twice) gets its gradients ADDED by the engine inside the pass, which reads them on arrival: more than one live node means
@@ -200,7 +200,7 @@ def _alias(t):
 
 
 def _may_defer(bias):
-    if not defer_bias_gradients or bias is None or not hasattr(torch._C, "_current_graph_task_id"):
+    if not defer_parameter_gradients or bias is None or not hasattr(torch._C, "_current_graph_task_id"):
         return False
     if torch._C._current_graph_task_id() < 0 or torch.is_grad_enabled():      # not an engine pass / double backward
         return False

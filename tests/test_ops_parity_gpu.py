@@ -529,7 +529,7 @@ def test_tapped_layer_output_sums_its_two_gradients_in_the_batchnorm_backward(gp
 
 def test_bias_gradients_of_a_backward_pass_are_finished_in_one_batched_launch(gpu):
     """Inside an autograd pass the per-layer bias-gradient reductions are queued and finished by ONE
-    geom_colsum_batch_f32 launch at the end of the pass (layers.defer_bias_gradients): same bits as the immediate
+    geom_colsum_batch_f32 launch at the end of the pass (layers.defer_parameter_gradients): same bits as the immediate
     reduction, complete when backward() returns, nothing left pending; a bias with an existing .grad (accumulation) or a
     hook takes the immediate path; torch.autograd.grad sees finished values; and a captured pass replays."""
     from geometrics_amd import meshgen
@@ -542,7 +542,7 @@ def test_bias_gradients_of_a_backward_pass_are_finished_in_one_batched_launch(gp
     g_out = torch.randn(5, V.shape[0], 40, device=gpu)
 
     def run(defer, prepare=None):
-        layers.defer_bias_gradients = defer
+        layers.defer_parameter_gradients = defer
         try:
             for p in stack.parameters():
                 p.grad = None
@@ -555,7 +555,7 @@ def test_bias_gradients_of_a_backward_pass_are_finished_in_one_batched_launch(gp
             assert not layers._pending_colsums
             return [layer.bias.grad.clone() for layer in stack], [layer._weight().grad.clone() for layer in stack]
         finally:
-            layers.defer_bias_gradients = True
+            layers.defer_parameter_gradients = True
 
     now_b, now_w = run(False)
     later_b, later_w = run(True)
@@ -578,7 +578,7 @@ def test_bias_gradients_of_a_backward_pass_are_finished_in_one_batched_launch(gp
     tied = layers.Batch_Image_ZERON_GCNGCN(48, 48).to(gpu)
     tied.bias = stack[1].bias
     def tied_pass(defer):
-        layers.defer_bias_gradients = defer
+        layers.defer_parameter_gradients = defer
         try:
             for p_ in list(stack.parameters()) + [tied.weight1]:
                 p_.grad = None
@@ -588,7 +588,7 @@ def test_bias_gradients_of_a_backward_pass_are_finished_in_one_batched_launch(gp
             assert not layers._pending_colsums
             return stack[1].bias.grad.clone()
         finally:
-            layers.defer_bias_gradients = True
+            layers.defer_parameter_gradients = True
     assert torch.equal(tied_pass(False), tied_pass(True))
     del tied
     # torch.autograd.grad: captured gradients are finished when the call returns
