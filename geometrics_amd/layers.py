@@ -10,6 +10,7 @@ the tensor's identity + version) and replaces the reference's dense `adj @ suppo
 """
 import ctypes
 import math
+import threading
 import weakref
 
 import torch
@@ -283,7 +284,7 @@ class _ZeroNAggregate(torch.autograd.Function):
         if s.shape[1] != csr.nv:
             raise RuntimeError("support has %d vertices but the adjacency has %d" % (s.shape[1], csr.nv))
         bias_c = None if bias is None else _lib.require(bias, "bias", torch.float32, 1)
-        ctx.arena = _slabs
+        ctx.arena = current_slabs()
         out = _new_like(s, "aggregated", ctx.arena)
         mask = aggregate_forward(s, bias_c, csr, k, act, out, want_mask=support.requires_grad)
         ctx.csr, ctx.k, ctx.act, ctx.has_bias = csr, k, act, bias is not None
@@ -359,7 +360,13 @@ class _Slabs:
         return cur[0][index]
 
 
-_slabs = None             # the active arena (set by weight_gradient_batching)
+_active = threading.local()    # .slabs = the arena of the forward pass running on this thread (weight_gradient_batching)
+
+
+def current_slabs():
+    return getattr(_active, "slabs", None)
+
+
 _pending_dense = {}       # autograd graph-task id -> [(x2d, g2d, dW slot alias, stream)] in backward order
 
 
@@ -373,14 +380,13 @@ class weight_gradient_batching:
         self.depth = depth
 
     def __enter__(self):
-        global _slabs
-        self.outer = _slabs
-        _slabs = _Slabs(self.depth)
+        self.outer = current_slabs()
+        # nothing to batch without a backward pass: an inference forward keeps its plain, progressively freed allocations
+        _active.slabs = _Slabs(self.depth) if torch.is_grad_enabled() else None
         return self
 
     def __exit__(self, *exc):
-        global _slabs
-        _slabs = self.outer
+        _active.slabs = self.outer
         return False
 
 
@@ -470,11 +476,12 @@ class _Dense(torch.autograd.Function):
 
 def _dense(x, w):
     """input @ weight of a 0N-GCN layer; w = the layer's weight parameter ([Cin, Cout] or [1, Cin, Cout])."""
-    if (_slabs is None or not x.is_cuda or x.dtype != torch.float32 or w.dtype != torch.float32
+    arena = current_slabs()
+    if (arena is None or not x.is_cuda or x.dtype != torch.float32 or w.dtype != torch.float32
             or not (w.dim() == 2 or (w.dim() == 3 and w.shape[0] == 1))
             or not (x.requires_grad or w.requires_grad) or not torch.is_grad_enabled()):
         return torch.matmul(x, w.squeeze(0) if w.dim() == 3 else w)   # [1,Cin,Cout]: one GEMM, not B broadcast bmm's
-    return _Dense.apply(x, w, _slabs)
+    return _Dense.apply(x, w, arena)
 
 
 def _uniform(t, bound):

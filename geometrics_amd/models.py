@@ -34,7 +34,7 @@ class _VertexBN(torch.autograd.Function):
         b, nv, c = xc.shape
         dev = xc.device
         res, res_ld = _residual_operand(residual, xc)   # a column slice of a wider row-major tensor is read in place
-        out = _layers._new_like(xc, "normalised", _layers._slabs)   # a slot of the pass's stacked buffers when batching is on
+        out = _layers._new_like(xc, "normalised", _layers.current_slabs())   # a slot of the pass's stacked buffers when batching is on
         mean = torch.empty(nv, dtype=torch.float32, device=dev)
         invstd = torch.empty(nv, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
