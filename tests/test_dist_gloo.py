@@ -49,7 +49,7 @@ def _worker(rank, world, port, out):
     bucket.flat[:bucket.numel].div_(world)
     gdist.barrier()
     if rank == 0:
-        out.put((bucket.flat[:bucket.numel].clone(), float(mean_loss)))
+        out.put((bucket.flat[:bucket.numel].numpy().copy(), float(mean_loss)))     # by value: a tensor would be fetched from this process later
     dist.destroy_process_group()
 
 
@@ -62,6 +62,7 @@ def test_two_rank_gradient_bucket_and_loss_match_single_process():
     for p in procs:
         p.start()
     flat, mean_loss = out.get()
+    flat = torch.from_numpy(flat)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -104,8 +105,9 @@ def _bn_worker(rank, world, port, out):
     gw, gb = bn.weight.grad.clone(), bn.bias.grad.clone()
     dist.all_reduce(gw), dist.all_reduce(gb)                # what the flat gradient bucket does for every parameter
     gdist.barrier()
-    out.put((rank, y.detach(), x.grad, res.grad, gw, gb, bn.running_mean.clone(), bn.running_var.clone(),
-             int(bn.state_dict()["num_batches_tracked"])))
+    by_value = lambda t: t.detach().numpy().copy()          # a tensor would be fetched from this process after it has gone
+    out.put((rank, by_value(y), by_value(x.grad), by_value(res.grad), by_value(gw), by_value(gb), by_value(bn.running_mean),
+             by_value(bn.running_var), int(bn.state_dict()["num_batches_tracked"])))
     dist.destroy_process_group()
 
 
@@ -121,6 +123,7 @@ def test_vertex_batchnorm_uses_global_batch_statistics_across_ranks():
     for p in procs:
         p.start()
     got = sorted([out.get(timeout=90) for _ in range(2)], key=lambda t: t[0])
+    got = [tuple(torch.from_numpy(v) if hasattr(v, "dtype") else v for v in item) for item in got]
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
