@@ -16,10 +16,11 @@ FLAG_FIX_REGION6 = 2
 FLAG_TRI_BRUTE_FORCE = 4
 FLAG_NN_FMA = 8
 FLAG_TRI_WS_READY = 16
-ABI_VERSION = 4
+ABI_VERSION = 5
 EUNSUPPORTED = -3
 ADAM_MAX_TENSORS = 64
 COLSUM_MAX_JOBS = 32
+DENSE_MAX_LAYERS = 8
 ADAM_STATE_WORDS = 72
 
 _vp = ctypes.c_void_p
@@ -68,6 +69,10 @@ _SIGNATURES = {
     "geom_pool_features_bwd_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "geom_colsum_batch_f32": [_i, _vp, _vp, _vp, _vp, _vp],
     "geom_adam_step_f32": [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _i, _vp],
+    "geom_dense_fwd_f32": [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "geom_dense_bwd_input_f32": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "geom_dense_bwd_weight_f32": [_i, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "geom_dense_reduce_f32": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "geom_zn_gcn_aggregate_fwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "geom_zn_gcn_aggregate_ell_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "geom_zn_gcn_aggregate_ell_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
@@ -118,6 +123,8 @@ def lib():
         L.geom_zn_gcn_bwd_scratch_floats.argtypes = [_i, _i, _i]
         L.geom_zn_gcn_bwd_partial_rows.restype = ctypes.c_int64
         L.geom_zn_gcn_bwd_partial_rows.argtypes = [_i, _i, _i, _i, _i]
+        L.geom_dense_bwd_weight_workspace_floats.restype = ctypes.c_int64
+        L.geom_dense_bwd_weight_workspace_floats.argtypes = [_i, _i, _i]
         L.geom_tri_distance_workspace_bytes.restype = ctypes.c_size_t
         L.geom_tri_distance_workspace_bytes.argtypes = [_i, _i, _i]
         for name, args in _SIGNATURES.items():
@@ -132,7 +139,8 @@ def declared_symbols():
     return sorted(["geom_abi_version", "geom_strerror", "geom_tri_distance_workspace_bytes",
                    "geom_zn_gcn_bwd_scratch_floats", "geom_zn_gcn_bwd_partial_rows", "geom_pool_features_bwd_workspace_bytes",
                    "geom_segment_max_workspace_bytes", "geom_zn_gcn_relu_mask_words",
-                   "geom_surface_bin_count_words", "geom_surface_bin_list_words", "geom_surface_order_words"] + list(_SIGNATURES))
+                   "geom_surface_bin_count_words", "geom_surface_bin_list_words", "geom_surface_order_words",
+                   "geom_dense_bwd_weight_workspace_floats"] + list(_SIGNATURES))
 
 
 def check(code, what):

@@ -24,6 +24,12 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
+# per-file additions.  dense_gemm.hip: keep the MFMA accumulators in (unified) VGPRs -- with the default heuristic hipcc
+# (ROCm 7.2) allocates the accumulators of the pipelined loop as untied AGPR tuples and repairs the rotation with ~85
+# v_accvgpr moves per stage, in front of the first MFMA of every stage
+EXTRA_FLAGS = {"dense_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
@@ -86,7 +92,7 @@ def build_lib(force=False, verbose=False):
     for src in sources():
         obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj]
+        cmd = [hipcc] + HIPCC_FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

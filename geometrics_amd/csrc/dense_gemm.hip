@@ -1,0 +1,834 @@
+// Dense products of the 0N-GCN layers on the gfx950 matrix cores, exact fp32 (v_mfma_f32_16x16x4_f32).
+//
+// One 0N-GCN layer is  out = act([A . S[:, :k] | S[:, k:]] + bias)  with  S = X . W  (reference layers.py:107-116,
+// 30-41, 140-152).  `X . W`, and in the backward `dX = G . W^T` and `dW = X^T . G`, are dense [b*V, Cin] x [Cin, C]
+// contractions: 66 % of the step at the BASELINE shard when they are library calls.  The shapes are the awkward kind for
+// a library -- 20 496 rows against a 192-wide output, a 963-wide (4-byte aligned, never 16) inner dimension, a
+// weight gradient whose output is 192 x 192 against 20 496 summed rows -- and every one of them has work before or after
+// it that only this code can fold in: the bias + ReLU + sign bits of the pass-through columns (so that the aggregation
+// kernel touches k = C/3 columns instead of C), a composite gradient operand [A^T g' | g . relu'] that is never
+// materialised, split-K partial sums that go to the end-of-pass reduction launch that exists anyway.
+//
+// fp32 MFMA runs at the fp32 VECTOR rate (64 flop/clk/SIMD = 157.3 TFLOP/s, MI355X_MICROARCH.md): one instruction is 32
+// cycles for 2 operand registers, 16x less operand traffic per cycle than the bf16 forms -- so these kernels are bound by
+// the matrix pipe itself and the design goal is the opposite of a bf16 GEMM's: keep ONE workgroup of 4 waves per CU
+// issuing MFMAs back to back and get everything else (staging, LDS reads, epilogue) out of the way in the gaps.
+//   * tile = RB row-blocks of 16 rows x NCW*64 output columns per workgroup; each of the 4 waves owns NCW column blocks
+//     of all RB row-blocks (RB*NCW independent accumulators: no dependent-MFMA stalls), so a k-step of 4 needs RB + NCW
+//     ds_read_b32 for RB*NCW MFMAs;
+//   * the inner dimension advances 32 elements per stage through double-buffered LDS: the global loads of stage s+1 are
+//     issued before the MFMAs of stage s and written to LDS after them, one barrier per stage;
+//   * 20 496 rows = 1281 row-blocks = 5 per CU + ONE: the leftover row-blocks are not given to a few workgroups as a
+//     sixth row-block (+20 % for them = for the launch) but spread fragment by fragment: workgroups 0..NCW-1 stage the
+//     leftover rows as well and each of their waves computes one extra fragment (+1 MFMA on 15);
+//   * operands are consumed in the layout they have in memory (row-major X and G, [Cin, C] weights): panels whose
+//     inner index is contiguous are stored [row][34] in LDS, panels whose inner index is the slow one [t][R+16] -- both
+//     conflict-free for the fragment reads (bank = 2*row + t resp. 16*g + x);
+//   * a weight gradient (inner dimension = all rows) is split over the rows so that all CUs work; partial tiles go to a
+//     workspace and are added up in slot order by a reduction kernel -- a fixed order, so results are bit-reproducible.
+#include "geom_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; }; // 16 bytes at 4-byte alignment (963-float rows)
+
+constexpr int DG_THREADS = 256;
+constexpr int DG_WAVES = 4;
+constexpr int DG_BK = 32; // inner-dimension elements per LDS stage
+constexpr int DG_KS = 8;  // MFMA k-steps (4 elements each) per stage
+constexpr int LD_TC = 34; // stride of a [row][t] panel: fragment reads hit bank (2*row + t) % 32 -- all distinct
+
+// stride of a [t][r] panel of R columns: the smallest s >= R with s % 32 == 16 (rows t and t+1 half a bank row apart)
+__host__ __device__ constexpr int ld_rc(int r) { return ((r + 15) / 32) * 32 + 16; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Panel staging.  A panel is the slice of one operand a stage needs: R rows x 32 inner elements.
+//   TC ("t contiguous"): element (r, t) at g[r * ld + t] in memory, at lds[r * 34 + t] in LDS;
+//   RC ("r contiguous"): element (r, t) at g[t * ld + r] in memory, at lds[t * ld_rc(R) + r] in LDS.
+// Loads go to registers first (issued before a stage's MFMAs, stored to LDS after them).  Rows beyond the valid range
+// are clamped (their results are never stored), inner positions beyond `tmax` are zero-filled.
+// ---------------------------------------------------------------------------------------------------------------------
+
+// A loader has three steps so that nothing between "issue" and the MFMAs waits for memory:
+//   prepare(...)     per tile / chunk: the byte offset of every element this thread fetches relative to the stage's base,
+//                    rows and columns CLAMPED into the valid range (clamped duplicates only feed outputs that are not stored);
+//   issue_pass(p..)  unconditional load at base + min(offset, limit): `base` is wave-uniform (it carries the stage's inner
+//                    offset), `limit` = the last valid position of the whole operand, so the stage that holds the end of the
+//                    inner dimension reads valid memory without a branch;
+//   store_pass(p..)  registers -> LDS; ZERO: inner positions >= tmax are zero-filled (only the A operand does that: one
+//                    zero factor is enough).
+// A pass is one load / store instruction per thread; the pipeline below spreads the passes over a stage's MFMAs.
+__device__ __forceinline__ float ldg(const float *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ f32x4 ldg4(const float *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+// TC panel, 16-byte loads (rows 16-byte aligned, T % 4 == 0): 8 threads per row, 32 rows per pass
+template <int R>
+struct PanelTCv {
+    static constexpr int PASSES = (R + 31) / 32;
+    static constexpr int WIDTH = 4;
+    f32x4 v[PASSES];
+    unsigned off[PASSES];
+    // rowoff(r) -> ELEMENT offset of (clamped) row r
+    template <typename RowOff>
+    __device__ __forceinline__ void prepare(RowOff rowoff, unsigned /*ld*/)
+    {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int r = p * 32 + (threadIdx.x >> 3);
+            off[p] = ((unsigned)rowoff(r < R ? r : R - 1) + (threadIdx.x & 7) * 4u) * 4u;
+        }
+    }
+    static __device__ __forceinline__ const float *stage_base(const float *g, unsigned /*ld*/, int t0) { return g + t0; }
+    static __device__ __forceinline__ unsigned stage_limit(unsigned total, unsigned /*ld*/, int t0) { return (total - 4u - (unsigned)t0) * 4u; }
+    __device__ __forceinline__ void issue_pass(int p, const float *base, unsigned limit) { v[p] = ldg4(base, min(off[p], limit)); }
+    template <bool ZERO>
+    __device__ __forceinline__ void store_pass(int p, float *lds, int t0, int tmax) const
+    {
+        const int tl = (threadIdx.x & 7) * 4;
+        const int r = p * 32 + (threadIdx.x >> 3);
+        if (R % 32 == 0 || r < R) { // 34-float rows are 8-byte aligned: two ds_write_b64
+            const bool tin = !ZERO || t0 + tl < tmax;
+            float2 *d = reinterpret_cast<float2 *>(lds + r * LD_TC + tl);
+            d[0] = make_float2(tin ? v[p][0] : 0.f, tin ? v[p][1] : 0.f);
+            d[1] = make_float2(tin ? v[p][2] : 0.f, tin ? v[p][3] : 0.f);
+        }
+    }
+};
+
+// TC panel, 4-byte loads (rows that are only dword aligned: the 963-wide features): 32 threads per row, 8 rows per pass
+template <int R>
+struct PanelTCs {
+    static constexpr int PASSES = R / 8;
+    static constexpr int WIDTH = 1;
+    float v[PASSES];
+    unsigned off[PASSES];
+    template <typename RowOff>
+    __device__ __forceinline__ void prepare(RowOff rowoff, unsigned /*ld*/)
+    {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) off[p] = ((unsigned)rowoff(p * 8 + (threadIdx.x >> 5)) + (threadIdx.x & 31)) * 4u;
+    }
+    static __device__ __forceinline__ const float *stage_base(const float *g, unsigned /*ld*/, int t0) { return g + t0; }
+    static __device__ __forceinline__ unsigned stage_limit(unsigned total, unsigned /*ld*/, int t0) { return (total - 1u - (unsigned)t0) * 4u; }
+    __device__ __forceinline__ void issue_pass(int p, const float *base, unsigned limit) { v[p] = ldg(base, min(off[p], limit)); }
+    template <bool ZERO>
+    __device__ __forceinline__ void store_pass(int p, float *lds, int t0, int tmax) const
+    {
+        const int tl = threadIdx.x & 31;
+        const bool tin = !ZERO || t0 + tl < tmax;
+        lds[(p * 8 + (threadIdx.x >> 5)) * LD_TC + tl] = tin ? v[p] : 0.f;
+    }
+};
+
+// RC panel, 16-byte loads along r: element e = thread + 256 * p of the 32 x R/4 grid
+template <int R>
+struct PanelRCv {
+    static constexpr int Q = R / 4;
+    static constexpr int PASSES = (32 * Q + DG_THREADS - 1) / DG_THREADS;
+    static constexpr bool EXACT = (32 * Q) % DG_THREADS == 0;
+    static constexpr int WIDTH = 4;
+    f32x4 v[PASSES];
+    unsigned off[PASSES];
+    // coloff(r4) -> ELEMENT offset of the (clamped) 4-column group r4 within a row; ld = row pitch in elements
+    template <typename ColOff>
+    __device__ __forceinline__ void prepare(ColOff coloff, unsigned ld)
+    {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int e = threadIdx.x + p * DG_THREADS;
+            const int tl = EXACT ? e / Q : min(e / Q, 31);
+            off[p] = ((unsigned)tl * ld + (unsigned)coloff(e % Q)) * 4u;
+        }
+    }
+    static __device__ __forceinline__ const float *stage_base(const float *g, unsigned ld, int t0) { return g + (int64_t)t0 * ld; }
+    static __device__ __forceinline__ unsigned stage_limit(unsigned total, unsigned ld, int t0) { return (total - 4u - (unsigned)t0 * ld) * 4u; }
+    __device__ __forceinline__ void issue_pass(int p, const float *base, unsigned limit) { v[p] = ldg4(base, min(off[p], limit)); }
+    template <bool ZERO>
+    __device__ __forceinline__ void store_pass(int p, float *lds, int t0, int tmax) const
+    {
+        const int e = threadIdx.x + p * DG_THREADS;
+        const int tl = e / Q, r4 = e % Q;
+        if (EXACT || tl < 32) {
+            f32x4 x = v[p];
+            if (ZERO && !(t0 + tl < tmax)) x = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4 *>(lds + tl * ld_rc(R) + r4 * 4) = x;
+        }
+    }
+};
+
+// RC panel, 4-byte loads along r (963-wide rows): element e = thread + 256 * p of the 32 x R grid
+template <int R>
+struct PanelRCs {
+    static constexpr int PASSES = (32 * R + DG_THREADS - 1) / DG_THREADS;
+    static constexpr bool EXACT = (32 * R) % DG_THREADS == 0;
+    static constexpr int WIDTH = 1;
+    float v[PASSES];
+    unsigned off[PASSES];
+    template <typename ColOff>
+    __device__ __forceinline__ void prepare(ColOff coloff, unsigned ld)
+    {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int e = threadIdx.x + p * DG_THREADS;
+            const int tl = EXACT ? e / R : min(e / R, 31);
+            off[p] = ((unsigned)tl * ld + (unsigned)coloff(e % R)) * 4u;
+        }
+    }
+    static __device__ __forceinline__ const float *stage_base(const float *g, unsigned ld, int t0) { return g + (int64_t)t0 * ld; }
+    static __device__ __forceinline__ unsigned stage_limit(unsigned total, unsigned ld, int t0) { return (total - 1u - (unsigned)t0 * ld) * 4u; }
+    __device__ __forceinline__ void issue_pass(int p, const float *base, unsigned limit) { v[p] = ldg(base, min(off[p], limit)); }
+    template <bool ZERO>
+    __device__ __forceinline__ void store_pass(int p, float *lds, int t0, int tmax) const
+    {
+        const int e = threadIdx.x + p * DG_THREADS;
+        const int tl = e / R, r = e % R;
+        if (EXACT || tl < 32) lds[tl * ld_rc(R) + r] = (!ZERO || t0 + tl < tmax) ? v[p] : 0.f;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One stage of the pipeline = 8 k-steps of MFMAs out of LDS buffer `cur`, with everything else of the stage issued in
+// their shadow (one wave per SIMD: an MFMA occupies the matrix pipe for 32 cycles, the wave can issue ~5 other
+// instructions meanwhile -- MI355X_MICROARCH.md):
+//   k-steps 0-3: the staging registers (operand slices of the NEXT stage, loaded during the previous one) go to LDS buffer
+//                `wr`; then ONE barrier (mid-stage, so that no wave waits at a stage boundary with an empty pipe);
+//   k-steps 4-7: the loads of the stage after next are issued into the same registers;
+//   every k-step: the fragments of the following k-step are requested first -- the last one reads `wr`, i.e. the first
+//                k-step of the next stage, so the MFMA stream never stops between stages.
+// Three LDS buffers make the single barrier sufficient: `wr` was last read two stages ago, and every wave has passed the
+// previous stage's barrier since.
+// The accumulator of fragment (rb, jj) of this wave holds, in lane l = 16*g + x, C[16*rb + x][16*cb + 4*g + r] for
+// r = 0..3 (cb = the wave's jj-th column block): the weight-side fragment is passed as the instruction's first operand, so
+// a lane's four registers are four CONSECUTIVE output columns (one 16-byte store).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int RB, int NCW, bool EXTRA>
+struct Frags {
+    float a[2][RB + 1], b[2][NCW + 1];
+};
+
+template <int RB, int NCW, bool A_TC, bool B_TC, int RA, int RBW, bool EXTRA>
+__device__ __forceinline__ void fetch_frags(Frags<RB, NCW, EXTRA> &f, int buf, const float *la, const float *lb, int s, int wave,
+                                            int xcb)
+{
+    const int x = threadIdx.x & 15, g = (threadIdx.x >> 4) & 3;
+    const float *pa = A_TC ? la + x * LD_TC + g : la + g * ld_rc(RA) + x;
+    const float *pb = B_TC ? lb + (wave * NCW * 16 + x) * LD_TC + g : lb + g * ld_rc(RBW) + wave * NCW * 16 + x;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) f.a[buf][i] = A_TC ? pa[i * 16 * LD_TC + 4 * s] : pa[4 * s * ld_rc(RA) + i * 16];
+#pragma unroll
+    for (int j = 0; j < NCW; ++j) f.b[buf][j] = B_TC ? pb[j * 16 * LD_TC + 4 * s] : pb[4 * s * ld_rc(RBW) + j * 16];
+    if (EXTRA) { // the leftover row-block: rows RB*16.. of the A panel, column block xcb
+        const float *pbx = B_TC ? lb + (xcb * 16 + x) * LD_TC + g : lb + g * ld_rc(RBW) + xcb * 16 + x;
+        f.a[buf][RB] = A_TC ? pa[RB * 16 * LD_TC + 4 * s] : pa[4 * s * ld_rc(RA) + RB * 16];
+        f.b[buf][NCW] = B_TC ? pbx[4 * s] : pbx[4 * s * ld_rc(RBW)];
+    }
+}
+
+struct StageIO {
+    int st_t0, st_tmax;      // inner range of the stage held in the staging registers (zero-fill of the A operand)
+    const float *a_base, *b_base; // stage bases + clamp limits of the loads to issue
+    unsigned a_limit, b_limit;
+};
+
+template <int RB, int NCW, bool A_TC, bool B_TC, int RA, int RBW, bool EXTRA, int A_FLOATS, class PA, class PB>
+__device__ __forceinline__ void gemm_stage(const float *cur, float *wr, f32x4 (&acc)[RB][NCW], f32x4 &accx,
+                                           Frags<RB, NCW, EXTRA> &f, PA &pa, PB &pb, const StageIO &io, int wave, int xcb)
+{
+    constexpr int U = PA::PASSES + PB::PASSES; // staging instructions per thread and direction
+#pragma unroll
+    for (int s = 0; s < DG_KS; ++s) {
+        // fragments of the next k-step (of the next stage after the last one)
+        if (s + 1 < DG_KS) fetch_frags<RB, NCW, A_TC, B_TC, RA, RBW, EXTRA>(f, (s + 1) & 1, cur, cur + A_FLOATS, s + 1, wave, xcb);
+        else fetch_frags<RB, NCW, A_TC, B_TC, RA, RBW, EXTRA>(f, 0, wr, wr + A_FLOATS, 0, wave, xcb);
+        // this k-step's share of the staging work
+        const int h = s & 3, u0 = h * U / 4, u1 = (h + 1) * U / 4;
+#pragma unroll
+        for (int u = u0; u < u1; ++u) {
+            if (s < 4) {
+                if (u < PA::PASSES) pa.template store_pass<true>(u, wr, io.st_t0, io.st_tmax);
+                else pb.template store_pass<false>(u - PA::PASSES, wr + A_FLOATS, io.st_t0, io.st_tmax);
+            } else {
+                if (u < PA::PASSES) pa.issue_pass(u, io.a_base, io.a_limit);
+                else pb.issue_pass(u - PA::PASSES, io.b_base, io.b_limit);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int j = 0; j < NCW; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.b[s & 1][j], f.a[s & 1][i], acc[i][j], 0, 0, 0);
+        if (EXTRA) accx = __builtin_amdgcn_mfma_f32_16x16x4f32(f.b[s & 1][NCW], f.a[s & 1][RB], accx, 0, 0, 0);
+        // one MFMA, then what fits into its 32 cycles
+#pragma unroll
+        for (int m = 0; m < RB * NCW + (EXTRA ? 1 : 0); ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // DS read
+            if (s < 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); // DS write
+            else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // VMEM read
+            __builtin_amdgcn_sched_group_barrier(0x006, 2, 0); // VALU / SALU
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s == 3) {
+            __syncthreads(); // `wr` is complete; its first fragments are requested four k-steps from here
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row kernel:  C[i][j] = sum_t A[i][t] * B(t, j),  A row-major [I, T]; tiles of RB*16 rows.
+//   B_TC = false: B(t, j) = b[t * ldb + j]   (forward: W [Cin, C])
+//   B_TC = true : B(t, j) = b[j * ldb + t]   (input gradient: W again, read as W^T)
+// Workgroup w takes row tiles w, w + G, ...; all column chunks (NCW*64 wide) of a tile in turn.  The rows beyond the last
+// full tile ("leftover" row-blocks, fewer than RB) are spread over the first workgroups as extra fragments (see top).
+// ---------------------------------------------------------------------------------------------------------------------
+enum { EPI_PLAIN = 0, EPI_ZN = 1 };
+
+struct RowArgs {
+    const float *a;
+    int64_t lda;
+    const float *b;
+    int64_t ldb;
+    float *c;
+    int64_t ldc;
+    int I, J, T;
+    int n_tiles;   // full tiles of RB row-blocks
+    int left_rb;   // leftover row-blocks (< RB), handled as extras
+    int n_chunks;  // ceil(J / (NCW*64))
+    // EPI_ZN: columns < ksplit go raw to sup[i * ksplit + j]; columns >= ksplit get bias + ReLU and go to c; one sign bit
+    // per element of c's pass-through columns to mask[i * (J/16) + j/16] (bit j % 16)
+    int ksplit;
+    float *sup;
+    const float *bias;
+    unsigned short *mask;
+};
+
+template <int RB, int NCW, bool B_TC, bool A_VEC, int EPI, bool HAS_X>
+__device__ __forceinline__ void rows_body(const RowArgs &q, float *lds)
+{
+    constexpr int RA = (RB + 1) * 16;     // rows of the A panel (the last 16 = a leftover row-block, when staged)
+    constexpr int RAL = HAS_X ? RA : RB * 16;
+    constexpr int CW = NCW * 64;          // output columns per chunk
+    constexpr int A_FLOATS = RA * LD_TC;
+    constexpr int B_FLOATS = B_TC ? CW * LD_TC : 32 * ld_rc(CW);
+    constexpr int BUF = A_FLOATS + B_FLOATS;
+    const int wave = threadIdx.x >> 6;
+    const int G = gridDim.x, w = blockIdx.x;
+    // leftover row-block handled by this workgroup (every chunk of it): workgroups [NCW*e, NCW*e + NCW) take leftover
+    // row-block e, wave v of workgroup NCW*e + u the column block 4*u + v of each chunk
+    const int xrow0 = HAS_X ? (q.n_tiles * RB + w / NCW) * 16 : 0;
+    const int xcb = (w % NCW) * DG_WAVES + wave;
+    const int nst = (q.T + DG_BK - 1) / DG_BK;
+    int my_tiles = w < q.n_tiles ? (q.n_tiles - 1 - w) / G + 1 : 0;
+    if (my_tiles == 0 && HAS_X) my_tiles = 1; // extras only (fewer full tiles than workgroups): an empty tile carries them
+    const int total = my_tiles * q.n_chunks * nst;
+    if (total == 0) return;
+
+    typedef typename std::conditional<A_VEC, PanelTCv<RAL>, PanelTCs<RAL>>::type PA;
+    typedef typename std::conditional<B_TC, PanelTCv<CW>, PanelRCv<CW>>::type PB;
+    PA pa;
+    PB pb;
+    const unsigned a_total = (unsigned)q.I * (unsigned)q.lda;
+    const unsigned b_total = B_TC ? (unsigned)q.J * (unsigned)q.ldb : (unsigned)q.T * (unsigned)q.ldb;
+    // the loader runs two stages ahead of the MFMAs; past the end it stays on the last stage (harmless re-loads)
+    int l_tile = w, l_chunk = 0, l_st = 0, l_count = 0;
+    auto prepare_a = [&]() {
+        const int tile = l_tile;
+        pa.prepare([=](int r) -> unsigned {
+            // the leftover row-block (panel rows RB*16..) is fetched with every tile of the workgroup and used by the first
+            int row = r < RB * 16 ? (tile < q.n_tiles ? tile : 0) * RB * 16 + r : xrow0 + (r - RB * 16);
+            row = row < q.I ? row : q.I - 1;
+            return (unsigned)row * (unsigned)q.lda;
+        }, (unsigned)q.lda);
+    };
+    auto prepare_b = [&]() {
+        const int j0 = l_chunk * CW;
+        if constexpr (B_TC) {
+            pb.prepare([=](int r) -> unsigned { const int j = j0 + r; return (unsigned)(j < q.J ? j : q.J - 1) * (unsigned)q.ldb; }, (unsigned)q.ldb);
+        } else {
+            pb.prepare([=](int r4) -> unsigned { const int j = j0 + r4 * 4; return (unsigned)(j < q.J ? j : q.J - 4); }, (unsigned)q.ldb);
+        }
+    };
+    StageIO io;
+    auto aim = [&]() { // bases / limits of the loader's current stage
+        io.a_base = PA::stage_base(q.a, (unsigned)q.lda, l_st * DG_BK);
+        io.a_limit = PA::stage_limit(a_total, (unsigned)q.lda, l_st * DG_BK);
+        io.b_base = PB::stage_base(q.b, (unsigned)q.ldb, l_st * DG_BK);
+        io.b_limit = PB::stage_limit(b_total, (unsigned)q.ldb, l_st * DG_BK);
+    };
+    auto advance = [&]() {
+        if (l_count + 1 >= total) return;
+        ++l_count;
+        if (++l_st == nst) {
+            l_st = 0;
+            if (++l_chunk == q.n_chunks) {
+                l_chunk = 0, l_tile += G;
+                prepare_a();
+            }
+            if (q.n_chunks > 1) prepare_b();
+        }
+    };
+    auto issue_all = [&]() {
+#pragma unroll
+        for (int p = 0; p < PA::PASSES; ++p) pa.issue_pass(p, io.a_base, io.a_limit);
+#pragma unroll
+        for (int p = 0; p < PB::PASSES; ++p) pb.issue_pass(p, io.b_base, io.b_limit);
+    };
+
+    // prologue: stage 0 -> LDS buffer 0, stage 1 -> registers
+    prepare_a();
+    prepare_b();
+    aim();
+    issue_all();
+#pragma unroll
+    for (int p = 0; p < PA::PASSES; ++p) pa.template store_pass<true>(p, lds, 0, q.T);
+#pragma unroll
+    for (int p = 0; p < PB::PASSES; ++p) pb.template store_pass<false>(p, lds + A_FLOATS, 0, q.T);
+    advance();
+    aim();
+    issue_all();
+    io.st_t0 = l_st * DG_BK, io.st_tmax = q.T;
+    advance();
+    aim();
+    __syncthreads();
+    Frags<RB, NCW, HAS_X> fr;
+    fetch_frags<RB, NCW, true, B_TC, RA, CW, HAS_X>(fr, 0, lds, lds + A_FLOATS, 0, wave, xcb);
+
+    const int x = threadIdx.x & 15, g = (threadIdx.x >> 4) & 3;
+    int it = 0;
+    for (int c_tile = w, pass = 0; pass < my_tiles; ++pass, c_tile += G) {
+        for (int c_chunk = 0; c_chunk < q.n_chunks; ++c_chunk) {
+            f32x4 acc[RB][NCW], accx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int j = 0; j < NCW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int st = 0; st < nst; ++st, ++it) {
+                const float *cur = lds + (it % 3) * BUF;
+                float *wr = lds + ((it + 1) % 3) * BUF;
+                gemm_stage<RB, NCW, true, B_TC, RA, CW, HAS_X, A_FLOATS>(cur, wr, acc, accx, fr, pa, pb, io, wave, xcb);
+                // the registers now hold the stage the loader was aimed at; aim at the one after it
+                io.st_t0 = l_st * DG_BK;
+                advance();
+                aim();
+            }
+            // the chunk is complete: epilogue
+            const int j0 = c_chunk * CW;
+            auto emit = [&](const f32x4 &val, int row, int cb) {
+                const int j = j0 + cb * 16 + 4 * g;
+                if (row >= q.I || j >= q.J) return;
+                f32x4 v = val;
+                if (EPI == EPI_ZN) {
+                    if (j < q.ksplit) { // aggregated columns: raw support, compact [I, ksplit]
+                        *reinterpret_cast<f32x4 *>(q.sup + (int64_t)row * q.ksplit + j) = v;
+                        return;
+                    }
+                    const f32x4 bb = q.bias ? *reinterpret_cast<const f32x4 *>(q.bias + j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    unsigned bits = 0u;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float t = v[r] + bb[r];
+                        v[r] = t > 0.f ? t : 0.f;
+                        bits |= (t > 0.f ? 1u : 0u) << r;
+                    }
+                    if (q.mask) { // 16 sign bits per (row, column block): the four g-lanes of a row combine their nibbles
+                        unsigned m = bits << (4 * g);
+                        m |= __shfl_xor(m, 16);
+                        m |= __shfl_xor(m, 32);
+                        if (g == 0) q.mask[(int64_t)row * (q.J >> 4) + (j >> 4)] = (unsigned short)m;
+                    }
+                }
+                float *dst = q.c + (int64_t)row * q.ldc + j;
+                if (j + 3 < q.J) {
+                    *reinterpret_cast<f4u *>(dst) = f4u{v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (j + r < q.J) dst[r] = v[r];
+                }
+            };
+            if (c_tile < q.n_tiles) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < NCW; ++jj) emit(acc[i][jj], (c_tile * RB + i) * 16 + x, wave * NCW + jj);
+            }
+            if (HAS_X && pass == 0) emit(accx, xrow0 + x, xcb);
+        }
+    }
+}
+
+template <int RB, int NCW, bool B_TC, bool A_VEC, int EPI>
+__global__ __launch_bounds__(DG_THREADS) void dense_rows_kernel(RowArgs q)
+{
+    constexpr int RA = (RB + 1) * 16;
+    constexpr int CW = NCW * 64;
+    __shared__ __attribute__((aligned(16))) float lds[3 * (RA * LD_TC + (B_TC ? CW * LD_TC : 32 * ld_rc(CW)))];
+    // the workgroups that carry a leftover row-block run their own instantiation of the whole loop (one more accumulator)
+    if ((int)blockIdx.x < q.left_rb * NCW) rows_body<RB, NCW, B_TC, A_VEC, EPI, true>(q, lds);
+    else rows_body<RB, NCW, B_TC, A_VEC, EPI, false>(q, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Split kernel (weight gradient):  P[slot][i][j] = sum over this slot's rows t of  A[t][i0 + i] * B[t][j],
+// A = X [T, I] and B = G [T, J <= NCW*64], both read as stored (the summed index is the slow one).  Output tiles of
+// SPLIT_RB*16 rows of dW, each split s_full ways over T; the I % (SPLIT_RB*16) leftover rows (963 = 10 * 96 + 3) are
+// single row-blocks with their own, smaller number of splits (a sixth of the work per split) and a 1-row-block body.
+// Workgroup w < full_tiles * s_full: tile = w % full_tiles, split = w / full_tiles (neighbouring workgroups = the tiles
+// of one split = the same rows of G: they share it through L2); the others: leftover row-block (w - nfull) / s_left.
+// ---------------------------------------------------------------------------------------------------------------------
+struct SplitArgs {
+    const float *a;
+    int64_t lda;
+    const float *b;
+    int64_t ldb;
+    float *part;  // [slots][SPLIT_RB*16][NCW*64]; a leftover slot uses its first 16 rows
+    int I, J, T;
+    int full_tiles, s_full, left_rb, s_left;
+    float *colsum; // optional [s_full][J]: column sums of B over each split's rows (the bias gradient), tile 0 only
+};
+
+template <int RB, int RBP, int NCW, bool A_VEC>
+__device__ __forceinline__ void split_body(const SplitArgs &q, float *lds, int i0, int split, int nsplit, int slot, bool want_cs)
+{
+    constexpr int RA = RB * 16;
+    constexpr int CW = NCW * 64;
+    constexpr int A_FLOATS = 32 * ld_rc(RA);
+    constexpr int B_FLOATS = 32 * ld_rc(CW);
+    constexpr int BUF = A_FLOATS + B_FLOATS;
+    const int wave = threadIdx.x >> 6;
+    // rows of the summed dimension in units of 4 (one MFMA k-step); T % 4 != 0 is zero-filled by the loaders
+    const int n4 = (q.T + 3) / 4;
+    const int t_begin = (int)((int64_t)n4 * split / nsplit) * 4;
+    const int t_end = min((int)((int64_t)n4 * (split + 1) / nsplit) * 4, q.T);
+    const int nst = (t_end - t_begin + DG_BK - 1) / DG_BK;
+
+    f32x4 acc[RB][NCW], accx;
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < NCW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    typedef typename std::conditional<A_VEC, PanelRCv<RA>, PanelRCs<RA>>::type PA;
+    typedef PanelRCv<CW> PB;
+    PA pa;
+    PB pb;
+    f32x4 csum[PB::PASSES];
+#pragma unroll
+    for (int p = 0; p < PB::PASSES; ++p) csum[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (nst > 0) {
+        if constexpr (A_VEC) pa.prepare([=](int r4) -> unsigned { const int i = i0 + r4 * 4; return (unsigned)(i < q.I ? i : q.I - 4); }, (unsigned)q.lda);
+        else pa.prepare([=](int r) -> unsigned { const int i = i0 + r; return (unsigned)(i < q.I ? i : q.I - 1); }, (unsigned)q.lda);
+        pb.prepare([=](int r4) -> unsigned { const int j = r4 * 4; return (unsigned)(j < q.J ? j : q.J - 4); }, (unsigned)q.ldb);
+        const unsigned a_total = (unsigned)q.T * (unsigned)q.lda, b_total = (unsigned)q.T * (unsigned)q.ldb;
+        StageIO io;
+        int l_st = 0;
+        auto aim = [&]() {
+            const int t0 = t_begin + l_st * DG_BK;
+            io.a_base = PA::stage_base(q.a, (unsigned)q.lda, t0);
+            io.a_limit = PA::stage_limit(a_total, (unsigned)q.lda, t0);
+            io.b_base = PB::stage_base(q.b, (unsigned)q.ldb, t0);
+            io.b_limit = PB::stage_limit(b_total, (unsigned)q.ldb, t0);
+        };
+        auto advance = [&]() { if (l_st + 1 < nst) ++l_st; };
+        auto issue_all = [&]() {
+#pragma unroll
+            for (int p = 0; p < PA::PASSES; ++p) pa.issue_pass(p, io.a_base, io.a_limit);
+#pragma unroll
+            for (int p = 0; p < PB::PASSES; ++p) pb.issue_pass(p, io.b_base, io.b_limit);
+        };
+        aim();
+        issue_all();
+#pragma unroll
+        for (int p = 0; p < PA::PASSES; ++p) pa.template store_pass<true>(p, lds, t_begin, t_end);
+#pragma unroll
+        for (int p = 0; p < PB::PASSES; ++p) pb.template store_pass<false>(p, lds + A_FLOATS, t_begin, t_end);
+        advance();
+        aim();
+        issue_all();
+        io.st_t0 = t_begin + l_st * DG_BK, io.st_tmax = t_end;
+        advance();
+        aim();
+        __syncthreads();
+        Frags<RB, NCW, false> fr;
+        fetch_frags<RB, NCW, false, false, RA, CW, false>(fr, 0, lds, lds + A_FLOATS, 0, wave, 0);
+        for (int st = 0; st < nst; ++st) {
+            const float *cur = lds + (st % 3) * BUF;
+            float *wr = lds + ((st + 1) % 3) * BUF;
+            if (want_cs) { // the stage's slice of G lies in LDS in front of this wave: its column sums = the bias gradient
+                // (rows of the A operand beyond t_end are zero, G's are not: count only the rows of this split)
+                const float *gb = cur + A_FLOATS;
+                const int t0 = t_begin + st * DG_BK;
+#pragma unroll
+                for (int p = 0; p < PB::PASSES; ++p) {
+                    const int e = threadIdx.x + p * DG_THREADS;
+                    const int tl = e / (CW / 4);
+                    const f32x4 gv = *reinterpret_cast<const f32x4 *>(gb + tl * ld_rc(CW) + (e % (CW / 4)) * 4);
+                    if (t0 + tl < t_end) csum[p] += gv;
+                }
+            }
+            gemm_stage<RB, NCW, false, false, RA, CW, false, A_FLOATS>(cur, wr, acc, accx, fr, pa, pb, io, wave, 0);
+            io.st_t0 = t_begin + l_st * DG_BK;
+            advance();
+            aim();
+        }
+    }
+    // partial tile: lane holds P[16*rb + x][16*cb + 4g .. +3]
+    const int x = threadIdx.x & 15, g = (threadIdx.x >> 4) & 3;
+    float *dst = q.part + (int64_t)slot * (RBP * 16) * CW;
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NCW; ++jj)
+            *reinterpret_cast<f32x4 *>(dst + (i * 16 + x) * CW + (wave * NCW + jj) * 16 + 4 * g) = acc[i][jj];
+    if (want_cs) {
+        // thread e = thread + 256*p owns columns 4*(e % Q).. of inner rows e / Q: fold the rows through LDS in a fixed order
+        constexpr int Q = CW / 4;
+        __syncthreads(); // every wave is done with the LDS buffers
+        float *red = lds; // [32][CW]
+#pragma unroll
+        for (int p = 0; p < PB::PASSES; ++p) {
+            const int e = threadIdx.x + p * DG_THREADS;
+            if (PB::EXACT || e / Q < 32) *reinterpret_cast<f32x4 *>(red + (e / Q) * CW + (e % Q) * 4) = csum[p];
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < q.J; j += DG_THREADS) {
+            float t = 0.f;
+            for (int r = 0; r < 32; ++r) t += red[r * CW + j];
+            q.colsum[(int64_t)split * q.J + j] = t;
+        }
+    }
+}
+
+template <int RB, int NCW, bool A_VEC>
+__global__ __launch_bounds__(DG_THREADS) void dense_split_kernel(SplitArgs q)
+{
+    __shared__ __attribute__((aligned(16))) float lds[3 * (32 * ld_rc(RB * 16) + 32 * ld_rc(NCW * 64))];
+    const int w = blockIdx.x;
+    const int nfull = q.full_tiles * q.s_full;
+    if (w < nfull) {
+        const int tile = w % q.full_tiles, split = w / q.full_tiles;
+        split_body<RB, RB, NCW, A_VEC>(q, lds, tile * RB * 16, split, q.s_full, tile * q.s_full + split,
+                                       q.colsum != nullptr && tile == 0);
+    } else {
+        const int e = (w - nfull) / q.s_left, split = (w - nfull) % q.s_left;
+        split_body<1, RB, NCW, A_VEC>(q, lds, (q.full_tiles * RB + e) * 16, split, q.s_left, w, false);
+    }
+}
+
+// out[i][j] = sum over the splits of tile(i) of part[slot][i % RA][j], in slot order.  One thread per 4 columns.
+struct ReduceJob {
+    const float *part;
+    float *out;
+    int I, J, RA, CW, full_tiles, s_full, s_left; // rows beyond the full tiles: 16-row tiles of s_left splits each
+};
+struct ReduceJobs {
+    ReduceJob job[GEOM_DENSE_MAX_REDUCE_JOBS];
+};
+
+__global__ __launch_bounds__(256) void dense_reduce_kernel(ReduceJobs jobs)
+{
+    const ReduceJob q = jobs.job[blockIdx.y];
+    const int jq = q.J >> 2;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= q.I * jq) return;
+    const int i = e / jq, j = (e % jq) * 4;
+    int tile = i / q.RA, il = i % q.RA;
+    const bool full = tile < q.full_tiles;
+    const int n = full ? q.s_full : q.s_left;
+    int slot0 = tile * q.s_full;
+    if (!full) {
+        const int r = i - q.full_tiles * q.RA;
+        slot0 = q.full_tiles * q.s_full + (r >> 4) * q.s_left, il = r & 15;
+    }
+    const float *p = q.part + ((int64_t)slot0 * q.RA + il) * q.CW + j;
+    const int64_t pitch = (int64_t)q.RA * q.CW;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 4 <= n; s += 4) { // four loads in flight, added in slot order
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(p + (s + 0) * pitch);
+        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(p + (s + 1) * pitch);
+        const f32x4 a2 = *reinterpret_cast<const f32x4 *>(p + (s + 2) * pitch);
+        const f32x4 a3 = *reinterpret_cast<const f32x4 *>(p + (s + 3) * pitch);
+        t = (((t + a0) + a1) + a2) + a3;
+    }
+    for (; s < n; ++s) t = t + *reinterpret_cast<const f32x4 *>(p + s * pitch);
+    float *o = q.out + (int64_t)i * q.J + j;
+    o[0] = t[0], o[1] = t[1], o[2] = t[2], o[3] = t[3];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int SPLIT_RB = 6; // weight-gradient tiles: 96 rows x 192 columns
+
+int num_cus()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// rows-kernel geometry: RB row-blocks per tile such that the busiest workgroup does the least work
+struct RowGeo {
+    int rb, n_tiles, left_rb, grid;
+};
+RowGeo row_geometry(int rows, int ncw, int cus)
+{
+    const int n_rb = (rows + 15) / 16;
+    RowGeo best{0, 0, 0, 0};
+    long best_cost = -1;
+    const int cand[] = {5, 6, 4, 3, 2, 1};
+    for (int rb : cand) {
+        int n_tiles = n_rb / rb, left = n_rb % rb;
+        if (left * ncw > cus || (n_tiles == 0 && left == 0)) continue;
+        const int grid = n_tiles < cus ? (n_tiles > left * ncw ? n_tiles : left * ncw) : cus;
+        if (grid <= 0) continue;
+        const int passes = (n_tiles + grid - 1) / grid;
+        // cost in fragments per wave of the busiest workgroup: passes * rb * ncw (+1 with a leftover fragment)
+        const long cost = (long)(passes > 0 ? passes : 1) * rb * ncw + (left ? 1 : 0);
+        if (best_cost < 0 || cost < best_cost) best = RowGeo{rb, n_tiles, left, grid}, best_cost = cost;
+    }
+    return best;
+}
+
+template <int NCW, bool B_TC, bool A_VEC, int EPI>
+int launch_rows_rb(const RowArgs &q, const RowGeo &geo, hipStream_t s)
+{
+    const dim3 grid(geo.grid), block(DG_THREADS);
+    switch (geo.rb) {
+    case 1: hipLaunchKernelGGL((dense_rows_kernel<1, NCW, B_TC, A_VEC, EPI>), grid, block, 0, s, q); break;
+    case 2: hipLaunchKernelGGL((dense_rows_kernel<2, NCW, B_TC, A_VEC, EPI>), grid, block, 0, s, q); break;
+    case 3: hipLaunchKernelGGL((dense_rows_kernel<3, NCW, B_TC, A_VEC, EPI>), grid, block, 0, s, q); break;
+    case 4: hipLaunchKernelGGL((dense_rows_kernel<4, NCW, B_TC, A_VEC, EPI>), grid, block, 0, s, q); break;
+    case 5: hipLaunchKernelGGL((dense_rows_kernel<5, NCW, B_TC, A_VEC, EPI>), grid, block, 0, s, q); break;
+    case 6: hipLaunchKernelGGL((dense_rows_kernel<6, NCW, B_TC, A_VEC, EPI>), grid, block, 0, s, q); break;
+    default: return GEOM_EINVAL;
+    }
+    return geom::launch_status();
+}
+
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+} // namespace
+
+// support = x . w (+ the 0N-GCN pass-through epilogue)
+extern "C" int geom_dense_fwd_f32(int rows, int cin, int c, const float *x, const float *w, int ksplit, const float *bias,
+                                  float *out, float *sup, uint16_t *mask, void *stream)
+{
+    if (rows < 0 || cin <= 0 || c <= 0) return GEOM_EINVAL;
+    if (c % 16 != 0 || c > 192 || (int64_t)rows * cin > 0x7fffffffLL) return GEOM_EUNSUPPORTED;
+    if (rows == 0) return 0;
+    if (!x || !w || !out || !aligned16(w) || !aligned16(out)) return GEOM_EINVAL;
+    const bool zn = ksplit > 0;
+    if (zn && (ksplit % 16 != 0 || ksplit >= c || !sup || !aligned16(sup) || (bias && !aligned16(bias)))) return GEOM_EINVAL;
+    const RowGeo geo = row_geometry(rows, 3, num_cus());
+    RowArgs q{x, cin, w, c, out, c, rows, c, cin, geo.n_tiles, geo.left_rb, 1, zn ? ksplit : 0, sup, bias, mask};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool avec = cin % 4 == 0 && aligned16(x);
+    if (zn) return avec ? launch_rows_rb<3, false, true, EPI_ZN>(q, geo, s) : launch_rows_rb<3, false, false, EPI_ZN>(q, geo, s);
+    return avec ? launch_rows_rb<3, false, true, EPI_PLAIN>(q, geo, s) : launch_rows_rb<3, false, false, EPI_PLAIN>(q, geo, s);
+}
+
+// grad_x = g . w^T   (g [rows, c], w [cin, c], grad_x [rows, cin])
+extern "C" int geom_dense_bwd_input_f32(int rows, int cin, int c, const float *g, const float *w, float *grad_x, void *stream)
+{
+    if (rows < 0 || cin <= 0 || c <= 0) return GEOM_EINVAL;
+    if (c % 4 != 0 || (int64_t)rows * (cin > c ? cin : c) > 0x7fffffffLL) return GEOM_EUNSUPPORTED;
+    if (rows == 0) return 0;
+    if (!g || !w || !grad_x || !aligned16(g) || !aligned16(w)) return GEOM_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int ncw = cin > 192 ? 4 : 3;
+    const RowGeo geo = row_geometry(rows, ncw, num_cus());
+    RowArgs q{g, c, w, c, grad_x, cin, rows, cin, c, geo.n_tiles, geo.left_rb, (cin + ncw * 64 - 1) / (ncw * 64), 0, nullptr,
+              nullptr, nullptr};
+    return ncw == 4 ? launch_rows_rb<4, true, true, EPI_PLAIN>(q, geo, s) : launch_rows_rb<3, true, true, EPI_PLAIN>(q, geo, s);
+}
+
+namespace {
+struct SplitGeo {
+    int full_tiles, left_rb, s_full, s_left, slots;
+};
+SplitGeo split_geometry(int cin, int rows, int cus)
+{
+    SplitGeo g;
+    const int ra = SPLIT_RB * 16;
+    g.full_tiles = cin / ra;
+    g.left_rb = (cin % ra + 15) / 16;
+    const int n4 = (rows + 3) / 4;
+    // a leftover row-block is 1/SPLIT_RB of a full tile: equal work per workgroup <=> s_left = s_full / SPLIT_RB
+    g.s_full = g.full_tiles ? (int)((int64_t)cus * SPLIT_RB / (g.full_tiles * SPLIT_RB + g.left_rb)) : 0;
+    if (g.full_tiles && g.s_full < 1) g.s_full = 1;
+    g.s_left = 0;
+    if (g.left_rb) {
+        const int rest = cus - g.full_tiles * g.s_full;
+        g.s_left = rest / g.left_rb > 0 ? rest / g.left_rb : 1;
+    }
+    if (g.s_full > n4) g.s_full = n4;
+    if (g.s_left > n4) g.s_left = n4;
+    g.slots = g.full_tiles * g.s_full + g.left_rb * g.s_left;
+    return g;
+}
+} // namespace
+
+extern "C" int64_t geom_dense_bwd_weight_workspace_floats(int rows, int cin, int c)
+{
+    if (rows <= 0 || cin <= 0 || c <= 0 || c > 192) return 0;
+    const SplitGeo g = split_geometry(cin, rows, num_cus());
+    return (int64_t)g.slots * SPLIT_RB * 16 * 192 + (int64_t)(g.s_full > 0 ? g.s_full : g.s_left) * c;
+}
+
+// partial sums of grad_w = x^T . g into `workspace`; geom_dense_reduce_f32 finishes them (and the bias gradient)
+extern "C" int geom_dense_bwd_weight_f32(int rows, int cin, int c, const float *x, const float *g, float *workspace,
+                                         int want_colsum, void *stream)
+{
+    if (rows <= 0 || cin <= 0 || c <= 0) return GEOM_EINVAL;
+    if (c % 4 != 0 || c > 192 || (int64_t)rows * (cin > c ? cin : c) > 0x7fffffffLL) return GEOM_EUNSUPPORTED;
+    if (!x || !g || !workspace || !aligned16(g) || !aligned16(workspace)) return GEOM_EINVAL;
+    const SplitGeo geo = split_geometry(cin, rows, num_cus());
+    if (want_colsum && geo.full_tiles == 0) return GEOM_EUNSUPPORTED;
+    float *colsum = want_colsum ? workspace + (int64_t)geo.slots * SPLIT_RB * 16 * 192 : nullptr;
+    SplitArgs q{x, cin, g, c, workspace, cin, c, rows, geo.full_tiles, geo.s_full, geo.left_rb, geo.s_left, colsum};
+    const dim3 grid(geo.slots), block(DG_THREADS);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (cin % 4 == 0 && aligned16(x)) hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB, 3, true>), grid, block, 0, s, q);
+    else hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB, 3, false>), grid, block, 0, s, q);
+    return geom::launch_status();
+}
+
+// grad_w[i] (and grad_bias[i], may be NULL) of `count` layers out of their workspaces, ONE launch
+extern "C" int geom_dense_reduce_f32(int count, const int *rows, const int *cin, const int *c, const float *const *workspaces,
+                                     float *const *grad_w, float *const *grad_bias, void *stream)
+{
+    if (count < 0 || count > GEOM_DENSE_MAX_REDUCE_JOBS / 2) return GEOM_ETOOBIG;
+    if (count == 0) return 0;
+    if (!rows || !cin || !c || !workspaces || !grad_w) return GEOM_EINVAL;
+    ReduceJobs jobs;
+    int n = 0, widest = 0;
+    for (int l = 0; l < count; ++l) {
+        if (!workspaces[l] || !grad_w[l] || rows[l] <= 0 || cin[l] <= 0 || c[l] <= 0 || c[l] > 192 || c[l] % 4) return GEOM_EINVAL;
+        const SplitGeo g = split_geometry(cin[l], rows[l], num_cus());
+        jobs.job[n++] = ReduceJob{workspaces[l], grad_w[l], cin[l], c[l], SPLIT_RB * 16, 192, g.full_tiles, g.s_full, g.s_left};
+        widest = cin[l] * (c[l] / 4) > widest ? cin[l] * (c[l] / 4) : widest;
+        if (grad_bias && grad_bias[l]) { // column sums: a 1-row "tile" per split, pitch = c
+            if (g.full_tiles == 0) return GEOM_EUNSUPPORTED;
+            jobs.job[n++] = ReduceJob{workspaces[l] + (int64_t)g.slots * SPLIT_RB * 16 * 192, grad_bias[l], 1, c[l], 1, c[l], 1,
+                                      g.s_full, 0};
+        }
+    }
+    hipLaunchKernelGGL(dense_reduce_kernel, dim3((widest + 255) / 256, n), dim3(256), 0, static_cast<hipStream_t>(stream), jobs);
+    return geom::launch_status();
+}

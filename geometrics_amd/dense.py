@@ -1,0 +1,91 @@
+"""Dense products of the 0N-GCN layers on the fp32 matrix cores (csrc/dense_gemm.hip) -- thin host wrappers over the
+C ABI (`geom_dense_*`, include/geom_hip.h).  The reference computes `support = torch.matmul(input, weight)`
+(layers.py:30, 107, 140) and leaves its two gradients to autograd's library calls; these entry points are the same three
+products, exact fp32, with the layer's own epilogue / prologue folded in (see the kernel file for why).
+
+Everything here takes 2-D row-major views: x [rows, cin] (rows = b*V), w [cin, c].
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def supported(cin, c, rows=1):
+    """Shapes the matrix-core kernels take (anything else: the library product)."""
+    return 0 < c <= 192 and c % 16 == 0 and cin > 0 and rows * max(cin, c) < 2 ** 30
+
+
+def forward(x, w, out=None):
+    """support = x @ w."""
+    rows, cin = x.shape
+    c = w.shape[1]
+    out = torch.empty(rows, c, dtype=torch.float32, device=x.device) if out is None else out
+    with torch.cuda.device(x.device):
+        _lib.call("geom_dense_fwd_f32", rows, cin, c, x.data_ptr(), w.data_ptr(), 0, None, out.data_ptr(), None, None)
+    return out
+
+
+def forward_split(x, w, bias, ksplit, out, sup, mask):
+    """out[:, ksplit:] = relu(x @ w[:, ksplit:] + bias[ksplit:]) (finished), sup = x @ w[:, :ksplit] (raw, compact), the
+    sign bits of the finished columns into mask [rows, c/16] (uint16 as int16)."""
+    rows, cin = x.shape
+    c = w.shape[1]
+    with torch.cuda.device(x.device):
+        _lib.call("geom_dense_fwd_f32", rows, cin, c, x.data_ptr(), w.data_ptr(), ksplit, _lib.ptr(bias), out.data_ptr(),
+                  sup.data_ptr(), _lib.ptr(mask))
+
+
+def backward_input(g, w, out=None):
+    """grad_x = g @ w.T   (g [rows, c], w [cin, c])."""
+    rows, c = g.shape
+    cin = w.shape[0]
+    out = torch.empty(rows, cin, dtype=torch.float32, device=g.device) if out is None else out
+    with torch.cuda.device(g.device):
+        _lib.call("geom_dense_bwd_input_f32", rows, cin, c, g.data_ptr(), w.data_ptr(), out.data_ptr())
+    return out
+
+
+def weight_workspace(rows, cin, c, device):
+    n = int(_lib.lib().geom_dense_bwd_weight_workspace_floats(rows, cin, c))
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def backward_weight_partials(x, g, workspace, want_colsum=False):
+    """Per-split partial tiles of x.T @ g (and of g's column sums) into `workspace`; `reduce` finishes them."""
+    rows, cin = x.shape
+    c = g.shape[1]
+    with torch.cuda.device(x.device):
+        _lib.call("geom_dense_bwd_weight_f32", rows, cin, c, x.data_ptr(), g.data_ptr(), workspace.data_ptr(),
+                  1 if want_colsum else 0)
+
+
+def reduce(jobs, stream=None):
+    """jobs = [(rows, cin, c, workspace, grad_w, grad_bias or None)]: all pending weight / bias gradients in ONE launch."""
+    n = len(jobs)
+    if n == 0:
+        return
+    if n > _lib.DENSE_MAX_LAYERS:
+        for i in range(0, n, _lib.DENSE_MAX_LAYERS):
+            reduce(jobs[i:i + _lib.DENSE_MAX_LAYERS], stream)
+        return
+    ints = lambda k: (ctypes.c_int * n)(*[j[k] for j in jobs])
+    ptrs = lambda k: (ctypes.c_void_p * n)(*[None if j[k] is None else j[k].data_ptr() for j in jobs])
+    dev = jobs[0][3].device
+    with torch.cuda.device(dev):
+        s = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        _lib.check(_lib.lib().geom_dense_reduce_f32(n, ints(0), ints(1), ints(2), ptrs(3), ptrs(4), ptrs(5), s),
+                   "geom_dense_reduce_f32")
+
+
+def backward_weight(x, g, want_bias=False):
+    """grad_w = x.T @ g (and grad_bias = column sums of g): partial launch + reduction launch."""
+    rows, cin = x.shape
+    c = g.shape[1]
+    ws = weight_workspace(rows, cin, c, x.device)
+    backward_weight_partials(x, g, ws, want_bias)
+    gw = torch.empty(cin, c, dtype=torch.float32, device=x.device)
+    gb = torch.empty(c, dtype=torch.float32, device=x.device) if want_bias else None
+    reduce([(rows, cin, c, ws, gw, gb)])
+    return gw, gb

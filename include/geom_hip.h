@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GEOM_ABI_VERSION 4
+#define GEOM_ABI_VERSION 5
 
 /* argument errors */
 #define GEOM_EINVAL   (-1) /* bad size / null pointer */
@@ -268,6 +268,33 @@ int geom_zn_gcn_aggregate_ell_bwd_f32(int b, int nv, int c, int k, int w, const 
                                       const float *over_valT, const float *grad_out, const float *out,
                                       const uint16_t *relu_mask, int act, float *grad_support,
                                       float *grad_bias, float *scratch, void *stream);
+
+/* ---- dense products of a 0N-GCN layer on the fp32 matrix cores (layers.py:30, 107, 140: `support = input . W`) -------
+ * Exact fp32 (v_mfma_f32_16x16x4_f32: a k-ordered fma chain per output element, no reduced precision).  Row-major
+ * operands as the reference holds them: x [rows, cin] (rows = b*V), w [cin, c], c <= 192 and c % 16 == 0 for the forward,
+ * anything else GEOM_EUNSUPPORTED (callers then use the library product).  x may be only 4-byte aligned per row (cin = 963).
+ *
+ * geom_dense_fwd_f32: support = x . w.
+ *   ksplit == 0: out [rows, c] = support.
+ *   ksplit  > 0 (% 16 == 0, < c; layers.py:108-116 with k = ksplit, activation ReLU): the aggregated columns go RAW to
+ *     sup [rows, ksplit] (compact), the pass-through columns are finished: out[r, j] = relu(support[r, j] + bias[j]) for
+ *     j >= ksplit (bias may be NULL), and mask (may be NULL) [rows, c/16] uint16 receives their sign bits (bit j % 16 of word
+ *     (r, j / 16) = out[r, j] > 0; the words of the aggregated columns are left for the aggregation kernel).
+ * geom_dense_bwd_input_f32: grad_x [rows, cin] = g [rows, c] . w^T.
+ * geom_dense_bwd_weight_f32: per-split partial tiles of grad_w = x^T . g (and, want_colsum != 0, of the column sums of g =
+ *   the bias gradient) into `workspace` (geom_dense_bwd_weight_workspace_floats floats, 16-byte aligned);
+ * geom_dense_reduce_f32 adds them up in a fixed order -- ONE launch for the pending weight / bias gradients of up to
+ *   GEOM_DENSE_MAX_LAYERS layers (host arrays of per-layer sizes and pointers; grad_bias or its entries may be NULL). */
+#define GEOM_DENSE_MAX_LAYERS 8
+#define GEOM_DENSE_MAX_REDUCE_JOBS 16
+int geom_dense_fwd_f32(int rows, int cin, int c, const float *x, const float *w, int ksplit, const float *bias,
+                       float *out, float *sup, uint16_t *mask, void *stream);
+int geom_dense_bwd_input_f32(int rows, int cin, int c, const float *g, const float *w, float *grad_x, void *stream);
+int64_t geom_dense_bwd_weight_workspace_floats(int rows, int cin, int c);
+int geom_dense_bwd_weight_f32(int rows, int cin, int c, const float *x, const float *g, float *workspace,
+                              int want_colsum, void *stream);
+int geom_dense_reduce_f32(int count, const int *rows, const int *cin, const int *c, const float *const *workspaces,
+                          float *const *grad_w, float *const *grad_bias, void *stream);
 
 /* Coordinate update of a deformation stage (GEOMetrics.py:121,126,131) when the predicted offsets are the
  * three leading channels of a wider feature tensor: pos[r,:] = base[r,:] + scale*feat[r,:3] for `rows`

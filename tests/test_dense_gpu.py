@@ -1,0 +1,99 @@
+"""The fp32 matrix-core products of the 0N-GCN layers (csrc/dense_gemm.hip) against float64 products of the same operands.
+
+Reference semantics: `support = torch.matmul(input, weight)` (layers.py:30, 107, 140) and autograd's two gradients of it.
+Tolerance: an fp32 fma chain over K terms against float64 is ~1e-7 * sum|a*b| (MI355X guide, FP32-input MFMA); the checks
+below allow 2e-6 of the row/column scale -- far inside the 1e-5 the layer fixtures are held to."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # rows, cin, c
+    (20496, 963, 192),   # BASELINE shard, layer 1 (4-byte aligned rows)
+    (20496, 192, 192),   # hidden layers
+    (7712, 1155, 192),   # reference training shape (16 x 482), block input
+    (7712, 192, 192),
+    (2562, 963, 192),    # one mesh: fewer tiles than CUs
+    (1000, 37, 48),      # odd everything
+    (16, 4, 16),
+    (83, 192, 192),
+]
+
+
+def _close(got, want, scale_axis=None, tol=5e-6):
+    got = got.double().cpu()
+    want = want.cpu()
+    scale = want.abs().max().item() + 1e-30
+    err = (got - want).abs().max().item()
+    assert err <= tol * scale * 50, (err, scale)      # max-norm
+    # relative Frobenius: catches a transposed / shifted tile that a max-norm of similar magnitudes would not
+    assert (got - want).norm().item() <= tol * want.norm().item() + 1e-30
+
+
+def _operands(rows, cin, c, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(rows, cin, generator=g)
+    w = torch.randn(cin, c, generator=g) * 0.1
+    gr = torch.randn(rows, c, generator=g)
+    return x.cuda(), w.cuda(), gr.cuda()
+
+
+@pytest.mark.parametrize("rows,cin,c", SHAPES)
+def test_forward_matches_float64(rows, cin, c):
+    from geometrics_amd import dense
+    x, w, _ = _operands(rows, cin, c)
+    out = dense.forward(x, w)
+    _close(out, x.double() @ w.double())
+
+
+@pytest.mark.parametrize("rows,cin,c", SHAPES)
+def test_input_gradient_matches_float64(rows, cin, c):
+    from geometrics_amd import dense
+    x, w, g = _operands(rows, cin, c, 1)
+    out = dense.backward_input(g, w)
+    _close(out, g.double() @ w.double().t())
+
+
+@pytest.mark.parametrize("rows,cin,c", SHAPES)
+def test_weight_and_bias_gradient_match_float64(rows, cin, c):
+    from geometrics_amd import dense
+    x, w, g = _operands(rows, cin, c, 2)
+    want_bias = cin >= 96          # the column sums ride on the first full output tile
+    gw, gb = dense.backward_weight(x, g, want_bias)
+    _close(gw, x.double().t() @ g.double())
+    if want_bias:
+        _close(gb, g.double().sum(0))
+    # bit-reproducible: fixed split order
+    gw2, _ = dense.backward_weight(x, g, False)
+    assert torch.equal(gw, gw2)
+
+
+@pytest.mark.parametrize("rows,cin", [(20496, 963), (20496, 192), (2562, 192), (83, 192)])
+def test_split_epilogue_finishes_the_pass_through_columns(rows, cin):
+    """ksplit mode (layers.py:108-116, ReLU): aggregated columns raw and compact, pass-through columns with bias + ReLU,
+    sign bits of the pass-through columns."""
+    from geometrics_amd import dense
+    c, k = 192, 64
+    x, w, _ = _operands(rows, cin, c, 3)
+    bias = torch.randn(c, device="cuda") * 0.5
+    out = torch.full((rows, c), float("nan"), device="cuda")
+    sup = torch.empty(rows, k, device="cuda")
+    mask = torch.zeros(rows, c // 16, dtype=torch.int16, device="cuda")
+    dense.forward_split(x, w, bias, k, out, sup, mask)
+    full = dense.forward(x, w)
+    assert torch.equal(sup, full[:, :k])                       # same arithmetic, same bits
+    assert torch.equal(out[:, k:], torch.relu(full[:, k:] + bias[k:]))
+    assert bool(torch.isnan(out[:, :k]).all())                 # the aggregated columns of `out` are not touched
+    bits = (mask.view(rows, c // 16, 1).int() & 0xffff) >> torch.arange(16, device="cuda").view(1, 1, 16) & 1
+    want = (out[:, k:] > 0).view(rows, (c - k) // 16, 16).int()
+    assert torch.equal(bits[:, k // 16:], want)
+    assert int(bits[:, :k // 16].sum()) == 0
+
+
+def test_unsupported_shapes_are_refused():
+    from geometrics_amd import _lib
+    x = torch.zeros(4, 4, device="cuda")
+    code = _lib.lib().geom_dense_fwd_f32(4, 4, 200, x.data_ptr(), x.data_ptr(), 0, None, x.data_ptr(), None, None, None)
+    assert code == _lib.EUNSUPPORTED
