@@ -87,9 +87,12 @@ class Workload:
     def forward_backward(self):
         self.opt.zero_grad()
         self.feat.grad = None
-        pos = self.positions()
-        self.loss = utils.batch_point_to_surface(pos, self.info, self.gt, num=S_PTS)
-        self.loss.backward(self.seed_grad)                  # explicit seed: no ones_like fill launch
+        # nothing reads a parameter gradient before backward() returns (no hooks, no DDP: the bucket is packed afterwards),
+        # so the bias / weight gradients of the pass are finished by batched launches at its end
+        with layers.deferred_parameter_gradients():
+            pos = self.positions()
+            self.loss = utils.batch_point_to_surface(pos, self.info, self.gt, num=S_PTS)
+            self.loss.backward(self.seed_grad)              # explicit seed: no ones_like fill launch
         if self.world > 1:
             self.bucket.pack(self.loss.detach() * self.batch, self.count)
 
@@ -370,7 +373,8 @@ def component_times(w):
     def gcn_fb():
         w.opt.zero_grad()
         w.feat.grad = None
-        w.positions().sum().backward()
+        with layers.deferred_parameter_gradients():
+            w.positions().sum().backward()
     out["0N-GCN stack forward+backward"] = event_time_us(gcn_fb, iters=10)
     for p in w.stack.parameters():
         if p.grad is None:
@@ -405,16 +409,18 @@ def training_shape_times(dev, batch=16):
     def step():
         opt.zero_grad()
         feats.grad = pooled.grad = None
-        f, coords = block(feats, pooled, info["adj"])
-        loss = utils.batch_point_to_surface(base + coords, info, gt, num=S_PTS)
-        loss.backward()
+        with layers.deferred_parameter_gradients():
+            f, coords = block(feats, pooled, info["adj"])
+            loss = utils.batch_point_to_surface(base + coords, info, gt, num=S_PTS)
+            loss.backward()
         opt.step()
 
     def block_only():
         opt.zero_grad()
         feats.grad = pooled.grad = None
-        f, coords = block(feats, pooled, info["adj"])
-        (f.sum() + coords.sum()).backward()
+        with layers.deferred_parameter_gradients():
+            f, coords = block(feats, pooled, info["adj"])
+            (f.sum() + coords.sum()).backward()
 
     pos = base.clone().requires_grad_(True)
 

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "geom_dense_fwd_f32": [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_dense_bwd_input_f32": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "geom_dense_bwd_weight_f32": [_i, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "geom_dense_bwd_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "geom_dense_reduce_f32": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "geom_zn_gcn_aggregate_fwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "geom_zn_gcn_aggregate_ell_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],

@@ -38,6 +38,7 @@ constexpr int DG_THREADS = 256;
 constexpr int DG_WAVES = 4;
 constexpr int DG_BK = 32; // inner-dimension elements per LDS stage
 constexpr int DG_KS = 8;  // MFMA k-steps (4 elements each) per stage
+constexpr int SPLIT_RB = 6; // weight-gradient tiles: 96 rows x 192 columns
 constexpr int LD_TC = 34; // stride of a [row][t] panel: fragment reads hit bank (2*row + t) % 32 -- all distinct
 
 // stride of a [t][r] panel of R columns: the smallest s >= R with s % 32 == 16 (rows t and t+1 half a bank row apart)
@@ -74,7 +75,7 @@ template <int R>
 struct PanelTCv {
     static constexpr int PASSES = (R + 31) / 32;
     static constexpr int WIDTH = 4;
-    f32x4 v[PASSES];
+    f32x4 v[2][PASSES]; // two register sets: one being loaded while the other waits for its turn to go to LDS
     unsigned off[PASSES];
     // rowoff(r) -> ELEMENT offset of (clamped) row r
     template <typename RowOff>
@@ -88,8 +89,9 @@ struct PanelTCv {
     }
     static __device__ __forceinline__ const float *stage_base(const float *g, unsigned /*ld*/, int t0) { return g + t0; }
     static __device__ __forceinline__ unsigned stage_limit(unsigned total, unsigned /*ld*/, int t0) { return (total - 4u - (unsigned)t0) * 4u; }
-    __device__ __forceinline__ void issue_pass(int p, const float *base, unsigned limit) { v[p] = ldg4(base, min(off[p], limit)); }
-    template <bool ZERO>
+    template <int SET>
+    __device__ __forceinline__ void issue_pass(int p, const float *base, unsigned limit) { v[SET][p] = ldg4(base, min(off[p], limit)); }
+    template <bool ZERO, int SET>
     __device__ __forceinline__ void store_pass(int p, float *lds, int t0, int tmax) const
     {
         const int tl = (threadIdx.x & 7) * 4;
@@ -97,8 +99,8 @@ struct PanelTCv {
         if (R % 32 == 0 || r < R) { // 34-float rows are 8-byte aligned: two ds_write_b64
             const bool tin = !ZERO || t0 + tl < tmax;
             float2 *d = reinterpret_cast<float2 *>(lds + r * LD_TC + tl);
-            d[0] = make_float2(tin ? v[p][0] : 0.f, tin ? v[p][1] : 0.f);
-            d[1] = make_float2(tin ? v[p][2] : 0.f, tin ? v[p][3] : 0.f);
+            d[0] = make_float2(tin ? v[SET][p][0] : 0.f, tin ? v[SET][p][1] : 0.f);
+            d[1] = make_float2(tin ? v[SET][p][2] : 0.f, tin ? v[SET][p][3] : 0.f);
         }
     }
 };
@@ -108,7 +110,7 @@ template <int R>
 struct PanelTCs {
     static constexpr int PASSES = R / 8;
     static constexpr int WIDTH = 1;
-    float v[PASSES];
+    float v[2][PASSES];
     unsigned off[PASSES];
     template <typename RowOff>
     __device__ __forceinline__ void prepare(RowOff rowoff, unsigned /*ld*/)
@@ -118,13 +120,14 @@ struct PanelTCs {
     }
     static __device__ __forceinline__ const float *stage_base(const float *g, unsigned /*ld*/, int t0) { return g + t0; }
     static __device__ __forceinline__ unsigned stage_limit(unsigned total, unsigned /*ld*/, int t0) { return (total - 1u - (unsigned)t0) * 4u; }
-    __device__ __forceinline__ void issue_pass(int p, const float *base, unsigned limit) { v[p] = ldg(base, min(off[p], limit)); }
-    template <bool ZERO>
+    template <int SET>
+    __device__ __forceinline__ void issue_pass(int p, const float *base, unsigned limit) { v[SET][p] = ldg(base, min(off[p], limit)); }
+    template <bool ZERO, int SET>
     __device__ __forceinline__ void store_pass(int p, float *lds, int t0, int tmax) const
     {
         const int tl = threadIdx.x & 31;
         const bool tin = !ZERO || t0 + tl < tmax;
-        lds[(p * 8 + (threadIdx.x >> 5)) * LD_TC + tl] = tin ? v[p] : 0.f;
+        lds[(p * 8 + (threadIdx.x >> 5)) * LD_TC + tl] = tin ? v[SET][p] : 0.f;
     }
 };
 
@@ -135,7 +138,7 @@ struct PanelRCv {
     static constexpr int PASSES = (32 * Q + DG_THREADS - 1) / DG_THREADS;
     static constexpr bool EXACT = (32 * Q) % DG_THREADS == 0;
     static constexpr int WIDTH = 4;
-    f32x4 v[PASSES];
+    f32x4 v[2][PASSES];
     unsigned off[PASSES];
     // coloff(r4) -> ELEMENT offset of the (clamped) 4-column group r4 within a row; ld = row pitch in elements
     template <typename ColOff>
@@ -150,14 +153,15 @@ struct PanelRCv {
     }
     static __device__ __forceinline__ const float *stage_base(const float *g, unsigned ld, int t0) { return g + (int64_t)t0 * ld; }
     static __device__ __forceinline__ unsigned stage_limit(unsigned total, unsigned ld, int t0) { return (total - 4u - (unsigned)t0 * ld) * 4u; }
-    __device__ __forceinline__ void issue_pass(int p, const float *base, unsigned limit) { v[p] = ldg4(base, min(off[p], limit)); }
-    template <bool ZERO>
+    template <int SET>
+    __device__ __forceinline__ void issue_pass(int p, const float *base, unsigned limit) { v[SET][p] = ldg4(base, min(off[p], limit)); }
+    template <bool ZERO, int SET>
     __device__ __forceinline__ void store_pass(int p, float *lds, int t0, int tmax) const
     {
         const int e = threadIdx.x + p * DG_THREADS;
         const int tl = e / Q, r4 = e % Q;
         if (EXACT || tl < 32) {
-            f32x4 x = v[p];
+            f32x4 x = v[SET][p];
             if (ZERO && !(t0 + tl < tmax)) x = (f32x4){0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4 *>(lds + tl * ld_rc(R) + r4 * 4) = x;
         }
@@ -170,7 +174,7 @@ struct PanelRCs {
     static constexpr int PASSES = (32 * R + DG_THREADS - 1) / DG_THREADS;
     static constexpr bool EXACT = (32 * R) % DG_THREADS == 0;
     static constexpr int WIDTH = 1;
-    float v[PASSES];
+    float v[2][PASSES];
     unsigned off[PASSES];
     template <typename ColOff>
     __device__ __forceinline__ void prepare(ColOff coloff, unsigned ld)
@@ -184,13 +188,14 @@ struct PanelRCs {
     }
     static __device__ __forceinline__ const float *stage_base(const float *g, unsigned ld, int t0) { return g + (int64_t)t0 * ld; }
     static __device__ __forceinline__ unsigned stage_limit(unsigned total, unsigned ld, int t0) { return (total - 1u - (unsigned)t0 * ld) * 4u; }
-    __device__ __forceinline__ void issue_pass(int p, const float *base, unsigned limit) { v[p] = ldg(base, min(off[p], limit)); }
-    template <bool ZERO>
+    template <int SET>
+    __device__ __forceinline__ void issue_pass(int p, const float *base, unsigned limit) { v[SET][p] = ldg(base, min(off[p], limit)); }
+    template <bool ZERO, int SET>
     __device__ __forceinline__ void store_pass(int p, float *lds, int t0, int tmax) const
     {
         const int e = threadIdx.x + p * DG_THREADS;
         const int tl = e / R, r = e % R;
-        if (EXACT || tl < 32) lds[tl * ld_rc(R) + r] = (!ZERO || t0 + tl < tmax) ? v[p] : 0.f;
+        if (EXACT || tl < 32) lds[tl * ld_rc(R) + r] = (!ZERO || t0 + tl < tmax) ? v[SET][p] : 0.f;
     }
 };
 
@@ -198,13 +203,15 @@ struct PanelRCs {
 // One stage of the pipeline = 8 k-steps of MFMAs out of LDS buffer `cur`, with everything else of the stage issued in
 // their shadow (one wave per SIMD: an MFMA occupies the matrix pipe for 32 cycles, the wave can issue ~5 other
 // instructions meanwhile -- MI355X_MICROARCH.md):
-//   k-steps 0-3: the staging registers (operand slices of the NEXT stage, loaded during the previous one) go to LDS buffer
-//                `wr`; then ONE barrier (mid-stage, so that no wave waits at a stage boundary with an empty pipe);
-//   k-steps 4-7: the loads of the stage after next are issued into the same registers;
+//   k-steps 0-3: the loads of the stage AFTER NEXT are issued into staging register set SET;
+//   k-steps 4-6: the other register set (the NEXT stage's operand slices, loaded during the previous stage: a full stage
+//                = 1.6 us of latency budget; half a stage measured as `s_waitcnt vmcnt` stalls) goes to LDS buffer `wr`;
+//                then ONE barrier;
 //   every k-step: the fragments of the following k-step are requested first -- the last one reads `wr`, i.e. the first
 //                k-step of the next stage, so the MFMA stream never stops between stages.
-// Three LDS buffers make the single barrier sufficient: `wr` was last read two stages ago, and every wave has passed the
-// previous stage's barrier since.
+// Two LDS buffers and the single barrier are enough: between two barriers every wave reads only `cur` (its last request, for
+// k-step 7, is issued in k-step 6 in front of the barrier) and writes only `wr`, which nobody reads before the barrier.
+// 2 x 40 KB per workgroup: TWO workgroups fit a CU's 160 KB -- see the combined backward launch.
 // The accumulator of fragment (rb, jj) of this wave holds, in lane l = 16*g + x, C[16*rb + x][16*cb + 4*g + r] for
 // r = 0..3 (cb = the wave's jj-th column block): the weight-side fragment is passed as the instruction's first operand, so
 // a lane's four registers are four CONSECUTIVE output columns (one 16-byte store).
@@ -238,28 +245,44 @@ struct StageIO {
     unsigned a_limit, b_limit;
 };
 
-template <int RB, int NCW, bool A_TC, bool B_TC, int RA, int RBW, bool EXTRA, int A_FLOATS, class PA, class PB>
+template <int RB, int NCW, bool A_TC, bool B_TC, int RA, int RBW, bool EXTRA, int A_FLOATS, int SET, class PA, class PB, class Tail>
 __device__ __forceinline__ void gemm_stage(const float *cur, float *wr, f32x4 (&acc)[RB][NCW], f32x4 &accx,
-                                           Frags<RB, NCW, EXTRA> &f, PA &pa, PB &pb, const StageIO &io, int wave, int xcb)
+                                           Frags<RB, NCW, EXTRA> &f, PA &pa, PB &pb, const StageIO &io, int wave, int xcb,
+                                           Tail tail)
 {
     constexpr int U = PA::PASSES + PB::PASSES; // staging instructions per thread and direction
 #pragma unroll
     for (int s = 0; s < DG_KS; ++s) {
         // fragments of the next k-step (of the next stage after the last one)
+#ifndef DG_PROBE_NO_FETCH
         if (s + 1 < DG_KS) fetch_frags<RB, NCW, A_TC, B_TC, RA, RBW, EXTRA>(f, (s + 1) & 1, cur, cur + A_FLOATS, s + 1, wave, xcb);
         else fetch_frags<RB, NCW, A_TC, B_TC, RA, RBW, EXTRA>(f, 0, wr, wr + A_FLOATS, 0, wave, xcb);
+#endif
         // this k-step's share of the staging work
-        const int h = s & 3, u0 = h * U / 4, u1 = (h + 1) * U / 4;
+#ifdef DG_PROBE_NO_ISSUE
+        if (false) {
+#else
+        if (s < 4) {
+#endif
 #pragma unroll
-        for (int u = u0; u < u1; ++u) {
-            if (s < 4) {
-                if (u < PA::PASSES) pa.template store_pass<true>(u, wr, io.st_t0, io.st_tmax);
-                else pb.template store_pass<false>(u - PA::PASSES, wr + A_FLOATS, io.st_t0, io.st_tmax);
-            } else {
-                if (u < PA::PASSES) pa.issue_pass(u, io.a_base, io.a_limit);
-                else pb.issue_pass(u - PA::PASSES, io.b_base, io.b_limit);
+            for (int u = s * U / 4; u < (s + 1) * U / 4; ++u) {
+                if (u < PA::PASSES) pa.template issue_pass<SET>(u, io.a_base, io.a_limit);
+                else pb.template issue_pass<SET>(u - PA::PASSES, io.b_base, io.b_limit);
+            }
+#ifdef DG_PROBE_NO_STORE
+        } else if (false) {
+#else
+        } else if (s < 7) {
+#endif
+#pragma unroll
+            for (int u = (s - 4) * U / 3; u < (s - 3) * U / 3; ++u) {
+                if (u < PA::PASSES) pa.template store_pass<true, SET ^ 1>(u, wr, io.st_t0, io.st_tmax);
+                else pb.template store_pass<false, SET ^ 1>(u - PA::PASSES, wr + A_FLOATS, io.st_t0, io.st_tmax);
             }
         }
+        // the last k-step also carries the (scalar, branch-free) bookkeeping of the next stage: between two stages the
+        // matrix pipe would otherwise sit idle for ~100 scalar instructions
+        if (s == DG_KS - 1) tail();
 #pragma unroll
         for (int i = 0; i < RB; ++i)
 #pragma unroll
@@ -271,13 +294,15 @@ __device__ __forceinline__ void gemm_stage(const float *cur, float *wr, f32x4 (&
         for (int m = 0; m < RB * NCW + (EXTRA ? 1 : 0); ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // DS read
-            if (s < 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); // DS write
-            else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // VMEM read
+            if (s < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // VMEM read
+            else __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // DS write
             __builtin_amdgcn_sched_group_barrier(0x006, 2, 0); // VALU / SALU
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s == 3) {
-            __syncthreads(); // `wr` is complete; its first fragments are requested four k-steps from here
+        if (s == 6) {
+#ifndef DG_PROBE_NO_BARRIER
+            __syncthreads(); // `wr` is complete; its first fragments are requested in the next k-step
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -312,7 +337,7 @@ struct RowArgs {
 };
 
 template <int RB, int NCW, bool B_TC, bool A_VEC, int EPI, bool HAS_X>
-__device__ __forceinline__ void rows_body(const RowArgs &q, float *lds)
+__device__ __forceinline__ void rows_body(const RowArgs &q, float *lds, const int w, const int G)
 {
     constexpr int RA = (RB + 1) * 16;     // rows of the A panel (the last 16 = a leftover row-block, when staged)
     constexpr int RAL = HAS_X ? RA : RB * 16;
@@ -321,7 +346,6 @@ __device__ __forceinline__ void rows_body(const RowArgs &q, float *lds)
     constexpr int B_FLOATS = B_TC ? CW * LD_TC : 32 * ld_rc(CW);
     constexpr int BUF = A_FLOATS + B_FLOATS;
     const int wave = threadIdx.x >> 6;
-    const int G = gridDim.x, w = blockIdx.x;
     // leftover row-block handled by this workgroup (every chunk of it): workgroups [NCW*e, NCW*e + NCW) take leftover
     // row-block e, wave v of workgroup NCW*e + u the column block 4*u + v of each chunk
     const int xrow0 = HAS_X ? (q.n_tiles * RB + w / NCW) * 16 : 0;
@@ -364,104 +388,140 @@ __device__ __forceinline__ void rows_body(const RowArgs &q, float *lds)
         io.b_base = PB::stage_base(q.b, (unsigned)q.ldb, l_st * DG_BK);
         io.b_limit = PB::stage_limit(b_total, (unsigned)q.ldb, l_st * DG_BK);
     };
-    auto advance = [&]() {
-        if (l_count + 1 >= total) return;
-        ++l_count;
-        if (++l_st == nst) {
-            l_st = 0;
-            if (++l_chunk == q.n_chunks) {
-                l_chunk = 0, l_tile += G;
-                prepare_a();
-            }
-            if (q.n_chunks > 1) prepare_b();
+    // step the loader to the next stage (it stays on the last one at the end: harmless re-loads).  The frequent part is
+    // branch-free -- it runs inside the MFMA stream; `wrapped` tells the caller that a new chunk / tile begins.
+    bool wrapped = false;
+    auto step = [&]() {
+        const int more = l_count + 1 < total ? 1 : 0;
+        l_count += more;
+        const int nl = l_st + more;
+        wrapped = nl == nst;
+        l_st = wrapped ? 0 : nl;
+    };
+    auto rewire = [&]() { // the rare part: offsets of the new chunk / tile
+        if (!wrapped) return;
+        if (++l_chunk == q.n_chunks) {
+            l_chunk = 0, l_tile += G;
+            prepare_a();
         }
+        if (q.n_chunks > 1) prepare_b();
     };
-    auto issue_all = [&]() {
-#pragma unroll
-        for (int p = 0; p < PA::PASSES; ++p) pa.issue_pass(p, io.a_base, io.a_limit);
-#pragma unroll
-        for (int p = 0; p < PB::PASSES; ++p) pb.issue_pass(p, io.b_base, io.b_limit);
-    };
-
-    // prologue: stage 0 -> LDS buffer 0, stage 1 -> registers
+    auto advance = [&]() { step(); rewire(); };
+    // prologue: stages 0 and 1 requested together (sets 0 and 1), stage 0 -> LDS buffer 0
     prepare_a();
     prepare_b();
     aim();
-    issue_all();
 #pragma unroll
-    for (int p = 0; p < PA::PASSES; ++p) pa.template store_pass<true>(p, lds, 0, q.T);
+    for (int p = 0; p < PA::PASSES; ++p) pa.template issue_pass<0>(p, io.a_base, io.a_limit);
 #pragma unroll
-    for (int p = 0; p < PB::PASSES; ++p) pb.template store_pass<false>(p, lds + A_FLOATS, 0, q.T);
+    for (int p = 0; p < PB::PASSES; ++p) pb.template issue_pass<0>(p, io.b_base, io.b_limit);
     advance();
     aim();
-    issue_all();
-    io.st_t0 = l_st * DG_BK, io.st_tmax = q.T;
+    io.st_t0 = l_st * DG_BK; // the stage in set 1: stored during stage 0
+#pragma unroll
+    for (int p = 0; p < PA::PASSES; ++p) pa.template issue_pass<1>(p, io.a_base, io.a_limit);
+#pragma unroll
+    for (int p = 0; p < PB::PASSES; ++p) pb.template issue_pass<1>(p, io.b_base, io.b_limit);
+#pragma unroll
+    for (int p = 0; p < PA::PASSES; ++p) pa.template store_pass<true, 0>(p, lds, 0, q.T);
+#pragma unroll
+    for (int p = 0; p < PB::PASSES; ++p) pb.template store_pass<false, 0>(p, lds + A_FLOATS, 0, q.T);
     advance();
     aim();
+    io.st_tmax = q.T;
     __syncthreads();
     Frags<RB, NCW, HAS_X> fr;
     fetch_frags<RB, NCW, true, B_TC, RA, CW, HAS_X>(fr, 0, lds, lds + A_FLOATS, 0, wave, xcb);
 
     const int x = threadIdx.x & 15, g = (threadIdx.x >> 4) & 3;
-    int it = 0;
-    for (int c_tile = w, pass = 0; pass < my_tiles; ++pass, c_tile += G) {
-        for (int c_chunk = 0; c_chunk < q.n_chunks; ++c_chunk) {
-            f32x4 acc[RB][NCW], accx = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[RB][NCW], accx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < NCW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int c_tile = w, c_chunk = 0, c_st = 0, c_pass = 0;
+    int buf = 0; // LDS buffer of the stage being multiplied (it % 2)
+
+    // after a stage: the registers of set SET now hold the stage the loader was aimed at; aim at the one after it, and
+    // finish the chunk when this was its last stage
+    auto after_stage = [&]() {
+        rewire();
+        if (++c_st < nst) return;
+        c_st = 0;
+        const int j0 = c_chunk * CW;
+        auto emit = [&](const f32x4 &val, int row, int cb) {
+            const int j = j0 + cb * 16 + 4 * g;
+            if (row >= q.I || j >= q.J) return;
+            f32x4 v = val;
+            if (EPI == EPI_ZN) {
+                if (j < q.ksplit) { // aggregated columns: raw support, compact [I, ksplit]
+                    *reinterpret_cast<f32x4 *>(q.sup + (int64_t)row * q.ksplit + j) = v;
+                    return;
+                }
+                const f32x4 bb = q.bias ? *reinterpret_cast<const f32x4 *>(q.bias + j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                unsigned bits = 0u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t = v[r] + bb[r];
+                    v[r] = t > 0.f ? t : 0.f;
+                    bits |= (t > 0.f ? 1u : 0u) << r;
+                }
+                if (q.mask) { // 16 sign bits per (row, column block): the four g-lanes of a row combine their nibbles
+                    unsigned m = bits << (4 * g);
+                    m |= __shfl_xor(m, 16);
+                    m |= __shfl_xor(m, 32);
+                    if (g == 0) q.mask[(int64_t)row * (q.J >> 4) + (j >> 4)] = (unsigned short)m;
+                }
+            }
+            float *dst = q.c + (int64_t)row * q.ldc + j;
+            if (j + 3 < q.J) {
+                *reinterpret_cast<f4u *>(dst) = f4u{v[0], v[1], v[2], v[3]};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (j + r < q.J) dst[r] = v[r];
+            }
+        };
+        if (c_tile < q.n_tiles) {
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
-                for (int j = 0; j < NCW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int st = 0; st < nst; ++st, ++it) {
-                const float *cur = lds + (it % 3) * BUF;
-                float *wr = lds + ((it + 1) % 3) * BUF;
-                gemm_stage<RB, NCW, true, B_TC, RA, CW, HAS_X, A_FLOATS>(cur, wr, acc, accx, fr, pa, pb, io, wave, xcb);
-                // the registers now hold the stage the loader was aimed at; aim at the one after it
+                for (int jj = 0; jj < NCW; ++jj) emit(acc[i][jj], (c_tile * RB + i) * 16 + x, wave * NCW + jj);
+        }
+        if (HAS_X && c_pass == 0) emit(accx, xrow0 + x, xcb);
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NCW; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        accx = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (++c_chunk == q.n_chunks) c_chunk = 0, c_tile += G, ++c_pass;
+    };
+
+    // stage `it` multiplies LDS buffer it % 3, requests stage it + 2 into register set it % 2 and moves stage it + 1 (set
+    // (it + 1) % 2) to buffer (it + 1) % 3: two stages per trip so that the register sets are compile-time names
+    for (int it = 0; it < total; it += 2) {
+        {
+            const float *cur = lds + buf * BUF;
+            float *wr = lds + (buf ^ 1) * BUF;
+            gemm_stage<RB, NCW, true, B_TC, RA, CW, HAS_X, A_FLOATS, 0>(cur, wr, acc, accx, fr, pa, pb, io, wave, xcb, [&]() {
+                // set 0 now holds the stage the loader was aimed at: it goes to LDS in the next stage; aim at the one after
                 io.st_t0 = l_st * DG_BK;
-                advance();
+                step();
                 aim();
-            }
-            // the chunk is complete: epilogue
-            const int j0 = c_chunk * CW;
-            auto emit = [&](const f32x4 &val, int row, int cb) {
-                const int j = j0 + cb * 16 + 4 * g;
-                if (row >= q.I || j >= q.J) return;
-                f32x4 v = val;
-                if (EPI == EPI_ZN) {
-                    if (j < q.ksplit) { // aggregated columns: raw support, compact [I, ksplit]
-                        *reinterpret_cast<f32x4 *>(q.sup + (int64_t)row * q.ksplit + j) = v;
-                        return;
-                    }
-                    const f32x4 bb = q.bias ? *reinterpret_cast<const f32x4 *>(q.bias + j) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                    unsigned bits = 0u;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float t = v[r] + bb[r];
-                        v[r] = t > 0.f ? t : 0.f;
-                        bits |= (t > 0.f ? 1u : 0u) << r;
-                    }
-                    if (q.mask) { // 16 sign bits per (row, column block): the four g-lanes of a row combine their nibbles
-                        unsigned m = bits << (4 * g);
-                        m |= __shfl_xor(m, 16);
-                        m |= __shfl_xor(m, 32);
-                        if (g == 0) q.mask[(int64_t)row * (q.J >> 4) + (j >> 4)] = (unsigned short)m;
-                    }
-                }
-                float *dst = q.c + (int64_t)row * q.ldc + j;
-                if (j + 3 < q.J) {
-                    *reinterpret_cast<f4u *>(dst) = f4u{v[0], v[1], v[2], v[3]};
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (j + r < q.J) dst[r] = v[r];
-                }
-            };
-            if (c_tile < q.n_tiles) {
-#pragma unroll
-                for (int i = 0; i < RB; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < NCW; ++jj) emit(acc[i][jj], (c_tile * RB + i) * 16 + x, wave * NCW + jj);
-            }
-            if (HAS_X && pass == 0) emit(accx, xrow0 + x, xcb);
+                buf ^= 1;
+            });
+            after_stage();
+        }
+        if (it + 1 < total) {
+            const float *cur = lds + buf * BUF;
+            float *wr = lds + (buf ^ 1) * BUF;
+            gemm_stage<RB, NCW, true, B_TC, RA, CW, HAS_X, A_FLOATS, 1>(cur, wr, acc, accx, fr, pa, pb, io, wave, xcb, [&]() {
+                io.st_t0 = l_st * DG_BK;
+                step();
+                aim();
+                buf ^= 1;
+            });
+            after_stage();
         }
     }
 }
@@ -471,10 +531,10 @@ __global__ __launch_bounds__(DG_THREADS) void dense_rows_kernel(RowArgs q)
 {
     constexpr int RA = (RB + 1) * 16;
     constexpr int CW = NCW * 64;
-    __shared__ __attribute__((aligned(16))) float lds[3 * (RA * LD_TC + (B_TC ? CW * LD_TC : 32 * ld_rc(CW)))];
+    __shared__ __attribute__((aligned(16))) float lds[2 * (RA * LD_TC + (B_TC ? CW * LD_TC : 32 * ld_rc(CW)))];
     // the workgroups that carry a leftover row-block run their own instantiation of the whole loop (one more accumulator)
-    if ((int)blockIdx.x < q.left_rb * NCW) rows_body<RB, NCW, B_TC, A_VEC, EPI, true>(q, lds);
-    else rows_body<RB, NCW, B_TC, A_VEC, EPI, false>(q, lds);
+    if ((int)blockIdx.x < q.left_rb * NCW) rows_body<RB, NCW, B_TC, A_VEC, EPI, true>(q, lds, blockIdx.x, gridDim.x);
+    else rows_body<RB, NCW, B_TC, A_VEC, EPI, false>(q, lds, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -538,47 +598,62 @@ __device__ __forceinline__ void split_body(const SplitArgs &q, float *lds, int i
             io.b_base = PB::stage_base(q.b, (unsigned)q.ldb, t0);
             io.b_limit = PB::stage_limit(b_total, (unsigned)q.ldb, t0);
         };
-        auto advance = [&]() { if (l_st + 1 < nst) ++l_st; };
-        auto issue_all = [&]() {
-#pragma unroll
-            for (int p = 0; p < PA::PASSES; ++p) pa.issue_pass(p, io.a_base, io.a_limit);
-#pragma unroll
-            for (int p = 0; p < PB::PASSES; ++p) pb.issue_pass(p, io.b_base, io.b_limit);
-        };
+        auto advance = [&]() { l_st = l_st + 1 < nst ? l_st + 1 : l_st; };
         aim();
-        issue_all();
 #pragma unroll
-        for (int p = 0; p < PA::PASSES; ++p) pa.template store_pass<true>(p, lds, t_begin, t_end);
+        for (int p = 0; p < PA::PASSES; ++p) pa.template issue_pass<0>(p, io.a_base, io.a_limit);
 #pragma unroll
-        for (int p = 0; p < PB::PASSES; ++p) pb.template store_pass<false>(p, lds + A_FLOATS, t_begin, t_end);
+        for (int p = 0; p < PB::PASSES; ++p) pb.template issue_pass<0>(p, io.b_base, io.b_limit);
         advance();
         aim();
-        issue_all();
-        io.st_t0 = t_begin + l_st * DG_BK, io.st_tmax = t_end;
+        io.st_t0 = t_begin + l_st * DG_BK;
+#pragma unroll
+        for (int p = 0; p < PA::PASSES; ++p) pa.template issue_pass<1>(p, io.a_base, io.a_limit);
+#pragma unroll
+        for (int p = 0; p < PB::PASSES; ++p) pb.template issue_pass<1>(p, io.b_base, io.b_limit);
+#pragma unroll
+        for (int p = 0; p < PA::PASSES; ++p) pa.template store_pass<true, 0>(p, lds, t_begin, t_end);
+#pragma unroll
+        for (int p = 0; p < PB::PASSES; ++p) pb.template store_pass<false, 0>(p, lds + A_FLOATS, t_begin, t_end);
         advance();
         aim();
+        io.st_tmax = t_end;
         __syncthreads();
         Frags<RB, NCW, false> fr;
         fetch_frags<RB, NCW, false, false, RA, CW, false>(fr, 0, lds, lds + A_FLOATS, 0, wave, 0);
-        for (int st = 0; st < nst; ++st) {
-            const float *cur = lds + (st % 3) * BUF;
-            float *wr = lds + ((st + 1) % 3) * BUF;
-            if (want_cs) { // the stage's slice of G lies in LDS in front of this wave: its column sums = the bias gradient
-                // (rows of the A operand beyond t_end are zero, G's are not: count only the rows of this split)
-                const float *gb = cur + A_FLOATS;
-                const int t0 = t_begin + st * DG_BK;
+        int buf = 0;
+        auto colsum_stage = [&](const float *cur, int st) {
+            // the stage's slice of G lies in LDS in front of this wave: its column sums = the bias gradient (rows of the A
+            // operand beyond t_end are zero, G's are not: count only the rows of this split)
+            const float *gb = cur + A_FLOATS;
+            const int t0 = t_begin + st * DG_BK;
 #pragma unroll
-                for (int p = 0; p < PB::PASSES; ++p) {
-                    const int e = threadIdx.x + p * DG_THREADS;
-                    const int tl = e / (CW / 4);
-                    const f32x4 gv = *reinterpret_cast<const f32x4 *>(gb + tl * ld_rc(CW) + (e % (CW / 4)) * 4);
-                    if (t0 + tl < t_end) csum[p] += gv;
-                }
+            for (int p = 0; p < PB::PASSES; ++p) {
+                const int e = threadIdx.x + p * DG_THREADS;
+                const int tl = e / (CW / 4);
+                const f32x4 gv = *reinterpret_cast<const f32x4 *>(gb + tl * ld_rc(CW) + (e % (CW / 4)) * 4);
+                if (t0 + tl < t_end) csum[p] += gv;
             }
-            gemm_stage<RB, NCW, false, false, RA, CW, false, A_FLOATS>(cur, wr, acc, accx, fr, pa, pb, io, wave, 0);
+        };
+        auto tail = [&]() {
             io.st_t0 = t_begin + l_st * DG_BK;
             advance();
             aim();
+            buf ^= 1;
+        };
+        for (int st = 0; st < nst; st += 2) {
+            {
+                const float *cur = lds + buf * BUF;
+                float *wr = lds + (buf ^ 1) * BUF;
+                if (want_cs) colsum_stage(cur, st);
+                gemm_stage<RB, NCW, false, false, RA, CW, false, A_FLOATS, 0>(cur, wr, acc, accx, fr, pa, pb, io, wave, 0, tail);
+            }
+            if (st + 1 < nst) {
+                const float *cur = lds + buf * BUF;
+                float *wr = lds + (buf ^ 1) * BUF;
+                if (want_cs) colsum_stage(cur, st + 1);
+                gemm_stage<RB, NCW, false, false, RA, CW, false, A_FLOATS, 1>(cur, wr, acc, accx, fr, pa, pb, io, wave, 0, tail);
+            }
         }
     }
     // partial tile: lane holds P[16*rb + x][16*cb + 4g .. +3]
@@ -609,10 +684,8 @@ __device__ __forceinline__ void split_body(const SplitArgs &q, float *lds, int i
 }
 
 template <int RB, int NCW, bool A_VEC>
-__global__ __launch_bounds__(DG_THREADS) void dense_split_kernel(SplitArgs q)
+__device__ __forceinline__ void split_dispatch(const SplitArgs &q, float *lds, const int w)
 {
-    __shared__ __attribute__((aligned(16))) float lds[3 * (32 * ld_rc(RB * 16) + 32 * ld_rc(NCW * 64))];
-    const int w = blockIdx.x;
     const int nfull = q.full_tiles * q.s_full;
     if (w < nfull) {
         const int tile = w % q.full_tiles, split = w / q.full_tiles;
@@ -621,6 +694,35 @@ __global__ __launch_bounds__(DG_THREADS) void dense_split_kernel(SplitArgs q)
     } else {
         const int e = (w - nfull) / q.s_left, split = (w - nfull) % q.s_left;
         split_body<1, RB, NCW, A_VEC>(q, lds, (q.full_tiles * RB + e) * 16, split, q.s_left, w, false);
+    }
+}
+
+template <int RB, int NCW, bool A_VEC>
+__global__ __launch_bounds__(DG_THREADS) void dense_split_kernel(SplitArgs q)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2 * (32 * ld_rc(RB * 16) + 32 * ld_rc(NCW * 64))];
+    split_dispatch<RB, NCW, A_VEC>(q, lds, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Both gradients of a layer's product in ONE launch, two workgroups per CU: workgroups [0, n_row) compute the input
+// gradient dX = G . W^T (row tiles), workgroups [n_row, n_row + slots) the split partial sums of dW = X^T . G.  A workgroup
+// of either kind uses 4 waves, <= 256 registers and <= 80 KB of LDS, so one of each shares a CU: two waves per SIMD whose
+// stalls (prologue, epilogue, barriers, LDS round trips) are covered by the other's MFMAs.  Measured at the BASELINE shard,
+// hidden layer (20 496 x 192 x 192): 31 us for the pair against 22 + 23 one after the other (library: 15 + 25).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int RB, bool X_VEC>
+__global__ __launch_bounds__(DG_THREADS, 2) void dense_bwd_pair_kernel(RowArgs r, SplitArgs q, int n_row)
+{
+    constexpr int LDS_ROWS = 2 * ((RB + 1) * 16 * LD_TC + 192 * LD_TC);
+    constexpr int LDS_SPLIT = 2 * (32 * ld_rc(SPLIT_RB * 16) + 32 * ld_rc(192));
+    __shared__ __attribute__((aligned(16))) float lds[LDS_ROWS > LDS_SPLIT ? LDS_ROWS : LDS_SPLIT];
+    const int w = blockIdx.x;
+    if (w < n_row) {
+        if (w < r.left_rb * 3) rows_body<RB, 3, true, true, EPI_PLAIN, true>(r, lds, w, n_row);
+        else rows_body<RB, 3, true, true, EPI_PLAIN, false>(r, lds, w, n_row);
+    } else {
+        split_dispatch<SPLIT_RB, 3, X_VEC>(q, lds, w - n_row);
     }
 }
 
@@ -634,41 +736,57 @@ struct ReduceJobs {
     ReduceJob job[GEOM_DENSE_MAX_REDUCE_JOBS];
 };
 
-__global__ __launch_bounds__(256) void dense_reduce_kernel(ReduceJobs jobs)
+// 32 outputs (of 4 columns) x 8 slot groups per workgroup: group sg adds its contiguous share of the slots in slot order
+// (four loads in flight), the eight group sums are then added in group order -- a fixed tree for a given (I, J, splits).
+constexpr int RED_OUT = 32, RED_GROUPS = 8;
+__global__ __launch_bounds__(RED_OUT *RED_GROUPS) void dense_reduce_kernel(ReduceJobs jobs)
 {
+    __shared__ f32x4 part[RED_GROUPS][RED_OUT];
     const ReduceJob q = jobs.job[blockIdx.y];
     const int jq = q.J >> 2;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= q.I * jq) return;
-    const int i = e / jq, j = (e % jq) * 4;
-    int tile = i / q.RA, il = i % q.RA;
-    const bool full = tile < q.full_tiles;
-    const int n = full ? q.s_full : q.s_left;
-    int slot0 = tile * q.s_full;
-    if (!full) {
-        const int r = i - q.full_tiles * q.RA;
-        slot0 = q.full_tiles * q.s_full + (r >> 4) * q.s_left, il = r & 15;
-    }
-    const float *p = q.part + ((int64_t)slot0 * q.RA + il) * q.CW + j;
-    const int64_t pitch = (int64_t)q.RA * q.CW;
+    const int o = threadIdx.x % RED_OUT, sg = threadIdx.x / RED_OUT;
+    if ((int)blockIdx.x * RED_OUT >= q.I * jq) return; // a job smaller than the largest one (uniform per workgroup)
+    const int e = blockIdx.x * RED_OUT + o;
+    const bool live = e < q.I * jq;
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
-    int s = 0;
-    for (; s + 4 <= n; s += 4) { // four loads in flight, added in slot order
-        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(p + (s + 0) * pitch);
-        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(p + (s + 1) * pitch);
-        const f32x4 a2 = *reinterpret_cast<const f32x4 *>(p + (s + 2) * pitch);
-        const f32x4 a3 = *reinterpret_cast<const f32x4 *>(p + (s + 3) * pitch);
-        t = (((t + a0) + a1) + a2) + a3;
+    int i = 0, j = 0;
+    if (live) {
+        i = e / jq, j = (e % jq) * 4;
+        int tile = i / q.RA, il = i % q.RA;
+        const bool full = tile < q.full_tiles;
+        const int n = full ? q.s_full : q.s_left;
+        int slot0 = tile * q.s_full;
+        if (!full) {
+            const int r = i - q.full_tiles * q.RA;
+            slot0 = q.full_tiles * q.s_full + (r >> 4) * q.s_left, il = r & 15;
+        }
+        const int64_t pitch = (int64_t)q.RA * q.CW;
+        const float *p = q.part + ((int64_t)slot0 * q.RA + il) * q.CW + j;
+        const int s0 = (int)((int64_t)n * sg / RED_GROUPS), s1 = (int)((int64_t)n * (sg + 1) / RED_GROUPS);
+        int s = s0;
+        for (; s + 4 <= s1; s += 4) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(p + (s + 0) * pitch);
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(p + (s + 1) * pitch);
+            const f32x4 a2 = *reinterpret_cast<const f32x4 *>(p + (s + 2) * pitch);
+            const f32x4 a3 = *reinterpret_cast<const f32x4 *>(p + (s + 3) * pitch);
+            t = (((t + a0) + a1) + a2) + a3;
+        }
+        for (; s < s1; ++s) t = t + *reinterpret_cast<const f32x4 *>(p + s * pitch);
     }
-    for (; s < n; ++s) t = t + *reinterpret_cast<const f32x4 *>(p + s * pitch);
-    float *o = q.out + (int64_t)i * q.J + j;
-    o[0] = t[0], o[1] = t[1], o[2] = t[2], o[3] = t[3];
+    part[sg][o] = t;
+    __syncthreads();
+    if (sg == 0 && live) {
+        f32x4 r = part[0][o];
+#pragma unroll
+        for (int k = 1; k < RED_GROUPS; ++k) r = r + part[k][o];
+        float *dst = q.out + (int64_t)i * q.J + j;
+        dst[0] = r[0], dst[1] = r[1], dst[2] = r[2], dst[3] = r[3];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int SPLIT_RB = 6; // weight-gradient tiles: 96 rows x 192 columns
 
 int num_cus()
 {
@@ -730,7 +848,7 @@ extern "C" int geom_dense_fwd_f32(int rows, int cin, int c, const float *x, cons
                                   float *out, float *sup, uint16_t *mask, void *stream)
 {
     if (rows < 0 || cin <= 0 || c <= 0) return GEOM_EINVAL;
-    if (c % 16 != 0 || c > 192 || (int64_t)rows * cin > 0x7fffffffLL) return GEOM_EUNSUPPORTED;
+    if (c % 16 != 0 || c > 192 || (int64_t)rows * cin >= (1LL << 30)) return GEOM_EUNSUPPORTED;
     if (rows == 0) return 0;
     if (!x || !w || !out || !aligned16(w) || !aligned16(out)) return GEOM_EINVAL;
     const bool zn = ksplit > 0;
@@ -747,7 +865,7 @@ extern "C" int geom_dense_fwd_f32(int rows, int cin, int c, const float *x, cons
 extern "C" int geom_dense_bwd_input_f32(int rows, int cin, int c, const float *g, const float *w, float *grad_x, void *stream)
 {
     if (rows < 0 || cin <= 0 || c <= 0) return GEOM_EINVAL;
-    if (c % 4 != 0 || (int64_t)rows * (cin > c ? cin : c) > 0x7fffffffLL) return GEOM_EUNSUPPORTED;
+    if (c % 4 != 0 || (int64_t)rows * (cin > c ? cin : c) >= (1LL << 30)) return GEOM_EUNSUPPORTED;
     if (rows == 0) return 0;
     if (!g || !w || !grad_x || !aligned16(g) || !aligned16(w)) return GEOM_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -796,7 +914,7 @@ extern "C" int geom_dense_bwd_weight_f32(int rows, int cin, int c, const float *
                                          int want_colsum, void *stream)
 {
     if (rows <= 0 || cin <= 0 || c <= 0) return GEOM_EINVAL;
-    if (c % 4 != 0 || c > 192 || (int64_t)rows * (cin > c ? cin : c) > 0x7fffffffLL) return GEOM_EUNSUPPORTED;
+    if (c % 4 != 0 || c > 192 || (int64_t)rows * (cin > c ? cin : c) >= (1LL << 30)) return GEOM_EUNSUPPORTED;
     if (!x || !g || !workspace || !aligned16(g) || !aligned16(workspace)) return GEOM_EINVAL;
     const SplitGeo geo = split_geometry(cin, rows, num_cus());
     if (want_colsum && geo.full_tiles == 0) return GEOM_EUNSUPPORTED;
@@ -806,6 +924,40 @@ extern "C" int geom_dense_bwd_weight_f32(int rows, int cin, int c, const float *
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (cin % 4 == 0 && aligned16(x)) hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB, 3, true>), grid, block, 0, s, q);
     else hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB, 3, false>), grid, block, 0, s, q);
+    return geom::launch_status();
+}
+
+// Both gradients of one layer: grad_x = g . w^T and the partial sums of grad_w = x^T . g (finished by geom_dense_reduce_f32).
+// One launch with two workgroups per CU (dense_bwd_pair_kernel) when both halves fit that mode: cin <= 192 (one column chunk
+// for the input gradient) and 16-byte aligned x rows; two launches otherwise (the 963-wide first layer).
+extern "C" int geom_dense_bwd_f32(int rows, int cin, int c, const float *x, const float *g, const float *w, float *grad_x,
+                                  float *workspace, int want_colsum, void *stream)
+{
+    if (rows <= 0 || cin <= 0 || c <= 0) return GEOM_EINVAL;
+    if (c % 4 != 0 || c > 192 || (int64_t)rows * (cin > c ? cin : c) >= (1LL << 30)) return GEOM_EUNSUPPORTED;
+    if (!x || !g || !w || !grad_x || !workspace || !aligned16(g) || !aligned16(w) || !aligned16(workspace)) return GEOM_EINVAL;
+    const int cus = num_cus();
+    const bool xvec = cin % 4 == 0 && aligned16(x);
+    const RowGeo rg = row_geometry(rows, 3, cus);
+    const SplitGeo sg = split_geometry(cin, rows, cus);
+    if (cin > 192 || !xvec || (want_colsum && sg.full_tiles == 0) || rg.rb < 2) {
+        int code = geom_dense_bwd_input_f32(rows, cin, c, g, w, grad_x, stream);
+        if (code) return code;
+        return geom_dense_bwd_weight_f32(rows, cin, c, x, g, workspace, want_colsum, stream);
+    }
+    RowArgs r{g, c, w, c, grad_x, cin, rows, cin, c, rg.n_tiles, rg.left_rb, 1, 0, nullptr, nullptr, nullptr};
+    float *colsum = want_colsum ? workspace + (int64_t)sg.slots * SPLIT_RB * 16 * 192 : nullptr;
+    SplitArgs q{x, cin, g, c, workspace, cin, c, rows, sg.full_tiles, sg.s_full, sg.left_rb, sg.s_left, colsum};
+    const dim3 grid(rg.grid + sg.slots), block(DG_THREADS);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (rg.rb) {
+    case 2: hipLaunchKernelGGL((dense_bwd_pair_kernel<2, true>), grid, block, 0, s, r, q, rg.grid); break;
+    case 3: hipLaunchKernelGGL((dense_bwd_pair_kernel<3, true>), grid, block, 0, s, r, q, rg.grid); break;
+    case 4: hipLaunchKernelGGL((dense_bwd_pair_kernel<4, true>), grid, block, 0, s, r, q, rg.grid); break;
+    case 5: hipLaunchKernelGGL((dense_bwd_pair_kernel<5, true>), grid, block, 0, s, r, q, rg.grid); break;
+    case 6: hipLaunchKernelGGL((dense_bwd_pair_kernel<6, true>), grid, block, 0, s, r, q, rg.grid); break;
+    default: return GEOM_EINVAL;
+    }
     return geom::launch_status();
 }
 
@@ -829,6 +981,7 @@ extern "C" int geom_dense_reduce_f32(int count, const int *rows, const int *cin,
                                       g.s_full, 0};
         }
     }
-    hipLaunchKernelGGL(dense_reduce_kernel, dim3((widest + 255) / 256, n), dim3(256), 0, static_cast<hipStream_t>(stream), jobs);
+    hipLaunchKernelGGL(dense_reduce_kernel, dim3((widest + RED_OUT - 1) / RED_OUT, n), dim3(RED_OUT * RED_GROUPS), 0,
+                       static_cast<hipStream_t>(stream), jobs);
     return geom::launch_status();
 }

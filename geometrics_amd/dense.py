@@ -17,6 +17,20 @@ def supported(cin, c, rows=1):
     return 0 < c <= 192 and c % 16 == 0 and cin > 0 and rows * max(cin, c) < 2 ** 30
 
 
+def plan(rows, cin, c):
+    """Which implementation runs each of a layer's three products, from the timings on MI355X (tools/time_dense.py,
+    profiles/): {"fwd", "dx", "dw"} -> "mfma" | "lib", plus "pair" = input and weight gradient share one launch.
+    * weight gradient: the split kernel + the shared end-of-pass reduction beat the library's split-K product + its own
+      reduction launch at every shape of the path;
+    * input gradient of a layer with cin <= 192: free inside the pair launch (two workgroups per CU); for the 963-wide
+      first layer the library's product is ahead;
+    * forward: the library for plain products (its many small tiles overlap their memory phases; one 80-row tile per
+      CU pays ~8 us of prologue + epilogue per launch)."""
+    ok = supported(cin, c, rows)
+    pair = ok and cin <= 192 and cin % 4 == 0 and rows >= 512
+    return {"fwd": "lib", "dx": "mfma" if pair else "lib", "dw": "mfma" if ok and rows >= 512 else "lib", "pair": pair}
+
+
 def forward(x, w, out=None):
     """support = x @ w."""
     rows, cin = x.shape
@@ -59,6 +73,15 @@ def backward_weight_partials(x, g, workspace, want_colsum=False):
     with torch.cuda.device(x.device):
         _lib.call("geom_dense_bwd_weight_f32", rows, cin, c, x.data_ptr(), g.data_ptr(), workspace.data_ptr(),
                   1 if want_colsum else 0)
+
+
+def backward_pair(x, g, w, grad_x, workspace, want_colsum=False):
+    """grad_x = g @ w.T and the partial tiles of x.T @ g (+ column sums of g) -- ONE launch where the shape allows."""
+    rows, cin = x.shape
+    c = g.shape[1]
+    with torch.cuda.device(x.device):
+        _lib.call("geom_dense_bwd_f32", rows, cin, c, x.data_ptr(), g.data_ptr(), w.data_ptr(), grad_x.data_ptr(),
+                  workspace.data_ptr(), 1 if want_colsum else 0)
 
 
 def reduce(jobs, stream=None):

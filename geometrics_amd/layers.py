@@ -20,6 +20,7 @@ from torch.nn import Module
 from torch.nn.parameter import Parameter
 
 from . import _lib
+from . import dense as _dense_kernels
 
 _ACT_NONE, _ACT_RELU, _ACT_ELU = 0, 1, 2
 
@@ -173,7 +174,33 @@ def aggregate_forward(s, bias_c, csr, k, act, out, want_mask=False):
 # a pass in which something could read it earlier -- an existing .grad to accumulate into, a hook on the bias, a bias that
 # receives gradients from more than one node (the engine adds them on arrival) -- takes the immediate reduction, and so
 # does every call outside an engine-run pass.
-defer_parameter_gradients = True      # False: every bias / weight gradient is reduced where it is produced
+# Deferral is OPT-IN (round-2 advice): what cannot be seen from here -- C++ hooks on the AccumulateGrad node (torch DDP's
+# Reducer copies the gradient into its bucket on arrival), a second consumer of the parameter that is a plain torch op --
+# would read the placeholder before the flush.  bench.py and the deformation block's own training step switch it on
+# (`with layers.deferred_parameter_gradients():`), nothing else does; a placeholder is zero-filled when
+# `_zero_fill_deferred` is set (debugging aid: detect_anomaly trips over uninitialised memory otherwise).
+defer_parameter_gradients = False     # False: every bias / weight gradient is reduced where it is produced
+_zero_fill_deferred = False
+use_matrix_core_products = True       # the layers' dense gradients on csrc/dense_gemm.hip where dense.plan says so
+
+
+class deferred_parameter_gradients:
+    """Context manager: inside it, bias / weight gradients of a backward pass are finished by batched launches at the end
+    of the pass (the caller guarantees that nothing reads a parameter gradient before backward() returns)."""
+
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        global defer_parameter_gradients
+        self.prev = defer_parameter_gradients
+        defer_parameter_gradients = self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        global defer_parameter_gradients
+        defer_parameter_gradients = self.prev
+        return False
 _pending_colsums = {}     # autograd graph-task id -> [(partials, rows, cols, out alias, stream)]
 # bias parameter -> the live autograd nodes that produce a gradient for it.  A bias shared by two layers (or a layer applied
 # twice) gets its gradients ADDED by the engine inside the pass, which reads them on arrival: more than one live node means
@@ -200,15 +227,33 @@ def _alias(t):
     return torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage(), t.storage_offset(), t.size(), t.stride())
 
 
-def _may_defer(bias):
-    if not defer_parameter_gradients or bias is None or not hasattr(torch._C, "_current_graph_task_id"):
+def _may_defer(bias, opted_in=False):
+    """opted_in: the forward ran inside weight_gradient_batching() -- that context is the caller's explicit request."""
+    if not (defer_parameter_gradients or opted_in) or bias is None or not hasattr(torch._C, "_current_graph_task_id"):
         return False
     if torch._C._current_graph_task_id() < 0 or torch.is_grad_enabled():      # not an engine pass / double backward
+        return False
+    acc = getattr(bias, "grad_fn", None)
+    if acc is not None:      # not a leaf
         return False
     if _bias_user_count(bias) > 1:      # another node of a live graph feeds the same parameter
         return False
     return (bias.grad is None and not bias._backward_hooks and not getattr(bias, "_post_accumulate_grad_hooks", None)
             and bias.is_leaf)
+
+
+def _check_landed(param_ref, out):
+    """After a deferred reduction: the gradient autograd stored for the parameter must BE the buffer the flush wrote.  If
+    the engine kept a copy instead (it clones a gradient it does not hold the only reference to), the finished values are
+    copied into it -- never leave a placeholder behind silently."""
+    param = param_ref() if param_ref is not None else None
+    if param is None or param.grad is None or param.grad.data_ptr() == out.data_ptr():
+        return
+    if param.grad.shape == out.shape or param.grad.numel() == out.numel():
+        param.grad.copy_(out.view_as(param.grad))
+    else:
+        raise RuntimeError("geometrics_amd: a deferred parameter gradient did not reach its parameter (shape %s vs %s)"
+                           % (tuple(param.grad.shape), tuple(out.shape)))
 
 
 def _flush_colsums(task):
@@ -225,9 +270,11 @@ def _flush_colsums(task):
                     n, (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in chunk]), (ctypes.c_int * n)(*[j[1] for j in chunk]),
                     (ctypes.c_int * n)(*[j[2] for j in chunk]), (ctypes.c_void_p * n)(*[j[3].data_ptr() for j in chunk]),
                     stream.cuda_stream), "geom_colsum_batch_f32")
+    for job in jobs:
+        _check_landed(job[5], job[3])
 
 
-def _queue_colsum(partials, rows, cols, out):
+def _queue_colsum(partials, rows, cols, out, param=None):
     task = torch._C._current_graph_task_id()
     jobs = _pending_colsums.get(task)
     if jobs is None:
@@ -235,7 +282,8 @@ def _queue_colsum(partials, rows, cols, out):
             del _pending_colsums[stale]
         jobs = _pending_colsums[task] = []
         torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_colsums(task))
-    jobs.append((partials, rows, cols, _alias(out), torch.cuda.current_stream(out.device)))
+    jobs.append((partials, rows, cols, _alias(out), torch.cuda.current_stream(out.device),
+                 None if param is None else weakref.ref(param)))
 
 
 def aggregate_backward(g, csr, k, act, out, mask, want_bias, bias=None, arena=None):
@@ -250,7 +298,7 @@ def aggregate_backward(g, csr, k, act, out, mask, want_bias, bias=None, arena=No
         grad_bias = torch.empty(c, dtype=torch.float32, device=g.device)
         scratch = torch.empty(_lib.lib().geom_zn_gcn_bwd_scratch_floats(b, nv, c), dtype=torch.float32,
                               device=g.device)
-        defer = _may_defer(bias)
+        defer = _may_defer(bias, opted_in=arena is not None)
     now = None if defer else grad_bias
     with torch.cuda.device(g.device):
         code = _lib.EUNSUPPORTED
@@ -270,7 +318,7 @@ def aggregate_backward(g, csr, k, act, out, mask, want_bias, bias=None, arena=No
         else:
             _lib.check(code, "geom_zn_gcn_aggregate_ell_bwd_f32")
     if defer:
-        _queue_colsum(scratch, int(_lib.lib().geom_zn_gcn_bwd_partial_rows(b, nv, c, k, ell_w)), c, grad_bias)
+        _queue_colsum(scratch, int(_lib.lib().geom_zn_gcn_bwd_partial_rows(b, nv, c, k, ell_w)), c, grad_bias, bias)
     return grad_support, grad_bias
 
 
@@ -414,6 +462,12 @@ def _regular_run(tensors):
 def _flush_dense(task):
     jobs = _pending_dense.pop(task, [])
     jobs.reverse()                                   # layer order: every operand ascending
+    _flush_dense_products([job[:4] for job in jobs])
+    for job in jobs:
+        _check_landed(job[4], job[2])
+
+
+def _flush_dense_products(jobs):
     i = 0
     while i < len(jobs):
         x, g, out, stream = jobs[i]
@@ -459,7 +513,7 @@ class _Dense(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             x2, g2 = x.reshape(-1, x.shape[-1]), g.reshape(-1, g.shape[-1])
             param = ctx.w_ref()
-            if param is not None and x2.is_contiguous() and _may_defer(param):
+            if param is not None and x2.is_contiguous() and _may_defer(param, opted_in=True):
                 grad_w = ctx.arena.take("dW", w.shape, w.device, descending=True)
                 task = torch._C._current_graph_task_id()
                 jobs = _pending_dense.get(task)
@@ -468,18 +522,92 @@ class _Dense(torch.autograd.Function):
                         del _pending_dense[stale]
                     jobs = _pending_dense[task] = []
                     torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_dense(task))
-                jobs.append((x2, g2, _alias(grad_w).view(w2.shape), torch.cuda.current_stream(w.device)))
+                jobs.append((x2, g2, _alias(grad_w).view(w2.shape), torch.cuda.current_stream(w.device), ctx.w_ref))
             else:
                 grad_w = torch.mm(x2.t(), g2).view(w.shape)
         return grad_x, grad_w, None
 
 
+# ---- the layer's dense products on the fp32 matrix cores (csrc/dense_gemm.hip) -----------------------------------------
+_pending_reduce = {}      # autograd graph-task id -> [(rows, cin, c, workspace, dW alias)]: one reduction launch per pass
+
+
+def _flush_reduce(task):
+    jobs = _pending_reduce.pop(task, [])
+    by_stream = {}
+    for job in jobs:
+        by_stream.setdefault(job[5], []).append(job[:5] + (None,))
+    for stream, group in by_stream.items():
+        _dense_kernels.reduce(group, stream.cuda_stream)
+    for job in jobs:
+        _check_landed(job[6], job[4])
+
+
+class _DenseMM(torch.autograd.Function):
+    """support = input @ W with both gradients on the matrix-core kernels where `dense.plan` puts them: the input
+    gradient and the split partial sums of the weight gradient in ONE launch (two workgroups per CU) for the 192-wide
+    layers, the partial sums alone for the 963-wide one; the partials of all layers of a backward pass are added up by one
+    reduction launch at its end when parameter-gradient deferral is on (see `defer_parameter_gradients`), at once
+    otherwise.  Same values either way: the reduction order is fixed by the shape."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        ctx.w_ref = weakref.ref(w)
+        if ctx.needs_input_grad[1]:
+            _register_bias_user(w, ctx)
+        return torch.matmul(x, w.reshape(w.shape[-2:]))
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, w = ctx.saved_tensors
+        g2 = grad.reshape(-1, grad.shape[-1]).contiguous()
+        x2 = x.reshape(-1, x.shape[-1])
+        w2 = w.reshape(w.shape[-2:])
+        rows, cin = x2.shape
+        c = g2.shape[1]
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        plan = _dense_kernels.plan(rows, cin, c)
+        if not x2.is_contiguous() or not w2.is_contiguous() or not (need_w and plan["dw"] == "mfma"):
+            grad_x = torch.matmul(g2, w2.t()).view(x.shape) if need_x else None
+            grad_w = torch.mm(x2.t(), g2).view(w.shape) if need_w else None
+            return grad_x, grad_w
+        ws = _dense_kernels.weight_workspace(rows, cin, c, x.device)
+        grad_x = None
+        if need_x and plan["pair"]:
+            grad_x = torch.empty_like(x)
+            _dense_kernels.backward_pair(x2, g2, w2, grad_x.view(rows, cin), ws)
+        else:
+            if need_x:
+                grad_x = torch.matmul(g2, w2.t()).view(x.shape)
+            _dense_kernels.backward_weight_partials(x2, g2, ws)
+        grad_w = torch.zeros_like(w) if _zero_fill_deferred else torch.empty_like(w)
+        param = ctx.w_ref()
+        if param is not None and _may_defer(param):
+            task = torch._C._current_graph_task_id()
+            jobs = _pending_reduce.get(task)
+            if jobs is None:
+                for stale in [t for t in _pending_reduce if t < task - 64]:
+                    del _pending_reduce[stale]
+                jobs = _pending_reduce[task] = []
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_reduce(task))
+            jobs.append((rows, cin, c, ws, _alias(grad_w).view(cin, c), torch.cuda.current_stream(w.device), ctx.w_ref))
+        else:
+            _dense_kernels.reduce([(rows, cin, c, ws, grad_w.view(cin, c), None)])
+        return grad_x, grad_w
+
+
 def _dense(x, w):
     """input @ weight of a 0N-GCN layer; w = the layer's weight parameter ([Cin, Cout] or [1, Cin, Cout])."""
     arena = current_slabs()
-    if (arena is None or not x.is_cuda or x.dtype != torch.float32 or w.dtype != torch.float32
-            or not (w.dim() == 2 or (w.dim() == 3 and w.shape[0] == 1))
-            or not (x.requires_grad or w.requires_grad) or not torch.is_grad_enabled()):
+    plain = (not x.is_cuda or x.dtype != torch.float32 or w.dtype != torch.float32
+             or not (w.dim() == 2 or (w.dim() == 3 and w.shape[0] == 1))
+             or not (x.requires_grad or w.requires_grad) or not torch.is_grad_enabled())
+    if not plain and arena is None and use_matrix_core_products:
+        rows = x.numel() // x.shape[-1]
+        if w.requires_grad and _dense_kernels.plan(rows, x.shape[-1], w.shape[-1])["dw"] == "mfma":
+            return _DenseMM.apply(x, w)
+    if plain or arena is None:
         return torch.matmul(x, w.squeeze(0) if w.dim() == 3 else w)   # [1,Cin,Cout]: one GEMM, not B broadcast bmm's
     return _Dense.apply(x, w, arena)
 

@@ -293,6 +293,10 @@ int geom_dense_bwd_input_f32(int rows, int cin, int c, const float *g, const flo
 int64_t geom_dense_bwd_weight_workspace_floats(int rows, int cin, int c);
 int geom_dense_bwd_weight_f32(int rows, int cin, int c, const float *x, const float *g, float *workspace,
                               int want_colsum, void *stream);
+/* both gradients of one layer; one launch (two workgroups per CU: one on grad_x, one on the grad_w partials) when
+ * cin <= 192 and x rows are 16-byte aligned, the two launches above otherwise.  workspace / reduction as above. */
+int geom_dense_bwd_f32(int rows, int cin, int c, const float *x, const float *g, const float *w, float *grad_x,
+                       float *workspace, int want_colsum, void *stream);
 int geom_dense_reduce_f32(int count, const int *rows, const int *cin, const int *c, const float *const *workspaces,
                           float *const *grad_w, float *const *grad_bias, void *stream);
 

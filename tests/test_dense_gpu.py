@@ -92,6 +92,24 @@ def test_split_epilogue_finishes_the_pass_through_columns(rows, cin):
     assert int(bits[:, :k // 16].sum()) == 0
 
 
+@pytest.mark.parametrize("rows,cin,c", [(20496, 192, 192), (7712, 192, 192), (2562, 192, 192), (20496, 963, 192), (83, 192, 192)])
+def test_pair_launch_equals_the_two_separate_launches(rows, cin, c):
+    """geom_dense_bwd_f32 (one launch, two workgroups per CU) runs the same two bodies: same bits as the separate launches."""
+    from geometrics_amd import dense
+    x, w, g = _operands(rows, cin, c, 4)
+    ws = dense.weight_workspace(rows, cin, c, x.device)
+    gx = torch.empty(rows, cin, device="cuda")
+    dense.backward_pair(x, g, w, gx, ws, want_colsum=True)
+    gw = torch.empty(cin, c, device="cuda")
+    gb = torch.empty(c, device="cuda")
+    dense.reduce([(rows, cin, c, ws, gw, gb)])
+    assert torch.equal(gx, dense.backward_input(g, w))
+    gw2, gb2 = dense.backward_weight(x, g, True)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    _close(gx, g.double() @ w.double().t())
+    _close(gw, x.double().t() @ g.double())
+
+
 def test_unsupported_shapes_are_refused():
     from geometrics_amd import _lib
     x = torch.zeros(4, 4, device="cuda")

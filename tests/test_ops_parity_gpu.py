@@ -555,7 +555,7 @@ def test_bias_gradients_of_a_backward_pass_are_finished_in_one_batched_launch(gp
             assert not layers._pending_colsums
             return [layer.bias.grad.clone() for layer in stack], [layer._weight().grad.clone() for layer in stack]
         finally:
-            layers.defer_parameter_gradients = True
+            layers.defer_parameter_gradients = False
 
     now_b, now_w = run(False)
     later_b, later_w = run(True)
@@ -588,14 +588,17 @@ def test_bias_gradients_of_a_backward_pass_are_finished_in_one_batched_launch(gp
             assert not layers._pending_colsums
             return stack[1].bias.grad.clone()
         finally:
-            layers.defer_parameter_gradients = True
+            layers.defer_parameter_gradients = False
     assert torch.equal(tied_pass(False), tied_pass(True))
     del tied
+    # deferral is opt-in: by default nothing is pending at any time and the values are the same
+    assert layers.defer_parameter_gradients is False
     # torch.autograd.grad: captured gradients are finished when the call returns
-    h = x
-    for i, layer in enumerate(stack):
-        h = layer(h, adj, F.relu if i < 2 else None)
-    got = torch.autograd.grad(h, [layer.bias for layer in stack], g_out)
+    with layers.deferred_parameter_gradients():
+        h = x
+        for i, layer in enumerate(stack):
+            h = layer(h, adj, F.relu if i < 2 else None)
+        got = torch.autograd.grad(h, [layer.bias for layer in stack], g_out)
     assert all(torch.equal(a, b) for a, b in zip(got, now_b)) and not layers._pending_colsums
     # HIP-graph capture of forward + backward: the batched launch is part of the graph
     for p in stack.parameters():
@@ -615,7 +618,7 @@ def test_bias_gradients_of_a_backward_pass_are_finished_in_one_batched_launch(gp
     graph = torch.cuda.CUDAGraph()
     for p in stack.parameters():
         p.grad = None
-    with torch.cuda.graph(graph):
+    with layers.deferred_parameter_gradients(), torch.cuda.graph(graph):
         h = static_x
         for i, layer in enumerate(stack):
             h = layer(h, adj, F.relu if i < 2 else None)
@@ -670,9 +673,10 @@ def test_weight_gradients_of_equal_layers_come_from_one_batched_product(gpu):
     finally:
         torch.bmm = real_bmm
     assert seen == [((3, 48, 6 * V.shape[0]), seen[0][1], seen[0][2])] and seen[0][1][0] > 0 and seen[0][2][0] > 0   # ONE product for the three 48 x 48 layers
-    assert torch.equal(plain[0], batched[0]) and torch.equal(plain[1], batched[1])
-    for a, b in zip(plain[3], batched[3]):
-        assert torch.equal(a, b)
+    assert torch.equal(plain[0], batched[0])
+    close(batched[1].cpu().numpy(), plain[1].cpu().numpy(), 2e-5)   # input gradient: matrix-core kernel vs library product
+    for a, b in zip(plain[3], batched[3]):      # bias gradients: downstream of the input gradients (matrix-core kernel vs library)
+        close(b.cpu().numpy(), a.cpu().numpy(), 2e-5)
     for a, b in zip(plain[2], batched[2]):
         assert a.shape == b.shape
         close(b.cpu().numpy(), a.cpu().numpy(), 2e-5)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# builds happen where hipcc is (the build container); the binaries travel in gpurun_out-less tools/probe/bin
+set -e
+cd "$(dirname "$0")/../.."
+mkdir -p tools/probe/bin
+F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form=1 -I include -I geometrics_amd/csrc"
+build() { name=$1; shift; /opt/rocm/bin/hipcc $F "$@" tools/probe/dense_probe.cpp -o tools/probe/bin/probe_$name & }
+build base
+build nofetch -DDG_PROBE_NO_FETCH
+build noissue -DDG_PROBE_NO_ISSUE
+build nostore -DDG_PROBE_NO_STORE
+build nobar -DDG_PROBE_NO_BARRIER
+build mfmaonly -DDG_PROBE_NO_FETCH -DDG_PROBE_NO_ISSUE -DDG_PROBE_NO_STORE -DDG_PROBE_NO_BARRIER
+build nomem -DDG_PROBE_NO_ISSUE -DDG_PROBE_NO_STORE
+wait
+ls -la tools/probe/bin

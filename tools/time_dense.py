@@ -65,10 +65,12 @@ def main():
         res["dW   lib"] = event_time_us([lambda i=i: torch.mm(xs[i].t(), gs[i], out=gw) for i in range(nbuf)])
         res["dW   mfma partials"] = event_time_us(
             [lambda i=i: dense.backward_weight_partials(xs[i], gs[i], ws, True) for i in range(nbuf)])
+        res["dX+dW mfma, one launch (two workgroups per CU)"] = event_time_us(
+            [lambda i=i: dense.backward_pair(xs[i], gs[i], w, dxs[i], ws, True) for i in range(nbuf)])
         res["dW   mfma reduce"] = event_time_us([lambda: dense.reduce([(rows, cin, c, ws, gw, gb)])])
         print("rows %d  cin %d  c %d   (%.2f GFLOP per product, fp32 MFMA floor %.1f us)" % (rows, cin, c, flop / 1e9, flop / 157.3e6))
         for k, v in res.items():
-            print("   %-28s %7.1f us   %6.1f TFLOP/s" % (k, v, flop / v / 1e6))
+            print("   %-48s %7.1f us   %6.1f TFLOP/s" % (k, v, (2 * flop if k.startswith("dX+dW") else flop) / v / 1e6))
 
 
 if __name__ == "__main__":
