@@ -79,9 +79,11 @@ class Workload:
         h = self.feat
         # (layers.weight_gradient_batching() is for deep stacks -- the deformation block's twelve equal layers; for the two
         # equal layers here it was measured at +3 us per step: -8 on the products, +11 from the changed launch order)
-        for layer in self.stack:
+        for layer in self.stack[:-1]:
             h = layer(h, self.info["adj"], F.relu)
-        return ops.VertexHead.apply(self.base, h, 0.01)     # base + 0.01 * h[..., :3], one kernel each way
+        # base + 0.01 * h[..., :3] inside the last layer's aggregation launches (forward: positions from its epilogue;
+        # backward: [0.01 * grad_pos | 0] synthesised, never written or read)
+        return self.stack[-1].forward_positions(h, self.info["adj"], F.relu, self.base, 0.01)
 
     # one step = forward_backward() -> [exchange()] -> update(); captured as HIP graphs by capture()
     def forward_backward(self):

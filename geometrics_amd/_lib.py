@@ -77,6 +77,8 @@ _SIGNATURES = {
     "geom_zn_gcn_aggregate_fwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "geom_zn_gcn_aggregate_ell_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "geom_zn_gcn_aggregate_ell_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "geom_zn_gcn_aggregate_ell_head_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp],
+    "geom_zn_gcn_aggregate_ell_head_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp],
     "geom_zn_gcn_aggregate_bwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
 }
 

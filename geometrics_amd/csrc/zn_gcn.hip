@@ -304,12 +304,19 @@ struct EllArgs {
     const int *over_ptr, *over_col;
     const float *over_val;
     int b, chunks; // meshes, workgroups per mesh (filled in by the dispatcher)
+    // HEAD (the layer whose three leading output channels are a coordinate update, GEOMetrics.py:121,126,131):
+    //   forward : head_out[row] = head_in[row] + head_scale * out[row, :3]   (base positions in, new positions out)
+    //   backward: grad_out is not read at all -- it is [head_scale * head_in[row, :3] | 0 ...] by construction
+    //             (head_in = grad_pos [rows, 3]); x may be null
+    const float *head_in;
+    float *head_out;
+    float head_scale;
 };
 
 // MASK (ReLU, NC == 2 only): the forward also stores the sign of every output element as one bit (12 bits per
 // thread -> 0.66 MB per layer at the BASELINE shard), and the backward takes relu' from those bits instead of
 // re-reading the 15.7 MB forward output: 47 -> 32 MB of traffic for the backward launch.
-template <int ACT, bool BACKWARD, int W, int NC, bool MASK = false>
+template <int ACT, bool BACKWARD, int W, int NC, bool MASK = false, bool HEAD = false>
 __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a, int rows_per_block, int iters,
                                                                         float *colsum_partial)
 {
@@ -356,6 +363,12 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a
         if (BACKWARD && MASK) own_bits = a.mask[row * kg + j];
 #pragma unroll
         for (int i = BACKWARD ? 0 : 1; i <= NC; ++i) {
+            if (BACKWARD && HEAD) { // the upstream gradient is [scale * grad_pos | 0]: only the row's first float4 is non-zero
+                if (i == 0 && j == 0) {
+                    const float *gp = a.head_in + row * 3;
+                    own[0] = make_float4(a.head_scale * gp[0], a.head_scale * gp[1], a.head_scale * gp[2], 0.f);
+                }
+            } else
             own[i] = *reinterpret_cast<const float4 *>(xrow + c0 + a.k * i);
             if (BACKWARD && MASK) {
                 const unsigned m = own_bits >> (4 * i);
@@ -377,6 +390,13 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a
 #pragma unroll
         for (int n = 0; n < W; ++n) {
             const int64_t nrow = mesh_row0 + (nb[n] >= 0 ? nb[n] : r);
+            if (BACKWARD && HEAD) {
+                sv[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j == 0) {
+                    const float *gp = a.head_in + nrow * 3;
+                    sv[n] = make_float4(a.head_scale * gp[0], a.head_scale * gp[1], a.head_scale * gp[2], 0.f);
+                }
+            } else
             sv[n] = *reinterpret_cast<const float4 *>(a.x + nrow * a.c + c0);
             if (BACKWARD && MASK) nbits[n] = a.mask[nrow * kg + j];
             else if (BACKWARD && ACT != ACT_NONE) ov[n] = *reinterpret_cast<const float4 *>(a.saved + nrow * a.c + c0);
@@ -425,6 +445,13 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a
             for (int t = 0; t < TAIL; ++t) {
                 nrow[t] = mesh_row0 + tcol[t];
                 wv[t] = tval[t];
+                if (BACKWARD && HEAD) {
+                    tv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (j == 0) {
+                        const float *gp = a.head_in + nrow[t] * 3;
+                        tv[t] = make_float4(a.head_scale * gp[0], a.head_scale * gp[1], a.head_scale * gp[2], 0.f);
+                    }
+                } else
                 tv[t] = *reinterpret_cast<const float4 *>(a.x + nrow[t] * a.c + c0);
                 if (BACKWARD && MASK) tb[t] = a.mask[nrow[t] * kg + j];
                 else if (BACKWARD && ACT != ACT_NONE) to[t] = *reinterpret_cast<const float4 *>(a.saved + nrow[t] * a.c + c0);
@@ -474,6 +501,11 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_kernel(EllArgs a
                     sign_bits |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << (4 * i);
             }
             *reinterpret_cast<float4 *>(yrow + c0 + a.k * i) = v;
+            if (!BACKWARD && HEAD && i == 0 && j == 0) { // new positions = base + scale * the three leading channels
+                const float *bp = a.head_in + row * 3;
+                float *pp = a.head_out + row * 3;
+                pp[0] = bp[0] + a.head_scale * v.x, pp[1] = bp[1] + a.head_scale * v.y, pp[2] = bp[2] + a.head_scale * v.z;
+            }
         }
         if (!BACKWARD && MASK) a.mask[row * kg + j] = (unsigned short)sign_bits;
     }
@@ -512,6 +544,16 @@ void launch_ell_shape(const EllArgs &a, int w, dim3 grid, size_t lds, hipStream_
 {
     const dim3 block(GCN_THREADS);
     const int nc = ell_nc(a.c, a.k);
+    if (a.head_in) { // dispatch_ell admits it for split 3 with ReLU + mask or without activation only
+        if constexpr (ACT == ACT_RELU) {
+            if (w == 8) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 8, 2, true, true>), grid, block, lds, s, a, rpb, iters, partial);
+            else hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 16, 2, true, true>), grid, block, lds, s, a, rpb, iters, partial);
+        } else if constexpr (ACT == ACT_NONE) {
+            if (w == 8) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 8, 2, false, true>), grid, block, lds, s, a, rpb, iters, partial);
+            else hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 16, 2, false, true>), grid, block, lds, s, a, rpb, iters, partial);
+        }
+        return;
+    }
     if constexpr (ACT == ACT_RELU) {
         if (a.mask && nc == 2) {
             if (w == 8) hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 8, 2, true>), grid, block, lds, s, a, rpb, iters, partial);
@@ -531,7 +573,11 @@ int dispatch_ell(EllArgs a, int b, int w, int act, float *grad_bias, float *scra
     if (b < 0 || a.nv < 0 || a.c < 0 || a.k < 0 || a.k > a.c) return GEOM_EINVAL;
     if (!ell_supported(a.c, a.k, w)) return GEOM_EUNSUPPORTED;
     if (b == 0 || a.nv == 0) return 0;
-    if (!a.col || !a.val || !a.x || !a.y) return GEOM_EINVAL;
+    if (!a.col || !a.val || !a.y || (!a.x && !(BACKWARD && a.head_in))) return GEOM_EINVAL;
+    if (a.head_in) { // head mode: split 3, ReLU with the sign mask or no activation; the forward also needs head_out
+        if (ell_nc(a.c, a.k) != 2 || !((act == ACT_RELU && a.mask) || act == ACT_NONE) || (!BACKWARD && !a.head_out))
+            return GEOM_EUNSUPPORTED;
+    }
     if (a.mask && !(act == ACT_RELU && ell_nc(a.c, a.k) == 2)) return GEOM_EINVAL; // sign mask: ReLU, split 3 only
     if (BACKWARD && act != ACT_NONE && !a.saved && !a.mask) return GEOM_EINVAL;
     if (grad_bias && !scratch) return GEOM_EINVAL;
@@ -647,6 +693,17 @@ extern "C" int geom_zn_gcn_aggregate_ell_fwd_f32(int b, int nv, int c, int k, in
     return dispatch_ell<false>(a, b, w, act, nullptr, nullptr, stream);
 }
 
+extern "C" int geom_zn_gcn_aggregate_ell_head_fwd_f32(int b, int nv, int c, int k, int w, const int *ell_col,
+                                                      const float *ell_val, const int *over_ptr, const int *over_col,
+                                                      const float *over_val, const float *support, const float *bias,
+                                                      int act, float *out, uint16_t *relu_mask, const float *base,
+                                                      float scale, float *pos, void *stream)
+{
+    if (!base || !pos) return GEOM_EINVAL;
+    EllArgs a{ell_col, ell_val, support, bias, nullptr, out, nv, c, k, relu_mask, over_ptr, over_col, over_val, 0, 0, base, pos, scale};
+    return dispatch_ell<false>(a, b, w, act, nullptr, nullptr, stream);
+}
+
 extern "C" int64_t geom_zn_gcn_relu_mask_words(int b, int nv, int c, int k)
 {
     if (b <= 0 || nv <= 0 || ell_nc(c, k) != 2) return 0; // 0: this shape has no mask path
@@ -661,5 +718,17 @@ extern "C" int geom_zn_gcn_aggregate_ell_bwd_f32(int b, int nv, int c, int k, in
 {
     EllArgs a{ell_colT, ell_valT, grad_out, nullptr, out, grad_support, nv, c, k, const_cast<uint16_t *>(relu_mask),
               over_ptrT, over_colT, over_valT};
+    return dispatch_ell<true>(a, b, w, act, grad_bias, scratch, stream);
+}
+
+extern "C" int geom_zn_gcn_aggregate_ell_head_bwd_f32(int b, int nv, int c, int k, int w, const int *ell_colT,
+                                                      const float *ell_valT, const int *over_ptrT, const int *over_colT,
+                                                      const float *over_valT, const float *grad_pos, float scale,
+                                                      const uint16_t *relu_mask, int act, float *grad_support,
+                                                      float *grad_bias, float *scratch, void *stream)
+{
+    if (!grad_pos) return GEOM_EINVAL;
+    EllArgs a{ell_colT, ell_valT, nullptr, nullptr, nullptr, grad_support, nv, c, k, const_cast<uint16_t *>(relu_mask),
+              over_ptrT, over_colT, over_valT, 0, 0, grad_pos, nullptr, scale};
     return dispatch_ell<true>(a, b, w, act, grad_bias, scratch, stream);
 }

@@ -358,6 +358,79 @@ class _ZeroNAggregate(torch.autograd.Function):
         return (grad_support if ctx.needs_input_grad[0] else None), grad_bias, None, None, None
 
 
+class _ZeroNAggregateHead(torch.autograd.Function):
+    """positions = base + scale * act([A . S[..., :k] | S[..., k:]] + bias)[..., :3]: the aggregation of the layer whose
+    three leading channels are a stage's coordinate update (GEOMetrics.py:121,126,131), with the update in the same two
+    launches.  Forward: the aggregation kernel also writes the new positions.  Backward: the gradient of the layer output
+    is [scale * grad_pos | 0 ...] by construction -- it is never materialised (15.7 MB of zeros at the BASELINE shard) nor
+    read back; the aggregation backward synthesises it from grad_pos."""
+
+    @staticmethod
+    def forward(ctx, support, bias, base, csr, k, act, scale):
+        s = _lib.require(support, "support", torch.float32, 3)
+        base_c = _lib.require(base, "base", torch.float32, 3, 3)
+        b, nv, c = s.shape
+        bias_c = None if bias is None else _lib.require(bias, "bias", torch.float32, 1)
+        out = torch.empty_like(s)
+        pos = torch.empty_like(base_c)
+        mask = None
+        if act == _ACT_RELU:
+            mask = torch.empty(_lib.lib().geom_zn_gcn_relu_mask_words(b, nv, c, k), dtype=torch.int16, device=s.device)
+        over = csr.over or (None, None, None)
+        with torch.cuda.device(s.device):
+            _lib.call("geom_zn_gcn_aggregate_ell_head_fwd_f32", b, nv, c, k, csr.ell_w, csr.ell_col.data_ptr(),
+                      csr.ell_val.data_ptr(), _lib.ptr(over[0]), _lib.ptr(over[1]), _lib.ptr(over[2]), s.data_ptr(),
+                      _lib.ptr(bias_c), act, out.data_ptr(), _lib.ptr(mask), base_c.data_ptr(), float(scale), pos.data_ptr())
+        ctx.csr, ctx.k, ctx.act, ctx.scale, ctx.shape = csr, k, act, float(scale), (b, nv, c)
+        ctx.bias_ref = None if bias is None else weakref.ref(bias)
+        if bias is not None and ctx.needs_input_grad[1]:
+            _register_bias_user(bias, ctx)
+        if mask is not None:
+            ctx.save_for_backward(mask)
+        return pos
+
+    @staticmethod
+    def backward(ctx, grad_pos):
+        gp = grad_pos.contiguous()
+        b, nv, c = ctx.shape
+        csr, k = ctx.csr, ctx.k
+        mask = ctx.saved_tensors[0] if ctx.saved_tensors else None
+        grad_support = torch.empty(b, nv, c, dtype=torch.float32, device=gp.device)
+        grad_bias = scratch = None
+        defer = False
+        bias = ctx.bias_ref() if ctx.bias_ref is not None else None
+        if ctx.needs_input_grad[1] and ctx.bias_ref is not None:
+            grad_bias = torch.empty(c, dtype=torch.float32, device=gp.device)
+            scratch = torch.empty(_lib.lib().geom_zn_gcn_bwd_scratch_floats(b, nv, c), dtype=torch.float32, device=gp.device)
+            defer = _may_defer(bias)
+        over = csr.over_t or (None, None, None)
+        with torch.cuda.device(gp.device):
+            _lib.call("geom_zn_gcn_aggregate_ell_head_bwd_f32", b, nv, c, k, csr.ell_w, csr.ell_col_t.data_ptr(),
+                      csr.ell_val_t.data_ptr(), _lib.ptr(over[0]), _lib.ptr(over[1]), _lib.ptr(over[2]), gp.data_ptr(),
+                      ctx.scale, _lib.ptr(mask), ctx.act, grad_support.data_ptr(), _lib.ptr(None if defer else grad_bias),
+                      _lib.ptr(scratch))
+        if defer:
+            _queue_colsum(scratch, int(_lib.lib().geom_zn_gcn_bwd_partial_rows(b, nv, c, k, csr.ell_w)), c, grad_bias, bias)
+        return (grad_support if ctx.needs_input_grad[0] else None), grad_bias, (gp if ctx.needs_input_grad[2] else None), \
+            None, None, None, None
+
+
+def zero_n_aggregate_head(support, adj, bias, k, activation, base, scale):
+    """base + scale * zero_n_aggregate(...)[..., :3] for a [B,V,C] support: fused (see _ZeroNAggregateHead) for split-3
+    layers on a bounded-degree mesh with ReLU or no activation, the two separate operators otherwise."""
+    act = _ACT_NONE if activation is None else _activation_code(activation)
+    fused = (torch.is_tensor(support) and support.dim() == 3 and support.is_cuda and support.dtype == torch.float32
+             and not (torch.is_tensor(adj) and adj.dim() == 3) and (activation is None or act == _ACT_RELU))
+    if fused:
+        csr = adjacency_csr(adj)
+        c = support.shape[-1]
+        fused = bool(csr.ell_w) and k > 0 and k % 4 == 0 and c == 3 * k
+    if not fused:
+        from .ops import VertexHead
+        return VertexHead.apply(base, zero_n_aggregate(support, adj, bias, k, activation), scale)
+    return _ZeroNAggregateHead.apply(support, bias, base, csr, k, act, scale)
+
+
 def zero_n_aggregate(support, adj, bias, k, activation=None):
     """Shared tail of every 0N-GCN layer; accepts [V,C] or [B,V,C] support.  Returns the
     ACTIVATED output when `activation` is given (fused for relu / elu)."""
@@ -627,6 +700,12 @@ class _ZeroNBase(Module):
     def forward(self, input, adj, activation):
         support = _dense(input, self._weight())
         return zero_n_aggregate(support, adj, self.bias, support.shape[-1] // self.split, activation)
+
+    def forward_positions(self, input, adj, activation, base, scale):
+        """base + scale * self(input, adj, activation)[..., :3] -- the coordinate update of a deformation stage
+        (GEOMetrics.py:121,126,131) without materialising the layer output's gradient (see zero_n_aggregate_head)."""
+        support = _dense(input, self._weight())
+        return zero_n_aggregate_head(support, adj, self.bias, support.shape[-1] // self.split, activation, base, scale)
 
 
 class ZERON_GCN(_ZeroNBase):

@@ -300,6 +300,23 @@ int geom_dense_bwd_f32(int rows, int cin, int c, const float *x, const float *g,
 int geom_dense_reduce_f32(int count, const int *rows, const int *cin, const int *c, const float *const *workspaces,
                           float *const *grad_w, float *const *grad_bias, void *stream);
 
+/* HEAD mode of the ELL fast path: the layer whose three leading output channels are the coordinate update of a deformation
+ * stage (GEOMetrics.py:121,126,131: positions + block output[..., :3]).  Split 3 with ReLU + relu_mask or act == 0 only
+ * (else GEOM_EUNSUPPORTED: use the plain entry points + geom_vertex_head_*).
+ *   forward : as geom_zn_gcn_aggregate_ell_fwd_f32, and pos[r,:] = base[r,:] + scale * out[r,:3]  (base / pos [b*nv, 3]);
+ *   backward: the upstream gradient is [scale * grad_pos | 0 ...] by construction, so it is never materialised or read:
+ *             grad_support / grad_bias exactly as geom_zn_gcn_aggregate_ell_bwd_f32 would give for that grad_out. */
+int geom_zn_gcn_aggregate_ell_head_fwd_f32(int b, int nv, int c, int k, int w, const int *ell_col,
+                                           const float *ell_val, const int *over_ptr, const int *over_col,
+                                           const float *over_val, const float *support, const float *bias,
+                                           int act, float *out, uint16_t *relu_mask, const float *base,
+                                           float scale, float *pos, void *stream);
+int geom_zn_gcn_aggregate_ell_head_bwd_f32(int b, int nv, int c, int k, int w, const int *ell_colT,
+                                           const float *ell_valT, const int *over_ptrT, const int *over_colT,
+                                           const float *over_valT, const float *grad_pos, float scale,
+                                           const uint16_t *relu_mask, int act, float *grad_support,
+                                           float *grad_bias, float *scratch, void *stream);
+
 /* Coordinate update of a deformation stage (GEOMetrics.py:121,126,131) when the predicted offsets are the
  * three leading channels of a wider feature tensor: pos[r,:] = base[r,:] + scale*feat[r,:3] for `rows`
  * vertices (feat row length c), and its adjoint grad_feat[r,:] = [scale*grad_pos[r,:] | 0 ...] (c % 4 == 0). */

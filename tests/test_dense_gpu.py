@@ -115,3 +115,26 @@ def test_unsupported_shapes_are_refused():
     x = torch.zeros(4, 4, device="cuda")
     code = _lib.lib().geom_dense_fwd_f32(4, 4, 200, x.data_ptr(), x.data_ptr(), 0, None, x.data_ptr(), None, None, None)
     assert code == _lib.EUNSUPPORTED
+
+
+def test_head_mode_equals_aggregation_plus_vertex_head():
+    """layers.zero_n_aggregate_head (positions out of the aggregation launches, gradient of the layer output never
+    materialised) against zero_n_aggregate + ops.VertexHead: same positions bit for bit, same gradients bit for bit."""
+    import torch.nn.functional as F
+    from geometrics_amd import layers, meshgen, ops, utils
+    for gen, act in ((lambda: meshgen.icosphere(2), F.relu), (meshgen.uv_sphere, F.relu), (lambda: meshgen.icosphere(2), None)):
+        V, Fc = gen()
+        adj = utils.adj_init(torch.from_numpy(Fc).cuda())["adj"]
+        torch.manual_seed(5)
+        b, nv, c, k = 3, V.shape[0], 48, 16
+        sup = torch.randn(b, nv, c, device="cuda", requires_grad=True)
+        bias = torch.randn(c, device="cuda", requires_grad=True)
+        base = torch.randn(b, nv, 3, device="cuda", requires_grad=True)
+        gpos = torch.randn(b, nv, 3, device="cuda")
+        ref = ops.VertexHead.apply(base, layers.zero_n_aggregate(sup, adj, bias, k, act), 0.01)
+        ref_g = torch.autograd.grad(ref, [sup, bias, base], gpos)
+        got = layers.zero_n_aggregate_head(sup, adj, bias, k, act, base, 0.01)
+        got_g = torch.autograd.grad(got, [sup, bias, base], gpos)
+        assert torch.equal(got, ref)
+        for a, b_ in zip(got_g, ref_g):
+            assert torch.equal(a, b_)
