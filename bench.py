@@ -50,7 +50,7 @@ PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_counters.json")
 
 
 class Workload:
-    def __init__(self, dev, first_mesh, batch, seed=3041):
+    def __init__(self, dev, first_mesh, batch, seed=3041, force_dp=False):
         V, Fc = meshgen.icosphere(V_LEVEL)
         self.batch, self.nv, self.nf = batch, V.shape[0], Fc.shape[0]
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -65,8 +65,11 @@ class Workload:
         self.stack = torch.nn.ModuleList(
             [layers.Batch_Image_ZERON_GCNGCN(i, o) for i, o in ((FEAT, HID), (HID, HID), (HID, HID))]).to(dev)
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        # force_dp: take the N > 1 sequence (bucket pack / all-reduce / Adam on the bucket, two graphs) in a 1-rank group --
+        # the only way to run the RCCL collective between the two graph replays on a single-GPU box
+        self.dp = self.world > 1 or force_dp
         # flat DP bucket: all gradients + [loss_sum, mesh_count] -> exactly one all-reduce per step
-        self.bucket = gdist.GradBucket(self.stack.parameters(), extra=2) if self.world > 1 else None
+        self.bucket = gdist.GradBucket(self.stack.parameters(), extra=2, force_collective=force_dp) if self.dp else None
         self.count = torch.full((), float(batch), device=dev)
         self.seed_grad = torch.ones((), device=dev)
         self.rng = ops.manual_seed(seed, dev, mesh_offset=first_mesh)   # sampler keyed on the GLOBAL mesh index: N shards draw what one process would
@@ -95,15 +98,15 @@ class Workload:
             pos = self.positions()
             self.loss = utils.batch_point_to_surface(pos, self.info, self.gt, num=S_PTS)
             self.loss.backward(self.seed_grad)              # explicit seed: no ones_like fill launch
-        if self.world > 1:
+        if self.dp:
             self.bucket.pack(self.loss.detach() * self.batch, self.count)
 
     def exchange(self):
-        if self.world > 1:
+        if self.dp:
             self.bucket.all_reduce()            # ONE RCCL all-reduce: 259 200 grads + loss sum + count (1.04 MB)
 
     def update(self):
-        if self.world > 1:
+        if self.dp:
             self.opt.step(self.bucket.views, grad_scale=1.0 / self.world)   # mean over ranks folded into Adam
         else:
             self.opt.step()
@@ -114,7 +117,7 @@ class Workload:
         self.update()
 
     def mean_loss(self):
-        if self.world > 1:
+        if self.dp:
             return float(self.bucket.extra[0] / self.bucket.extra[1])
         return float(self.loss.detach())
 
@@ -131,7 +134,7 @@ class Workload:
                 self.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if self.world == 1:
+        if not self.dp:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.step()

@@ -37,8 +37,10 @@ def shard_range(total, rank, world):
     return first, base + (1 if rank < extra else 0)
 
 
-def all_reduce_sum_(t):
-    if dist.is_initialized() and dist.get_world_size() > 1:
+def all_reduce_sum_(t, force=False):
+    """In-place SUM over the ranks.  force: issue the collective even in a 1-rank group (how the test suite executes RCCL
+    itself -- backend "nccl" -- on a single GPU: tests/test_dist_step_gpu.py)."""
+    if dist.is_initialized() and (dist.get_world_size() > 1 or force):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
@@ -58,7 +60,8 @@ class GradBucket:
     `all_reduce()` sums the buffer across ranks, `views` are per-parameter views of the reduced buffer
     (the 1/world scale is applied inside the optimiser kernel)."""
 
-    def __init__(self, params, extra=0):
+    def __init__(self, params, extra=0, force_collective=False):
+        self.force = force_collective
         self.params = [p for p in params if p.requires_grad]
         ref = self.params[0]
         self.numel = sum(p.numel() for p in self.params)
@@ -75,7 +78,7 @@ class GradBucket:
         return self.flat
 
     def all_reduce(self):
-        all_reduce_sum_(self.flat)
+        all_reduce_sum_(self.flat, self.force)
         return self.views
 
     def pack_all_reduce(self, *scalars):

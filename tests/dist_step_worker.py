@@ -45,6 +45,32 @@ def run(rank, world, port, total_meshes, steps, out):
         torch.distributed.destroy_process_group()
 
 
+def run_rccl_single(port, total_meshes, steps, out):
+    """ONE rank, backend "nccl" (= RCCL) on cuda:0, bench.Workload forced onto its N > 1 sequence: graph A (forward +
+    backward + bucket pack) -> eager RCCL all-reduce of the flat bucket -> graph B (Adam on the bucket views)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch
+    import bench
+    from geometrics_amd import gemm_tuning
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1)
+    assert torch.distributed.get_backend() == "nccl"
+    gemm_tuning.enable()
+    wl = bench.Workload(dev, 0, total_meshes, force_dp=True)
+    assert wl.bucket is not None and wl.bucket.force
+    wl.capture()
+    assert len(wl.graphs) == 2
+    losses = []
+    for _ in range(steps):
+        wl.run()
+        torch.cuda.synchronize()
+        losses.append(wl.mean_loss())
+    out.put({"params": _flat(wl.stack.parameters()), "grads": wl.bucket.flat[:wl.bucket.numel].cpu().numpy(),
+             "losses": losses, "steps_taken": wl.opt.step_count})
+    torch.distributed.destroy_process_group()
+
+
 def run_serial(shards, total_meshes, steps, warm, out):
     """ONE process emulating `shards` data-parallel ranks in turn: every shard is a bench.Workload of its own (same
     kernels, same GEMM shapes as a real rank), gradients are summed in rank order, and every replica applies Adam with

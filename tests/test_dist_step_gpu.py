@@ -73,3 +73,20 @@ def test_two_rank_step_tracks_the_single_process_16_mesh_step(gpu):
     assert np.abs(two["grads"] - one["grads"]).max() <= 5e-2 * scale
     diff = np.abs(two["params"] - one["params"])
     assert diff.max() <= 2 * LR * (STEPS + WARM) * 1.01       # Adam moves an entry by at most lr per step
+
+
+@pytest.mark.timeout(600)
+def test_rccl_all_reduce_between_the_two_graph_replays_equals_the_single_graph_step(gpu):
+    """RCCL itself, once: a 1-rank process group with backend "nccl" on cuda:0 and bench.Workload forced onto its N > 1
+    sequence (graph A: forward + backward + bucket pack; eager RCCL all-reduce of the 1.04 MB bucket on NCCL's own
+    stream; graph B: Adam on the bucket views, grad_scale = 1).  The ordering of an asynchronous collective between two
+    graph replays is what an 8-GPU node will run and what the gloo tests cannot exercise (gloo blocks the host); with one
+    rank the sum is the identity, so parameters, gradients and losses must equal the plain single-graph step bit for bit."""
+    port = _free_port()
+    rccl = _collect(dist_step_worker.run_rccl_single, lambda n: [(port, 8, 5)], 1)
+    port2 = _free_port()
+    plain = _collect(dist_step_worker.run, lambda n: [(0, 1, port2, 8, 5)], 1)
+    assert rccl["steps_taken"] == plain["steps_taken"] == 5 + WARM
+    assert rccl["losses"] == plain["losses"]
+    np.testing.assert_array_equal(rccl["grads"], plain["grads"])
+    np.testing.assert_array_equal(rccl["params"], plain["params"])

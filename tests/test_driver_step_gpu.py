@@ -89,7 +89,7 @@ def test_training_step_with_the_drivers_call_shapes(gpu):
             dc = [tuple(t.cpu() for t in d) for d in draws]
             ref_s = [ref_ops.point_to_surface(pc[i], faces_c, gt_c, *dc[i]) for i in range(3)]
             for ours, ref in zip((s1, s2, s3), ref_s):
-                assert abs(ours.item() - ref.item()) <= 1e-4 * abs(ref.item())
+                assert abs(ours.item() - ref.item()) <= 1e-5 * abs(ref.item())    # north_star: loss within 1e-5 (fp32)
             ref_edge = sum(ref_ops.calc_edge(p, faces_c) for p in pc) * 300
             assert abs(edge_loss.item() - ref_edge.item()) <= 1e-5 * abs(ref_edge.item())
             li = lambda p: ref_ops.lap_info(p, adj_orig)
@@ -123,7 +123,7 @@ def test_validation_step_with_the_drivers_call_shapes(gpu):
         loss, f1 = utils.batch_point_to_point(p3, adj_info, sliced, num=2466, f1=True, draws=(ch, u, v))
         ref, ref_f1 = ref_ops.point_to_point(p3.cpu(), torch.from_numpy(F), sliced.cpu().contiguous(), ch.cpu(), u.cpu(), v.cpu(),
                                              f1=True)
-    assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())        # north_star: loss within 1e-5 (fp32)
     assert abs(f1 - ref_f1) < 1e-9
     # and with fresh in-kernel draws, as the driver calls it
     with torch.no_grad():

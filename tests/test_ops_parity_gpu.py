@@ -23,6 +23,11 @@ def dev(a, gpu, grad=False):
 
 
 def close(actual, expected, rtol, scale=None):
+    """MAX-NORM closeness: |actual - expected| <= rtol * max|expected| element-wise.  Deliberately not per-element relative:
+    the gradients compared with it are sums whose fp32 terms arrive in a different order on the GPU (atomics-free gathers,
+    split-K partials), so an entry 1000x smaller than the largest one legitimately carries the ABSOLUTE round-off of the
+    large terms that cancelled into it -- a 10 % relative error there is noise, and would pass; what the bound does catch
+    is any error that matters at the scale of the tensor (a wrong neighbour, a dropped term, a transposed tile)."""
     actual, expected = np.asarray(actual, np.float64), np.asarray(expected, np.float64)
     scale = np.abs(expected).max() if scale is None else scale
     assert np.abs(actual - expected).max() <= rtol * max(scale, 1e-30), \
@@ -1023,6 +1028,19 @@ def test_fused_surface_scan_equals_the_separate_scans_and_its_records_those_of_t
     if not two_sided:
         dt, pt, it = tri_distance_indexed(gt, verts, faces)
         assert torch.equal(a["tri_d"], dt) and torch.equal(a["option"], pt) and torch.equal(a["index"], it)
+    # ... and the CPU oracle DIRECTLY on the launch the bench times, all 8 meshes of the shard: both Chamfer directions in
+    # the launch's arithmetic (the reference's nnsearch restated; its FMA-contracted build for GEOM_FLAG_NN_FMA) and
+    # the point-to-triangle scan (distance bits, region code, triangle index) -- not only through its HIP siblings
+    import oracle
+    gt_h, pts_h, verts_h = gt.cpu().numpy(), points.cpu().numpy(), verts.cpu().numpy()
+    e1, j1, e2, j2 = oracle.chamfer_nn(gt_h, pts_h, oracle.FLAG_NN_FMA if fma else 0)
+    assert np.array_equal(a["idx_p"].cpu().numpy(), j1) and np.array_equal(a["idx_g"].cpu().numpy(), j2)
+    assert np.array_equal(a["sq_gt"].cpu().numpy().view(np.uint32), e1.view(np.uint32))
+    assert np.array_equal(a["sq_pred"].cpu().numpy().view(np.uint32), e2.view(np.uint32))
+    if not two_sided:
+        et, ept, eit = oracle.tri_scan_indexed(gt_h, verts_h, Fc)
+        assert np.array_equal(a["index"].cpu().numpy(), eit) and np.array_equal(a["option"].cpu().numpy(), ept)
+        assert np.array_equal(a["tri_d"].cpu().numpy().view(np.uint32), et.view(np.uint32))
 
 
 def test_prepare_launch_equals_draw_plus_prep(gpu):
