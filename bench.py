@@ -46,7 +46,7 @@ VALU_ISSUE_TERA_LANE_OPS = FP32_PEAK_TFLOPS / 2.0
 VALU_MEASURED_TERA_LANE_OPS = 103.0 / 2.0
 TRI_ALGO_FLOP_PER_PAIR = 60.0    # hoisted op count of the reference's decision tree per (point, triangle)
 NN_FLOP_PER_PAIR = 8.0           # 3 sub, 3 mul, 2 add
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_counters.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_counters.json")
 
 
 class Workload:
@@ -221,13 +221,19 @@ def pmc_row(kernel_prefix):
     return None
 
 
-def pmc_traffic_bytes(kernel_prefix):
-    """HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, KiB; calibrated 1:1 on the aggregation kernel's known byte
-    count, profiles/README.md), or None without valid counters."""
+FETCH_16B_FACTOR = 2.0     # MI355X_MICROARCH.md, HBM: on gfx950 rocprofv3's FETCH_SIZE reports exactly 1/2 of the bytes of a
+                           # wide coalesced streaming read (16 B / lane): doubled before it is compared with a byte count
+
+
+def pmc_traffic_bytes(kernel_prefix, fetch_factor=FETCH_16B_FACTOR):
+    """HBM-side bytes per launch = fetch_factor x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes; KiB per launch
+    in the committed file), or None without valid counters.  fetch_factor = 2 for kernels whose reads are 16 B per lane
+    (the guide's gfx950 correction -- consistent with the aggregation kernel, whose 10.5 MB compulsory pass-through read
+    alone exceeds the raw 8.4 MB the counter shows); WRITE_SIZE is taken as reported."""
     row = pmc_row(kernel_prefix)
     if row is None or "FETCH_SIZE_KB_per_launch" not in row:
         return None
-    return int((row["FETCH_SIZE_KB_per_launch"] + row["WRITE_SIZE_KB_per_launch"]) * 1024)
+    return int((fetch_factor * row["FETCH_SIZE_KB_per_launch"] + row["WRITE_SIZE_KB_per_launch"]) * 1024)
 
 
 def valu_rate(kernel_prefix, launch_us):
@@ -301,54 +307,134 @@ def kernel_rooflines(w):
     algo_flops = tri_pairs * TRI_ALGO_FLOP_PER_PAIR + nn_pairs * NN_FLOP_PER_PAIR
     executed = valu_rate("surface_scan_kernel", t_scan)
     scan_bytes = b * (G_PTS * 12 + w.nv * 12 + w.nf * 24 + G_PTS * 12) + b * (G_PTS + S_PTS) * (12 + 8)
-    if executed is not None:
-        achieved, frac = executed["tera_lane_ops_per_s"], executed["frac_of_spec_issue_rate"]
-        basis = "executed"
-    else:   # no valid counters for these sources: the brute-force-equivalent NN rate is still an executed rate (no culling there)
-        achieved, frac, basis = None, None, "unavailable (profiles/r02_pmc_counters.json is stale for these kernel sources)"
-    roofline = {
+    scan_traffic = pmc_traffic_bytes("surface_scan_kernel")
+    scan = {
         "kernel": "surface_scan_kernel: Chamfer NN tiles (both directions) + point-to-triangle tiles (two-level culled scan) in "
                   "one heterogeneous launch",
-        "bound": "mfma",
-        "pipe": "fp32 VALU, un-fused arithmetic (arg-min scans, not contractions): one flop per executed lane-op, so the "
-                "issue ceiling is 157.3 / 2 = 78.6 TFLOP/s (256 CU x 4 SIMD x 32 lanes x 2.4 GHz); the dense f32 MFMA peak "
-                "equals the f32 FMA vector peak on gfx950",
-        "achieved": achieved, "peak": VALU_ISSUE_TERA_LANE_OPS, "unit": "TFLOP/s", "frac": frac, "basis": basis,
-        "traffic": pmc_traffic_bytes("surface_scan_kernel"),
-        "launch_us": round(t_scan, 1), "call_us_with_prep_launch": round(t_scan_all, 1),
-        "executed": executed,
-        "algorithmic": {"pairs_per_launch": {"tri": tri_pairs, "nn": nn_pairs},
-                        "flop_per_pair": {"tri": TRI_ALGO_FLOP_PER_PAIR, "nn": NN_FLOP_PER_PAIR},
-                        "brute_force_equivalent_tflops": round(algo_flops / (t_scan * 1e-6) / 1e12, 1),
-                        "algorithmic_speedup_vs_brute_force": round(algo_flops / (executed["lane_ops_per_launch"]), 2) if executed else None,
-                        "bytes_per_launch": scan_bytes, "hbm_gbs_algorithmic": round(scan_bytes / (t_scan * 1e-6) / 1e9, 1),
-                        "note": "SURVEY 8(d) figures: every (point, triangle) pair at 60 flop + every (point, point) pair at 8 "
-                                "flop.  The tri tiles cull ~95 % of their pairs (proven bit-exact against brute force), so this "
-                                "rate is not a utilisation; `achieved` / `frac` are the EXECUTED work (SQ_INSTS_VALU x 64 lanes)"},
+        "bound": "valu",
+        "pipe": "fp32 VALU issue, un-fused arithmetic (arg-min scans whose per-pair roundings are pinned, not contractions)",
+        "valu_issue_utilisation": None if executed is None else {
+            "achieved_tera_lane_ops_per_s": executed["tera_lane_ops_per_s"], "peak_tera_lane_ops_per_s": VALU_ISSUE_TERA_LANE_OPS,
+            "frac": executed["frac_of_spec_issue_rate"], "frac_of_measured_vfma_rate": executed["frac_of_measured_vfma_rate"],
+            "note": "SQ_INSTS_VALU x 64 lanes / launch time: EVERY VALU instruction (cull tests, selects, address math) at "
+                    "64 lanes -- an issue-slot occupancy, not useful flops"},
+        "flop_roofline": {"achieved": round(algo_flops / (t_scan * 1e-6) / 1e12, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(algo_flops / (t_scan * 1e-6) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                          "note": "SURVEY 8(d) ALGORITHMIC flops (every (point, triangle) pair at 60 + every (point, point) pair at "
+                                  "8) / launch time against the 157.3 TFLOP/s fp32 peak; above 1 is possible and means "
+                                  "culling, not utilisation: the tri tiles prove ~95 % of their pairs irrelevant (bit-exact "
+                                  "vs brute force)"},
+        "launch_us": round(t_scan, 1), "call_us_with_prep_launch": round(t_scan_all, 1), "executed": executed,
+        "algorithmic_bytes_per_launch": scan_bytes,
+        "traffic": scan_traffic,
+        "traffic_over_algorithmic": None if scan_traffic is None else round(scan_traffic / scan_bytes, 2),
+        "traffic_note": "2 x FETCH_SIZE + WRITE_SIZE; the excess over the algorithmic bytes is the triangle-record workspace "
+                        "the prep launch writes and all eight XCDs re-read through their own L2 (harmless at this launch time: "
+                        "< 0.2 TB/s)",
         "separate_launches_us": {"chamfer_nn": round(t_nn, 1), "tri_prep_plus_scan": round(t_prep_tri, 1),
                                  "tri_flat_scan": round(t_tri_flat, 1)},
-        "fma_arithmetic_us": {"chamfer_nn (GEOM_FLAG_NN_FMA)": round(t_nn_fma, 1), "fused call": round(t_scan_fma, 1)},
-        "note": "executed.frac_of_measured_vfma_rate relates the same rate to the 103 TFLOP/s the guide measures for un-packed "
-                "v_fma_f32 (51.5 T lane-ops/s): the practical issue ceiling"}
+        "fma_arithmetic_us": {"chamfer_nn (GEOM_FLAG_NN_FMA)": round(t_nn_fma, 1), "fused call": round(t_scan_fma, 1)}}
+    if prep_row is not None:
+        scan["prep_launch"] = {"kernel": "tri_prep_grouped_kernel", "valu_instructions_per_launch": int(prep_row.get("SQ_INSTS_VALU_per_launch", 0))}
     nn_exec = valu_rate("chamfer_nn_scalar_kernel", t_nn)
     nn_tflops = nn_pairs * NN_FLOP_PER_PAIR / (t_nn * 1e-6) / 1e12
     agg_bytes = 2 * b * w.nv * HID * 4 + csr.nnz * 12 + (w.nv + 1) * 4
     agg_gbs = agg_bytes / (t_agg * 1e-6) / 1e9
+    agg_step_us = step_profile_us("zn_aggregate_ell_kernel<1, false")
+    # ---- the layers' dense gradients on the fp32 matrix cores (csrc/dense_gemm.hip): the longest hand-written launches
+    from geometrics_amd import dense
+    rows = b * w.nv
+    x1 = w.feat.detach().reshape(rows, FEAT)
+    xh = torch.randn(rows, HID, device=pos.device)
+    g = torch.randn(rows, HID, device=pos.device)
+    w1 = w.stack[0].weight1.detach().reshape(FEAT, HID)
+    wh = w.stack[1].weight1.detach().reshape(HID, HID)
+    ws1 = dense.weight_workspace(rows, FEAT, HID, pos.device)
+    wsh = dense.weight_workspace(rows, HID, HID, pos.device)
+    dxh = torch.empty(rows, HID, device=pos.device)
+    t_dw1 = event_time_us(lambda: dense.backward_weight_partials(x1, g, ws1))
+    t_pair = event_time_us(lambda: dense.backward_pair(xh, g, wh, dxh, wsh))
+    t_dw1_lib = event_time_us(lambda: torch.mm(x1.t(), g))
+    gw1, gwh = torch.empty(FEAT, HID, device=pos.device), torch.empty(HID, HID, device=pos.device)
+    t_red = event_time_us(lambda: dense.reduce([(rows, FEAT, HID, ws1, gw1, None), (rows, HID, HID, wsh, gwh, None),
+                                                (rows, HID, HID, wsh, gwh, None)]))
+    dw1_flop = 2.0 * rows * FEAT * HID
+    pair_flop = 4.0 * rows * HID * HID
+    dw1_bytes = rows * FEAT * 4 + rows * HID * 4 + ws1.numel() * 4      # X once + G once + the partial tiles written
+    dw1_traffic = pmc_traffic_bytes("dense_split_kernel", fetch_factor=1.0)
+    dw1_step = step_profile_us("dense_split_kernel")
+    roofline = {
+        "kernel": "dense_split_kernel: split-K partial sums of the first layer's weight gradient dW = X^T . G "
+                  "([%d, 963]^T x [%d, 192]) on v_mfma_f32_16x16x4_f32 -- the longest hand-written launch of the step" % (rows, rows),
+        "bound": "mfma",
+        "achieved": round(dw1_flop / (t_dw1 * 1e-6) / 1e12, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(dw1_flop / (t_dw1 * 1e-6) / 1e12 / FP32_PEAK_TFLOPS, 4),
+        "basis": "algorithmic = executed: a dense contraction, 2 * rows * 963 * 192 flop per launch, exact fp32 (no reduced "
+                 "precision, nothing skipped); launch time from HIP events around a HIP-graph replay of 30 launches on the "
+                 "launch stream",
+        "launch_us": round(t_dw1, 1), "launch_us_in_step_profile": dw1_step,
+        "library_same_product_us": round(t_dw1_lib, 1),
+        "algorithmic_bytes_per_launch": int(dw1_bytes),
+        "traffic": dw1_traffic,
+        "traffic_note": "FETCH_SIZE + WRITE_SIZE as reported (X is read with 4-byte loads -- its 963-float rows are never 16-byte "
+                        "aligned -- so the guide's x2 for 16 B/lane reads does not apply to the bulk of the fetch)",
+        "sustained_clock_note": "under sustained fp32 MFMA load the chip runs ~2.08 GHz (a loop of nothing but these MFMAs: "
+                                "1.85 us per 3840-cycle stage), i.e. ~136 TFLOP/s is what the matrix pipe delivers; the "
+                                "library's best product of this step reaches 124"}
     others = {
+        "surface_scan_kernel (both arg-min scans of the surface loss)": scan,
+        "dense_bwd_pair_kernel (hidden layer: dX and the dW partials in ONE launch, two workgroups per CU)": {
+            "bound": "mfma", "achieved": round(pair_flop / (t_pair * 1e-6) / 1e12, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(pair_flop / (t_pair * 1e-6) / 1e12 / FP32_PEAK_TFLOPS, 4), "launch_us": round(t_pair, 1),
+            "launch_us_in_step_profile": step_profile_us("dense_bwd_pair_kernel"),
+            "library_three_launches_us_in_round2_step": 40.6},
+        "dense_reduce_kernel (all weight gradients of a pass, fixed order)": {
+            "bound": "hbm", "launch_us": round(t_red, 1),
+            "achieved": round((ws1.numel() + 2 * wsh.numel()) * 4 / (t_red * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round((ws1.numel() + 2 * wsh.numel()) * 4 / (t_red * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
         "chamfer_nn_scalar_kernel (stand-alone launch)": {
-            "bound": "mfma", "pipe": "fp32 VALU, un-fused (brute force: algorithmic == executed pairs)",
-            "achieved": round(nn_tflops, 2), "peak": VALU_ISSUE_TERA_LANE_OPS, "unit": "TFLOP/s",
+            "bound": "valu", "pipe": "fp32 VALU, un-fused (brute force: algorithmic == executed pairs)",
+            "achieved": round(nn_tflops, 2), "peak": VALU_ISSUE_TERA_LANE_OPS, "unit": "T lane-op/s (= TFLOP/s: one flop per lane-op)",
             "frac": round(nn_tflops / VALU_ISSUE_TERA_LANE_OPS, 4), "launch_us": round(t_nn, 1), "executed": nn_exec,
             "traffic": pmc_traffic_bytes("chamfer_nn_scalar_kernel")},
         "zn_aggregate_ell_kernel (forward, sign mask)": {
             "bound": "hbm", "achieved": round(agg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(agg_gbs / HBM_PEAK_GBS, 4), "launch_us": round(t_agg, 1), "algorithmic_bytes_per_launch": agg_bytes,
             "traffic": pmc_traffic_bytes("zn_aggregate_ell_kernel<1, false"),
-            "note": "timed back to back on one buffer pair: reads are served from the 256 MiB infinity cache"},
+            "in_step": None if agg_step_us is None else {
+                "launch_us": agg_step_us, "achieved": round(agg_bytes / (agg_step_us * 1e-6) / 1e9, 1),
+                "frac": round(agg_bytes / (agg_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "from the committed rocprofv3 trace of the step (profiles/r03_step_kernel_stats.csv): operands come "
+                        "from HBM there"},
+            "note": "`launch_us` is timed back to back on one buffer pair: reads are served from the 256 MiB infinity cache; "
+                    "the in-step figure is the honest one"},
     }
-    if prep_row is not None:
-        roofline["prep_launch"] = {"kernel": "tri_prep_grouped_kernel", "valu_instructions_per_launch": int(prep_row.get("SQ_INSTS_VALU_per_launch", 0))}
     return roofline, others
+
+
+_step_profile = None
+
+
+def step_profile_us(kernel_prefix):
+    """Average duration (us) of a kernel in the committed rocprofv3 kernel trace of the step (profiles/r03_step_kernel_stats.csv),
+    or None when the file is missing / does not list it."""
+    global _step_profile
+    if _step_profile is None:
+        _step_profile = {}
+        try:
+            import csv
+            with open(os.path.join(ROOT, "profiles", "r03_step_kernel_stats.csv")) as f:
+                for r in csv.DictReader(f):
+                    name = r.get("Name") or r.get("Kernel_Name") or ""
+                    avg = r.get("AverageNs") or r.get("Average") or ""
+                    if name and avg:
+                        _step_profile[name.strip('"')] = float(avg) / 1e3
+        except (OSError, ValueError):
+            pass
+    for name, us in _step_profile.items():
+        if name.startswith(kernel_prefix):
+            return round(us, 1)
+    return None
 
 
 def component_times(w):
@@ -443,6 +529,28 @@ def training_shape_times(dev, batch=16):
             "deformation_block_fwd_bwd_us": round(t_block, 1), "surface_loss_fwd_bwd_us": round(t_loss, 1),
             "aggregation_kernel": "ELL table width %d%s" % (csr.ell_w, " + CSR tail for the long rows" if csr.over else "")
                                   if csr.ell_w else "generic CSR"}
+
+
+def whole_batch_times(dev, meshes=64, steps=20, warmup=5):
+    """BASELINE config 5's WHOLE batch (64 meshes) on this one GPU, same step, HIP-graph replay: the strong-scaling anchor
+    for the 8-GPU target (64 meshes / 8 GPUs = the 8-mesh shard that `value` is quoted on).  Reported beside the headline."""
+    torch.cuda.empty_cache()
+    w = Workload(dev, 0, meshes)
+    w.capture()
+    for _ in range(warmup):
+        w.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        w.run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"workload": "config 5 whole batch on ONE GPU: %d meshes per step (strong-scaling anchor; the headline is the "
+                       "8-mesh weak-scaling shard)" % meshes,
+           "ms_per_step": round(dt * 1e3, 4), "meshes_per_s": round(meshes / dt, 1), "final_loss": round(w.mean_loss(), 6)}
+    del w
+    torch.cuda.empty_cache()
+    return out
 
 
 def _cpu_model():
@@ -569,6 +677,7 @@ def main():
         if world == 1 and not args.steps_only:
             line["components_us"] = component_times(w)
             line["reference_training_shape"] = training_shape_times(dev)
+            line["whole_batch_single_gpu"] = whole_batch_times(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -58,9 +58,20 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float lr, floa
     const int which = lo;
     const int local = blockIdx.x - t.first_block[which];
 
-    const float t_old = state[0];
-    const float b1t = t_old == 0.f ? b1 : state[1] * b1;
-    const float b2t = t_old == 0.f ? b2 : state[2] * b2;
+    // The step state is read ONCE per workgroup, by the thread that later signs the workgroup's arrival, with agent-scope
+    // atomic loads, and handed to the other threads through LDS: that thread's loads have RETURNED (their values were
+    // stored to LDS in front of the barrier) before it can reach its arrival atomic -- the order "read the state, then
+    // arrive" is a data dependency, not an assumption about issue order or about where a compiler places plain loads.
+    __shared__ float st[3];
+    if (threadIdx.x == 0) {
+        st[0] = __hip_atomic_load(state + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st[1] = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st[2] = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const float t_old = st[0];
+    const float b1t = t_old == 0.f ? b1 : st[1] * b1;
+    const float b2t = t_old == 0.f ? b2 : st[2] * b2;
     const float bc1 = 1.f - b1t;
     const float bc2_sqrt = sqrtf(1.f - b2t);
     const float step_size = lr / bc1;
@@ -93,9 +104,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float lr, floa
     }
 
     if (!advance) return;
-    // arrival tree.  Only the ORDER "my read of the state, then my arrival" matters, and the hardware gives it for free:
-    // the state values feed this workgroup's stores, so they have returned long before the atomic below is issued (waves
-    // issue in order); the compiler barrier keeps the atomic from being hoisted above them.  Relaxed atomics on purpose:
+    // arrival tree.  Only the ORDER "this workgroup's read of the state, then its arrival" matters; it holds by construction
+    // (see the load above: same thread, values consumed before the barrier).  Relaxed atomics on purpose:
     // a release here would write back the L2 lines this workgroup just dirtied with p / m / v (measured: 13.9 us for the
     // launch with acq_rel arrivals against ~4 us), and nothing reads those before the kernel boundary anyway.
     __syncthreads();
@@ -110,9 +120,9 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float lr, floa
             __hip_atomic_store(cnt + 1 + leaf, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == leaves - 1) {
                 __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                state[0] = t_old + 1.f;
-                state[1] = b1t;
-                state[2] = b2t;
+                __hip_atomic_store(state + 0, t_old + 1.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(state + 1, b1t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(state + 2, b2t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }

@@ -32,7 +32,27 @@ constexpr int SGA_THREADS = 256;
 constexpr int ORD_THREADS = 1024;
 constexpr int ORD_WAVES = ORD_THREADS / GEOM_WAVE;
 constexpr int VTX_LANES = 8;    // lanes that share a vertex in the gather: one incident face each, then an ordered fold
-constexpr size_t ORD_LDS_LIMIT = 150 * 1024;
+// dynamic LDS one workgroup may take for the ordering pass: what the device grants (160 KiB on gfx950) minus 10 KiB for the
+// kernels' static arrays; read from the device once, so a part with less LDS answers GEOM_EUNSUPPORTED instead of failing
+// the launch
+inline size_t ord_lds_limit()
+{
+    static size_t limit = 0;
+    if (!limit) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        size_t have = 64 * 1024;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            have = prop.sharedMemPerBlock;
+            if (prop.sharedMemPerBlockOptin > have) have = prop.sharedMemPerBlockOptin;
+            if (prop.maxSharedMemoryPerMultiProcessor > have) have = prop.maxSharedMemoryPerMultiProcessor;
+        }
+        limit = have > 16 * 1024 ? have - 10 * 1024 : have;
+        if (limit > 150 * 1024) limit = 150 * 1024;
+    }
+    return limit;
+}
+#define ORD_LDS_LIMIT (ord_lds_limit())
 
 enum { OTHER_NONE = 0, OTHER_NN = 1, OTHER_TRI = 2 };
 
@@ -268,8 +288,8 @@ template <bool REGS>
 __global__ __launch_bounds__(ORD_THREADS) void surface_finalize_kernel(FinalizeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) int ord_lds[];
-    int *off = ord_lds;                       // [nf+1]: counts, then offsets
-    int *seg = off + (a.nf + 1);              // [per]
+    int *off = ord_lds;                       // [nf+1]: counts, then offsets (ordering only)
+    int *seg = off + (a.want_order ? a.nf + 1 : 0); // [per]
     int *wave_total = seg + (a.want_order ? a.per : 0);
     float *fsum = reinterpret_cast<float *>(wave_total + ORD_WAVES);
     const int mesh = a.want_order ? blockIdx.x : a.b, tid = threadIdx.x; // without ordering the grid is the loss workgroup alone
@@ -580,8 +600,10 @@ extern "C" int geom_surface_finalize_f32(int b, int nf, int num, const int64_t *
                    scale_other, coef_sample, coef_other, b, nf, num, n_gt, other, per, want_order ? 1 : 0, records_ready ? 1 : 0, off, seg, pface,
                    slot, rec, loss};
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // without ordering the single (loss) workgroup touches only its reduction scratch: independent of nf, so the
+    // documented fallback beyond the ordering limit (want_order = 0 + scatter backward) really launches
     const size_t lds = want_order ? order_lds_bytes(nf, per) + 2 * ORD_WAVES * sizeof(float)
-                                  : ((size_t)nf + 1 + ORD_WAVES + 4) * sizeof(int) + 2 * ORD_WAVES * sizeof(float);
+                                  : ((size_t)ORD_WAVES + 4) * sizeof(int) + 2 * ORD_WAVES * sizeof(float);
     if (per <= FIN_ITEMS * ORD_THREADS) {
         static const hipError_t opt_in = hipFuncSetAttribute(reinterpret_cast<const void *>(surface_finalize_kernel<true>),
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ORD_LDS_LIMIT + 1024);

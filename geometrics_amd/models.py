@@ -10,9 +10,10 @@ A BatchNorm output that feeds the next layer AND a later residual average is han
 the same memory (`tap`), so that its two upstream gradients meet inside the BN backward kernel instead of in a separate
 accumulation pass; the block input's leading columns (the first residual) are tapped the same way (`_InputTap`).
 (Measured and rejected: aggregation + BatchNorm in ONE launch -- DESIGN section 4.)
-Data-parallel note: under torch.distributed with more than one rank the BatchNorm statistics are those of the GLOBAL
-batch (per-vertex sums all-reduced, `_SyncVertexBN`), i.e. N shards normalise exactly as the single-GPU reference does
-over its whole batch; `VertexBatchNorm.sync_across_ranks = False` restores local-shard statistics on the fused kernel.
+Data-parallel note: by default every rank normalises with the statistics of its own shard (fused kernel, no collective,
+graph-capturable: DDP semantics).  `VertexBatchNorm.sync_across_ranks = True` switches to the statistics of the GLOBAL
+batch (`_SyncVertexBN`: per-vertex mean, then centred second moment, all-reduced), i.e. N shards normalise exactly as the
+single-GPU reference does over its whole batch -- eager only, the all-reduces sit inside forward / backward.
 """
 import torch
 import torch.nn.functional as F
@@ -120,20 +121,22 @@ class _SyncVertexBN(torch.autograd.Function):
     """nn.BatchNorm1d(verts) over the GLOBAL batch of a data-parallel job: the per-vertex sums of x and x^2 (forward) and
     of g and g*x_hat (backward) are all-reduced across the ranks, so N shards of B/N meshes normalise exactly as ONE
     process holding all B meshes -- the reference's semantics (it is single-GPU: models.py:237-297 sees the whole
-    batch).  Plain torch ops + two small all-reduces ([V, 2] floats each way); used only when a process group with more
-    than one rank is active."""
+    batch).  Plain torch ops + small all-reduces ([V] floats: mean and centred second moment forward, [V, 2] backward);
+    opt-in (`VertexBatchNorm.sync_across_ranks = True`), used only when a process group with more than one rank is active."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
         import torch.distributed as dist
-        local = torch.stack((x.sum(dim=(0, 2)), (x * x).sum(dim=(0, 2))), dim=1)          # [V, 2]
+        # two-pass statistics, like the fused kernel: the global mean first, then the CENTRED second moment (E[x^2] - mean^2
+        # cancels catastrophically for activations whose mean is large against their spread)
         count = torch.tensor([x.shape[0] * x.shape[2]], dtype=x.dtype, device=x.device)
-        packed = torch.cat((local.reshape(-1), count))
+        packed = torch.cat((x.sum(dim=(0, 2)), count))
         dist.all_reduce(packed)
         n = packed[-1]
-        tot = packed[:-1].view(-1, 2)
-        mean = tot[:, 0] / n
-        var = (tot[:, 1] / n - mean * mean).clamp_min(0.0)                                  # biased, as used for normalisation
+        mean = packed[:-1] / n
+        centred = ((x - mean.view(1, -1, 1)) ** 2).sum(dim=(0, 2))
+        dist.all_reduce(centred)
+        var = centred / n                                                                   # biased, as used for normalisation
         invstd = torch.rsqrt(var + eps)
         with torch.no_grad():
             running_mean.mul_(1 - momentum).add_(momentum * mean)
@@ -170,8 +173,12 @@ class VertexBatchNorm(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self._pending_batches = 0   # counted on the host; folded into the buffer when the state is saved
 
-    sync_across_ranks = True   # under torch.distributed with > 1 rank: statistics of the GLOBAL batch (the reference is
-    #                            single-GPU and normalises over the whole batch); False = local-shard statistics, fused kernel
+    # False (default): local-shard statistics on the fused kernel -- torch DDP's semantics, no collective inside forward /
+    # backward, HIP-graph capturable.  True: under torch.distributed with > 1 rank the statistics are those of the GLOBAL
+    # batch (the reference is single-GPU and normalises over its whole batch: exact N-shard == 1-process equivalence), at
+    # the price of three blocking all-reduces per layer and step ISSUED INSIDE forward / backward: that path cannot be
+    # captured into a HIP graph and is for eager multi-rank training only.
+    sync_across_ranks = False
 
     def _synchronised(self):
         return (self.training and self.sync_across_ranks and torch.distributed.is_available()

@@ -138,3 +138,38 @@ def test_head_mode_equals_aggregation_plus_vertex_head():
         assert torch.equal(got, ref)
         for a, b_ in zip(got_g, ref_g):
             assert torch.equal(a, b_)
+
+
+def test_fused_adam_graph_replays_track_torch_adam():
+    """The in-kernel step advance (arrival tree, state read through an atomic load + LDS broadcast) under HIP-graph replay:
+    N replays of ONE captured FusedAdam launch against N steps of torch.optim.Adam on the same gradients -- a wrong bias
+    correction on any replay (a workgroup reading the state after another one advanced it) shows up at the 1e-3 level."""
+    from geometrics_amd import optim
+    torch.manual_seed(11)
+    shapes = [(963, 192), (192,), (192, 192), (5,), (1, 192, 192), (3000, 7)]
+    ours = [torch.randn(*s, device="cuda").requires_grad_(True) for s in shapes]
+    ref = [p.detach().clone().requires_grad_(True) for p in ours]
+    grads = [torch.randn(*s, device="cuda") for s in shapes]
+    opt = optim.FusedAdam(ours, lr=1e-3)
+    ref_opt = torch.optim.Adam(ref, lr=1e-3)
+    for p, g in zip(ours, grads):
+        p.grad = g
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        opt.step()                      # warm-up step 1 (eager)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        opt.step()                      # captured, not executed
+    n_replays = 9
+    for _ in range(n_replays):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert opt.step_count == 1 + n_replays
+    for _ in range(1 + n_replays):
+        for p, g in zip(ref, grads):
+            p.grad = g.clone()
+        ref_opt.step()
+    for a, b in zip(ours, ref):
+        assert torch.allclose(a.detach(), b.detach(), rtol=2e-5, atol=2e-6)
