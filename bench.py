@@ -294,6 +294,9 @@ def kernel_rooflines(w):
         t_scan = event_time_us(fused_scan_call(w, pos, pred, _lib.FLAG_TRI_WS_READY, share=scan))   # the fused launch alone
         t_prep_tri = event_time_us(lambda: tri_distance_indexed(w.gt, pos, w.faces))  # prep + tri-only scan
         t_tri_flat = event_time_us(lambda: tri_distance_indexed(w.gt, pos, w.faces, order=None))
+        from geometrics_amd.tri_distance import tri_distance as tri_soup
+        corners = [pos[:, w.faces[:, i]].contiguous() for i in range(3)]      # what utils.py:467-469 hands to tri_dist
+        t_tri_soup = event_time_us(lambda: tri_soup(w.gt, *corners))
         t_nn = event_time_us(lambda: chamfer_nn(w.gt, pred, 0))
         t_nn_fma = event_time_us(lambda: chamfer_nn(w.gt, pred, _lib.FLAG_NN_FMA))
         t_scan_fma = event_time_us(fused_scan_call(w, pos, pred, _lib.FLAG_NN_FMA))
@@ -332,7 +335,8 @@ def kernel_rooflines(w):
                         "the prep launch writes and all eight XCDs re-read through their own L2 (harmless at this launch time: "
                         "< 0.2 TB/s)",
         "separate_launches_us": {"chamfer_nn": round(t_nn, 1), "tri_prep_plus_scan": round(t_prep_tri, 1),
-                                 "tri_flat_scan": round(t_tri_flat, 1)},
+                                 "tri_flat_scan": round(t_tri_flat, 1),
+                                 "tri_reference_shaped_module (corner tensors, cached Morton order)": round(t_tri_soup, 1)},
         "fma_arithmetic_us": {"chamfer_nn (GEOM_FLAG_NN_FMA)": round(t_nn_fma, 1), "fused call": round(t_scan_fma, 1)}}
     if prep_row is not None:
         scan["prep_launch"] = {"kernel": "tri_prep_grouped_kernel", "valu_instructions_per_launch": int(prep_row.get("SQ_INSTS_VALU_per_launch", 0))}

@@ -10,6 +10,10 @@
 #include <torch/extension.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/hip/HIPGraphsC10Utils.h>
+
+#include <map>
+#include <utility>
 
 #include "geom_hip.h"
 
@@ -48,6 +52,49 @@ void chamfer_forward_cuda(at::Tensor xyz1, at::Tensor xyz2, at::Tensor dist1, at
              "geom_chamfer_nn_f32");
 }
 
+// Visiting order for the two-level scan when all there is are corner tensors (no face list): one order per (triangle
+// count, device), rebuilt every 256 calls on the device from the first mesh's centroids (30-bit Morton curve; a dozen
+// small ATen launches, no host synchronisation), never during a stream capture.  A stale order costs speed only: the
+// scan's keys carry the original triangle index.  Same policy as geometrics_amd.tri_distance.soup_order.
+at::Tensor morton_order(const at::Tensor &centroids)
+{
+    auto c = at::nan_to_num(centroids, 0.0, 0.0, 0.0);
+    auto lo = std::get<0>(c.min(0));
+    auto span = (std::get<0>(c.max(0)) - lo).clamp_min(1e-30);
+    auto q = ((c - lo) / span * 1023.0).to(at::kLong).clamp(0, 1023);
+    auto spread = [](at::Tensor x) {
+        x = (x | (x * 65536)) & 0x030000FF;
+        x = (x | (x * 256)) & 0x0300F00F;
+        x = (x | (x * 16)) & 0x030C30C3;
+        return (x | (x * 4)) & 0x09249249;
+    };
+    auto code = spread(q.select(1, 0)) | (spread(q.select(1, 1)) * 2) | (spread(q.select(1, 2)) * 4);
+    return at::argsort(code, /*stable=*/true, 0, false).to(at::kInt).contiguous();
+}
+
+struct SoupOrder {
+    at::Tensor order;
+    int calls = 0;
+};
+
+const at::Tensor *soup_order(const at::Tensor &tri1, const at::Tensor &tri2, const at::Tensor &tri3)
+{
+    static std::map<std::pair<int64_t, int>, SoupOrder> cache;
+    const int64_t m = tri1.size(1);
+    if (tri1.size(0) == 0 || m < 64) return nullptr;
+    auto &slot = cache[{m, (int)tri1.get_device()}];
+    const bool capturing = c10::hip::currentStreamCaptureStatusMayInitCtx() != c10::hip::CaptureStatus::None;
+    if (slot.order.defined() && (slot.calls < 256 || capturing)) {
+        ++slot.calls;
+        return &slot.order;
+    }
+    if (capturing) return nullptr;
+    at::NoGradGuard no_grad;
+    slot.order = morton_order((tri1[0] + tri2[0] + tri3[0]) * (1.0 / 3.0));
+    slot.calls = 1;
+    return &slot.order;
+}
+
 void tri_forward_cuda(at::Tensor xyz1, at::Tensor tri1, at::Tensor tri2, at::Tensor tri3, at::Tensor dist, at::Tensor point,
                       at::Tensor index, int64_t flags)
 {
@@ -62,11 +109,17 @@ void tri_forward_cuda(at::Tensor xyz1, at::Tensor tri1, at::Tensor tri2, at::Ten
     check_points(point, "point", at::kInt, 2, n);
     check_points(index, "index", at::kInt, 2, n);
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(xyz1.device());   // PyTorch-ROCm tensors carry device type "cuda"
-    // workspace-free culled scan: the exact prototype of the reference launcher (tri_distance.cpp:4-13)
-    raise_on(geom_tri_distance_f32((int)b, (int)n, xyz1.data_ptr<float>(), (int)m, tri1.data_ptr<float>(), tri2.data_ptr<float>(),
-                                   tri3.data_ptr<float>(), dist.data_ptr<float>(), point.data_ptr<int>(), index.data_ptr<int>(),
-                                   (unsigned)flags, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
-             "geom_tri_distance_f32");
+    // the reference launcher's arguments (tri_distance.cpp:4-13) + what the fast scan needs: a visiting order (cached, see
+    // above) and a scratch tensor for the per-triangle records (torch's caching allocator: free after the first call,
+    // capture-safe)
+    const at::Tensor *order = soup_order(tri1, tri2, tri3);
+    const size_t ws_bytes = geom_tri_distance_workspace_bytes((int)b, (int)n, (int)m);
+    at::Tensor ws = at::empty({(int64_t)(ws_bytes / 4 + 4)}, xyz1.options());
+    raise_on(geom_tri_distance_ws_f32((int)b, (int)n, xyz1.data_ptr<float>(), (int)m, tri1.data_ptr<float>(), tri2.data_ptr<float>(),
+                                      tri3.data_ptr<float>(), order ? order->data_ptr<int>() : nullptr, dist.data_ptr<float>(),
+                                      point.data_ptr<int>(), index.data_ptr<int>(), (unsigned)flags, ws.data_ptr<float>(), ws_bytes,
+                                      c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
+             "geom_tri_distance_ws_f32");
 }
 
 } // namespace

@@ -79,6 +79,36 @@ def face_order(verts, faces):
     return order
 
 
+# ---- the reference-shaped entry (tri1 / tri2 / tri3 corner tensors, tri_distance.py:9-43): no face list to key a cache on --
+# the corner tensors are fresh gathers every step (utils.py:467-470).  What stays the same from call to call is the TOPOLOGY
+# behind them, and mesh deformation keeps a topology's visiting order coherent; so one order is kept per (triangle count,
+# device) and rebuilt on the device (Morton curve of the first mesh's centroids: a dozen small launches, no host
+# synchronisation) every SOUP_REFRESH calls -- a stale or foreign order can only cost speed, never change a result
+# (the scan's keys carry the original triangle index).
+SOUP_REFRESH = 256
+_soup_orders = {}   # (m, device) -> [order, calls since it was built]
+
+
+def soup_order(tri1, tri2, tri3):
+    """Visiting order for a [B,M,3] x 3 triangle soup (see above); None while a HIP graph is being captured before any
+    order exists (the flat scan then serves the call)."""
+    m = tri1.shape[1]
+    if tri1.shape[0] == 0 or m < 64:
+        return None
+    key = (m, tri1.device)
+    hit = _soup_orders.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if hit is not None and (hit[1] < SOUP_REFRESH or capturing):
+        hit[1] += 1
+        return hit[0]
+    if capturing:
+        return None
+    with torch.no_grad():
+        order = morton_order((tri1[0] + tri2[0] + tri3[0]) * (1.0 / 3.0))
+    _soup_orders[key] = [order, 1]
+    return order
+
+
 def _order_ptr(order, m, dev):
     if order is None:
         return None, None
@@ -120,7 +150,9 @@ def forward_cuda(xyz1, tri1, tri2, tri3, dist, point, index, flags=0, use_worksp
     _lib.check(code, "geom_tri_distance_f32")
 
 
-def tri_distance(xyz1, tri1, tri2, tri3, flags=0, use_workspace=True, order=None):
+def tri_distance(xyz1, tri1, tri2, tri3, flags=0, use_workspace=True, order="auto"):
+    """order: "auto" (cached Morton order of the triangle centroids -> two-level scan, see soup_order), None (flat scan)
+    or an explicit int32 permutation of the triangles."""
     xyz1 = _lib.require(xyz1.detach(), "xyz1", torch.float32, 3, 3)
     tris = [_lib.require(t.detach(), "tri%d" % (i + 1), torch.float32, 3, 3) for i, t in enumerate((tri1, tri2, tri3))]
     dev = _lib.same_device(xyz1, *tris)
@@ -129,6 +161,8 @@ def tri_distance(xyz1, tri1, tri2, tri3, flags=0, use_workspace=True, order=None
         if t.shape != tris[0].shape or t.shape[0] != b:
             raise RuntimeError("tri1/tri2/tri3 must share one [B,M,3] shape with xyz1's batch")
     dist, point, index = _outputs(b, n, dev)
+    if isinstance(order, str):
+        order = soup_order(*tris) if use_workspace else None
     forward_cuda(xyz1, tris[0], tris[1], tris[2], dist, point, index, flags, use_workspace, order)
     return dist, point, index
 

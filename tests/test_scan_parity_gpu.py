@@ -436,3 +436,37 @@ def test_compiled_forward_cuda_entry_points_equal_the_ctypes_binding(oracle_mod,
     np.testing.assert_array_equal(dist.cpu().numpy().view(np.uint32), et.view(np.uint32))
     with pytest.raises(RuntimeError):
         _shim.cd.forward_cuda(a.double(), c, d1, d2, i1, i2)
+
+
+def test_reference_shaped_tri_module_takes_the_two_level_scan_with_a_cached_order(gpu):
+    """TriDistance()(xyz, tri1, tri2, tri3) (tri_distance.py:9-43; no face list): the module keeps one Morton order per
+    triangle count and runs the two-level scan with it -- same bits as the flat scan and as the oracle, also with an order
+    cached from ANOTHER geometry of the same size (a stale order may cost speed, never a result), and through the
+    compiled `tri.forward_cuda` entry point."""
+    import oracle
+    from geometrics_amd import _shim, tri_distance as td
+    V, Fc = meshgen.icosphere(3)
+    B, n = 2, 700
+    faces = torch.from_numpy(Fc).to(gpu)
+    gt = torch.from_numpy(meshgen.gt_cloud(B, n)).to(gpu)
+    td._soup_orders.clear()
+    for seed in (0, 7):                 # second pass: the cached order belongs to the first geometry
+        verts = torch.from_numpy(meshgen.jittered_batch(V, B, first=seed)).to(gpu)
+        if seed:
+            verts = verts.flip(1).contiguous()      # same triangle count, every triangle somewhere else
+        tris = [verts[:, faces[:, i]].contiguous() for i in range(3)]
+        d, p, i = td.TriDistance()(gt, *tris)
+        d0, p0, i0 = td.tri_distance(gt, *tris, order=None)
+        assert torch.equal(d, d0) and torch.equal(p, p0) and torch.equal(i, i0)
+        ed, ep, ei = oracle.tri_scan(gt.cpu().numpy(), *(t.cpu().numpy() for t in tris))
+        assert np.array_equal(i.cpu().numpy(), ei) and np.array_equal(p.cpu().numpy(), ep)
+        assert np.array_equal(d.cpu().numpy().view(np.uint32), ed.view(np.uint32))
+        dist, point, index = (torch.empty(B, n, dtype=t, device=gpu) for t in (torch.float32, torch.int32, torch.int32))
+        _shim.tri.forward_cuda(gt, *tris, dist, point, index)
+        assert torch.equal(dist, d) and torch.equal(point, p) and torch.equal(index, i)
+    key = (Fc.shape[0], gt.device)
+    assert key in td._soup_orders and td._soup_orders[key][1] == 2       # built once, used twice
+    td._soup_orders[key][1] = td.SOUP_REFRESH                             # due for a rebuild
+    old = td._soup_orders[key][0]
+    td.TriDistance()(gt, *tris)
+    assert td._soup_orders[key][1] == 1 and td._soup_orders[key][0] is not old
