@@ -737,16 +737,19 @@ struct ReduceJobs {
 };
 
 // 32 outputs (of 4 columns) x 8 slot groups per workgroup: group sg adds its contiguous share of the slots in slot order
-// (four loads in flight), the eight group sums are then added in group order -- a fixed tree for a given (I, J, splits).
-constexpr int RED_OUT = 32, RED_GROUPS = 8;
-__global__ __launch_bounds__(RED_OUT *RED_GROUPS) void dense_reduce_kernel(ReduceJobs jobs)
+// (four loads in flight), the group sums are then added in group order -- a fixed tree for a given (I, J, splits).  Jobs
+// with a single output row and many slots (column sums: the bias gradients, 1 288 partial rows at the BASELINE shard) take
+// 4 outputs x 64 groups instead, so that the slot dimension is what the threads share.
+constexpr int RED_THREADS = 256, RED_OUT = 32;
+__global__ __launch_bounds__(RED_THREADS) void dense_reduce_kernel(ReduceJobs jobs)
 {
-    __shared__ f32x4 part[RED_GROUPS][RED_OUT];
+    __shared__ f32x4 part[RED_THREADS];
     const ReduceJob q = jobs.job[blockIdx.y];
     const int jq = q.J >> 2;
-    const int o = threadIdx.x % RED_OUT, sg = threadIdx.x / RED_OUT;
-    if ((int)blockIdx.x * RED_OUT >= q.I * jq) return; // a job smaller than the largest one (uniform per workgroup)
-    const int e = blockIdx.x * RED_OUT + o;
+    const int outs = q.I == 1 ? 4 : RED_OUT, groups = RED_THREADS / outs;
+    const int o = threadIdx.x % outs, sg = threadIdx.x / outs;
+    if ((int)blockIdx.x * outs >= q.I * jq) return; // a job smaller than the largest one (uniform per workgroup)
+    const int e = blockIdx.x * outs + o;
     const bool live = e < q.I * jq;
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
     int i = 0, j = 0;
@@ -762,7 +765,7 @@ __global__ __launch_bounds__(RED_OUT *RED_GROUPS) void dense_reduce_kernel(Reduc
         }
         const int64_t pitch = (int64_t)q.RA * q.CW;
         const float *p = q.part + ((int64_t)slot0 * q.RA + il) * q.CW + j;
-        const int s0 = (int)((int64_t)n * sg / RED_GROUPS), s1 = (int)((int64_t)n * (sg + 1) / RED_GROUPS);
+        const int s0 = (int)((int64_t)n * sg / groups), s1 = (int)((int64_t)n * (sg + 1) / groups);
         int s = s0;
         for (; s + 4 <= s1; s += 4) {
             const f32x4 a0 = *reinterpret_cast<const f32x4 *>(p + (s + 0) * pitch);
@@ -773,12 +776,11 @@ __global__ __launch_bounds__(RED_OUT *RED_GROUPS) void dense_reduce_kernel(Reduc
         }
         for (; s < s1; ++s) t = t + *reinterpret_cast<const f32x4 *>(p + s * pitch);
     }
-    part[sg][o] = t;
+    part[sg * outs + o] = t;
     __syncthreads();
     if (sg == 0 && live) {
-        f32x4 r = part[0][o];
-#pragma unroll
-        for (int k = 1; k < RED_GROUPS; ++k) r = r + part[k][o];
+        f32x4 r = part[o];
+        for (int k = 1; k < groups; ++k) r = r + part[k * outs + o];
         float *dst = q.out + (int64_t)i * q.J + j;
         dst[0] = r[0], dst[1] = r[1], dst[2] = r[2], dst[3] = r[3];
     }
@@ -961,6 +963,44 @@ extern "C" int geom_dense_bwd_f32(int rows, int cin, int c, const float *x, cons
     return geom::launch_status();
 }
 
+// grad_w[i] (and grad_bias[i], may be NULL) of `count` layers out of their workspaces, ONE launch -- which also finishes
+// `ncs` pending column-sum jobs (cs_outs[i][0..cs_cols[i]) = column sums of cs_partials[i], cs_rows[i] x cs_cols[i] row-major:
+// the per-workgroup bias-gradient partials of the aggregation backward, what geom_colsum_batch_f32 does in a launch of
+// its own).  Host arrays; count + ncs jobs in total <= GEOM_DENSE_MAX_REDUCE_JOBS.
+extern "C" int geom_dense_reduce2_f32(int count, const int *rows, const int *cin, const int *c, const float *const *workspaces,
+                                      float *const *grad_w, float *const *grad_bias, int ncs, const float *const *cs_partials,
+                                      const int *cs_rows, const int *cs_cols, float *const *cs_outs, void *stream)
+{
+    if (count < 0 || ncs < 0) return GEOM_EINVAL;
+    if (count + ncs == 0) return 0;
+    if (count && (!rows || !cin || !c || !workspaces || !grad_w)) return GEOM_EINVAL;
+    if (ncs && (!cs_partials || !cs_rows || !cs_cols || !cs_outs)) return GEOM_EINVAL;
+    ReduceJobs jobs;
+    int n = 0, widest = 0;
+    for (int l = 0; l < count; ++l) {
+        if (!workspaces[l] || !grad_w[l] || rows[l] <= 0 || cin[l] <= 0 || c[l] <= 0 || c[l] > 192 || c[l] % 4) return GEOM_EINVAL;
+        if (n + 2 > GEOM_DENSE_MAX_REDUCE_JOBS) return GEOM_ETOOBIG;
+        const SplitGeo g = split_geometry(cin[l], rows[l], num_cus());
+        jobs.job[n++] = ReduceJob{workspaces[l], grad_w[l], cin[l], c[l], SPLIT_RB * 16, 192, g.full_tiles, g.s_full, g.s_left};
+        widest = cin[l] * (c[l] / 4) > widest ? cin[l] * (c[l] / 4) : widest;
+        if (grad_bias && grad_bias[l]) { // column sums: a 1-row "tile" per split, pitch = c
+            if (g.full_tiles == 0) return GEOM_EUNSUPPORTED;
+            jobs.job[n++] = ReduceJob{workspaces[l] + (int64_t)g.slots * SPLIT_RB * 16 * 192, grad_bias[l], 1, c[l], 1, c[l], 1,
+                                      g.s_full, 0};
+            widest = c[l] / 4 * (RED_OUT / 4) > widest ? c[l] / 4 * (RED_OUT / 4) : widest;
+        }
+    }
+    for (int i = 0; i < ncs; ++i) {
+        if (!cs_partials[i] || !cs_outs[i] || cs_rows[i] < 0 || cs_cols[i] <= 0 || cs_cols[i] % 4) return GEOM_EINVAL;
+        if (n + 1 > GEOM_DENSE_MAX_REDUCE_JOBS) return GEOM_ETOOBIG;
+        jobs.job[n++] = ReduceJob{cs_partials[i], cs_outs[i], 1, cs_cols[i], 1, cs_cols[i], 1, cs_rows[i], 0};
+        widest = cs_cols[i] / 4 * (RED_OUT / 4) > widest ? cs_cols[i] / 4 * (RED_OUT / 4) : widest; // 4 outputs per workgroup
+    }
+    hipLaunchKernelGGL(dense_reduce_kernel, dim3((widest + RED_OUT - 1) / RED_OUT, n), dim3(RED_THREADS), 0,
+                       static_cast<hipStream_t>(stream), jobs);
+    return geom::launch_status();
+}
+
 // grad_w[i] (and grad_bias[i], may be NULL) of `count` layers out of their workspaces, ONE launch
 extern "C" int geom_dense_reduce_f32(int count, const int *rows, const int *cin, const int *c, const float *const *workspaces,
                                      float *const *grad_w, float *const *grad_bias, void *stream)
@@ -981,7 +1021,7 @@ extern "C" int geom_dense_reduce_f32(int count, const int *rows, const int *cin,
                                       g.s_full, 0};
         }
     }
-    hipLaunchKernelGGL(dense_reduce_kernel, dim3((widest + RED_OUT - 1) / RED_OUT, n), dim3(RED_OUT * RED_GROUPS), 0,
+    hipLaunchKernelGGL(dense_reduce_kernel, dim3((widest + RED_OUT - 1) / RED_OUT, n), dim3(RED_THREADS), 0,
                        static_cast<hipStream_t>(stream), jobs);
     return geom::launch_status();
 }

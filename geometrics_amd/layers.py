@@ -202,6 +202,7 @@ class deferred_parameter_gradients:
         defer_parameter_gradients = self.prev
         return False
 _pending_colsums = {}     # autograd graph-task id -> [(partials, rows, cols, out alias, stream)]
+_pending_reduce = {}      # autograd graph-task id -> [(rows, cin, c, workspace, dW alias, stream, param ref)]: weight-gradient partials
 # bias parameter -> the live autograd nodes that produce a gradient for it.  A bias shared by two layers (or a layer applied
 # twice) gets its gradients ADDED by the engine inside the pass, which reads them on arrival: more than one live node means
 # immediate reduction for all of them.  Nodes leave the set when their graph is freed.
@@ -256,6 +257,50 @@ def _check_landed(param_ref, out):
                            % (tuple(param.grad.shape), tuple(out.shape)))
 
 
+_flush_registered = set()     # graph tasks whose end-of-pass callback is queued
+
+
+def _register_flush(task):
+    """ONE end-of-pass callback per backward pass: it finishes the pending bias-gradient column sums AND the pending
+    weight-gradient partial sums, in one launch where their shapes allow."""
+    if task in _flush_registered:
+        return
+    for stale in [t for t in _flush_registered if t < task - 64]:      # passes that died of an exception
+        _flush_registered.discard(stale)
+        _pending_colsums.pop(stale, None)
+        _pending_reduce.pop(stale, None)
+    _flush_registered.add(task)
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_pass(task))
+
+
+def _flush_pass(task):
+    _flush_registered.discard(task)
+    red = _pending_reduce.get(task, [])
+    cs = _pending_colsums.get(task, [])
+    streams = {j[5] for j in red} | {j[4] for j in cs}
+    joint = (red and cs and len(streams) == 1 and all(j[2] % 4 == 0 for j in cs)
+             and 2 * len(red) + len(cs) <= _lib.DENSE_MAX_REDUCE_JOBS)
+    if not joint:
+        _flush_colsums(task)
+        _flush_reduce(task)
+        return
+    _pending_reduce.pop(task, None)
+    _pending_colsums.pop(task, None)
+    stream = next(iter(streams))
+    n, m = len(red), len(cs)
+    ints = lambda seq: (ctypes.c_int * len(seq))(*seq)
+    ptrs = lambda seq: (ctypes.c_void_p * len(seq))(*[t.data_ptr() for t in seq])
+    with torch.cuda.device(stream.device):
+        _lib.check(_lib.lib().geom_dense_reduce2_f32(
+            n, ints([j[0] for j in red]), ints([j[1] for j in red]), ints([j[2] for j in red]), ptrs([j[3] for j in red]),
+            ptrs([j[4] for j in red]), None, m, ptrs([j[0] for j in cs]), ints([j[1] for j in cs]), ints([j[2] for j in cs]),
+            ptrs([j[3] for j in cs]), stream.cuda_stream), "geom_dense_reduce2_f32")
+    for job in red:
+        _check_landed(job[6], job[4])
+    for job in cs:
+        _check_landed(job[5], job[3])
+
+
 def _flush_colsums(task):
     jobs = _pending_colsums.pop(task, [])
     by_stream = {}
@@ -278,10 +323,8 @@ def _queue_colsum(partials, rows, cols, out, param=None):
     task = torch._C._current_graph_task_id()
     jobs = _pending_colsums.get(task)
     if jobs is None:
-        for stale in [t for t in _pending_colsums if t < task - 64]:      # passes that died of an exception
-            del _pending_colsums[stale]
         jobs = _pending_colsums[task] = []
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_colsums(task))
+    _register_flush(task)
     jobs.append((partials, rows, cols, _alias(out), torch.cuda.current_stream(out.device),
                  None if param is None else weakref.ref(param)))
 
@@ -602,7 +645,6 @@ class _Dense(torch.autograd.Function):
 
 
 # ---- the layer's dense products on the fp32 matrix cores (csrc/dense_gemm.hip) -----------------------------------------
-_pending_reduce = {}      # autograd graph-task id -> [(rows, cin, c, workspace, dW alias)]: one reduction launch per pass
 
 
 def _flush_reduce(task):
@@ -660,10 +702,8 @@ class _DenseMM(torch.autograd.Function):
             task = torch._C._current_graph_task_id()
             jobs = _pending_reduce.get(task)
             if jobs is None:
-                for stale in [t for t in _pending_reduce if t < task - 64]:
-                    del _pending_reduce[stale]
                 jobs = _pending_reduce[task] = []
-                torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_reduce(task))
+            _register_flush(task)
             jobs.append((rows, cin, c, ws, _alias(grad_w).view(cin, c), torch.cuda.current_stream(w.device), ctx.w_ref))
         else:
             _dense_kernels.reduce([(rows, cin, c, ws, grad_w.view(cin, c), None)])

@@ -286,7 +286,7 @@ int geom_zn_gcn_aggregate_ell_bwd_f32(int b, int nv, int c, int k, int w, const 
  * geom_dense_reduce_f32 adds them up in a fixed order -- ONE launch for the pending weight / bias gradients of up to
  *   GEOM_DENSE_MAX_LAYERS layers (host arrays of per-layer sizes and pointers; grad_bias or its entries may be NULL). */
 #define GEOM_DENSE_MAX_LAYERS 8
-#define GEOM_DENSE_MAX_REDUCE_JOBS 16
+#define GEOM_DENSE_MAX_REDUCE_JOBS 32
 int geom_dense_fwd_f32(int rows, int cin, int c, const float *x, const float *w, int ksplit, const float *bias,
                        float *out, float *sup, uint16_t *mask, void *stream);
 int geom_dense_bwd_input_f32(int rows, int cin, int c, const float *g, const float *w, float *grad_x, void *stream);
@@ -297,6 +297,11 @@ int geom_dense_bwd_weight_f32(int rows, int cin, int c, const float *x, const fl
  * cin <= 192 and x rows are 16-byte aligned, the two launches above otherwise.  workspace / reduction as above. */
 int geom_dense_bwd_f32(int rows, int cin, int c, const float *x, const float *g, const float *w, float *grad_x,
                        float *workspace, int want_colsum, void *stream);
+/* geom_dense_reduce_f32 + `ncs` column-sum jobs (cs_outs[i] = column sums of the cs_rows[i] x cs_cols[i] row-major cs_partials[i],
+ * cs_cols % 4 == 0) in the same launch: the bias gradients of the aggregation backward join the weight gradients. */
+int geom_dense_reduce2_f32(int count, const int *rows, const int *cin, const int *c, const float *const *workspaces,
+                           float *const *grad_w, float *const *grad_bias, int ncs, const float *const *cs_partials,
+                           const int *cs_rows, const int *cs_cols, float *const *cs_outs, void *stream);
 int geom_dense_reduce_f32(int count, const int *rows, const int *cin, const int *c, const float *const *workspaces,
                           float *const *grad_w, float *const *grad_bias, void *stream);
 

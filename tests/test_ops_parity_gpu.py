@@ -564,7 +564,10 @@ def test_bias_gradients_of_a_backward_pass_are_finished_in_one_batched_launch(gp
 
     now_b, now_w = run(False)
     later_b, later_w = run(True)
-    for a, b in zip(now_b + now_w, later_b + later_w):
+    for a, b in zip(now_b + now_w, later_b + later_w):      # the end-of-pass launch adds the same partials in its own fixed
+        close(b.cpu().numpy(), a.cpu().numpy(), 2e-6)       # order (one launch for bias AND weight gradients): round-off only
+    again_b, again_w = run(True)
+    for a, b in zip(later_b + later_w, again_b + again_w):  # and it is reproducible bit for bit
         assert torch.equal(a, b)
     close(later_b[2].cpu().numpy(), g_out.sum((0, 1)).cpu().numpy(), 1e-4)       # last layer, no activation: plain column sums
 
@@ -578,7 +581,9 @@ def test_bias_gradients_of_a_backward_pass_are_finished_in_one_batched_launch(gp
     hook = stack[1].bias.register_hook(lambda gr: seen.append(gr.clone()))       # a hook reads it inside the pass
     hook_b, _ = run(True)
     hook.remove()
-    assert torch.equal(seen[0], now_b[1]) and all(torch.equal(a, b) for a, b in zip(hook_b, now_b))
+    assert torch.equal(seen[0], now_b[1]) and torch.equal(hook_b[1], now_b[1])
+    for a, b in zip(hook_b, now_b):
+        close(a.cpu().numpy(), b.cpu().numpy(), 2e-6)
     # a bias shared by two layers: the engine adds the two gradients inside the pass, so neither may be postponed
     tied = layers.Batch_Image_ZERON_GCNGCN(48, 48).to(gpu)
     tied.bias = stack[1].bias
@@ -594,7 +599,7 @@ def test_bias_gradients_of_a_backward_pass_are_finished_in_one_batched_launch(gp
             return stack[1].bias.grad.clone()
         finally:
             layers.defer_parameter_gradients = False
-    assert torch.equal(tied_pass(False), tied_pass(True))
+    assert torch.equal(tied_pass(False), tied_pass(True))      # a shared bias is never postponed: same launches either way
     del tied
     # deferral is opt-in: by default nothing is pending at any time and the values are the same
     assert layers.defer_parameter_gradients is False
@@ -604,7 +609,9 @@ def test_bias_gradients_of_a_backward_pass_are_finished_in_one_batched_launch(gp
         for i, layer in enumerate(stack):
             h = layer(h, adj, F.relu if i < 2 else None)
         got = torch.autograd.grad(h, [layer.bias for layer in stack], g_out)
-    assert all(torch.equal(a, b) for a, b in zip(got, now_b)) and not layers._pending_colsums
+    assert not layers._pending_colsums
+    for a, b in zip(got, now_b):
+        close(a.cpu().numpy(), b.cpu().numpy(), 2e-6)
     # HIP-graph capture of forward + backward: the batched launch is part of the graph
     for p in stack.parameters():
         p.grad = None
