@@ -3,7 +3,7 @@
 # Three separate passes (TCC counters do not fit one pass; PMC runs carry --kernel-trace only), eager launches so
 # that every kernel is an individual dispatch.  Run on the GPU box from the repo root:
 #     bash tools/pmc_traffic.sh   ->  gpurun_out/pmc/{fetch,write,valu}/..., then
-#     python tools/pmc_traffic_json.py gpurun_out/pmc profiles/r02_pmc_counters.json
+#     python tools/pmc_traffic_json.py gpurun_out/pmc profiles/r03_pmc_counters.json
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "valu SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES"; do
