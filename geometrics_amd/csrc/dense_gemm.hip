@@ -66,8 +66,14 @@ __device__ __forceinline__ float ldg(const float *base, unsigned byte_off)
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 __device__ __forceinline__ f32x4 ldg4(const float *base, unsigned byte_off)
+{ // 16 bytes at 4-byte alignment (still ONE global_load_dwordx4): the 963-float rows of the first layer's features
+    const f4u v = *reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(base) + byte_off);
+    return (f32x4){v.x, v.y, v.z, v.w};
+}
+struct __attribute__((packed, aligned(4))) f3u { float x, y, z; };
+__device__ __forceinline__ f3u ldg3(const float *base, unsigned byte_off)
 {
-    return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(base) + byte_off);
+    return *reinterpret_cast<const f3u *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
 // TC panel, 16-byte loads (rows 16-byte aligned, T % 4 == 0): 8 threads per row, 32 rows per pass
@@ -556,151 +562,213 @@ struct SplitArgs {
     float *colsum; // optional [s_full][J]: column sums of B over each split's rows (the bias gradient), tile 0 only
 };
 
-template <int RB, int RBP, int NCW, bool A_VEC>
+// The split body keeps only the X panel in LDS.  G (the operand every wave needs a DIFFERENT 48-column slice of, and that
+// all workgroups of a split share through L2) goes straight into fragment registers: lane (x, g) of a wave loads the 12
+// bytes G[t0 + 4s + g][48*wave + 3x .. +2] -- 16 lanes x 12 B = one contiguous 192-byte run per row -- and MFMA number u of
+// the k-step takes component u as its column-side operand, so accumulator (i, u) of the lane holds
+// C[16 i + x'][48*wave + 12 g' + 3 r + u]: twelve CONSECUTIVE output columns per lane.  The registers form a ring over two
+// stages x 8 k-steps: the slot a k-step has just consumed is refilled at once with the same k-step of the stage after
+// next.  Measured before (probe builds with the LDS traffic removed): the G panel's LDS writes + fragment reads were ~15 of
+// the first layer's 77 us.
+template <int RB, int RA, int A_FLOATS, int SET, class PA, class Tail>
+__device__ __forceinline__ void split_stage(const float *cur, float *wr, f32x4 (&acc)[RB][3], float (&fa)[2][RB], f3u (&bq)[2][DG_KS],
+                                            PA &pa, const StageIO &io, unsigned b_lane, unsigned b_step, Tail tail)
+{
+    constexpr int U = PA::PASSES;
+    const int x = threadIdx.x & 15, g = (threadIdx.x >> 4) & 3;
+    const float *b_base = io.b_base; // by value: `tail` re-aims io in the last k-step, the refills below belong to this aim
+    const unsigned b_limit = io.b_limit;
+#pragma unroll
+    for (int s = 0; s < DG_KS; ++s) {
+        { // X fragments of the next k-step (of the next stage after the last one)
+            const float *src = s + 1 < DG_KS ? cur : wr;
+            const int sn = s + 1 < DG_KS ? s + 1 : 0;
+            const float *pa_l = src + g * ld_rc(RA) + x;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) fa[(s + 1) & 1][i] = pa_l[4 * sn * ld_rc(RA) + i * 16];
+        }
+        if (s < 4) {
+#pragma unroll
+            for (int u = s * U / 4; u < (s + 1) * U / 4; ++u) pa.template issue_pass<SET>(u, io.a_base, io.a_limit);
+        } else if (s < 7) {
+#pragma unroll
+            for (int u = (s - 4) * U / 3; u < (s - 3) * U / 3; ++u) pa.template store_pass<true, SET ^ 1>(u, wr, io.st_t0, io.st_tmax);
+        }
+        if (s == DG_KS - 1) tail();
+        const f3u b = bq[SET][s];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, fa[s & 1][i], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, fa[s & 1][i], acc[i][1], 0, 0, 0);
+            acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, fa[s & 1][i], acc[i][2], 0, 0, 0);
+        }
+        bq[SET][s] = ldg3(b_base, min(b_lane + (unsigned)s * b_step, b_limit)); // the same k-step of the stage after next
+#pragma unroll
+        for (int m = 0; m < RB * 3; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // DS read
+            if (s < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // VMEM read
+            else __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // DS write
+            __builtin_amdgcn_sched_group_barrier(0x006, 2, 0); // VALU / SALU
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s == 6) {
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int RB, int RBP, bool A_VEC>
 __device__ __forceinline__ void split_body(const SplitArgs &q, float *lds, int i0, int split, int nsplit, int slot, bool want_cs)
 {
     constexpr int RA = RB * 16;
-    constexpr int CW = NCW * 64;
+    constexpr int CW = 192;
     constexpr int A_FLOATS = 32 * ld_rc(RA);
-    constexpr int B_FLOATS = 32 * ld_rc(CW);
-    constexpr int BUF = A_FLOATS + B_FLOATS;
+    constexpr int BUF = A_FLOATS;
     const int wave = threadIdx.x >> 6;
-    // rows of the summed dimension in units of 4 (one MFMA k-step); T % 4 != 0 is zero-filled by the loaders
+    const int x = threadIdx.x & 15, g = (threadIdx.x >> 4) & 3;
+    // rows of the summed dimension in units of 4 (one MFMA k-step); T % 4 != 0 is zero-filled by the X loader
     const int n4 = (q.T + 3) / 4;
     const int t_begin = (int)((int64_t)n4 * split / nsplit) * 4;
     const int t_end = min((int)((int64_t)n4 * (split + 1) / nsplit) * 4, q.T);
     const int nst = (t_end - t_begin + DG_BK - 1) / DG_BK;
 
-    f32x4 acc[RB][NCW], accx;
+    f32x4 acc[RB][3];
 #pragma unroll
     for (int i = 0; i < RB; ++i)
 #pragma unroll
-        for (int j = 0; j < NCW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f; // column sums of G over this split's rows == g (mod 4), columns 48*wave + 3x ..
 
     typedef typename std::conditional<A_VEC, PanelRCv<RA>, PanelRCs<RA>>::type PA;
-    typedef PanelRCv<CW> PB;
     PA pa;
-    PB pb;
-    f32x4 csum[PB::PASSES];
-#pragma unroll
-    for (int p = 0; p < PB::PASSES; ++p) csum[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (nst > 0) {
-        if constexpr (A_VEC) pa.prepare([=](int r4) -> unsigned { const int i = i0 + r4 * 4; return (unsigned)(i < q.I ? i : q.I - 4); }, (unsigned)q.lda);
+        if constexpr (A_VEC) pa.prepare([=](int r4) -> unsigned { const int i = i0 + r4 * 4; return (unsigned)(i + 3 < q.I ? i : q.I - 4); }, (unsigned)q.lda);
         else pa.prepare([=](int r) -> unsigned { const int i = i0 + r; return (unsigned)(i < q.I ? i : q.I - 1); }, (unsigned)q.lda);
-        pb.prepare([=](int r4) -> unsigned { const int j = r4 * 4; return (unsigned)(j < q.J ? j : q.J - 4); }, (unsigned)q.ldb);
         const unsigned a_total = (unsigned)q.T * (unsigned)q.lda, b_total = (unsigned)q.T * (unsigned)q.ldb;
+        // G: this lane's 12 bytes of row g of a k-step, columns clamped into the row (J % 4 == 0 but maybe not % 3)
+        const int jc = min(wave * 48 + 3 * x, q.J - 3);
+        const unsigned b_lane = ((unsigned)g * (unsigned)q.ldb + (unsigned)jc) * 4u;
+        const unsigned b_step = 4u * (unsigned)q.ldb * 4u; // four rows per k-step
         StageIO io;
         int l_st = 0;
         auto aim = [&]() {
             const int t0 = t_begin + l_st * DG_BK;
             io.a_base = PA::stage_base(q.a, (unsigned)q.lda, t0);
             io.a_limit = PA::stage_limit(a_total, (unsigned)q.lda, t0);
-            io.b_base = PB::stage_base(q.b, (unsigned)q.ldb, t0);
-            io.b_limit = PB::stage_limit(b_total, (unsigned)q.ldb, t0);
+            io.b_base = q.b + (int64_t)t0 * q.ldb;
+            io.b_limit = (b_total - 3u - (unsigned)t0 * (unsigned)q.ldb) * 4u;
         };
         auto advance = [&]() { l_st = l_st + 1 < nst ? l_st + 1 : l_st; };
+        f3u bq[2][DG_KS];
+        float fa[2][RB];
+        // prologue: stages 0 and 1 requested together; X of stage 0 -> LDS buffer 0
         aim();
 #pragma unroll
         for (int p = 0; p < PA::PASSES; ++p) pa.template issue_pass<0>(p, io.a_base, io.a_limit);
 #pragma unroll
-        for (int p = 0; p < PB::PASSES; ++p) pb.template issue_pass<0>(p, io.b_base, io.b_limit);
+        for (int s = 0; s < DG_KS; ++s) bq[0][s] = ldg3(io.b_base, min(b_lane + (unsigned)s * b_step, io.b_limit));
         advance();
         aim();
         io.st_t0 = t_begin + l_st * DG_BK;
 #pragma unroll
         for (int p = 0; p < PA::PASSES; ++p) pa.template issue_pass<1>(p, io.a_base, io.a_limit);
 #pragma unroll
-        for (int p = 0; p < PB::PASSES; ++p) pb.template issue_pass<1>(p, io.b_base, io.b_limit);
+        for (int s = 0; s < DG_KS; ++s) bq[1][s] = ldg3(io.b_base, min(b_lane + (unsigned)s * b_step, io.b_limit));
 #pragma unroll
         for (int p = 0; p < PA::PASSES; ++p) pa.template store_pass<true, 0>(p, lds, t_begin, t_end);
-#pragma unroll
-        for (int p = 0; p < PB::PASSES; ++p) pb.template store_pass<false, 0>(p, lds + A_FLOATS, t_begin, t_end);
         advance();
         aim();
         io.st_tmax = t_end;
         __syncthreads();
-        Frags<RB, NCW, false> fr;
-        fetch_frags<RB, NCW, false, false, RA, CW, false>(fr, 0, lds, lds + A_FLOATS, 0, wave, 0);
-        int buf = 0;
-        auto colsum_stage = [&](const float *cur, int st) {
-            // the stage's slice of G lies in LDS in front of this wave: its column sums = the bias gradient (rows of the A
-            // operand beyond t_end are zero, G's are not: count only the rows of this split)
-            const float *gb = cur + A_FLOATS;
-            const int t0 = t_begin + st * DG_BK;
+        {
+            const float *pa_l = lds + g * ld_rc(RA) + x;
 #pragma unroll
-            for (int p = 0; p < PB::PASSES; ++p) {
-                const int e = threadIdx.x + p * DG_THREADS;
-                const int tl = e / (CW / 4);
-                const f32x4 gv = *reinterpret_cast<const f32x4 *>(gb + tl * ld_rc(CW) + (e % (CW / 4)) * 4);
-                if (t0 + tl < t_end) csum[p] += gv;
-            }
-        };
+            for (int i = 0; i < RB; ++i) fa[0][i] = pa_l[i * 16];
+        }
+        int buf = 0;
         auto tail = [&]() {
             io.st_t0 = t_begin + l_st * DG_BK;
             advance();
             aim();
             buf ^= 1;
         };
+        // rows of G beyond t_end belong to the next split (their X factors are zero-filled): the bias gradient counts only
+        // this split's rows
+        auto colsum_stage = [&](const f3u (&b)[DG_KS], int st) {
+            const int t0 = t_begin + st * DG_BK + g;
+#pragma unroll
+            for (int s = 0; s < DG_KS; ++s) {
+                const bool in = t0 + 4 * s < t_end;
+                cs0 += in ? b[s].x : 0.f, cs1 += in ? b[s].y : 0.f, cs2 += in ? b[s].z : 0.f;
+            }
+        };
         for (int st = 0; st < nst; st += 2) {
             {
                 const float *cur = lds + buf * BUF;
                 float *wr = lds + (buf ^ 1) * BUF;
-                if (want_cs) colsum_stage(cur, st);
-                gemm_stage<RB, NCW, false, false, RA, CW, false, A_FLOATS, 0>(cur, wr, acc, accx, fr, pa, pb, io, wave, 0, tail);
+                if (want_cs) colsum_stage(bq[0], st);
+                split_stage<RB, RA, A_FLOATS, 0>(cur, wr, acc, fa, bq, pa, io, b_lane, b_step, tail);
             }
             if (st + 1 < nst) {
                 const float *cur = lds + buf * BUF;
                 float *wr = lds + (buf ^ 1) * BUF;
-                if (want_cs) colsum_stage(cur, st + 1);
-                gemm_stage<RB, NCW, false, false, RA, CW, false, A_FLOATS, 1>(cur, wr, acc, accx, fr, pa, pb, io, wave, 0, tail);
+                if (want_cs) colsum_stage(bq[1], st + 1);
+                split_stage<RB, RA, A_FLOATS, 1>(cur, wr, acc, fa, bq, pa, io, b_lane, b_step, tail);
             }
         }
     }
-    // partial tile: lane holds P[16*rb + x][16*cb + 4g .. +3]
-    const int x = threadIdx.x & 15, g = (threadIdx.x >> 4) & 3;
+    // partial tile: the lane's twelve consecutive columns of row 16 i + x
     float *dst = q.part + (int64_t)slot * (RBP * 16) * CW;
+    const int j0 = wave * 48 + 12 * g;
 #pragma unroll
-    for (int i = 0; i < RB; ++i)
+    for (int i = 0; i < RB; ++i) {
+        float e[12];
 #pragma unroll
-        for (int jj = 0; jj < NCW; ++jj)
-            *reinterpret_cast<f32x4 *>(dst + (i * 16 + x) * CW + (wave * NCW + jj) * 16 + 4 * g) = acc[i][jj];
-    if (want_cs) {
-        // thread e = thread + 256*p owns columns 4*(e % Q).. of inner rows e / Q: fold the rows through LDS in a fixed order
-        constexpr int Q = CW / 4;
-        __syncthreads(); // every wave is done with the LDS buffers
-        float *red = lds; // [32][CW]
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int p = 0; p < PB::PASSES; ++p) {
-            const int e = threadIdx.x + p * DG_THREADS;
-            if (PB::EXACT || e / Q < 32) *reinterpret_cast<f32x4 *>(red + (e / Q) * CW + (e % Q) * 4) = csum[p];
+            for (int u = 0; u < 3; ++u) e[3 * r + u] = acc[i][u][r];
+        f32x4 *d = reinterpret_cast<f32x4 *>(dst + (i * 16 + x) * CW + j0);
+        d[0] = (f32x4){e[0], e[1], e[2], e[3]};
+        d[1] = (f32x4){e[4], e[5], e[6], e[7]};
+        d[2] = (f32x4){e[8], e[9], e[10], e[11]};
+    }
+    if (want_cs) { // fold the four row classes (lanes x, x+16, x+32, x+48) in a fixed order; lanes g == 0 own the result
+        float t0 = cs0, t1 = cs1, t2 = cs2;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            t0 += __shfl(cs0, x + 16 * k), t1 += __shfl(cs1, x + 16 * k), t2 += __shfl(cs2, x + 16 * k);
         }
-        __syncthreads();
-        for (int j = threadIdx.x; j < q.J; j += DG_THREADS) {
-            float t = 0.f;
-            for (int r = 0; r < 32; ++r) t += red[r * CW + j];
-            q.colsum[(int64_t)split * q.J + j] = t;
+        const int j = wave * 48 + 3 * x;
+        if (g == 0 && j + 2 < q.J) {
+            float *o = q.colsum + (int64_t)split * q.J + j;
+            o[0] = t0, o[1] = t1, o[2] = t2;
         }
     }
 }
 
+// A_VEC: the leftover row-blocks may use 16-byte loads too (I % 4 == 0).  FULL tiles always do: their column groups never
+// reach the end of a row, so 4-byte alignment is all they need (the 963-float rows of the first layer's features).
 template <int RB, int NCW, bool A_VEC>
 __device__ __forceinline__ void split_dispatch(const SplitArgs &q, float *lds, const int w)
 {
+    static_assert(NCW == 3, "the split body owns 48 columns per wave");
     const int nfull = q.full_tiles * q.s_full;
     if (w < nfull) {
         const int tile = w % q.full_tiles, split = w / q.full_tiles;
-        split_body<RB, RB, NCW, A_VEC>(q, lds, tile * RB * 16, split, q.s_full, tile * q.s_full + split,
-                                       q.colsum != nullptr && tile == 0);
+        split_body<RB, RB, true>(q, lds, tile * RB * 16, split, q.s_full, tile * q.s_full + split,
+                                 q.colsum != nullptr && tile == 0);
     } else {
         const int e = (w - nfull) / q.s_left, split = (w - nfull) % q.s_left;
-        split_body<1, RB, NCW, A_VEC>(q, lds, (q.full_tiles * RB + e) * 16, split, q.s_left, w, false);
+        split_body<1, RB, A_VEC>(q, lds, (q.full_tiles * RB + e) * 16, split, q.s_left, w, false);
     }
 }
 
 template <int RB, int NCW, bool A_VEC>
 __global__ __launch_bounds__(DG_THREADS) void dense_split_kernel(SplitArgs q)
 {
-    __shared__ __attribute__((aligned(16))) float lds[2 * (32 * ld_rc(RB * 16) + 32 * ld_rc(NCW * 64))];
+    __shared__ __attribute__((aligned(16))) float lds[2 * 32 * ld_rc(RB * 16)];
     split_dispatch<RB, NCW, A_VEC>(q, lds, blockIdx.x);
 }
 
@@ -715,7 +783,7 @@ template <int RB, bool X_VEC>
 __global__ __launch_bounds__(DG_THREADS, 2) void dense_bwd_pair_kernel(RowArgs r, SplitArgs q, int n_row)
 {
     constexpr int LDS_ROWS = 2 * ((RB + 1) * 16 * LD_TC + 192 * LD_TC);
-    constexpr int LDS_SPLIT = 2 * (32 * ld_rc(SPLIT_RB * 16) + 32 * ld_rc(192));
+    constexpr int LDS_SPLIT = 2 * 32 * ld_rc(SPLIT_RB * 16);
     __shared__ __attribute__((aligned(16))) float lds[LDS_ROWS > LDS_SPLIT ? LDS_ROWS : LDS_SPLIT];
     const int w = blockIdx.x;
     if (w < n_row) {
@@ -916,7 +984,8 @@ extern "C" int geom_dense_bwd_weight_f32(int rows, int cin, int c, const float *
                                          int want_colsum, void *stream)
 {
     if (rows <= 0 || cin <= 0 || c <= 0) return GEOM_EINVAL;
-    if (c % 4 != 0 || c > 192 || (int64_t)rows * (cin > c ? cin : c) >= (1LL << 30)) return GEOM_EUNSUPPORTED;
+    // c % 12: a lane owns whole 3-column groups of G (12-byte loads) and whole 4-column groups of the partial tile
+    if (c % 12 != 0 || c > 192 || (int64_t)rows * (cin > c ? cin : c) >= (1LL << 30)) return GEOM_EUNSUPPORTED;
     if (!x || !g || !workspace || !aligned16(g) || !aligned16(workspace)) return GEOM_EINVAL;
     const SplitGeo geo = split_geometry(cin, rows, num_cus());
     if (want_colsum && geo.full_tiles == 0) return GEOM_EUNSUPPORTED;
@@ -936,13 +1005,13 @@ extern "C" int geom_dense_bwd_f32(int rows, int cin, int c, const float *x, cons
                                   float *workspace, int want_colsum, void *stream)
 {
     if (rows <= 0 || cin <= 0 || c <= 0) return GEOM_EINVAL;
-    if (c % 4 != 0 || c > 192 || (int64_t)rows * (cin > c ? cin : c) >= (1LL << 30)) return GEOM_EUNSUPPORTED;
+    if (c % 12 != 0 || c > 192 || (int64_t)rows * (cin > c ? cin : c) >= (1LL << 30)) return GEOM_EUNSUPPORTED;
     if (!x || !g || !w || !grad_x || !workspace || !aligned16(g) || !aligned16(w) || !aligned16(workspace)) return GEOM_EINVAL;
     const int cus = num_cus();
     const bool xvec = cin % 4 == 0 && aligned16(x);
     const RowGeo rg = row_geometry(rows, 3, cus);
     const SplitGeo sg = split_geometry(cin, rows, cus);
-    if (cin > 192 || !xvec || (want_colsum && sg.full_tiles == 0) || rg.rb < 2) {
+    if (cin > 192 || !xvec || (want_colsum && sg.full_tiles == 0) || rg.rb < 2 || rg.rb > 5) { // rb 6: 82 KB of LDS, no pairing
         int code = geom_dense_bwd_input_f32(rows, cin, c, g, w, grad_x, stream);
         if (code) return code;
         return geom_dense_bwd_weight_f32(rows, cin, c, x, g, workspace, want_colsum, stream);
@@ -957,7 +1026,6 @@ extern "C" int geom_dense_bwd_f32(int rows, int cin, int c, const float *x, cons
     case 3: hipLaunchKernelGGL((dense_bwd_pair_kernel<3, true>), grid, block, 0, s, r, q, rg.grid); break;
     case 4: hipLaunchKernelGGL((dense_bwd_pair_kernel<4, true>), grid, block, 0, s, r, q, rg.grid); break;
     case 5: hipLaunchKernelGGL((dense_bwd_pair_kernel<5, true>), grid, block, 0, s, r, q, rg.grid); break;
-    case 6: hipLaunchKernelGGL((dense_bwd_pair_kernel<6, true>), grid, block, 0, s, r, q, rg.grid); break;
     default: return GEOM_EINVAL;
     }
     return geom::launch_status();

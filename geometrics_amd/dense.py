@@ -28,6 +28,8 @@ def plan(rows, cin, c):
       CU pays ~8 us of prologue + epilogue per launch)."""
     ok = supported(cin, c, rows)
     pair = ok and cin <= 192 and cin % 4 == 0 and rows >= 512
+    ok = ok and c % 48 == 0        # the weight-gradient kernel: every wave owns whole 12-column groups of the output
+    pair = pair and ok
     return {"fwd": "lib", "dx": "mfma" if pair else "lib", "dw": "mfma" if ok and rows >= 512 else "lib", "pair": pair}
 
 

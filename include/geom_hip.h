@@ -281,7 +281,7 @@ int geom_zn_gcn_aggregate_ell_bwd_f32(int b, int nv, int c, int k, int w, const 
  *     j >= ksplit (bias may be NULL), and mask (may be NULL) [rows, c/16] uint16 receives their sign bits (bit j % 16 of word
  *     (r, j / 16) = out[r, j] > 0; the words of the aggregated columns are left for the aggregation kernel).
  * geom_dense_bwd_input_f32: grad_x [rows, cin] = g [rows, c] . w^T.
- * geom_dense_bwd_weight_f32: per-split partial tiles of grad_w = x^T . g (and, want_colsum != 0, of the column sums of g =
+ * geom_dense_bwd_weight_f32 (c % 12 == 0, else GEOM_EUNSUPPORTED): per-split partial tiles of grad_w = x^T . g (and, want_colsum != 0, of the column sums of g =
  *   the bias gradient) into `workspace` (geom_dense_bwd_weight_workspace_floats floats, 16-byte aligned);
  * geom_dense_reduce_f32 adds them up in a fixed order -- ONE launch for the pending weight / bias gradients of up to
  *   GEOM_DENSE_MAX_LAYERS layers (host arrays of per-layer sizes and pointers; grad_bias or its entries may be NULL). */

@@ -56,7 +56,7 @@ def test_input_gradient_matches_float64(rows, cin, c):
     _close(out, g.double() @ w.double().t())
 
 
-@pytest.mark.parametrize("rows,cin,c", SHAPES)
+@pytest.mark.parametrize("rows,cin,c", [s if s[2] % 12 == 0 else (s[0], s[1], 48) for s in SHAPES] + [(4000, 100, 96)])
 def test_weight_and_bias_gradient_match_float64(rows, cin, c):
     from geometrics_amd import dense
     x, w, g = _operands(rows, cin, c, 2)
@@ -115,6 +115,10 @@ def test_unsupported_shapes_are_refused():
     x = torch.zeros(4, 4, device="cuda")
     code = _lib.lib().geom_dense_fwd_f32(4, 4, 200, x.data_ptr(), x.data_ptr(), 0, None, x.data_ptr(), None, None, None)
     assert code == _lib.EUNSUPPORTED
+    code = _lib.lib().geom_dense_bwd_weight_f32(4, 4, 16, x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, None)
+    assert code == _lib.EUNSUPPORTED          # 16 output columns: not whole 12-column groups
+    from geometrics_amd import dense
+    assert dense.plan(20496, 192, 64)["dw"] == "lib" and dense.plan(20496, 192, 192)["pair"]
 
 
 def test_head_mode_equals_aggregation_plus_vertex_head():
