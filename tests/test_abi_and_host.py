@@ -202,3 +202,20 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.geom_adam_step_f32(1, None, None, None, None, None, 1e-3, .9, .999, 1e-8, 1.0, None, 1, None) == -1
     assert L.geom_adam_step_f32(0, None, None, None, None, None, 1e-3, .9, .999, 1e-8, 1.0, None, 1, None) == 0
     assert L.geom_chamfer_nn_f32(1, 4, p, 4, p, p, p, p, p, _lib.FLAG_NN_FMA | _lib.FLAG_REF_TAIL_TRUNC, None) == -1
+
+
+def test_dense_plan_routes_each_product_by_shape():
+    """geometrics_amd.dense.plan (host logic, no GPU): which of a layer's three products go to the matrix-core kernels.
+    Forward stays with the library; 192-wide layers get both gradients in the pair launch; the 963-wide layer gets the
+    split weight-gradient kernel only; narrow / odd / tiny shapes stay with the library altogether."""
+    from geometrics_amd import dense
+    hidden = dense.plan(20496, 192, 192)
+    assert hidden == {"fwd": "lib", "dx": "mfma", "dw": "mfma", "pair": True}
+    first = dense.plan(20496, 963, 192)
+    assert first["dw"] == "mfma" and first["dx"] == "lib" and not first["pair"] and first["fwd"] == "lib"
+    assert dense.plan(7712, 192, 192)["pair"]                       # the reference's training batch (16 x 482 vertices)
+    assert dense.plan(324, 192, 192)["dw"] == "lib"                 # two 162-vertex meshes: launch-bound either way
+    assert dense.plan(20496, 192, 3)["dw"] == "lib"                 # the 3-channel output layer of a deformation block
+    assert dense.plan(20496, 192, 64)["dw"] == "lib"                # not whole 12-column groups per wave
+    assert dense.plan(2 ** 21, 963, 192)["dw"] == "lib"             # beyond the kernels' 32-bit byte offsets
+    assert dense.supported(963, 192, 20496) and not dense.supported(963, 200, 20496)
