@@ -89,12 +89,14 @@ class Workload:
         return self.stack[-1].forward_positions(h, self.info["adj"], F.relu, self.base, 0.01)
 
     # one step = forward_backward() -> [exchange()] -> update(); captured as HIP graphs by capture()
-    def forward_backward(self):
+    def forward_backward(self, step_in_backward=False):
         self.opt.zero_grad()
         self.feat.grad = None
         # nothing reads a parameter gradient before backward() returns (no hooks, no DDP: the bucket is packed afterwards),
-        # so the bias / weight gradients of the pass are finished by batched launches at its end
-        with layers.deferred_parameter_gradients():
+        # so the bias / weight gradients of the pass are finished by ONE launch at its end -- which, in a single-process
+        # step, applies Adam to them as well (step_in_backward: no optimiser launch of its own)
+        import contextlib
+        with layers.deferred_parameter_gradients(), (self.opt.in_backward() if step_in_backward else contextlib.nullcontext()):
             pos = self.positions()
             self.loss = utils.batch_point_to_surface(pos, self.info, self.gt, num=S_PTS)
             self.loss.backward(self.seed_grad)              # explicit seed: no ones_like fill launch
@@ -112,7 +114,7 @@ class Workload:
             self.opt.step()
 
     def step(self):
-        self.forward_backward()
+        self.forward_backward(step_in_backward=not self.dp)
         self.exchange()
         self.update()
 

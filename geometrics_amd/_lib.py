@@ -22,7 +22,7 @@ ADAM_MAX_TENSORS = 64
 COLSUM_MAX_JOBS = 32
 DENSE_MAX_LAYERS = 8
 DENSE_MAX_REDUCE_JOBS = 32
-ADAM_STATE_WORDS = 72
+ADAM_STATE_WORDS = 2112
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -75,6 +75,8 @@ _SIGNATURES = {
     "geom_dense_bwd_weight_f32": [_i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "geom_dense_bwd_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "geom_dense_reduce2_f32": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "geom_dense_reduce_adam_f32": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f,
+                                   _vp, _vp],
     "geom_dense_reduce_f32": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "geom_zn_gcn_aggregate_fwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "geom_zn_gcn_aggregate_ell_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],

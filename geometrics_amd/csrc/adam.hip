@@ -16,11 +16,11 @@
 //   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
 //   p -= lr / (1-b1^t) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
 #include "geom_common.h"
+#include "adam_math.h"
 
 namespace {
 
-constexpr int ADAM_LEAVES = 64;
-static_assert(GEOM_ADAM_STATE_WORDS >= 4 + ADAM_LEAVES, "state layout: {t, b1^t, b2^t, root, leaf[64]}");
+using geom::adam_update;
 
 struct AdamTensors {
     float *p[GEOM_ADAM_MAX_TENSORS];
@@ -31,17 +31,6 @@ struct AdamTensors {
     int first_block[GEOM_ADAM_MAX_TENSORS + 1]; // workgroups [first_block[i], first_block[i+1]) own tensor i
     int count;
 };
-
-__device__ __forceinline__ void adam_update(float &p, float g, float &m, float &v, float b1, float b2, float eps,
-                                            float grad_scale, float step_size, float bc2_sqrt)
-{
-    const float gi = g * grad_scale;
-    const float mi = b1 * m + (1.f - b1) * gi;
-    const float vi = b2 * v + (1.f - b2) * gi * gi;
-    m = mi;
-    v = vi;
-    p -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
-}
 
 // state: [0] t (float), [1] b1^t, [2] b2^t, [3] root arrivals, [4..67] leaf arrivals (uint words)
 __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float lr, float b1, float b2, float eps,
@@ -58,23 +47,9 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float lr, floa
     const int which = lo;
     const int local = blockIdx.x - t.first_block[which];
 
-    // The step state is read ONCE per workgroup, by the thread that later signs the workgroup's arrival, with agent-scope
-    // atomic loads, and handed to the other threads through LDS: that thread's loads have RETURNED (their values were
-    // stored to LDS in front of the barrier) before it can reach its arrival atomic -- the order "read the state, then
-    // arrive" is a data dependency, not an assumption about issue order or about where a compiler places plain loads.
     __shared__ float st[3];
-    if (threadIdx.x == 0) {
-        st[0] = __hip_atomic_load(state + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        st[1] = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        st[2] = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    const float t_old = st[0];
-    const float b1t = t_old == 0.f ? b1 : st[1] * b1;
-    const float b2t = t_old == 0.f ? b2 : st[2] * b2;
-    const float bc1 = 1.f - b1t;
-    const float bc2_sqrt = sqrtf(1.f - b2t);
-    const float step_size = lr / bc1;
+    const geom::AdamStep as = geom::adam_read_state(state, st, lr, b1, b2);   // see adam_math.h for the ordering argument
+    const float step_size = as.step_size, bc2_sqrt = as.bc2_sqrt;
 
     float *p = t.p[which], *m = t.m[which], *v = t.v[which];
     const float *g = t.g[which];
@@ -104,28 +79,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float lr, floa
     }
 
     if (!advance) return;
-    // arrival tree.  Only the ORDER "this workgroup's read of the state, then its arrival" matters; it holds by construction
-    // (see the load above: same thread, values consumed before the barrier).  Relaxed atomics on purpose:
-    // a release here would write back the L2 lines this workgroup just dirtied with p / m / v (measured: 13.9 us for the
-    // launch with acq_rel arrivals against ~4 us), and nothing reads those before the kernel boundary anyway.
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        asm volatile("" ::: "memory");
-        unsigned *cnt = reinterpret_cast<unsigned *>(state) + 3;
-        const unsigned nblk = gridDim.x;
-        const unsigned leaf = blockIdx.x % ADAM_LEAVES;
-        const unsigned leaf_total = (nblk - leaf + ADAM_LEAVES - 1) / ADAM_LEAVES; // workgroups mapped to this leaf
-        const unsigned leaves = nblk < ADAM_LEAVES ? nblk : ADAM_LEAVES;
-        if (__hip_atomic_fetch_add(cnt + 1 + leaf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == leaf_total - 1) {
-            __hip_atomic_store(cnt + 1 + leaf, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == leaves - 1) {
-                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(state + 0, t_old + 1.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(state + 1, b1t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(state + 2, b2t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
+    geom::adam_arrive(state, as, blockIdx.x, gridDim.x);
 }
 
 } // namespace

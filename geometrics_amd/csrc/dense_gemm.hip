@@ -27,6 +27,7 @@
 //   * a weight gradient (inner dimension = all rows) is split over the rows so that all CUs work; partial tiles go to a
 //     workspace and are added up in slot order by a reduction kernel -- a fixed order, so results are bit-reproducible.
 #include "geom_common.h"
+#include "adam_math.h"
 #include <type_traits>
 
 namespace {
@@ -803,20 +804,35 @@ struct ReduceJob {
 struct ReduceJobs {
     ReduceJob job[GEOM_DENSE_MAX_REDUCE_JOBS];
 };
+// Optional: the optimiser step on the gradients this launch finishes (geometrics_amd.optim.FusedAdam.fuse_into_backward):
+// job i's output IS the gradient of parameter p[i] (same [I, J] layout), so the thread that writes a gradient element also
+// updates the parameter and its two moments -- the stand-alone Adam launch (7.6 us) and its re-read of the gradients go
+// away.  Same arithmetic and the same device-side step protocol as adam.hip (adam_math.h): same bits.
+struct ReduceAdam {
+    float *p[GEOM_DENSE_MAX_REDUCE_JOBS], *m[GEOM_DENSE_MAX_REDUCE_JOBS], *v[GEOM_DENSE_MAX_REDUCE_JOBS]; // null: no update
+    float lr, b1, b2, eps;
+    float *state; // null: no optimiser step in this launch
+    // workgroups that hold outputs ("active"): only they read the step state and sign the arrival tree.  active_first[j] =
+    // active workgroups of the jobs before j (their dense index), n_active = all of them
+    int active_first[GEOM_DENSE_MAX_REDUCE_JOBS + 1];
+};
 
 // 32 outputs (of 4 columns) x 8 slot groups per workgroup: group sg adds its contiguous share of the slots in slot order
 // (four loads in flight), the group sums are then added in group order -- a fixed tree for a given (I, J, splits).  Jobs
 // with a single output row and many slots (column sums: the bias gradients, 1 288 partial rows at the BASELINE shard) take
 // 4 outputs x 64 groups instead, so that the slot dimension is what the threads share.
 constexpr int RED_THREADS = 256, RED_OUT = 32;
-__global__ __launch_bounds__(RED_THREADS) void dense_reduce_kernel(ReduceJobs jobs)
+__global__ __launch_bounds__(RED_THREADS) void dense_reduce_kernel(ReduceJobs jobs, ReduceAdam adam)
 {
     __shared__ f32x4 part[RED_THREADS];
+    __shared__ float st[3];
     const ReduceJob q = jobs.job[blockIdx.y];
     const int jq = q.J >> 2;
     const int outs = q.I == 1 ? 4 : RED_OUT, groups = RED_THREADS / outs;
+    if ((int)blockIdx.x * outs >= q.I * jq) return; // a job smaller than the largest one leaves whole workgroups idle
+    geom::AdamStep as{};
+    if (adam.state) as = geom::adam_read_state(adam.state, st, adam.lr, adam.b1, adam.b2); // uniform per workgroup
     const int o = threadIdx.x % outs, sg = threadIdx.x / outs;
-    if ((int)blockIdx.x * outs >= q.I * jq) return; // a job smaller than the largest one (uniform per workgroup)
     const int e = blockIdx.x * outs + o;
     const bool live = e < q.I * jq;
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
@@ -849,8 +865,24 @@ __global__ __launch_bounds__(RED_THREADS) void dense_reduce_kernel(ReduceJobs jo
     if (sg == 0 && live) {
         f32x4 r = part[o];
         for (int k = 1; k < groups; ++k) r = r + part[k * outs + o];
-        float *dst = q.out + (int64_t)i * q.J + j;
+        const int64_t at = (int64_t)i * q.J + j;
+        float *dst = q.out + at;
         dst[0] = r[0], dst[1] = r[1], dst[2] = r[2], dst[3] = r[3];
+        float *pp = adam.state ? adam.p[blockIdx.y] : nullptr;
+        if (pp) {
+            float *pm = adam.m[blockIdx.y] + at, *pv = adam.v[blockIdx.y] + at;
+            pp += at;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a = pp[k], b = pm[k], c = pv[k];
+                geom::adam_update(a, r[k], b, c, adam.b1, adam.b2, adam.eps, 1.f, as.step_size, as.bc2_sqrt);
+                pm[k] = b, pv[k] = c, pp[k] = a;
+            }
+        }
+    }
+    if (adam.state) {
+        const int nj = gridDim.y;
+        geom::adam_arrive(adam.state, as, adam.active_first[blockIdx.y] + blockIdx.x, adam.active_first[nj]);
     }
 }
 
@@ -1031,41 +1063,88 @@ extern "C" int geom_dense_bwd_f32(int rows, int cin, int c, const float *x, cons
     return geom::launch_status();
 }
 
-// grad_w[i] (and grad_bias[i], may be NULL) of `count` layers out of their workspaces, ONE launch -- which also finishes
-// `ncs` pending column-sum jobs (cs_outs[i][0..cs_cols[i]) = column sums of cs_partials[i], cs_rows[i] x cs_cols[i] row-major:
-// the per-workgroup bias-gradient partials of the aggregation backward, what geom_colsum_batch_f32 does in a launch of
-// its own).  Host arrays; count + ncs jobs in total <= GEOM_DENSE_MAX_REDUCE_JOBS.
+namespace {
+// the jobs of geom_dense_reduce2_f32 / geom_dense_reduce_adam_f32: weight gradients first (job l = layer l), then the
+// column-sum jobs (job count + i)
+int build_reduce_jobs(ReduceJobs &jobs, int &n, int &widest, int count, const int *rows, const int *cin, const int *c,
+                      const float *const *workspaces, float *const *grad_w, int ncs, const float *const *cs_partials,
+                      const int *cs_rows, const int *cs_cols, float *const *cs_outs)
+{
+    if (count < 0 || ncs < 0) return GEOM_EINVAL;
+    if (count && (!rows || !cin || !c || !workspaces || !grad_w)) return GEOM_EINVAL;
+    if (ncs && (!cs_partials || !cs_rows || !cs_cols || !cs_outs)) return GEOM_EINVAL;
+    if (count + ncs > GEOM_DENSE_MAX_REDUCE_JOBS) return GEOM_ETOOBIG;
+    n = 0, widest = 0;
+    for (int l = 0; l < count; ++l) {
+        if (!workspaces[l] || !grad_w[l] || rows[l] <= 0 || cin[l] <= 0 || c[l] <= 0 || c[l] > 192 || c[l] % 4) return GEOM_EINVAL;
+        const SplitGeo g = split_geometry(cin[l], rows[l], num_cus());
+        jobs.job[n++] = ReduceJob{workspaces[l], grad_w[l], cin[l], c[l], SPLIT_RB * 16, 192, g.full_tiles, g.s_full, g.s_left};
+        widest = cin[l] * (c[l] / 4) > widest ? cin[l] * (c[l] / 4) : widest;
+    }
+    for (int i = 0; i < ncs; ++i) {
+        if (!cs_partials[i] || !cs_outs[i] || cs_rows[i] < 0 || cs_cols[i] <= 0 || cs_cols[i] % 4) return GEOM_EINVAL;
+        jobs.job[n++] = ReduceJob{cs_partials[i], cs_outs[i], 1, cs_cols[i], 1, cs_cols[i], 1, cs_rows[i], 0};
+        widest = cs_cols[i] / 4 * (RED_OUT / 4) > widest ? cs_cols[i] / 4 * (RED_OUT / 4) : widest; // 4 outputs per workgroup
+    }
+    return 0;
+}
+} // namespace
+
+// Weight gradients of `count` layers out of their workspaces AND `ncs` pending column-sum jobs (cs_outs[i][0..cs_cols[i]) =
+// column sums of cs_partials[i], cs_rows[i] x cs_cols[i] row-major: the per-workgroup bias-gradient partials of the
+// aggregation backward, what geom_colsum_batch_f32 does in a launch of its own) in ONE launch.  Host arrays; count + ncs
+// jobs in total <= GEOM_DENSE_MAX_REDUCE_JOBS.
 extern "C" int geom_dense_reduce2_f32(int count, const int *rows, const int *cin, const int *c, const float *const *workspaces,
                                       float *const *grad_w, float *const *grad_bias, int ncs, const float *const *cs_partials,
                                       const int *cs_rows, const int *cs_cols, float *const *cs_outs, void *stream)
 {
-    if (count < 0 || ncs < 0) return GEOM_EINVAL;
+    if (grad_bias) return GEOM_EINVAL; // bias gradients travel as column-sum jobs here
     if (count + ncs == 0) return 0;
-    if (count && (!rows || !cin || !c || !workspaces || !grad_w)) return GEOM_EINVAL;
-    if (ncs && (!cs_partials || !cs_rows || !cs_cols || !cs_outs)) return GEOM_EINVAL;
     ReduceJobs jobs;
-    int n = 0, widest = 0;
+    int n, widest;
+    const int code = build_reduce_jobs(jobs, n, widest, count, rows, cin, c, workspaces, grad_w, ncs, cs_partials, cs_rows, cs_cols, cs_outs);
+    if (code) return code;
+    ReduceAdam adam{};
+    hipLaunchKernelGGL(dense_reduce_kernel, dim3((widest + RED_OUT - 1) / RED_OUT, n), dim3(RED_THREADS), 0,
+                       static_cast<hipStream_t>(stream), jobs, adam);
+    return geom::launch_status();
+}
+
+// The same launch + the Adam step of the parameters whose gradients it finishes: w_p/w_m/w_v[l] = parameter, first and
+// second moment of layer l's weight (same [cin, c] layout as grad_w[l]), b_p/b_m/b_v[i] likewise for column-sum job i
+// (entries may be NULL: gradient only).  `state` = the optimiser's device-side step state (geom_adam_step_f32); it is
+// advanced once by this launch.  grad_scale is 1 (single-process step; a data-parallel step reduces the gradients across
+// ranks first and uses geom_adam_step_f32).
+extern "C" int geom_dense_reduce_adam_f32(int count, const int *rows, const int *cin, const int *c,
+                                          const float *const *workspaces, float *const *grad_w, float *const *w_p,
+                                          float *const *w_m, float *const *w_v, int ncs, const float *const *cs_partials,
+                                          const int *cs_rows, const int *cs_cols, float *const *cs_outs, float *const *b_p,
+                                          float *const *b_m, float *const *b_v, float lr, float beta1, float beta2, float eps,
+                                          float *state, void *stream)
+{
+    if (count + ncs == 0 || !state) return GEOM_EINVAL;
+    if ((count && (!w_p || !w_m || !w_v)) || (ncs && (!b_p || !b_m || !b_v))) return GEOM_EINVAL;
+    ReduceJobs jobs;
+    int n, widest;
+    const int code = build_reduce_jobs(jobs, n, widest, count, rows, cin, c, workspaces, grad_w, ncs, cs_partials, cs_rows, cs_cols, cs_outs);
+    if (code) return code;
+    ReduceAdam adam{};
     for (int l = 0; l < count; ++l) {
-        if (!workspaces[l] || !grad_w[l] || rows[l] <= 0 || cin[l] <= 0 || c[l] <= 0 || c[l] > 192 || c[l] % 4) return GEOM_EINVAL;
-        if (n + 2 > GEOM_DENSE_MAX_REDUCE_JOBS) return GEOM_ETOOBIG;
-        const SplitGeo g = split_geometry(cin[l], rows[l], num_cus());
-        jobs.job[n++] = ReduceJob{workspaces[l], grad_w[l], cin[l], c[l], SPLIT_RB * 16, 192, g.full_tiles, g.s_full, g.s_left};
-        widest = cin[l] * (c[l] / 4) > widest ? cin[l] * (c[l] / 4) : widest;
-        if (grad_bias && grad_bias[l]) { // column sums: a 1-row "tile" per split, pitch = c
-            if (g.full_tiles == 0) return GEOM_EUNSUPPORTED;
-            jobs.job[n++] = ReduceJob{workspaces[l] + (int64_t)g.slots * SPLIT_RB * 16 * 192, grad_bias[l], 1, c[l], 1, c[l], 1,
-                                      g.s_full, 0};
-            widest = c[l] / 4 * (RED_OUT / 4) > widest ? c[l] / 4 * (RED_OUT / 4) : widest;
-        }
+        adam.p[l] = w_p[l], adam.m[l] = w_m[l], adam.v[l] = w_v[l];
+        if (w_p[l] && (!w_m[l] || !w_v[l])) return GEOM_EINVAL;
     }
     for (int i = 0; i < ncs; ++i) {
-        if (!cs_partials[i] || !cs_outs[i] || cs_rows[i] < 0 || cs_cols[i] <= 0 || cs_cols[i] % 4) return GEOM_EINVAL;
-        if (n + 1 > GEOM_DENSE_MAX_REDUCE_JOBS) return GEOM_ETOOBIG;
-        jobs.job[n++] = ReduceJob{cs_partials[i], cs_outs[i], 1, cs_cols[i], 1, cs_cols[i], 1, cs_rows[i], 0};
-        widest = cs_cols[i] / 4 * (RED_OUT / 4) > widest ? cs_cols[i] / 4 * (RED_OUT / 4) : widest; // 4 outputs per workgroup
+        adam.p[count + i] = b_p[i], adam.m[count + i] = b_m[i], adam.v[count + i] = b_v[i];
+        if (b_p[i] && (!b_m[i] || !b_v[i])) return GEOM_EINVAL;
+    }
+    adam.lr = lr, adam.b1 = beta1, adam.b2 = beta2, adam.eps = eps, adam.state = state;
+    adam.active_first[0] = 0;
+    for (int j = 0; j < n; ++j) {
+        const int outs = jobs.job[j].I == 1 ? 4 : RED_OUT;
+        adam.active_first[j + 1] = adam.active_first[j] + (jobs.job[j].I * (jobs.job[j].J >> 2) + outs - 1) / outs;
     }
     hipLaunchKernelGGL(dense_reduce_kernel, dim3((widest + RED_OUT - 1) / RED_OUT, n), dim3(RED_THREADS), 0,
-                       static_cast<hipStream_t>(stream), jobs);
+                       static_cast<hipStream_t>(stream), jobs, adam);
     return geom::launch_status();
 }
 
@@ -1090,6 +1169,6 @@ extern "C" int geom_dense_reduce_f32(int count, const int *rows, const int *cin,
         }
     }
     hipLaunchKernelGGL(dense_reduce_kernel, dim3((widest + RED_OUT - 1) / RED_OUT, n), dim3(RED_THREADS), 0,
-                       static_cast<hipStream_t>(stream), jobs);
+                       static_cast<hipStream_t>(stream), jobs, ReduceAdam{});
     return geom::launch_status();
 }

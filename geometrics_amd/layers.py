@@ -258,6 +258,7 @@ def _check_landed(param_ref, out):
 
 
 _flush_registered = set()     # graph tasks whose end-of-pass callback is queued
+_backward_optimizer = None     # optim.FusedAdam.fuse_into_backward(): its step rides in the end-of-pass launch when that launch covers it
 
 
 def _register_flush(task):
@@ -290,11 +291,31 @@ def _flush_pass(task):
     n, m = len(red), len(cs)
     ints = lambda seq: (ctypes.c_int * len(seq))(*seq)
     ptrs = lambda seq: (ctypes.c_void_p * len(seq))(*[t.data_ptr() for t in seq])
+    opt = _backward_optimizer
+    slots = None
+    if opt is not None:     # the optimiser's step rides along when this launch finishes the gradient of every one of its parameters
+        owners = [j[6]() if j[6] is not None else None for j in red] + [j[5]() if j[5] is not None else None for j in cs]
+        index = {id(p): k for k, p in enumerate(opt.params)}
+        slots = [index.get(id(p)) if p is not None else None for p in owners]
+        if None in slots or sorted(slots) != list(range(len(opt.params))) or opt.params[0].device != stream.device:
+            slots = None
     with torch.cuda.device(stream.device):
-        _lib.check(_lib.lib().geom_dense_reduce2_f32(
-            n, ints([j[0] for j in red]), ints([j[1] for j in red]), ints([j[2] for j in red]), ptrs([j[3] for j in red]),
-            ptrs([j[4] for j in red]), None, m, ptrs([j[0] for j in cs]), ints([j[1] for j in cs]), ints([j[2] for j in cs]),
-            ptrs([j[3] for j in cs]), stream.cuda_stream), "geom_dense_reduce2_f32")
+        if slots is None:
+            _lib.check(_lib.lib().geom_dense_reduce2_f32(
+                n, ints([j[0] for j in red]), ints([j[1] for j in red]), ints([j[2] for j in red]), ptrs([j[3] for j in red]),
+                ptrs([j[4] for j in red]), None, m, ptrs([j[0] for j in cs]), ints([j[1] for j in cs]), ints([j[2] for j in cs]),
+                ptrs([j[3] for j in cs]), stream.cuda_stream), "geom_dense_reduce2_f32")
+        else:
+            pick = lambda seq, ks: ptrs([seq[k] for k in ks])
+            wk, bk = slots[:n], slots[n:]
+            params = [p.data for p in opt.params]
+            _lib.check(_lib.lib().geom_dense_reduce_adam_f32(
+                n, ints([j[0] for j in red]), ints([j[1] for j in red]), ints([j[2] for j in red]), ptrs([j[3] for j in red]),
+                ptrs([j[4] for j in red]), pick(params, wk), pick(opt.exp_avg, wk), pick(opt.exp_avg_sq, wk),
+                m, ptrs([j[0] for j in cs]), ints([j[1] for j in cs]), ints([j[2] for j in cs]), ptrs([j[3] for j in cs]),
+                pick(params, bk), pick(opt.exp_avg, bk), pick(opt.exp_avg_sq, bk), float(opt.lr), float(opt.betas[0]),
+                float(opt.betas[1]), float(opt.eps), opt.state.data_ptr(), stream.cuda_stream), "geom_dense_reduce_adam_f32")
+            opt._stepped_in_backward = True
     for job in red:
         _check_landed(job[6], job[4])
     for job in cs:

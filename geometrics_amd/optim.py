@@ -10,6 +10,23 @@ import torch
 from . import _lib
 
 
+class _InBackward:
+    def __init__(self, opt):
+        self.opt = opt
+
+    def __enter__(self):
+        from . import layers
+        self.prev = layers._backward_optimizer
+        layers._backward_optimizer = self.opt
+        self.opt._stepped_in_backward = False
+        return self.opt
+
+    def __exit__(self, *exc):
+        from . import layers
+        layers._backward_optimizer = self.prev
+        return False
+
+
 class FusedAdam:
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
         self.params = [p for p in params if p.requires_grad]
@@ -32,6 +49,17 @@ class FusedAdam:
         """Steps taken so far (one host read)."""
         return int(self.state[0].item())
 
+    def in_backward(self):
+        """Context manager around forward + backward of ONE iteration: the step is applied INSIDE the backward pass, in the
+        launch that finishes the gradients (layers' end-of-pass reduction, geom_dense_reduce_adam_f32) -- no optimiser
+        launch of its own, no second read of the gradients.  It happens only if (a) parameter-gradient deferral is on
+        (`layers.deferred_parameter_gradients()`) and (b) that one launch finishes the gradient of EVERY parameter of this
+        optimiser, each exactly once; the following `step()` (no arguments, grad_scale 1) is then a no-op.  Otherwise
+        nothing changes and `step()` does the work.  For `zero_grad(); backward(); step()` loops -- not for gradient
+        accumulation over several passes, and not for data-parallel steps (they reduce the gradients across ranks between
+        backward and step)."""
+        return _InBackward(self)
+
     def zero_grad(self):
         for p in self.params:
             p.grad = None
@@ -40,6 +68,9 @@ class FusedAdam:
         """grads: tensors to read instead of p.grad (e.g. views of an all-reduced flat bucket).  A parameter whose
         gradient is None is left untouched, as torch.optim.Adam does (the reference block's bn14 is never used)."""
         if grads is None:
+            if getattr(self, "_stepped_in_backward", False) and grad_scale == 1.0:
+                self._stepped_in_backward = False       # the backward pass's reduction launch has applied this step
+                return
             grads = [p.grad for p in self.params]
         live = [i for i, g in enumerate(grads) if g is not None]
         if not live:

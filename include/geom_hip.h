@@ -302,6 +302,15 @@ int geom_dense_bwd_f32(int rows, int cin, int c, const float *x, const float *g,
 int geom_dense_reduce2_f32(int count, const int *rows, const int *cin, const int *c, const float *const *workspaces,
                            float *const *grad_w, float *const *grad_bias, int ncs, const float *const *cs_partials,
                            const int *cs_rows, const int *cs_cols, float *const *cs_outs, void *stream);
+/* geom_dense_reduce2_f32 + the Adam step (torch.optim.Adam's rule, as geom_adam_step_f32) of the parameters whose gradients
+ * the launch finishes: w_p / w_m / w_v[l] = parameter and its two moments for layer l's weight, b_p / b_m / b_v[i] for column-sum
+ * job i (entries may be NULL: gradient only); `state` = the optimiser's device-side step state, advanced once by this launch;
+ * grad_scale = 1.  Single-process steps only: a data-parallel step reduces across ranks first. */
+int geom_dense_reduce_adam_f32(int count, const int *rows, const int *cin, const int *c, const float *const *workspaces,
+                               float *const *grad_w, float *const *w_p, float *const *w_m, float *const *w_v, int ncs,
+                               const float *const *cs_partials, const int *cs_rows, const int *cs_cols, float *const *cs_outs,
+                               float *const *b_p, float *const *b_m, float *const *b_v, float lr, float beta1, float beta2,
+                               float eps, float *state, void *stream);
 int geom_dense_reduce_f32(int count, const int *rows, const int *cin, const int *c, const float *const *workspaces,
                           float *const *grad_w, float *const *grad_bias, void *stream);
 
@@ -457,13 +466,14 @@ int geom_segment_max_bwd_f32(int nseg, const int64_t *offsets, int64_t total_row
  * launch.  params/grads/exp_avg/exp_avg_sq/sizes are HOST arrays of `count` device pointers / lengths;
  * grads are multiplied by grad_scale first (1/world after a SUM all-reduce).  `state` is
  * GEOM_ADAM_STATE_WORDS 4-byte device words, zero-initialised by the caller once: {t, beta1^t, beta2^t}
- * as floats followed by the arrival counters of the in-kernel step advance.  Every call applies the bias
+ * as floats followed by the arrival counters of the in-kernel step advance (root at word 3, leaf l at word 32 * (1 + l): one
+ * cache line each).  Every call applies the bias
  * corrections of step t+1; with advance != 0 the last workgroup to finish moves the state to t+1 (so a
  * captured HIP graph replays the correct correction, with no separate tick launch).  An optimiser holding
  * more than GEOM_ADAM_MAX_TENSORS tensors issues several calls on one stream for one step: advance = 0 on
  * all but the last. */
 #define GEOM_ADAM_MAX_TENSORS 64
-#define GEOM_ADAM_STATE_WORDS 72
+#define GEOM_ADAM_STATE_WORDS 2112 /* {t, b1^t, b2^t}, the root counter, 64 leaf counters one 128-byte line apart */
 int geom_adam_step_f32(int count, float *const *params, const float *const *grads, float *const *exp_avg,
                        float *const *exp_avg_sq, const int64_t *sizes, float lr, float beta1, float beta2,
                        float eps, float grad_scale, float *state, int advance, void *stream);

@@ -177,3 +177,71 @@ def test_fused_adam_graph_replays_track_torch_adam():
         ref_opt.step()
     for a, b in zip(ours, ref):
         assert torch.allclose(a.detach(), b.detach(), rtol=2e-5, atol=2e-6)
+
+
+def test_adam_inside_the_backward_pass_equals_the_separate_launch():
+    """optim.FusedAdam.in_backward(): the step applied by the end-of-pass reduction launch (geom_dense_reduce_adam_f32)
+    against the same iterations with the stand-alone optimiser launch: parameters, moments and step count bit for bit, over
+    several iterations (bias corrections advance), eager and as a replayed HIP graph; and a pass that does not cover every
+    parameter leaves the step to `step()`."""
+    import torch.nn.functional as F
+    from geometrics_amd import layers, meshgen, optim, utils
+    V, Fc = meshgen.uv_sphere()
+    adj = utils.adj_init(torch.from_numpy(Fc).cuda())["adj"]
+    x = torch.randn(4, V.shape[0], 40, device="cuda")
+    target = torch.randn(4, V.shape[0], 48, device="cuda")
+
+    def make():
+        torch.manual_seed(3)
+        stack = torch.nn.ModuleList([layers.Batch_Image_ZERON_GCNGCN(40, 48), layers.Batch_Image_ZERON_GCNGCN(48, 48),
+                                     layers.Batch_Image_ZERON_GCNGCN(48, 48)]).cuda()
+        return stack, optim.FusedAdam(stack.parameters(), lr=1e-2)
+
+    def iteration(stack, opt, fused):
+        import contextlib
+        opt.zero_grad()
+        with layers.deferred_parameter_gradients(), (opt.in_backward() if fused else contextlib.nullcontext()):
+            h = x
+            for layer in stack:
+                h = layer(h, adj, F.relu)
+            ((h - target) ** 2).mean().backward()
+        stepped = bool(getattr(opt, "_stepped_in_backward", False))
+        opt.step()
+        return stepped
+
+    a, oa = make()
+    b, ob = make()
+    for _ in range(4):
+        assert iteration(a, oa, True) is True          # the launch covered all six parameters: step() was a no-op
+        assert iteration(b, ob, False) is False
+    assert oa.step_count == ob.step_count == 4
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.equal(p, q) and torch.equal(p.grad, q.grad)
+    for m1, m2 in zip(oa.exp_avg + oa.exp_avg_sq, ob.exp_avg + ob.exp_avg_sq):
+        assert torch.equal(m1, m2)
+    # an optimiser that ALSO owns a parameter this pass does not produce a gradient for: nothing is fused
+    extra = torch.nn.Parameter(torch.zeros(5, device="cuda"))
+    oc = optim.FusedAdam(list(a.parameters()) + [extra], lr=1e-2)
+    od = optim.FusedAdam(list(b.parameters()) + [torch.nn.Parameter(torch.zeros(5, device="cuda"))], lr=1e-2)
+    assert iteration(a, oc, True) is False and iteration(b, od, False) is False
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.equal(p, q)
+    # replayed as a HIP graph
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        iteration(a, oa, True)
+        iteration(b, ob, False)
+    torch.cuda.current_stream().wait_stream(side)
+    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(ga):
+        iteration(a, oa, True)
+    with torch.cuda.graph(gb):
+        iteration(b, ob, False)
+    for _ in range(3):
+        ga.replay()
+        gb.replay()
+    torch.cuda.synchronize()
+    assert oa.step_count == ob.step_count
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.equal(p, q)

@@ -1,6 +1,6 @@
 """One step of `python bench.py --steps N --warmup W --no-cpu-baseline --steps-only` in launch order, from the rocprofv3
 kernel trace of that command:   python tools/step_timeline.py <trace dir> [out.txt]
-A step = the launches between two consecutive adam_kernel dispatches of the graph replay (the last complete one)."""
+A step = the launches between two consecutive step-closing dispatches of the graph replay (the last complete one)."""
 import csv
 import glob
 import re
@@ -8,7 +8,11 @@ import sys
 
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+# the last launch of a step: the stand-alone Adam launch, or -- when the optimiser step rides in the end-of-pass reduction
+# (single-process step since round 3) -- that reduction launch
 adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+if len(adam) < 2:
+    adam = [i for i, r in enumerate(rows) if "dense_reduce_kernel" in r["Kernel_Name"]]
 a, b = adam[-2], adam[-1]
 
 
