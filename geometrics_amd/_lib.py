@@ -16,7 +16,7 @@ FLAG_FIX_REGION6 = 2
 FLAG_TRI_BRUTE_FORCE = 4
 FLAG_NN_FMA = 8
 FLAG_TRI_WS_READY = 16
-ABI_VERSION = 5
+ABI_VERSION = 6
 EUNSUPPORTED = -3
 ADAM_MAX_TENSORS = 64
 COLSUM_MAX_JOBS = 32
@@ -32,6 +32,7 @@ _f = ctypes.c_float
 # name -> argtypes; every function returns int (0 ok / hipError_t / negative GEOM_E*)
 _SIGNATURES = {
     "geom_chamfer_nn_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp],
+    "geom_chamfer_nn_culled_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp],
     "geom_tri_distance_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp],
     "geom_tri_distance_indexed_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _u, _vp],
     "geom_tri_distance_ws_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp, ctypes.c_size_t, _vp],
@@ -45,9 +46,10 @@ _SIGNATURES = {
     "geom_surface_loss_bwd_f32": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp],
     "geom_surface_finalize_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i,
                                   _i, _vp, _vp, _vp],
-    "geom_surface_prepare_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _u, _vp, ctypes.c_size_t, _vp, _vp],
+    "geom_surface_prepare_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _u, _vp, ctypes.c_size_t, _vp, _vp, _vp],
+    "geom_nn_cull_index_f32": [_i, _i, _vp, _vp, _vp, _vp],
     "geom_surface_scan_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                              _vp, _vp, _f, _f, _vp, _u, _vp, ctypes.c_size_t, _vp, _vp],
+                              _vp, _vp, _f, _f, _vp, _u, _vp, ctypes.c_size_t, _vp, _vp, _vp],
     "geom_surface_gather_f32": [_i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "geom_vertex_head_fwd_f32": [ctypes.c_int64, _i, _vp, _vp, _f, _vp, _vp],
     "geom_vertex_head_bwd_f32": [ctypes.c_int64, _i, _vp, _f, _vp, _vp],
@@ -85,6 +87,12 @@ _SIGNATURES = {
     "geom_zn_gcn_aggregate_ell_head_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp],
     "geom_zn_gcn_aggregate_bwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
 }
+
+
+class SurfaceCull(ctypes.Structure):
+    """struct geom_surface_cull (include/geom_hip.h): the buffers of the culled Chamfer scan inside the surface step."""
+    _fields_ = [("gt_order", ctypes.c_void_p), ("gt_index", ctypes.c_void_p), ("face_rank", ctypes.c_void_p),
+                ("sample_order", ctypes.c_void_p), ("sample_index", ctypes.c_void_p)]
 
 
 def call(name, *args):
@@ -132,6 +140,10 @@ def lib():
         L.geom_zn_gcn_bwd_partial_rows.argtypes = [_i, _i, _i, _i, _i]
         L.geom_dense_bwd_weight_workspace_floats.restype = ctypes.c_int64
         L.geom_dense_bwd_weight_workspace_floats.argtypes = [_i, _i, _i]
+        L.geom_chamfer_nn_culled_workspace_floats.restype = ctypes.c_int64
+        L.geom_chamfer_nn_culled_workspace_floats.argtypes = [_i, _i, _i]
+        L.geom_nn_cull_index_floats.restype = ctypes.c_int64
+        L.geom_nn_cull_index_floats.argtypes = [_i, _i]
         L.geom_tri_distance_workspace_bytes.restype = ctypes.c_size_t
         L.geom_tri_distance_workspace_bytes.argtypes = [_i, _i, _i]
         for name, args in _SIGNATURES.items():
@@ -147,7 +159,8 @@ def declared_symbols():
                    "geom_zn_gcn_bwd_scratch_floats", "geom_zn_gcn_bwd_partial_rows", "geom_pool_features_bwd_workspace_bytes",
                    "geom_segment_max_workspace_bytes", "geom_zn_gcn_relu_mask_words",
                    "geom_surface_bin_count_words", "geom_surface_bin_list_words", "geom_surface_order_words",
-                   "geom_dense_bwd_weight_workspace_floats"] + list(_SIGNATURES))
+                   "geom_dense_bwd_weight_workspace_floats", "geom_chamfer_nn_culled_workspace_floats",
+                   "geom_nn_cull_index_floats"] + list(_SIGNATURES))
 
 
 def check(code, what):

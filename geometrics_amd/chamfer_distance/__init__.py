@@ -51,6 +51,47 @@ def chamfer_nn(xyz1, xyz2, flags=None):
     return dist1, idx1, dist2, idx2
 
 
+def chamfer_nn_culled(xyz1, xyz2, order1="morton", order2="morton", flags=None):
+    """chamfer_nn through the culled scan (csrc/nn_scan.h nn_culled_body): the same four tensors, bit for bit, for ANY
+    visiting orders (int32 [B,N] / [B,M] permutations, "morton" = made here on the device, None = the clouds' own order);
+    coherent orders let the scan skip most (query tile, target run) pairs.  The surface step has its own route to this
+    scan (ops.GtIndex); this entry serves stand-alone Chamfer calls on clouds that are reused or already ordered."""
+    if flags is None:
+        flags = _arithmetic_flags
+    xyz1 = _lib.require(xyz1.detach(), "xyz1", torch.float32, 3, 3)
+    xyz2 = _lib.require(xyz2.detach(), "xyz2", torch.float32, 3, 3)
+    dev = _lib.same_device(xyz1, xyz2)
+    b, n, _ = xyz1.shape
+    b2, m, _ = xyz2.shape
+    if b != b2:
+        raise RuntimeError("batch sizes differ: %d vs %d" % (b, b2))
+
+    def visiting(order, cloud, name):
+        if isinstance(order, str):
+            if order != "morton":
+                raise ValueError("order must be a tensor, None or 'morton'")
+            from ..tri_distance import morton_order
+            return torch.stack([morton_order(cloud[i]) for i in range(b)]) if b else None
+        if order is None:
+            return None
+        order = _lib.require(order, name, torch.int32, 2)
+        if order.shape != cloud.shape[:2] or order.device != dev:
+            raise RuntimeError("%s must be an int32 [B,N] permutation per cloud on the clouds' device" % name)
+        return order
+
+    o1, o2 = visiting(order1, xyz1, "order1"), visiting(order2, xyz2, "order2")
+    dist1 = torch.empty(b, n, dtype=torch.float32, device=dev)
+    dist2 = torch.empty(b, m, dtype=torch.float32, device=dev)
+    idx1 = torch.empty(b, n, dtype=torch.int32, device=dev)
+    idx2 = torch.empty(b, m, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    ws = torch.empty(max(int(L.geom_chamfer_nn_culled_workspace_floats(b, n, m)), 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("geom_chamfer_nn_culled_f32", b, n, xyz1.data_ptr(), m, xyz2.data_ptr(), _lib.ptr(o1), _lib.ptr(o2),
+                  dist1.data_ptr(), idx1.data_ptr(), dist2.data_ptr(), idx2.data_ptr(), flags, ws.data_ptr())
+    return dist1, idx1, dist2, idx2
+
+
 def forward_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2, flags=0):
     """Same call shape as the reference's pybind `cd.forward_cuda` (chamfer_distance.cpp:15-27,36-38):
     caller-allocated outputs, filled in place."""

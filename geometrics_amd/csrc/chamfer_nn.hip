@@ -172,6 +172,20 @@ __global__ __launch_bounds__(NNS_THREADS) void chamfer_nn_scalar_kernel(NNJob jo
     nn_scalar_body<FMA>(job, blockIdx.x, NNRecords{nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0});
 }
 
+template <bool FMA>
+__global__ __launch_bounds__(NNS_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void chamfer_nn_culled_kernel(NNJob job, NNCull cu)
+{
+    nn_culled_body<FMA>(job, cu, blockIdx.x, NNRecords{nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0});
+}
+
+__global__ __launch_bounds__(256) void nn_cull_index_kernel(int n, const float *xyz, const int *order, float *xs, float4 *sph)
+{
+    const int mesh = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x; // whole waves run: the run spheres are 16-lane reductions
+    nn_cull_prep_point(xyz + (size_t)mesh * n * 3, order ? order + (size_t)mesh * n : nullptr, n, p, xs + (size_t)mesh * nn_cull_stride(n),
+                       sph + (size_t)mesh * (n / NNS_GROUP));
+}
+
 } // namespace
 
 extern "C" int geom_chamfer_nn_f32(int b, int n, const float *xyz, int m, const float *xyz2,
@@ -197,3 +211,77 @@ extern "C" int geom_chamfer_nn_f32(int b, int n, const float *xyz, int m, const 
         hipLaunchKernelGGL(chamfer_nn_scalar_kernel<false>, grid, dim3(NNS_THREADS), 0, s, job);
     return geom::launch_status();
 }
+
+/* the index of one cloud for the culled scan: [b][n/16] run spheres (float4), then [b][nn_cull_stride(n)] floats of the
+ * cloud in visiting order */
+extern "C" int64_t geom_nn_cull_index_floats(int b, int n)
+{
+    if (b <= 0 || n <= 0) return 0;
+    return (int64_t)b * (4 * ((int64_t)n / NNS_GROUP) + (int64_t)nn_cull_stride(n));
+}
+
+extern "C" int geom_nn_cull_index_f32(int b, int n, const float *xyz, const int *order, float *index, void *stream)
+{
+    if (b < 0 || n < 0) return GEOM_EINVAL;
+    if (b == 0 || n == 0) return 0;
+    if (!xyz || !index || ((uintptr_t)index & 15)) return GEOM_EINVAL;
+    if (b > 65535) return GEOM_ETOOBIG;
+    float4 *sph = reinterpret_cast<float4 *>(index);
+    hipLaunchKernelGGL(nn_cull_index_kernel, dim3((n + 255) / 256, b), dim3(256), 0, static_cast<hipStream_t>(stream), n, xyz, order,
+                       reinterpret_cast<float *>(sph + (size_t)b * (n / NNS_GROUP)), sph);
+    return geom::launch_status();
+}
+
+/* workspace floats of geom_chamfer_nn_culled_f32: the indices of both clouds */
+extern "C" int64_t geom_chamfer_nn_culled_workspace_floats(int b, int n, int m)
+{
+    return geom_nn_cull_index_floats(b, n) + geom_nn_cull_index_floats(b, m);
+}
+
+extern "C" int geom_chamfer_nn_culled_f32(int b, int n, const float *xyz, int m, const float *xyz2, const int *order1,
+                                          const int *order2, float *result, int *result_i, float *result2, int *result2_i,
+                                          unsigned flags, float *workspace, void *stream)
+{
+    if (b < 0 || n < 0 || m < 0) return GEOM_EINVAL;
+    if (b == 0 || (n == 0 && m == 0)) return 0;
+    if (n == 0 || m == 0) return GEOM_EINVAL;
+    if (!xyz || !xyz2 || !result || !result_i || !result2 || !result2_i || !workspace || ((uintptr_t)workspace & 15)) return GEOM_EINVAL;
+#ifndef NN_CULL_STATS
+    if (flags & ~GEOM_FLAG_NN_FMA) return GEOM_EUNSUPPORTED;
+#endif
+    if (b > 65535) return GEOM_ETOOBIG;
+    NNJob job{xyz, xyz2, result, result2, result_i, result2_i, b, n, m};
+    float *index1 = workspace, *index2 = workspace + geom_nn_cull_index_floats(b, n);
+    int rc = geom_nn_cull_index_f32(b, n, xyz, order1, index1, stream);
+    if (rc == 0) rc = geom_nn_cull_index_f32(b, m, xyz2, order2, index2, stream);
+    if (rc != 0) return rc;
+    const float4 *sph1 = reinterpret_cast<const float4 *>(index1), *sph2 = reinterpret_cast<const float4 *>(index2);
+    const float *xs1 = reinterpret_cast<const float *>(sph1 + (size_t)b * (n / NNS_GROUP));
+    const float *xs2 = reinterpret_cast<const float *>(sph2 + (size_t)b * (m / NNS_GROUP));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int longer = n > m ? n : m;
+#ifdef NN_CULL_STATS
+    NNCull cu{xs1, xs2, order1, order2, sph1, sph2, flags >> 16};
+    flags &= 0xffff;
+#else
+    NNCull cu{xs1, xs2, order1, order2, sph1, sph2};
+#endif
+    const int64_t blocks = (int64_t)geom::NUM_XCD * ((longer + NN_QUERIES - 1) / NN_QUERIES) * ((2 * (int64_t)b + 7) / 8);
+    if (blocks > 0x7fffffffLL) return GEOM_ETOOBIG;
+    dim3 grid(geom::xcd_grid(2 * b, (longer + NN_QUERIES - 1) / NN_QUERIES), 1, 1);
+    if (flags & GEOM_FLAG_NN_FMA) hipLaunchKernelGGL(chamfer_nn_culled_kernel<true>, grid, dim3(NNS_THREADS), 0, s, job, cu);
+    else hipLaunchKernelGGL(chamfer_nn_culled_kernel<false>, grid, dim3(NNS_THREADS), 0, s, job, cu);
+    return geom::launch_status();
+}
+
+#ifdef NN_CULL_STATS
+extern "C" void geom_cull_stats(unsigned long long *out, int reset)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(nn_cull_stats), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {};
+        hipMemcpyToSymbol(HIP_SYMBOL(nn_cull_stats), z, sizeof(z));
+    }
+}
+#endif

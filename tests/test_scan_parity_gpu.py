@@ -120,6 +120,84 @@ def test_nn_fma_reference_vectors_and_mode_switch(oracle_mod, gpu):
         chamfer_nn(_dev(a, gpu), _dev(c, gpu), FLAG_NN_FMA | FLAG_REF_TAIL_TRUNC)
 
 
+def _orders(kind, b, n, gpu, seed=0):
+    if kind == "reversed":
+        return torch.arange(n - 1, -1, -1, dtype=torch.int32, device=gpu).repeat(b, 1).contiguous()
+    if kind == "random":
+        gen = torch.Generator().manual_seed(seed)
+        return torch.stack([torch.randperm(n, generator=gen) for _ in range(b)]).to(torch.int32).to(gpu)
+    return kind        # "morton" / None: made by the wrapper
+
+
+def _check_culled(oracle_mod, gpu, a, c, flags=0, kinds=("morton", None, "reversed", "random")):
+    from geometrics_amd.chamfer_distance import chamfer_nn_culled
+    e1, j1, e2, j2 = oracle_mod.chamfer_nn(a, c, flags)
+    for kind in kinds:
+        d1, i1, d2, i2 = chamfer_nn_culled(_dev(a, gpu), _dev(c, gpu), _orders(kind, a.shape[0], a.shape[1], gpu, 1),
+                                           _orders(kind, c.shape[0], c.shape[1], gpu, 2), flags)
+        np.testing.assert_array_equal(i1.cpu().numpy(), j1, err_msg=str(kind))
+        np.testing.assert_array_equal(i2.cpu().numpy(), j2, err_msg=str(kind))
+        np.testing.assert_array_equal(d1.cpu().numpy().view(np.uint32), e1.view(np.uint32), err_msg=str(kind))
+        np.testing.assert_array_equal(d2.cpu().numpy().view(np.uint32), e2.view(np.uint32), err_msg=str(kind))
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 500, 500), (2, 3000, 3000), (3, 1, 1), (2, 7, 2466), (1, 2466, 5), (2, 63, 65),
+                                   (1, 1025, 1023), (4, 300, 4097), (1, 16, 16), (1, 15, 17), (2, 9000, 130)])
+@pytest.mark.parametrize("flags", [0, FLAG_NN_FMA])
+def test_culled_nn_equals_the_oracle_for_any_order(oracle_mod, gpu, b, n, m, flags):
+    """The culled scan (visiting orders, run spheres, packed evaluation, exact tie path) against the CPU restatement of
+    the reference's sequential scan: indices and distances bit for bit, whatever the orders -- coherent (Morton), the
+    clouds' own, reversed, random -- and in both arithmetics; ragged sizes, fewer than one run, more than one sphere chunk."""
+    rng = np.random.default_rng(b * 1000003 + n * 131 + m)
+    a = rng.standard_normal((b, n, 3)).astype(np.float32)
+    c = rng.standard_normal((b, m, 3)).astype(np.float32)
+    _check_culled(oracle_mod, gpu, a, c, flags)
+
+
+def test_culled_nn_ties_nan_inf_and_the_reference_vectors(oracle_mod, gpu):
+    from helpers import golden, golden_names
+    from geometrics_amd.chamfer_distance import chamfer_nn_culled
+    rng = np.random.default_rng(5)
+    a = rng.integers(-3, 4, (2, 777, 3)).astype(np.float32)       # integer grid: masses of exact ties, within and across runs
+    c = rng.integers(-3, 4, (2, 1300, 3)).astype(np.float32)
+    c[:, 600:900] = c[:, :300]                                      # duplicated targets
+    for flags in (0, FLAG_NN_FMA):
+        _check_culled(oracle_mod, gpu, a, c, flags)
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal((1, 70, 3)).astype(np.float32)
+    c = rng.standard_normal((1, 300, 3)).astype(np.float32)
+    c[0, 0, 1], a[0, 3, 0], c[0, 17] = np.nan, np.inf, np.nan      # NaN seed sticks; an all-inf query; a NaN that never wins
+    a[0, 40], c[0, 200, 2] = np.nan, -np.inf
+    for flags in (0, FLAG_NN_FMA):
+        e1, j1, e2, j2 = oracle_mod.chamfer_nn(a, c, flags)
+        for kind in ("morton", None, "random"):
+            d1, i1, d2, i2 = chamfer_nn_culled(_dev(a, gpu), _dev(c, gpu), _orders(kind, 1, 70, gpu), _orders(kind, 1, 300, gpu), flags)
+            np.testing.assert_array_equal(i1.cpu().numpy(), j1)
+            np.testing.assert_array_equal(i2.cpu().numpy(), j2)
+            np.testing.assert_array_equal(np.isnan(d1.cpu().numpy()), np.isnan(e1))
+            np.testing.assert_array_equal(np.isnan(d2.cpu().numpy()), np.isnan(e2))
+            ok = ~np.isnan(e1)
+            np.testing.assert_array_equal(d1.cpu().numpy()[ok].view(np.uint32), e1[ok].view(np.uint32))
+    # the reference's own outputs (tests/golden: generated from its nnsearch, both builds)
+    fx = golden("nnfma_outputs")
+    for name in golden_names("nn_"):
+        g = golden(name)
+        if name == "nn_config2_outputs":
+            a, c = meshgen.gt_cloud(2, 3000, first=int(g["gt_first"])), meshgen.gt_cloud(2, 3000, first=int(g["pred_first"]))
+        else:
+            a, c = g["xyz1"], g["xyz2"]
+        d1, i1, d2, i2 = chamfer_nn_culled(_dev(a, gpu), _dev(c, gpu))
+        np.testing.assert_array_equal(i1.cpu().numpy(), g["idx1"])
+        np.testing.assert_array_equal(i2.cpu().numpy(), g["idx2"])
+        d1, i1, d2, i2 = chamfer_nn_culled(_dev(a, gpu), _dev(c, gpu), flags=FLAG_NN_FMA)
+        np.testing.assert_array_equal(i1.cpu().numpy(), fx[name + ".idx1"])
+        np.testing.assert_array_equal(d1.cpu().numpy().view(np.uint32), fx[name + ".dist1"].view(np.uint32))
+    with pytest.raises(RuntimeError):
+        chamfer_nn_culled(_dev(a, gpu), _dev(c, gpu), flags=FLAG_REF_TAIL_TRUNC)      # the truncation mode stays on the plain scan
+    with pytest.raises(RuntimeError):
+        chamfer_nn_culled(_dev(a, gpu), _dev(c, gpu), torch.zeros(1, 3, dtype=torch.int32, device=gpu))
+
+
 def test_chamfer_module_contract(gpu):
     x = torch.rand(2, 100, 3, device=gpu, requires_grad=True)
     y = torch.rand(2, 80, 3, device=gpu)
