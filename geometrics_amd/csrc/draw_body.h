@@ -3,7 +3,6 @@
 // launch -- both depend only on the vertex positions).
 #pragma once
 #include "geom_common.h"
-#include "nn_scan.h"
 #include "tri_math.h"
 
 namespace {
@@ -35,24 +34,11 @@ __device__ __forceinline__ float u01(unsigned x) { return (x >> 8) * 0x1p-24f; }
 // tick launch.  The counter is keyed on the global mesh index, so data-parallel ranks that share a seed draw exactly
 // what one process holding the whole batch would draw (and never the same samples for different meshes).
 
-// SORTED (the culled Chamfer scan of the same step, nn_scan.h): ONE workgroup draws all samples of the mesh and then lists
-// them in a visiting order -- by the position of their face in the triangle order (face_rank), ascending sample index
-// inside a face, i.e. neighbours in space are neighbours in the list as far as the face order is coherent -- and writes
-// the order, the visiting-order copy of the sampled points and its run spheres (the "index" nn_culled_body reads).
-struct DrawSort {
-    const int *face_rank; // [nf] position of every face in the triangle order
-    int *order;           // [b,num] out: visiting position -> sample
-    float *xs;            // [b][nn_cull_stride(num)] out
-    float4 *sph;          // [b][num / 16] out
-};
-constexpr int DRAW_SORT_CHUNKS = 4; // samples per mesh on the sorted route: at most 4096
-
 // chunk / mesh: which 1024 samples of which mesh; groups: workgroups of this launch that run this body (the arrival count)
-template <bool SORTED>
 __device__ __forceinline__ void draw_samples_body(int chunk, int mesh, unsigned long long groups, int nv, const float *verts,
                                                   int nf, const int64_t *faces, int num, const float *uniforms, int64_t plane,
                                                   unsigned long long *rng_state, int64_t *choices, float *u, float *v,
-                                                  float *points, const DrawSort &srt)
+                                                  float *points)
 {
     __shared__ float cdf[DRAW_MAX_FACES];
     __shared__ float wave_total[DRAW_THREADS / GEOM_WAVE];
@@ -95,6 +81,7 @@ __device__ __forceinline__ void draw_samples_body(int chunk, int mesh, unsigned 
     __syncthreads();
     const float total = cdf[nf - 1];
 
+    const int i = chunk * DRAW_THREADS + threadIdx.x;
     if (rng_state) {
         __syncthreads(); // every thread of this workgroup holds the position before the workgroup reports in
         if (threadIdx.x == 0) {
@@ -104,124 +91,40 @@ __device__ __forceinline__ void draw_samples_body(int chunk, int mesh, unsigned 
             }
         }
     }
-    // sample i of the mesh: the draw, its outputs; returns the face and the point
-    auto draw = [&](int i, int &face, geom::V3 &pt) {
-        const int64_t o = (int64_t)mesh * num + i;
-        float r0, r1, r2;
-        if (rng_state) { // in-kernel Philox: counter = (sample, mesh, stream position), key = seed
-            const uint4 r = philox4x32_10(make_uint4((unsigned)i, (unsigned)(mesh0 + mesh), (unsigned)pos, (unsigned)(pos >> 32)),
-                                          make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
-            r0 = u01(r.x), r1 = u01(r.y), r2 = u01(r.z);
-        } else {
-            r0 = uniforms[o], r1 = uniforms[plane + o], r2 = uniforms[2 * plane + o];
-        }
-        const float target = r0 * total;
-        int lo = 0, hi = nf - 1; // first f with cdf[f] > target, clamped to the last face
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (cdf[mid] > target) hi = mid;
-            else lo = mid + 1;
-        }
-        choices[o] = lo;
-        const float su = sqrtf(r1);
-        u[o] = su;
-        v[o] = r2;
-        face = lo;
-        if (points || SORTED) { // the sampled point itself, same expression as sample_fwd_kernel (utils.py:630)
-            const geom::V3 x = draw_ld3(V + 3 * faces[3 * (size_t)lo + 0]);
-            const geom::V3 y = draw_ld3(V + 3 * faces[3 * (size_t)lo + 1]);
-            const geom::V3 z = draw_ld3(V + 3 * faces[3 * (size_t)lo + 2]);
-            const float w0 = 1.f - su;
-            const float w1 = su * (1.f - r2);
-            const float w2 = su * r2;
-            pt = (x * w0 + y * w1) + z * w2;
-            if (points) {
-                points[3 * o + 0] = pt.x;
-                points[3 * o + 1] = pt.y;
-                points[3 * o + 2] = pt.z;
-            }
-        }
-    };
-    if constexpr (!SORTED) {
-        const int i = chunk * DRAW_THREADS + threadIdx.x;
-        if (i >= num) return;
-        int face;
-        geom::V3 pt;
-        draw(i, face, pt);
+    if (i >= num) return;
+    const int64_t o = (int64_t)mesh * num + i;
+    float r0, r1, r2;
+    if (rng_state) { // in-kernel Philox: counter = (sample, mesh, stream position), key = seed
+        const uint4 r = philox4x32_10(make_uint4((unsigned)i, (unsigned)(mesh0 + mesh), (unsigned)pos, (unsigned)(pos >> 32)),
+                                      make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+        r0 = u01(r.x), r1 = u01(r.y), r2 = u01(r.z);
     } else {
-        constexpr int CAP = DRAW_SORT_CHUNKS * DRAW_THREADS;
-        __shared__ float pts[3][CAP];
-        __shared__ int keys[CAP], tmp[CAP];
-#pragma unroll
-        for (int c = 0; c < DRAW_SORT_CHUNKS; ++c) {
-            const int i = c * DRAW_THREADS + threadIdx.x;
-            if (i < num) {
-                int face;
-                geom::V3 pt;
-                draw(i, face, pt);
-                keys[i] = srt.face_rank[face];
-                pts[0][i] = pt.x, pts[1][i] = pt.y, pts[2][i] = pt.z;
-            }
-        }
-        __syncthreads(); // the CDF has been read for the last time: its LDS becomes the histogram of the counting sort
-        int *hist = reinterpret_cast<int *>(cdf);
-        for (int f = threadIdx.x; f < nf; f += DRAW_THREADS) hist[f] = 0;
-        __syncthreads();
-        for (int i = threadIdx.x; i < num; i += DRAW_THREADS) atomicAdd(&hist[keys[i]], 1);
-        __syncthreads();
-        int cnt = 0; // exclusive scan of the nf counts: consecutive bins per thread, wave scan, wave totals
-        for (int f = f0; f < f1; ++f) {
-            const int t = hist[f];
-            hist[f] = cnt;
-            cnt += t;
-        }
-        int inc = cnt;
-        for (int off = 1; off < GEOM_WAVE; off <<= 1) {
-            const int t = __shfl_up(inc, off, GEOM_WAVE);
-            if (lane >= off) inc += t;
-        }
-        int *wave_cnt = reinterpret_cast<int *>(wave_total);
-        if (lane == GEOM_WAVE - 1) wave_cnt[wave] = inc;
-        __syncthreads();
-        int before = inc - cnt;
-        for (int w = 0; w < wave; ++w) before += wave_cnt[w];
-        for (int f = f0; f < f1; ++f) hist[f] += before;
-        __syncthreads();
-        for (int i = threadIdx.x; i < num; i += DRAW_THREADS) tmp[atomicAdd(&hist[keys[i]], 1)] = i; // hist[k]: end of bin k now
-        __syncthreads();
-        // the atomics placed the samples of a face in arrival order: rank them by sample index (a handful per face), so that
-        // the order is a pure function of the draws
-        int place[DRAW_SORT_CHUNKS];
-#pragma unroll
-        for (int c = 0; c < DRAW_SORT_CHUNKS; ++c) {
-            const int i = c * DRAW_THREADS + threadIdx.x;
-            place[c] = -1;
-            if (i < num) {
-                const int k = keys[i];
-                const int first = k ? hist[k - 1] : 0, last = hist[k];
-                int below = 0;
-                for (int j = first; j < last; ++j) below += tmp[j] < i;
-                place[c] = first + below;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < DRAW_SORT_CHUNKS; ++c)
-            if (place[c] >= 0) keys[place[c]] = c * DRAW_THREADS + threadIdx.x; // keys: visiting position -> sample from here on
-        __syncthreads();
-        float *xs = srt.xs + (size_t)mesh * nn_cull_stride(num);
-        float4 *sph = srt.sph + (size_t)mesh * (num / NNS_GROUP);
-        for (int p0 = 0; p0 < num; p0 += DRAW_THREADS) { // whole waves: the run spheres are 16-lane reductions
-            const int p = p0 + threadIdx.x;
-            float px = 0.f, py = 0.f, pz = 0.f;
-            if (p < num) {
-                const int i = keys[p];
-                srt.order[(size_t)mesh * num + p] = i;
-                px = pts[0][i], py = pts[1][i], pz = pts[2][i];
-            }
-            nn_cull_emit(px, py, pz, num, p, xs, sph);
-        }
+        r0 = uniforms[o], r1 = uniforms[plane + o], r2 = uniforms[2 * plane + o];
+    }
+    const float target = r0 * total;
+    int lo = 0, hi = nf - 1; // first f with cdf[f] > target, clamped to the last face
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] > target) hi = mid;
+        else lo = mid + 1;
+    }
+    choices[o] = lo;
+    const float su = sqrtf(r1);
+    u[o] = su;
+    v[o] = r2;
+    if (points) { // the sampled point itself, same expression as sample_fwd_kernel (utils.py:630)
+        const geom::V3 x = draw_ld3(V + 3 * faces[3 * (size_t)lo + 0]);
+        const geom::V3 y = draw_ld3(V + 3 * faces[3 * (size_t)lo + 1]);
+        const geom::V3 z = draw_ld3(V + 3 * faces[3 * (size_t)lo + 2]);
+        const float w0 = 1.f - su;
+        const float w1 = su * (1.f - r2);
+        const float w2 = su * r2;
+        const geom::V3 pt = (x * w0 + y * w1) + z * w2;
+        points[3 * o + 0] = pt.x;
+        points[3 * o + 1] = pt.y;
+        points[3 * o + 2] = pt.z;
     }
 }
+
 
 } // namespace

@@ -349,7 +349,6 @@ __device__ __forceinline__ void nn_culled_body(const NNJob &job, const NNCull &c
     for (int t = threadIdx.x; t < min(NNC_SPH, runs); t += NNS_THREADS) sph[t] = S[t];
     if (wave == 0) qp[0][lane] = qx, qp[1][lane] = qy, qp[2][lane] = qz;
     __syncthreads();
-    if (NN_DBG(32)) { out_d[q0] = qx + f0x + own.x + sph[lane].x + qo[0] + qo[1]; return; }
 
     float best = INFINITY;
     int best_grp = -1, best_orig = INT_MAX;
@@ -403,7 +402,6 @@ __device__ __forceinline__ void nn_culled_body(const NNJob &job, const NNCull &c
         const int rstar = __builtin_amdgcn_readlane(kr, at ? __builtin_ctzll(at) : 0);
         // seeds: eight neighbouring runs of the visiting order around it, one per wave; the lanes share the best of the eight
         const int lo = max(0, min(rstar - 3, runs - NNS_WAVES));
-        if (NN_DBG(64)) { out_d[q0] = qx + f0x + lo + qo[0] + qo[1]; return; }
         if (lo + wave < runs) {
             nn_fetch_run(Ts + (size_t)(lo + wave) * NNC_RUN_FLOATS, &stage[wave][0][0], lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -414,7 +412,6 @@ __device__ __forceinline__ void nn_culled_body(const NNJob &job, const NNCull &c
         float bound = seed_d[0][lane];
 #pragma unroll
         for (int w = 1; w < NNS_WAVES; ++w) bound = fminf(bound, seed_d[w][lane]);
-        if (NN_DBG(128)) { out_d[q0] = qx + f0x + bound + qo[0] + qo[1]; return; }
         const bool geo = live && qx - qx == 0.f && qy - qy == 0.f && qz - qz == 0.f;
         const unsigned long long geo_mask = __builtin_amdgcn_ballot_w64(geo);
         // s_q >= sqrt of the lane's bound: v_sqrt_f32 is good to 1 ulp, the margins are 2^-10 relative + 2^-12 |q|_1
@@ -499,7 +496,7 @@ __device__ __forceinline__ void nn_culled_body(const NNJob &job, const NNCull &c
                 }
                 pending += more;
             }
-            if (pending) flush(); // before the spheres' chunk... (pend_sph holds copies: only for simplicity)
+            if (pending) flush();
         }
         if (wave == 0) NN_STAT(0, 1);
     }
@@ -519,7 +516,6 @@ __device__ __forceinline__ void nn_culled_body(const NNJob &job, const NNCull &c
         part_i[NNS_WAVES][lane] = tail_o;
     }
     __syncthreads();
-    if (NN_DBG(256)) { out_d[q0] = part_d[0][lane] + f0x + qo[0] + qo[1]; return; }
 
     // closing phase, thread <-> (query, member of a run): the smallest distance of the eight waves, the lowest original
     // index among the targets that attain it (the members of the winning run(s), one per thread; same arithmetic => exact

@@ -791,16 +791,16 @@ __global__ __launch_bounds__(256) void tri_prep_grouped_kernel(TriJob job, TriGw
 // The per-step PREPARATION of the surface loss in one launch: everything that depends only on the vertex positions --
 // the random face draws (+ the sampled points) of batch_sample and the triangle records / group spheres of the
 // two-level scan.  Workgroups [0, draw_blocks) run a draw chunk, the rest 1024 triangle slots each.
-template <bool FIX6, bool SORTED>
+template <bool FIX6>
 __global__ __launch_bounds__(DRAW_THREADS) void surface_prepare_kernel(int draw_blocks, int draw_chunks, int nv, const float *verts,
                                                                         int nf, const int64_t *faces, int num,
                                                                         unsigned long long *rng_state, int64_t *choices, float *u,
                                                                         float *v, float *points, TriJob job, TriGws ws,
-                                                                        const int *__restrict__ order, int prep_chunks, DrawSort srt)
+                                                                        const int *__restrict__ order, int prep_chunks)
 {
-    if ((int)blockIdx.x < draw_blocks) { // SORTED: one workgroup per mesh (draw_chunks == 1) draws everything and sorts
-        draw_samples_body<SORTED>(blockIdx.x % draw_chunks, blockIdx.x / draw_chunks, (unsigned long long)draw_blocks, nv, verts, nf,
-                                  faces, num, nullptr, 0, rng_state, choices, u, v, points, srt);
+    if ((int)blockIdx.x < draw_blocks) {
+        draw_samples_body(blockIdx.x % draw_chunks, blockIdx.x / draw_chunks, (unsigned long long)draw_blocks, nv, verts, nf,
+                          faces, num, nullptr, 0, rng_state, choices, u, v, points);
     } else {
         const int pid = blockIdx.x - draw_blocks;
         tri_prep_grouped_body<true, false, FIX6>(job, ws, order, (pid % prep_chunks) * DRAW_THREADS + threadIdx.x, pid / prep_chunks);
@@ -1076,15 +1076,14 @@ __global__ __launch_bounds__(HS_WAVES * GEOM_WAVE) void tri_scan_grouped_kernel(
 // build (3 workgroups per CU instead of 2, 13 registers spilled): 55.3.  PMC of this launch: 32.0 M VALU instructions
 // = 40 T lane-ops/s, 0.51 of the 78.6 T spec issue rate and 0.78 of the 51.5 T the chip sustains on un-packed v_fma_f32
 // (MI355X_MICROARCH.md: 103 TFLOP/s measured) -- the fused launch is VALU-issue bound, what is left is instruction count.
-template <bool FIX6, bool FMA, bool CULL>
+template <bool FIX6, bool FMA>
 __global__ __launch_bounds__(8 * GEOM_WAVE) void surface_scan_kernel(const float *__restrict__ xyz, int b, int n, int m, TriGws ws,
                                                                       float *__restrict__ dist, int *__restrict__ point,
                                                                       int *__restrict__ index, SurfaceOut surf, NNJob job,
-                                                                      NNRecords rr, int tri_blocks, NNCull cull)
+                                                                      NNRecords rr, int tri_blocks)
 {
     static_assert(NNS_THREADS == 8 * GEOM_WAVE, "both bodies are written for 8-wave workgroups");
     if ((int)blockIdx.x < tri_blocks) tri_scan_grouped_body<false, FIX6, 8>(blockIdx.x, xyz, b, n, m, ws, dist, point, index, surf);
-    else if (CULL) nn_culled_body<FMA>(job, cull, blockIdx.x - tri_blocks, rr);
     else nn_scalar_body<FMA>(job, blockIdx.x - tri_blocks, rr);
 }
 
@@ -1297,8 +1296,7 @@ extern "C" int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, 
                                      const int64_t *faces, const int *tri_order, float *tri_dist, int *option, int *index,
                                      float *sq, float *closest, float *weights, const float *u, const float *v,
                                      float coef_sample, float coef_other, int *order_scratch, unsigned flags,
-                                     void *workspace, size_t workspace_bytes, int *records_written,
-                                     const geom_surface_cull *cull, void *stream)
+                                     void *workspace, size_t workspace_bytes, int *records_written, void *stream)
 {
     if (records_written) *records_written = 0;
     if (b < 0 || n_gt < 0 || num < 0 || nf < 0 || nv < 0) return GEOM_EINVAL;
@@ -1345,29 +1343,13 @@ extern "C" int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, 
             const unsigned tri_blocks = geom::xcd_grid(b, qtiles);
             SurfaceOut so{verts, faces, nv, sq, closest, weights, rec, coef_other, (int)cap, num};
             const dim3 grid(tri_blocks + nn_blocks), block(8 * GEOM_WAVE);
-            // the Chamfer tiles take the culled scan when the caller handed over the indices of both clouds (the gt
-            // cloud's: static; the sampled points': written by geom_surface_prepare_f32 of the same step)
-            const bool culled = cull && cull->gt_index && cull->sample_index && cull->sample_order;
-            if (culled && (((uintptr_t)cull->gt_index | (uintptr_t)cull->sample_index) & 15)) return GEOM_EINVAL;
-            NNCull nc{};
-            if (culled) {
-                const float4 *s1 = reinterpret_cast<const float4 *>(cull->gt_index), *s2 = reinterpret_cast<const float4 *>(cull->sample_index);
-                nc = NNCull{reinterpret_cast<const float *>(s1 + (size_t)b * (n_gt / NNS_GROUP)),
-                            reinterpret_cast<const float *>(s2 + (size_t)b * (num / NNS_GROUP)), cull->gt_order, cull->sample_order, s1, s2};
-            }
-#define GEOM_LAUNCH_SCAN(F6, FM, CU)                                                                                            \
-    hipLaunchKernelGGL((surface_scan_kernel<F6, FM, CU>), grid, block, 0, s, gt, b, n_gt, nf, gws, tri_dist, option, index, so, job, \
-                       rr, (int)tri_blocks, nc)
-#define GEOM_LAUNCH_SCAN2(F6, FM)                                                                                               \
-    do {                                                                                                                        \
-        if (culled) GEOM_LAUNCH_SCAN(F6, FM, true);                                                                             \
-        else GEOM_LAUNCH_SCAN(F6, FM, false);                                                                                   \
-    } while (0)
-            if (fix6 && fma) GEOM_LAUNCH_SCAN2(true, true);
-            else if (fix6) GEOM_LAUNCH_SCAN2(true, false);
-            else if (fma) GEOM_LAUNCH_SCAN2(false, true);
-            else GEOM_LAUNCH_SCAN2(false, false);
-#undef GEOM_LAUNCH_SCAN2
+#define GEOM_LAUNCH_SCAN(F6, FM)                                                                                                \
+    hipLaunchKernelGGL((surface_scan_kernel<F6, FM>), grid, block, 0, s, gt, b, n_gt, nf, gws, tri_dist, option, index, so, job, rr, \
+                       (int)tri_blocks)
+            if (fix6 && fma) GEOM_LAUNCH_SCAN(true, true);
+            else if (fix6) GEOM_LAUNCH_SCAN(true, false);
+            else if (fma) GEOM_LAUNCH_SCAN(false, true);
+            else GEOM_LAUNCH_SCAN(false, false);
 #undef GEOM_LAUNCH_SCAN
             if (records_written) *records_written = rec != nullptr;
             return geom::launch_status();
@@ -1393,7 +1375,7 @@ extern "C" int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, 
 extern "C" int geom_surface_prepare_f32(int b, int nv, const float *verts, int nf, const int64_t *faces, int num,
                                         uint64_t *rng_state, int64_t *choices, float *u, float *v, float *points, int n_gt,
                                         const int *tri_order, unsigned flags, void *workspace, size_t workspace_bytes,
-                                        int *prepared, const geom_surface_cull *cull, void *stream)
+                                        int *prepared, void *stream)
 {
     if (prepared) *prepared = 0;
     if (b < 0 || nv < 0 || nf < 0 || num < 0 || n_gt < 0) return GEOM_EINVAL;
@@ -1415,33 +1397,15 @@ extern "C" int geom_surface_prepare_f32(int b, int nv, const float *verts, int n
     TriGws gws{base, base + (size_t)b * m_pad, grp, first, reinterpret_cast<unsigned long long *>(first + (size_t)b * 3), m_pad, 1};
     TriJob tj{nullptr, nullptr, nullptr, nullptr, verts, faces, nullptr, nullptr, nullptr, b, n_gt, nf, nv};
     const int prep_chunks = (m_pad + DRAW_THREADS - 1) / DRAW_THREADS;
-    unsigned long long *st = reinterpret_cast<unsigned long long *>(rng_state);
-    // the culled Chamfer scan of the same step wants the samples in a visiting order: one workgroup per mesh then draws
-    // all of them and sorts (draw_body.h)
-    const bool sorted = cull && cull->face_rank && cull->sample_order && cull->sample_index && num >= NN_QUERIES &&
-                        num <= DRAW_SORT_CHUNKS * DRAW_THREADS;
-    if (sorted && ((uintptr_t)cull->sample_index & 15)) return GEOM_EINVAL;
-    if (sorted) {
-        float4 *sph = reinterpret_cast<float4 *>(cull->sample_index);
-        DrawSort srt{cull->face_rank, cull->sample_order, reinterpret_cast<float *>(sph + (size_t)b * (num / NNS_GROUP)), sph};
-        const dim3 grid(b + prep_chunks * b), block(DRAW_THREADS);
-        if (flags & GEOM_FLAG_FIX_REGION6)
-            hipLaunchKernelGGL((surface_prepare_kernel<true, true>), grid, block, 0, s, b, 1, nv, verts, nf, faces, num, st, choices, u, v,
-                               points, tj, gws, tri_order, prep_chunks, srt);
-        else
-            hipLaunchKernelGGL((surface_prepare_kernel<false, true>), grid, block, 0, s, b, 1, nv, verts, nf, faces, num, st, choices, u,
-                               v, points, tj, gws, tri_order, prep_chunks, srt);
-        if (prepared) *prepared = 3; // bit 0: triangle records; bit 1: the sampled points' index
-        return geom::launch_status();
-    }
     const int draw_blocks = draw_chunks * b;
     const dim3 grid(draw_blocks + prep_chunks * b), block(DRAW_THREADS);
+    unsigned long long *st = reinterpret_cast<unsigned long long *>(rng_state);
     if (flags & GEOM_FLAG_FIX_REGION6)
-        hipLaunchKernelGGL((surface_prepare_kernel<true, false>), grid, block, 0, s, draw_blocks, draw_chunks, nv, verts, nf, faces, num,
-                           st, choices, u, v, points, tj, gws, tri_order, prep_chunks, DrawSort{});
+        hipLaunchKernelGGL(surface_prepare_kernel<true>, grid, block, 0, s, draw_blocks, draw_chunks, nv, verts, nf, faces, num, st,
+                           choices, u, v, points, tj, gws, tri_order, prep_chunks);
     else
-        hipLaunchKernelGGL((surface_prepare_kernel<false, false>), grid, block, 0, s, draw_blocks, draw_chunks, nv, verts, nf, faces, num,
-                           st, choices, u, v, points, tj, gws, tri_order, prep_chunks, DrawSort{});
+        hipLaunchKernelGGL(surface_prepare_kernel<false>, grid, block, 0, s, draw_blocks, draw_chunks, nv, verts, nf, faces, num, st,
+                           choices, u, v, points, tj, gws, tri_order, prep_chunks);
     if (prepared) *prepared = 1;
     return geom::launch_status();
 }

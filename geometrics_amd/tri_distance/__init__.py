@@ -79,21 +79,6 @@ def face_order(verts, faces):
     return order
 
 
-def face_rank(verts, faces):
-    """The inverse of face_order: int32 [F], the position of every face in the visiting order (None when there is no
-    order).  The surface step sorts its random samples by it (ops.draw_samples(..., gt_index=...))."""
-    order = face_order(verts, faces)
-    if order is None:
-        return None
-    hit = _order_cache.get(id(faces))
-    if len(hit) == 3:
-        rank = torch.empty_like(order)
-        rank[order.long()] = torch.arange(order.numel(), dtype=torch.int32, device=order.device)
-        hit = hit + (rank,)
-        _order_cache[id(faces)] = hit
-    return hit[3]
-
-
 # ---- the reference-shaped entry (tri1 / tri2 / tri3 corner tensors, tri_distance.py:9-43): no face list to key a cache on --
 # the corner tensors are fresh gathers every step (utils.py:467-470).  What stays the same from call to call is the TOPOLOGY
 # behind them, and mesh deformation keeps a topology's visiting order coherent; so one order is kept per (triangle count,

@@ -1011,7 +1011,7 @@ def test_fused_surface_scan_equals_the_separate_scans_and_its_records_those_of_t
                                           o["idx_p"].data_ptr(), o["sq_pred"].data_ptr(), o["idx_g"].data_ptr(), *tri,
                                           u.data_ptr(), v.data_ptr(), coef_s, coef_o,
                                           o["order"].data_ptr() if with_records else None, flags, o["ws"].data_ptr(), ws_bytes,
-                                          ctypes.byref(wrote), None, L.stream_ptr()), "geom_surface_scan_f32")
+                                          ctypes.byref(wrote), L.stream_ptr()), "geom_surface_scan_f32")
         assert wrote.value == int(with_records)
         other = o["sq_gt"] if two_sided else o["sq"]
         L.call("geom_surface_finalize_f32", B, nf, num, choices.data_ptr(), u.data_ptr(), v.data_ptr(), points.data_ptr(), n_gt,
@@ -1085,56 +1085,6 @@ def test_prepare_launch_equals_draw_plus_prep(gpu):
                                  v[:2].contiguous(), False, 3000.0)[0]
     assert abs(part.item() - ref.item()) <= 1e-5 * abs(ref.item())
     assert torch.isfinite(loss)
-
-
-def test_surface_step_with_the_culled_chamfer_tiles_is_bit_identical(gpu):
-    """The surface step with a GtIndex (sorted draws + index of the sampled points written by the prepare launch, culled
-    Chamfer tiles in the scan launch) against the same step without: same draws, same loss, same squared distances, same
-    gradient -- bit for bit, in both arithmetics, with a Morton and with a deliberately incoherent gt order; and the
-    visiting order of the samples is a pure function of the draws (ascending face rank, ascending sample inside a face)."""
-    from geometrics_amd import chamfer_distance as cd
-    from geometrics_amd.tri_distance import face_rank
-    V, Fc = meshgen.icosphere(4)
-    B, num = 8, 3000
-    verts = dev(meshgen.jittered_batch(V, B), gpu).requires_grad_(True)
-    faces, gt = dev(Fc, gpu), dev(meshgen.gt_cloud(B, num), gpu)
-    rank = face_rank(verts.detach(), faces)
-    assert rank is not None and torch.equal(torch.sort(rank).values.cpu(), torch.arange(Fc.shape[0], dtype=torch.int32))
-    gen = torch.Generator().manual_seed(3)
-    shuffled = torch.stack([torch.randperm(num, generator=gen) for _ in range(B)]).to(torch.int32).to(gpu)
-    try:
-        for arithmetic in ("unfused", "fma"):
-            cd.set_arithmetic(arithmetic)
-            for gi in (ops.GtIndex(gt), ops.GtIndex(gt, shuffled)):
-                res = []
-                for index in (None, gi):
-                    ops.manual_seed(77)
-                    d = ops.draw_samples(verts, faces, num, with_points=True, prepare_scan_for=num, gt_index=index)
-                    assert isinstance(d[4], ops.ScanPrep) == (index is not None)
-                    verts.grad = None
-                    loss, sq_gt, sq_pred = ops.SurfaceLoss.apply(verts, faces, gt, d[0], d[1], d[2], False, 3000.0, d[3], d[4], index)
-                    loss.backward()
-                    res.append((d[0].clone(), d[1].clone(), d[2].clone(), d[3].clone(), loss.detach().clone(), sq_gt.clone(),
-                                sq_pred.clone(), verts.grad.clone()))
-                    if index is not None:
-                        order = d[4].sample_order.long()
-                        assert torch.equal(torch.sort(order, 1).values, torch.arange(num, device=gpu).expand(B, num))
-                        key = rank.long()[torch.gather(d[0], 1, order)] * num + order      # (face rank, sample) ascending
-                        assert bool((key[:, 1:] > key[:, :-1]).all())
-                for x, y in zip(*res):
-                    assert torch.equal(x, y)
-    finally:
-        cd.set_arithmetic("unfused")
-    # the helper the training loop calls
-    gi = ops.GtIndex(gt)
-    info = {"faces": faces}
-    ops.manual_seed(5)
-    a = utils.batch_point_to_surface(verts.detach(), info, gt, num=num)
-    ops.manual_seed(5)
-    b_ = utils.batch_point_to_surface(verts.detach(), info, gt, num=num, gt_index=gi)
-    assert torch.equal(a, b_)
-    with pytest.raises(RuntimeError):
-        utils.batch_point_to_surface(verts.detach(), info, gt.clone(), num=num, gt_index=gi)    # built for another tensor
 
 
 def test_tri_surface_fused_call_equals_scan_plus_point_to_triangle(gpu):
