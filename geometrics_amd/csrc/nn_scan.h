@@ -488,13 +488,18 @@ __device__ __forceinline__ void nn_culled_body(const NNJob &job, const NNCull &c
                 const bool is_mine = keep && (ord & (NNS_WAVES - 1)) == wave;
                 const unsigned long long mine = __builtin_amdgcn_ballot_w64(is_mine);
                 const int more = __builtin_popcountll(mine);
-                if (pending + more > NNC_SLOTS) flush();
-                if (is_mine) {
-                    const int k = pending + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0u));
-                    pend_sph[wave][k] = sp;
-                    pend_run[wave][k] = g;
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0u));
+                for (int queued = 0; queued < more;) { // into the pending list, as many as there is room for; flush when full
+                    if (pending == NNC_SLOTS) flush();
+                    const int take = min(NNC_SLOTS - pending, more - queued);
+                    const int k = rank - queued;
+                    if (is_mine && k >= 0 && k < take) {
+                        pend_sph[wave][pending + k] = sp;
+                        pend_run[wave][pending + k] = g;
+                    }
+                    pending += take;
+                    queued += take;
                 }
-                pending += more;
             }
             if (pending) flush();
         }

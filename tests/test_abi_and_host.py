@@ -174,6 +174,26 @@ def test_compiled_forward_cuda_shim_loads_and_validates():
         _shim.tri.forward_cuda(z, z, z, z, torch.zeros(1, 2), i, i)
 
 
+def test_culled_chamfer_entry_points_validate_before_launching():
+    """geom_nn_cull_index_* / geom_chamfer_nn_culled_*: sizes of the index (run spheres + the cloud in rows of whole runs,
+    16-byte aligned), argument checks, empty batches -- nothing here reaches a launch."""
+    L = _lib.lib()
+    assert L.geom_nn_cull_index_floats(1, 3000) == 4 * 187 + 9000
+    assert L.geom_nn_cull_index_floats(2, 17) == 2 * (4 * 1 + 52)             # 51 floats -> a 52-float row
+    assert L.geom_nn_cull_index_floats(0, 10) == 0 and L.geom_nn_cull_index_floats(3, 0) == 0
+    assert L.geom_chamfer_nn_culled_workspace_floats(2, 3000, 17) == L.geom_nn_cull_index_floats(2, 3000) + L.geom_nn_cull_index_floats(2, 17)
+    buf = (ctypes.c_float * 64)()
+    p16 = (ctypes.addressof(buf) + 15) & ~15
+    assert L.geom_nn_cull_index_f32(-1, 4, p16, None, p16, None) == -1
+    assert L.geom_nn_cull_index_f32(0, 4, None, None, None, None) == 0         # empty batch
+    assert L.geom_nn_cull_index_f32(1, 4, p16, None, p16 + 4, None) == -1      # index not 16-byte aligned
+    assert L.geom_nn_cull_index_f32(1, 4, None, None, p16, None) == -1
+    nn = lambda b, n, m, flags, ws: L.geom_chamfer_nn_culled_f32(b, n, p16, m, p16, None, None, p16, p16, p16, p16, flags, ws, None)
+    assert nn(-1, 4, 4, 0, p16) == -1 and nn(1, 0, 4, 0, p16) == -1 and nn(1, 4, 4, 0, None) == -1 and nn(1, 4, 4, 0, p16 + 8) == -1
+    assert nn(0, 4, 4, 0, None) == 0 and nn(3, 0, 0, 0, None) == 0
+    assert nn(1, 4, 4, _lib.FLAG_REF_TAIL_TRUNC, p16) == _lib.EUNSUPPORTED      # the truncation mode stays on the plain scan
+
+
 def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     """The round-2 entry points (fused scan, prepare, finalize, gather, Adam with in-kernel step advance): sizes and
     pointers are validated before any launch, empty batches are no-ops."""
