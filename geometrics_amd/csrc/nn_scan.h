@@ -44,7 +44,12 @@ __device__ __forceinline__ float nn_sqdist(float tx, float ty, float tz, float q
     return FMA ? geom::sqdist3_fma(tx, ty, tz, qx, qy, qz) : geom::sqdist3(tx, ty, tz, qx, qy, qz);
 }
 
-// FMA = the contracted arithmetic of GEOM_FLAG_NN_FMA (6 lane-ops per pair instead of 8)
+typedef float nn_f2 __attribute__((ext_vector_type(2)));
+
+// FMA = the contracted arithmetic of GEOM_FLAG_NN_FMA (6 lane-ops per pair instead of 8).
+// Measured and not taken (round 3): the subtractions and squares issued two components at a time from the SGPR pairs
+// (v_pk_add_f32 / v_pk_mul_f32: same bits, 14.7 M instead of 21.4 M VALU instructions per 8-mesh launch) -- 32.1 us
+// against 31.3: the packed instructions issue at about half the rate of the scalar ones here.
 template <bool FMA>
 __device__ __forceinline__ void nn_scalar_body(const NNJob &job, int bid, const NNRecords &rr)
 {
@@ -215,8 +220,6 @@ __device__ __forceinline__ size_t nn_cull_at(int n, int p, int c)
     return p < full ? (size_t)(p / NNS_GROUP) * NNC_RUN_FLOATS + c * NNS_GROUP + (p % NNS_GROUP)
                     : (size_t)full * 3 + (size_t)(p - full) * 3 + c;
 }
-
-typedef float nn_f2 __attribute__((ext_vector_type(2)));
 
 template <bool FMA>
 __device__ __forceinline__ nn_f2 nn_sqdist2(nn_f2 tx, nn_f2 ty, nn_f2 tz, float qx, float qy, float qz)
