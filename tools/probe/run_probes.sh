@@ -14,3 +14,7 @@ build mfmaonly -DDG_PROBE_NO_FETCH -DDG_PROBE_NO_ISSUE -DDG_PROBE_NO_STORE -DDG_
 build nomem -DDG_PROBE_NO_ISSUE -DDG_PROBE_NO_STORE
 wait
 ls -la tools/probe/bin
+
+# counters + ablation knobs of the culled Chamfer scan (tools/probe/cull_report.sh, stats_tool.py, cull_knobs.sh, cull_pmc.sh)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fno-gpu-rdc -fno-slp-vectorize -DNN_CULL_STATS \
+    -I include -I geometrics_amd/csrc -shared geometrics_amd/csrc/chamfer_nn.hip -o tools/probe/libcullstats.so
