@@ -198,6 +198,35 @@ def test_culled_nn_ties_nan_inf_and_the_reference_vectors(oracle_mod, gpu):
         chamfer_nn_culled(_dev(a, gpu), _dev(c, gpu), torch.zeros(1, 3, dtype=torch.int32, device=gpu))
 
 
+def test_large_clouds_take_the_culled_scan_with_the_same_results(oracle_mod, gpu, monkeypatch):
+    """chamfer_nn / ChamferDistance dispatch clouds above AUTO_CULL_PAIRS to the culled scan (Morton orders made on the
+    device): same four tensors, bit for bit -- checked against the plain scan and the oracle with the threshold lowered."""
+    from geometrics_amd import chamfer_distance as cd
+    rng = np.random.default_rng(77)
+    a = rng.standard_normal((2, 2100, 3)).astype(np.float32)
+    c = rng.standard_normal((2, 1900, 3)).astype(np.float32)
+    c[:, 1000:1100] = c[:, :100]
+    plain = chamfer_nn(_dev(a, gpu), _dev(c, gpu))
+    calls = []
+    real = cd.chamfer_nn_culled
+    monkeypatch.setattr(cd, "chamfer_nn_culled", lambda *args, **kw: (calls.append(1), real(*args, **kw))[1])
+    monkeypatch.setattr(cd, "AUTO_CULL_PAIRS", 1_000_000)
+    auto = cd.chamfer_nn(_dev(a, gpu), _dev(c, gpu))
+    i1, i2 = ChamferDistance()(_dev(a, gpu), _dev(c, gpu))
+    assert len(calls) == 2
+    for x, y in zip(plain, auto):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    assert torch.equal(i1, plain[1]) and torch.equal(i2, plain[3])
+    e1, j1, e2, j2 = oracle_mod.chamfer_nn(a, c)
+    np.testing.assert_array_equal(auto[1].cpu().numpy(), j1)
+    np.testing.assert_array_equal(auto[2].cpu().numpy().view(np.uint32), e2.view(np.uint32))
+    calls.clear()
+    cd.chamfer_nn(_dev(a, gpu), _dev(c, gpu), FLAG_REF_TAIL_TRUNC)       # the truncation mode never dispatches
+    monkeypatch.setattr(cd, "AUTO_CULL_PAIRS", 0)
+    cd.chamfer_nn(_dev(a, gpu), _dev(c, gpu))
+    assert not calls
+
+
 def test_chamfer_module_contract(gpu):
     x = torch.rand(2, 100, 3, device=gpu, requires_grad=True)
     y = torch.rand(2, 80, 3, device=gpu)
