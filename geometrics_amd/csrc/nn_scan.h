@@ -174,15 +174,19 @@ __device__ __forceinline__ void nn_scalar_body(const NNJob &job, int bid, const 
 // (perm: visiting position -> original index), as a copy in that order -- whole runs of NNS_GROUP consecutive points stored
 // x[16] y[16] z[16], the ragged tail as xyz triples -- with a bounding sphere per run.  A tile is 64 consecutive queries of
 // the order, i.e. a compact patch, and the workgroup's eight waves hold the SAME 64 queries (lane <-> query):
-//   1. the run spheres of the target cloud go to LDS in one sweep; the run nearest to the patch centre and its seven
-//      neighbours in the order are the SEEDS: wave w evaluates one, the lanes share the best of the eight as their bound;
-//   2. wave w tests runs w, w+8, ... against every lane's own bound,
-//          |q - c_run|^2 > (s_q + R_run)^2  for every lane  =>  no target of the run can beat or tie any lane's best,
-//      s_q = sqrt(bound_q) and R_run with the margins of the culled triangle scan;
-//   3. the admitted runs (a few per wave) are fetched global -> LDS without passing through registers, all fetches of a
-//      batch in flight together, and evaluated with the brute-force scan's arithmetic -- two targets per packed
-//      instruction (v_pk_add/mul/fma_f32 are IEEE per component: the same bits) -- group minimum first, the exact index
-//      recovered once at the end.
+//   1. every load that depends on nothing goes out first (queries, the target cloud's run spheres -> LDS, the patch's own
+//      run spheres, the first target); the run nearest to the patch centre and its seven neighbours in the order are the
+//      SEEDS: wave w evaluates one, the lanes share the best of the eight as their bound;
+//   2. patch-level test, lane <-> run, 64 runs per step:  |c_run - c| > r_patch + max_q s_q + R_run  drops a run for every
+//      query at once (triangle inequality); the kept runs are dealt to the waves round-robin into per-wave pending lists;
+//   3. a wave's pending runs are fetched global -> LDS without passing through registers (LDS-DMA, five runs per
+//      instruction, all in flight), then each takes the lanes' own test
+//          |q - c_run|^2 > (s_q + R_run)^2  for every lane  =>  no target of the run can beat or tie any lane's best
+//      (s_q = sqrt(bound_q) and R_run with the margins of the culled triangle scan) and, if some lane admits
+//      it, the brute-force scan's arithmetic -- two targets per packed instruction (v_pk_add/mul/fma_f32 are IEEE per
+//      component: the same bits) -- group minimum first;
+//   4. closing phase, thread <-> (query, member of a run): the minimum over the waves' partial results and the exact
+//      original index inside the winning run(s).
 // Candidates are ordered lexicographically on (distance, ORIGINAL index) -- an exact tie between two runs takes a rare
 // slow path -- so the result is the brute-force scan's bit for bit for ANY visiting order; a bad order only costs speed.
 // NaN / inf: every comparison is written so that a NaN falls on the "evaluate" side; a run with a non-finite point has
