@@ -29,6 +29,18 @@ struct AdamStep {
     float t_old, b1t, b2t, step_size, bc2_sqrt;
 };
 
+// the step quantities from the published state st = {t, b1^t, b2^t} (LDS, after the barrier that published it)
+__device__ __forceinline__ AdamStep adam_step_from(const float *st, float lr, float b1, float b2)
+{
+    AdamStep a;
+    a.t_old = st[0];
+    a.b1t = a.t_old == 0.f ? b1 : st[1] * b1;
+    a.b2t = a.t_old == 0.f ? b2 : st[2] * b2;
+    a.step_size = lr / (1.f - a.b1t);
+    a.bc2_sqrt = sqrtf(1.f - a.b2t);
+    return a;
+}
+
 // The step state is read ONCE per workgroup, by the thread that later signs the workgroup's arrival, with agent-scope
 // atomic loads, and handed to the other threads through LDS (`st`, 3 floats): that thread's loads have RETURNED (their
 // values were stored to LDS in front of the barrier) before it can reach its arrival atomic -- the order "read the state,
@@ -41,13 +53,7 @@ __device__ __forceinline__ AdamStep adam_read_state(const float *state, float *s
         st[2] = __hip_atomic_load(state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    AdamStep a;
-    a.t_old = st[0];
-    a.b1t = a.t_old == 0.f ? b1 : st[1] * b1;
-    a.b2t = a.t_old == 0.f ? b2 : st[2] * b2;
-    a.step_size = lr / (1.f - a.b1t);
-    a.bc2_sqrt = sqrtf(1.f - a.b2t);
-    return a;
+    return adam_step_from(st, lr, b1, b2);
 }
 
 // Arrival tree (call with every thread of every workgroup of the launch, after the workgroup's last use of the state;

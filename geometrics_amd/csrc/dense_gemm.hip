@@ -800,9 +800,12 @@ struct ReduceJob {
     const float *part;
     float *out;
     int I, J, RA, CW, full_tiles, s_full, s_left; // rows beyond the full tiles: 16-row tiles of s_left splits each
+    int outs;                                     // outputs (of 4 columns) per workgroup, see reduce_outs()
 };
 struct ReduceJobs {
     ReduceJob job[GEOM_DENSE_MAX_REDUCE_JOBS];
+    int first[GEOM_DENSE_MAX_REDUCE_JOBS + 1]; // flat grid: job j owns workgroups [first[j], first[j + 1])
+    int n;
 };
 // Optional: the optimiser step on the gradients this launch finishes (geometrics_amd.optim.FusedAdam.fuse_into_backward):
 // job i's output IS the gradient of parameter p[i] (same [I, J] layout), so the thread that writes a gradient element also
@@ -812,28 +815,40 @@ struct ReduceAdam {
     float *p[GEOM_DENSE_MAX_REDUCE_JOBS], *m[GEOM_DENSE_MAX_REDUCE_JOBS], *v[GEOM_DENSE_MAX_REDUCE_JOBS]; // null: no update
     float lr, b1, b2, eps;
     float *state; // null: no optimiser step in this launch
-    // workgroups that hold outputs ("active"): only they read the step state and sign the arrival tree.  active_first[j] =
-    // active workgroups of the jobs before j (their dense index), n_active = all of them
-    int active_first[GEOM_DENSE_MAX_REDUCE_JOBS + 1];
+    int vec;      // every p / m / v pointer is 16-byte aligned: float4 accesses
 };
 
-// 32 outputs (of 4 columns) x 8 slot groups per workgroup: group sg adds its contiguous share of the slots in slot order
-// (four loads in flight), the group sums are then added in group order -- a fixed tree for a given (I, J, splits).  Jobs
-// with a single output row and many slots (column sums: the bias gradients, 1 288 partial rows at the BASELINE shard) take
-// 4 outputs x 64 groups instead, so that the slot dimension is what the threads share.
-constexpr int RED_THREADS = 256, RED_OUT = 32;
+// `outs` outputs (of 4 columns) x 256 / outs slot groups per workgroup: group sg adds its contiguous share of the slots in
+// slot order (eight loads in flight), the group sums are then added in group order -- a fixed tree for a given (I, J,
+// splits).  The more slots a job has, the more groups share them (reduce_outs): 64 x 4 for the 25 splits of the 963-wide
+// layer, 16 x 16 for the 128 splits of a 192-wide one (whose 19 MB of partial tiles used to hang on 144 workgroups of 32-deep
+// serial sums: 6.6 us alone against 3.9 for the first layer's), 4 x 64 for the 1 288 partial rows of a bias gradient.
+constexpr int RED_THREADS = 256;
+inline int reduce_outs(int slots) { return slots <= 32 ? 64 : slots <= 64 ? 32 : slots <= 128 ? 16 : slots <= 256 ? 8 : 4; }
 __global__ __launch_bounds__(RED_THREADS) void dense_reduce_kernel(ReduceJobs jobs, ReduceAdam adam)
 {
     __shared__ f32x4 part[RED_THREADS];
     __shared__ float st[3];
-    const ReduceJob q = jobs.job[blockIdx.y];
+    // flat grid: every workgroup holds outputs (a job smaller than the largest one used to leave whole workgroups idle:
+    // 5 800 of 8 670 at the BASELINE shard)
+    int jb = 0;
+    while (jb + 1 < jobs.n && (int)blockIdx.x >= jobs.first[jb + 1]) ++jb;
+    const ReduceJob q = jobs.job[jb];
+    const int bx = blockIdx.x - jobs.first[jb];
     const int jq = q.J >> 2;
-    const int outs = q.I == 1 ? 4 : RED_OUT, groups = RED_THREADS / outs;
-    if ((int)blockIdx.x * outs >= q.I * jq) return; // a job smaller than the largest one leaves whole workgroups idle
-    geom::AdamStep as{};
-    if (adam.state) as = geom::adam_read_state(adam.state, st, adam.lr, adam.b1, adam.b2); // uniform per workgroup
+    const int outs = q.outs, groups = RED_THREADS / outs;
+    // the optimiser's step state is REQUESTED first and published to the workgroup at the barrier the partial sums need
+    // anyway: its round trip rides under theirs.  (Thread 0 -- the one that signs the arrival at the end -- reads it with
+    // agent-scope atomic loads and stores it to LDS in front of that barrier: "read the state, then arrive" stays a data
+    // dependency, adam_math.h.)
+    float s_t = 0.f, s_b1 = 0.f, s_b2 = 0.f;
+    if (adam.state && threadIdx.x == 0) {
+        s_t = __hip_atomic_load(adam.state + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_b1 = __hip_atomic_load(adam.state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_b2 = __hip_atomic_load(adam.state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const int o = threadIdx.x % outs, sg = threadIdx.x / outs;
-    const int e = blockIdx.x * outs + o;
+    const int e = bx * outs + o;
     const bool live = e < q.I * jq;
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
     int i = 0, j = 0;
@@ -850,40 +865,62 @@ __global__ __launch_bounds__(RED_THREADS) void dense_reduce_kernel(ReduceJobs jo
         const int64_t pitch = (int64_t)q.RA * q.CW;
         const float *p = q.part + ((int64_t)slot0 * q.RA + il) * q.CW + j;
         const int s0 = (int)((int64_t)n * sg / groups), s1 = (int)((int64_t)n * (sg + 1) / groups);
-        int s = s0;
-        for (; s + 4 <= s1; s += 4) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(p + (s + 0) * pitch);
-            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(p + (s + 1) * pitch);
-            const f32x4 a2 = *reinterpret_cast<const f32x4 *>(p + (s + 2) * pitch);
-            const f32x4 a3 = *reinterpret_cast<const f32x4 *>(p + (s + 3) * pitch);
-            t = (((t + a0) + a1) + a2) + a3;
+        // eight loads in flight per round (a group's share of the slots is 3-7 here: ONE round trip), added in slot order
+        for (int s = s0; s < s1; s += 8) {
+            f32x4 a[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (s + k < s1) a[k] = *reinterpret_cast<const f32x4 *>(p + (int64_t)(s + k) * pitch);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (s + k < s1) t = t + a[k];
         }
-        for (; s < s1; ++s) t = t + *reinterpret_cast<const f32x4 *>(p + s * pitch);
+    }
+    // the parameter and its moments (16 bytes at a time) are requested in front of the barrier as well
+    const int64_t at = (int64_t)i * q.J + j;
+    float *pp = adam.state ? adam.p[jb] : nullptr;
+    const bool vec = pp && adam.vec;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, bm = a, cv = a;
+    if (vec && sg == 0 && live) {
+        a = *reinterpret_cast<const f32x4 *>(pp + at);
+        bm = *reinterpret_cast<const f32x4 *>(adam.m[jb] + at);
+        cv = *reinterpret_cast<const f32x4 *>(adam.v[jb] + at);
     }
     part[sg * outs + o] = t;
+    if (adam.state && threadIdx.x == 0) st[0] = s_t, st[1] = s_b1, st[2] = s_b2;
     __syncthreads();
+    geom::AdamStep as{};
+    if (adam.state) as = geom::adam_step_from(st, adam.lr, adam.b1, adam.b2); // uniform per workgroup
     if (sg == 0 && live) {
         f32x4 r = part[o];
         for (int k = 1; k < groups; ++k) r = r + part[k * outs + o];
-        const int64_t at = (int64_t)i * q.J + j;
         float *dst = q.out + at;
-        dst[0] = r[0], dst[1] = r[1], dst[2] = r[2], dst[3] = r[3];
-        float *pp = adam.state ? adam.p[blockIdx.y] : nullptr;
-        if (pp) {
-            float *pm = adam.m[blockIdx.y] + at, *pv = adam.v[blockIdx.y] + at;
-            pp += at;
+        if (vec) {
+            f32x4 *p4 = reinterpret_cast<f32x4 *>(pp + at), *m4 = reinterpret_cast<f32x4 *>(adam.m[jb] + at),
+                  *v4 = reinterpret_cast<f32x4 *>(adam.v[jb] + at);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float a = pp[k], b = pm[k], c = pv[k];
-                geom::adam_update(a, r[k], b, c, adam.b1, adam.b2, adam.eps, 1.f, as.step_size, as.bc2_sqrt);
-                pm[k] = b, pv[k] = c, pp[k] = a;
+                float pa = a[k], pb = bm[k], pc = cv[k];
+                geom::adam_update(pa, r[k], pb, pc, adam.b1, adam.b2, adam.eps, 1.f, as.step_size, as.bc2_sqrt);
+                a[k] = pa, bm[k] = pb, cv[k] = pc;
+            }
+            *reinterpret_cast<f32x4 *>(dst) = r;
+            *m4 = bm, *v4 = cv, *p4 = a;
+        } else {
+            dst[0] = r[0], dst[1] = r[1], dst[2] = r[2], dst[3] = r[3];
+            if (pp) {
+                float *pm = adam.m[jb] + at, *pv = adam.v[jb] + at;
+                pp += at;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float a = pp[k], b = pm[k], c = pv[k];
+                    geom::adam_update(a, r[k], b, c, adam.b1, adam.b2, adam.eps, 1.f, as.step_size, as.bc2_sqrt);
+                    pm[k] = b, pv[k] = c, pp[k] = a;
+                }
             }
         }
     }
-    if (adam.state) {
-        const int nj = gridDim.y;
-        geom::adam_arrive(adam.state, as, adam.active_first[blockIdx.y] + blockIdx.x, adam.active_first[nj]);
-    }
+    if (adam.state) geom::adam_arrive(adam.state, as, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1064,6 +1101,18 @@ extern "C" int geom_dense_bwd_f32(int rows, int cin, int c, const float *x, cons
 }
 
 namespace {
+// flat grid of dense_reduce_kernel: only workgroups that hold outputs are launched
+void flat_grid(ReduceJobs &jobs, int n)
+{
+    jobs.n = n;
+    jobs.first[0] = 0;
+    for (int j = 0; j < n; ++j) {
+        ReduceJob &q = jobs.job[j];
+        q.outs = reduce_outs(q.s_full > q.s_left ? q.s_full : q.s_left);
+        jobs.first[j + 1] = jobs.first[j] + (q.I * (q.J >> 2) + q.outs - 1) / q.outs;
+    }
+}
+
 // the jobs of geom_dense_reduce2_f32 / geom_dense_reduce_adam_f32: weight gradients first (job l = layer l), then the
 // column-sum jobs (job count + i)
 int build_reduce_jobs(ReduceJobs &jobs, int &n, int &widest, int count, const int *rows, const int *cin, const int *c,
@@ -1078,14 +1127,14 @@ int build_reduce_jobs(ReduceJobs &jobs, int &n, int &widest, int count, const in
     for (int l = 0; l < count; ++l) {
         if (!workspaces[l] || !grad_w[l] || rows[l] <= 0 || cin[l] <= 0 || c[l] <= 0 || c[l] > 192 || c[l] % 4) return GEOM_EINVAL;
         const SplitGeo g = split_geometry(cin[l], rows[l], num_cus());
-        jobs.job[n++] = ReduceJob{workspaces[l], grad_w[l], cin[l], c[l], SPLIT_RB * 16, 192, g.full_tiles, g.s_full, g.s_left};
+        jobs.job[n++] = ReduceJob{workspaces[l], grad_w[l], cin[l], c[l], SPLIT_RB * 16, 192, g.full_tiles, g.s_full, g.s_left, 0};
         widest = cin[l] * (c[l] / 4) > widest ? cin[l] * (c[l] / 4) : widest;
     }
     for (int i = 0; i < ncs; ++i) {
         if (!cs_partials[i] || !cs_outs[i] || cs_rows[i] < 0 || cs_cols[i] <= 0 || cs_cols[i] % 4) return GEOM_EINVAL;
-        jobs.job[n++] = ReduceJob{cs_partials[i], cs_outs[i], 1, cs_cols[i], 1, cs_cols[i], 1, cs_rows[i], 0};
-        widest = cs_cols[i] / 4 * (RED_OUT / 4) > widest ? cs_cols[i] / 4 * (RED_OUT / 4) : widest; // 4 outputs per workgroup
+        jobs.job[n++] = ReduceJob{cs_partials[i], cs_outs[i], 1, cs_cols[i], 1, cs_cols[i], 1, cs_rows[i], 0, 0};
     }
+    flat_grid(jobs, n);
     return 0;
 }
 } // namespace
@@ -1105,8 +1154,7 @@ extern "C" int geom_dense_reduce2_f32(int count, const int *rows, const int *cin
     const int code = build_reduce_jobs(jobs, n, widest, count, rows, cin, c, workspaces, grad_w, ncs, cs_partials, cs_rows, cs_cols, cs_outs);
     if (code) return code;
     ReduceAdam adam{};
-    hipLaunchKernelGGL(dense_reduce_kernel, dim3((widest + RED_OUT - 1) / RED_OUT, n), dim3(RED_THREADS), 0,
-                       static_cast<hipStream_t>(stream), jobs, adam);
+    hipLaunchKernelGGL(dense_reduce_kernel, dim3(jobs.first[n]), dim3(RED_THREADS), 0, static_cast<hipStream_t>(stream), jobs, adam);
     return geom::launch_status();
 }
 
@@ -1138,13 +1186,11 @@ extern "C" int geom_dense_reduce_adam_f32(int count, const int *rows, const int 
         if (b_p[i] && (!b_m[i] || !b_v[i])) return GEOM_EINVAL;
     }
     adam.lr = lr, adam.b1 = beta1, adam.b2 = beta2, adam.eps = eps, adam.state = state;
-    adam.active_first[0] = 0;
-    for (int j = 0; j < n; ++j) {
-        const int outs = jobs.job[j].I == 1 ? 4 : RED_OUT;
-        adam.active_first[j + 1] = adam.active_first[j] + (jobs.job[j].I * (jobs.job[j].J >> 2) + outs - 1) / outs;
-    }
-    hipLaunchKernelGGL(dense_reduce_kernel, dim3((widest + RED_OUT - 1) / RED_OUT, n), dim3(RED_THREADS), 0,
-                       static_cast<hipStream_t>(stream), jobs, adam);
+    uintptr_t bits = 0;
+    for (int j = 0; j < n; ++j)
+        if (adam.p[j]) bits |= (uintptr_t)adam.p[j] | (uintptr_t)adam.m[j] | (uintptr_t)adam.v[j] | (uintptr_t)jobs.job[j].out;
+    adam.vec = (bits & 15) == 0;
+    hipLaunchKernelGGL(dense_reduce_kernel, dim3(jobs.first[n]), dim3(RED_THREADS), 0, static_cast<hipStream_t>(stream), jobs, adam);
     return geom::launch_status();
 }
 
@@ -1160,15 +1206,16 @@ extern "C" int geom_dense_reduce_f32(int count, const int *rows, const int *cin,
     for (int l = 0; l < count; ++l) {
         if (!workspaces[l] || !grad_w[l] || rows[l] <= 0 || cin[l] <= 0 || c[l] <= 0 || c[l] > 192 || c[l] % 4) return GEOM_EINVAL;
         const SplitGeo g = split_geometry(cin[l], rows[l], num_cus());
-        jobs.job[n++] = ReduceJob{workspaces[l], grad_w[l], cin[l], c[l], SPLIT_RB * 16, 192, g.full_tiles, g.s_full, g.s_left};
+        jobs.job[n++] = ReduceJob{workspaces[l], grad_w[l], cin[l], c[l], SPLIT_RB * 16, 192, g.full_tiles, g.s_full, g.s_left, 0};
         widest = cin[l] * (c[l] / 4) > widest ? cin[l] * (c[l] / 4) : widest;
         if (grad_bias && grad_bias[l]) { // column sums: a 1-row "tile" per split, pitch = c
             if (g.full_tiles == 0) return GEOM_EUNSUPPORTED;
             jobs.job[n++] = ReduceJob{workspaces[l] + (int64_t)g.slots * SPLIT_RB * 16 * 192, grad_bias[l], 1, c[l], 1, c[l], 1,
-                                      g.s_full, 0};
+                                      g.s_full, 0, 0};
         }
     }
-    hipLaunchKernelGGL(dense_reduce_kernel, dim3((widest + RED_OUT - 1) / RED_OUT, n), dim3(RED_THREADS), 0,
-                       static_cast<hipStream_t>(stream), jobs, ReduceAdam{});
+    flat_grid(jobs, n);
+    hipLaunchKernelGGL(dense_reduce_kernel, dim3(jobs.first[n]), dim3(RED_THREADS), 0, static_cast<hipStream_t>(stream), jobs,
+                       ReduceAdam{});
     return geom::launch_status();
 }
