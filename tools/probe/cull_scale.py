@@ -1,5 +1,7 @@
-import sys, time, torch, numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+"""Culled against brute-force Chamfer scan over cloud sizes (python wall time per call).  GPU box only."""
+import os, sys, time, torch, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from geometrics_amd import meshgen
 from geometrics_amd.chamfer_distance import chamfer_nn, chamfer_nn_culled
 from geometrics_amd.tri_distance import morton_order

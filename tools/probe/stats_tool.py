@@ -1,9 +1,12 @@
+"""Counters and ablation timings of the culled Chamfer scan from the probe build (tools/probe/libcullstats.so =
+chamfer_nn.hip with -DNN_CULL_STATS, tools/probe/run_probes.sh).  GPU box only."""
 import ctypes, os, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch, numpy as np
 import time_culled_nn as T
 from geometrics_amd import _lib, meshgen
-L = ctypes.CDLL("/root/repo/tools/probe/libcullstats.so")
+L = ctypes.CDLL(os.path.join(ROOT, "tools", "probe", "libcullstats.so"))
 dev = torch.device("cuda:0")
 b, n = 8, 3000
 gt = torch.from_numpy(meshgen.gt_cloud(b, n)).to(dev)
