@@ -165,8 +165,8 @@ def settle_clocks(dev, ms):
     """Device conditioning in front of the W warm-up steps: `ms` milliseconds of a neutral library GEMM (NOT the workload).
     The chip leaves its idle power state over the first ~100 ms of load -- the setup in front of the timed region (mesh
     generation, eager capture steps) leaves it idle -- and a K = 20, W = 5 run (15 ms of GPU time) is otherwise timed on
-    the ramp: measured on one box, ms per step at K = 20 / W = 5: 0.536 without, 0.514 after 20 ms, 0.497 after 100 ms,
-    0.497 after 500 ms; steady state (K = 200, W = 20) 0.498.  0 switches it off."""
+    the ramp: measured on one box, ms per step at K = 20 / W = 5: 0.4935 without, 0.4749 after 20 ms, 0.4561 after 100 ms,
+    0.4559 after 250 ms; steady state (K = 200, W = 20) 0.4550.  0 switches it off."""
     if ms <= 0:
         return
     a = torch.randn(4096, 4096, device=dev)

@@ -101,6 +101,23 @@ def ptr(t):
 _lib = None
 
 
+def _refuse_stale_library():
+    """A library built from OTHER kernel sources than the ones on disk (an edit or a checkout without a rebuild) would run
+    silently -- wrong numbers in every profile taken with it.  The build stamps the library with the digest of its sources;
+    a mismatch is an error (GEOM_ALLOW_STALE_LIB=1 to load it anyway).  No stamp or no sources on disk: nothing to compare."""
+    if os.environ.get("GEOM_ALLOW_STALE_LIB"):
+        return
+    try:
+        from . import build
+        built = build.built_digest()
+        current = build.source_digest() if built else None
+    except Exception:        # an installation without the sources
+        return
+    if built and current and built != current:
+        raise RuntimeError("geometrics_amd: %s was built from other kernel sources than the ones on disk -- rebuild it with "
+                           "`python -m geometrics_amd.build` (or set GEOM_ALLOW_STALE_LIB=1)" % LIB_PATH)
+
+
 def lib():
     """The loaded library; raises RuntimeError when it has not been built."""
     global _lib
@@ -109,6 +126,7 @@ def lib():
             raise RuntimeError(
                 "geometrics_amd: %s is missing -- build it with `python -m geometrics_amd.build` "
                 "(hipcc, gfx950). There is no CPU/PyTorch fallback." % LIB_PATH)
+        _refuse_stale_library()
         L = ctypes.CDLL(LIB_PATH)
         L.geom_abi_version.restype = _i
         L.geom_strerror.restype = ctypes.c_char_p

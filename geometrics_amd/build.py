@@ -15,6 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgeom_hip.so")
+STAMP = os.path.join(LIBDIR, "libgeom_hip.digest")      # sha256 of the sources the library was built from (build artefact)
 SHIM = os.path.join(LIBDIR, "geom_torch_shim.so")       # pybind `forward_cuda` entry points on top of the C ABI
 SHIM_SRC = os.path.join(CSRC, "torch_shim.cpp")
 
@@ -48,6 +49,8 @@ def source_digest():
 
 def _stale():
     if not os.path.exists(LIB):
+        return True
+    if built_digest() not in (None, source_digest()):   # sources changed back and forth (a checkout): mtimes do not tell
         return True
     t = os.path.getmtime(LIB)
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
@@ -104,7 +107,18 @@ def build_lib(force=False, verbose=False):
             print(out.decode(errors="replace"))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", LIB]
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:      # what the library was built from: the loader refuses a library older than its sources
+        f.write(source_digest() + "\n")
     return LIB
+
+
+def built_digest():
+    """Digest of the sources the library on disk was built from (None: no stamp, e.g. a library built by other means)."""
+    try:
+        with open(STAMP) as f:
+            return f.read().strip() or None
+    except OSError:
+        return None
 
 
 if __name__ == "__main__":

@@ -174,6 +174,22 @@ def test_compiled_forward_cuda_shim_loads_and_validates():
         _shim.tri.forward_cuda(z, z, z, z, torch.zeros(1, 2), i, i)
 
 
+def test_a_library_built_from_other_sources_is_refused(monkeypatch):
+    """The loader compares the digest the build stamped the library with against the kernel sources on disk: an edit or
+    a checkout without a rebuild must not run silently (it did once: a whole set of timings taken with a stale kernel)."""
+    from geometrics_amd import build
+    assert build.built_digest() == build.source_digest()            # the library under test is the current one
+    _lib._refuse_stale_library()
+    monkeypatch.setattr(build, "built_digest", lambda: "0" * 64)
+    with pytest.raises(RuntimeError, match="rebuild"):
+        _lib._refuse_stale_library()
+    monkeypatch.setenv("GEOM_ALLOW_STALE_LIB", "1")
+    _lib._refuse_stale_library()
+    monkeypatch.delenv("GEOM_ALLOW_STALE_LIB")
+    monkeypatch.setattr(build, "built_digest", lambda: None)        # no stamp: nothing to compare
+    _lib._refuse_stale_library()
+
+
 def test_culled_chamfer_entry_points_validate_before_launching():
     """geom_nn_cull_index_* / geom_chamfer_nn_culled_*: sizes of the index (run spheres + the cloud in rows of whole runs,
     16-byte aligned), argument checks, empty batches -- nothing here reaches a launch."""
