@@ -68,13 +68,25 @@ def weight_workspace(rows, cin, c, device):
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
+# bench.py: a list; while it is set every weight-partial launch is bracketed by HIP events on its stream and appends
+# (rows, cin, c, start, end) -- the launch timed where it runs, inside a step
+launch_probe = None
+
+
 def backward_weight_partials(x, g, workspace, want_colsum=False):
     """Per-split partial tiles of x.T @ g (and of g's column sums) into `workspace`; `reduce` finishes them."""
     rows, cin = x.shape
     c = g.shape[1]
+    probe = launch_probe
     with torch.cuda.device(x.device):
+        if probe is not None:
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
         _lib.call("geom_dense_bwd_weight_f32", rows, cin, c, x.data_ptr(), g.data_ptr(), workspace.data_ptr(),
                   1 if want_colsum else 0)
+        if probe is not None:
+            end.record()
+            probe.append((rows, cin, c, start, end))
 
 
 def backward_pair(x, g, w, grad_x, workspace, want_colsum=False):
