@@ -35,6 +35,7 @@ from geometrics_amd.chamfer_distance import chamfer_nn  # noqa: E402
 from geometrics_amd.tri_distance import tri_distance_indexed  # noqa: E402
 
 V_LEVEL, S_PTS, G_PTS, FEAT, HID = 4, 3000, 3000, 963, 192
+EAGER_DP_UPDATE = bool(int(os.environ.get("GEOM_EAGER_DP_UPDATE", "1")))   # N > 1: Adam launched eagerly behind the all-reduce (0: as a second graph)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector peak == f32 MFMA dense peak
 
@@ -69,8 +70,11 @@ class Workload:
         # the only way to run the RCCL collective between the two graph replays on a single-GPU box
         self.dp = self.world > 1 or force_dp
         # flat DP bucket: all gradients + [loss_sum, mesh_count] -> exactly one all-reduce per step
-        self.bucket = gdist.GradBucket(self.stack.parameters(), extra=2, force_collective=force_dp) if self.dp else None
+        self.bucket = gdist.GradBucket(self.stack.parameters(), extra=2, force_collective=force_dp, bind=True) if self.dp else None
         self.count = torch.full((), float(batch), device=dev)
+        # [loss_sum, mesh_count] of the shard = base + loss * scale: one launch writes both trailing scalars of the bucket
+        self.extra_scale = torch.tensor([float(batch), 0.0], device=dev)
+        self.extra_base = torch.tensor([0.0, float(batch)], device=dev)
         self.seed_grad = torch.ones((), device=dev)
         self.rng = ops.manual_seed(seed, dev, mesh_offset=first_mesh)   # sampler keyed on the GLOBAL mesh index: N shards draw what one process would
         # GEOMetrics.py:73 (Adam, lr 1e-4): every parameter tensor in one launch, step count on the device
@@ -101,7 +105,11 @@ class Workload:
             self.loss = utils.batch_point_to_surface(pos, self.info, self.gt, num=S_PTS)
             self.loss.backward(self.seed_grad)              # explicit seed: no ones_like fill launch
         if self.dp:
-            self.bucket.pack(self.loss.detach() * self.batch, self.count)
+            if self.bucket.bound:       # the gradients are in the bucket already (layers.bind_gradient_targets)
+                self.bucket.pack()
+                torch.addcmul(self.extra_base, self.loss.detach().expand(2), self.extra_scale, out=self.bucket.extra)
+            else:
+                self.bucket.pack(self.loss.detach() * self.batch, self.count)
 
     def exchange(self):
         if self.dp:
@@ -125,8 +133,9 @@ class Workload:
 
     def capture(self, warm=3):
         """Record the step into HIP graphs so that no python runs between its ~45 launches (library
-        GEMMs, our C-ABI kernels, fused Adam).  N=1: one graph.  N>1: graph A = forward + backward +
-        bucket pack, then the single all-reduce issued eagerly on the same stream, then graph B = Adam
+        GEMMs, our C-ABI kernels, fused Adam).  N=1: one graph.  N>1: graph A = forward + backward (the
+        gradients land in the bucket) + the bucket's two scalars, then the single all-reduce issued eagerly on the same
+        stream, then Adam -- one launch, issued eagerly too (GEOM_EAGER_DP_UPDATE=0: as a second graph B)
         -- the collective stays outside the captured region, so nothing depends on RCCL's
         graph-capture support."""
         side = torch.cuda.Stream()
@@ -142,13 +151,17 @@ class Workload:
                 self.step()
             self.graphs = (g,)
         else:
-            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga):
                 self.forward_backward()
             self.exchange()
-            with torch.cuda.graph(gb, pool=ga.pool()):
-                self.update()
-            self.graphs = (ga, gb)
+            if EAGER_DP_UPDATE:          # the update is ONE launch: issued eagerly behind the collective, every step
+                self.graphs = (ga, None)
+            else:
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, pool=ga.pool()):
+                    self.update()
+                self.graphs = (ga, gb)
 
     def run(self):
         if self.graphs is None:
@@ -158,7 +171,10 @@ class Workload:
         else:
             self.graphs[0].replay()
             self.exchange()
-            self.graphs[1].replay()
+            if self.graphs[1] is None:
+                self.update()
+            else:
+                self.graphs[1].replay()
 
 
 def settle_clocks(dev, ms):

@@ -60,7 +60,7 @@ class GradBucket:
     `all_reduce()` sums the buffer across ranks, `views` are per-parameter views of the reduced buffer
     (the 1/world scale is applied inside the optimiser kernel)."""
 
-    def __init__(self, params, extra=0, force_collective=False):
+    def __init__(self, params, extra=0, force_collective=False, bind=False):
         self.force = force_collective
         self.params = [p for p in params if p.requires_grad]
         ref = self.params[0]
@@ -71,10 +71,25 @@ class GradBucket:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.extra = self.flat[self.numel:]
+        # bind=True: the layers' gradient launches write straight into the views (layers.bind_gradient_targets), so that
+        # pack() only has to place the trailing scalars and whatever gradient did not come from those launches
+        self.bound = bool(bind)
+        if bind:
+            from . import layers
+            layers.bind_gradient_targets(self.params, self.views)
 
     def pack(self, *scalars):
-        parts = [p.grad.reshape(-1) for p in self.params] + [s.reshape(1).to(self.flat.dtype) for s in scalars]
-        torch.cat(parts, out=self.flat)
+        if not self.bound:
+            parts = [p.grad.reshape(-1) for p in self.params] + [s.reshape(1).to(self.flat.dtype) for s in scalars]
+            torch.cat(parts, out=self.flat)
+            return self.flat
+        for p, view in zip(self.params, self.views):
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != view.data_ptr():       # produced elsewhere (a library fallback): gather it
+                view.copy_(p.grad)
+        if scalars:
+            torch.stack([s.reshape(()).to(self.flat.dtype) for s in scalars], out=self.extra[:len(scalars)])
         return self.flat
 
     def all_reduce(self):

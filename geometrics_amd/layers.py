@@ -181,6 +181,33 @@ def aggregate_forward(s, bias_c, csr, k, act, out, want_mask=False):
 # `_zero_fill_deferred` is set (debugging aid: detect_anomaly trips over uninitialised memory otherwise).
 defer_parameter_gradients = False     # False: every bias / weight gradient is reduced where it is produced
 _zero_fill_deferred = False
+
+# Gradient targets (data-parallel steps: geometrics_amd.dist.GradBucket(bind=True)): a parameter bound to a tensor of its
+# shape gets its gradient WRITTEN THERE by the launches of this module -- the reduction launch at the end of the pass writes
+# straight into the flat all-reduce bucket, autograd adopts the tensor as `.grad` (a fresh, contiguous tensor object of
+# the parameter's layout is taken as is, not copied), and the bucket's pack launch has nothing left to gather.
+_gradient_targets = {}
+
+
+def bind_gradient_targets(params, tensors):
+    """`tensors[i]` (same shape / dtype / device as `params[i]`, contiguous) receives the gradient of `params[i]` from now on;
+    None unbinds.  Only gradients this module produces itself land there (a library-product fallback returns its own tensor)."""
+    for p, t in zip(params, tensors):
+        key = id(p)
+        if t is None:
+            _gradient_targets.pop(key, None)
+            continue
+        if t.shape != p.shape or t.dtype != p.dtype or t.device != p.device or not t.is_contiguous():
+            raise ValueError("a gradient target must match its parameter's shape, dtype and device and be contiguous")
+        _gradient_targets[key] = (weakref.ref(p, lambda _r, k=key: _gradient_targets.pop(k, None)), t)
+
+
+def _gradient_buffer(param, like):
+    """Where the gradient of `param` (may be None: unknown) goes: its bound target, else a new tensor like `like`."""
+    hit = _gradient_targets.get(id(param)) if param is not None else None
+    if hit is not None and hit[0]() is param and hit[1].shape == like.shape:
+        return hit[1].detach()           # a fresh tensor object over the target's memory (autograd adopts it as .grad)
+    return torch.zeros_like(like) if _zero_fill_deferred else torch.empty_like(like)
 use_matrix_core_products = True       # the layers' dense gradients on csrc/dense_gemm.hip where dense.plan says so
 
 
@@ -359,7 +386,8 @@ def aggregate_backward(g, csr, k, act, out, mask, want_bias, bias=None, arena=No
     grad_bias = scratch = None
     defer = False
     if want_bias:   # column sums of g come out of the same kernel (per-block partials + fixed-order reduce)
-        grad_bias = torch.empty(c, dtype=torch.float32, device=g.device)
+        grad_bias = _gradient_buffer(bias, bias) if bias is not None and bias.shape == (c,) and bias.dtype == torch.float32 \
+            else torch.empty(c, dtype=torch.float32, device=g.device)
         scratch = torch.empty(_lib.lib().geom_zn_gcn_bwd_scratch_floats(b, nv, c), dtype=torch.float32,
                               device=g.device)
         defer = _may_defer(bias, opted_in=arena is not None)
@@ -464,7 +492,8 @@ class _ZeroNAggregateHead(torch.autograd.Function):
         defer = False
         bias = ctx.bias_ref() if ctx.bias_ref is not None else None
         if ctx.needs_input_grad[1] and ctx.bias_ref is not None:
-            grad_bias = torch.empty(c, dtype=torch.float32, device=gp.device)
+            grad_bias = _gradient_buffer(bias, bias) if bias is not None and bias.shape == (c,) and bias.dtype == torch.float32 \
+                else torch.empty(c, dtype=torch.float32, device=gp.device)
             scratch = torch.empty(_lib.lib().geom_zn_gcn_bwd_scratch_floats(b, nv, c), dtype=torch.float32, device=gp.device)
             defer = _may_defer(bias)
         over = csr.over_t or (None, None, None)
@@ -717,8 +746,8 @@ class _DenseMM(torch.autograd.Function):
             if need_x:
                 grad_x = torch.matmul(g2, w2.t()).view(x.shape)
             _dense_kernels.backward_weight_partials(x2, g2, ws)
-        grad_w = torch.zeros_like(w) if _zero_fill_deferred else torch.empty_like(w)
         param = ctx.w_ref()
+        grad_w = _gradient_buffer(param, w)
         if param is not None and _may_defer(param):
             task = torch._C._current_graph_task_id()
             jobs = _pending_reduce.get(task)

@@ -174,6 +174,28 @@ def test_compiled_forward_cuda_shim_loads_and_validates():
         _shim.tri.forward_cuda(z, z, z, z, torch.zeros(1, 2), i, i)
 
 
+def test_bound_gradient_bucket_gathers_only_what_did_not_land_in_it():
+    """dist.GradBucket(bind=True): the per-parameter views are registered as gradient targets (the layers' launches write
+    there and autograd adopts the tensor); pack() then copies only gradients that were produced elsewhere, zero-fills a
+    missing one, and places the trailing scalars."""
+    import torch
+    from geometrics_amd import dist as gdist, layers
+    a, b = torch.nn.Parameter(torch.zeros(2, 3)), torch.nn.Parameter(torch.zeros(4))
+    c = torch.nn.Parameter(torch.zeros(5))
+    bucket = gdist.GradBucket([a, b, c], extra=2, bind=True)
+    assert layers._gradient_buffer(a, a).data_ptr() == bucket.views[0].data_ptr()       # a launch would write here
+    assert layers._gradient_buffer(None, a).data_ptr() != bucket.views[0].data_ptr()
+    a.grad = bucket.views[0].detach()              # what autograd does with the tensor a backward returned
+    a.grad.fill_(1.5)
+    b.grad = torch.full((4,), 2.5)                 # a gradient from somewhere else (library fallback)
+    flat = bucket.pack(torch.tensor(7.0), torch.tensor(8.0))
+    assert flat.tolist() == [1.5] * 6 + [2.5] * 4 + [0.0] * 5 + [7.0, 8.0]
+    with pytest.raises(ValueError):
+        layers.bind_gradient_targets([a], [torch.zeros(3, 2)])
+    layers.bind_gradient_targets([a, b, c], [None, None, None])
+    assert layers._gradient_buffer(a, a).data_ptr() != bucket.views[0].data_ptr()
+
+
 def test_a_library_built_from_other_sources_is_refused(monkeypatch):
     """The loader compares the digest the build stamped the library with against the kernel sources on disk: an edit or
     a checkout without a rebuild must not run silently (it did once: a whole set of timings taken with a stale kernel)."""

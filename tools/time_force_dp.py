@@ -1,5 +1,5 @@
-"""The N > 1 step sequence on ONE GPU (1-rank RCCL group): graph A (forward + backward + bucket pack) -> eager all-reduce of
-the flat bucket -> graph B (Adam on the bucket).  Prints ms per step beside the N = 1 single-graph step -- the fixed cost the
+"""The N > 1 step sequence on ONE GPU (1-rank RCCL group): graph A (forward + backward into the bucket) -> eager all-reduce of
+the flat bucket -> Adam on the bucket (eager launch; GEOM_EAGER_DP_UPDATE=0: graph B).  Prints ms per step beside the N = 1 single-graph step -- the fixed cost the
 data-parallel path adds before any link time.  GPU box only:  python tools/time_force_dp.py"""
 import os
 import sys
@@ -19,5 +19,5 @@ for force in (False, True):
     wl = bench.Workload(dev, 0, 8, force_dp=force)
     wl.capture()
     t = bench.time_steps(wl.run, 300, 30)
-    print("force_dp=%s: %d graph(s), %.4f ms per step" % (force, len(wl.graphs), t / 300 * 1e3), flush=True)
+    print("force_dp=%s: %d graph(s), %.4f ms per step" % (force, sum(g is not None for g in wl.graphs), t / 300 * 1e3), flush=True)
 torch.distributed.destroy_process_group()
