@@ -711,7 +711,8 @@ def main():
             torch.cuda.synchronize()
             from geometrics_amd import _lib
             _lib.clear_hip_error()
-    settle_clocks(dev, args.clock_warmup_ms)
+    gdist.barrier()          # ranks finish their setup at different times: condition the devices together, so that
+    settle_clocks(dev, args.clock_warmup_ms)   # nobody idles at the barrier in front of the timed region and cools down again
     elapsed = time_steps(w.run, args.steps, args.warmup)
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
