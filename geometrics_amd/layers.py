@@ -205,7 +205,9 @@ def bind_gradient_targets(params, tensors):
 def _gradient_buffer(param, like):
     """Where the gradient of `param` (may be None: unknown) goes: its bound target, else a new tensor like `like`."""
     hit = _gradient_targets.get(id(param)) if param is not None else None
-    if hit is not None and hit[0]() is param and hit[1].shape == like.shape:
+    # (a parameter that already holds a gradient is being ACCUMULATED into: the new gradient must not overwrite the old one's
+    # memory, which is what the target is by then)
+    if hit is not None and hit[0]() is param and hit[1].shape == like.shape and param.grad is None:
         return hit[1].detach()           # a fresh tensor object over the target's memory (autograd adopts it as .grad)
     return torch.zeros_like(like) if _zero_fill_deferred else torch.empty_like(like)
 use_matrix_core_products = True       # the layers' dense gradients on csrc/dense_gemm.hip where dense.plan says so

@@ -187,6 +187,7 @@ def test_bound_gradient_bucket_gathers_only_what_did_not_land_in_it():
     assert layers._gradient_buffer(None, a).data_ptr() != bucket.views[0].data_ptr()
     a.grad = bucket.views[0].detach()              # what autograd does with the tensor a backward returned
     a.grad.fill_(1.5)
+    assert layers._gradient_buffer(a, a).data_ptr() != bucket.views[0].data_ptr()       # accumulating: never onto the old gradient
     b.grad = torch.full((4,), 2.5)                 # a gradient from somewhere else (library fallback)
     flat = bucket.pack(torch.tensor(7.0), torch.tensor(8.0))
     assert flat.tolist() == [1.5] * 6 + [2.5] * 4 + [0.0] * 5 + [7.0, 8.0]
