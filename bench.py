@@ -323,7 +323,10 @@ def in_step_launch_us(w, steps=24):
     dense.launch_probe = rec = []
     try:
         for _ in range(steps):
-            w.step()
+            # rank-local on purpose: only rank 0 runs these probes while the others wait at the closing barrier, so the
+            # all-reduce of a data-parallel step must not be issued here (it would pair with their barrier)
+            w.forward_backward(step_in_backward=not w.dp)
+            w.update()
         torch.cuda.synchronize()
     finally:
         dense.launch_probe = None
@@ -670,6 +673,44 @@ def cpu_baseline(budget_s=12.0):
             "host_cpus": os.cpu_count()}
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` typed as is (no torchrun, WORLD_SIZE unset): this process becomes the launcher -- it starts
+    N copies of this script, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT in
+    their environment, exactly what torch.distributed.run would set), passes rank 0's single JSON line through on stdout and
+    returns the worst exit code.  A rank that dies takes the others down with it (their PIDs, nothing by pattern)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        alive = set(range(n))
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0:
+                    rc = rc or code
+                    print("bench.py: rank %d exited with code %d; stopping the other ranks" % (r, code), file=sys.stderr)
+                    for q in alive:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -687,11 +728,16 @@ def main():
                          "what tools/pmc_traffic.sh runs together with --launch eager")
     args = ap.parse_args()
 
-    rank, world, local = gdist.init_from_env()
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
+    shared_gpu = bool(os.environ.get("GEOM_DIST_BACKEND"))     # test hook: ranks share a device, gloo carries the collective
+    if args.gpus > torch.cuda.device_count() and not shared_gpu:
+        raise SystemExit("--gpus %d but only %d HIP device(s) are visible (one rank per GPU)" % (args.gpus, torch.cuda.device_count()))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # typed without a launcher: start the N ranks ourselves
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    rank, world, local = gdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher started another number of ranks" % (args.gpus, world))
     dev = torch.device("cuda", local % torch.cuda.device_count())   # one rank per GPU (modulo only for 1-GPU tests)
     torch.cuda.set_device(dev)
 
@@ -714,10 +760,16 @@ def main():
     gdist.barrier()          # ranks finish their setup at different times: condition the devices together, so that
     settle_clocks(dev, args.clock_warmup_ms)   # nobody idles at the barrier in front of the timed region and cools down again
     elapsed = time_steps(w.run, args.steps, args.warmup)
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    # [max, -min] of the ranks' own clocks in one MAX all-reduce; ranks_seen = an all-reduce of ones through the SAME group the
+    # gradient bucket uses, so the line shows how many ranks the collective really spanned
+    own = elapsed
+    t = torch.tensor([elapsed, -elapsed], device=dev, dtype=torch.float64)
+    seen = torch.ones((), device=dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(t.item())
+        torch.distributed.all_reduce(seen, op=torch.distributed.ReduceOp.SUM)
+    elapsed, fastest = float(t[0].item()), -float(t[1].item())
+    ranks_seen = int(round(float(seen.item())))
 
     if rank == 0:
         total_meshes = per_gpu * world * args.steps
@@ -726,10 +778,14 @@ def main():
             "value": round(total_meshes / elapsed, 2), "unit": "meshes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ranks_seen": ranks_seen,
+            "ms_per_step_ranks": {"max": round(elapsed / args.steps * 1e3, 4), "min": round(fastest / args.steps * 1e3, 4),
+                                  "rank0": round(own / args.steps * 1e3, 4)},
             "config": {"workload": "BASELINE config 5 shard: %d independent 2562-vert/5120-face meshes per GPU, full "
                                    "loss (face sampling 3000 pts + Chamfer NN vs 3000 GT pts + tri_distance 3000x5120 + "
-                                   "point-to-surface) on top of a 3-layer 0N-GCN 963-192-192-192, fwd+bwd, flat-bucket "
-                                   "grad all-reduce, Adam step" % per_gpu,
+                                   "point-to-surface) on top of a 3-layer 0N-GCN 963-192-192-192, fwd+bwd, %sAdam step"
+                                   % (per_gpu, "flat-bucket grad all-reduce over %d ranks (%s), " % (world, torch.distributed.get_backend())
+                                      if world > 1 else "single process (no collective), "),
                        "meshes_per_gpu": per_gpu, "global_batch": per_gpu * world, "parallelism": "dp%d" % world,
                        "launch": launch, "gemm_selection": "tunableop file" if tuned else "library default",
                        "clock_warmup_ms": args.clock_warmup_ms},

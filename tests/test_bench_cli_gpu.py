@@ -1,0 +1,56 @@
+"""-m gpu: bench.py AS THE DRIVER TYPES IT.  `python bench.py --gpus N ...` with no launcher around it must start its N
+ranks itself, and the single JSON line must say how many ranks the collective really spanned (`ranks_seen`).  On a 1-GPU
+box the two ranks share cuda:0 and gloo carries the all-reduce (GEOM_DIST_BACKEND, the hook tests/test_dist_step_gpu.py
+uses too); on an 8-GPU node the same command runs one rank per GPU over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env=None, timeout=540):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(extra_env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, timeout=timeout,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, "bench.py %s failed (%d):\n%s" % (" ".join(args), p.returncode, p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "expected exactly ONE JSON line on stdout, got %d:\n%s" % (len(lines), p.stdout[-2000:])
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus_2_typed_without_a_launcher_spawns_its_ranks(gpu):
+    line = _run(["--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--steps-only", "--clock-warmup-ms", "0"],
+                {"GEOM_DIST_BACKEND": "gloo"})
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    assert line["config"]["global_batch"] == 16 and line["config"]["parallelism"] == "dp2"
+    assert line["steps"] == 5 and line["warmup"] == 2 and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["ms_per_step"] > 0
+    r = line["ms_per_step_ranks"]
+    assert r["min"] <= r["rank0"] <= r["max"] == line["ms_per_step"]
+    assert "all-reduce over 2 ranks" in line["config"]["workload"]
+
+
+@pytest.mark.timeout(600)
+def test_bench_single_gpu_line_has_the_contract_fields(gpu):
+    line = _run(["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--steps-only", "--clock-warmup-ms", "0"])
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1
+    assert "all-reduce" not in line["config"]["workload"]          # no collective exists in the single-process step
+    for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in line
+
+
+def test_more_ranks_than_devices_is_refused_loudly(gpu):
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GEOM_DIST_BACKEND")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       env=env, cwd=ROOT, timeout=300, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode != 0 and "HIP device" in p.stderr
