@@ -61,10 +61,14 @@ def chamfer_nn(xyz1, xyz2, flags=None):
     return dist1, idx1, dist2, idx2
 
 
-def chamfer_nn_culled(xyz1, xyz2, order1="morton", order2="morton", flags=None):
+def chamfer_nn_culled(xyz1, xyz2, order1="morton", order2="morton", flags=None, validate=True):
     """chamfer_nn through the culled scan (csrc/nn_scan.h nn_culled_body): the same four tensors, bit for bit, for ANY
-    visiting orders (int32 [B,N] / [B,M] permutations, "morton" = made here on the device, None = the clouds' own order);
-    coherent orders let the scan skip most (query tile, target run) pairs.  The surface step has its own route to this
+    visiting orders that are PERMUTATIONS of the clouds (int32 [B,N] / [B,M], "morton" = made here on the device, None = the
+    clouds' own order); coherent orders let the scan skip most (query tile, target run) pairs -- an incoherent permutation
+    only costs speed.  A tensor that is NOT a permutation (an entry out of range, or one repeated) is refused: the kernels
+    index the clouds and the outputs with its entries unchecked, so it would read and write out of bounds or leave outputs
+    unwritten.  The check (sort + compare, one host sync per supplied order) is skipped only with validate=False or while
+    the stream is being captured -- then the caller vouches for the order.  The surface step has its own route to this
     scan (ops.GtIndex); this entry serves stand-alone Chamfer calls on clouds that are reused or already ordered."""
     if flags is None:
         flags = _arithmetic_flags
@@ -87,6 +91,11 @@ def chamfer_nn_culled(xyz1, xyz2, order1="morton", order2="morton", flags=None):
         order = _lib.require(order, name, torch.int32, 2)
         if order.shape != cloud.shape[:2] or order.device != dev:
             raise RuntimeError("%s must be an int32 [B,N] permutation per cloud on the clouds' device" % name)
+        if validate and order.numel() and not torch.cuda.is_current_stream_capturing():
+            want = torch.arange(order.shape[1], dtype=torch.int32, device=dev)
+            if not bool((order.sort(dim=1).values == want).all()):
+                raise ValueError("%s is not a permutation of 0..%d in every row (out-of-range or repeated entries)"
+                                 % (name, order.shape[1] - 1))
         return order
 
     o1, o2 = visiting(order1, xyz1, "order1"), visiting(order2, xyz2, "order2")

@@ -13,6 +13,7 @@
 #include <c10/hip/HIPGraphsC10Utils.h>
 
 #include <map>
+#include <mutex>
 #include <utility>
 
 #include "geom_hip.h"
@@ -75,24 +76,37 @@ at::Tensor morton_order(const at::Tensor &centroids)
 struct SoupOrder {
     at::Tensor order;
     int calls = 0;
+    bool captured = false;   // handed out during a stream capture: a graph holds its address, never replace it
 };
 
-const at::Tensor *soup_order(const at::Tensor &tri1, const at::Tensor &tri2, const at::Tensor &tri3)
+// Returns the tensor BY VALUE (a reference count of its own): a concurrent refresh from another thread cannot free the
+// memory under the caller's launch.  The cache itself is guarded by a mutex.
+at::Tensor soup_order(const at::Tensor &tri1, const at::Tensor &tri2, const at::Tensor &tri3)
 {
     static std::map<std::pair<int64_t, int>, SoupOrder> cache;
+    static std::mutex guard;
     const int64_t m = tri1.size(1);
-    if (tri1.size(0) == 0 || m < 64) return nullptr;
-    auto &slot = cache[{m, (int)tri1.get_device()}];
+    if (tri1.size(0) == 0 || m < 64) return at::Tensor();
     const bool capturing = c10::hip::currentStreamCaptureStatusMayInitCtx() != c10::hip::CaptureStatus::None;
-    if (slot.order.defined() && (slot.calls < 256 || capturing)) {
-        ++slot.calls;
-        return &slot.order;
+    {
+        std::lock_guard<std::mutex> lock(guard);
+        auto &slot = cache[{m, (int)tri1.get_device()}];
+        if (slot.order.defined() && (slot.calls < 256 || capturing || slot.captured)) {
+            ++slot.calls;
+            slot.captured = slot.captured || capturing;
+            return slot.order;
+        }
     }
-    if (capturing) return nullptr;
+    if (capturing) return at::Tensor();
     at::NoGradGuard no_grad;
-    slot.order = morton_order((tri1[0] + tri2[0] + tri3[0]) * (1.0 / 3.0));
-    slot.calls = 1;
-    return &slot.order;
+    at::Tensor fresh = morton_order((tri1[0] + tri2[0] + tri3[0]) * (1.0 / 3.0));
+    std::lock_guard<std::mutex> lock(guard);
+    auto &slot = cache[{m, (int)tri1.get_device()}];
+    if (!slot.captured) {
+        slot.order = fresh;
+        slot.calls = 1;
+    }
+    return slot.order;
 }
 
 void tri_forward_cuda(at::Tensor xyz1, at::Tensor tri1, at::Tensor tri2, at::Tensor tri3, at::Tensor dist, at::Tensor point,
@@ -112,11 +126,11 @@ void tri_forward_cuda(at::Tensor xyz1, at::Tensor tri1, at::Tensor tri2, at::Ten
     // the reference launcher's arguments (tri_distance.cpp:4-13) + what the fast scan needs: a visiting order (cached, see
     // above) and a scratch tensor for the per-triangle records (torch's caching allocator: free after the first call,
     // capture-safe)
-    const at::Tensor *order = soup_order(tri1, tri2, tri3);
+    const at::Tensor order = soup_order(tri1, tri2, tri3);
     const size_t ws_bytes = geom_tri_distance_workspace_bytes((int)b, (int)n, (int)m);
     at::Tensor ws = at::empty({(int64_t)(ws_bytes / 4 + 4)}, xyz1.options());
     raise_on(geom_tri_distance_ws_f32((int)b, (int)n, xyz1.data_ptr<float>(), (int)m, tri1.data_ptr<float>(), tri2.data_ptr<float>(),
-                                      tri3.data_ptr<float>(), order ? order->data_ptr<int>() : nullptr, dist.data_ptr<float>(),
+                                      tri3.data_ptr<float>(), order.defined() ? order.data_ptr<int>() : nullptr, dist.data_ptr<float>(),
                                       point.data_ptr<int>(), index.data_ptr<int>(), (unsigned)flags, ws.data_ptr<float>(), ws_bytes,
                                       c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
              "geom_tri_distance_ws_f32");

@@ -207,7 +207,11 @@ def _gradient_buffer(param, like):
     hit = _gradient_targets.get(id(param)) if param is not None else None
     # (a parameter that already holds a gradient is being ACCUMULATED into: the new gradient must not overwrite the old one's
     # memory, which is what the target is by then)
-    if hit is not None and hit[0]() is param and hit[1].shape == like.shape and param.grad is None:
+    # (a parameter fed by more than one live autograd node -- a shared weight or bias, a layer applied twice -- has its
+    # gradients ADDED by the engine: each node needs memory of its own, or the second would overwrite the first's before the
+    # sum is formed; GradBucket.pack() gathers a gradient that did not land in its view by copy)
+    if (hit is not None and hit[0]() is param and hit[1].shape == like.shape and param.grad is None
+            and _bias_user_count(param) <= 1):
         return hit[1].detach()           # a fresh tensor object over the target's memory (autograd adopts it as .grad)
     return torch.zeros_like(like) if _zero_fill_deferred else torch.empty_like(like)
 use_matrix_core_products = True       # the layers' dense gradients on csrc/dense_gemm.hip where dense.plan says so

@@ -180,9 +180,19 @@ class VertexBatchNorm(nn.Module):
     # captured into a HIP graph and is for eager multi-rank training only.
     sync_across_ranks = False
 
+    _warned_local_statistics = False
+
     def _synchronised(self):
-        return (self.training and self.sync_across_ranks and torch.distributed.is_available()
-                and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1)
+        many = (self.training and torch.distributed.is_available() and torch.distributed.is_initialized()
+                and torch.distributed.get_world_size() > 1)
+        if many and not self.sync_across_ranks and not VertexBatchNorm._warned_local_statistics:
+            VertexBatchNorm._warned_local_statistics = True       # once per process: the default changed in round 3
+            import warnings
+            warnings.warn("geometrics_amd VertexBatchNorm: %d ranks are active and sync_across_ranks is False -- every rank "
+                          "normalises with the statistics of its OWN shard (DDP semantics), which is not what the single-GPU "
+                          "reference computes over its whole batch; set VertexBatchNorm.sync_across_ranks = True for "
+                          "global-batch statistics (eager only)" % torch.distributed.get_world_size(), stacklevel=3)
+        return many and self.sync_across_ranks
 
     MAX_VALUES_PER_VERTEX = 4096   # b * c held in the registers of one workgroup (csrc/vertex_bn.hip)
 

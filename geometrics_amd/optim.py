@@ -16,6 +16,11 @@ class _InBackward:
 
     def __enter__(self):
         from . import layers
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise RuntimeError("FusedAdam.in_backward() would step on the LOCAL gradients, before the all-reduce across the "
+                               "%d ranks; data-parallel steps call step(bucket.views, grad_scale=1/world) after the exchange"
+                               % dist.get_world_size())
         self.prev = layers._backward_optimizer
         layers._backward_optimizer = self.opt
         self.opt._stepped_in_backward = False
@@ -61,6 +66,7 @@ class FusedAdam:
         return _InBackward(self)
 
     def zero_grad(self):
+        self._stepped_in_backward = False       # a new iteration: an in-backward step nobody consumed must not swallow a later step()
         for p in self.params:
             p.grad = None
 
@@ -71,6 +77,13 @@ class FusedAdam:
             if getattr(self, "_stepped_in_backward", False) and grad_scale == 1.0:
                 self._stepped_in_backward = False       # the backward pass's reduction launch has applied this step
                 return
+        if getattr(self, "_stepped_in_backward", False):
+            # the pass already applied a step with the parameters' own gradients and scale 1: a second, different step on top
+            # of it is never what the caller meant
+            self._stepped_in_backward = False
+            raise RuntimeError("FusedAdam.step(grads=..., grad_scale=...) after a backward pass that already applied the step "
+                               "(in_backward()): this iteration would be stepped twice")
+        if grads is None:
             grads = [p.grad for p in self.params]
         live = [i for i, g in enumerate(grads) if g is not None]
         if not live:

@@ -86,26 +86,29 @@ def face_order(verts, faces):
 # synchronisation) every SOUP_REFRESH calls -- a stale or foreign order can only cost speed, never change a result
 # (the scan's keys carry the original triangle index).
 SOUP_REFRESH = 256
-_soup_orders = {}   # (m, device) -> [order, calls since it was built]
+_soup_orders = {}   # (m, device) -> [order, calls since it was built, handed out during a stream capture]
 
 
 def soup_order(tri1, tri2, tri3):
     """Visiting order for a [B,M,3] x 3 triangle soup (see above); None while a HIP graph is being captured before any
-    order exists (the flat scan then serves the call)."""
+    order exists (the flat scan then serves the call).  An order that was handed out DURING a capture is never replaced:
+    the graph has its address baked in, and a refreshed entry would free the memory its replays read (the prep kernel
+    drops out-of-range entries, so triangles would silently go missing from the arg-min)."""
     m = tri1.shape[1]
     if tri1.shape[0] == 0 or m < 64:
         return None
     key = (m, tri1.device)
     hit = _soup_orders.get(key)
     capturing = torch.cuda.is_current_stream_capturing()
-    if hit is not None and (hit[1] < SOUP_REFRESH or capturing):
+    if hit is not None and (hit[1] < SOUP_REFRESH or capturing or hit[2]):
         hit[1] += 1
+        hit[2] = hit[2] or capturing
         return hit[0]
     if capturing:
         return None
     with torch.no_grad():
         order = morton_order((tri1[0] + tri2[0] + tri3[0]) * (1.0 / 3.0))
-    _soup_orders[key] = [order, 1]
+    _soup_orders[key] = [order, 1, False]
     return order
 
 

@@ -47,6 +47,10 @@ def _worker(rank, world, port, out):
     mean_loss = bucket.extra[0] / bucket.extra[1]
     assert float(bucket.extra[1]) == 8.0
     bucket.flat[:bucket.numel].div_(world)
+    # an optimiser step inside backward() would use the LOCAL gradients: refused while more than one rank is active
+    from geometrics_amd import optim
+    with pytest.raises(RuntimeError, match="before the all-reduce"):
+        optim._InBackward(object()).__enter__()
     gdist.barrier()
     if rank == 0:
         out.put((bucket.flat[:bucket.numel].numpy().copy(), float(mean_loss)))     # by value: a tensor would be fetched from this process later

@@ -325,6 +325,30 @@ def test_fused_adam_matches_torch_adam(gpu):
         close(p.detach().cpu().numpy(), r.detach().cpu().numpy(), 2e-6)
 
 
+def test_in_backward_step_protocol_cannot_step_twice_or_swallow_a_later_step(gpu):
+    """Round-3 advice on FusedAdam.in_backward(): after a pass that applied the step, step(grads=...) / step(grad_scale != 1)
+    must raise instead of stepping a second time; a flag nobody consumed is cleared by the next zero_grad() so that it cannot
+    swallow a later, unrelated step(); and the context refuses to be entered under a multi-rank process group (checked in
+    tests/test_dist_gloo.py)."""
+    from geometrics_amd import optim
+    p = torch.nn.Parameter(torch.ones(8, device=gpu))
+    opt = optim.FusedAdam([p], lr=1e-2)
+    opt._stepped_in_backward = True                    # what the end-of-pass launch leaves behind
+    with pytest.raises(RuntimeError, match="stepped twice"):
+        opt.step([torch.ones(8, device=gpu)])
+    opt._stepped_in_backward = True
+    with pytest.raises(RuntimeError, match="stepped twice"):
+        opt.step(grad_scale=0.5)
+    opt._stepped_in_backward = True
+    opt.step()                                         # the plain call consumes the flag: a no-op
+    assert opt.step_count == 0 and not opt._stepped_in_backward
+    opt._stepped_in_backward = True                    # ... never consumed ...
+    opt.zero_grad()                                    # ... the next iteration starts
+    p.grad = torch.ones(8, device=gpu)
+    opt.step()
+    assert opt.step_count == 1 and float(p.detach().max()) < 1.0
+
+
 def test_fused_adam_many_tensors_and_graph_replay(gpu):
     """More than 64 tensors (a deformation block has 56, GEOMetrics.py:73 hands Adam hundreds): chunks of 64 share the
     bias corrections of ONE step (only the last chunk advances the device-side state), odd sizes take the scalar tail,
@@ -640,6 +664,42 @@ def test_bias_gradients_of_a_backward_pass_are_finished_in_one_batched_launch(gp
     torch.cuda.synchronize()
     close(stack[2].bias.grad.cpu().numpy(), g_out.sum((0, 1)).cpu().numpy(), 1e-4)
     assert not torch.equal(stack[0].bias.grad, now_b[0]) and torch.isfinite(stack[0].bias.grad).all()
+
+
+def test_a_layer_applied_twice_keeps_both_gradients_under_bound_gradient_targets(gpu):
+    """dist.GradBucket(bind=True) hands the layers' launches the bucket view as the gradient's memory.  A parameter fed
+    by TWO live autograd nodes (one layer applied twice: shared weight and bias) gets its two gradients ADDED by the engine,
+    so each node must write memory of its own -- with one shared target the second node would overwrite the first's values
+    before the sum is formed (round-3 advice).  Bound and unbound runs must agree, with and without deferral."""
+    from geometrics_amd import dist as gdist, meshgen
+    torch.manual_seed(5)
+    V, Fc = meshgen.icosphere(2)
+    adj = utils.adj_init(torch.from_numpy(Fc).to(gpu))["adj"]
+    layer = layers.Batch_Image_ZERON_GCNGCN(192, 192).to(gpu)
+    head = layers.Batch_Image_ZERON_GCNGCN(192, 192).to(gpu)
+    x = torch.randn(8, V.shape[0], 192, device=gpu)
+    g_out = torch.randn(8, V.shape[0], 192, device=gpu)
+    params = list(layer.parameters()) + list(head.parameters())
+
+    def run(defer):
+        for p_ in params:
+            p_.grad = None
+        with layers.deferred_parameter_gradients(defer):
+            h = layer(layer(x, adj, F.relu), adj, F.relu)          # the same layer twice
+            head(h, adj, F.relu).backward(g_out)
+        return [p_.grad.clone() for p_ in params]
+
+    plain = run(False)
+    bucket = gdist.GradBucket(params, extra=2, bind=True)
+    try:
+        for defer in (False, True):
+            bound = run(defer)
+            bucket.pack(torch.tensor(1.0, device=gpu), torch.tensor(2.0, device=gpu))
+            for want, got, view in zip(plain, bound, bucket.views):
+                close(got.cpu().numpy(), want.cpu().numpy(), 2e-6)
+                assert torch.equal(view, got)                      # and pack() gathered what did not land in the view
+    finally:
+        layers.bind_gradient_targets(params, [None] * len(params))
 
 
 def test_weight_gradients_of_equal_layers_come_from_one_batched_product(gpu):

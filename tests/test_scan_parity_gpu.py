@@ -154,6 +154,26 @@ def test_culled_nn_equals_the_oracle_for_any_order(oracle_mod, gpu, b, n, m, fla
     _check_culled(oracle_mod, gpu, a, c, flags)
 
 
+def test_culled_nn_refuses_an_order_that_is_not_a_permutation(gpu):
+    """The kernels index the clouds and the outputs with the order's entries unchecked (nn_scan.h nn_cull_prep_point,
+    nn_culled_body), so a supplied order with an out-of-range or a repeated entry must be refused on the host (round-3
+    advice), for either cloud; a proper permutation passes."""
+    from geometrics_amd.chamfer_distance import chamfer_nn_culled
+    rng = np.random.default_rng(1)
+    a, c = _dev(rng.standard_normal((2, 130, 3)).astype(np.float32), gpu), _dev(rng.standard_normal((2, 90, 3)).astype(np.float32), gpu)
+    good1, good2 = _orders("random", 2, 130, gpu), _orders("random", 2, 90, gpu)
+    chamfer_nn_culled(a, c, good1, good2)
+    for bad_value in (130, -1, 5):                    # past the end, negative, a duplicate of another entry
+        bad = good1.clone()
+        bad[1, 7] = bad_value if bad_value != 5 else bad[1, 8]
+        with pytest.raises(ValueError, match="not a permutation"):
+            chamfer_nn_culled(a, c, bad, good2)
+    bad2 = good2.clone()
+    bad2[0, 0] = 90
+    with pytest.raises(ValueError, match="order2"):
+        chamfer_nn_culled(a, c, good1, bad2)
+
+
 def test_culled_nn_ties_nan_inf_and_the_reference_vectors(oracle_mod, gpu):
     from helpers import golden, golden_names
     from geometrics_amd.chamfer_distance import chamfer_nn_culled
