@@ -13,3 +13,5 @@ There is no CPU fallback: every op raises if libgeom_hip.so is missing or a tens
 on a HIP device.
 """
 __version__ = "0.1.0"
+
+from ._lib import reference_quirks, set_reference_quirks  # noqa: E402,F401  (package-wide GEOM_FLAG_REF_TAIL_TRUNC: GEOM_REF_QUIRKS=1)

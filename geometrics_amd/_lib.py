@@ -24,6 +24,35 @@ DENSE_MAX_LAYERS = 8
 DENSE_MAX_REDUCE_JOBS = 32
 ADAM_STATE_WORDS = 2112
 
+# ---- package-wide reference-quirk mode (SURVEY quirk register Q1 / Q3) ------------------------------------------------
+# The shipped CUDA kernels drop the tail of every 512-wide tile of targets / triangles (chamfer_distance.cu:31-33,
+# tri_distance.cu:129,134); the default here is the full scan (= the reference's CPU nnsearch and its legacy kernels).
+# With the mode on, every call that does not pass flags of its own -- ChamferDistance(), TriDistance(), chamfer_nn(),
+# tri_distance(), batch_point_to_point / _surface, the compiled forward_cuda entry points -- reproduces the truncation
+# exactly (GEOM_FLAG_REF_TAIL_TRUNC): what an unmodified driver needs to re-obtain the numbers of the reference's CUDA
+# build, e.g. its validation F1 at 2466 points (GEOMetrics.py:227,349), where the last 2 targets are never seen.
+_reference_quirks = os.environ.get("GEOM_REF_QUIRKS", "0") not in ("", "0")
+
+
+def set_reference_quirks(on=True):
+    """Switch the package-wide reference-quirk mode (initial value: environment variable GEOM_REF_QUIRKS)."""
+    global _reference_quirks
+    _reference_quirks = bool(on)
+    from . import _shim
+    if _shim._module is not None:          # the compiled entry points keep their own copy of the switch
+        _shim._module.set_reference_quirks(_reference_quirks)
+    return _reference_quirks
+
+
+def reference_quirks():
+    return _reference_quirks
+
+
+def quirk_flags():
+    """Flags of a call that passes none: GEOM_FLAG_REF_TAIL_TRUNC in reference-quirk mode, else 0."""
+    return FLAG_REF_TAIL_TRUNC if _reference_quirks else 0
+
+
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
 _u = ctypes.c_uint

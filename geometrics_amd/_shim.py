@@ -20,6 +20,7 @@ def module():
         spec = importlib.util.spec_from_file_location("geom_torch_shim", SHIM_PATH)
         _module = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(_module)
+        _module.set_reference_quirks(_lib.reference_quirks())      # follow the package-wide switch, not only the environment
     return _module
 
 

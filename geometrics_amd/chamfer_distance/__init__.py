@@ -29,7 +29,13 @@ def set_arithmetic(mode):
 
 
 def default_flags():
-    return _arithmetic_flags
+    """Flags of an NN scan issued without flags of its own: the package arithmetic + the reference-quirk mode
+    (geometrics_amd.set_reference_quirks / GEOM_REF_QUIRKS: the shipped CUDA kernel's tail truncation)."""
+    quirks = _lib.quirk_flags()
+    if quirks and _arithmetic_flags:
+        raise RuntimeError("reference-quirk mode reproduces the shipped kernel's tile structure in the un-fused arithmetic "
+                           "only: chamfer_distance.set_arithmetic('unfused') or switch set_reference_quirks(False)")
+    return _arithmetic_flags | quirks
 
 
 # Clouds with at least this many (query, target) pairs per mesh go through the culled scan on Morton orders made on the
@@ -42,7 +48,7 @@ AUTO_CULL_PAIRS = 2_000_000_000
 def chamfer_nn(xyz1, xyz2, flags=None):
     """(dist1 [B,N] f32, idx1 [B,N] i32, dist2 [B,M] f32, idx2 [B,M] i32)."""
     if flags is None:
-        flags = _arithmetic_flags
+        flags = default_flags()
     xyz1 = _lib.require(xyz1.detach(), "xyz1", torch.float32, 3, 3)
     xyz2 = _lib.require(xyz2.detach(), "xyz2", torch.float32, 3, 3)
     dev = _lib.same_device(xyz1, xyz2)
@@ -71,7 +77,7 @@ def chamfer_nn_culled(xyz1, xyz2, order1="morton", order2="morton", flags=None, 
     the stream is being captured -- then the caller vouches for the order.  The surface step has its own route to this
     scan (ops.GtIndex); this entry serves stand-alone Chamfer calls on clouds that are reused or already ordered."""
     if flags is None:
-        flags = _arithmetic_flags
+        flags = default_flags()
     xyz1 = _lib.require(xyz1.detach(), "xyz1", torch.float32, 3, 3)
     xyz2 = _lib.require(xyz2.detach(), "xyz2", torch.float32, 3, 3)
     dev = _lib.same_device(xyz1, xyz2)
@@ -111,9 +117,11 @@ def chamfer_nn_culled(xyz1, xyz2, order1="morton", order2="morton", flags=None, 
     return dist1, idx1, dist2, idx2
 
 
-def forward_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2, flags=0):
+def forward_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2, flags=None):
     """Same call shape as the reference's pybind `cd.forward_cuda` (chamfer_distance.cpp:15-27,36-38):
     caller-allocated outputs, filled in place."""
+    if flags is None:
+        flags = default_flags()
     b, n, _ = xyz1.shape
     m = xyz2.shape[1]
     with torch.cuda.device(xyz1.device):

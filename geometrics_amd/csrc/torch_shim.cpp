@@ -12,6 +12,9 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <c10/hip/HIPGraphsC10Utils.h>
 
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -34,6 +37,27 @@ void raise_on(int code, const char *what)
     TORCH_CHECK(code == 0, what, " failed: ", geom_strerror(code), " (code ", code, ")");
 }
 
+// Package-wide reference-quirk mode (SURVEY quirk register Q1/Q3): calls that pass no flags reproduce the shipped CUDA
+// kernels' tail truncation (chamfer_distance.cu:31-33, tri_distance.cu:129,134).  Initialised from GEOM_REF_QUIRKS, switched
+// at run time by set_reference_quirks() (geometrics_amd.set_reference_quirks() forwards to it).
+std::atomic<int> g_reference_quirks{-1};
+
+bool reference_quirks()
+{
+    int q = g_reference_quirks.load();
+    if (q < 0) {
+        const char *env = std::getenv("GEOM_REF_QUIRKS");
+        q = (env && env[0] && std::strcmp(env, "0") != 0) ? 1 : 0;
+        g_reference_quirks.store(q);
+    }
+    return q == 1;
+}
+
+unsigned resolve_flags(int64_t flags)
+{
+    return flags < 0 ? (reference_quirks() ? GEOM_FLAG_REF_TAIL_TRUNC : 0u) : (unsigned)flags;
+}
+
 void chamfer_forward_cuda(at::Tensor xyz1, at::Tensor xyz2, at::Tensor dist1, at::Tensor dist2, at::Tensor idx1,
                           at::Tensor idx2, int64_t flags)
 {
@@ -48,7 +72,7 @@ void chamfer_forward_cuda(at::Tensor xyz1, at::Tensor xyz2, at::Tensor dist1, at
     TORCH_CHECK(dist1.size(0) == b && dist2.size(0) == b && idx1.size(0) == b && idx2.size(0) == b, "output batch sizes differ");
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(xyz1.device());   // PyTorch-ROCm tensors carry device type "cuda"
     raise_on(geom_chamfer_nn_f32((int)b, (int)n, xyz1.data_ptr<float>(), (int)m, xyz2.data_ptr<float>(), dist1.data_ptr<float>(),
-                                 idx1.data_ptr<int>(), dist2.data_ptr<float>(), idx2.data_ptr<int>(), (unsigned)flags,
+                                 idx1.data_ptr<int>(), dist2.data_ptr<float>(), idx2.data_ptr<int>(), resolve_flags(flags),
                                  c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
              "geom_chamfer_nn_f32");
 }
@@ -131,7 +155,7 @@ void tri_forward_cuda(at::Tensor xyz1, at::Tensor tri1, at::Tensor tri2, at::Ten
     at::Tensor ws = at::empty({(int64_t)(ws_bytes / 4 + 4)}, xyz1.options());
     raise_on(geom_tri_distance_ws_f32((int)b, (int)n, xyz1.data_ptr<float>(), (int)m, tri1.data_ptr<float>(), tri2.data_ptr<float>(),
                                       tri3.data_ptr<float>(), order.defined() ? order.data_ptr<int>() : nullptr, dist.data_ptr<float>(),
-                                      point.data_ptr<int>(), index.data_ptr<int>(), (unsigned)flags, ws.data_ptr<float>(), ws_bytes,
+                                      point.data_ptr<int>(), index.data_ptr<int>(), resolve_flags(flags), ws.data_ptr<float>(), ws_bytes,
                                       c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
              "geom_tri_distance_ws_f32");
 }
@@ -141,7 +165,10 @@ void tri_forward_cuda(at::Tensor xyz1, at::Tensor tri1, at::Tensor tri2, at::Ten
 PYBIND11_MODULE(geom_torch_shim, m)
 {
     m.def("chamfer_forward_cuda", &chamfer_forward_cuda, "chamfer_distance.cpp:36-38 forward_cuda on libgeom_hip.so",
-          py::arg("xyz1"), py::arg("xyz2"), py::arg("dist1"), py::arg("dist2"), py::arg("idx1"), py::arg("idx2"), py::arg("flags") = 0);
+          py::arg("xyz1"), py::arg("xyz2"), py::arg("dist1"), py::arg("dist2"), py::arg("idx1"), py::arg("idx2"), py::arg("flags") = -1);
     m.def("tri_forward_cuda", &tri_forward_cuda, "tri_distance.cpp:34-36 forward_cuda on libgeom_hip.so", py::arg("xyz1"),
-          py::arg("tri1"), py::arg("tri2"), py::arg("tri3"), py::arg("dist"), py::arg("point"), py::arg("index"), py::arg("flags") = 0);
+          py::arg("tri1"), py::arg("tri2"), py::arg("tri3"), py::arg("dist"), py::arg("point"), py::arg("index"), py::arg("flags") = -1);
+    m.def("set_reference_quirks", [](bool on) { g_reference_quirks.store(on ? 1 : 0); },
+          "calls without flags reproduce the shipped CUDA kernels' tail truncation (GEOM_FLAG_REF_TAIL_TRUNC)");
+    m.def("reference_quirks", &reference_quirks);
 }

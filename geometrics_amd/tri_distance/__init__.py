@@ -134,8 +134,10 @@ def _workspace(b, n, m, dev):
     return torch.empty(max(nbytes, 16) // 4, dtype=torch.float32, device=dev), nbytes
 
 
-def forward_cuda(xyz1, tri1, tri2, tri3, dist, point, index, flags=0, use_workspace=True, order=None):
+def forward_cuda(xyz1, tri1, tri2, tri3, dist, point, index, flags=None, use_workspace=True, order=None):
     """Same call shape as the reference's pybind `tri.forward_cuda` (tri_distance.cpp:16-30,34-36)."""
+    if flags is None:
+        flags = _lib.quirk_flags()
     b, n, _ = xyz1.shape
     m = tri1.shape[1]
     with torch.cuda.device(xyz1.device):
@@ -153,8 +155,10 @@ def forward_cuda(xyz1, tri1, tri2, tri3, dist, point, index, flags=0, use_worksp
     _lib.check(code, "geom_tri_distance_f32")
 
 
-def tri_distance(xyz1, tri1, tri2, tri3, flags=0, use_workspace=True, order="auto"):
-    """order: "auto" (cached Morton order of the triangle centroids -> two-level scan, see soup_order), None (flat scan)
+def tri_distance(xyz1, tri1, tri2, tri3, flags=None, use_workspace=True, order="auto"):
+    """flags: None = the package default (0, or GEOM_FLAG_REF_TAIL_TRUNC in reference-quirk mode:
+    geometrics_amd.set_reference_quirks / GEOM_REF_QUIRKS).
+    order: "auto" (cached Morton order of the triangle centroids -> two-level scan, see soup_order), None (flat scan)
     or an explicit int32 permutation of the triangles."""
     xyz1 = _lib.require(xyz1.detach(), "xyz1", torch.float32, 3, 3)
     tris = [_lib.require(t.detach(), "tri%d" % (i + 1), torch.float32, 3, 3) for i, t in enumerate((tri1, tri2, tri3))]
@@ -164,14 +168,17 @@ def tri_distance(xyz1, tri1, tri2, tri3, flags=0, use_workspace=True, order="aut
         if t.shape != tris[0].shape or t.shape[0] != b:
             raise RuntimeError("tri1/tri2/tri3 must share one [B,M,3] shape with xyz1's batch")
     dist, point, index = _outputs(b, n, dev)
+    if flags is None:
+        flags = _lib.quirk_flags()
     if isinstance(order, str):
         order = soup_order(*tris) if use_workspace else None
     forward_cuda(xyz1, tris[0], tris[1], tris[2], dist, point, index, flags, use_workspace, order)
     return dist, point, index
 
 
-def tri_distance_indexed(xyz1, verts, faces, flags=0, use_workspace=True, order="auto"):
-    """Corners gathered in-kernel from verts [B,V,3] through faces [F,3] (int64).  order: "auto" (cached k-d leaf
+def tri_distance_indexed(xyz1, verts, faces, flags=None, use_workspace=True, order="auto"):
+    """Corners gathered in-kernel from verts [B,V,3] through faces [F,3] (int64).  flags: None = the package default (see
+    tri_distance).  order: "auto" (cached k-d leaf
     order of the face centroids -> two-level scan), None (flat scan) or an explicit int32 permutation."""
     xyz1 = _lib.require(xyz1.detach(), "xyz1", torch.float32, 3, 3)
     verts = _lib.require(verts.detach(), "verts", torch.float32, 3, 3)
@@ -180,6 +187,8 @@ def tri_distance_indexed(xyz1, verts, faces, flags=0, use_workspace=True, order=
     b, n, _ = xyz1.shape
     if verts.shape[0] != b:
         raise RuntimeError("verts and xyz1 batch sizes differ")
+    if flags is None:
+        flags = _lib.quirk_flags()
     dist, point, index = _outputs(b, n, dev)
     with torch.cuda.device(dev):
         if use_workspace:

@@ -33,8 +33,10 @@ def face_areas(verts, faces):
     return torch.sqrt(a + b + c) / 2
 
 
-def _nn(gt, pred):
-    _, idx_p, _, idx_g = oracle.chamfer_nn(gt.detach().float().numpy(), pred.detach().float().numpy())
+def _nn(gt, pred, flags=0):
+    """flags = oracle.FLAG_REF_TAIL_TRUNC: the shipped CUDA kernel's tile structure (chamfer_distance.cu:6-55) instead of the
+    full sequential scan."""
+    _, idx_p, _, idx_g = oracle.chamfer_nn(gt.detach().float().numpy(), pred.detach().float().numpy(), flags)
     return torch.from_numpy(idx_p).long(), torch.from_numpy(idx_g).long()
 
 
@@ -50,10 +52,10 @@ def _f1(pred_counters, gt_counters, pred, gt, num):
     return score / to_pred.shape[0]
 
 
-def point_to_point(verts, faces, gt, choices, u, v, f1=False):
+def point_to_point(verts, faces, gt, choices, u, v, f1=False, nn_flags=0):
     """utils.py:393-438 with the draws replayed."""
     pred = sample_points(verts, faces, choices, u, v)
-    idx_p, idx_g = _nn(gt, pred)
+    idx_p, idx_g = _nn(gt, pred, nn_flags)
     pred_counters = torch.gather(pred, 1, idx_p.unsqueeze(-1).expand(-1, -1, 3))
     gt_counters = torch.gather(gt, 1, idx_g.unsqueeze(-1).expand(-1, -1, 3))
     dist_1 = ((gt_counters - pred) ** 2).sum(-1).mean()
@@ -85,10 +87,10 @@ def point_to_line(p, a, b, c, option):
     return ((closest_point(p, a, b, c, option) - p) ** 2).sum(-1).mean()
 
 
-def point_to_surface(verts, faces, gt, choices, u, v, f1=False, tri_flags=0):
+def point_to_surface(verts, faces, gt, choices, u, v, f1=False, tri_flags=0, nn_flags=0):
     """utils.py:441-502 with the draws replayed; the tri scan is the C oracle."""
     pred = sample_points(verts, faces, choices, u, v)
-    idx_p, idx_g = _nn(gt, pred)
+    idx_p, idx_g = _nn(gt, pred, nn_flags)
     pred_counters = torch.gather(pred, 1, idx_p.unsqueeze(-1).expand(-1, -1, 3))
     gt_counters = torch.gather(gt, 1, idx_g.unsqueeze(-1).expand(-1, -1, 3))
     dist_1 = ((gt_counters - pred) ** 2).sum(-1).mean()

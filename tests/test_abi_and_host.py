@@ -174,6 +174,30 @@ def test_compiled_forward_cuda_shim_loads_and_validates():
         _shim.tri.forward_cuda(z, z, z, z, torch.zeros(1, 2), i, i)
 
 
+def test_reference_quirk_mode_switch_reaches_every_flagless_default(monkeypatch):
+    """geometrics_amd.set_reference_quirks / GEOM_REF_QUIRKS: the default flags of the NN and tri entry points become
+    GEOM_FLAG_REF_TAIL_TRUNC; explicit flags are never touched; the FMA arithmetic does not combine with it."""
+    import geometrics_amd
+    from geometrics_amd import chamfer_distance as cd
+    assert not geometrics_amd.reference_quirks() and cd.default_flags() == 0 and _lib.quirk_flags() == 0
+    try:
+        geometrics_amd.set_reference_quirks(True)
+        assert cd.default_flags() == _lib.FLAG_REF_TAIL_TRUNC == _lib.quirk_flags() == 1
+        cd.set_arithmetic("fma")
+        with pytest.raises(RuntimeError, match="un-fused"):
+            cd.default_flags()
+    finally:
+        cd.set_arithmetic("unfused")
+        geometrics_amd.set_reference_quirks(False)
+    assert cd.default_flags() == 0
+    import importlib
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-c", "import geometrics_amd as g; print(int(g.reference_quirks()))"],
+                         env=dict(os.environ, GEOM_REF_QUIRKS="1"), cwd=ROOT, stdout=subprocess.PIPE, text=True, timeout=120)
+    assert out.stdout.strip() == "1"
+
+
 def test_bound_gradient_bucket_gathers_only_what_did_not_land_in_it():
     """dist.GradBucket(bind=True): the per-parameter views are registered as gradient targets (the layers' launches write
     there and autograd adopts the tensor); pack() then copies only gradients that were produced elsewhere, zero-fills a

@@ -60,6 +60,73 @@ def test_nn_reference_tail_truncation(oracle_mod, gpu, m):
     _check_nn(oracle_mod, gpu, a, c, FLAG_REF_TAIL_TRUNC)
 
 
+def test_package_wide_reference_quirk_mode_at_the_validation_shape(oracle_mod, gpu):
+    """geometrics_amd.set_reference_quirks(True) / GEOM_REF_QUIRKS=1: every call that passes no flags -- the module objects
+    an unmodified driver holds (ChamferDistance(), TriDistance()), the fused losses, the compiled forward_cuda entry points --
+    reproduces the SHIPPED CUDA kernels' tail truncation (chamfer_distance.cu:31-33, tri_distance.cu:129,134).  Shape: the
+    reference's validation, 2466 points (GEOMetrics.py:227,349): 2466 = 4*512 + 418 and 418 % 4 = 2, so the last 2 targets /
+    triangles of the final tile are never seen.  Checked against the tiled restatement of the kernel (oracle.nn_tiled /
+    tri_scan with FLAG_REF_TAIL_TRUNC) bit for bit, and against the reference-emitted fixture nn_ragged_m2466 (the FULL scan
+    of the reference's CPU nnsearch): identical wherever the winner is not one of the 2 dropped targets."""
+    import geometrics_amd
+    from helpers import golden
+    from geometrics_amd import _shim, utils
+    from geometrics_amd.chamfer_distance import ChamferDistance
+    from geometrics_amd.tri_distance import TriDistance
+    from oracle import ref_ops
+    g = golden("nn_ragged_m2466")
+    a, c = g["xyz1"], g["xyz2"]                                    # [1, 97, 3] queries, [1, 2466, 3] targets
+    assert c.shape[1] == 2466 and not geometrics_amd.reference_quirks()
+    full1, _ = ChamferDistance()(_dev(a, gpu), _dev(c, gpu))
+    np.testing.assert_array_equal(full1.cpu().numpy(), g["idx1"])   # default mode = the reference's CPU scan
+    rng = np.random.default_rng(2466)
+    V, Fc = meshgen.icosphere(3)                                    # 642 vertices, 1280 faces: 1280 % 512 = 256 -> no tri tail;
+    tris = rng.standard_normal((3, 2, 2466, 3)).astype(np.float32)  # ... so a 2466-triangle soup for the tri scan
+    q = rng.standard_normal((2, 300, 3)).astype(np.float32)
+    for k, t in enumerate((2464, 2465)):                            # the two triangles of the dropped tail hug a query each
+        tris[:, :, t] = q[:, k][None] + 0.01 * rng.standard_normal((3, 2, 3)).astype(np.float32)
+    verts = meshgen.jittered_batch(V, 2)
+    gt = meshgen.gt_cloud(2, 2466)
+    ch, u, v = meshgen.sampling_draws(verts, Fc, 2466)
+    try:
+        assert geometrics_amd.set_reference_quirks(True) and geometrics_amd.reference_quirks()
+        i1, i2 = ChamferDistance()(_dev(a, gpu), _dev(c, gpu))
+        e1, j1, e2, j2 = oracle_mod.chamfer_nn(a, c, FLAG_REF_TAIL_TRUNC)
+        np.testing.assert_array_equal(i1.cpu().numpy(), j1)
+        np.testing.assert_array_equal(i2.cpu().numpy(), j2)
+        seen = g["idx1"] < 2464                                     # the reference's full-scan winner survives the truncation
+        assert (~seen).sum() < seen.sum()
+        np.testing.assert_array_equal(i1.cpu().numpy()[seen], g["idx1"][seen])
+        assert (i1.cpu().numpy()[~seen] < 2464).all()
+        # the compiled entry points (what the reference's own wrappers would import) follow the same switch
+        d1, d2 = torch.empty(1, 97, device=gpu), torch.empty(1, 2466, device=gpu)
+        k1, k2 = torch.empty(1, 97, dtype=torch.int32, device=gpu), torch.empty(1, 2466, dtype=torch.int32, device=gpu)
+        _shim.cd.forward_cuda(_dev(a, gpu), _dev(c, gpu), d1, d2, k1, k2)
+        np.testing.assert_array_equal(k1.cpu().numpy(), j1)
+        np.testing.assert_array_equal(d1.cpu().numpy().view(np.uint32), e1.view(np.uint32))
+        # TriDistance(): 2466 triangles
+        dist, point, index = TriDistance()(_dev(q, gpu), *(_dev(t, gpu) for t in tris))
+        ed, ep, ei = oracle_mod.tri_scan(q, tris[0], tris[1], tris[2], FLAG_REF_TAIL_TRUNC)
+        fd, _, fi = oracle_mod.tri_scan(q, tris[0], tris[1], tris[2], 0)
+        np.testing.assert_array_equal(index.cpu().numpy(), ei)
+        np.testing.assert_array_equal(point.cpu().numpy(), ep)
+        np.testing.assert_array_equal(dist.cpu().numpy().view(np.uint32), ed.view(np.uint32))
+        assert (ei < 2464).all() and (fi >= 2464).any()             # the case does exercise the dropped triangles
+        # the fused losses at the validation shape: loss and F1 of the truncated scans
+        tv, tf, tg = torch.from_numpy(verts), torch.from_numpy(Fc), torch.from_numpy(gt)
+        draws = tuple(torch.from_numpy(x) for x in (ch, u, v))
+        info = utils.adj_init(tf.to(gpu))
+        loss, f1 = utils.batch_point_to_point(tv.to(gpu), info, tg.to(gpu), num=2466, f1=True, draws=tuple(x.to(gpu) for x in draws))
+        want, want_f1 = ref_ops.point_to_point(tv, tf, tg, *draws, f1=True, nn_flags=FLAG_REF_TAIL_TRUNC)
+        full = ref_ops.point_to_point(tv, tf, tg, *draws)
+        assert abs(float(loss) - float(want)) <= 1e-5 * abs(float(want)) and abs(f1 - want_f1) <= 1e-9
+        assert float(want) != float(full)                           # the mode changes the number, as in the CUDA build
+    finally:
+        geometrics_amd.set_reference_quirks(False)
+    again, _ = ChamferDistance()(_dev(a, gpu), _dev(c, gpu))
+    np.testing.assert_array_equal(again.cpu().numpy(), g["idx1"])
+
+
 def test_nn_nan_and_inf_follow_the_sequential_scan(oracle_mod, gpu):
     rng = np.random.default_rng(9)
     a = rng.standard_normal((1, 70, 3)).astype(np.float32)
