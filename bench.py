@@ -51,7 +51,8 @@ PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_counters.json")
 
 
 class Workload:
-    def __init__(self, dev, first_mesh, batch, seed=3041, force_dp=False):
+    def __init__(self, dev, first_mesh, batch, seed=3041, force_dp=False, activation=F.relu):
+        self.act = activation          # the reference's F.relu (GEOMetrics.py); F.elu only in the smooth-activation parity test
         V, Fc = meshgen.icosphere(V_LEVEL)
         self.batch, self.nv, self.nf = batch, V.shape[0], Fc.shape[0]
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -87,10 +88,10 @@ class Workload:
         # (layers.weight_gradient_batching() is for deep stacks -- the deformation block's twelve equal layers; for the two
         # equal layers here it was measured at +3 us per step: -8 on the products, +11 from the changed launch order)
         for layer in self.stack[:-1]:
-            h = layer(h, self.info["adj"], F.relu)
+            h = layer(h, self.info["adj"], self.act)
         # base + 0.01 * h[..., :3] inside the last layer's aggregation launches (forward: positions from its epilogue;
         # backward: [0.01 * grad_pos | 0] synthesised, never written or read)
-        return self.stack[-1].forward_positions(h, self.info["adj"], F.relu, self.base, 0.01)
+        return self.stack[-1].forward_positions(h, self.info["adj"], self.act, self.base, 0.01)
 
     # one step = forward_backward() -> [exchange()] -> update(); captured as HIP graphs by capture()
     def forward_backward(self, step_in_backward=False):

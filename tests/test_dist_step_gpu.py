@@ -22,10 +22,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _collect(target, args, nproc):
+def _collect(target, args, nproc, tail=()):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=target, args=a + (out,), daemon=True) for a in args(nproc)]
+    procs = [ctx.Process(target=target, args=a + (out,) + tuple(tail), daemon=True) for a in args(nproc)]
     for p in procs:
         p.start()
     try:
@@ -40,9 +40,9 @@ def _collect(target, args, nproc):
     return result
 
 
-def _launch(world):
+def _launch(world, activation="relu"):
     port = _free_port()
-    return _collect(dist_step_worker.run, lambda n: [(r, n, port, TOTAL, STEPS) for r in range(n)], world)
+    return _collect(dist_step_worker.run, lambda n: [(r, n, port, TOTAL, STEPS) for r in range(n)], world, (activation,))
 
 
 @pytest.mark.timeout(600)
@@ -59,7 +59,22 @@ def test_two_rank_step_equals_the_serial_two_shard_step_bitwise(gpu):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_step_tracks_the_single_process_16_mesh_step(gpu):
+def test_two_rank_elu_step_equals_the_single_process_16_mesh_step_to_round_off(gpu):
+    """The same comparison with a SMOOTH activation (ELU in all three layers): no unit can switch sides, so two ranks of 8
+    meshes against ONE process holding all 16 differ only by the round-off of other GEMM kernel selections and another
+    summation order of the weight gradients -- 1e-4 of the gradient's scale (the ReLU variant below needs 5e-2 because of
+    unit flips, not because anything is loose).  Same samples, same loss."""
+    two = _launch(2, "elu")
+    one = _launch(1, "elu")
+    assert two["steps_taken"] == one["steps_taken"] == STEPS + WARM
+    np.testing.assert_allclose(two["losses"], one["losses"], rtol=2e-5)
+    scale = np.abs(one["grads"]).max()
+    assert np.abs(two["grads"] - one["grads"]).max() <= 1e-4 * scale
+    assert np.abs(two["params"] - one["params"]).max() <= 2 * LR * (STEPS + WARM) * 1.01
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_relu_step_tracks_the_single_process_16_mesh_step_up_to_relu_unit_flips(gpu):
     """Against ONE process holding all 16 meshes in one batch the agreement is that of fp32 training, not bitwise: the
     [16*2562, 963] GEMMs run other library kernels than the [8*2562, 963] ones, pre-activations move by an ulp, a few
     dozen of the 12 M ReLU units sitting within round-off of zero switch sides, and each switch changes dW by one

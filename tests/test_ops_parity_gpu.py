@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import bits, golden
+from helpers import bits, fp64_surface_gradient, golden, rows_close
 from geometrics_amd import layers, meshgen, ops, utils
 from oracle import ref_ops
 
@@ -38,6 +38,42 @@ def draws(g, gpu):
     return dev(g["choices"], gpu), dev(g["u"], gpu), dev(g["v"], gpu)
 
 
+# Per-row gradient bounds (helpers.rows_close): |error| <= rtol * (sum of the absolute contributions meeting in the element).
+# The sampling backward is a weighted sum of given vectors: a few fp32 roundings per term.  The surface-loss backward forms
+# its terms from fp32 DIFFERENCES of coordinates (pred - gt, closest - gt: ~0.02 between numbers of size ~0.5, i.e. 1e-6
+# relative per term before any summation) and the plane / edge projections of the point-to-triangle candidates; the
+# reference's own fp32 autograd sits at 1.7e-5 of the row mass on the same inputs.
+ROW_RTOL_SAMPLING = 2e-6
+ROW_RTOL_SURFACE = 5e-5
+
+
+# ---------------------------------------------------------------- adjacency ----
+def test_adjacency_built_on_the_device_matches_reference_vectors(gpu):
+    """utils.adj_init / calc_adj / normalize_adj (reference utils.py:96-131) ON THE DEVICE, bit for bit against the
+    matrices the imported reference produced (tests/golden adj_ico162: the full dense pair; adj_482: the reference's own
+    template mesh, non-zeros) -- the CPU suite holds the same comparison for host tensors -- and the CSR / ELL tables the
+    aggregation kernels read are exactly that matrix."""
+    g = golden("adj_ico162")
+    info = utils.adj_init(dev(g["faces"], gpu))
+    assert info["adj"].is_cuda and info["adj_orig"].is_cuda and info["faces"].dtype == torch.int64
+    np.testing.assert_array_equal(info["adj_orig"].cpu().numpy(), g["adj_orig"])
+    np.testing.assert_array_equal(bits(info["adj"].cpu().numpy()), bits(g["adj"]))
+    np.testing.assert_array_equal(bits(utils.normalize_adj(utils.calc_adj(dev(g["faces"], gpu))).cpu().numpy()), bits(g["adj"]))
+    g = golden("adj_482")
+    info = utils.adj_init(dev(g["faces"], gpu))
+    dense = info["adj"].cpu().numpy()
+    r, c = np.nonzero(dense)
+    np.testing.assert_array_equal(r, g["nnz_rows"])
+    np.testing.assert_array_equal(c, g["nnz_cols"])
+    np.testing.assert_array_equal(bits(dense[r, c]), bits(g["nnz_vals"]))
+    csr = layers.adjacency_csr(info["adj"])                       # what the kernels read: same pattern, same value bits
+    rowptr, col, val = (t.cpu().numpy() for t in (csr.rowptr, csr.col, csr.val))
+    assert csr.nnz == len(r) == 3362
+    np.testing.assert_array_equal(np.repeat(np.arange(482), np.diff(rowptr)), r)
+    np.testing.assert_array_equal(col, c)
+    np.testing.assert_array_equal(bits(val), bits(g["nnz_vals"]))
+
+
 # ------------------------------------------------------------------ sampling ----
 def test_batch_sample_matches_reference_fixture(gpu):
     g = golden("sample_v162")
@@ -46,6 +82,14 @@ def test_batch_sample_matches_reference_fixture(gpu):
     np.testing.assert_array_equal(bits(pts.detach().cpu().numpy()), bits(g["points"]))
     pts.backward(dev(g["grad_points"], gpu))
     close(verts.grad.cpu().numpy(), g["grad_verts"], 1e-5)
+    # per ROW, against float64: grad_verts[v] = sum over the samples on v's faces of weight * grad_point, all weights >= 0, so
+    # the same backward applied to |grad_points| is the mass of absolute contributions that meet in the row
+    ch, u, v = (torch.from_numpy(g[k]) for k in ("choices", "u", "v"))
+    v64 = torch.from_numpy(g["verts"]).double().requires_grad_(True)
+    p64 = ref_ops.sample_points(v64, torch.from_numpy(g["faces"]), ch, u.double(), v.double())
+    exact, = torch.autograd.grad(p64, v64, torch.from_numpy(g["grad_points"]).double(), retain_graph=True)
+    mass, = torch.autograd.grad(p64, v64, torch.from_numpy(g["grad_points"]).double().abs())
+    rows_close(verts.grad.cpu().numpy(), exact.numpy(), mass.numpy(), ROW_RTOL_SAMPLING, "batch_sample grad_verts")
 
 
 def test_face_areas_and_random_draws(gpu):
@@ -77,8 +121,14 @@ def test_losses_match_reference_fixture(gpu, name, fn):
     loss.backward()
     close(loss.item(), g["loss"], 1e-5)
     assert abs(f1 - float(g["f1"])) < 1e-9
-    close(verts.grad.cpu().numpy(), g["grad_verts"], 1e-4)
+    close(verts.grad.cpu().numpy(), g["grad_verts"], 1e-4)       # vs the reference's own fp32 autograd (itself round-off noisy)
     assert isinstance(f1, float) and loss.dim() == 0
+    # per ROW against the float64 closed form (helpers.fp64_surface_gradient): the backward is an atomics-free gather in a
+    # fixed order, so every vertex row is held to its OWN scale, not to the tensor's largest entry
+    exact_loss, exact, mass = fp64_surface_gradient(g["verts"], g["faces"], g["gt"], g["choices"], g["u"], g["v"],
+                                                    two_sided=(fn == "batch_point_to_point"))
+    close(loss.item(), exact_loss, 1e-5)
+    rows_close(verts.grad.cpu().numpy(), exact, mass, ROW_RTOL_SURFACE, fn + " grad_verts")
 
 
 def test_calc_point_to_line_all_options(gpu):
@@ -108,6 +158,9 @@ def test_losses_at_baseline_size(gpu, fn):
     loss.backward()
     close(loss.item(), ref.item(), 1e-5)
     close(gv.grad.cpu().numpy(), cv.grad.numpy(), 1e-4)
+    exact_loss, exact, mass = fp64_surface_gradient(verts, Fc, gt, ch, u, v, two_sided=(fn == "point_to_point"))
+    close(loss.item(), exact_loss, 1e-5)
+    rows_close(gv.grad.cpu().numpy(), exact, mass, ROW_RTOL_SURFACE, fn + " grad_verts at the BASELINE size")
 
 
 def test_device_sum_is_reproducible(gpu):
