@@ -114,6 +114,10 @@ def rows_close(actual, exact, mass, rtol, what=""):
     err = np.abs(actual - exact)
     bound = rtol * mass + 1e-30
     worst = float((err / bound).max())
+    log = os.environ.get("GEOM_MARGIN_LOG")
+    if log:                       # margins of a run, for choosing / reporting the bounds (tools and DESIGN quote them)
+        with open(log, "a") as f:
+            f.write("%s: worst %.3g of the row mass (bound %g), max abs err %.3g\n" % (what, worst * rtol, rtol, err.max()))
     assert worst <= 1.0, "%s: worst element is %.2fx its bound (rtol %g of the row's term mass); max err %g" % (
         what, worst, rtol, err.max())
     return worst * rtol          # the rtol that would just have passed: reported by the tests that print their margins
