@@ -51,7 +51,7 @@ PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_counters.json")
 
 
 class Workload:
-    def __init__(self, dev, first_mesh, batch, seed=3041, force_dp=False, activation=F.relu):
+    def __init__(self, dev, first_mesh, batch, seed=3041, force_dp=False, activation=F.relu, lr=1e-4):
         self.act = activation          # the reference's F.relu (GEOMetrics.py); F.elu only in the smooth-activation parity test
         V, Fc = meshgen.icosphere(V_LEVEL)
         self.batch, self.nv, self.nf = batch, V.shape[0], Fc.shape[0]
@@ -79,7 +79,7 @@ class Workload:
         self.seed_grad = torch.ones((), device=dev)
         self.rng = ops.manual_seed(seed, dev, mesh_offset=first_mesh)   # sampler keyed on the GLOBAL mesh index: N shards draw what one process would
         # GEOMetrics.py:73 (Adam, lr 1e-4): every parameter tensor in one launch, step count on the device
-        self.opt = optim.FusedAdam(self.stack.parameters(), lr=1e-4)
+        self.opt = optim.FusedAdam(self.stack.parameters(), lr=lr)
         self.loss = None
         self.graphs = None
 

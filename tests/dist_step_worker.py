@@ -13,9 +13,10 @@ def _flat(tensors):
     return torch.cat([t.detach().reshape(-1) for t in tensors]).cpu().numpy()
 
 
-def run(rank, world, port, total_meshes, steps, out, activation="relu"):
+def run(rank, world, port, total_meshes, steps, out, activation="relu", lr=1e-4):
     """One rank of a `world`-rank job over `total_meshes` meshes, exactly as bench.py runs it (activation "elu": the
-    smooth-activation variant of the same step, for the comparison that ReLU's unit flips would blur)."""
+    smooth-activation variant of the same step, for the comparison that ReLU's unit flips would blur; lr = 0 keeps the
+    parameters where they are, so that every step's gradient can be compared across job shapes)."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), GEOM_DIST_BACKEND="gloo")     # both ranks share cuda:0; gloo carries the all-reduce
     import torch
@@ -28,7 +29,7 @@ def run(rank, world, port, total_meshes, steps, out, activation="relu"):
     gemm_tuning.enable()
     first, count = gdist.shard_range(total_meshes, rank, world)
     import torch.nn.functional as F
-    wl = bench.Workload(dev, first, count, activation={"relu": F.relu, "elu": F.elu}[activation])
+    wl = bench.Workload(dev, first, count, activation={"relu": F.relu, "elu": F.elu}[activation], lr=lr)
     wl.capture()                       # N=1: one graph; N>1: graph A / eager all-reduce / graph B, as bench.py runs it
     losses = []
     for _ in range(steps):

@@ -98,26 +98,35 @@ def fp64_surface_gradient(verts, faces, gt, choices, u, v, two_sided, scale=3000
     loss.backward()
     grad = torch.zeros(b, nv, 3, dtype=torch.float64)
     mass = torch.zeros(b, nv, 3, dtype=torch.float64)
-    for vid, c in groups:
+    floor = torch.zeros(b, nv, 3, dtype=torch.float64)
+    # Every term is 2 * coef * (a DIFFERENCE of two fp32 coordinates) * (a weight <= 1): the difference carries the absolute
+    # rounding of the coordinates themselves (ulps of max|coordinate|), however small it is -- a gt point lying 1e-5 from the
+    # surface has a term a thousand times smaller than that rounding.  `floor` = one coordinate ulp through every term that
+    # meets in the element; the bound is rtol * mass + floor_ulps * floor.
+    ulp = float(np.finfo(np.float32).eps) * float(max(np.abs(verts).max(), np.abs(gt).max()))
+    for (vid, c), coef in zip(groups, (scale / (b * num), scale / (b * n_gt))):
         index = vid.reshape(b, -1, 1).expand(-1, -1, 3)
         g = c.grad.reshape(b, -1, 3)
         grad.scatter_add_(1, index, g)
         mass.scatter_add_(1, index, g.abs())
-    return float(loss.detach()), grad.numpy(), mass.numpy()
+        floor.scatter_add_(1, index, torch.full_like(g, 2.0 * coef * ulp))
+    return float(loss.detach()), grad.numpy(), mass.numpy(), floor.numpy()
 
 
-def rows_close(actual, exact, mass, rtol, what=""):
-    """|actual - exact| <= rtol * mass ELEMENT BY ELEMENT, where mass = the sum of the absolute contributions that meet in
-    the element: a wrong neighbour or a dropped term on a low-gradient vertex fails here even when the tensor's largest
-    entry is 1000x bigger (the max-norm `close` of test_ops_parity_gpu.py would let it pass)."""
+def rows_close(actual, exact, mass, rtol, what="", floor=None, floor_ulps=0.0):
+    """|actual - exact| <= rtol * mass + floor_ulps * floor ELEMENT BY ELEMENT, where mass = the sum of the absolute
+    contributions that meet in the element (and floor = one coordinate ulp through each of them, see
+    fp64_surface_gradient): a wrong neighbour or a dropped term on a low-gradient vertex fails here even when the tensor's
+    largest entry is 1000x bigger (the max-norm `close` of test_ops_parity_gpu.py would let it pass)."""
     actual, exact, mass = (np.asarray(x, np.float64) for x in (actual, exact, mass))
     err = np.abs(actual - exact)
-    bound = rtol * mass + 1e-30
+    bound = rtol * mass + (0.0 if floor is None else floor_ulps * np.asarray(floor, np.float64)) + 1e-30
     worst = float((err / bound).max())
     log = os.environ.get("GEOM_MARGIN_LOG")
-    if log:                       # margins of a run, for choosing / reporting the bounds (tools and DESIGN quote them)
+    if log:                       # margins of a run, for choosing / reporting the bounds (DESIGN quotes them)
         with open(log, "a") as f:
-            f.write("%s: worst %.3g of the row mass (bound %g), max abs err %.3g\n" % (what, worst * rtol, rtol, err.max()))
-    assert worst <= 1.0, "%s: worst element is %.2fx its bound (rtol %g of the row's term mass); max err %g" % (
-        what, worst, rtol, err.max())
-    return worst * rtol          # the rtol that would just have passed: reported by the tests that print their margins
+            f.write("%s: worst element at %.3g of its bound (rtol %g, floor %g ulp), max abs err %.3g, max |exact| %.3g\n"
+                    % (what, worst, rtol, floor_ulps, err.max(), np.abs(exact).max()))
+    assert worst <= 1.0, "%s: worst element is %.2fx its bound (rtol %g of the row's term mass + %g coordinate ulps per term); " \
+                         "max err %g" % (what, worst, rtol, floor_ulps, err.max())
+    return worst
