@@ -35,7 +35,6 @@ from geometrics_amd.chamfer_distance import chamfer_nn  # noqa: E402
 from geometrics_amd.tri_distance import tri_distance_indexed  # noqa: E402
 
 V_LEVEL, S_PTS, G_PTS, FEAT, HID = 4, 3000, 3000, 963, 192
-EAGER_DP_UPDATE = bool(int(os.environ.get("GEOM_EAGER_DP_UPDATE", "1")))   # N > 1: Adam launched eagerly behind the all-reduce (0: as a second graph)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector peak == f32 MFMA dense peak
 
@@ -67,21 +66,27 @@ class Workload:
         self.stack = torch.nn.ModuleList(
             [layers.Batch_Image_ZERON_GCNGCN(i, o) for i, o in ((FEAT, HID), (HID, HID), (HID, HID))]).to(dev)
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-        # force_dp: take the N > 1 sequence (bucket pack / all-reduce / Adam on the bucket, two graphs) in a 1-rank group --
-        # the only way to run the RCCL collective between the two graph replays on a single-GPU box
+        # force_dp: take the N > 1 sequence in a 1-rank group -- the only way to run the RCCL collective inside the step on
+        # a single-GPU box
         self.dp = self.world > 1 or force_dp
-        # flat DP bucket: all gradients + [loss_sum, mesh_count] -> exactly one all-reduce per step
-        self.bucket = gdist.GradBucket(self.stack.parameters(), extra=2, force_collective=force_dp, bind=True) if self.dp else None
-        self.count = torch.full((), float(batch), device=dev)
-        # [loss_sum, mesh_count] of the shard = base + loss * scale: one launch writes both trailing scalars of the bucket
-        self.extra_scale = torch.tensor([float(batch), 0.0], device=dev)
-        self.extra_base = torch.tensor([0.0, float(batch)], device=dev)
+        # flat DP bucket: all gradients + the shard's loss sum -> exactly one all-reduce per step.  The gradients are WRITTEN
+        # into it by the end-of-pass reduction launch (bind=True) and the loss by the loss reduction (loss_out): no pack launch
+        self.bucket = gdist.GradBucket(self.stack.parameters(), extra=1, force_collective=force_dp, bind=True) if self.dp else None
+        self.total_meshes = batch * self.world      # equal shards (bench.py: --meshes-per-gpu on every rank)
         self.seed_grad = torch.ones((), device=dev)
         self.rng = ops.manual_seed(seed, dev, mesh_offset=first_mesh)   # sampler keyed on the GLOBAL mesh index: N shards draw what one process would
         # GEOMetrics.py:73 (Adam, lr 1e-4): every parameter tensor in one launch, step count on the device
         self.opt = optim.FusedAdam(self.stack.parameters(), lr=lr)
         self.loss = None
         self.graphs = None
+        # N > 1 choreography: the all-reduce is issued from `side`, which waits only for `grads_ready` --
+        # recorded inside the backward pass right behind the reduction launch -- so the collective travels while the first
+        # layer's input-gradient product (postponed behind the reduction: layers.late_input_gradients) still runs; the Adam
+        # step on the reduced bucket opens the NEXT step (`pending`), inside its graph: no eager launch between two replays
+        self.side = torch.cuda.Stream(device=dev) if self.dp else None
+        self.grads_ready = torch.cuda.Event(external=True) if self.dp else None
+        self.pending = False          # an all-reduced bucket is waiting for its Adam step
+        self.packed_late = False      # pack() had to launch copies behind the ready-event (a gradient that did not land in its view)
 
     def positions(self):
         h = self.feat
@@ -93,28 +98,50 @@ class Workload:
         # backward: [0.01 * grad_pos | 0] synthesised, never written or read)
         return self.stack[-1].forward_positions(h, self.info["adj"], self.act, self.base, 0.01)
 
-    # one step = forward_backward() -> [exchange()] -> update(); captured as HIP graphs by capture()
+    # N = 1: one step = forward_backward(step_in_backward=True): ONE graph, Adam inside the end-of-pass reduction launch.
+    # N > 1: one step = [Adam on the bucket all-reduced by the PREVIOUS step] -> forward -> backward (weight-gradient
+    #        partials, reduction launch -> bucket, event, first layer's input gradient) as ONE graph; the all-reduce is issued
+    #        behind the event from a side stream.  finish() applies the last pending Adam step.
     def forward_backward(self, step_in_backward=False):
+        import contextlib
+        if self.dp and self.pending:
+            self.update()
+            self.pending = False
         self.opt.zero_grad()
         self.feat.grad = None
-        # nothing reads a parameter gradient before backward() returns (no hooks, no DDP: the bucket is packed afterwards),
+        # nothing reads a parameter gradient before backward() returns (no hooks, no DDP: the gradients land in the bucket),
         # so the bias / weight gradients of the pass are finished by ONE launch at its end -- which, in a single-process
         # step, applies Adam to them as well (step_in_backward: no optimiser launch of its own)
-        import contextlib
-        with layers.deferred_parameter_gradients(), (self.opt.in_backward() if step_in_backward else contextlib.nullcontext()):
+        self.ready_recorded = False
+        late = layers.late_input_gradients(self._parameter_gradients_ready) if self.dp else contextlib.nullcontext()
+        with layers.deferred_parameter_gradients(), late, (self.opt.in_backward() if step_in_backward else contextlib.nullcontext()):
             pos = self.positions()
-            self.loss = utils.batch_point_to_surface(pos, self.info, self.gt, num=S_PTS)
+            self.loss = utils.batch_point_to_surface(pos, self.info, self.gt, num=S_PTS,
+                                                     loss_out=self.bucket.extra if self.dp else None)
             self.loss.backward(self.seed_grad)              # explicit seed: no ones_like fill launch
         if self.dp:
-            if self.bucket.bound:       # the gradients are in the bucket already (layers.bind_gradient_targets)
-                self.bucket.pack()
-                torch.addcmul(self.extra_base, self.loss.detach().expand(2), self.extra_scale, out=self.bucket.extra)
-            else:
-                self.bucket.pack(self.loss.detach() * self.batch, self.count)
+            # normally pack() launches nothing (everything was written in place) and the event sits behind the reduction launch
+            self.packed_late = self.bucket.pack() or not self.ready_recorded
+
+    def _parameter_gradients_ready(self):
+        """Called inside the backward pass, right behind the end-of-pass reduction launch (which wrote the bucket)."""
+        self.grads_ready.record()
+        self.ready_recorded = True
 
     def exchange(self):
-        if self.dp:
-            self.bucket.all_reduce()            # ONE RCCL all-reduce: 259 200 grads + loss sum + count (1.04 MB)
+        """ONE all-reduce per step: 259 200 gradients + the shard's loss (1.04 MB), issued from the side stream behind the
+        event of the reduction launch; the launch stream then waits for it (before the next step's Adam)."""
+        if not self.dp:
+            return
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self.side):
+            if self.packed_late:
+                self.side.wait_stream(main)                 # a late copy into the bucket: wait for everything queued so far
+            else:
+                self.side.wait_event(self.grads_ready)
+            self.bucket.all_reduce()
+        main.wait_stream(self.side)
+        self.pending = True
 
     def update(self):
         if self.dp:
@@ -125,20 +152,28 @@ class Workload:
     def step(self):
         self.forward_backward(step_in_backward=not self.dp)
         self.exchange()
-        self.update()
+        if not self.dp:
+            self.update()      # (a no-op: the reduction launch of the pass applied it)
+
+    def finish(self):
+        """Apply the Adam step a data-parallel run still owes (the update of step s opens step s + 1)."""
+        if self.dp and self.pending:
+            self.update()
+            self.pending = False
 
     def mean_loss(self):
         if self.dp:
-            return float(self.bucket.extra[0] / self.bucket.extra[1])
+            return float(self.bucket.extra[0]) * self.batch / self.total_meshes      # sum of the shards' means, equal shards
         return float(self.loss.detach())
 
     def capture(self, warm=3):
-        """Record the step into HIP graphs so that no python runs between its ~45 launches (library
-        GEMMs, our C-ABI kernels, fused Adam).  N=1: one graph.  N>1: graph A = forward + backward (the
-        gradients land in the bucket) + the bucket's two scalars, then the single all-reduce issued eagerly on the same
-        stream, then Adam -- one launch, issued eagerly too (GEOM_EAGER_DP_UPDATE=0: as a second graph B)
-        -- the collective stays outside the captured region, so nothing depends on RCCL's
-        graph-capture support."""
+        """Record the step into a HIP graph so that no python runs between its launches (library GEMMs, our C-ABI kernels,
+        Adam).  N = 1: the whole step.  N > 1: [Adam of the previous step, forward, backward, reduction -> bucket, external
+        event, first layer's input gradient]; the collective itself stays OUTSIDE the captured region (nothing depends on
+        RCCL's graph-capture support): it is issued after the replay from a side stream that waits for the graph's event
+        node.  Whether such an event orders work outside the graph is checked on the device first
+        (gdist.external_events_order_graph_nodes); if not, the side stream waits for the whole replay instead (correct,
+        no overlap)."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -146,36 +181,32 @@ class Workload:
                 self.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if not self.dp:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.step()
-            self.graphs = (g,)
-        else:
-            ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
-                self.forward_backward()
-            self.exchange()
-            if EAGER_DP_UPDATE:          # the update is ONE launch: issued eagerly behind the collective, every step
-                self.graphs = (ga, None)
-            else:
-                gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, pool=ga.pool()):
-                    self.update()
-                self.graphs = (ga, gb)
+        if self.dp and not gdist.external_events_order_graph_nodes(self.feat.device):
+            print("bench.py: external events do not order graph nodes on this stack; the all-reduce waits for the whole "
+                  "replay (no overlap with the input-gradient product)", file=sys.stderr)
+            self.overlap = False
+        owed = self.pending
+        if self.dp and not owed:
+            raise RuntimeError("capture() of a data-parallel step needs at least one warm-up step: the captured step opens "
+                               "with the Adam update of the step before it")
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.forward_backward(step_in_backward=not self.dp)
+            if not self.dp:
+                self.update()
+        self.pending = owed               # capturing executed nothing: the update recorded at the graph's head is still owed
+        if self.dp and not self.overlap:
+            self.packed_late = True       # exchange(): wait_stream(main) instead of the event
+        self.graphs = (g,)
+
+    overlap = True
 
     def run(self):
         if self.graphs is None:
             self.step()
-        elif len(self.graphs) == 1:
-            self.graphs[0].replay()
         else:
             self.graphs[0].replay()
             self.exchange()
-            if self.graphs[1] is None:
-                self.update()
-            else:
-                self.graphs[1].replay()
 
 
 def settle_clocks(dev, ms):

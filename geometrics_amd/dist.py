@@ -79,18 +79,25 @@ class GradBucket:
             layers.bind_gradient_targets(self.params, self.views)
 
     def pack(self, *scalars):
+        """Gather into the flat buffer whatever is not there yet.  Returns True when that took a launch (an unbound bucket
+        always; a bound one only for gradients that did not land in their views, missing gradients, or scalars) -- a
+        data-parallel step that orders its collective behind an event recorded EARLIER must then wait for these copies too."""
         if not self.bound:
             parts = [p.grad.reshape(-1) for p in self.params] + [s.reshape(1).to(self.flat.dtype) for s in scalars]
             torch.cat(parts, out=self.flat)
-            return self.flat
+            return True
+        launched = False
         for p, view in zip(self.params, self.views):
             if p.grad is None:
                 view.zero_()
+                launched = True
             elif p.grad.data_ptr() != view.data_ptr():       # produced elsewhere (a library fallback): gather it
                 view.copy_(p.grad)
+                launched = True
         if scalars:
             torch.stack([s.reshape(()).to(self.flat.dtype) for s in scalars], out=self.extra[:len(scalars)])
-        return self.flat
+            launched = True
+        return launched
 
     def all_reduce(self):
         all_reduce_sum_(self.flat, self.force)
@@ -99,6 +106,65 @@ class GradBucket:
     def pack_all_reduce(self, *scalars):
         self.pack(*scalars)
         return self.all_reduce()
+
+
+_external_events = {}
+
+
+def external_events_order_graph_nodes(device):
+    """Does an EXTERNAL event recorded by a node inside a replayed HIP graph order work that another stream enqueues
+    behind `wait_event` -- and does that work start while the rest of the graph is still running?  Measured on the device
+    (once per device, a few milliseconds): graph = [slow producer writes a] -> external record -> [tail]; side stream:
+    wait(event); b = a.  True only if b is never stale.  The data-parallel step (bench.py) orders its gradient all-reduce
+    this way and falls back to waiting for the whole replay when the answer is no."""
+    key = torch.device(device).index
+    if key in _external_events:
+        return _external_events[key]
+    ok = False
+    try:
+        with torch.cuda.device(device):
+            big = torch.randn(2048, 2048, device=device)
+            out = torch.empty_like(big)
+            a = torch.zeros(1 << 16, device=device)
+            b = torch.zeros_like(a)
+            step = torch.zeros((), device=device)
+            ready = torch.cuda.Event(external=True)
+            side = torch.cuda.Stream(device=device)
+
+            def body():
+                step.add_(1.0)
+                for _ in range(4):
+                    torch.mm(big, big, out=out)            # a wait that does not wait reads the previous replay's value
+                a.copy_(step.expand_as(a))
+                ready.record()
+                for _ in range(4):
+                    torch.mm(big, big, out=out)
+
+            warm = torch.cuda.Stream(device=device)
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):
+                body()
+            torch.cuda.current_stream().wait_stream(warm)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()
+            torch.cuda.synchronize()
+            ok = True
+            for _ in range(8):
+                g.replay()
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    b.copy_(a)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                want = float(step)
+                ok = ok and float(b[0]) == want and float(b[-1]) == want
+    except Exception:       # no external events on this stack: the caller takes the whole-replay dependency
+        ok = False
+        torch.cuda.synchronize()
+    _external_events[key] = ok
+    return ok
 
 
 def barrier():

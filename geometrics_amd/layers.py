@@ -234,6 +234,63 @@ class deferred_parameter_gradients:
         global defer_parameter_gradients
         defer_parameter_gradients = self.prev
         return False
+# ---- the input gradient of a layer whose input is a LEAF, issued AFTER the parameter gradients of the pass are final ------
+# Data-parallel steps (bench.py, N > 1): the only thing the gradient all-reduce has to wait for is the end-of-pass reduction
+# launch; the first layer's input gradient dX = G . W^T (65 us at the BASELINE shard, a third of the all-reduce window an
+# 8-GPU ring needs) is needed by nobody before backward() returns -- its consumer is the leaf's .grad.  Inside
+# `late_input_gradients()` such a product is therefore postponed like the parameter-gradient reductions: the node hands
+# autograd the (not yet written) gradient buffer, and the end-of-pass callback launches the product AFTER the reduction
+# launch and after `parameter_gradients_ready` callbacks have run -- which is where a data-parallel step records the event
+# its collective waits for, so that the all-reduce travels while the product runs.  Same safeguards as the other deferrals
+# (leaf without hooks or an existing .grad, a single consumer, an engine-run pass); opt-in, nothing else uses it.
+late_input_gradient_products = False
+_pending_late = {}        # autograd graph-task id -> [(g2, w2, grad_x alias, stream, input ref)]
+parameter_gradients_ready = []   # callables run by the end-of-pass callback right after the reduction launch(es)
+
+
+class late_input_gradients:
+    """Context manager around forward + backward (see above); `on_parameter_gradients` = a callable run inside the
+    end-of-pass callback once every parameter gradient of the pass has been launched, before the postponed products."""
+
+    def __init__(self, on_parameter_gradients=None, enabled=True):
+        self.enabled, self.hook = enabled, on_parameter_gradients
+
+    def __enter__(self):
+        global late_input_gradient_products
+        self.prev = late_input_gradient_products
+        late_input_gradient_products = self.enabled
+        if self.hook is not None:
+            parameter_gradients_ready.append(self.hook)
+        return self
+
+    def __exit__(self, *exc):
+        global late_input_gradient_products
+        late_input_gradient_products = self.prev
+        if self.hook is not None:
+            parameter_gradients_ready.remove(self.hook)
+        return False
+
+
+def _may_postpone_input_gradient(x):
+    """A leaf nobody can observe before backward() returns: no hooks, no gradient to accumulate into, an engine-run
+    first-order pass, deferral of the parameter gradients active (the flush this rides on)."""
+    if not (late_input_gradient_products and defer_parameter_gradients) or not hasattr(torch._C, "_current_graph_task_id"):
+        return False
+    if torch._C._current_graph_task_id() < 0 or torch.is_grad_enabled():
+        return False
+    return (x.is_leaf and x.grad is None and not x._backward_hooks
+            and not getattr(x, "_post_accumulate_grad_hooks", None))
+
+
+def _flush_late(task):
+    for hook in list(parameter_gradients_ready):
+        hook()
+    for g2, w2, out, stream, x_ref in _pending_late.pop(task, []):
+        with torch.cuda.stream(stream), torch.no_grad():
+            torch.mm(g2, w2.t(), out=out)
+        _check_landed(x_ref, out)
+
+
 _pending_colsums = {}     # autograd graph-task id -> [(partials, rows, cols, out alias, stream)]
 _pending_reduce = {}      # autograd graph-task id -> [(rows, cin, c, workspace, dW alias, stream, param ref)]: weight-gradient partials
 # bias parameter -> the live autograd nodes that produce a gradient for it.  A bias shared by two layers (or a layer applied
@@ -303,11 +360,19 @@ def _register_flush(task):
         _flush_registered.discard(stale)
         _pending_colsums.pop(stale, None)
         _pending_reduce.pop(stale, None)
+        _pending_late.pop(stale, None)
     _flush_registered.add(task)
     torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_pass(task))
 
 
 def _flush_pass(task):
+    try:
+        _flush_parameter_gradients(task)
+    finally:
+        _flush_late(task)      # the postponed input-gradient products: behind the reduction launch(es) and the ready-callbacks
+
+
+def _flush_parameter_gradients(task):
     _flush_registered.discard(task)
     red = _pending_reduce.get(task, [])
     cs = _pending_colsums.get(task, [])
@@ -745,13 +810,21 @@ class _DenseMM(torch.autograd.Function):
             return grad_x, grad_w
         ws = _dense_kernels.weight_workspace(rows, cin, c, x.device)
         grad_x = None
+        late = None
         if need_x and plan["pair"]:
             grad_x = torch.empty_like(x)
             _dense_kernels.backward_pair(x2, g2, w2, grad_x.view(rows, cin), ws)
         else:
-            if need_x:
+            if need_x and _may_postpone_input_gradient(x):
+                grad_x = torch.empty_like(x)      # written by the end-of-pass callback, behind the reduction launch
+                late = (g2, w2, _alias(grad_x).view(rows, cin), torch.cuda.current_stream(x.device), weakref.ref(x))
+            elif need_x:
                 grad_x = torch.matmul(g2, w2.t()).view(x.shape)
             _dense_kernels.backward_weight_partials(x2, g2, ws)
+        if late is not None:
+            task = torch._C._current_graph_task_id()
+            _pending_late.setdefault(task, []).append(late)
+            _register_flush(task)
         param = ctx.w_ref()
         grad_w = _gradient_buffer(param, w)
         if param is not None and _may_defer(param):

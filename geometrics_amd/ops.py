@@ -174,7 +174,7 @@ class SurfaceLoss(torch.autograd.Function):
     distances feed the F1 score and are not differentiable."""
 
     @staticmethod
-    def forward(ctx, verts, faces, gt, choices, u, v, two_sided, scale, points=None, tri_ws=None):
+    def forward(ctx, verts, faces, gt, choices, u, v, two_sided, scale, points=None, tri_ws=None, loss_out=None):
         verts_c = _f32(verts.detach(), "verts", 3, 3)
         gt_c = _f32(gt.detach(), "gt_points", 3, 3)
         faces = _lib.require(faces, "faces", torch.int64, 2, 3)
@@ -192,7 +192,12 @@ class SurfaceLoss(torch.autograd.Function):
         points = _f32(points.detach(), "points", 3, 3) if have_points else torch.empty(b, num, 3, **f32)
         if points.shape != (b, num, 3):
             raise RuntimeError("points must be [B,num,3] for the given draws")
-        out = torch.empty((), **f32)
+        if loss_out is None:
+            out = torch.empty((), **f32)
+        else:     # the caller's memory receives the loss (a data-parallel step: the tail of its all-reduce bucket -- no copy launch)
+            if not (loss_out.is_cuda and loss_out.device == dev and loss_out.dtype == torch.float32 and loss_out.numel() == 1):
+                raise RuntimeError("loss_out must be ONE fp32 element on the mesh batch's device")
+            out = loss_out.detach().view(())
         sq_gt, sq_pred = torch.empty(b, n_gt, **f32), torch.empty(b, num, **f32)
         idx_p, idx_g = torch.empty(b, n_gt, **i32), torch.empty(b, num, **i32)
         if not two_sided:
@@ -283,7 +288,7 @@ class SurfaceLoss(torch.autograd.Function):
                               u.data_ptr(), v.data_ptr(), points.data_ptr(), n_gt, gt.data_ptr(), saved[6].data_ptr(),
                               index.data_ptr(), closest.data_ptr(), weights.data_ptr(), grad.data_ptr(),
                               ctx.scale / (b * num), ctx.scale / (b * n_gt), grad_verts.data_ptr())
-        return grad_verts, None, None, None, None, None, None, None, None, None
+        return grad_verts, None, None, None, None, None, None, None, None, None, None
 
 
 class Laplacian(torch.autograd.Function):

@@ -76,7 +76,7 @@ def _f_score(sq_to_pred, sq_to_gt, num):
     return float(f.mean())
 
 
-def _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, two_sided):
+def _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, two_sided, loss_out=None):
     faces = adj_info["faces"]
     points = tri_ws = None
     if draws is None:   # one kernel draws AND gathers the points (and, for the one-sided loss, prepares the triangle
@@ -89,21 +89,23 @@ def _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, two_sided):
     else:
         choices, u, v = draws
     loss, sq_gt, sq_pred = ops.SurfaceLoss.apply(pred_vert, faces, gt_points, choices, u, v, two_sided, LOSS_SCALE,
-                                                 points, tri_ws)
+                                                 points, tri_ws, loss_out)
     if f1:
         return loss, _f_score(sq_gt, sq_pred, num)
     return loss
 
 
-def batch_point_to_point(pred_vert, adj_info, gt_points, num=1000, f1=False, draws=None):
+def batch_point_to_point(pred_vert, adj_info, gt_points, num=1000, f1=False, draws=None, loss_out=None):
     """Two-sided Chamfer loss between sampled surface points and gt (reference utils.py:393-438).
-    One fused autograd node (ops.SurfaceLoss); `draws` replays pre-drawn randoms."""
-    return _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, True)
+    One fused autograd node (ops.SurfaceLoss); `draws` replays pre-drawn randoms; `loss_out` (one fp32 device element)
+    receives the loss -- the returned tensor aliases it (a data-parallel step points it at its all-reduce bucket)."""
+    return _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, True, loss_out)
 
 
-def batch_point_to_surface(pred_vert, adj_info, gt_points, num=1000, f1=False, draws=None):
-    """Chamfer (prediction -> gt) + point-to-surface (gt -> mesh) loss (reference utils.py:441-502)."""
-    return _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, False)
+def batch_point_to_surface(pred_vert, adj_info, gt_points, num=1000, f1=False, draws=None, loss_out=None):
+    """Chamfer (prediction -> gt) + point-to-surface (gt -> mesh) loss (reference utils.py:441-502); `draws`, `loss_out`
+    as for batch_point_to_point."""
+    return _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, False, loss_out)
 
 
 def calc_point_to_line(p, triangles, point_options):

@@ -36,6 +36,7 @@ def run(rank, world, port, total_meshes, steps, out, activation="relu", lr=1e-4)
         wl.run()
         torch.cuda.synchronize()
         losses.append(wl.mean_loss())
+    wl.finish()                        # N > 1: the Adam step of the last iteration is still owed (it opens the next one)
     if world > 1:                      # the reduced bucket of the last step, scaled as Adam consumed it
         grads = (wl.bucket.flat[:wl.bucket.numel] / world).cpu().numpy()
     else:
@@ -63,13 +64,14 @@ def run_rccl_single(port, total_meshes, steps, out):
     wl = bench.Workload(dev, 0, total_meshes, force_dp=True)
     assert wl.bucket is not None and wl.bucket.force
     wl.capture()
-    assert len(wl.graphs) == 2
+    assert len(wl.graphs) == 1 and wl.pending          # ONE graph per step; it opens with the Adam step still owed
     losses = []
     for _ in range(steps):
         wl.run()
         torch.cuda.synchronize()
         losses.append(wl.mean_loss())
-    out.put({"params": _flat(wl.stack.parameters()), "grads": wl.bucket.flat[:wl.bucket.numel].cpu().numpy(),
+    wl.finish()
+    out.put({"overlap": bool(wl.overlap and not wl.packed_late),"params": _flat(wl.stack.parameters()), "grads": wl.bucket.flat[:wl.bucket.numel].cpu().numpy(),
              "losses": losses, "steps_taken": wl.opt.step_count})
     torch.distributed.destroy_process_group()
 
@@ -96,6 +98,6 @@ def run_serial(shards, total_meshes, steps, warm, out):
             wl.opt.step(summed, grad_scale=1.0 / shards)
         torch.cuda.synchronize()
         if it >= warm:
-            losses.append(float(tail / sum((wl.count for wl in wls[1:]), wls[0].count)))
+            losses.append(float(tail) / sum(wl.batch for wl in wls))
     out.put({"params": _flat(wls[0].stack.parameters()), "grads": _flat(summed) / shards, "losses": losses,
              "steps_taken": wls[0].opt.step_count})

@@ -213,8 +213,10 @@ def test_bound_gradient_bucket_gathers_only_what_did_not_land_in_it():
     a.grad.fill_(1.5)
     assert layers._gradient_buffer(a, a).data_ptr() != bucket.views[0].data_ptr()       # accumulating: never onto the old gradient
     b.grad = torch.full((4,), 2.5)                 # a gradient from somewhere else (library fallback)
-    flat = bucket.pack(torch.tensor(7.0), torch.tensor(8.0))
-    assert flat.tolist() == [1.5] * 6 + [2.5] * 4 + [0.0] * 5 + [7.0, 8.0]
+    assert bucket.pack(torch.tensor(7.0), torch.tensor(8.0)) is True      # it had to launch copies: reported to the caller
+    assert bucket.flat.tolist() == [1.5] * 6 + [2.5] * 4 + [0.0] * 5 + [7.0, 8.0]
+    b.grad, c.grad = bucket.views[1].detach(), bucket.views[2].detach()
+    assert bucket.pack() is False                                          # everything in place: nothing to launch
     with pytest.raises(ValueError):
         layers.bind_gradient_targets([a], [torch.zeros(3, 2)])
     layers.bind_gradient_targets([a, b, c], [None, None, None])

@@ -758,6 +758,49 @@ def test_a_layer_applied_twice_keeps_both_gradients_under_bound_gradient_targets
         layers.bind_gradient_targets(params, [None] * len(params))
 
 
+def test_late_input_gradient_is_the_same_product_issued_behind_the_reduction_launch(gpu):
+    """layers.late_input_gradients(): the first layer's input gradient dX = G . W^T (its consumer is a LEAF's .grad) is
+    launched by the end-of-pass callback, AFTER the reduction launch that finishes the parameter gradients and after the
+    `on_parameter_gradients` callback (where a data-parallel step records the event its all-reduce waits for).  Same
+    product, same library kernel: bit-identical to the immediate path; the callback runs exactly once per pass, with every
+    parameter gradient of the pass already launched; a leaf with a hook or an existing .grad takes the immediate path."""
+    torch.manual_seed(11)
+    V, Fc = meshgen.icosphere(3)
+    adj = utils.adj_init(torch.from_numpy(Fc).to(gpu))["adj"]
+    stack = torch.nn.ModuleList([layers.Batch_Image_ZERON_GCNGCN(963, 192), layers.Batch_Image_ZERON_GCNGCN(192, 192)]).to(gpu)
+    x = torch.randn(4, V.shape[0], 963, device=gpu, requires_grad=True)
+    g_out = torch.randn(4, V.shape[0], 192, device=gpu)
+    calls = []
+
+    def run(late, prepare=None):
+        for p_ in stack.parameters():
+            p_.grad = None
+        x.grad = None
+        calls.clear()
+        if prepare:
+            prepare()
+        hook = lambda: calls.append(len(layers._pending_reduce) + len(layers._pending_colsums))
+        with layers.deferred_parameter_gradients(), layers.late_input_gradients(hook, enabled=late):
+            stack[1](stack[0](x, adj, F.relu), adj, F.relu).backward(g_out)
+        assert not layers._pending_late and not layers._pending_reduce
+        return x.grad.clone(), [p_.grad.clone() for p_ in stack.parameters()]
+
+    now_x, now_p = run(False)
+    assert calls == [0]                                   # the callback still runs once per pass (the event must be recorded)
+    late_x, late_p = run(True)
+    assert calls == [0]                                   # ... with nothing left pending: the reduction launch is out
+    assert torch.equal(late_x, now_x)
+    for a, b in zip(late_p, now_p):
+        assert torch.equal(a, b)
+    seen = []
+    h = x.register_hook(lambda gr: seen.append(gr.clone()))
+    hook_x, _ = run(True)                                 # somebody reads the gradient inside the pass: immediate product
+    h.remove()
+    assert torch.equal(seen[0], now_x) and torch.equal(hook_x, now_x)
+    acc_x, _ = run(True, lambda: setattr(x, "grad", torch.ones_like(x)))     # accumulation reads it at once too
+    assert torch.equal(acc_x, now_x + 1.0)
+
+
 def test_weight_gradients_of_equal_layers_come_from_one_batched_product(gpu):
     """Inside layers.weight_gradient_batching() the weight gradients of a stack are postponed to the end of the backward
     pass and runs of equal layers are issued as ONE strided-batched product over stacked activation / gradient buffers:

@@ -1,6 +1,7 @@
-"""The N > 1 step sequence on ONE GPU (1-rank RCCL group): graph A (forward + backward into the bucket) -> eager all-reduce of
-the flat bucket -> Adam on the bucket (eager launch; GEOM_EAGER_DP_UPDATE=0: graph B).  Prints ms per step beside the N = 1 single-graph step -- the fixed cost the
-data-parallel path adds before any link time.  GPU box only:  python tools/time_force_dp.py"""
+"""The N > 1 step sequence on ONE GPU (1-rank RCCL group): ONE graph per step = [Adam on the bucket the previous step
+all-reduced, forward, backward, reduction launch -> bucket, external event, first layer's input gradient] + the RCCL
+all-reduce issued behind the event from a side stream.  Prints ms per step beside the N = 1 single-graph step -- the fixed
+cost the data-parallel path adds before any link time.  GPU box only:  python tools/time_force_dp.py"""
 import os
 import sys
 import time
@@ -19,5 +20,6 @@ for force in (False, True):
     wl = bench.Workload(dev, 0, 8, force_dp=force)
     wl.capture()
     t = bench.time_steps(wl.run, 300, 30)
-    print("force_dp=%s: %d graph(s), %.4f ms per step" % (force, sum(g is not None for g in wl.graphs), t / 300 * 1e3), flush=True)
+    print("force_dp=%s: %d graph(s), overlap=%s, %.4f ms per step" % (force, len(wl.graphs), bool(wl.dp and wl.overlap and not wl.packed_late),
+                                                                      t / 300 * 1e3), flush=True)
 torch.distributed.destroy_process_group()
