@@ -84,7 +84,7 @@ class Workload:
         # layer's input-gradient product (postponed behind the reduction: layers.late_input_gradients) still runs; the Adam
         # step on the reduced bucket opens the NEXT step (`pending`), inside its graph: no eager launch between two replays
         self.side = torch.cuda.Stream(device=dev) if self.dp else None
-        self.grads_ready = torch.cuda.Event(external=True) if self.dp else None
+        self.grads_ready = gdist.GraphEvent(dev) if self.dp else None
         self.pending = False          # an all-reduced bucket is waiting for its Adam step
         self.packed_late = False      # pack() had to launch copies behind the ready-event (a gradient that did not land in its view)
 
@@ -138,7 +138,7 @@ class Workload:
             if self.packed_late:
                 self.side.wait_stream(main)                 # a late copy into the bucket: wait for everything queued so far
             else:
-                self.side.wait_event(self.grads_ready)
+                self.grads_ready.wait(self.side)
             self.bucket.all_reduce()
         main.wait_stream(self.side)
         self.pending = True

@@ -108,6 +108,43 @@ class GradBucket:
         return self.all_reduce()
 
 
+class GraphEvent:
+    """An event that orders work OUTSIDE a replayed HIP graph behind a node in the MIDDLE of it: `record()` on a capturing
+    stream becomes an external event-record node (geom_event_record: hipEventRecordExternal), `wait(stream)` makes a
+    stream outside the graph wait for the most recently enqueued record.  (torch.cuda.Event(external=True) is refused on
+    ROCm builds, hence the raw HIP handles through the C ABI.)  Outside a capture: an ordinary event."""
+
+    def __init__(self, device):
+        import ctypes
+        from . import _lib
+        self.device = torch.device(device)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().geom_event_create(ctypes.byref(handle)), "geom_event_create")
+        self.handle = handle
+
+    def record(self, stream=None):
+        from . import _lib
+        stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().geom_event_record(self.handle, stream.cuda_stream), "geom_event_record")
+
+    def wait(self, stream=None):
+        from . import _lib
+        stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().geom_stream_wait_event(stream.cuda_stream, self.handle), "geom_stream_wait_event")
+
+    def __del__(self):
+        try:
+            from . import _lib
+            if self.handle:
+                _lib.lib().geom_event_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 _external_events = {}
 
 
@@ -128,7 +165,7 @@ def external_events_order_graph_nodes(device):
             a = torch.zeros(1 << 16, device=device)
             b = torch.zeros_like(a)
             step = torch.zeros((), device=device)
-            ready = torch.cuda.Event(external=True)
+            ready = GraphEvent(device)
             side = torch.cuda.Stream(device=device)
 
             def body():
@@ -154,7 +191,7 @@ def external_events_order_graph_nodes(device):
             for _ in range(8):
                 g.replay()
                 with torch.cuda.stream(side):
-                    side.wait_event(ready)
+                    ready.wait(side)
                     b.copy_(a)
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()

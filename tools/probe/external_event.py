@@ -6,7 +6,12 @@ Correct ordering: b == step every time, and the copy finishes BEFORE the tail do
 import sys
 import time
 
+import os
+
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from geometrics_amd.dist import GraphEvent  # noqa: E402
 
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
@@ -15,7 +20,7 @@ out = torch.empty_like(big)
 a = torch.zeros(1 << 20, device=dev)
 b = torch.zeros_like(a)
 step = torch.zeros((), device=dev)
-ready = torch.cuda.Event(external=True)
+ready = GraphEvent(dev)
 side = torch.cuda.Stream()
 
 def body():
@@ -42,7 +47,7 @@ for it in range(50):
     g.replay()
     done_copy, done_tail = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(side):
-        side.wait_event(ready)
+        ready.wait(side)
         b.copy_(a)
         done_copy.record()
     done_tail.record()
