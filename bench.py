@@ -80,13 +80,15 @@ class Workload:
         self.loss = None
         self.graphs = None
         # N > 1 choreography: the all-reduce is issued from `side`, which waits only for `grads_ready` --
-        # recorded inside the backward pass right behind the reduction launch -- so the collective travels while the first
-        # layer's input-gradient product (postponed behind the reduction: layers.late_input_gradients) still runs; the Adam
-        # step on the reduced bucket opens the NEXT step (`pending`), inside its graph: no eager launch between two replays
+        # recorded right behind the end-of-pass reduction launch -- so the collective travels while the first layer's
+        # input-gradient product (postponed behind the reduction: layers.late_input_gradients) still runs; the Adam step on
+        # the reduced bucket opens the NEXT step (`pending`), inside its graph: no eager launch between two replays
         self.side = torch.cuda.Stream(device=dev) if self.dp else None
-        self.grads_ready = gdist.GraphEvent(dev) if self.dp else None
+        self.grads_ready = torch.cuda.Event() if self.dp else None
         self.pending = False          # an all-reduced bucket is waiting for its Adam step
         self.packed_late = False      # pack() had to launch copies behind the ready-event (a gradient that did not land in its view)
+        self.ready_recorded = False
+        self._splitting = None        # (graph A, graph B) while capture() records the step: the pass is cut behind the reduction launch
 
     def positions(self):
         h = self.feat
@@ -124,22 +126,40 @@ class Workload:
             self.packed_late = self.bucket.pack() or not self.ready_recorded
 
     def _parameter_gradients_ready(self):
-        """Called inside the backward pass, right behind the end-of-pass reduction launch (which wrote the bucket)."""
-        self.grads_ready.record()
+        """Called inside the backward pass (end-of-pass callback), right behind the reduction launch that wrote the bucket
+        and in front of the postponed input-gradient product.  Eager step: record the event the collective waits for.
+        While capture() records the step: END graph A here and BEGIN graph B -- the collective is issued between their
+        replays (an event-record node inside ONE graph would do, but this stack refuses external events during capture:
+        tools/probe/external_event.py)."""
+        if self._splitting is not None:
+            ga, gb = self._splitting
+            ga.capture_end()
+            gb.capture_begin(pool=ga.pool())
+            self._splitting = None
+        else:
+            self.grads_ready.record()
         self.ready_recorded = True
 
-    def exchange(self):
+    def exchange(self, tail=None):
         """ONE all-reduce per step: 259 200 gradients + the shard's loss (1.04 MB), issued from the side stream behind the
-        event of the reduction launch; the launch stream then waits for it (before the next step's Adam)."""
+        event of the reduction launch; `tail` (graph B: the postponed input gradient) is replayed on the launch stream
+        meanwhile; the launch stream then waits for the collective (before the next step's Adam)."""
         if not self.dp:
             return
         main = torch.cuda.current_stream()
+        if tail is not None and not self.packed_late:
+            self.grads_ready.record()                       # between the two replays = behind the reduction launch
+        elif tail is not None:
+            tail.replay()                                   # a late copy into the bucket sits in graph B: no overlap
+            tail = None
         with torch.cuda.stream(self.side):
             if self.packed_late:
-                self.side.wait_stream(main)                 # a late copy into the bucket: wait for everything queued so far
+                self.side.wait_stream(main)                 # wait for everything queued so far
             else:
-                self.grads_ready.wait(self.side)
+                self.side.wait_event(self.grads_ready)
             self.bucket.all_reduce()
+        if tail is not None:
+            tail.replay()
         main.wait_stream(self.side)
         self.pending = True
 
@@ -167,13 +187,11 @@ class Workload:
         return float(self.loss.detach())
 
     def capture(self, warm=3):
-        """Record the step into a HIP graph so that no python runs between its launches (library GEMMs, our C-ABI kernels,
-        Adam).  N = 1: the whole step.  N > 1: [Adam of the previous step, forward, backward, reduction -> bucket, external
-        event, first layer's input gradient]; the collective itself stays OUTSIDE the captured region (nothing depends on
-        RCCL's graph-capture support): it is issued after the replay from a side stream that waits for the graph's event
-        node.  Whether such an event orders work outside the graph is checked on the device first
-        (gdist.external_events_order_graph_nodes); if not, the side stream waits for the whole replay instead (correct,
-        no overlap)."""
+        """Record the step into HIP graphs so that no python runs between its launches (library GEMMs, our C-ABI kernels,
+        Adam).  N = 1: ONE graph, the whole step.  N > 1: graph A = [Adam of the previous step, forward, backward, reduction
+        launch -> bucket], graph B = [the first layer's input gradient]; the collective itself stays OUTSIDE the captured
+        region (nothing depends on RCCL's graph-capture support): it is issued between the two replays from a side stream and
+        runs beside graph B."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -181,32 +199,47 @@ class Workload:
                 self.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if self.dp and not gdist.external_events_order_graph_nodes(self.feat.device):
-            print("bench.py: external events do not order graph nodes on this stack; the all-reduce waits for the whole "
-                  "replay (no overlap with the input-gradient product)", file=sys.stderr)
-            self.overlap = False
-        owed = self.pending
-        if self.dp and not owed:
+        if not self.dp:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.forward_backward(step_in_backward=True)
+                self.update()
+            self.graphs = (g,)
+            return
+        if not self.pending:
             raise RuntimeError("capture() of a data-parallel step needs at least one warm-up step: the captured step opens "
                                "with the Adam update of the step before it")
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.forward_backward(step_in_backward=not self.dp)
-            if not self.dp:
-                self.update()
-        self.pending = owed               # capturing executed nothing: the update recorded at the graph's head is still owed
-        if self.dp and not self.overlap:
-            self.packed_late = True       # exchange(): wait_stream(main) instead of the event
-        self.graphs = (g,)
-
-    overlap = True
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        with torch.cuda.stream(cap):
+            ga.capture_begin()
+            self._splitting = (ga, gb)
+            try:
+                self.forward_backward()
+            except BaseException:
+                (ga if self._splitting is not None else gb).capture_end()
+                self._splitting = None
+                raise
+            if self._splitting is not None:      # the pass never reached the callback: nothing to overlap with
+                ga.capture_end()
+                self._splitting, gb = None, None
+            else:
+                gb.capture_end()
+        torch.cuda.current_stream().wait_stream(cap)
+        self.pending = True               # capturing executed nothing: the update recorded at the head of graph A is still owed
+        self.graphs = (ga, gb)
 
     def run(self):
         if self.graphs is None:
             self.step()
         else:
             self.graphs[0].replay()
-            self.exchange()
+            if self.dp:
+                self.exchange(self.graphs[1])
 
 
 def settle_clocks(dev, ms):

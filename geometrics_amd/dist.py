@@ -108,102 +108,6 @@ class GradBucket:
         return self.all_reduce()
 
 
-class GraphEvent:
-    """An event that orders work OUTSIDE a replayed HIP graph behind a node in the MIDDLE of it: `record()` on a capturing
-    stream becomes an external event-record node (geom_event_record: hipEventRecordExternal), `wait(stream)` makes a
-    stream outside the graph wait for the most recently enqueued record.  (torch.cuda.Event(external=True) is refused on
-    ROCm builds, hence the raw HIP handles through the C ABI.)  Outside a capture: an ordinary event."""
-
-    def __init__(self, device):
-        import ctypes
-        from . import _lib
-        self.device = torch.device(device)
-        handle = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().geom_event_create(ctypes.byref(handle)), "geom_event_create")
-        self.handle = handle
-
-    def record(self, stream=None):
-        from . import _lib
-        stream = torch.cuda.current_stream(self.device) if stream is None else stream
-        with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().geom_event_record(self.handle, stream.cuda_stream), "geom_event_record")
-
-    def wait(self, stream=None):
-        from . import _lib
-        stream = torch.cuda.current_stream(self.device) if stream is None else stream
-        with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().geom_stream_wait_event(stream.cuda_stream, self.handle), "geom_stream_wait_event")
-
-    def __del__(self):
-        try:
-            from . import _lib
-            if self.handle:
-                _lib.lib().geom_event_destroy(self.handle)
-                self.handle = None
-        except Exception:
-            pass
-
-
-_external_events = {}
-
-
-def external_events_order_graph_nodes(device):
-    """Does an EXTERNAL event recorded by a node inside a replayed HIP graph order work that another stream enqueues
-    behind `wait_event` -- and does that work start while the rest of the graph is still running?  Measured on the device
-    (once per device, a few milliseconds): graph = [slow producer writes a] -> external record -> [tail]; side stream:
-    wait(event); b = a.  True only if b is never stale.  The data-parallel step (bench.py) orders its gradient all-reduce
-    this way and falls back to waiting for the whole replay when the answer is no."""
-    key = torch.device(device).index
-    if key in _external_events:
-        return _external_events[key]
-    ok = False
-    try:
-        with torch.cuda.device(device):
-            big = torch.randn(2048, 2048, device=device)
-            out = torch.empty_like(big)
-            a = torch.zeros(1 << 16, device=device)
-            b = torch.zeros_like(a)
-            step = torch.zeros((), device=device)
-            ready = GraphEvent(device)
-            side = torch.cuda.Stream(device=device)
-
-            def body():
-                step.add_(1.0)
-                for _ in range(4):
-                    torch.mm(big, big, out=out)            # a wait that does not wait reads the previous replay's value
-                a.copy_(step.expand_as(a))
-                ready.record()
-                for _ in range(4):
-                    torch.mm(big, big, out=out)
-
-            warm = torch.cuda.Stream(device=device)
-            warm.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(warm):
-                body()
-            torch.cuda.current_stream().wait_stream(warm)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                body()
-            torch.cuda.synchronize()
-            ok = True
-            for _ in range(8):
-                g.replay()
-                with torch.cuda.stream(side):
-                    ready.wait(side)
-                    b.copy_(a)
-                torch.cuda.current_stream().wait_stream(side)
-                torch.cuda.synchronize()
-                want = float(step)
-                ok = ok and float(b[0]) == want and float(b[-1]) == want
-    except Exception:       # no external events on this stack: the caller takes the whole-replay dependency
-        ok = False
-        torch.cuda.synchronize()
-    _external_events[key] = ok
-    return ok
-
-
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GEOM_ABI_VERSION 7
+#define GEOM_ABI_VERSION 6
 
 /* argument errors */
 #define GEOM_EINVAL   (-1) /* bad size / null pointer */
@@ -51,18 +51,6 @@ extern "C" {
 int geom_abi_version(void);
 /* static string for a code returned by any entry point */
 const char *geom_strerror(int code);
-
-/* ---- stream / event utilities of the data-parallel step (host only; no reference counterpart: the reference is
- * single-GPU) ----------------------------------------------------------------------------------------------------
- * `event` = a hipEvent_t, `stream` = a hipStream_t, as void*.  geom_event_record on a stream that is being CAPTURED
- * records an EXTERNAL event (hipEventRecordExternal): an event-record node in the middle of the graph that a stream
- * outside the graph can wait for (geom_stream_wait_event, issued after the graph launch) -- how the gradient
- * all-reduce starts behind the end-of-pass reduction launch while the rest of the replayed step is still running.
- * Outside a capture it is a plain hipEventRecord.  Return: hipError_t as int. */
-int geom_event_create(void **event);
-int geom_event_destroy(void *event);
-int geom_event_record(void *event, void *stream);
-int geom_stream_wait_event(void *stream, void *event);
 
 /* ---- Chamfer nearest neighbour, both directions in one launch --------------------
  * Replaces ChamferDistanceKernelLauncher (chamfer_distance/chamfer_distance.cpp:4-12,

@@ -30,7 +30,7 @@ def run(rank, world, port, total_meshes, steps, out, activation="relu", lr=1e-4)
     first, count = gdist.shard_range(total_meshes, rank, world)
     import torch.nn.functional as F
     wl = bench.Workload(dev, first, count, activation={"relu": F.relu, "elu": F.elu}[activation], lr=lr)
-    wl.capture()                       # N=1: one graph; N>1: graph A / eager all-reduce / graph B, as bench.py runs it
+    wl.capture()                       # N=1: one graph; N>1: graph A / all-reduce beside graph B, as bench.py runs it
     losses = []
     for _ in range(steps):
         wl.run()
@@ -50,8 +50,9 @@ def run(rank, world, port, total_meshes, steps, out, activation="relu", lr=1e-4)
 
 
 def run_rccl_single(port, total_meshes, steps, out):
-    """ONE rank, backend "nccl" (= RCCL) on cuda:0, bench.Workload forced onto its N > 1 sequence: graph A (forward +
-    backward + bucket pack) -> eager RCCL all-reduce of the flat bucket -> graph B (Adam on the bucket views)."""
+    """ONE rank, backend "nccl" (= RCCL) on cuda:0, bench.Workload forced onto its N > 1 sequence: graph A (Adam of the
+    previous step, forward, backward, reduction launch -> bucket) -> RCCL all-reduce of the flat bucket from the side
+    stream, beside graph B (the first layer's postponed input gradient)."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     import torch
     import bench
@@ -64,14 +65,14 @@ def run_rccl_single(port, total_meshes, steps, out):
     wl = bench.Workload(dev, 0, total_meshes, force_dp=True)
     assert wl.bucket is not None and wl.bucket.force
     wl.capture()
-    assert len(wl.graphs) == 1 and wl.pending          # ONE graph per step; it opens with the Adam step still owed
+    assert len(wl.graphs) == 2 and wl.graphs[1] is not None and wl.pending   # graph A opens with the Adam step still owed; B = the postponed product
     losses = []
     for _ in range(steps):
         wl.run()
         torch.cuda.synchronize()
         losses.append(wl.mean_loss())
     wl.finish()
-    out.put({"overlap": bool(wl.overlap and not wl.packed_late),"params": _flat(wl.stack.parameters()), "grads": wl.bucket.flat[:wl.bucket.numel].cpu().numpy(),
+    out.put({"overlap": not wl.packed_late, "params": _flat(wl.stack.parameters()), "grads": wl.bucket.flat[:wl.bucket.numel].cpu().numpy(),
              "losses": losses, "steps_taken": wl.opt.step_count})
     torch.distributed.destroy_process_group()
 

@@ -1,7 +1,8 @@
 """-m gpu: the REAL data-parallel step with two ranks.  Two processes share cuda:0 (gloo carries the collective; RCCL
 needs one GPU per rank), each runs bench.Workload on its contiguous shard of 16 meshes through bench.py's own N>1
-sequence (HIP graph A = forward + backward + bucket pack, eager all-reduce of the flat bucket with the [loss_sum,
-count] tail, HIP graph B = Adam with grad_scale = 1/world), and the result must equal ONE process stepping all 16
+sequence (HIP graph A = Adam of the previous step (grad_scale = 1/world) + forward + backward + the reduction launch that
+writes the flat bucket; the all-reduce of the bucket with the loss tail from a side stream, beside HIP graph B = the first
+layer's postponed input gradient), and the result must equal ONE process stepping all 16
 meshes: same samples (the sampler is keyed on the global mesh index), same mean loss, same parameters."""
 import socket
 
@@ -47,7 +48,7 @@ def _launch(world, activation="relu", lr=LR):
 
 @pytest.mark.timeout(600)
 def test_two_rank_step_equals_the_serial_two_shard_step_bitwise(gpu):
-    """Graph A / all-reduce / graph B on two ranks against one process that steps the same two 8-mesh shards in turn
+    """Graph A / all-reduce beside graph B on two ranks against one process that steps the same two 8-mesh shards in turn
     and sums their gradients: identical kernels and GEMM shapes per shard, a + b == b + a, x * 0.5 exact -- so every
     parameter, the averaged gradient and every step's mean loss must agree to the last bit."""
     two = _launch(2)
@@ -104,6 +105,7 @@ def test_rccl_all_reduce_between_the_two_graph_replays_equals_the_single_graph_s
     port2 = _free_port()
     plain = _collect(dist_step_worker.run, lambda n: [(0, 1, port2, 8, 5)], 1)
     assert rccl["steps_taken"] == plain["steps_taken"] == 5 + WARM
+    assert rccl["overlap"]                 # the collective was ordered behind the reduction launch only, not behind graph B
     assert rccl["losses"] == plain["losses"]
     np.testing.assert_array_equal(rccl["grads"], plain["grads"])
     np.testing.assert_array_equal(rccl["params"], plain["params"])

@@ -1,6 +1,6 @@
-"""The N > 1 step sequence on ONE GPU (1-rank RCCL group): ONE graph per step = [Adam on the bucket the previous step
-all-reduced, forward, backward, reduction launch -> bucket, external event, first layer's input gradient] + the RCCL
-all-reduce issued behind the event from a side stream.  Prints ms per step beside the N = 1 single-graph step -- the fixed
+"""The N > 1 step sequence on ONE GPU (1-rank RCCL group): graph A = [Adam on the bucket the previous step all-reduced,
+forward, backward, reduction launch -> bucket], the RCCL all-reduce issued from a side stream, graph B = [first layer's
+input gradient] beside it.  Prints ms per step beside the N = 1 single-graph step -- the fixed
 cost the data-parallel path adds before any link time.  GPU box only:  python tools/time_force_dp.py"""
 import os
 import sys
@@ -20,6 +20,6 @@ for force in (False, True):
     wl = bench.Workload(dev, 0, 8, force_dp=force)
     wl.capture()
     t = bench.time_steps(wl.run, 300, 30)
-    print("force_dp=%s: %d graph(s), overlap=%s, %.4f ms per step" % (force, len(wl.graphs), bool(wl.dp and wl.overlap and not wl.packed_late),
+    print("force_dp=%s: %d graph(s), overlap=%s, %.4f ms per step" % (force, len(wl.graphs), bool(wl.dp and wl.graphs[1] is not None and not wl.packed_late),
                                                                       t / 300 * 1e3), flush=True)
 torch.distributed.destroy_process_group()
