@@ -30,7 +30,7 @@ def _collect(target, args, nproc, tail=()):
     for p in procs:
         p.start()
     try:
-        result = out.get(timeout=240)          # read BEFORE joining: the reporting process blocks in put() until then
+        result = out.get(timeout=150)          # read BEFORE joining: the reporting process blocks in put() until then
         for p in procs:
             p.join(60)
             assert p.exitcode == 0, "worker failed (exit code %s)" % p.exitcode
