@@ -134,7 +134,7 @@ class Workload:
         if self._splitting is not None:
             ga, gb = self._splitting
             ga.capture_end()
-            gb.capture_begin(pool=ga.pool())
+            gb.capture_begin(pool=ga.pool(), capture_error_mode="relaxed")
             self._splitting = None
         else:
             self.grads_ready.record()
@@ -216,7 +216,9 @@ class Workload:
         gc.collect()
         torch.cuda.empty_cache()
         with torch.cuda.stream(cap):
-            ga.capture_begin()
+            # "relaxed": the end-of-pass callback may run on autograd's device thread, and a capture begun in any other mode
+            # must be ended by the thread that began it
+            ga.capture_begin(capture_error_mode="relaxed")
             self._splitting = (ga, gb)
             try:
                 self.forward_backward()
