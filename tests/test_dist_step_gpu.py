@@ -70,9 +70,12 @@ def test_two_rank_elu_step_equals_the_single_process_16_mesh_step_to_round_off(g
     two = _launch(2, "elu", 0.0)
     one = _launch(1, "elu", 0.0)
     assert two["steps_taken"] == one["steps_taken"] == STEPS + WARM
-    np.testing.assert_allclose(two["losses"], one["losses"], rtol=1e-5)
+    # (the loss is not a smooth function of round-off either: a surface sample whose uniform draw sits within an ulp of a
+    # face-area CDF boundary lands on the neighbouring face -- one of 48 000 samples moving is 1e-5 of the loss)
+    np.testing.assert_allclose(two["losses"], one["losses"], rtol=1e-4)
     scale = np.abs(one["grads"]).max()
-    assert np.abs(two["grads"] - one["grads"]).max() <= 1e-4 * scale
+    worst = np.abs(two["grads"] - one["grads"]).max() / scale
+    assert worst <= 1e-4, "gradient differs by %.2e of its scale" % worst
     np.testing.assert_array_equal(two["params"], one["params"])        # lr = 0: nobody moved
 
 
