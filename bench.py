@@ -35,6 +35,7 @@ from geometrics_amd.chamfer_distance import chamfer_nn  # noqa: E402
 from geometrics_amd.tri_distance import tri_distance_indexed  # noqa: E402
 
 V_LEVEL, S_PTS, G_PTS, FEAT, HID = 4, 3000, 3000, 963, 192
+DP_TAIL = os.environ.get("GEOM_DP_TAIL", "graph")   # N > 1: the postponed input-gradient product as graph B ("graph") or as an eager launch ("eager")
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector peak == f32 MFMA dense peak
 
@@ -115,7 +116,9 @@ class Workload:
         # so the bias / weight gradients of the pass are finished by ONE launch at its end -- which, in a single-process
         # step, applies Adam to them as well (step_in_backward: no optimiser launch of its own)
         self.ready_recorded = False
-        late = layers.late_input_gradients(self._parameter_gradients_ready) if self.dp else contextlib.nullcontext()
+        self.tail_jobs = [] if (self.dp and DP_TAIL == "eager") else None
+        late = (layers.late_input_gradients(self._parameter_gradients_ready, collect=self.tail_jobs) if self.dp
+                else contextlib.nullcontext())
         with layers.deferred_parameter_gradients(), late, (self.opt.in_backward() if step_in_backward else contextlib.nullcontext()):
             pos = self.positions()
             self.loss = utils.batch_point_to_surface(pos, self.info, self.gt, num=S_PTS,
@@ -134,7 +137,8 @@ class Workload:
         if self._splitting is not None:
             ga, gb = self._splitting
             ga.capture_end()
-            gb.capture_begin(pool=ga.pool(), capture_error_mode="relaxed")
+            if gb is not None:
+                gb.capture_begin(pool=ga.pool(), capture_error_mode="relaxed")
             self._splitting = None
         else:
             self.grads_ready.record()
@@ -147,10 +151,13 @@ class Workload:
         if not self.dp:
             return
         main = torch.cuda.current_stream()
+        if tail is None and self.tail_jobs:
+            tail = _EagerTail(self.tail_jobs)               # the postponed products as eager launches (GEOM_DP_TAIL=eager)
         if tail is not None and not self.packed_late:
-            self.grads_ready.record()                       # between the two replays = behind the reduction launch
+            if self.graphs is not None:                     # (an eager step recorded the event inside the pass already)
+                self.grads_ready.record()                   # between graph A and the tail = behind the reduction launch
         elif tail is not None:
-            tail.replay()                                   # a late copy into the bucket sits in graph B: no overlap
+            tail.replay()                                   # a late copy into the bucket sits behind the cut: no overlap
             tail = None
         with torch.cuda.stream(self.side):
             if self.packed_late:
@@ -209,7 +216,7 @@ class Workload:
         if not self.pending:
             raise RuntimeError("capture() of a data-parallel step needs at least one warm-up step: the captured step opens "
                                "with the Adam update of the step before it")
-        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        ga, gb = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if DP_TAIL == "graph" else None)
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
         import gc
@@ -229,8 +236,10 @@ class Workload:
             if self._splitting is not None:      # the pass never reached the callback: nothing to overlap with
                 ga.capture_end()
                 self._splitting, gb = None, None
-            else:
+            elif gb is not None:
                 gb.capture_end()
+            elif self.packed_late:
+                raise RuntimeError("a gradient did not land in the bucket: its copy would sit behind the captured region")
         torch.cuda.current_stream().wait_stream(cap)
         self.pending = True               # capturing executed nothing: the update recorded at the head of graph A is still owed
         self.graphs = (ga, gb)
@@ -242,6 +251,17 @@ class Workload:
             self.graphs[0].replay()
             if self.dp:
                 self.exchange(self.graphs[1])
+
+
+class _EagerTail:
+    """The postponed products of a step as eager launches (same interface as a graph: replay())."""
+
+    def __init__(self, jobs):
+        self.jobs = jobs
+
+    def replay(self):
+        for job in self.jobs:
+            job()
 
 
 def settle_clocks(dev, ms):

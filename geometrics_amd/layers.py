@@ -252,8 +252,11 @@ class late_input_gradients:
     """Context manager around forward + backward (see above); `on_parameter_gradients` = a callable run inside the
     end-of-pass callback once every parameter gradient of the pass has been launched, before the postponed products."""
 
-    def __init__(self, on_parameter_gradients=None, enabled=True):
-        self.enabled, self.hook = enabled, on_parameter_gradients
+    def __init__(self, on_parameter_gradients=None, enabled=True, collect=None):
+        """collect: a list -- the postponed products are NOT launched by the callback but appended to it as callables
+        (each launches one product into the gradient buffer autograd already holds); the caller launches them, e.g. after
+        issuing a collective.  They stay valid for as long as their tensors do (a captured step replays them every step)."""
+        self.enabled, self.hook, self.collect = enabled, on_parameter_gradients, collect
 
     def __enter__(self):
         global late_input_gradient_products
@@ -261,6 +264,8 @@ class late_input_gradients:
         late_input_gradient_products = self.enabled
         if self.hook is not None:
             parameter_gradients_ready.append(self.hook)
+        self.prev_collect = _late_collect[0]
+        _late_collect[0] = self.collect
         return self
 
     def __exit__(self, *exc):
@@ -268,6 +273,7 @@ class late_input_gradients:
         late_input_gradient_products = self.prev
         if self.hook is not None:
             parameter_gradients_ready.remove(self.hook)
+        _late_collect[0] = self.prev_collect
         return False
 
 
@@ -282,13 +288,29 @@ def _may_postpone_input_gradient(x):
             and not getattr(x, "_post_accumulate_grad_hooks", None))
 
 
+_late_collect = [None]
+
+
+def _late_product(g2, w2, out, stream):
+    def launch():
+        with torch.cuda.stream(stream), torch.no_grad():
+            torch.mm(g2, w2.t(), out=out)
+    return launch
+
+
 def _flush_late(task):
     for hook in list(parameter_gradients_ready):
         hook()
     for g2, w2, out, stream, x_ref in _pending_late.pop(task, []):
-        with torch.cuda.stream(stream), torch.no_grad():
-            torch.mm(g2, w2.t(), out=out)
-        _check_landed(x_ref, out)
+        launch = _late_product(g2, w2, out, stream)
+        if _late_collect[0] is None:
+            launch()
+            _check_landed(x_ref, out)
+            continue
+        _late_collect[0].append(launch)
+        x = x_ref()
+        if x is not None and x.grad is not None and x.grad.data_ptr() != out.data_ptr():      # the engine kept a clone
+            _late_collect[0].append(lambda x=x, out=out: x.grad.copy_(out.view_as(x.grad)))
 
 
 _pending_colsums = {}     # autograd graph-task id -> [(partials, rows, cols, out alias, stream)]
