@@ -35,7 +35,10 @@ from geometrics_amd.chamfer_distance import chamfer_nn  # noqa: E402
 from geometrics_amd.tri_distance import tri_distance_indexed  # noqa: E402
 
 V_LEVEL, S_PTS, G_PTS, FEAT, HID = 4, 3000, 3000, 963, 192
-DP_TAIL = os.environ.get("GEOM_DP_TAIL", "graph")   # N > 1: the postponed input-gradient product as graph B ("graph") or as an eager launch ("eager")
+# N > 1, how the collective gets in front of the postponed input-gradient product of the captured step: "event" = ONE graph
+# with an event-record node behind the reduction launch (gdist.capture_with_event); "graph" = two graphs, cut there;
+# "eager" = graph A + the product as an eager launch (measured: profiles/r04_dp_fixed_cost.txt)
+DP_TAIL = os.environ.get("GEOM_DP_TAIL", "event")
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector peak == f32 MFMA dense peak
 
@@ -90,6 +93,7 @@ class Workload:
         self.packed_late = False      # pack() had to launch copies behind the ready-event (a gradient that did not land in its view)
         self.ready_recorded = False
         self._splitting = None        # (graph A, graph B) while capture() records the step: the pass is cut behind the reduction launch
+        self._marking = False         # capture() records ONE graph and marks the place of the event node
 
     def positions(self):
         h = self.feat
@@ -134,7 +138,9 @@ class Workload:
         While capture() records the step: END graph A here and BEGIN graph B -- the collective is issued between their
         replays (an event-record node inside ONE graph would do, but this stack refuses external events during capture:
         tools/probe/external_event.py)."""
-        if self._splitting is not None:
+        if self._marking:
+            gdist.mark_event_here()       # capture_with_event turns the marker into the node that records grads_ready
+        elif self._splitting is not None:
             ga, gb = self._splitting
             ga.capture_end()
             if gb is not None:
@@ -154,8 +160,8 @@ class Workload:
         if tail is None and self.tail_jobs:
             tail = _EagerTail(self.tail_jobs)               # the postponed products as eager launches (GEOM_DP_TAIL=eager)
         if tail is not None and not self.packed_late:
-            if self.graphs is not None:                     # (an eager step recorded the event inside the pass already)
-                self.grads_ready.record()                   # between graph A and the tail = behind the reduction launch
+            if self.graphs is not None:                     # (an eager step recorded the event inside the pass already,
+                self.grads_ready.record()                   # a one-graph step records it by a node); here: between graph A and the tail
         elif tail is not None:
             tail.replay()                                   # a late copy into the bucket sits behind the cut: no overlap
             tail = None
@@ -216,7 +222,26 @@ class Workload:
         if not self.pending:
             raise RuntimeError("capture() of a data-parallel step needs at least one warm-up step: the captured step opens "
                                "with the Adam update of the step before it")
-        ga, gb = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if DP_TAIL == "graph" else None)
+        tail_mode = DP_TAIL
+        if tail_mode == "event":
+            self._marking = True
+            try:
+                g = gdist.capture_with_event(self.forward_backward, self.grads_ready)
+            except gdist.EventNodeUnavailable as exc:      # loudly, and on to the two-graph form
+                print("bench.py: no event-record node in the captured step (%s); cutting it into two graphs instead" % exc,
+                      file=sys.stderr)
+                tail_mode, g = "graph", None
+            finally:
+                self._marking = False
+            if g is not None:
+                if self.packed_late:
+                    raise RuntimeError("a gradient did not land in the bucket: its copy sits behind the event node")
+                self.pending = True       # capturing executed nothing: the update recorded at the graph's head is still owed
+                self.graphs = (g, None)
+                self.event_in_graph = True
+                return
+            self.pending = True
+        ga, gb = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if tail_mode == "graph" else None)
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
         import gc
@@ -243,6 +268,8 @@ class Workload:
         torch.cuda.current_stream().wait_stream(cap)
         self.pending = True               # capturing executed nothing: the update recorded at the head of graph A is still owed
         self.graphs = (ga, gb)
+
+    event_in_graph = False
 
     def run(self):
         if self.graphs is None:
