@@ -35,10 +35,6 @@ from geometrics_amd.chamfer_distance import chamfer_nn  # noqa: E402
 from geometrics_amd.tri_distance import tri_distance_indexed  # noqa: E402
 
 V_LEVEL, S_PTS, G_PTS, FEAT, HID = 4, 3000, 3000, 963, 192
-# N > 1, how the collective gets in front of the postponed input-gradient product of the captured step: "event" = ONE graph
-# with an event-record node behind the reduction launch (gdist.capture_with_event); "graph" = two graphs, cut there;
-# "eager" = graph A + the product as an eager launch (measured: profiles/r04_dp_fixed_cost.txt)
-DP_TAIL = os.environ.get("GEOM_DP_TAIL", "event")
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector peak == f32 MFMA dense peak
 
@@ -83,17 +79,16 @@ class Workload:
         self.opt = optim.FusedAdam(self.stack.parameters(), lr=lr)
         self.loss = None
         self.graphs = None
-        # N > 1 choreography: the all-reduce is issued from `side`, which waits only for `grads_ready` --
-        # recorded right behind the end-of-pass reduction launch -- so the collective travels while the first layer's
-        # input-gradient product (postponed behind the reduction: layers.late_input_gradients) still runs; the Adam step on
-        # the reduced bucket opens the NEXT step (`pending`), inside its graph: no eager launch between two replays
-        self.side = torch.cuda.Stream(device=dev) if self.dp else None
-        self.grads_ready = torch.cuda.Event() if self.dp else None
+        # N > 1 choreography: the all-reduce is issued right behind the end-of-pass reduction launch and
+        # travels on RCCL's stream while the first layer's input-gradient product (postponed behind the reduction:
+        # layers.late_input_gradients) runs on the launch stream; the Adam step on the reduced bucket opens the NEXT step
+        # (`pending`), inside its graph: no eager launch between two replays
         self.pending = False          # an all-reduced bucket is waiting for its Adam step
-        self.packed_late = False      # pack() had to launch copies behind the ready-event (a gradient that did not land in its view)
-        self.ready_recorded = False
+        self.work = None              # the collective in flight
+        self.packed_late = False      # pack() had to launch copies behind the reduction launch (a gradient that did not land in its view)
+        self.reached_cut = False
+        self.tail_jobs = None         # the postponed products of the pass (eager step: launched by exchange())
         self._splitting = None        # (graph A, graph B) while capture() records the step: the pass is cut behind the reduction launch
-        self._marking = False         # capture() records ONE graph and marks the place of the event node
 
     def positions(self):
         h = self.feat
@@ -119,8 +114,8 @@ class Workload:
         # nothing reads a parameter gradient before backward() returns (no hooks, no DDP: the gradients land in the bucket),
         # so the bias / weight gradients of the pass are finished by ONE launch at its end -- which, in a single-process
         # step, applies Adam to them as well (step_in_backward: no optimiser launch of its own)
-        self.ready_recorded = False
-        self.tail_jobs = [] if (self.dp and DP_TAIL == "eager") else None
+        self.reached_cut = False
+        self.tail_jobs = [] if (self.dp and self._splitting is None) else None     # eager step: exchange() launches them
         late = (layers.late_input_gradients(self._parameter_gradients_ready, collect=self.tail_jobs) if self.dp
                 else contextlib.nullcontext())
         with layers.deferred_parameter_gradients(), late, (self.opt.in_backward() if step_in_backward else contextlib.nullcontext()):
@@ -129,51 +124,39 @@ class Workload:
                                                      loss_out=self.bucket.extra if self.dp else None)
             self.loss.backward(self.seed_grad)              # explicit seed: no ones_like fill launch
         if self.dp:
-            # normally pack() launches nothing (everything was written in place) and the event sits behind the reduction launch
-            self.packed_late = self.bucket.pack() or not self.ready_recorded
+            # normally pack() launches nothing: everything was written in place by the reduction launch
+            self.packed_late = self.bucket.pack() or not self.reached_cut
 
     def _parameter_gradients_ready(self):
         """Called inside the backward pass (end-of-pass callback), right behind the reduction launch that wrote the bucket
-        and in front of the postponed input-gradient product.  Eager step: record the event the collective waits for.
-        While capture() records the step: END graph A here and BEGIN graph B -- the collective is issued between their
-        replays (an event-record node inside ONE graph would do, but this stack refuses external events during capture:
-        tools/probe/external_event.py)."""
-        if self._marking:
-            gdist.mark_event_here()       # capture_with_event turns the marker into the node that records grads_ready
-        elif self._splitting is not None:
+        and in front of the postponed input-gradient product.  While capture() records the step: END graph A here and BEGIN
+        graph B -- the collective is issued between their replays.  (ONE graph with an event-record node at this place
+        would be the natural form; measured and rejected)"""
+        if self._splitting is not None:
             ga, gb = self._splitting
             ga.capture_end()
-            if gb is not None:
-                gb.capture_begin(pool=ga.pool(), capture_error_mode="relaxed")
+            gb.capture_begin(pool=ga.pool(), capture_error_mode="relaxed")
             self._splitting = None
-        else:
-            self.grads_ready.record()
-        self.ready_recorded = True
+        self.reached_cut = True
 
     def exchange(self, tail=None):
-        """ONE all-reduce per step: 259 200 gradients + the shard's loss (1.04 MB), issued from the side stream behind the
-        event of the reduction launch; `tail` (graph B: the postponed input gradient) is replayed on the launch stream
-        meanwhile; the launch stream then waits for the collective (before the next step's Adam)."""
+        """ONE all-reduce per step: 259 200 gradients + the shard's loss (1.04 MB).  It is started behind what the launch
+        stream holds so far -- the reduction launch that wrote the bucket -- and runs on RCCL's stream while `tail` (graph B,
+        or the eager step's postponed products) runs on the launch stream; the launch stream then waits for the
+        collective, in front of the next step's Adam.  Two cross-stream dependencies per step, the same as a collective
+        that overlaps with nothing."""
         if not self.dp:
             return
-        main = torch.cuda.current_stream()
         if tail is None and self.tail_jobs:
-            tail = _EagerTail(self.tail_jobs)               # the postponed products as eager launches (GEOM_DP_TAIL=eager)
-        if tail is not None and not self.packed_late:
-            if self.graphs is not None:                     # (an eager step recorded the event inside the pass already,
-                self.grads_ready.record()                   # a one-graph step records it by a node); here: between graph A and the tail
-        elif tail is not None:
-            tail.replay()                                   # a late copy into the bucket sits behind the cut: no overlap
+            tail = _EagerTail(self.tail_jobs)
+        if tail is not None and self.packed_late:           # a late copy into the bucket sits behind the cut: no overlap
+            tail.replay()
             tail = None
-        with torch.cuda.stream(self.side):
-            if self.packed_late:
-                self.side.wait_stream(main)                 # wait for everything queued so far
-            else:
-                self.side.wait_event(self.grads_ready)
-            self.bucket.all_reduce()
+        work = self.bucket.all_reduce_async()
         if tail is not None:
             tail.replay()
-        main.wait_stream(self.side)
+        if work is not None:
+            work.wait()
         self.pending = True
 
     def update(self):
@@ -222,26 +205,7 @@ class Workload:
         if not self.pending:
             raise RuntimeError("capture() of a data-parallel step needs at least one warm-up step: the captured step opens "
                                "with the Adam update of the step before it")
-        tail_mode = DP_TAIL
-        if tail_mode == "event":
-            self._marking = True
-            try:
-                g = gdist.capture_with_event(self.forward_backward, self.grads_ready)
-            except gdist.EventNodeUnavailable as exc:      # loudly, and on to the two-graph form
-                print("bench.py: no event-record node in the captured step (%s); cutting it into two graphs instead" % exc,
-                      file=sys.stderr)
-                tail_mode, g = "graph", None
-            finally:
-                self._marking = False
-            if g is not None:
-                if self.packed_late:
-                    raise RuntimeError("a gradient did not land in the bucket: its copy sits behind the event node")
-                self.pending = True       # capturing executed nothing: the update recorded at the graph's head is still owed
-                self.graphs = (g, None)
-                self.event_in_graph = True
-                return
-            self.pending = True
-        ga, gb = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if tail_mode == "graph" else None)
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
         import gc
@@ -261,15 +225,11 @@ class Workload:
             if self._splitting is not None:      # the pass never reached the callback: nothing to overlap with
                 ga.capture_end()
                 self._splitting, gb = None, None
-            elif gb is not None:
+            else:
                 gb.capture_end()
-            elif self.packed_late:
-                raise RuntimeError("a gradient did not land in the bucket: its copy would sit behind the captured region")
         torch.cuda.current_stream().wait_stream(cap)
         self.pending = True               # capturing executed nothing: the update recorded at the head of graph A is still owed
         self.graphs = (ga, gb)
-
-    event_in_graph = False
 
     def run(self):
         if self.graphs is None:

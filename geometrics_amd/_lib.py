@@ -16,7 +16,7 @@ FLAG_FIX_REGION6 = 2
 FLAG_TRI_BRUTE_FORCE = 4
 FLAG_NN_FMA = 8
 FLAG_TRI_WS_READY = 16
-ABI_VERSION = 7
+ABI_VERSION = 6
 EUNSUPPORTED = -3
 ADAM_MAX_TENSORS = 64
 COLSUM_MAX_JOBS = 32
@@ -60,8 +60,6 @@ _f = ctypes.c_float
 
 # name -> argtypes; every function returns int (0 ok / hipError_t / negative GEOM_E*)
 _SIGNATURES = {
-    "geom_graph_marker": [_vp],
-    "geom_graph_event_at_marker": [_vp, _vp, ctypes.POINTER(_i)],
     "geom_chamfer_nn_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _u, _vp],
     "geom_chamfer_nn_culled_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp],
     "geom_tri_distance_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp],

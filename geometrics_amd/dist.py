@@ -103,48 +103,17 @@ class GradBucket:
         all_reduce_sum_(self.flat, self.force)
         return self.views
 
+    def all_reduce_async(self):
+        """Start the all-reduce behind everything queued on the CURRENT stream so far and return at once: work queued on
+        this stream afterwards runs BESIDE the collective (RCCL has its own stream); `wait()` on the returned handle orders
+        the current stream behind the collective (None: nothing was issued -- a single process)."""
+        if dist.is_initialized() and (dist.get_world_size() > 1 or self.force):
+            return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
+        return None
+
     def pack_all_reduce(self, *scalars):
         self.pack(*scalars)
         return self.all_reduce()
-
-
-class EventNodeUnavailable(RuntimeError):
-    """The captured graph could not be given its event-record node (the caller falls back to two graphs)."""
-
-
-def mark_event_here(stream=None):
-    """Inside a capture started by `capture_with_event`: the place where the event is to be recorded (an empty marker
-    kernel on the capturing stream -- geom_graph_marker -- that the surgery replaces by an event-record node)."""
-    from . import _lib
-    stream = torch.cuda.current_stream() if stream is None else stream
-    _lib.check(_lib.lib().geom_graph_marker(stream.cuda_stream), "geom_graph_marker")
-
-
-def capture_with_event(body, event):
-    """Capture `body()` into ONE HIP graph in which `event` (a torch.cuda.Event) is recorded by a NODE at the place where
-    body called mark_event_here(): a stream outside the graph that does `wait_event(event)` after `graph.replay()` is
-    ordered behind that place only, not behind the rest of the graph.  (Stream capture cannot create such a node on this
-    stack -- external events are refused -- so the capture drops a marker kernel there and geom_graph_event_at_marker
-    swaps it for hipGraphAddEventRecordNode before the graph is instantiated.)  Returns the instantiated graph."""
-    import ctypes
-    from . import _lib
-    event.record()                      # the handle exists only after a first record
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph(keep_graph=True)
-    with torch.cuda.graph(g):
-        body()
-    replaced = ctypes.c_int(0)
-    try:
-        _lib.check(_lib.lib().geom_graph_event_at_marker(ctypes.c_void_p(g.raw_cuda_graph()), ctypes.c_void_p(event.cuda_event),
-                                                         ctypes.byref(replaced)), "geom_graph_event_at_marker")
-        if replaced.value != 1:
-            raise RuntimeError("%d markers in the captured graph (body must call mark_event_here() exactly once, on the "
-                               "capturing stream)" % replaced.value)
-        g.instantiate()
-    except RuntimeError as exc:
-        _lib.clear_hip_error()
-        raise EventNodeUnavailable(str(exc)) from exc
-    return g
 
 
 def barrier():

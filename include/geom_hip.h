@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GEOM_ABI_VERSION 7
+#define GEOM_ABI_VERSION 6
 
 /* argument errors */
 #define GEOM_EINVAL   (-1) /* bad size / null pointer */
@@ -51,17 +51,6 @@ extern "C" {
 int geom_abi_version(void);
 /* static string for a code returned by any entry point */
 const char *geom_strerror(int code);
-
-/* ---- an event-record node in the middle of a captured step (host only; no reference counterpart: the reference is
- * single-GPU) -----------------------------------------------------------------------------------------------------
- * geom_graph_marker launches an EMPTY kernel on `stream` (a hipStream_t): captured, it marks a place in the graph.
- * geom_graph_event_at_marker(graph, event, &replaced) replaces every such node of `graph` (a hipGraph_t that has not
- * been instantiated yet) by an event-record node for `event` (a hipEvent_t): a stream OUTSIDE the graph that waits for
- * the event after the graph launch is ordered behind the marker's predecessors only -- how the gradient all-reduce of a
- * data-parallel step starts behind the end-of-pass reduction launch while the rest of the replayed step is still
- * running.  Return: 0 or a hipError_t / GEOM_E* code; *replaced = the number of markers found. */
-int geom_graph_marker(void *stream);
-int geom_graph_event_at_marker(void *graph, void *event, int *replaced);
 
 /* ---- Chamfer nearest neighbour, both directions in one launch --------------------
  * Replaces ChamferDistanceKernelLauncher (chamfer_distance/chamfer_distance.cpp:4-12,

@@ -1,13 +1,12 @@
 """Where do the ~35 us go that the two-graph data-parallel step costs over the single-graph step?  Variants of the per-step
 host sequence on the SAME two captured graphs (A = Adam + forward + backward + reduction, B = the postponed product), timed
 on one GPU with a 1-rank RCCL group.  Timing experiment only (the reduced variants are not correct steps).
-GPU box only:  GEOM_DP_TAIL=graph python tools/probe/dp_gaps.py"""
+GPU box only:  python tools/probe/dp_gaps.py"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-os.environ["GEOM_DP_TAIL"] = "graph"
 import torch                                   # noqa: E402
 import bench                                   # noqa: E402
 from geometrics_amd import gemm_tuning         # noqa: E402
@@ -20,7 +19,7 @@ wl = bench.Workload(dev, 0, 8, force_dp=True)
 wl.capture()
 ga, gb = wl.graphs
 main = torch.cuda.current_stream()
-side, ev = wl.side, wl.grads_ready
+side, ev = torch.cuda.Stream(), torch.cuda.Event()
 
 
 def v_graphs_only():
@@ -58,7 +57,13 @@ def v_join_only():
     gb.replay()
     main.wait_stream(side)
 
-for name, fn in (("A ; B", v_graphs_only), ("A ; record ; B", v_event), ("A ; record ; side waits ; B", v_event_sidewait),
+def v_async():
+    ga.replay()
+    work = wl.bucket.all_reduce_async()
+    gb.replay()
+    work.wait()
+
+for name, fn in (("A ; B", v_graphs_only), ("shipped: A ; async all-reduce ; B ; launch stream waits for it", v_async), ("A ; record ; B", v_event), ("A ; record ; side waits ; B", v_event_sidewait),
                  ("A ; record ; side: wait + all-reduce ; B", v_collective_no_join),
                  ("A ; record ; side waits ; B ; main waits side", v_join_only),
                  ("A ; all-reduce on the launch stream ; B", v_collective_on_main),
