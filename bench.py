@@ -115,7 +115,8 @@ class Workload:
         # so the bias / weight gradients of the pass are finished by ONE launch at its end -- which, in a single-process
         # step, applies Adam to them as well (step_in_backward: no optimiser launch of its own)
         self.reached_cut = False
-        self.tail_jobs = [] if (self.dp and self._splitting is None) else None     # eager step: exchange() launches them
+        capturing = self._splitting is not None
+        self.tail_jobs = [] if self.dp else None           # the postponed products, collected by the end-of-pass callback
         late = (layers.late_input_gradients(self._parameter_gradients_ready, collect=self.tail_jobs) if self.dp
                 else contextlib.nullcontext())
         with layers.deferred_parameter_gradients(), late, (self.opt.in_backward() if step_in_backward else contextlib.nullcontext()):
@@ -124,6 +125,12 @@ class Workload:
                                                      loss_out=self.bucket.extra if self.dp else None)
             self.loss.backward(self.seed_grad)              # explicit seed: no ones_like fill launch
         if self.dp:
+            if capturing:
+                # graph B: launched HERE, from the thread that also launches them in an eager step (exchange()) -- the
+                # callback runs on autograd's thread, whose library handle would be created inside the capture
+                for job in self.tail_jobs:
+                    job()
+                self.tail_jobs = None
             # normally pack() launches nothing: everything was written in place by the reduction launch
             self.packed_late = self.bucket.pack() or not self.reached_cut
 
