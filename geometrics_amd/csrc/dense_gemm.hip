@@ -39,7 +39,8 @@ constexpr int DG_THREADS = 256;
 constexpr int DG_WAVES = 4;
 constexpr int DG_BK = 32; // inner-dimension elements per LDS stage
 constexpr int DG_KS = 8;  // MFMA k-steps (4 elements each) per stage
-constexpr int SPLIT_RB = 6; // weight-gradient tiles: 96 rows x 192 columns
+constexpr int SPLIT_RB = 6;        // weight-gradient tiles: 96 rows x 192 columns ...
+constexpr int SPLIT_RB_NARROW = 3; // ... 48 rows for layers of <= 192 inputs (see split_geometry)
 constexpr int LD_TC = 34; // stride of a [row][t] panel: fragment reads hit bank (2*row + t) % 32 -- all distinct
 
 // stride of a [t][r] panel of R columns: the smallest s >= R with s % 32 == 16 (rows t and t+1 half a bank row apart)
@@ -780,18 +781,18 @@ __global__ __launch_bounds__(DG_THREADS) void dense_split_kernel(SplitArgs q)
 // stalls (prologue, epilogue, barriers, LDS round trips) are covered by the other's MFMAs.  Measured at the BASELINE shard,
 // hidden layer (20 496 x 192 x 192): 31 us for the pair against 22 + 23 one after the other (library: 15 + 25).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int RB, bool X_VEC>
+template <int RB, int SRB, bool X_VEC>
 __global__ __launch_bounds__(DG_THREADS, 2) void dense_bwd_pair_kernel(RowArgs r, SplitArgs q, int n_row)
 {
     constexpr int LDS_ROWS = 2 * ((RB + 1) * 16 * LD_TC + 192 * LD_TC);
-    constexpr int LDS_SPLIT = 2 * 32 * ld_rc(SPLIT_RB * 16);
+    constexpr int LDS_SPLIT = 2 * 32 * ld_rc(SRB * 16);
     __shared__ __attribute__((aligned(16))) float lds[LDS_ROWS > LDS_SPLIT ? LDS_ROWS : LDS_SPLIT];
     const int w = blockIdx.x;
     if (w < n_row) {
         if (w < r.left_rb * 3) rows_body<RB, 3, true, true, EPI_PLAIN, true>(r, lds, w, n_row);
         else rows_body<RB, 3, true, true, EPI_PLAIN, false>(r, lds, w, n_row);
     } else {
-        split_dispatch<SPLIT_RB, 3, X_VEC>(q, lds, w - n_row);
+        split_dispatch<SRB, 3, X_VEC>(q, lds, w - n_row);
     }
 }
 
@@ -1017,17 +1018,26 @@ extern "C" int geom_dense_bwd_input_f32(int rows, int cin, int c, const float *g
 
 namespace {
 struct SplitGeo {
-    int full_tiles, left_rb, s_full, s_left, slots;
+    int rb, full_tiles, left_rb, s_full, s_left, slots;
 };
+// Tile height of a weight gradient's partial sums.  The workgroup count is fixed by the chip (one per CU), so tiles x splits
+// ~ 256 and the bytes of partial tiles written here and read back by the reduction launch are splits x (cin x c x 4): the
+// MORE output tiles, the FEWER splits of the summed rows and the less traffic.  A 192-wide layer: 2 tiles of 96 rows x 128
+// splits = 18.9 MB, 4 tiles of 48 rows x 64 splits = 9.4 MB for the same MFMA work per workgroup (a stage is then 72 MFMAs
+// per wave instead of 144: still enough shadow for the X panel and the G loads, measured profiles/r04_split_tiles.txt).
+// The 963-wide layer keeps 96-row tiles (25 splits already; its launch is the step's longest and the taller tile is the
+// more efficient loop).
+inline int split_rb(int cin) { return cin <= 192 ? SPLIT_RB_NARROW : SPLIT_RB; }
 SplitGeo split_geometry(int cin, int rows, int cus)
 {
     SplitGeo g;
-    const int ra = SPLIT_RB * 16;
+    g.rb = split_rb(cin);
+    const int ra = g.rb * 16;
     g.full_tiles = cin / ra;
     g.left_rb = (cin % ra + 15) / 16;
     const int n4 = (rows + 3) / 4;
-    // a leftover row-block is 1/SPLIT_RB of a full tile: equal work per workgroup <=> s_left = s_full / SPLIT_RB
-    g.s_full = g.full_tiles ? (int)((int64_t)cus * SPLIT_RB / (g.full_tiles * SPLIT_RB + g.left_rb)) : 0;
+    // a leftover row-block is 1/rb of a full tile: equal work per workgroup <=> s_left = s_full / rb
+    g.s_full = g.full_tiles ? (int)((int64_t)cus * g.rb / (g.full_tiles * g.rb + g.left_rb)) : 0;
     if (g.full_tiles && g.s_full < 1) g.s_full = 1;
     g.s_left = 0;
     if (g.left_rb) {
@@ -1045,7 +1055,7 @@ extern "C" int64_t geom_dense_bwd_weight_workspace_floats(int rows, int cin, int
 {
     if (rows <= 0 || cin <= 0 || c <= 0 || c > 192) return 0;
     const SplitGeo g = split_geometry(cin, rows, num_cus());
-    return (int64_t)g.slots * SPLIT_RB * 16 * 192 + (int64_t)(g.s_full > 0 ? g.s_full : g.s_left) * c;
+    return (int64_t)g.slots * g.rb * 16 * 192 + (int64_t)(g.s_full > 0 ? g.s_full : g.s_left) * c;
 }
 
 // partial sums of grad_w = x^T . g into `workspace`; geom_dense_reduce_f32 finishes them (and the bias gradient)
@@ -1058,12 +1068,18 @@ extern "C" int geom_dense_bwd_weight_f32(int rows, int cin, int c, const float *
     if (!x || !g || !workspace || !aligned16(g) || !aligned16(workspace)) return GEOM_EINVAL;
     const SplitGeo geo = split_geometry(cin, rows, num_cus());
     if (want_colsum && geo.full_tiles == 0) return GEOM_EUNSUPPORTED;
-    float *colsum = want_colsum ? workspace + (int64_t)geo.slots * SPLIT_RB * 16 * 192 : nullptr;
+    float *colsum = want_colsum ? workspace + (int64_t)geo.slots * geo.rb * 16 * 192 : nullptr;
     SplitArgs q{x, cin, g, c, workspace, cin, c, rows, geo.full_tiles, geo.s_full, geo.left_rb, geo.s_left, colsum};
     const dim3 grid(geo.slots), block(DG_THREADS);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (cin % 4 == 0 && aligned16(x)) hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB, 3, true>), grid, block, 0, s, q);
-    else hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB, 3, false>), grid, block, 0, s, q);
+    const bool xvec = cin % 4 == 0 && aligned16(x);
+    if (geo.rb == SPLIT_RB_NARROW) {
+        if (xvec) hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB_NARROW, 3, true>), grid, block, 0, s, q);
+        else hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB_NARROW, 3, false>), grid, block, 0, s, q);
+    } else {
+        if (xvec) hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB, 3, true>), grid, block, 0, s, q);
+        else hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB, 3, false>), grid, block, 0, s, q);
+    }
     return geom::launch_status();
 }
 
@@ -1086,15 +1102,16 @@ extern "C" int geom_dense_bwd_f32(int rows, int cin, int c, const float *x, cons
         return geom_dense_bwd_weight_f32(rows, cin, c, x, g, workspace, want_colsum, stream);
     }
     RowArgs r{g, c, w, c, grad_x, cin, rows, cin, c, rg.n_tiles, rg.left_rb, 1, 0, nullptr, nullptr, nullptr};
-    float *colsum = want_colsum ? workspace + (int64_t)sg.slots * SPLIT_RB * 16 * 192 : nullptr;
+    float *colsum = want_colsum ? workspace + (int64_t)sg.slots * sg.rb * 16 * 192 : nullptr;
     SplitArgs q{x, cin, g, c, workspace, cin, c, rows, sg.full_tiles, sg.s_full, sg.left_rb, sg.s_left, colsum};
     const dim3 grid(rg.grid + sg.slots), block(DG_THREADS);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static_assert(SPLIT_RB_NARROW == 3, "cin <= 192 (the pair mode's range) takes the narrow split tiles");
     switch (rg.rb) {
-    case 2: hipLaunchKernelGGL((dense_bwd_pair_kernel<2, true>), grid, block, 0, s, r, q, rg.grid); break;
-    case 3: hipLaunchKernelGGL((dense_bwd_pair_kernel<3, true>), grid, block, 0, s, r, q, rg.grid); break;
-    case 4: hipLaunchKernelGGL((dense_bwd_pair_kernel<4, true>), grid, block, 0, s, r, q, rg.grid); break;
-    case 5: hipLaunchKernelGGL((dense_bwd_pair_kernel<5, true>), grid, block, 0, s, r, q, rg.grid); break;
+    case 2: hipLaunchKernelGGL((dense_bwd_pair_kernel<2, SPLIT_RB_NARROW, true>), grid, block, 0, s, r, q, rg.grid); break;
+    case 3: hipLaunchKernelGGL((dense_bwd_pair_kernel<3, SPLIT_RB_NARROW, true>), grid, block, 0, s, r, q, rg.grid); break;
+    case 4: hipLaunchKernelGGL((dense_bwd_pair_kernel<4, SPLIT_RB_NARROW, true>), grid, block, 0, s, r, q, rg.grid); break;
+    case 5: hipLaunchKernelGGL((dense_bwd_pair_kernel<5, SPLIT_RB_NARROW, true>), grid, block, 0, s, r, q, rg.grid); break;
     default: return GEOM_EINVAL;
     }
     return geom::launch_status();
@@ -1127,7 +1144,7 @@ int build_reduce_jobs(ReduceJobs &jobs, int &n, int &widest, int count, const in
     for (int l = 0; l < count; ++l) {
         if (!workspaces[l] || !grad_w[l] || rows[l] <= 0 || cin[l] <= 0 || c[l] <= 0 || c[l] > 192 || c[l] % 4) return GEOM_EINVAL;
         const SplitGeo g = split_geometry(cin[l], rows[l], num_cus());
-        jobs.job[n++] = ReduceJob{workspaces[l], grad_w[l], cin[l], c[l], SPLIT_RB * 16, 192, g.full_tiles, g.s_full, g.s_left, 0};
+        jobs.job[n++] = ReduceJob{workspaces[l], grad_w[l], cin[l], c[l], g.rb * 16, 192, g.full_tiles, g.s_full, g.s_left, 0};
         widest = cin[l] * (c[l] / 4) > widest ? cin[l] * (c[l] / 4) : widest;
     }
     for (int i = 0; i < ncs; ++i) {
@@ -1206,11 +1223,11 @@ extern "C" int geom_dense_reduce_f32(int count, const int *rows, const int *cin,
     for (int l = 0; l < count; ++l) {
         if (!workspaces[l] || !grad_w[l] || rows[l] <= 0 || cin[l] <= 0 || c[l] <= 0 || c[l] > 192 || c[l] % 4) return GEOM_EINVAL;
         const SplitGeo g = split_geometry(cin[l], rows[l], num_cus());
-        jobs.job[n++] = ReduceJob{workspaces[l], grad_w[l], cin[l], c[l], SPLIT_RB * 16, 192, g.full_tiles, g.s_full, g.s_left, 0};
+        jobs.job[n++] = ReduceJob{workspaces[l], grad_w[l], cin[l], c[l], g.rb * 16, 192, g.full_tiles, g.s_full, g.s_left, 0};
         widest = cin[l] * (c[l] / 4) > widest ? cin[l] * (c[l] / 4) : widest;
         if (grad_bias && grad_bias[l]) { // column sums: a 1-row "tile" per split, pitch = c
             if (g.full_tiles == 0) return GEOM_EUNSUPPORTED;
-            jobs.job[n++] = ReduceJob{workspaces[l] + (int64_t)g.slots * SPLIT_RB * 16 * 192, grad_bias[l], 1, c[l], 1, c[l], 1,
+            jobs.job[n++] = ReduceJob{workspaces[l] + (int64_t)g.slots * g.rb * 16 * 192, grad_bias[l], 1, c[l], 1, c[l], 1,
                                       g.s_full, 0, 0};
         }
     }
