@@ -1025,8 +1025,8 @@ struct SplitGeo {
 // MORE output tiles, the FEWER splits of the summed rows and the less traffic.  A 192-wide layer: 2 tiles of 96 rows x 128
 // splits = 18.9 MB, 4 tiles of 48 rows x 64 splits = 9.4 MB for the same MFMA work per workgroup (a stage is then 72 MFMAs
 // per wave instead of 144: still enough shadow for the X panel and the G loads, measured profiles/r04_split_tiles.txt).
-// The 963-wide layer keeps 96-row tiles (25 splits already; its launch is the step's longest and the taller tile is the
-// more efficient loop).
+// The 963-wide layer keeps 96-row tiles (25 splits already): with 48-row tiles x 12 splits its launch -- the step's
+// longest -- went from 65.7 to 71.4 us for 1.2 us less in the reduction launch.
 inline int split_rb(int cin) { return cin <= 192 ? SPLIT_RB_NARROW : SPLIT_RB; }
 SplitGeo split_geometry(int cin, int rows, int cus)
 {
