@@ -10,6 +10,7 @@ build nofetch -DDG_PROBE_NO_FETCH
 build noissue -DDG_PROBE_NO_ISSUE
 build nostore -DDG_PROBE_NO_STORE
 build nobar -DDG_PROBE_NO_BARRIER
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/probe/mfma_rate.cpp -o tools/probe/bin/mfma_rate &
 build mfmaonly -DDG_PROBE_NO_FETCH -DDG_PROBE_NO_ISSUE -DDG_PROBE_NO_STORE -DDG_PROBE_NO_BARRIER
 build nomem -DDG_PROBE_NO_ISSUE -DDG_PROBE_NO_STORE
 wait
