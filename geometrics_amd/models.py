@@ -248,8 +248,16 @@ class BatchMeshDeformationBlock(nn.Module):
         """gc_i -> bn_i -> ReLU (-> residual average); tap: see VertexBatchNorm.forward."""
         return getattr(self, "bn%d" % i)(getattr(self, "gc%d" % i)(x, adj, _identity), relu=True, residual=residual, tap=tap)
 
+    # How the twelve equal hidden layers get their weight gradients: True = ONE strided-batched library product at the end of
+    # the backward pass (layers.weight_gradient_batching), False = the matrix-core pair launch per layer (input gradient and
+    # weight-gradient partials together, csrc/dense_gemm.hip) + the shared end-of-pass reduction.  Measured at the reference's
+    # training shape (batch 16 x 482 vertices) and at the BASELINE shard: profiles/r04_training_shape_variants.txt.
+    batch_weight_gradients = True
+
     def forward(self, features, pooled, adj):
-        with _layers.weight_gradient_batching(depth=14):   # the twelve equal hidden layers: one batched weight-gradient product
+        import contextlib
+        batching = _layers.weight_gradient_batching(depth=14) if self.batch_weight_gradients else contextlib.nullcontext()
+        with batching:
             full, lead = _InputTap.apply(features, pooled, self.hidden)
             x = self._layer(1, full, adj)
             feats, feats_r = self._layer(2, x, adj, residual=lead, tap=True)
@@ -291,3 +299,23 @@ class MeshEncoder(nn.Module):
 
     def encode_batch(self, batch):
         return self.reduce(self._trunk(batch.verts, batch), batch, F.elu)
+
+    def graphed_encode(self, batch, warmup=3):
+        """encode_batch for batches of a FIXED topology (the sizes and connectivity of `batch`; positions vary), with the
+        forward and the backward pass each replayed as ONE HIP graph: `f = enc.graphed_encode(batch); latents = f(verts)`
+        with verts [sum(V), 3] is differentiable like the eager call (parameters and, when verts requires grad, verts).
+        The eager path is launch-bound -- 17 layers x (product, aggregation) + the segmented max, forward and backward:
+        ~90 launches of a few microseconds each from python (tools/time_encoder.py) -- which is what the capture removes.
+        torch.cuda.make_graphed_callables does the capture (static input / output / gradient buffers, autograd-aware)."""
+        encoder = self
+
+        class _Encode(nn.Module):     # the encoder's parameters are this module's: their gradients flow through the graph
+            def __init__(self):
+                super().__init__()
+                self.encoder = encoder
+
+            def forward(self, verts):
+                return self.encoder.reduce(self.encoder._trunk(verts, batch), batch, F.elu)
+
+        sample = batch.verts.detach().clone().requires_grad_(batch.verts.requires_grad)
+        return torch.cuda.make_graphed_callables(_Encode(), (sample,), num_warmup_iters=warmup)

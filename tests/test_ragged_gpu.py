@@ -123,6 +123,38 @@ def test_per_mesh_forward_equals_ragged_batch(gpu):
     assert float((together - alone).abs().max()) <= 2e-5 * float(alone.abs().max())   # GEMM tiling may differ with M
 
 
+def test_graphed_encode_equals_the_eager_ragged_batch_for_new_positions(gpu):
+    """MeshEncoder.graphed_encode(batch): forward and backward of encode_batch replayed as HIP graphs for a FIXED
+    topology.  For positions the capture never saw it must return what the eager call returns -- latents, parameter
+    gradients and the gradient of the positions, bit for bit (the same kernels on the same shapes) -- twice in a row (static
+    buffers are reused) and with a different upstream gradient."""
+    from geometrics_amd import models, ragged
+    fx = golden("mesh_encoder_ragged")
+    verts, faces = _meshes(fx, gpu)
+    enc = fill_parameters(models.MeshEncoder(50), 3).to(gpu)
+    batch = ragged.RaggedMeshBatch.from_faces(verts, faces)
+    batch.verts.requires_grad_(True)
+    graphed = enc.graphed_encode(batch)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    for trial in range(3):
+        moved = (batch.verts.detach() + 0.01 * torch.randn(batch.verts.shape, generator=gen).to(gpu)).requires_grad_(True)
+        upstream = torch.randn(3, 50, generator=gen).to(gpu)
+        enc.zero_grad(set_to_none=True)
+        batch_moved = ragged.RaggedMeshBatch(moved, batch.sizes, batch.csr)
+        want = enc.encode_batch(batch_moved)
+        (want * upstream).sum().backward()
+        want_grads = [p.grad.clone() for p in enc.parameters()]
+        want_dv = moved.grad.clone()
+        enc.zero_grad(set_to_none=True)
+        moved2 = moved.detach().clone().requires_grad_(True)
+        got = graphed(moved2)
+        (got * upstream).sum().backward()
+        assert torch.equal(got, want), trial
+        assert torch.equal(moved2.grad, want_dv), trial
+        for p, g in zip(enc.parameters(), want_grads):
+            assert torch.equal(p.grad, g), trial
+
+
 def test_ragged_rejects_bad_input(gpu):
     from geometrics_amd import ragged
     v = torch.zeros(4, 3, device=gpu)

@@ -73,12 +73,24 @@ def main():
         enc.zero_grad(set_to_none=True)
         enc.encode_batch(ragged.RaggedMeshBatch.from_faces(verts, faces)).square().mean().backward()
 
+    graphed = enc.graphed_encode(batch)
+
+    def graphed_step():
+        enc.zero_grad(set_to_none=True)
+        graphed(batch.verts).square().mean().backward()
+
     with torch.no_grad():
         a = reference_formulation(params, names, verts, adjs)
         b = enc.encode_batch(batch)
     print("meshes %d, vertices %d, max |latent diff| %.2e (max |latent| %.2e)"
           % (len(verts), batch.total, float((a - b).abs().max()), float(a.abs().max())))
-    t_ref, t_new, t_build = timed(ref_step), timed(ragged_step), timed(ragged_step_with_build)
+    ragged_step()
+    eager_grads = [p.grad.clone() for p in enc.parameters()]
+    graphed_step()
+    worst = max(float((p.grad - g).abs().max()) for p, g in zip(enc.parameters(), eager_grads))
+    print("graphed vs eager: max |parameter gradient diff| %.2e" % worst)
+    t_ref, t_new, t_build, t_graph = timed(ref_step), timed(ragged_step), timed(ragged_step_with_build), timed(graphed_step)
+    print("ragged batch, forward + backward as two HIP graphs %8.3f ms  (%.1fx)" % (t_graph, t_ref / t_graph))
     print("reference formulation (per-mesh loop, dense adj)  %8.3f ms" % t_ref)
     print("ragged batch, prebuilt CSR                        %8.3f ms  (%.1fx)" % (t_new, t_ref / t_new))
     print("ragged batch incl. CSR assembly from faces        %8.3f ms  (%.1fx)" % (t_build, t_ref / t_build))
