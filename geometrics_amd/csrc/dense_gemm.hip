@@ -41,6 +41,7 @@ constexpr int DG_BK = 32; // inner-dimension elements per LDS stage
 constexpr int DG_KS = 8;  // MFMA k-steps (4 elements each) per stage
 constexpr int SPLIT_RB = 6;        // weight-gradient tiles: 96 rows x 192 columns ...
 constexpr int SPLIT_RB_NARROW = 3; // ... 48 rows for layers of <= 192 inputs (see split_geometry)
+constexpr int SPLIT_KP_WIDE = 2;   // k-parts (waves per SIMD) of the stand-alone weight-gradient launch of a wide layer, see split_stage
 constexpr int LD_TC = 34; // stride of a [row][t] panel: fragment reads hit bank (2*row + t) % 32 -- all distinct
 
 // stride of a [t][r] panel of R columns: the smallest s >= R with s % 32 == 16 (rows t and t+1 half a bank row apart)
@@ -139,12 +140,12 @@ struct PanelTCs {
     }
 };
 
-// RC panel, 16-byte loads along r: element e = thread + 256 * p of the 32 x R/4 grid
-template <int R>
+// RC panel, 16-byte loads along r: element e = thread + NT * p of the 32 x R/4 grid (NT = threads of the workgroup)
+template <int R, int NT = DG_THREADS>
 struct PanelRCv {
     static constexpr int Q = R / 4;
-    static constexpr int PASSES = (32 * Q + DG_THREADS - 1) / DG_THREADS;
-    static constexpr bool EXACT = (32 * Q) % DG_THREADS == 0;
+    static constexpr int PASSES = (32 * Q + NT - 1) / NT;
+    static constexpr bool EXACT = (32 * Q) % NT == 0;
     static constexpr int WIDTH = 4;
     f32x4 v[2][PASSES];
     unsigned off[PASSES];
@@ -154,7 +155,7 @@ struct PanelRCv {
     {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const int e = threadIdx.x + p * DG_THREADS;
+            const int e = threadIdx.x + p * NT;
             const int tl = EXACT ? e / Q : min(e / Q, 31);
             off[p] = ((unsigned)tl * ld + (unsigned)coloff(e % Q)) * 4u;
         }
@@ -166,7 +167,7 @@ struct PanelRCv {
     template <bool ZERO, int SET>
     __device__ __forceinline__ void store_pass(int p, float *lds, int t0, int tmax) const
     {
-        const int e = threadIdx.x + p * DG_THREADS;
+        const int e = threadIdx.x + p * NT;
         const int tl = e / Q, r4 = e % Q;
         if (EXACT || tl < 32) {
             f32x4 x = v[SET][p];
@@ -176,11 +177,11 @@ struct PanelRCv {
     }
 };
 
-// RC panel, 4-byte loads along r (963-wide rows): element e = thread + 256 * p of the 32 x R grid
-template <int R>
+// RC panel, 4-byte loads along r (963-wide rows): element e = thread + NT * p of the 32 x R grid
+template <int R, int NT = DG_THREADS>
 struct PanelRCs {
-    static constexpr int PASSES = (32 * R + DG_THREADS - 1) / DG_THREADS;
-    static constexpr bool EXACT = (32 * R) % DG_THREADS == 0;
+    static constexpr int PASSES = (32 * R + NT - 1) / NT;
+    static constexpr bool EXACT = (32 * R) % NT == 0;
     static constexpr int WIDTH = 1;
     float v[2][PASSES];
     unsigned off[PASSES];
@@ -189,7 +190,7 @@ struct PanelRCs {
     {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const int e = threadIdx.x + p * DG_THREADS;
+            const int e = threadIdx.x + p * NT;
             const int tl = EXACT ? e / R : min(e / R, 31);
             off[p] = ((unsigned)tl * ld + (unsigned)coloff(e % R)) * 4u;
         }
@@ -201,7 +202,7 @@ struct PanelRCs {
     template <bool ZERO, int SET>
     __device__ __forceinline__ void store_pass(int p, float *lds, int t0, int tmax) const
     {
-        const int e = threadIdx.x + p * DG_THREADS;
+        const int e = threadIdx.x + p * NT;
         const int tl = e / R, r = e % R;
         if (EXACT || tl < 32) lds[tl * ld_rc(R) + r] = (!ZERO || t0 + tl < tmax) ? v[SET][p] : 0.f;
     }
@@ -572,31 +573,42 @@ struct SplitArgs {
 // stages x 8 k-steps: the slot a k-step has just consumed is refilled at once with the same k-step of the stage after
 // next.  Measured before (probe builds with the LDS traffic removed): the G panel's LDS writes + fragment reads were ~15 of
 // the first layer's 77 us.
-template <int RB, int RA, int A_FLOATS, int SET, class PA, class Tail>
-__device__ __forceinline__ void split_stage(const float *cur, float *wr, f32x4 (&acc)[RB][3], float (&fa)[2][RB], f3u (&bq)[2][DG_KS],
-                                            PA &pa, const StageIO &io, unsigned b_lane, unsigned b_step, Tail tail)
+// KP = k-parts: with KP == 2 the workgroup has EIGHT waves, two per SIMD -- wave v and wave v + 4 own the same 48 output
+// columns and share the X panel, the first takes the even k-steps of every stage, the second the odd ones, each into its
+// own accumulators (added up through LDS at the end: split_body).  One wave per SIMD cannot hide its own stalls (fragment
+// reads, the stage barrier, s_waitcnt in front of the LDS stores): PMC showed the matrix pipe 64-73 % busy with one wave;
+// two waves on a SIMD issue into each other's gaps.  A wave then runs KS = 8 / KP k-steps per stage: loads of the stage
+// after next in its first KS/2 steps, LDS stores in the following ones, barrier behind step KS - 2, the first fragments of
+// the next stage requested in the last step.
+template <int RB, int RA, int A_FLOATS, int SET, int KP, class PA, class Tail>
+__device__ __forceinline__ void split_stage(const float *cur, float *wr, f32x4 (&acc)[RB][3], float (&fa)[2][RB], f3u (&bq)[2][DG_KS / KP],
+                                            PA &pa, const StageIO &io, unsigned b_lane, unsigned b_step, int kpart, Tail tail)
 {
     constexpr int U = PA::PASSES;
+    constexpr int KS = DG_KS / KP;             // k-steps of this wave per stage
+    constexpr int LOADS = KS / 2;              // steps [0, LOADS): issue the loads; [LOADS, KS - 1): LDS stores
+    constexpr int STORES = KS - 1 - LOADS;
     const int x = threadIdx.x & 15, g = (threadIdx.x >> 4) & 3;
     const float *b_base = io.b_base; // by value: `tail` re-aims io in the last k-step, the refills below belong to this aim
     const unsigned b_limit = io.b_limit;
 #pragma unroll
-    for (int s = 0; s < DG_KS; ++s) {
-        { // X fragments of the next k-step (of the next stage after the last one)
-            const float *src = s + 1 < DG_KS ? cur : wr;
-            const int sn = s + 1 < DG_KS ? s + 1 : 0;
+    for (int s = 0; s < KS; ++s) {
+        { // X fragments of this wave's next k-step (of the next stage after the last one): global k-step KP * s' + kpart
+            const float *src = s + 1 < KS ? cur : wr;
+            const int sn = (s + 1 < KS ? KP * (s + 1) : 0) + kpart;
             const float *pa_l = src + g * ld_rc(RA) + x;
 #pragma unroll
             for (int i = 0; i < RB; ++i) fa[(s + 1) & 1][i] = pa_l[4 * sn * ld_rc(RA) + i * 16];
         }
-        if (s < 4) {
+        if (s < LOADS) {
 #pragma unroll
-            for (int u = s * U / 4; u < (s + 1) * U / 4; ++u) pa.template issue_pass<SET>(u, io.a_base, io.a_limit);
-        } else if (s < 7) {
+            for (int u = s * U / LOADS; u < (s + 1) * U / LOADS; ++u) pa.template issue_pass<SET>(u, io.a_base, io.a_limit);
+        } else if (s < KS - 1) {
 #pragma unroll
-            for (int u = (s - 4) * U / 3; u < (s - 3) * U / 3; ++u) pa.template store_pass<true, SET ^ 1>(u, wr, io.st_t0, io.st_tmax);
+            for (int u = (s - LOADS) * U / STORES; u < (s - LOADS + 1) * U / STORES; ++u)
+                pa.template store_pass<true, SET ^ 1>(u, wr, io.st_t0, io.st_tmax);
         }
-        if (s == DG_KS - 1) tail();
+        if (s == KS - 1) tail();
         const f3u b = bq[SET][s];
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
@@ -604,31 +616,34 @@ __device__ __forceinline__ void split_stage(const float *cur, float *wr, f32x4 (
             acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, fa[s & 1][i], acc[i][1], 0, 0, 0);
             acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, fa[s & 1][i], acc[i][2], 0, 0, 0);
         }
-        bq[SET][s] = ldg3(b_base, min(b_lane + (unsigned)s * b_step, b_limit)); // the same k-step of the stage after next
+        bq[SET][s] = ldg3(b_base, min(b_lane + (unsigned)(KP * s) * b_step, b_limit)); // the same k-step of the stage after next
 #pragma unroll
         for (int m = 0; m < RB * 3; ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // DS read
-            if (s < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // VMEM read
-            else __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // DS write
+            if (s < LOADS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // VMEM read
+            else __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);           // DS write
             __builtin_amdgcn_sched_group_barrier(0x006, 2, 0); // VALU / SALU
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s == 6) {
+        if (s == KS - 2) {
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
-template <int RB, int RBP, bool A_VEC>
+template <int RB, int RBP, bool A_VEC, int KP = 1>
 __device__ __forceinline__ void split_body(const SplitArgs &q, float *lds, int i0, int split, int nsplit, int slot, bool want_cs)
 {
     constexpr int RA = RB * 16;
     constexpr int CW = 192;
     constexpr int A_FLOATS = 32 * ld_rc(RA);
     constexpr int BUF = A_FLOATS;
-    const int wave = threadIdx.x >> 6;
+    constexpr int NT = DG_THREADS * KP;
+    constexpr int KS = DG_KS / KP;
+    const int wave = (threadIdx.x >> 6) & 3;     // which 48 output columns
+    const int kpart = KP == 1 ? 0 : (int)(threadIdx.x >> 8); // which k-steps of a stage (waves v and v + 4 share a SIMD)
     const int x = threadIdx.x & 15, g = (threadIdx.x >> 4) & 3;
     // rows of the summed dimension in units of 4 (one MFMA k-step); T % 4 != 0 is zero-filled by the X loader
     const int n4 = (q.T + 3) / 4;
@@ -643,16 +658,17 @@ __device__ __forceinline__ void split_body(const SplitArgs &q, float *lds, int i
         for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f; // column sums of G over this split's rows == g (mod 4), columns 48*wave + 3x ..
 
-    typedef typename std::conditional<A_VEC, PanelRCv<RA>, PanelRCs<RA>>::type PA;
+    typedef typename std::conditional<A_VEC, PanelRCv<RA, NT>, PanelRCs<RA, NT>>::type PA;
     PA pa;
     if (nst > 0) {
         if constexpr (A_VEC) pa.prepare([=](int r4) -> unsigned { const int i = i0 + r4 * 4; return (unsigned)(i + 3 < q.I ? i : q.I - 4); }, (unsigned)q.lda);
         else pa.prepare([=](int r) -> unsigned { const int i = i0 + r; return (unsigned)(i < q.I ? i : q.I - 1); }, (unsigned)q.lda);
         const unsigned a_total = (unsigned)q.T * (unsigned)q.lda, b_total = (unsigned)q.T * (unsigned)q.ldb;
-        // G: this lane's 12 bytes of row g of a k-step, columns clamped into the row (J % 4 == 0 but maybe not % 3)
+        // G: this lane's 12 bytes of row g of a k-step, columns clamped into the row (J % 4 == 0 but maybe not % 3); the wave's
+        // first k-step of a stage is k-step `kpart`
         const int jc = min(wave * 48 + 3 * x, q.J - 3);
-        const unsigned b_lane = ((unsigned)g * (unsigned)q.ldb + (unsigned)jc) * 4u;
         const unsigned b_step = 4u * (unsigned)q.ldb * 4u; // four rows per k-step
+        const unsigned b_lane = ((unsigned)g * (unsigned)q.ldb + (unsigned)jc) * 4u + (unsigned)kpart * b_step;
         StageIO io;
         int l_st = 0;
         auto aim = [&]() {
@@ -663,21 +679,21 @@ __device__ __forceinline__ void split_body(const SplitArgs &q, float *lds, int i
             io.b_limit = (b_total - 3u - (unsigned)t0 * (unsigned)q.ldb) * 4u;
         };
         auto advance = [&]() { l_st = l_st + 1 < nst ? l_st + 1 : l_st; };
-        f3u bq[2][DG_KS];
+        f3u bq[2][KS];
         float fa[2][RB];
         // prologue: stages 0 and 1 requested together; X of stage 0 -> LDS buffer 0
         aim();
 #pragma unroll
         for (int p = 0; p < PA::PASSES; ++p) pa.template issue_pass<0>(p, io.a_base, io.a_limit);
 #pragma unroll
-        for (int s = 0; s < DG_KS; ++s) bq[0][s] = ldg3(io.b_base, min(b_lane + (unsigned)s * b_step, io.b_limit));
+        for (int s = 0; s < KS; ++s) bq[0][s] = ldg3(io.b_base, min(b_lane + (unsigned)(KP * s) * b_step, io.b_limit));
         advance();
         aim();
         io.st_t0 = t_begin + l_st * DG_BK;
 #pragma unroll
         for (int p = 0; p < PA::PASSES; ++p) pa.template issue_pass<1>(p, io.a_base, io.a_limit);
 #pragma unroll
-        for (int s = 0; s < DG_KS; ++s) bq[1][s] = ldg3(io.b_base, min(b_lane + (unsigned)s * b_step, io.b_limit));
+        for (int s = 0; s < KS; ++s) bq[1][s] = ldg3(io.b_base, min(b_lane + (unsigned)(KP * s) * b_step, io.b_limit));
 #pragma unroll
         for (int p = 0; p < PA::PASSES; ++p) pa.template store_pass<true, 0>(p, lds, t_begin, t_end);
         advance();
@@ -687,7 +703,7 @@ __device__ __forceinline__ void split_body(const SplitArgs &q, float *lds, int i
         {
             const float *pa_l = lds + g * ld_rc(RA) + x;
 #pragma unroll
-            for (int i = 0; i < RB; ++i) fa[0][i] = pa_l[i * 16];
+            for (int i = 0; i < RB; ++i) fa[0][i] = pa_l[4 * kpart * ld_rc(RA) + i * 16];
         }
         int buf = 0;
         auto tail = [&]() {
@@ -698,11 +714,11 @@ __device__ __forceinline__ void split_body(const SplitArgs &q, float *lds, int i
         };
         // rows of G beyond t_end belong to the next split (their X factors are zero-filled): the bias gradient counts only
         // this split's rows
-        auto colsum_stage = [&](const f3u (&b)[DG_KS], int st) {
-            const int t0 = t_begin + st * DG_BK + g;
+        auto colsum_stage = [&](const f3u (&b)[KS], int st) {
+            const int t0 = t_begin + st * DG_BK + g + 4 * kpart;
 #pragma unroll
-            for (int s = 0; s < DG_KS; ++s) {
-                const bool in = t0 + 4 * s < t_end;
+            for (int s = 0; s < KS; ++s) {
+                const bool in = t0 + 4 * KP * s < t_end;
                 cs0 += in ? b[s].x : 0.f, cs1 += in ? b[s].y : 0.f, cs2 += in ? b[s].z : 0.f;
             }
         };
@@ -711,15 +727,49 @@ __device__ __forceinline__ void split_body(const SplitArgs &q, float *lds, int i
                 const float *cur = lds + buf * BUF;
                 float *wr = lds + (buf ^ 1) * BUF;
                 if (want_cs) colsum_stage(bq[0], st);
-                split_stage<RB, RA, A_FLOATS, 0>(cur, wr, acc, fa, bq, pa, io, b_lane, b_step, tail);
+                split_stage<RB, RA, A_FLOATS, 0, KP>(cur, wr, acc, fa, bq, pa, io, b_lane, b_step, kpart, tail);
             }
             if (st + 1 < nst) {
                 const float *cur = lds + buf * BUF;
                 float *wr = lds + (buf ^ 1) * BUF;
                 if (want_cs) colsum_stage(bq[1], st + 1);
-                split_stage<RB, RA, A_FLOATS, 1>(cur, wr, acc, fa, bq, pa, io, b_lane, b_step, tail);
+                split_stage<RB, RA, A_FLOATS, 1, KP>(cur, wr, acc, fa, bq, pa, io, b_lane, b_step, kpart, tail);
             }
         }
+    }
+    if constexpr (KP == 2) {
+        // the odd k-steps' accumulators (and column sums) go to their even partners through LDS, lane for lane: float4
+        // (wave, i, u) of lane l at [((wave * H + i') * 3 + u) * 64 + l] -- 1 KB contiguous per wave instruction -- H = 2
+        // row-blocks per round, so that the exchange needs no more LDS than the kernel's two panels hold
+        constexpr int H = 2;
+        static_assert(DG_WAVES * H * 3 * 64 * 4 <= 2 * 32 * ld_rc(RBP * 16), "the exchange reuses the panel buffers");
+        f32x4 *xch = reinterpret_cast<f32x4 *>(lds);
+        const int l = threadIdx.x & 63;
+#pragma unroll
+        for (int i0r = 0; i0r < RB; i0r += H) {
+            __syncthreads(); // the panels (first round) / the partners' reads of the previous round are done
+            if (kpart == 1) {
+#pragma unroll
+                for (int i = i0r; i < RB && i < i0r + H; ++i)
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) xch[((wave * H + (i - i0r)) * 3 + u) * 64 + l] = acc[i][u];
+            }
+            __syncthreads();
+            if (kpart == 0) {
+#pragma unroll
+                for (int i = i0r; i < RB && i < i0r + H; ++i)
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) acc[i][u] = acc[i][u] + xch[((wave * H + (i - i0r)) * 3 + u) * 64 + l];
+            }
+        }
+        if (want_cs) {
+            __syncthreads();
+            float *xf = lds;
+            if (kpart == 1) xf[(wave * 3 + 0) * 64 + l] = cs0, xf[(wave * 3 + 1) * 64 + l] = cs1, xf[(wave * 3 + 2) * 64 + l] = cs2;
+            __syncthreads();
+            if (kpart == 0) cs0 += xf[(wave * 3 + 0) * 64 + l], cs1 += xf[(wave * 3 + 1) * 64 + l], cs2 += xf[(wave * 3 + 2) * 64 + l];
+        }
+        if (kpart == 1) return;
     }
     // partial tile: the lane's twelve consecutive columns of row 16 i + x
     float *dst = q.part + (int64_t)slot * (RBP * 16) * CW;
@@ -752,26 +802,28 @@ __device__ __forceinline__ void split_body(const SplitArgs &q, float *lds, int i
 
 // A_VEC: the leftover row-blocks may use 16-byte loads too (I % 4 == 0).  FULL tiles always do: their column groups never
 // reach the end of a row, so 4-byte alignment is all they need (the 963-float rows of the first layer's features).
-template <int RB, int NCW, bool A_VEC>
+template <int RB, int NCW, bool A_VEC, int KP = 1>
 __device__ __forceinline__ void split_dispatch(const SplitArgs &q, float *lds, const int w)
 {
     static_assert(NCW == 3, "the split body owns 48 columns per wave");
     const int nfull = q.full_tiles * q.s_full;
     if (w < nfull) {
         const int tile = w % q.full_tiles, split = w / q.full_tiles;
-        split_body<RB, RB, true>(q, lds, tile * RB * 16, split, q.s_full, tile * q.s_full + split,
-                                 q.colsum != nullptr && tile == 0);
+        split_body<RB, RB, true, KP>(q, lds, tile * RB * 16, split, q.s_full, tile * q.s_full + split,
+                                     q.colsum != nullptr && tile == 0);
     } else {
         const int e = (w - nfull) / q.s_left, split = (w - nfull) % q.s_left;
-        split_body<1, RB, A_VEC>(q, lds, (q.full_tiles * RB + e) * 16, split, q.s_left, w, false);
+        split_body<1, RB, A_VEC, KP>(q, lds, (q.full_tiles * RB + e) * 16, split, q.s_left, w, false);
     }
 }
 
-template <int RB, int NCW, bool A_VEC>
-__global__ __launch_bounds__(DG_THREADS) void dense_split_kernel(SplitArgs q)
+// KP = 2: eight waves per workgroup, see split_stage -- the stand-alone launch, one workgroup per CU (the 963-wide first
+// layer).  The pair launch keeps KP = 1: there the second wave of a SIMD is the row workgroup that shares the CU.
+template <int RB, int NCW, bool A_VEC, int KP>
+__global__ __launch_bounds__(DG_THREADS * KP) void dense_split_kernel(SplitArgs q)
 {
     __shared__ __attribute__((aligned(16))) float lds[2 * 32 * ld_rc(RB * 16)];
-    split_dispatch<RB, NCW, A_VEC>(q, lds, blockIdx.x);
+    split_dispatch<RB, NCW, A_VEC, KP>(q, lds, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1070,15 +1122,17 @@ extern "C" int geom_dense_bwd_weight_f32(int rows, int cin, int c, const float *
     if (want_colsum && geo.full_tiles == 0) return GEOM_EUNSUPPORTED;
     float *colsum = want_colsum ? workspace + (int64_t)geo.slots * geo.rb * 16 * 192 : nullptr;
     SplitArgs q{x, cin, g, c, workspace, cin, c, rows, geo.full_tiles, geo.s_full, geo.left_rb, geo.s_left, colsum};
-    const dim3 grid(geo.slots), block(DG_THREADS);
+    const dim3 grid(geo.slots);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool xvec = cin % 4 == 0 && aligned16(x);
     if (geo.rb == SPLIT_RB_NARROW) {
-        if (xvec) hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB_NARROW, 3, true>), grid, block, 0, s, q);
-        else hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB_NARROW, 3, false>), grid, block, 0, s, q);
+        const dim3 block(DG_THREADS);
+        if (xvec) hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB_NARROW, 3, true, 1>), grid, block, 0, s, q);
+        else hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB_NARROW, 3, false, 1>), grid, block, 0, s, q);
     } else {
-        if (xvec) hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB, 3, true>), grid, block, 0, s, q);
-        else hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB, 3, false>), grid, block, 0, s, q);
+        const dim3 block(DG_THREADS * SPLIT_KP_WIDE);
+        if (xvec) hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB, 3, true, SPLIT_KP_WIDE>), grid, block, 0, s, q);
+        else hipLaunchKernelGGL((dense_split_kernel<SPLIT_RB, 3, false, SPLIT_KP_WIDE>), grid, block, 0, s, q);
     }
     return geom::launch_status();
 }
