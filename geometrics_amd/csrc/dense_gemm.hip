@@ -41,7 +41,10 @@ constexpr int DG_BK = 32; // inner-dimension elements per LDS stage
 constexpr int DG_KS = 8;  // MFMA k-steps (4 elements each) per stage
 constexpr int SPLIT_RB = 6;        // weight-gradient tiles: 96 rows x 192 columns ...
 constexpr int SPLIT_RB_NARROW = 3; // ... 48 rows for layers of <= 192 inputs (see split_geometry)
-constexpr int SPLIT_KP_WIDE = 2;   // k-parts (waves per SIMD) of the stand-alone weight-gradient launch of a wide layer, see split_stage
+#ifndef DG_SPLIT_KP
+#define DG_SPLIT_KP 2
+#endif
+constexpr int SPLIT_KP_WIDE = DG_SPLIT_KP;   // k-parts (waves per SIMD) of the stand-alone weight-gradient launch of a wide layer, see split_stage
 constexpr int LD_TC = 34; // stride of a [row][t] panel: fragment reads hit bank (2*row + t) % 32 -- all distinct
 
 // stride of a [t][r] panel of R columns: the smallest s >= R with s % 32 == 16 (rows t and t+1 half a bank row apart)
@@ -167,13 +170,13 @@ struct PanelRCv {
     template <bool ZERO, int SET>
     __device__ __forceinline__ void store_pass(int p, float *lds, int t0, int tmax) const
     {
+        // past the panel's last row (EXACT == false) the thread holds a copy of row 31's element (prepare clamps): it stores the
+        // same value to the same address -- no branch inside the MFMA stream
         const int e = threadIdx.x + p * NT;
-        const int tl = e / Q, r4 = e % Q;
-        if (EXACT || tl < 32) {
-            f32x4 x = v[SET][p];
-            if (ZERO && !(t0 + tl < tmax)) x = (f32x4){0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4 *>(lds + tl * ld_rc(R) + r4 * 4) = x;
-        }
+        const int tl = EXACT ? e / Q : min(e / Q, 31), r4 = e % Q;
+        f32x4 x = v[SET][p];
+        if (ZERO && !(t0 + tl < tmax)) x = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(lds + tl * ld_rc(R) + r4 * 4) = x;
     }
 };
 
@@ -203,8 +206,8 @@ struct PanelRCs {
     __device__ __forceinline__ void store_pass(int p, float *lds, int t0, int tmax) const
     {
         const int e = threadIdx.x + p * NT;
-        const int tl = e / R, r = e % R;
-        if (EXACT || tl < 32) lds[tl * ld_rc(R) + r] = (!ZERO || t0 + tl < tmax) ? v[SET][p] : 0.f;
+        const int tl = EXACT ? e / R : min(e / R, 31), r = e % R;      // (clamped duplicates: see PanelRCv)
+        lds[tl * ld_rc(R) + r] = (!ZERO || t0 + tl < tmax) ? v[SET][p] : 0.f;
     }
 };
 
@@ -593,6 +596,7 @@ __device__ __forceinline__ void split_stage(const float *cur, float *wr, f32x4 (
     const unsigned b_limit = io.b_limit;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
+#ifndef DG_PROBE_NO_FETCH
         { // X fragments of this wave's next k-step (of the next stage after the last one): global k-step KP * s' + kpart
             const float *src = s + 1 < KS ? cur : wr;
             const int sn = (s + 1 < KS ? KP * (s + 1) : 0) + kpart;
@@ -600,10 +604,19 @@ __device__ __forceinline__ void split_stage(const float *cur, float *wr, f32x4 (
 #pragma unroll
             for (int i = 0; i < RB; ++i) fa[(s + 1) & 1][i] = pa_l[4 * sn * ld_rc(RA) + i * 16];
         }
+#endif
+#ifdef DG_PROBE_NO_ISSUE
+        if (false) {
+#else
         if (s < LOADS) {
+#endif
 #pragma unroll
             for (int u = s * U / LOADS; u < (s + 1) * U / LOADS; ++u) pa.template issue_pass<SET>(u, io.a_base, io.a_limit);
+#ifdef DG_PROBE_NO_STORE
+        } else if (false) {
+#else
         } else if (s < KS - 1) {
+#endif
 #pragma unroll
             for (int u = (s - LOADS) * U / STORES; u < (s - LOADS + 1) * U / STORES; ++u)
                 pa.template store_pass<true, SET ^ 1>(u, wr, io.st_t0, io.st_tmax);
@@ -616,7 +629,9 @@ __device__ __forceinline__ void split_stage(const float *cur, float *wr, f32x4 (
             acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, fa[s & 1][i], acc[i][1], 0, 0, 0);
             acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, fa[s & 1][i], acc[i][2], 0, 0, 0);
         }
+#ifndef DG_PROBE_NO_G
         bq[SET][s] = ldg3(b_base, min(b_lane + (unsigned)(KP * s) * b_step, b_limit)); // the same k-step of the stage after next
+#endif
 #pragma unroll
         for (int m = 0; m < RB * 3; ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
@@ -627,7 +642,9 @@ __device__ __forceinline__ void split_stage(const float *cur, float *wr, f32x4 (
         }
         __builtin_amdgcn_sched_barrier(0);
         if (s == KS - 2) {
+#ifndef DG_PROBE_NO_BARRIER
             __syncthreads();
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }

@@ -13,6 +13,16 @@ build nobar -DDG_PROBE_NO_BARRIER
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/probe/mfma_rate.cpp -o tools/probe/bin/mfma_rate &
 build mfmaonly -DDG_PROBE_NO_FETCH -DDG_PROBE_NO_ISSUE -DDG_PROBE_NO_STORE -DDG_PROBE_NO_BARRIER
 build nomem -DDG_PROBE_NO_ISSUE -DDG_PROBE_NO_STORE
+# the weight-gradient (split) kernel of the wide layer, piece by piece, one and two waves per SIMD (dense_probe ... prints "dW")
+for kp in 1 2; do
+    build split_kp${kp} -DDG_SPLIT_KP=$kp
+    build split_kp${kp}_nofetch -DDG_SPLIT_KP=$kp -DDG_PROBE_NO_FETCH
+    build split_kp${kp}_noissue -DDG_SPLIT_KP=$kp -DDG_PROBE_NO_ISSUE -DDG_PROBE_NO_STORE
+    build split_kp${kp}_nostore -DDG_SPLIT_KP=$kp -DDG_PROBE_NO_STORE
+    build split_kp${kp}_nog -DDG_SPLIT_KP=$kp -DDG_PROBE_NO_G
+    build split_kp${kp}_nobar -DDG_SPLIT_KP=$kp -DDG_PROBE_NO_BARRIER
+    build split_kp${kp}_mfmaonly -DDG_SPLIT_KP=$kp -DDG_PROBE_NO_FETCH -DDG_PROBE_NO_ISSUE -DDG_PROBE_NO_STORE -DDG_PROBE_NO_G -DDG_PROBE_NO_BARRIER
+done
 wait
 ls -la tools/probe/bin
 
