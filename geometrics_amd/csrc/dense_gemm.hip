@@ -42,7 +42,7 @@ constexpr int DG_KS = 8;  // MFMA k-steps (4 elements each) per stage
 constexpr int SPLIT_RB = 6;        // weight-gradient tiles: 96 rows x 192 columns ...
 constexpr int SPLIT_RB_NARROW = 3; // ... 48 rows for layers of <= 192 inputs (see split_geometry)
 #ifndef DG_SPLIT_KP
-#define DG_SPLIT_KP 2
+#define DG_SPLIT_KP 1   // measured (profiles/r04_split_kernel_ablation.txt): two waves per SIMD buy nothing -- 66.8 vs 65.7 us
 #endif
 constexpr int SPLIT_KP_WIDE = DG_SPLIT_KP;   // k-parts (waves per SIMD) of the stand-alone weight-gradient launch of a wide layer, see split_stage
 constexpr int LD_TC = 34; // stride of a [row][t] panel: fragment reads hit bank (2*row + t) % 32 -- all distinct
@@ -834,8 +834,12 @@ __device__ __forceinline__ void split_dispatch(const SplitArgs &q, float *lds, c
     }
 }
 
-// KP = 2: eight waves per workgroup, see split_stage -- the stand-alone launch, one workgroup per CU (the 963-wide first
-// layer).  The pair launch keeps KP = 1: there the second wave of a SIMD is the row workgroup that shares the CU.
+// KP = 2: eight waves per workgroup, see split_stage -- built for the stand-alone launch of the 963-wide first layer (one
+// workgroup per CU) on the suspicion that a single wave per SIMD leaves the matrix pipe idle during its own stalls.  The
+// ablation says otherwise (tools/probe/run_probes.sh, profiles/r04_split_kernel_ablation.txt): with EVERYTHING but the
+// MFMAs removed from the loop the launch still takes 59.5 us of its 65.7 -- 50 us of MFMA issue at the full 2.39 GHz the chip
+// holds under this kernel + ~9.5 us of launch, first loads and the 18.5 MB burst of partial tiles at the end -- and a
+// second wave per SIMD changes nothing (66.8).  Kept as a build option (-DDG_SPLIT_KP=2), the shipped value is 1.
 template <int RB, int NCW, bool A_VEC, int KP>
 __global__ __launch_bounds__(DG_THREADS * KP) void dense_split_kernel(SplitArgs q)
 {
