@@ -46,7 +46,8 @@ VALU_ISSUE_TERA_LANE_OPS = FP32_PEAK_TFLOPS / 2.0
 VALU_MEASURED_TERA_LANE_OPS = 103.0 / 2.0
 TRI_ALGO_FLOP_PER_PAIR = 60.0    # hoisted op count of the reference's decision tree per (point, triangle)
 NN_FLOP_PER_PAIR = 8.0           # 3 sub, 3 mul, 2 add
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_counters.json")
+PROFILE_TAG = "r04"           # the committed profiles these figures are read from / compared with
+PMC_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_counters.json")
 
 
 class Workload:
@@ -497,6 +498,8 @@ def kernel_rooflines(w):
     gw1, gwh = torch.empty(FEAT, HID, device=pos.device), torch.empty(HID, HID, device=pos.device)
     t_red = event_time_us(lambda: dense.reduce([(rows, FEAT, HID, ws1, gw1, None), (rows, HID, HID, wsh, gwh, None),
                                                 (rows, HID, HID, wsh, gwh, None)]))
+    red_bytes = (ws1.numel() + 2 * wsh.numel()) * 4.0       # the partial tiles the launch reads (outputs: 1 MB)
+    red_step_us = step_profile_us("dense_reduce_kernel")
     dw1_flop = 2.0 * rows * FEAT * HID
     pair_flop = 4.0 * rows * HID * HID
     dw1_bytes = rows * FEAT * 4 + rows * HID * 4 + ws1.numel() * 4      # X once + G once + the partial tiles written
@@ -522,9 +525,13 @@ def kernel_rooflines(w):
         "traffic": dw1_traffic,
         "traffic_note": "FETCH_SIZE + WRITE_SIZE as reported (X is read with 4-byte loads -- its 963-float rows are never 16-byte "
                         "aligned -- so the guide's x2 for 16 B/lane reads does not apply to the bulk of the fetch)",
-        "sustained_clock_note": "under sustained fp32 MFMA load the chip runs ~2.08 GHz (a loop of nothing but these MFMAs: "
-                                "1.85 us per 3840-cycle stage), i.e. ~136 TFLOP/s is what the matrix pipe delivers; the "
-                                "library's best product of this step reaches 124"}
+        "pipe_rate_note": "the matrix pipe itself sustains 155 TFLOP/s (an MFMA-only loop holds 2.36 GHz for seconds: "
+                          "profiles/r04_mfma_pipe_rate.txt -- the guide's figure; round 3's '136 at 2.08 GHz' was wrong), and this "
+                          "kernel runs at the full 2.39 GHz (tools/probe/kernel_clock.py).  Of its launch time 50.0 us are MFMA issue "
+                          "(26 stages x 144 MFMAs x 32 cycles), ~9.5 us are what no loop tuning touches (launch, the first stages' "
+                          "loads from HBM, the 18.5 MB burst of partial tiles at the end: the SAME launch with nothing but MFMAs in "
+                          "its loop takes 59.5 us) and ~6 us loop inefficiency (X panel loads + LDS stores): "
+                          "profiles/r04_split_kernel_ablation.txt"}
     others = {
         "surface_scan_kernel (both arg-min scans of the surface loss)": scan,
         "dense_bwd_pair_kernel (hidden layer: dX and the dW partials in ONE launch, two workgroups per CU)": {
@@ -534,8 +541,16 @@ def kernel_rooflines(w):
             "library_three_launches_us_in_round2_step": 40.6},
         "dense_reduce_kernel (all weight gradients of a pass, fixed order)": {
             "bound": "hbm", "launch_us": round(t_red, 1),
-            "achieved": round((ws1.numel() + 2 * wsh.numel()) * 4 / (t_red * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round((ws1.numel() + 2 * wsh.numel()) * 4 / (t_red * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
+            "achieved": round(red_bytes / (t_red * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(red_bytes / (t_red * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_launch": int(red_bytes),
+            "in_step": None if red_step_us is None else {
+                "launch_us": red_step_us, "achieved": round(red_bytes / (red_step_us * 1e-6) / 1e9, 1),
+                "frac": round(red_bytes / (red_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "from the committed rocprofv3 trace of the step (profiles/%s_step_kernel_stats.csv): there the launch also "
+                        "applies Adam (+7 MB of parameters and moments, not counted) and its partial tiles come from HBM" % PROFILE_TAG},
+            "note": "`launch_us` is timed back to back on the same workspaces: the partial tiles are served from the 256 MiB "
+                    "infinity cache; the in-step figure is the honest one"},
         "chamfer_nn_scalar_kernel (stand-alone launch)": {
             "bound": "valu", "pipe": "fp32 VALU, un-fused (brute force: algorithmic == executed pairs)",
             "achieved": round(nn_tflops, 2), "peak": VALU_ISSUE_TERA_LANE_OPS, "unit": "T lane-op/s (= TFLOP/s: one flop per lane-op)",
@@ -548,8 +563,8 @@ def kernel_rooflines(w):
             "in_step": None if agg_step_us is None else {
                 "launch_us": agg_step_us, "achieved": round(agg_bytes / (agg_step_us * 1e-6) / 1e9, 1),
                 "frac": round(agg_bytes / (agg_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                "note": "from the committed rocprofv3 trace of the step (profiles/r03_step_kernel_stats.csv): operands come "
-                        "from HBM there"},
+                "note": "from the committed rocprofv3 trace of the step (profiles/%s_step_kernel_stats.csv): operands come "
+                        "from HBM there" % PROFILE_TAG},
             "note": "`launch_us` is timed back to back on one buffer pair: reads are served from the 256 MiB infinity cache; "
                     "the in-step figure is the honest one"},
     }
@@ -560,14 +575,14 @@ _step_profile = None
 
 
 def step_profile_us(kernel_prefix):
-    """Average duration (us) of a kernel in the committed rocprofv3 kernel trace of the step (profiles/r03_step_kernel_stats.csv),
-    or None when the file is missing / does not list it."""
+    """Average duration (us) of a kernel in the committed rocprofv3 kernel trace of the step
+    (profiles/<PROFILE_TAG>_step_kernel_stats.csv), or None when the file is missing / does not list it."""
     global _step_profile
     if _step_profile is None:
         _step_profile = {}
         try:
             import csv
-            with open(os.path.join(ROOT, "profiles", "r03_step_kernel_stats.csv")) as f:
+            with open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_step_kernel_stats.csv")) as f:
                 for r in csv.DictReader(f):
                     name = r.get("Name") or r.get("Kernel_Name") or ""
                     avg = r.get("AverageNs") or r.get("Average") or ""
@@ -869,7 +884,11 @@ def main():
                                       if world > 1 else "single process (no collective), "),
                        "meshes_per_gpu": per_gpu, "global_batch": per_gpu * world, "parallelism": "dp%d" % world,
                        "launch": launch, "gemm_selection": "tunableop file" if tuned else "library default",
-                       "clock_warmup_ms": args.clock_warmup_ms},
+                       "clock_warmup_ms": args.clock_warmup_ms,
+                       "dp_sequence": None if world == 1 else
+                       "per step: graph A [Adam on the bucket the previous step all-reduced, forward, backward, reduction launch "
+                       "-> bucket] ; ONE async all-reduce (gradients + loss, 1.04 MB) beside graph B [first layer's input "
+                       "gradient] ; the launch stream waits for the collective"},
             "final_loss": round(w.mean_loss(), 6),
         }
         if not args.steps_only:
