@@ -63,6 +63,12 @@ def v_async():
     gb.replay()
     work.wait()
 
+prio = os.environ.get("DP_GAPS_PRIORITY")
+if prio is not None:      # the launch stream with a priority of its own (-1 = high): does the command processor favour it?
+    torch.cuda.set_stream(torch.cuda.Stream(priority=int(prio)))
+    main = torch.cuda.current_stream()
+    print("launch stream priority", prio)
+
 for name, fn in (("A ; B", v_graphs_only), ("shipped: A ; async all-reduce ; B ; launch stream waits for it", v_async), ("A ; record ; B", v_event), ("A ; record ; side waits ; B", v_event_sidewait),
                  ("A ; record ; side: wait + all-reduce ; B", v_collective_no_join),
                  ("A ; record ; side waits ; B ; main waits side", v_join_only),
