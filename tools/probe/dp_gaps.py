@@ -57,6 +57,13 @@ def v_join_only():
     gb.replay()
     main.wait_stream(side)
 
+def v_b_first():
+    ga.replay(); ev.record(); gb.replay()
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        wl.bucket.all_reduce()
+    main.wait_stream(side)
+
 def v_async():
     ga.replay()
     work = wl.bucket.all_reduce_async()
@@ -69,7 +76,7 @@ if prio is not None:      # the launch stream with a priority of its own (-1 = h
     main = torch.cuda.current_stream()
     print("launch stream priority", prio)
 
-for name, fn in (("A ; B", v_graphs_only), ("shipped: A ; async all-reduce ; B ; launch stream waits for it", v_async), ("A ; record ; B", v_event), ("A ; record ; side waits ; B", v_event_sidewait),
+for name, fn in (("A ; B", v_graphs_only), ("A ; record ; B ; side: wait + all-reduce ; main waits side (B queued BEFORE the host-side collective call)", v_b_first), ("shipped: A ; async all-reduce ; B ; launch stream waits for it", v_async), ("A ; record ; B", v_event), ("A ; record ; side waits ; B", v_event_sidewait),
                  ("A ; record ; side: wait + all-reduce ; B", v_collective_no_join),
                  ("A ; record ; side waits ; B ; main waits side", v_join_only),
                  ("A ; all-reduce on the launch stream ; B", v_collective_on_main),
