@@ -61,7 +61,7 @@ def test_bench_whole_n_gt_1_path_with_rccl_on_one_gpu(gpu):
     """GEOM_BENCH_FORCE_DP=1: bench.py's complete N > 1 path -- RCCL process group, gradient bucket, two-graph step with the
     asynchronous all-reduce, the timed loop AND the per-kernel probes that follow it with RCCL's watchdog thread alive -- in
     a 1-rank group on this GPU.  What an 8-GPU node will run, minus the other seven ranks; the line must come out complete
-    (a capture invalidated by the watchdog's polling once cost the line its roofline: the probes capture thread-locally)."""
+    (the probes capture thread-locally, so that the watchdog's event polling cannot invalidate their captures)."""
     line = _run(["--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--clock-warmup-ms", "0"], {"GEOM_BENCH_FORCE_DP": "1"})
     assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and "forced_dp" in line["config"]
     assert line["config"]["launch"] == "hipgraph" and line["value"] > 0
