@@ -55,8 +55,9 @@ def global_mean_loss(local_loss_sum, local_count):
 
 class GradBucket:
     """One flat fp32 buffer for the DP exchange: every parameter gradient plus `extra` trailing scalars
-    (e.g. [loss_sum, mesh_count]), so a step needs exactly ONE all-reduce.  Autograd leaves a fresh
-    .grad on every parameter (no accumulate kernels); `pack()` gathers them with one launch,
+    (e.g. the shard's loss), so a step needs exactly ONE all-reduce.  Autograd leaves a fresh
+    .grad on every parameter (no accumulate kernels); `pack()` gathers them with one launch (bind=True: the layers' launches
+    write them in place and pack() has nothing to do),
     `all_reduce()` sums the buffer across ranks, `views` are per-parameter views of the reduced buffer
     (the 1/world scale is applied inside the optimiser kernel)."""
 

@@ -1,7 +1,7 @@
 """-m gpu: the REAL data-parallel step with two ranks.  Two processes share cuda:0 (gloo carries the collective; RCCL
 needs one GPU per rank), each runs bench.Workload on its contiguous shard of 16 meshes through bench.py's own N>1
 sequence (HIP graph A = Adam of the previous step (grad_scale = 1/world) + forward + backward + the reduction launch that
-writes the flat bucket; the all-reduce of the bucket with the loss tail from a side stream, beside HIP graph B = the first
+writes the flat bucket; the asynchronous all-reduce of the bucket with the loss tail, beside HIP graph B = the first
 layer's postponed input gradient), and the result must equal ONE process stepping all 16
 meshes: same samples (the sampler is keyed on the global mesh index), same mean loss, same parameters."""
 import socket
@@ -99,9 +99,10 @@ def test_two_rank_relu_step_tracks_the_single_process_16_mesh_step_up_to_relu_un
 @pytest.mark.timeout(600)
 def test_rccl_all_reduce_between_the_two_graph_replays_equals_the_single_graph_step(gpu):
     """RCCL itself, once: a 1-rank process group with backend "nccl" on cuda:0 and bench.Workload forced onto its N > 1
-    sequence (graph A: forward + backward + bucket pack; eager RCCL all-reduce of the 1.04 MB bucket on NCCL's own
-    stream; graph B: Adam on the bucket views, grad_scale = 1).  The ordering of an asynchronous collective between two
-    graph replays is what an 8-GPU node will run and what the gloo tests cannot exercise (gloo blocks the host); with one
+    sequence (graph A: Adam of the previous step on the bucket views (grad_scale = 1), forward, backward, reduction launch
+    -> bucket; the asynchronous RCCL all-reduce of the 1.04 MB bucket on NCCL's own stream; graph B: the first layer's postponed
+    input gradient beside it).  The ordering of an asynchronous collective between two graph replays is what an 8-GPU node
+    will run and what the gloo tests cannot exercise (gloo blocks the host); with one
     rank the sum is the identity, so parameters, gradients and losses must equal the plain single-graph step bit for bit."""
     port = _free_port()
     rccl = _collect(dist_step_worker.run_rccl_single, lambda n: [(port, 8, 5)], 1)
