@@ -32,9 +32,10 @@ sys.path.insert(0, ROOT)
 from geometrics_amd import dist as gdist  # noqa: E402
 from geometrics_amd import gemm_tuning, layers, meshgen, ops, optim, utils  # noqa: E402
 from geometrics_amd.chamfer_distance import chamfer_nn  # noqa: E402
-from geometrics_amd.tri_distance import tri_distance_indexed  # noqa: E402
+from geometrics_amd.tri_distance import kd_order, tri_distance_indexed  # noqa: E402
 
 V_LEVEL, S_PTS, G_PTS, FEAT, HID = 4, 3000, 3000, 963, 192
+CULLED_CHAMFER = True   # --plain-chamfer: the brute-force Chamfer tiles (same results; the A/B switch of the culled scan)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector peak == f32 MFMA dense peak
 
@@ -59,6 +60,11 @@ class Workload:
         self.faces = to(Fc)
         self.base = to(meshgen.jittered_batch(V, batch, first=first_mesh))
         self.gt = to(meshgen.gt_cloud(batch, G_PTS, first=first_mesh))
+        # static per ground-truth cloud (what a data loader computes once per object): a k-d visiting order and the index
+        # of the culled Chamfer scan.  Results do not depend on it (tests: bit-identical with and without).
+        self.gt_index = None
+        if CULLED_CHAMFER:
+            self.gt_index = ops.GtIndex(self.gt, torch.stack([kd_order(self.gt[i]) for i in range(batch)]))
         self.info = utils.adj_init(self.faces)
         # per-mesh seeds (global mesh index): a shard holds exactly the rows the whole-batch job would hold
         self.feat = torch.stack([torch.randn(self.nv, FEAT, generator=torch.Generator(device="cpu").manual_seed(seed + first_mesh + i))
@@ -122,7 +128,7 @@ class Workload:
                 else contextlib.nullcontext())
         with layers.deferred_parameter_gradients(), late, (self.opt.in_backward() if step_in_backward else contextlib.nullcontext()):
             pos = self.positions()
-            self.loss = utils.batch_point_to_surface(pos, self.info, self.gt, num=S_PTS,
+            self.loss = utils.batch_point_to_surface(pos, self.info, self.gt, num=S_PTS, gt_index=self.gt_index,
                                                      loss_out=self.bucket.extra if self.dp else None)
             self.loss.backward(self.seed_grad)              # explicit seed: no ones_like fill launch
         if self.dp:
@@ -622,7 +628,7 @@ def component_times(w):
 
     def loss_fb():
         pv.grad = None
-        utils.batch_point_to_surface(pv, w.info, w.gt, num=S_PTS).backward()
+        utils.batch_point_to_surface(pv, w.info, w.gt, num=S_PTS, gt_index=w.gt_index).backward()
     out["surface loss fwd+bwd (sampling, tri scan, NN, sums, scatter)"] = event_time_us(loss_fb, iters=10)
 
     def gcn_fwd():
@@ -826,6 +832,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clock-warmup-ms", type=float, default=250.0,
                     help="neutral GEMM load in front of the warm-up steps so that short runs are not timed on the clock ramp (0: off)")
+    ap.add_argument("--plain-chamfer", action="store_true", help="brute-force Chamfer tiles instead of the culled scan (same results)")
     ap.add_argument("--launch", choices=("graph", "eager"), default="graph",
                     help="replay the whole step as one HIP graph (default) or launch eagerly from python")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-stage event-timed breakdown")
@@ -833,6 +840,8 @@ def main():
                     help="no per-kernel timing loops (they capture HIP graphs, which rocprofv3 --pmc cannot trace): "
                          "what tools/pmc_traffic.sh runs together with --launch eager")
     args = ap.parse_args()
+    global CULLED_CHAMFER
+    CULLED_CHAMFER = not args.plain_chamfer
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")

@@ -75,10 +75,10 @@ _SIGNATURES = {
     "geom_surface_loss_bwd_f32": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp],
     "geom_surface_finalize_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i,
                                   _i, _vp, _vp, _vp],
-    "geom_surface_prepare_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _u, _vp, ctypes.c_size_t, _vp, _vp],
+    "geom_surface_prepare_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _u, _vp, ctypes.c_size_t, _vp, _vp, _vp],
     "geom_nn_cull_index_f32": [_i, _i, _vp, _vp, _vp, _vp],
     "geom_surface_scan_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                              _vp, _vp, _f, _f, _vp, _u, _vp, ctypes.c_size_t, _vp, _vp],
+                              _vp, _vp, _f, _f, _vp, _u, _vp, ctypes.c_size_t, _vp, _vp, _vp],
     "geom_surface_gather_f32": [_i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "geom_vertex_head_fwd_f32": [ctypes.c_int64, _i, _vp, _vp, _f, _vp, _vp],
     "geom_vertex_head_bwd_f32": [ctypes.c_int64, _i, _vp, _f, _vp, _vp],
@@ -116,6 +116,12 @@ _SIGNATURES = {
     "geom_zn_gcn_aggregate_ell_head_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp],
     "geom_zn_gcn_aggregate_bwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
 }
+
+
+class SurfaceCull(ctypes.Structure):
+    """struct geom_surface_cull (include/geom_hip.h): the buffers of the culled Chamfer scan inside the surface step."""
+    _fields_ = [("gt_order", ctypes.c_void_p), ("gt_index", ctypes.c_void_p), ("sample_index", ctypes.c_void_p),
+                ("faces_in_order", ctypes.c_void_p)]
 
 
 def call(name, *args):

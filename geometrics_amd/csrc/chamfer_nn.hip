@@ -175,7 +175,8 @@ __global__ __launch_bounds__(NNS_THREADS) void chamfer_nn_scalar_kernel(NNJob jo
 template <bool FMA>
 __global__ __launch_bounds__(NNS_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void chamfer_nn_culled_kernel(NNJob job, NNCull cu)
 {
-    nn_culled_body<FMA>(job, cu, blockIdx.x, NNRecords{nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0});
+    __shared__ NNCullLds lds;
+    nn_culled_body<FMA>(job, cu, blockIdx.x, NNRecords{nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0}, lds);
 }
 
 __global__ __launch_bounds__(256) void nn_cull_index_kernel(int n, const float *xyz, const int *order, float *xs, float4 *sph)

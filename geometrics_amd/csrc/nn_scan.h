@@ -296,16 +296,31 @@ __device__ __forceinline__ float nn_wave_min(float v)
     return fminf(fminf(r0, r1), fminf(r2, r3));
 }
 
+// The culled tile's LDS as ONE object, so that a kernel that runs this body beside another one (the fused surface scan: a
+// workgroup is EITHER a triangle tile OR a Chamfer tile) can overlay the two in a union -- separate __shared__ arrays of two
+// inlined bodies are added up by the compiler (70 KB for the pair = two workgroups per CU; 43 KB overlaid = three).
+struct NNCullLds {
+    float4 sph[NNC_SPH];
+    __attribute__((aligned(16))) float stage[NNS_WAVES][NNC_SLOTS][NNC_RUN_FLOATS];
+    float4 pend_sph[NNS_WAVES][NNC_SLOTS + 1]; // the wave's pending runs: sphere, run
+    int pend_run[NNS_WAVES][NNC_SLOTS + 1];
+    float part_d[NNS_WAVES + 1][NN_QUERIES], seed_d[NNS_WAVES][NN_QUERIES], qp[3][NN_QUERIES]; // + 1: the ragged tail's partial result
+    int part_i[NNS_WAVES + 1][NN_QUERIES], part_g[NNS_WAVES][NN_QUERIES];
+};
+
 template <bool FMA>
-__device__ __forceinline__ void nn_culled_body(const NNJob &job, const NNCull &cu, int bid, const NNRecords &rr)
+__device__ __forceinline__ void nn_culled_body(const NNJob &job, const NNCull &cu, int bid, const NNRecords &rr, NNCullLds &L)
 {
-    __shared__ float4 sph[NNC_SPH];
-    __shared__ __attribute__((aligned(16))) float stage[NNS_WAVES][NNC_SLOTS][NNC_RUN_FLOATS];
-    __shared__ float4 pend_sph[NNS_WAVES][NNC_SLOTS + 1]; // the wave's pending runs: sphere, run
-    __shared__ int pend_run[NNS_WAVES][NNC_SLOTS + 1];
+    auto &sph = L.sph;
+    auto &stage = L.stage;
+    auto &pend_sph = L.pend_sph;
+    auto &pend_run = L.pend_run;
     constexpr int PARTS = NNS_WAVES + 1;                  // one partial result per wave + the ragged tail's
-    __shared__ float part_d[PARTS][NN_QUERIES], seed_d[NNS_WAVES][NN_QUERIES], qp[3][NN_QUERIES];
-    __shared__ int part_i[PARTS][NN_QUERIES], part_g[NNS_WAVES][NN_QUERIES];
+    auto &part_d = L.part_d;
+    auto &seed_d = L.seed_d;
+    auto &qp = L.qp;
+    auto &part_i = L.part_i;
+    auto &part_g = L.part_g;
 
     const int longer = job.n > job.m ? job.n : job.m;
     int jobid, qtile;
@@ -356,6 +371,7 @@ __device__ __forceinline__ void nn_culled_body(const NNJob &job, const NNCull &c
     for (int t = threadIdx.x; t < min(NNC_SPH, runs); t += NNS_THREADS) sph[t] = S[t];
     if (wave == 0) qp[0][lane] = qx, qp[1][lane] = qy, qp[2][lane] = qz;
     __syncthreads();
+    if (NN_DBG(32)) { out_d[q0] = qx + f0x + own.x + sph[lane].x + qo[0] + qo[1]; return; }
 
     float best = INFINITY;
     int best_grp = -1, best_orig = INT_MAX;
@@ -409,6 +425,7 @@ __device__ __forceinline__ void nn_culled_body(const NNJob &job, const NNCull &c
         const int rstar = __builtin_amdgcn_readlane(kr, at ? __builtin_ctzll(at) : 0);
         // seeds: eight neighbouring runs of the visiting order around it, one per wave; the lanes share the best of the eight
         const int lo = max(0, min(rstar - 3, runs - NNS_WAVES));
+        if (NN_DBG(64)) { out_d[q0] = qx + f0x + lo + qo[0] + qo[1]; return; }
         if (lo + wave < runs) {
             nn_fetch_run(Ts + (size_t)(lo + wave) * NNC_RUN_FLOATS, &stage[wave][0][0], lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -419,6 +436,7 @@ __device__ __forceinline__ void nn_culled_body(const NNJob &job, const NNCull &c
         float bound = seed_d[0][lane];
 #pragma unroll
         for (int w = 1; w < NNS_WAVES; ++w) bound = fminf(bound, seed_d[w][lane]);
+        if (NN_DBG(128)) { out_d[q0] = qx + f0x + bound + qo[0] + qo[1]; return; }
         const bool geo = live && qx - qx == 0.f && qy - qy == 0.f && qz - qz == 0.f;
         const unsigned long long geo_mask = __builtin_amdgcn_ballot_w64(geo);
         // s_q >= sqrt of the lane's bound: v_sqrt_f32 is good to 1 ulp, the margins are 2^-10 relative + 2^-12 |q|_1
@@ -508,7 +526,7 @@ __device__ __forceinline__ void nn_culled_body(const NNJob &job, const NNCull &c
                     queued += take;
                 }
             }
-            if (pending) flush();
+            if (pending) flush(); // before the spheres' chunk... (pend_sph holds copies: only for simplicity)
         }
         if (wave == 0) NN_STAT(0, 1);
     }
@@ -528,6 +546,7 @@ __device__ __forceinline__ void nn_culled_body(const NNJob &job, const NNCull &c
         part_i[NNS_WAVES][lane] = tail_o;
     }
     __syncthreads();
+    if (NN_DBG(256)) { out_d[q0] = part_d[0][lane] + f0x + qo[0] + qo[1]; return; }
 
     // closing phase, thread <-> (query, member of a run): the smallest distance of the eight waves, the lowest original
     // index among the targets that attain it (the members of the winning run(s), one per thread; same arithmetic => exact

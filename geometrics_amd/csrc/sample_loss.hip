@@ -64,8 +64,8 @@ __global__ __launch_bounds__(DRAW_THREADS) void draw_samples_kernel(int nv, cons
                                                                      unsigned long long *rng_state,
                                                                      int64_t *choices, float *u, float *v, float *points)
 {
-    draw_samples_body(blockIdx.x, blockIdx.y, (unsigned long long)gridDim.x * gridDim.y, nv, verts, nf, faces, num, uniforms,
-                      plane, rng_state, choices, u, v, points);
+    draw_samples_body<false>(blockIdx.x, blockIdx.y, (unsigned long long)gridDim.x * gridDim.y, nv, verts, nf, faces, num, uniforms,
+                             plane, rng_state, choices, u, v, points, DrawSort{});
 }
 
 // -------------------------------------------------------------- face sampling ----

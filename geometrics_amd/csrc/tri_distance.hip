@@ -791,37 +791,51 @@ __global__ __launch_bounds__(256) void tri_prep_grouped_kernel(TriJob job, TriGw
 // The per-step PREPARATION of the surface loss in one launch: everything that depends only on the vertex positions --
 // the random face draws (+ the sampled points) of batch_sample and the triangle records / group spheres of the
 // two-level scan.  Workgroups [0, draw_blocks) run a draw chunk, the rest 1024 triangle slots each.
-template <bool FIX6>
+template <bool FIX6, bool SORTED>
 __global__ __launch_bounds__(DRAW_THREADS) void surface_prepare_kernel(int draw_blocks, int draw_chunks, int nv, const float *verts,
                                                                         int nf, const int64_t *faces, int num,
                                                                         unsigned long long *rng_state, int64_t *choices, float *u,
                                                                         float *v, float *points, TriJob job, TriGws ws,
-                                                                        const int *__restrict__ order, int prep_chunks)
+                                                                        const int *__restrict__ order, int prep_chunks, DrawSort srt)
 {
-    if ((int)blockIdx.x < draw_blocks) {
-        draw_samples_body(blockIdx.x % draw_chunks, blockIdx.x / draw_chunks, (unsigned long long)draw_blocks, nv, verts, nf,
-                          faces, num, nullptr, 0, rng_state, choices, u, v, points);
+    if ((int)blockIdx.x < draw_blocks) { // SORTED: one workgroup per mesh (draw_chunks == 1) draws everything and sorts
+        draw_samples_body<SORTED>(blockIdx.x % draw_chunks, blockIdx.x / draw_chunks, (unsigned long long)draw_blocks, nv, verts, nf,
+                                  faces, num, nullptr, 0, rng_state, choices, u, v, points, srt);
     } else {
         const int pid = blockIdx.x - draw_blocks;
         tri_prep_grouped_body<true, false, FIX6>(job, ws, order, (pid % prep_chunks) * DRAW_THREADS + threadIdx.x, pid / prep_chunks);
     }
 }
 
+// the tile's LDS as one object (see NNCullLds in nn_scan.h: the fused scan overlays the two bodies' LDS)
+template <int HS_WAVES>
+struct TriTileLds {
+    float4 gtile[HS_GCHUNK];
+    unsigned long long qbest[TRI_QUERIES]; // best evaluated (distance, triangle, region)
+    unsigned long long qseed[TRI_QUERIES]; // smallest group upper bound and its group
+    unsigned long long seed_part[HS_WAVES][TRI_QUERIES]; // per-wave candidates for it (no LDS atomics)
+    unsigned qs[TRI_QUERIES];              // seed slack (float bits, positive: uint order == float order)
+    float qp[3][TRI_QUERIES], qmag[TRI_QUERIES];
+    unsigned queue_a[HS_WAVES][HS_QA];
+    unsigned queue_b[HS_WAVES][HS_QB];
+};
+
 template <bool TRUNC, bool FIX6, int HS_WAVES>
 __device__ __forceinline__ void tri_scan_grouped_body(int bid, const float *__restrict__ xyz, int b, int n, int m,
                                                       const TriGws &ws, float *__restrict__ dist, int *__restrict__ point,
-                                                      int *__restrict__ index, const SurfaceOut &surf)
+                                                      int *__restrict__ index, const SurfaceOut &surf, TriTileLds<HS_WAVES> &L)
 {
     static_assert(HS_WAVES <= GRP, "the seed reduction maps wave w to member lane w");
     constexpr int HS_THREADS = HS_WAVES * GEOM_WAVE;
-    __shared__ float4 gtile[HS_GCHUNK];
-    __shared__ unsigned long long qbest[TRI_QUERIES]; // best evaluated (distance, triangle, region)
-    __shared__ unsigned long long qseed[TRI_QUERIES]; // smallest group upper bound and its group
-    __shared__ unsigned long long seed_part[HS_WAVES][TRI_QUERIES]; // per-wave candidates for it (no LDS atomics)
-    __shared__ unsigned qs[TRI_QUERIES];              // seed slack (float bits, positive: uint order == float order)
-    __shared__ float qp[3][TRI_QUERIES], qmag[TRI_QUERIES];
-    __shared__ unsigned queue_a[HS_WAVES][HS_QA];
-    __shared__ unsigned queue_b[HS_WAVES][HS_QB];
+    auto &gtile = L.gtile;
+    auto &qbest = L.qbest;
+    auto &qseed = L.qseed;
+    auto &seed_part = L.seed_part;
+    auto &qs = L.qs;
+    auto &qp = L.qp;
+    auto &qmag = L.qmag;
+    auto &queue_a = L.queue_a;
+    auto &queue_b = L.queue_b;
 
     const int split = ws.split, m_pad = ws.m_pad;
     int mesh, task;
@@ -1060,7 +1074,8 @@ __global__ __launch_bounds__(HS_WAVES * GEOM_WAVE) void tri_scan_grouped_kernel(
                                                                        int *__restrict__ point, int *__restrict__ index,
                                                                        SurfaceOut surf)
 {
-    tri_scan_grouped_body<TRUNC, FIX6, HS_WAVES>(blockIdx.x, xyz, b, n, m, ws, dist, point, index, surf);
+    __shared__ TriTileLds<HS_WAVES> lds;
+    tri_scan_grouped_body<TRUNC, FIX6, HS_WAVES>(blockIdx.x, xyz, b, n, m, ws, dist, point, index, surf, lds);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1076,15 +1091,32 @@ __global__ __launch_bounds__(HS_WAVES * GEOM_WAVE) void tri_scan_grouped_kernel(
 // build (3 workgroups per CU instead of 2, 13 registers spilled): 55.3.  PMC of this launch: 32.0 M VALU instructions
 // = 40 T lane-ops/s, 0.51 of the 78.6 T spec issue rate and 0.78 of the 51.5 T the chip sustains on un-packed v_fma_f32
 // (MI355X_MICROARCH.md: 103 TFLOP/s measured) -- the fused launch is VALU-issue bound, what is left is instruction count.
-template <bool FIX6, bool FMA>
-__global__ __launch_bounds__(8 * GEOM_WAVE) void surface_scan_kernel(const float *__restrict__ xyz, int b, int n, int m, TriGws ws,
-                                                                      float *__restrict__ dist, int *__restrict__ point,
-                                                                      int *__restrict__ index, SurfaceOut surf, NNJob job,
-                                                                      NNRecords rr, int tri_blocks)
+// CULL: the Chamfer tiles take the culled scan (nn_culled_body).  Its tiles are latency chains, not issue-bound loops, so
+// the launch wants THREE workgroups per CU: the two bodies' LDS is overlaid (a workgroup is one or the other: 43 KB instead
+// of 27 + 43) and the register budget is capped at 80 (6 waves per SIMD; the triangle body spills a dozen registers to
+// scratch there, measured harmless).  The brute-force variant keeps two workgroups per CU: it IS issue-bound, and capping
+// its registers only added spills (round 2: 55.3 against 48 us).
+template <bool FIX6, bool FMA, bool CULL>
+__global__ __launch_bounds__(8 * GEOM_WAVE, CULL ? 6 : 1) void surface_scan_kernel(const float *__restrict__ xyz, int b, int n, int m,
+                                                                                  TriGws ws, float *__restrict__ dist,
+                                                                                  int *__restrict__ point, int *__restrict__ index,
+                                                                                  SurfaceOut surf, NNJob job, NNRecords rr,
+                                                                                  int tri_blocks, NNCull cull)
 {
     static_assert(NNS_THREADS == 8 * GEOM_WAVE, "both bodies are written for 8-wave workgroups");
-    if ((int)blockIdx.x < tri_blocks) tri_scan_grouped_body<false, FIX6, 8>(blockIdx.x, xyz, b, n, m, ws, dist, point, index, surf);
-    else nn_scalar_body<FMA>(job, blockIdx.x - tri_blocks, rr);
+    if constexpr (CULL) {
+        __shared__ union Lds {
+            TriTileLds<8> tri;
+            NNCullLds nn;
+            __device__ Lds() {}
+        } lds;
+        if ((int)blockIdx.x < tri_blocks) tri_scan_grouped_body<false, FIX6, 8>(blockIdx.x, xyz, b, n, m, ws, dist, point, index, surf, lds.tri);
+        else nn_culled_body<FMA>(job, cull, blockIdx.x - tri_blocks, rr, lds.nn);
+    } else {
+        __shared__ TriTileLds<8> lds;
+        if ((int)blockIdx.x < tri_blocks) tri_scan_grouped_body<false, FIX6, 8>(blockIdx.x, xyz, b, n, m, ws, dist, point, index, surf, lds);
+        else nn_scalar_body<FMA>(job, blockIdx.x - tri_blocks, rr);
+    }
 }
 
 template <bool INDEXED, bool TRUNC, bool FIX6>
@@ -1296,7 +1328,8 @@ extern "C" int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, 
                                      const int64_t *faces, const int *tri_order, float *tri_dist, int *option, int *index,
                                      float *sq, float *closest, float *weights, const float *u, const float *v,
                                      float coef_sample, float coef_other, int *order_scratch, unsigned flags,
-                                     void *workspace, size_t workspace_bytes, int *records_written, void *stream)
+                                     void *workspace, size_t workspace_bytes, int *records_written,
+                                     const geom_surface_cull *cull, void *stream)
 {
     if (records_written) *records_written = 0;
     if (b < 0 || n_gt < 0 || num < 0 || nf < 0 || nv < 0) return GEOM_EINVAL;
@@ -1343,13 +1376,29 @@ extern "C" int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, 
             const unsigned tri_blocks = geom::xcd_grid(b, qtiles);
             SurfaceOut so{verts, faces, nv, sq, closest, weights, rec, coef_other, (int)cap, num};
             const dim3 grid(tri_blocks + nn_blocks), block(8 * GEOM_WAVE);
-#define GEOM_LAUNCH_SCAN(F6, FM)                                                                                                \
-    hipLaunchKernelGGL((surface_scan_kernel<F6, FM>), grid, block, 0, s, gt, b, n_gt, nf, gws, tri_dist, option, index, so, job, rr, \
-                       (int)tri_blocks)
-            if (fix6 && fma) GEOM_LAUNCH_SCAN(true, true);
-            else if (fix6) GEOM_LAUNCH_SCAN(true, false);
-            else if (fma) GEOM_LAUNCH_SCAN(false, true);
-            else GEOM_LAUNCH_SCAN(false, false);
+            // the Chamfer tiles take the culled scan when the caller handed over the indices of both clouds (the gt
+            // cloud's: static; the sampled points': written by geom_surface_prepare_f32 of the same step)
+            const bool culled = cull && cull->gt_index && cull->sample_index;
+            if (culled && (((uintptr_t)cull->gt_index | (uintptr_t)cull->sample_index) & 15)) return GEOM_EINVAL;
+            NNCull nc{};
+            if (culled) {
+                const float4 *s1 = reinterpret_cast<const float4 *>(cull->gt_index), *s2 = reinterpret_cast<const float4 *>(cull->sample_index);
+                nc = NNCull{reinterpret_cast<const float *>(s1 + (size_t)b * (n_gt / NNS_GROUP)),
+                            reinterpret_cast<const float *>(s2 + (size_t)b * (num / NNS_GROUP)), cull->gt_order, nullptr, s1, s2}; // samples: identity order
+            }
+#define GEOM_LAUNCH_SCAN(F6, FM, CU)                                                                                            \
+    hipLaunchKernelGGL((surface_scan_kernel<F6, FM, CU>), grid, block, 0, s, gt, b, n_gt, nf, gws, tri_dist, option, index, so, job, \
+                       rr, (int)tri_blocks, nc)
+#define GEOM_LAUNCH_SCAN2(F6, FM)                                                                                               \
+    do {                                                                                                                        \
+        if (culled) GEOM_LAUNCH_SCAN(F6, FM, true);                                                                             \
+        else GEOM_LAUNCH_SCAN(F6, FM, false);                                                                                   \
+    } while (0)
+            if (fix6 && fma) GEOM_LAUNCH_SCAN2(true, true);
+            else if (fix6) GEOM_LAUNCH_SCAN2(true, false);
+            else if (fma) GEOM_LAUNCH_SCAN2(false, true);
+            else GEOM_LAUNCH_SCAN2(false, false);
+#undef GEOM_LAUNCH_SCAN2
 #undef GEOM_LAUNCH_SCAN
             if (records_written) *records_written = rec != nullptr;
             return geom::launch_status();
@@ -1375,7 +1424,7 @@ extern "C" int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, 
 extern "C" int geom_surface_prepare_f32(int b, int nv, const float *verts, int nf, const int64_t *faces, int num,
                                         uint64_t *rng_state, int64_t *choices, float *u, float *v, float *points, int n_gt,
                                         const int *tri_order, unsigned flags, void *workspace, size_t workspace_bytes,
-                                        int *prepared, void *stream)
+                                        int *prepared, const geom_surface_cull *cull, void *stream)
 {
     if (prepared) *prepared = 0;
     if (b < 0 || nv < 0 || nf < 0 || num < 0 || n_gt < 0) return GEOM_EINVAL;
@@ -1397,15 +1446,32 @@ extern "C" int geom_surface_prepare_f32(int b, int nv, const float *verts, int n
     TriGws gws{base, base + (size_t)b * m_pad, grp, first, reinterpret_cast<unsigned long long *>(first + (size_t)b * 3), m_pad, 1};
     TriJob tj{nullptr, nullptr, nullptr, nullptr, verts, faces, nullptr, nullptr, nullptr, b, n_gt, nf, nv};
     const int prep_chunks = (m_pad + DRAW_THREADS - 1) / DRAW_THREADS;
+    unsigned long long *st = reinterpret_cast<unsigned long long *>(rng_state);
+    // the culled Chamfer scan of the same step wants the samples in a visiting order: the draw workgroups then generate them
+    // in the order of their faces' positions in tri_order (sorted uniforms from exponential spacings: draw_body.h) and write
+    // the samples' index -- run spheres + visiting-order copy
+    const bool sorted = cull && cull->sample_index && num >= NN_QUERIES && num < DRAW_SORT_CHUNKS * DRAW_THREADS;
+    if (sorted && ((uintptr_t)cull->sample_index & 15)) return GEOM_EINVAL;
     const int draw_blocks = draw_chunks * b;
     const dim3 grid(draw_blocks + prep_chunks * b), block(DRAW_THREADS);
-    unsigned long long *st = reinterpret_cast<unsigned long long *>(rng_state);
+    if (sorted) {
+        float4 *sph = reinterpret_cast<float4 *>(cull->sample_index);
+        DrawSort srt{tri_order, cull->faces_in_order, reinterpret_cast<float *>(sph + (size_t)b * (num / NNS_GROUP)), sph};
+        if (flags & GEOM_FLAG_FIX_REGION6)
+            hipLaunchKernelGGL((surface_prepare_kernel<true, true>), grid, block, 0, s, draw_blocks, draw_chunks, nv, verts, nf, faces,
+                               num, st, choices, u, v, points, tj, gws, tri_order, prep_chunks, srt);
+        else
+            hipLaunchKernelGGL((surface_prepare_kernel<false, true>), grid, block, 0, s, draw_blocks, draw_chunks, nv, verts, nf, faces,
+                               num, st, choices, u, v, points, tj, gws, tri_order, prep_chunks, srt);
+        if (prepared) *prepared = 3; // bit 0: triangle records; bit 1: the sampled points' index
+        return geom::launch_status();
+    }
     if (flags & GEOM_FLAG_FIX_REGION6)
-        hipLaunchKernelGGL(surface_prepare_kernel<true>, grid, block, 0, s, draw_blocks, draw_chunks, nv, verts, nf, faces, num, st,
-                           choices, u, v, points, tj, gws, tri_order, prep_chunks);
+        hipLaunchKernelGGL((surface_prepare_kernel<true, false>), grid, block, 0, s, draw_blocks, draw_chunks, nv, verts, nf, faces, num,
+                           st, choices, u, v, points, tj, gws, tri_order, prep_chunks, DrawSort{});
     else
-        hipLaunchKernelGGL(surface_prepare_kernel<false>, grid, block, 0, s, draw_blocks, draw_chunks, nv, verts, nf, faces, num, st,
-                           choices, u, v, points, tj, gws, tri_order, prep_chunks);
+        hipLaunchKernelGGL((surface_prepare_kernel<false, false>), grid, block, 0, s, draw_blocks, draw_chunks, nv, verts, nf, faces, num,
+                           st, choices, u, v, points, tj, gws, tri_order, prep_chunks, DrawSort{});
     if (prepared) *prepared = 1;
     return geom::launch_status();
 }

@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from . import chamfer_distance as _chamfer
 from .chamfer_distance import chamfer_nn
-from .tri_distance import face_order, tri_distance_indexed
+from .tri_distance import face_order, faces_in_order, morton_order, tri_distance_indexed
 
 
 def _f32(t, name, ndim, last=None):
@@ -159,6 +159,41 @@ def vertex_faces(faces, nv):
     return vf_ptr, vf_item
 
 
+class GtIndex:
+    """What the culled Chamfer scan of the surface step keeps per ground-truth cloud (static data: built once per batch of
+    objects, e.g. by the data loader): a spatially coherent visiting order [B,N] int32 and the index written from it by
+    geom_nn_cull_index_f32 (run spheres + the cloud in that order).  `order=None`: a 30-bit Morton order made on the
+    device.  Any order gives the same results, bit for bit; a bad one only costs speed."""
+
+    def __init__(self, gt_points, order=None):
+        gt = _f32(gt_points.detach(), "gt_points", 3, 3)
+        b, n, _ = gt.shape
+        if order is None:
+            order = torch.stack([morton_order(gt[i]) for i in range(b)]) if b else torch.empty(0, n, dtype=torch.int32, device=gt.device)
+        order = _lib.require(order, "order", torch.int32, 2)
+        if order.shape != (b, n) or order.device != gt.device:
+            raise RuntimeError("order must be an int32 [B,N] permutation per cloud on the clouds' device")
+        self.order = order
+        self.index = torch.empty(max(int(_lib.lib().geom_nn_cull_index_floats(b, n)), 4), dtype=torch.float32, device=gt.device)
+        self.shape, self.device = (b, n), gt.device
+        self.source = (gt.data_ptr(), gt._version)
+        with torch.cuda.device(gt.device):
+            _lib.call("geom_nn_cull_index_f32", b, n, gt.data_ptr(), order.data_ptr(), self.index.data_ptr())
+
+    def check(self, gt):
+        if tuple(gt.shape[:2]) != self.shape or gt.device != self.device or (gt.data_ptr(), gt._version) != self.source:
+            raise RuntimeError("this GtIndex was built for another ground-truth tensor (or the tensor was modified since)")
+
+
+class ScanPrep:
+    """What the draw launch of a step prepared for the scan of the same step (ops.draw_samples(prepare_scan_for=...)): the
+    triangle records and, on the culled route, the index of the sampled points (which were generated in visiting order)."""
+    __slots__ = ("tri_ws", "sample_index")
+
+    def __init__(self, tri_ws, sample_index=None):
+        self.tri_ws, self.sample_index = tri_ws, sample_index
+
+
 class SurfaceLoss(torch.autograd.Function):
     """The whole sampled-surface loss of the reference in one autograd node.
 
@@ -174,7 +209,7 @@ class SurfaceLoss(torch.autograd.Function):
     distances feed the F1 score and are not differentiable."""
 
     @staticmethod
-    def forward(ctx, verts, faces, gt, choices, u, v, two_sided, scale, points=None, tri_ws=None, loss_out=None):
+    def forward(ctx, verts, faces, gt, choices, u, v, two_sided, scale, points=None, tri_ws=None, loss_out=None, gt_index=None):
         verts_c = _f32(verts.detach(), "verts", 3, 3)
         gt_c = _f32(gt.detach(), "gt_points", 3, 3)
         faces = _lib.require(faces, "faces", torch.int64, 2, 3)
@@ -200,6 +235,13 @@ class SurfaceLoss(torch.autograd.Function):
             out = loss_out.detach().view(())
         sq_gt, sq_pred = torch.empty(b, n_gt, **f32), torch.empty(b, num, **f32)
         idx_p, idx_g = torch.empty(b, n_gt, **i32), torch.empty(b, num, **i32)
+        prep = tri_ws if isinstance(tri_ws, ScanPrep) else None
+        if prep is not None:
+            tri_ws = prep.tri_ws
+        cull = None
+        if gt_index is not None and prep is not None and prep.sample_index is not None and not two_sided:
+            gt_index.check(gt_c)    # the culled Chamfer tiles: both clouds' indices are there
+            cull = _lib.SurfaceCull(gt_index.order.data_ptr(), gt_index.index.data_ptr(), prep.sample_index.data_ptr(), None)
         if not two_sided:
             ws_bytes = L.geom_tri_distance_workspace_bytes(b, n_gt, nf)
             ws_ready = tri_ws is not None and have_points      # written by the draw launch (ops.draw_samples(prepare_scan_for=...))
@@ -235,7 +277,8 @@ class SurfaceLoss(torch.autograd.Function):
             _lib.check(L.geom_surface_scan_f32(
                 b, n_gt, gt_c.data_ptr(), num, points.data_ptr(), sq_gt.data_ptr(), idx_p.data_ptr(), sq_pred.data_ptr(),
                 idx_g.data_ptr(), *tri_args, u.data_ptr(), v.data_ptr(), coef_s, coef_o, order.data_ptr() if want else None,
-                flags, ws_ptr, ws_len, ctypes.byref(wrote), _lib.stream_ptr()), "geom_surface_scan_f32")
+                flags, ws_ptr, ws_len, ctypes.byref(wrote), ctypes.byref(cull) if cull is not None else None,
+                _lib.stream_ptr()), "geom_surface_scan_f32")
             # finalize: the loss reduction AND, when a gradient is wanted, the backward's preparation (points counting-sorted
             # by face in ascending id order; the records too when the scans could not write them) in one launch; the
             # backward is then a single gather launch
@@ -288,7 +331,7 @@ class SurfaceLoss(torch.autograd.Function):
                               u.data_ptr(), v.data_ptr(), points.data_ptr(), n_gt, gt.data_ptr(), saved[6].data_ptr(),
                               index.data_ptr(), closest.data_ptr(), weights.data_ptr(), grad.data_ptr(),
                               ctx.scale / (b * num), ctx.scale / (b * n_gt), grad_verts.data_ptr())
-        return grad_verts, None, None, None, None, None, None, None, None, None, None
+        return grad_verts, None, None, None, None, None, None, None, None, None, None, None
 
 
 class Laplacian(torch.autograd.Function):
@@ -466,7 +509,7 @@ def _rng_state(dev):
     return st
 
 
-def draw_samples(verts, faces, num, generator=None, with_points=False, prepare_scan_for=None):
+def draw_samples(verts, faces, num, generator=None, with_points=False, prepare_scan_for=None, gt_index=None):
     """The random part of batch_sample (reference utils.py:604-612, 627-628): choices [B,num] ~
     area-weighted with replacement, u = sqrt(U1), v = U2, in ONE kernel: per-mesh face-area CDF in LDS,
     binary search per sample, uniforms from an in-kernel Philox stream whose position lives on the device
@@ -476,7 +519,9 @@ def draw_samples(verts, faces, num, generator=None, with_points=False, prepare_s
     kernel could not produce them), which ops.SurfaceLoss accepts in place of its own gather launch.
     prepare_scan_for = n_gt (with with_points=True): the same launch also writes the triangle records of the surface scan
     of n_gt query points per mesh; a fifth return value is then the prepared workspace tensor (or None when the scan
-    will not take the fused route), to be handed to ops.SurfaceLoss as `tri_ws`."""
+    will not take the fused route), to be handed to ops.SurfaceLoss as `tri_ws`.  gt_index (an ops.GtIndex of the step's
+    ground-truth clouds): the launch also lists the samples in a visiting order and writes their index for the culled
+    Chamfer scan; the fifth return value is then an ops.ScanPrep carrying both."""
     verts_c = _f32(verts.detach(), "verts", 3, 3)
     faces = _lib.require(faces, "faces", torch.int64, 2, 3)
     b, nv, _ = verts_c.shape
@@ -494,11 +539,18 @@ def draw_samples(verts, faces, num, generator=None, with_points=False, prepare_s
                 ws_bytes = _lib.lib().geom_tri_distance_workspace_bytes(b, n_gt, nf)
                 tri_ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device=dev)
                 prepared = ctypes.c_int(0)
+                cull = s_index = None
+                if gt_index is not None:
+                    s_index = torch.empty(max(int(_lib.lib().geom_nn_cull_index_floats(b, num)), 4), dtype=torch.float32, device=dev)
+                    cull = _lib.SurfaceCull(None, None, s_index.data_ptr(), _lib.ptr(faces_in_order(verts_c, faces)))
                 code = _lib.lib().geom_surface_prepare_f32(
                     b, nv, verts_c.data_ptr(), nf, faces.data_ptr(), num, _rng_state(dev).data_ptr(), choices.data_ptr(),
                     u.data_ptr(), v.data_ptr(), points.data_ptr(), n_gt, _lib.ptr(face_order(verts_c, faces)), 0,
-                    tri_ws.data_ptr(), ws_bytes, ctypes.byref(prepared), _lib.stream_ptr())
+                    tri_ws.data_ptr(), ws_bytes, ctypes.byref(prepared), ctypes.byref(cull) if cull is not None else None,
+                    _lib.stream_ptr())
                 if code == 0:
+                    if prepared.value & 2:
+                        return choices, u, v, points, ScanPrep(tri_ws, s_index)
                     return choices, u, v, points, (tri_ws if prepared.value else None)
             else:
                 code = _lib.lib().geom_draw_samples_rng_f32(b, nv, verts_c.data_ptr(), faces.shape[0], faces.data_ptr(), num,
@@ -555,5 +607,5 @@ class VertexHead(torch.autograd.Function):
 
 __all__ = ["face_areas", "device_sum", "SampleFaces", "GatherSqDistSum", "PointToTriangleSum", "SurfaceLoss",
            "Laplacian", "EdgeSqLenSum", "PoolFeatures", "VertexHead", "SegmentMax", "manual_seed", "set_rng_state",
-           "draw_samples",
+           "draw_samples", "GtIndex", "ScanPrep",
            "chamfer_nn", "tri_distance_indexed"]

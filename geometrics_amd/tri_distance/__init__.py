@@ -79,6 +79,19 @@ def face_order(verts, faces):
     return order
 
 
+def faces_in_order(verts, faces):
+    """int32 [F,3]: faces[face_order] -- the corners of the face at every position of the visiting order (cached with the
+    order; None when there is none).  The sorted draws of the surface step read their corners from it."""
+    order = face_order(verts, faces)
+    if order is None:
+        return None
+    hit = _order_cache.get(id(faces))
+    if len(hit) == 3:
+        hit = hit + (faces[order.long()].to(torch.int32).contiguous(),)
+        _order_cache[id(faces)] = hit
+    return hit[3]
+
+
 # ---- the reference-shaped entry (tri1 / tri2 / tri3 corner tensors, tri_distance.py:9-43): no face list to key a cache on --
 # the corner tensors are fresh gathers every step (utils.py:467-470).  What stays the same from call to call is the TOPOLOGY
 # behind them, and mesh deformation keeps a topology's visiting order coherent; so one order is kept per (triangle count,

@@ -76,7 +76,7 @@ def _f_score(sq_to_pred, sq_to_gt, num):
     return float(f.mean())
 
 
-def _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, two_sided, loss_out=None):
+def _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, two_sided, loss_out=None, gt_index=None):
     faces = adj_info["faces"]
     points = tri_ws = None
     if draws is None:   # one kernel draws AND gathers the points (and, for the one-sided loss, prepares the triangle
@@ -85,11 +85,11 @@ def _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, two_sided, los
             choices, u, v, points = ops.draw_samples(pred_vert, faces, num, with_points=True)
         else:
             choices, u, v, points, tri_ws = ops.draw_samples(pred_vert, faces, num, with_points=True,
-                                                             prepare_scan_for=gt_points.shape[1])
+                                                             prepare_scan_for=gt_points.shape[1], gt_index=gt_index)
     else:
         choices, u, v = draws
     loss, sq_gt, sq_pred = ops.SurfaceLoss.apply(pred_vert, faces, gt_points, choices, u, v, two_sided, LOSS_SCALE,
-                                                 points, tri_ws, loss_out)
+                                                 points, tri_ws, loss_out, gt_index)
     if f1:
         return loss, _f_score(sq_gt, sq_pred, num)
     return loss
@@ -102,10 +102,11 @@ def batch_point_to_point(pred_vert, adj_info, gt_points, num=1000, f1=False, dra
     return _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, True, loss_out)
 
 
-def batch_point_to_surface(pred_vert, adj_info, gt_points, num=1000, f1=False, draws=None, loss_out=None):
+def batch_point_to_surface(pred_vert, adj_info, gt_points, num=1000, f1=False, draws=None, loss_out=None, gt_index=None):
     """Chamfer (prediction -> gt) + point-to-surface (gt -> mesh) loss (reference utils.py:441-502); `draws`, `loss_out`
-    as for batch_point_to_point."""
-    return _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, False, loss_out)
+    as for batch_point_to_point.  gt_index (optional, an ops.GtIndex built once for `gt_points`): the Chamfer tiles take
+    the culled scan -- same loss, same gradients, bit for bit."""
+    return _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, False, loss_out, gt_index)
 
 
 def calc_point_to_line(p, triangles, point_options):

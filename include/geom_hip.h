@@ -69,10 +69,6 @@ int geom_chamfer_nn_f32(int b, int n, const float *xyz, int m, const float *xyz2
  * neighbours in the list (e.g. a Morton / k-d order); the scan then skips every run of 16 targets whose bounding sphere
  * proves it irrelevant to all 64 queries of a tile.  A bad order only costs speed.  workspace:
  * geom_chamfer_nn_culled_workspace_floats(b, n, m) floats, 16-byte aligned.  flags: 0 or GEOM_FLAG_NN_FMA. */
-/* The index of ONE cloud (run spheres + the cloud in visiting order), for callers that keep a cloud across calls:
- * geom_nn_cull_index_floats(b, n) floats, 16-byte aligned, written by geom_nn_cull_index_f32. */
-int64_t geom_nn_cull_index_floats(int b, int n);
-int geom_nn_cull_index_f32(int b, int n, const float *xyz, const int *order, float *index, void *stream);
 int64_t geom_chamfer_nn_culled_workspace_floats(int b, int n, int m);
 int geom_chamfer_nn_culled_f32(int b, int n, const float *xyz, int m, const float *xyz2, const int *order1, const int *order2,
                                float *result, int *result_i, float *result2, int *result2_i, unsigned flags, float *workspace,
@@ -407,6 +403,27 @@ int geom_pool_features_bwd_f32(int b, int nv, const float *verts, const float *c
                                const float *grad_out, float *const *grad_blocks, float *grad_verts,
                                void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- culled Chamfer scan inside the surface step (optional; NULL everywhere = the brute-force tiles) ------------------
+ * The culled scan (geom_chamfer_nn_culled_f32) needs both clouds listed in a spatially coherent order, as an INDEX
+ * (geom_nn_cull_index_floats(b, n) floats, 16-byte aligned: the run spheres, then the cloud in that order):
+ *   gt cloud:      static per batch -- gt_order [b,n_gt] (any coherent order: a Morton or k-d order made by the data
+ *                  loader) and gt_index written ONCE by geom_nn_cull_index_f32(b, n_gt, gt, gt_order, gt_index);
+ *   sampled cloud: new every step -- given the struct, geom_surface_prepare_f32 GENERATES the samples in the order of their
+ *                  faces' positions in tri_order (sorted uniforms from exponential spacings: no sorting pass; the multiset
+ *                  of samples has the law of independent draws, only their order is no longer random -- which is why the
+ *                  stand-alone draw entry points never do this) and writes sample_index; *prepared gets bit 1 (value 2)
+ *                  when it did (num between 64 and 4095).  geom_surface_scan_f32 given the same struct then runs the
+ *                  culled tiles: the same outputs as the brute-force tiles for the same samples, bit for bit. */
+typedef struct geom_surface_cull {
+    const int *gt_order;     /* [b,n_gt] visiting position -> gt point (NULL: the cloud's own order) */
+    const float *gt_index;   /* geom_nn_cull_index_floats(b, n_gt) floats */
+    float *sample_index;     /* geom_nn_cull_index_floats(b, num) floats of scratch, written by the prepare call */
+    const int *faces_in_order; /* optional [nf,3] int32: the corners of face tri_order[j] at position j (static per face list
+                                * and order): saves the prepare launch a dependent load in each of its two gather chains */
+} geom_surface_cull;
+int64_t geom_nn_cull_index_floats(int b, int n);
+int geom_nn_cull_index_f32(int b, int n, const float *xyz, const int *order, float *index, void *stream);
+
 /* ---- per-step preparation of the surface loss in one launch ------------------------------------------------------
  * Everything that depends only on the vertex positions: the random face draws (+ sampled points) of batch_sample,
  * exactly geom_draw_samples_rng_f32, AND -- when the scan of the same step will take the fused route (coherent
@@ -416,7 +433,7 @@ int geom_pool_features_bwd_f32(int b, int nv, const float *verts, const float *c
 int geom_surface_prepare_f32(int b, int nv, const float *verts, int nf, const int64_t *faces, int num,
                              uint64_t *rng_state, int64_t *choices, float *u, float *v, float *points, int n_gt,
                              const int *tri_order, unsigned flags, void *workspace, size_t workspace_bytes,
-                             int *prepared, void *stream);
+                             int *prepared, const geom_surface_cull *cull, void *stream);
 
 /* ---- the two arg-min scans of the surface loss in one call (utils.py:451 + 470) ----------------------------------
  * gt [b,n_gt,3] against the sampled points [b,num,3]: nearest neighbours both ways, exactly geom_chamfer_nn_f32(gt,
@@ -435,7 +452,7 @@ int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, const float
                           const int *tri_order, float *tri_dist, int *option, int *index, float *sq, float *closest,
                           float *weights, const float *u, const float *v, float coef_sample, float coef_other,
                           int *order_scratch, unsigned flags, void *workspace, size_t workspace_bytes,
-                          int *records_written, void *stream);
+                          int *records_written, const geom_surface_cull *cull, void *stream);
 
 /* ---- surface loss: forward-side finalize + single-launch backward ------------------------------------------
  * geom_surface_finalize_f32 runs once after the two scans of batch_point_to_surface / batch_point_to_point

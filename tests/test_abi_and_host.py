@@ -270,12 +270,12 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     # geom_surface_scan_f32(b, n_gt, gt, num, points, sq_gt, idx_p, sq_pred, idx_g, nv, verts, nf, faces, order, ... )
     scan = lambda b, n_gt, num, gt: L.geom_surface_scan_f32(b, n_gt, gt, num, None, None, None, None, None, 0, None, 0, None, None,
                                                             None, None, None, None, None, None, None, None, 1.0, 1.0, None, 0, None,
-                                                            0, ctypes.byref(one), None)
+                                                            0, ctypes.byref(one), None, None)
     assert scan(-1, 4, 4, None) == -1 and scan(1, 0, 4, None) == -1 and scan(1, 4, 4, None) == -1
     assert scan(0, 4, 4, None) == 0 and one.value == 0            # empty batch; *records_written cleared
-    assert L.geom_surface_prepare_f32(1, 4, None, 4, None, 8, None, None, None, None, None, 8, None, 0, None, 0, None, None) == -1
-    assert L.geom_surface_prepare_f32(0, 4, None, 4, None, 8, None, None, None, None, None, 8, None, 0, None, 0, None, None) == 0
-    assert L.geom_surface_prepare_f32(1, 4, None, 20000, None, 8, None, None, None, None, None, 8, None, 0, None, 0, None, None) \
+    assert L.geom_surface_prepare_f32(1, 4, None, 4, None, 8, None, None, None, None, None, 8, None, 0, None, 0, None, None, None) == -1
+    assert L.geom_surface_prepare_f32(0, 4, None, 4, None, 8, None, None, None, None, None, 8, None, 0, None, 0, None, None, None) == 0
+    assert L.geom_surface_prepare_f32(1, 4, None, 20000, None, 8, None, None, None, None, None, 8, None, 0, None, 0, None, None, None) \
         == _lib.EUNSUPPORTED                                       # the face-area CDF lives in LDS: <= 16384 faces
     fin = lambda b, order, loss: L.geom_surface_finalize_f32(b, 8, 4, None, None, None, None, 4, None, None, None, None, None, None,
                                                              p, p, 1.0, 1.0, 1.0, 1.0, 0, 0, order, loss, None)

@@ -1172,7 +1172,7 @@ def test_fused_surface_scan_equals_the_separate_scans_and_its_records_those_of_t
                                           o["idx_p"].data_ptr(), o["sq_pred"].data_ptr(), o["idx_g"].data_ptr(), *tri,
                                           u.data_ptr(), v.data_ptr(), coef_s, coef_o,
                                           o["order"].data_ptr() if with_records else None, flags, o["ws"].data_ptr(), ws_bytes,
-                                          ctypes.byref(wrote), L.stream_ptr()), "geom_surface_scan_f32")
+                                          ctypes.byref(wrote), None, L.stream_ptr()), "geom_surface_scan_f32")
         assert wrote.value == int(with_records)
         other = o["sq_gt"] if two_sided else o["sq"]
         L.call("geom_surface_finalize_f32", B, nf, num, choices.data_ptr(), u.data_ptr(), v.data_ptr(), points.data_ptr(), n_gt,
@@ -1246,6 +1246,68 @@ def test_prepare_launch_equals_draw_plus_prep(gpu):
                                  v[:2].contiguous(), False, 3000.0)[0]
     assert abs(part.item() - ref.item()) <= 1e-5 * abs(ref.item())
     assert torch.isfinite(loss)
+
+
+def test_culled_chamfer_tiles_inside_the_surface_step(gpu):
+    """The culled Chamfer tiles of the fused scan (ops.GtIndex handed to the loss) against the brute-force tiles ON THE SAME
+    SAMPLES -- replayed through `draws=` -- : loss, both squared-distance outputs and the gradient bit for bit, in both
+    arithmetics, with a Morton and with a deliberately incoherent gt order.  On this route the draw launch GENERATES the
+    samples in visiting order (sorted uniforms from exponential spacings, csrc/draw_body.h): the position of a sample's face
+    in the triangle order never decreases along the sample index, every face id is valid, and the sampled multiset is
+    area-weighted like independent draws (frequencies against the areas; u = sqrt(U), v = U statistics)."""
+    from geometrics_amd import chamfer_distance as cd
+    from geometrics_amd.tri_distance import face_order
+    V, Fc = meshgen.icosphere(4)
+    B, num = 8, 3000
+    verts = dev(meshgen.jittered_batch(V, B), gpu).requires_grad_(True)
+    faces, gt = dev(Fc, gpu), dev(meshgen.gt_cloud(B, num), gpu)
+    order = face_order(verts.detach(), faces).long()
+    rank = torch.empty_like(order)
+    rank[order] = torch.arange(order.numel(), device=gpu)
+    gen = torch.Generator().manual_seed(3)
+    shuffled = torch.stack([torch.randperm(num, generator=gen) for _ in range(B)]).to(torch.int32).to(gpu)
+    try:
+        for arithmetic in ("unfused", "fma"):
+            cd.set_arithmetic(arithmetic)
+            for gi in (ops.GtIndex(gt), ops.GtIndex(gt, shuffled)):
+                ops.manual_seed(77)
+                d = ops.draw_samples(verts, faces, num, with_points=True, prepare_scan_for=num, gt_index=gi)
+                assert isinstance(d[4], ops.ScanPrep) and d[4].sample_index is not None
+                choices, u, v, points = d[:4]
+                assert int(choices.min()) >= 0 and int(choices.max()) < Fc.shape[0]
+                pos = rank[choices]
+                assert bool((pos[:, 1:] >= pos[:, :-1]).all())                   # generated in visiting order
+                verts.grad = None
+                loss, sq_gt, sq_pred = ops.SurfaceLoss.apply(verts, faces, gt, choices, u, v, False, 3000.0, points, d[4], None, gi)
+                loss.backward()
+                culled = (loss.detach().clone(), sq_gt.clone(), sq_pred.clone(), verts.grad.clone())
+                verts.grad = None                                                  # the same samples through the brute-force tiles
+                loss, sq_gt, sq_pred = ops.SurfaceLoss.apply(verts, faces, gt, choices, u, v, False, 3000.0)
+                loss.backward()
+                for x, y in zip(culled, (loss.detach(), sq_gt, sq_pred, verts.grad)):
+                    assert torch.equal(x, y)
+    finally:
+        cd.set_arithmetic("unfused")
+    # the sorted generation draws what independent draws would: area-weighted faces, u = sqrt(U1), v = U2
+    gi = ops.GtIndex(gt)
+    counts = torch.zeros(Fc.shape[0], dtype=torch.float64, device=gpu)
+    us, vs = [], []
+    ops.manual_seed(11)
+    rounds = 40
+    for _ in range(rounds):
+        d = ops.draw_samples(verts.detach(), faces, num, with_points=True, prepare_scan_for=num, gt_index=gi)
+        counts += torch.bincount(d[0][0], minlength=Fc.shape[0]).double()
+        us.append(d[1][0]), vs.append(d[2][0])
+    areas = ops.face_areas(verts.detach(), faces)[0].double()
+    freq, p = counts / (rounds * num), areas / areas.sum()
+    assert float((freq - p).abs().max()) < 6 * float((p.max() / (rounds * num)).sqrt())     # 6 sigma of a binomial frequency
+    uu, vv = torch.cat(us), torch.cat(vs)
+    assert abs(float((uu * uu).mean()) - 0.5) < 5e-3 and abs(float(vv.mean()) - 0.5) < 5e-3
+    # the helper the training loop calls; an index built for another tensor is refused
+    info = {"faces": faces}
+    assert utils.batch_point_to_surface(verts.detach(), info, gt, num=num, gt_index=gi).isfinite()
+    with pytest.raises(RuntimeError):
+        utils.batch_point_to_surface(verts.detach(), info, gt.clone(), num=num, gt_index=gi)
 
 
 def test_tri_surface_fused_call_equals_scan_plus_point_to_triangle(gpu):

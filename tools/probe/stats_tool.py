@@ -38,7 +38,7 @@ for how in (("kd",) if KNOB is not None else ("morton", "kd")):
             run(KNOB << 16)
         torch.cuda.synchronize()
         continue
-    for name, fl in (("full", 0), ("seeds only", 1 << 16), ("+ patch-level test", 2 << 16), ("+ fetches and lane tests", 4 << 16)):
+    for name, fl in (("full", 0), ("seeds only", 1 << 16), ("+ tests", 2 << 16), ("+ fetches", 4 << 16), ("full, no resolve", 16 << 16), ("seeds only, no resolve", 17 << 16)):
         print("  %-28s %.1f us (prep + scan)" % (name, T.timeit(lambda: run(fl), 200)))
     tiles = out[0]
     print(how, "rc", rc, "tiles", tiles, "admitted by the first test/tile %.1f" % (out[1] / tiles), "evaluated/tile %.1f" % (out[2] / tiles), "of runs", n // 16)
