@@ -372,9 +372,11 @@ def valu_rate(kernel_prefix, launch_us):
             "frac_of_measured_vfma_rate": round(rate / VALU_MEASURED_TERA_LANE_OPS, 4)}
 
 
-def fused_scan_call(w, pos, pred, flags=0, share=None):
+def fused_scan_call(w, pos, pred, flags=0, share=None, prep=None):
     """geom_surface_scan_f32 on the step's own tensors (outputs allocated once): prep launch + the fused NN / tri launch.
-    share = an earlier call object whose buffers (incl. the prepared tri workspace) are reused."""
+    share = an earlier call object whose buffers (incl. the prepared tri workspace) are reused.  prep = what the step's draw
+    launch returned (ops.draw_samples(..., prepare_scan_for, gt_index)): samples in visiting order + their index + the
+    triangle records -- the call then runs the step's own variant, the culled Chamfer tiles, on `pred` = those samples."""
     import ctypes
     from geometrics_amd import _lib as L
     from geometrics_amd.tri_distance import face_order
@@ -383,7 +385,7 @@ def fused_scan_call(w, pos, pred, flags=0, share=None):
     f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
     ws_bytes = lib.geom_tri_distance_workspace_bytes(b, n_gt, nf)
     if share is not None:
-        o, ws, order, u, v, tri_order = share.keep
+        o, ws, order, u, v, tri_order = share.keep[:6]
     else:
         o = [torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, **i32), torch.empty(b, num, **f32), torch.empty(b, num, **i32),
              torch.empty(b, n_gt, **f32), torch.empty(b, n_gt, **i32), torch.empty(b, n_gt, **i32), torch.empty(b, n_gt, **f32),
@@ -392,6 +394,11 @@ def fused_scan_call(w, pos, pred, flags=0, share=None):
         order = torch.empty(lib.geom_surface_order_words(b, nf, num, n_gt), **i32)
         u, v = torch.rand(b, num, device=dev), torch.rand(b, num, device=dev)
         tri_order = face_order(pos, w.faces)
+    cull = None
+    if prep is not None:      # the step's variant: culled Chamfer tiles on the samples the draw launch generated in visiting order
+        choices, u, v, pred, scan_prep = prep
+        ws, flags = scan_prep.tri_ws, flags | L.FLAG_TRI_WS_READY
+        cull = L.SurfaceCull(w.gt_index.order.data_ptr(), w.gt_index.index.data_ptr(), scan_prep.sample_index.data_ptr(), None)
     wrote = ctypes.c_int(0)
 
     def call():
@@ -400,8 +407,8 @@ def fused_scan_call(w, pos, pred, flags=0, share=None):
                                           tri_order.data_ptr(), o[4].data_ptr(), o[5].data_ptr(), o[6].data_ptr(),
                                           o[7].data_ptr(), o[8].data_ptr(), o[9].data_ptr(), u.data_ptr(), v.data_ptr(), 1.0, 1.0,
                                           order.data_ptr(), flags, ws.data_ptr(), ws_bytes, ctypes.byref(wrote),
-                                          L.stream_ptr()), "geom_surface_scan_f32")
-    call.keep = (o, ws, order, u, v, tri_order)
+                                          ctypes.byref(cull) if cull is not None else None, L.stream_ptr()), "geom_surface_scan_f32")
+    call.keep = (o, ws, order, u, v, tri_order, cull, prep)
     return call
 
 
@@ -440,9 +447,14 @@ def kernel_rooflines(w):
         pos = w.positions().contiguous()
         pred = utils.batch_sample(pos, w.faces, num=S_PTS)
         scan = fused_scan_call(w, pos, pred)
-        t_scan_all = event_time_us(scan)                                              # prep + fused launch
+        t_scan_all = event_time_us(scan)                                              # prep + fused launch, brute-force Chamfer tiles
         scan()                                                                        # workspace now holds this mesh's records
-        t_scan = event_time_us(fused_scan_call(w, pos, pred, _lib.FLAG_TRI_WS_READY, share=scan))   # the fused launch alone
+        t_scan_plain = event_time_us(fused_scan_call(w, pos, pred, _lib.FLAG_TRI_WS_READY, share=scan))   # the fused launch alone
+        t_scan = t_scan_plain
+        if w.gt_index is not None:      # the step's own variant: culled Chamfer tiles on samples generated in visiting order
+            prep = ops.draw_samples(pos, w.faces, S_PTS, with_points=True, prepare_scan_for=G_PTS, gt_index=w.gt_index)
+            if isinstance(prep[4], ops.ScanPrep) and prep[4].sample_index is not None:
+                t_scan = event_time_us(fused_scan_call(w, pos, pred, share=scan, prep=prep))
         t_prep_tri = event_time_us(lambda: tri_distance_indexed(w.gt, pos, w.faces))  # prep + tri-only scan
         t_tri_flat = event_time_us(lambda: tri_distance_indexed(w.gt, pos, w.faces, order=None))
         from geometrics_amd.tri_distance import tri_distance as tri_soup
@@ -478,7 +490,11 @@ def kernel_rooflines(w):
                                   "8) / launch time against the 157.3 TFLOP/s fp32 peak; above 1 is possible and means "
                                   "culling, not utilisation: the tri tiles prove ~95 % of their pairs irrelevant (bit-exact "
                                   "vs brute force)"},
-        "launch_us": round(t_scan, 1), "call_us_with_prep_launch": round(t_scan_all, 1), "executed": executed,
+        "launch_us": round(t_scan, 1), "launch_us_brute_force_chamfer_tiles": round(t_scan_plain, 1),
+        "chamfer_tiles": "culled (nn_culled_body: run spheres over samples the draw launch generates in face-visiting order and "
+                         "over the static gt index; bit-identical to the brute-force tiles)" if t_scan is not t_scan_plain
+                         else "brute force",
+        "call_us_with_prep_launch": round(t_scan_all, 1), "executed": executed,
         "algorithmic_bytes_per_launch": scan_bytes,
         "traffic": scan_traffic,
         "traffic_over_algorithmic": None if scan_traffic is None else round(scan_traffic / scan_bytes, 2),
