@@ -65,6 +65,11 @@ class Workload:
         self.gt_index = None
         if CULLED_CHAMFER:
             self.gt_index = ops.GtIndex(self.gt, torch.stack([kd_order(self.gt[i]) for i in range(batch)]))
+        # the faces' visiting order (k-d leaves of the face centroids, cached per face list) from the UNDEFORMED template, which
+        # every rank holds: on the culled route the samples are generated in that order, so ranks that derived it from the
+        # first mesh of their own shard would draw other (equally valid) samples than one process holding the whole batch
+        from geometrics_amd.tri_distance import face_order
+        face_order(to(V).unsqueeze(0), self.faces)
         self.info = utils.adj_init(self.faces)
         # per-mesh seeds (global mesh index): a shard holds exactly the rows the whole-batch job would hold
         self.feat = torch.stack([torch.randn(self.nv, FEAT, generator=torch.Generator(device="cpu").manual_seed(seed + first_mesh + i))
