@@ -60,22 +60,23 @@ def test_two_rank_step_equals_the_serial_two_shard_step_bitwise(gpu):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_elu_step_equals_the_single_process_16_mesh_step_to_round_off(gpu):
+def test_two_rank_elu_step_equals_the_single_process_16_mesh_step_up_to_sample_flips(gpu):
     """The same comparison made SHARP: a smooth activation (ELU in all three layers: no unit can switch sides) and lr = 0
     (Adam's normalised update turns a round-off difference in a near-zero gradient entry into a full +-lr parameter
     difference, which the next step's gradient then carries).  What is left between two ranks of 8 meshes and ONE process
-    holding all 16 is the round-off of other GEMM kernel selections and another summation order of the weight gradients:
-    1e-4 of the gradient's scale and 1e-5 on the loss (the ReLU / lr = 1e-4 variant below needs 5e-2 because of unit flips
-    and Adam drift, not because anything is loose).  Same samples in both job shapes."""
+    holding all 16: other GEMM kernel selections move 8 % of the vertex positions by one ulp (3e-8), the face-area CDF moves
+    with them, and a surface sample whose draw sits within that round-off of a CDF boundary lands on the neighbouring face --
+    3 to 5 of 48 000 samples per step (tools/probe/shard_flips.py), each worth ~3e-4 of the parameter gradient's scale and
+    ~1e-5 of the loss.  So: loss to 1e-4, gradient to 5e-3 (the ReLU / lr = 1e-4 variant below needs 5e-2 because of unit
+    flips and Adam drift).  The samples themselves are shard-invariant for equal positions (the sampler is keyed on the
+    global mesh index and the faces' visiting order comes from the template every rank holds)."""
     two = _launch(2, "elu", 0.0)
     one = _launch(1, "elu", 0.0)
     assert two["steps_taken"] == one["steps_taken"] == STEPS + WARM
-    # (the loss is not a smooth function of round-off either: a surface sample whose uniform draw sits within an ulp of a
-    # face-area CDF boundary lands on the neighbouring face -- one of 48 000 samples moving is 1e-5 of the loss)
     np.testing.assert_allclose(two["losses"], one["losses"], rtol=1e-4)
     scale = np.abs(one["grads"]).max()
     worst = np.abs(two["grads"] - one["grads"]).max() / scale
-    assert worst <= 1e-4, "gradient differs by %.2e of its scale" % worst
+    assert worst <= 5e-3, "gradient differs by %.2e of its scale" % worst
     np.testing.assert_array_equal(two["params"], one["params"])        # lr = 0: nobody moved
 
 
