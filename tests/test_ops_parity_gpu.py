@@ -1310,6 +1310,31 @@ def test_culled_chamfer_tiles_inside_the_surface_step(gpu):
         utils.batch_point_to_surface(verts.detach(), info, gt.clone(), num=num, gt_index=gi)
 
 
+def test_sorted_draws_are_shard_invariant(gpu):
+    """The samples the culled route generates (in face-visiting order) for a mesh depend on the seed, the stream position,
+    the mesh's GLOBAL index and its positions only -- not on which other meshes share the launch: 16 meshes drawn at once
+    equal the same 16 drawn as two shards of 8 (mesh_offset 0 / 8), provided both derive the faces' visiting order from the
+    same positions (the order is cached per face list on first use)."""
+    from geometrics_amd.tri_distance import face_order
+    V, Fc = meshgen.icosphere(4)
+    faces = dev(Fc, gpu)
+    face_order(dev(V, gpu).unsqueeze(0), faces)                       # the template: what every rank holds
+    verts = dev(meshgen.jittered_batch(V, 16), gpu)
+    gt = dev(meshgen.gt_cloud(16, 3000), gpu)
+
+    def draw(v, g, first):
+        ops.manual_seed(3041, gpu, mesh_offset=first)
+        d = ops.draw_samples(v, faces, 3000, with_points=True, prepare_scan_for=3000, gt_index=ops.GtIndex(g))
+        assert isinstance(d[4], ops.ScanPrep)
+        return [t.clone() for t in d[:4]]
+
+    whole = draw(verts, gt, 0)
+    parts = [draw(verts[:8].contiguous(), gt[:8].contiguous(), 0), draw(verts[8:].contiguous(), gt[8:].contiguous(), 8)]
+    for k in range(4):
+        assert torch.equal(whole[k], torch.cat([parts[0][k], parts[1][k]]))
+    ops.manual_seed(0, gpu)
+
+
 def test_tri_surface_fused_call_equals_scan_plus_point_to_triangle(gpu):
     """geom_tri_surface_fwd_f32 (scan epilogue writes sqdist / closest / weights) against the two separate entry
     points, for the two-level scan (fused), the flat scan, the brute-force scan and a single mesh (split query tiles:
