@@ -162,7 +162,8 @@ def lib():
                 "geometrics_amd: %s is missing -- build it with `python -m geometrics_amd.build` "
                 "(hipcc, gfx950). There is no CPU/PyTorch fallback." % LIB_PATH)
         _refuse_stale_library()
-        L = ctypes.CDLL(LIB_PATH)
+        # GEOM_LIB_OVERRIDE: an instrumented build of the same sources (tools/probe: tile stamps, counters) -- never the product
+        L = ctypes.CDLL(os.environ.get("GEOM_LIB_OVERRIDE") or LIB_PATH)
         L.geom_abi_version.restype = _i
         L.geom_strerror.restype = ctypes.c_char_p
         L.geom_strerror.argtypes = [_i]

@@ -1091,6 +1091,14 @@ __global__ __launch_bounds__(HS_WAVES * GEOM_WAVE) void tri_scan_grouped_kernel(
 // build (3 workgroups per CU instead of 2, 13 registers spilled): 55.3.  PMC of this launch: 32.0 M VALU instructions
 // = 40 T lane-ops/s, 0.51 of the 78.6 T spec issue rate and 0.78 of the 51.5 T the chip sustains on un-packed v_fma_f32
 // (MI355X_MICROARCH.md: 103 TFLOP/s measured) -- the fused launch is VALU-issue bound, what is left is instruction count.
+#ifdef SCAN_TILE_STAMPS
+__device__ long long scan_tile_stamps[4 * 4096]; // per workgroup {start, end (100 MHz wall clock), kind, hardware id}
+extern "C" int geom_probe_read_scan_stamps(long long *host, int rows)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(scan_tile_stamps), sizeof(long long) * 4 * (size_t)rows);
+}
+#endif
+
 // CULL: the Chamfer tiles take the culled scan (nn_culled_body).  Its tiles are latency chains, not issue-bound loops, so
 // the launch wants THREE workgroups per CU: the two bodies' LDS is overlaid (a workgroup is one or the other: 43 KB instead
 // of 27 + 43) and the register budget is capped at 80 (6 waves per SIMD; the triangle body spills a dozen registers to
@@ -1104,6 +1112,21 @@ __global__ __launch_bounds__(8 * GEOM_WAVE, CULL ? 6 : 1) void surface_scan_kern
                                                                                   int tri_blocks, NNCull cull)
 {
     static_assert(NNS_THREADS == 8 * GEOM_WAVE, "both bodies are written for 8-wave workgroups");
+#ifdef SCAN_TILE_STAMPS // tools/probe only: when each tile of the launch started and ended, and where (see scan_tile_stamps.py)
+    const long long stamp_t0 = wall_clock64();
+    struct StampOnExit {
+        long long t0;
+        int tri_blocks;
+        __device__ ~StampOnExit()
+        {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                long long *row = scan_tile_stamps + 4 * (size_t)blockIdx.x;
+                row[0] = t0, row[1] = wall_clock64(), row[2] = (int)blockIdx.x < tri_blocks ? 0 : 1, row[3] = __smid();
+            }
+        }
+    } stamp_on_exit{stamp_t0, tri_blocks};
+#endif
     if constexpr (CULL) {
         __shared__ union Lds {
             TriTileLds<8> tri;

@@ -29,3 +29,16 @@ ls -la tools/probe/bin
 # counters + ablation knobs of the culled Chamfer scan (tools/probe/cull_report.sh, stats_tool.py, cull_knobs.sh, cull_pmc.sh)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fno-gpu-rdc -fno-slp-vectorize -DNN_CULL_STATS \
     -I include -I geometrics_amd/csrc -shared geometrics_amd/csrc/chamfer_nn.hip -o tools/probe/libcullstats.so
+
+# the fused surface-scan launch with per-tile start / end stamps (tools/probe/scan_tile_stamps.py): the WHOLE library built with
+# -DSCAN_TILE_STAMPS, so that the python operators run on it unchanged (GEOM_LIB_OVERRIDE=tools/probe/bin/libgeom_scan_stamps.so)
+mkdir -p tools/probe/bin/stamps
+for f in geometrics_amd/csrc/*.hip; do
+    extra=""; case $f in *dense_gemm.hip) extra="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fno-gpu-rdc -fno-slp-vectorize -w -DSCAN_TILE_STAMPS $extra \
+        -I include -I geometrics_amd/csrc -c $f -o tools/probe/bin/stamps/$(basename $f .hip).o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fno-gpu-rdc tools/probe/bin/stamps/*.o -o tools/probe/bin/libgeom_scan_stamps.so
+rm -rf tools/probe/bin/stamps
+ls -la tools/probe/bin/libgeom_scan_stamps.so
