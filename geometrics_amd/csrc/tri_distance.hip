@@ -807,6 +807,19 @@ __global__ __launch_bounds__(DRAW_THREADS) void surface_prepare_kernel(int draw_
     }
 }
 
+#ifdef SCAN_TILE_STAMPS // tools/probe only: phase boundaries of every triangle tile (wave 0) + when each wave reaches the closing barrier
+__device__ long long scan_tri_phases[16 * 1024];
+extern "C" int geom_probe_read_tri_phases(long long *host, int rows)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(scan_tri_phases), sizeof(long long) * 16 * (size_t)rows);
+}
+#define TRI_PHASE(k) do { if (threadIdx.x == 0 && bid < 1024) scan_tri_phases[16 * bid + (k)] = wall_clock64(); } while (0)
+#define TRI_WAVE_DONE() do { if (lane == 0 && bid < 1024) scan_tri_phases[16 * bid + 8 + wave] = wall_clock64(); } while (0)
+#else
+#define TRI_PHASE(k) do { } while (0)
+#define TRI_WAVE_DONE() do { } while (0)
+#endif
+
 // the tile's LDS as one object (see NNCullLds in nn_scan.h: the fused scan overlays the two bodies' LDS)
 template <int HS_WAVES>
 struct TriTileLds {
@@ -930,10 +943,12 @@ __device__ __forceinline__ void tri_scan_grouped_body(int bid, const float *__re
         }
     };
 
+    TRI_PHASE(0); // entry (queries requested)
     for (int c0 = r_begin; c0 < r_end; c0 += HS_GCHUNK) {
         const int len = min(HS_GCHUNK, r_end - c0); // multiple of 4
         for (int t = threadIdx.x; t < len; t += HS_THREADS) gtile[t] = grp[c0 + t];
         __syncthreads();
+        TRI_PHASE(1); // group spheres staged
         const int batches = len / 4;
 
         // ---- A1: smallest upper bound (|p - c_g| + R_g) over this wave's groups ----
@@ -957,6 +972,7 @@ __device__ __forceinline__ void tri_scan_grouped_body(int bid, const float *__re
                                         : KEY_NONE;
         }
         __syncthreads();
+        TRI_PHASE(2); // A1 done
         // ---- A1': the 16 members of the seed group are evaluated literally, one thread per (query, member):
         //      the cull bound starts from a REAL candidate next to the query, not from a sphere estimate ----
         for (int t = threadIdx.x; t < TRI_QUERIES * GRP; t += HS_THREADS) { // wave-aligned: whole 16-lane groups
@@ -977,6 +993,7 @@ __device__ __forceinline__ void tri_scan_grouped_body(int bid, const float *__re
             }
         }
         __syncthreads();
+        TRI_PHASE(3); // A1' done
 
         // ---- A2 + B + C ----
         const int seed_g = (int)(unsigned)qseed[lane]; // already evaluated (KEY_NONE -> -1: matches no group)
@@ -1014,10 +1031,13 @@ __device__ __forceinline__ void tri_scan_grouped_body(int bid, const float *__re
             members(0, na);
             na = 0;
         }
+        TRI_WAVE_DONE(); // this wave's A2 + B + C of the chunk
         __syncthreads(); // gtile / qseed are rewritten by the next chunk
+        TRI_PHASE(4); // all waves through A2 + B + C
     }
     if (nb > 0) drain_b(0, nb);
     __syncthreads();
+    TRI_PHASE(5); // final drain
 
     if (split > 1) {
         if (wave == 0 && live && qbest[lane] != KEY_NONE) atomicMin(&ws.keys[(size_t)mesh * n + q], qbest[lane]);
@@ -1066,6 +1086,7 @@ __device__ __forceinline__ void tri_scan_grouped_body(int bid, const float *__re
             }
         }
     }
+    TRI_PHASE(6); // epilogue (wave 0)
 }
 
 template <bool TRUNC, bool FIX6, int HS_WAVES>

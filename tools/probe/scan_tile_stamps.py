@@ -54,3 +54,19 @@ print(" ".join("%d/%d" % (((start <= t) & (end > t) & (kind == 0)).sum(), ((star
 busy = (end - start).sum()
 print("# slot-time used %.0f us over %d workgroups = %.1f us per slot if 768 slots (3 per CU) were packed perfectly; span %.1f us"
       % (busy, len(buf), busy / 768.0, end.max()))
+
+if not plain:
+    L.geom_probe_read_tri_phases.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    ph = np.zeros((min(tri_tiles, 1024), 16), dtype=np.int64)
+    _lib.check(L.geom_probe_read_tri_phases(ph.ctypes.data, len(ph)), "geom_probe_read_tri_phases")
+    ph = ph[ph[:, 6] > 0]
+    names = ["staging of the group spheres", "A1 (smallest upper bound per query)", "A1' (16 literal evaluations of the seed group)",
+             "A2 + B + C until ALL waves are through", "final drain of queue B", "epilogue (outputs, point-to-surface records)"]
+    print("# phases of a triangle tile (wave 0's clock, us; %d tiles): median  p10  p90" % len(ph))
+    for k, name in enumerate(names):
+        d = (ph[:, k + 1] - ph[:, k]) / 100.0
+        print("%-52s %6.2f %6.2f %6.2f" % (name, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+    done = (ph[:, 8:16] - ph[:, 3:4]) / 100.0                  # every wave's A2 + B + C time from the end of A1'
+    print("%-52s %6.2f %6.2f %6.2f" % ("  A2 + B + C of the FASTEST wave of a tile", np.median(done.min(1)), np.percentile(done.min(1), 10), np.percentile(done.min(1), 90)))
+    print("%-52s %6.2f %6.2f %6.2f" % ("  A2 + B + C of the SLOWEST wave of a tile", np.median(done.max(1)), np.percentile(done.max(1), 10), np.percentile(done.max(1), 90)))
+    print("%-52s %6.2f %6.2f %6.2f" % ("  mean wave of a tile", np.median(done.mean(1)), np.percentile(done.mean(1), 10), np.percentile(done.mean(1), 90)))
