@@ -855,6 +855,8 @@ def main():
     ap.add_argument("--clock-warmup-ms", type=float, default=250.0,
                     help="neutral GEMM load in front of the warm-up steps so that short runs are not timed on the clock ramp (0: off)")
     ap.add_argument("--plain-chamfer", action="store_true", help="brute-force Chamfer tiles instead of the culled scan (same results)")
+    ap.add_argument("--riders", action="store_true", help="the first layer's split launch carries the reductions that are already due "
+                    "(same results; layers.carry_due_reductions, measured in profiles/r04_riders.txt and off by default)")
     ap.add_argument("--launch", choices=("graph", "eager"), default="graph",
                     help="replay the whole step as one HIP graph (default) or launch eagerly from python")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-stage event-timed breakdown")
@@ -864,6 +866,9 @@ def main():
     args = ap.parse_args()
     global CULLED_CHAMFER
     CULLED_CHAMFER = not args.plain_chamfer
+    if args.riders:
+        from geometrics_amd import layers as _layers
+        _layers.carry_due_reductions = True
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")

@@ -16,7 +16,7 @@ FLAG_FIX_REGION6 = 2
 FLAG_TRI_BRUTE_FORCE = 4
 FLAG_NN_FMA = 8
 FLAG_TRI_WS_READY = 16
-ABI_VERSION = 6
+ABI_VERSION = 7
 EUNSUPPORTED = -3
 ADAM_MAX_TENSORS = 64
 COLSUM_MAX_JOBS = 32
@@ -105,6 +105,7 @@ _SIGNATURES = {
     "geom_dense_bwd_input_f32": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "geom_dense_bwd_weight_f32": [_i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "geom_dense_bwd_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "geom_dense_bwd_weight_riders_f32": [_i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_dense_reduce2_f32": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_dense_reduce_adam_f32": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f,
                                    _vp, _vp],

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GEOM_ABI_VERSION 6
+#define GEOM_ABI_VERSION 7
 
 /* argument errors */
 #define GEOM_EINVAL   (-1) /* bad size / null pointer */
@@ -312,6 +312,15 @@ int geom_dense_bwd_f32(int rows, int cin, int c, const float *x, const float *g,
 int geom_dense_reduce2_f32(int count, const int *rows, const int *cin, const int *c, const float *const *workspaces,
                            float *const *grad_w, float *const *grad_bias, int ncs, const float *const *cs_partials,
                            const int *cs_rows, const int *cs_cols, float *const *cs_outs, void *stream);
+/* geom_dense_bwd_weight_f32 whose launch also CARRIES reductions that are already due: the weight gradients of `count` earlier
+ * layers (r_* as the first arguments of geom_dense_reduce2_f32) and `ncs` column-sum jobs are finished by extra workgroups on
+ * the second slot of every CU while the MFMA workgroups run; results bit-identical to geom_dense_reduce2_f32.  The riders'
+ * partial sums must be complete in stream order.  GEOM_EUNSUPPORTED for cin <= 192 (those layers take the pair launch). */
+int geom_dense_bwd_weight_riders_f32(int rows, int cin, int c, const float *x, const float *g, float *workspace,
+                                     int want_colsum, int count, const int *r_rows, const int *r_cin, const int *r_c,
+                                     const float *const *r_workspaces, float *const *r_grad_w, int ncs,
+                                     const float *const *cs_partials, const int *cs_rows, const int *cs_cols,
+                                     float *const *cs_outs, void *stream);
 /* geom_dense_reduce2_f32 + the Adam step (torch.optim.Adam's rule, as geom_adam_step_f32) of the parameters whose gradients
  * the launch finishes: w_p / w_m / w_v[l] = parameter and its two moments for layer l's weight, b_p / b_m / b_v[i] for column-sum
  * job i (entries may be NULL: gradient only); `state` = the optimiser's device-side step state, advanced once by this launch;

@@ -1310,6 +1310,43 @@ def test_culled_chamfer_tiles_inside_the_surface_step(gpu):
         utils.batch_point_to_surface(verts.detach(), info, gt.clone(), num=num, gt_index=gi)
 
 
+@pytest.mark.parametrize("level,B,num,n_gt,sorted_route", [(2, 32, 64, 512, True), (3, 6, 1000, 2750, True), (4, 2, 4095, 8200, True),
+                                                          (2, 7, 1531, 2466, True), (3, 6, 4096, 2750, False), (2, 40, 63, 448, False),
+                                                          (2, 2, 500, 500, False)])
+def test_sorted_draws_at_ragged_sizes(gpu, level, B, num, n_gt, sorted_route):
+    """The visiting-order generation at the ends of its range (64 <= num < 4096 samples, and a step large enough for the
+    fused scan route: >= 256 query tiles; outside, the draw launch falls back to independent draws and the scan to
+    brute-force Chamfer tiles), small meshes, gt clouds of another size than the sample count:
+    samples in visiting order, every face valid, and loss / distances / gradient bit-identical to the brute-force tiles on
+    the same samples."""
+    from geometrics_amd.tri_distance import face_order
+    V, Fc = meshgen.icosphere(level)
+    verts = dev(meshgen.jittered_batch(V, B), gpu).requires_grad_(True)
+    faces, gt = dev(Fc, gpu), dev(meshgen.gt_cloud(B, n_gt), gpu)
+    gi = ops.GtIndex(gt)
+    ops.manual_seed(5 + num)
+    d = ops.draw_samples(verts, faces, num, with_points=True, prepare_scan_for=n_gt, gt_index=gi)
+    choices, u, v, points = d[:4]
+    assert isinstance(d[4], ops.ScanPrep) == sorted_route
+    assert int(choices.min()) >= 0 and int(choices.max()) < Fc.shape[0]
+    assert float(u.min()) >= 0 and float(u.max()) <= 1 and float(v.min()) >= 0 and float(v.max()) < 1
+    if sorted_route:
+        order = face_order(verts.detach(), faces).long()
+        rank = torch.empty_like(order)
+        rank[order] = torch.arange(order.numel(), device=gpu)
+        pos = rank[choices]
+        assert bool((pos[:, 1:] >= pos[:, :-1]).all())
+    loss, sq_gt, sq_pred = ops.SurfaceLoss.apply(verts, faces, gt, choices, u, v, False, 3000.0, points, d[4], None, gi)
+    loss.backward()
+    first = (loss.detach().clone(), sq_gt.clone(), sq_pred.clone(), verts.grad.clone())
+    verts.grad = None
+    loss, sq_gt, sq_pred = ops.SurfaceLoss.apply(verts, faces, gt, choices, u, v, False, 3000.0)
+    loss.backward()
+    for x, y in zip(first, (loss.detach(), sq_gt, sq_pred, verts.grad)):
+        assert torch.equal(x, y)
+    ops.manual_seed(0, gpu)
+
+
 def test_sorted_draws_are_shard_invariant(gpu):
     """The samples the culled route generates (in face-visiting order) for a mesh depend on the seed, the stream position,
     the mesh's GLOBAL index and its positions only -- not on which other meshes share the launch: 16 meshes drawn at once
