@@ -377,7 +377,7 @@ def valu_rate(kernel_prefix, launch_us):
             "frac_of_measured_vfma_rate": round(rate / VALU_MEASURED_TERA_LANE_OPS, 4)}
 
 
-def fused_scan_call(w, pos, pred, flags=0, share=None, prep=None):
+def fused_scan_call(w, pos, pred, flags=0, share=None, prep=None, tail=False):
     """geom_surface_scan_f32 on the step's own tensors (outputs allocated once): prep launch + the fused NN / tri launch.
     share = an earlier call object whose buffers (incl. the prepared tri workspace) are reused.  prep = what the step's draw
     launch returned (ops.draw_samples(..., prepare_scan_for, gt_index)): samples in visiting order + their index + the
@@ -405,6 +405,9 @@ def fused_scan_call(w, pos, pred, flags=0, share=None, prep=None):
         ws, flags = scan_prep.tri_ws, flags | L.FLAG_TRI_WS_READY
         cull = L.SurfaceCull(w.gt_index.order.data_ptr(), w.gt_index.index.data_ptr(), scan_prep.sample_index.data_ptr(), None)
     wrote = ctypes.c_int(0)
+    # tail: the finalize pass inside the launch (what the step's own call does: ops.scan_finalize_tail); needs the draws' faces
+    loss = torch.empty((), dtype=torch.float32, device=pos.device)
+    tail_arg = L.SurfaceTail(prep[0].data_ptr(), 1.0, 1.0, 1, loss.data_ptr(), 0) if tail and prep is not None else None
 
     def call():
         L.check(lib.geom_surface_scan_f32(b, n_gt, w.gt.data_ptr(), num, pred.data_ptr(), o[0].data_ptr(), o[1].data_ptr(),
@@ -412,8 +415,9 @@ def fused_scan_call(w, pos, pred, flags=0, share=None, prep=None):
                                           tri_order.data_ptr(), o[4].data_ptr(), o[5].data_ptr(), o[6].data_ptr(),
                                           o[7].data_ptr(), o[8].data_ptr(), o[9].data_ptr(), u.data_ptr(), v.data_ptr(), 1.0, 1.0,
                                           order.data_ptr(), flags, ws.data_ptr(), ws_bytes, ctypes.byref(wrote),
-                                          ctypes.byref(cull) if cull is not None else None, L.stream_ptr()), "geom_surface_scan_f32")
-    call.keep = (o, ws, order, u, v, tri_order, cull, prep)
+                                          ctypes.byref(cull) if cull is not None else None,
+                                          ctypes.byref(tail_arg) if tail_arg is not None else None, L.stream_ptr()), "geom_surface_scan_f32")
+    call.keep = (o, ws, order, u, v, tri_order, cull, prep, loss, tail_arg)
     return call
 
 
@@ -455,11 +459,13 @@ def kernel_rooflines(w):
         t_scan_all = event_time_us(scan)                                              # prep + fused launch, brute-force Chamfer tiles
         scan()                                                                        # workspace now holds this mesh's records
         t_scan_plain = event_time_us(fused_scan_call(w, pos, pred, _lib.FLAG_TRI_WS_READY, share=scan))   # the fused launch alone
-        t_scan = t_scan_plain
+        t_scan = t_scan_step = t_scan_plain
         if w.gt_index is not None:      # the step's own variant: culled Chamfer tiles on samples generated in visiting order
             prep = ops.draw_samples(pos, w.faces, S_PTS, with_points=True, prepare_scan_for=G_PTS, gt_index=w.gt_index)
             if isinstance(prep[4], ops.ScanPrep) and prep[4].sample_index is not None:
                 t_scan = event_time_us(fused_scan_call(w, pos, pred, share=scan, prep=prep))
+                # ... and with the loss's finalize pass riding in the launch (ops.scan_finalize_tail: what the step runs)
+                t_scan_step = event_time_us(fused_scan_call(w, pos, pred, share=scan, prep=prep, tail=True))
         t_prep_tri = event_time_us(lambda: tri_distance_indexed(w.gt, pos, w.faces))  # prep + tri-only scan
         t_tri_flat = event_time_us(lambda: tri_distance_indexed(w.gt, pos, w.faces, order=None))
         from geometrics_amd.tri_distance import tri_distance as tri_soup
@@ -496,6 +502,11 @@ def kernel_rooflines(w):
                                   "culling, not utilisation: the tri tiles prove ~95 % of their pairs irrelevant (bit-exact "
                                   "vs brute force)"},
         "launch_us": round(t_scan, 1), "launch_us_brute_force_chamfer_tiles": round(t_scan_plain, 1),
+        "launch_us_with_the_finalize_roles": round(t_scan_step, 1),
+        "finalize_roles": "in the step the launch also carries the loss's finalize pass (b + 1 extra workgroups that order each mesh's "
+                          "points by face as soon as ITS triangle tiles are through and sum the loss behind the last tile; "
+                          "surface_finalize_kernel took 11.4 us as a launch of its own) -- the committed trace and the PMC row are "
+                          "of that launch; launch_us is the scans alone",
         "chamfer_tiles": "culled (nn_culled_body: run spheres over samples the draw launch generates in face-visiting order and "
                          "over the static gt index; bit-identical to the brute-force tiles)" if t_scan is not t_scan_plain
                          else "brute force",
@@ -855,6 +866,8 @@ def main():
     ap.add_argument("--clock-warmup-ms", type=float, default=250.0,
                     help="neutral GEMM load in front of the warm-up steps so that short runs are not timed on the clock ramp (0: off)")
     ap.add_argument("--plain-chamfer", action="store_true", help="brute-force Chamfer tiles instead of the culled scan (same results)")
+    ap.add_argument("--separate-finalize", action="store_true", help="the surface loss's finalize pass as a launch of its own instead of "
+                    "extra workgroups of the scan launch (same results; the A/B switch of ops.scan_finalize_tail)")
     ap.add_argument("--riders", action="store_true", help="the first layer's split launch carries the reductions that are already due "
                     "(same results; layers.carry_due_reductions, measured in profiles/r04_riders.txt and off by default)")
     ap.add_argument("--launch", choices=("graph", "eager"), default="graph",
@@ -866,6 +879,8 @@ def main():
     args = ap.parse_args()
     global CULLED_CHAMFER
     CULLED_CHAMFER = not args.plain_chamfer
+    if args.separate_finalize:
+        ops.scan_finalize_tail = False
     if args.riders:
         from geometrics_amd import layers as _layers
         _layers.carry_due_reductions = True

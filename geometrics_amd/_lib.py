@@ -78,7 +78,7 @@ _SIGNATURES = {
     "geom_surface_prepare_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _u, _vp, ctypes.c_size_t, _vp, _vp, _vp],
     "geom_nn_cull_index_f32": [_i, _i, _vp, _vp, _vp, _vp],
     "geom_surface_scan_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                              _vp, _vp, _f, _f, _vp, _u, _vp, ctypes.c_size_t, _vp, _vp, _vp],
+                              _vp, _vp, _f, _f, _vp, _u, _vp, ctypes.c_size_t, _vp, _vp, _vp, _vp],
     "geom_surface_gather_f32": [_i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "geom_vertex_head_fwd_f32": [ctypes.c_int64, _i, _vp, _vp, _f, _vp, _vp],
     "geom_vertex_head_bwd_f32": [ctypes.c_int64, _i, _vp, _f, _vp, _vp],
@@ -123,6 +123,12 @@ class SurfaceCull(ctypes.Structure):
     """struct geom_surface_cull (include/geom_hip.h): the buffers of the culled Chamfer scan inside the surface step."""
     _fields_ = [("gt_order", ctypes.c_void_p), ("gt_index", ctypes.c_void_p), ("sample_index", ctypes.c_void_p),
                 ("faces_in_order", ctypes.c_void_p)]
+
+
+class SurfaceTail(ctypes.Structure):
+    """struct geom_surface_tail (include/geom_hip.h): the finalize pass as trailing workgroups of the fused scan launch."""
+    _fields_ = [("choices", ctypes.c_void_p), ("scale_sample", ctypes.c_float), ("scale_other", ctypes.c_float),
+                ("want_order", ctypes.c_int), ("loss", ctypes.c_void_p), ("finalized", ctypes.c_int)]
 
 
 def call(name, *args):

@@ -71,6 +71,15 @@ __host__ __device__ __forceinline__ bool ref_tail_skipped(int k, int m)
 // slot the `tiles` workgroups of a job are consecutive.  Grid size = 8 * tiles * ceil(jobs / 8);
 // workgroups whose job index falls beyond `jobs` exit.  Placement only affects speed (L2 hits
 // instead of 8x refetch through the fabric), never results.
+// A store other workgroups of the SAME launch may read after a flag hand-off (the finalize tail of the fused surface scan):
+// agent scope = written through the XCD's L2, so the producer needs no L2 write-back (a release fence costs a buffer_wbl2
+// per wave: 9 000 of them made that launch 245 us instead of 45) -- only s_waitcnt vmcnt(0) before it signs off.
+template <typename T>
+__device__ __forceinline__ void store_agent(T *p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 constexpr int NUM_XCD = 8;
 // With fewer than 8 jobs every job is spread over floor(8 / jobs) XCDs (its tiles interleaved), so
 // a small batch still uses the whole chip.

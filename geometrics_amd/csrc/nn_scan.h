@@ -147,7 +147,7 @@ __device__ __forceinline__ void nn_scalar_body(const NNJob &job, int bid, const 
             acc_d = d_first;
             acc_i = 0;
         }
-        out_d[q] = acc_d;
+        geom::store_agent(out_d + q, acc_d); // read by the loss role of the fused scan's finalize tail
         out_i[q] = acc_i;
         if (rr.rec) { // surface-loss record of this point: (sampled point - gt partner) * coef and the sample's corner weights
             const float tx = T[3 * acc_i + 0], ty = T[3 * acc_i + 1], tz = T[3 * acc_i + 2];
@@ -594,7 +594,7 @@ __device__ __forceinline__ void nn_culled_body(const NNJob &job, const NNCull &c
                 acc_i = 0;
             }
             const int qq = qo[h];
-            out_d[qq] = acc_d;
+            geom::store_agent(out_d + qq, acc_d); // read by the loss role of the fused scan's finalize tail
             out_i[qq] = acc_i;
             if (rr.rec) { // surface-loss record of this point (see nn_scalar_body)
                 const float tx = T0[3 * acc_i + 0], ty = T0[3 * acc_i + 1], tz = T0[3 * acc_i + 2];

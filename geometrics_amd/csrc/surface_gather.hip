@@ -23,6 +23,7 @@
 #include "geom_common.h"
 #include "tri_math.h"
 #include "surface_layout.h"
+#include "finalize_body.h"
 
 namespace {
 
@@ -54,7 +55,11 @@ inline size_t ord_lds_limit()
 }
 #define ORD_LDS_LIMIT (ord_lds_limit())
 
-enum { OTHER_NONE = 0, OTHER_NN = 1, OTHER_TRI = 2 };
+using geom_finalize::OTHER_NONE;
+using geom_finalize::OTHER_NN;
+using geom_finalize::OTHER_TRI;
+using geom_finalize::FinalizeArgs;
+using geom_finalize::ld3;
 
 struct GatherArgs {
     const int *vf_ptr;  // [nv+1]
@@ -77,7 +82,6 @@ struct GatherArgs {
     float *grad_verts;
 };
 
-__device__ __forceinline__ V3 ld3(const float *p) { return geom::mk(p[0], p[1], p[2]); }
 
 __global__ __launch_bounds__(SGA_THREADS) void surface_bin_kernel(GatherArgs a)
 {
@@ -254,191 +258,11 @@ __global__ __launch_bounds__(SGA_THREADS) void surface_gather_kernel(GatherArgs 
 //   * one more workgroup reduces the two loss sums (fixed tree) meanwhile.
 // The backward is then ONE launch (surface_vertex_gather_kernel).  Compared with binning in the backward (bin ->
 // order -> gather, plus a one-workgroup loss reduction in the forward) this removes two launches and every global atomic.
-struct FinalizeArgs {
-    const int64_t *choices;
-    const float *u, *v, *points, *gt;
-    const int *idx_g, *idx_p, *index;
-    const float *closest, *weights;
-    const float *sq_sample, *sq_other; // [b,num], [b,n_gt]: the squared distances the loss sums
-    float scale_sample, scale_other;   // loss = scale_sample * sum(sq_sample) + scale_other * sum(sq_other)
-    float coef_sample, coef_other;     // gradient coefficients of the two kinds of points (without 2 * upstream grad)
-    int b, nf, num, n_gt, other, per, want_order, records_ready;
-    int *off, *seg, *pface, *slot;
-    float4 *rec;
-    float *loss;
-};
-
-constexpr int FIN_ITEMS = 8; // points per thread kept in registers (per <= 8192); beyond: through the pface / slot scratch
-
-__device__ __forceinline__ float block_sum_1024(float v, float *lds16, int tid)
-{
-    for (int d = GEOM_WAVE / 2; d > 0; d >>= 1) v += __shfl_down(v, d, GEOM_WAVE);
-    __syncthreads();
-    if ((tid & (GEOM_WAVE - 1)) == 0) lds16[tid >> 6] = v;
-    __syncthreads();
-    float t = 0.f;
-    if (tid < GEOM_WAVE) {
-        t = tid < ORD_WAVES ? lds16[tid] : 0.f;
-        for (int d = GEOM_WAVE / 2; d > 0; d >>= 1) t += __shfl_down(t, d, GEOM_WAVE);
-    }
-    return t; // valid in thread 0
-}
-
 template <bool REGS>
 __global__ __launch_bounds__(ORD_THREADS) void surface_finalize_kernel(FinalizeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) int ord_lds[];
-    int *off = ord_lds;                       // [nf+1]: counts, then offsets (ordering only)
-    int *seg = off + (a.want_order ? a.nf + 1 : 0); // [per]
-    int *wave_total = seg + (a.want_order ? a.per : 0);
-    float *fsum = reinterpret_cast<float *>(wave_total + ORD_WAVES);
-    const int mesh = a.want_order ? blockIdx.x : a.b, tid = threadIdx.x; // without ordering the grid is the loss workgroup alone
-    const int lane = tid & (GEOM_WAVE - 1), wave = tid >> 6;
-
-    // ---- the extra workgroup (blockIdx.x == b) reduces the loss while the others order their meshes: float4 loads, all
-    //      of a thread's loads in flight together, then a fixed tree -- no cross-workgroup hand-off at all ----
-    if (mesh == a.b) {
-        auto thread_sum = [&](const float *x, int64_t n) {
-            float acc = 0.f;
-            const bool vec = (((uintptr_t)x) & 15) == 0;
-            const int64_t n4 = vec ? n / 4 : 0;
-            const float4 *x4 = reinterpret_cast<const float4 *>(x);
-            for (int64_t base = 0; base < n4; base += (int64_t)8 * ORD_THREADS) {
-                float4 v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int64_t i = base + tid + (int64_t)k * ORD_THREADS;
-                    v[k] = i < n4 ? x4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-            }
-            for (int64_t i = 4 * n4 + tid; i < n; i += ORD_THREADS) acc += x[i];
-            return acc;
-        };
-        float s1 = thread_sum(a.sq_sample, (int64_t)a.b * a.num), s2 = thread_sum(a.sq_other, (int64_t)a.b * a.n_gt);
-        s1 = block_sum_1024(s1, fsum, tid);
-        s2 = block_sum_1024(s2, fsum + ORD_WAVES, tid);
-        if (tid == 0) a.loss[0] = s1 * a.scale_sample + s2 * a.scale_other;
-        return;
-    }
-
-    if (a.want_order) {
-        for (int f = tid; f <= a.nf; f += ORD_THREADS) off[f] = 0;
-        __syncthreads();
-        const int64_t p0 = (int64_t)mesh * a.per;
-        // record of point `id` -> global, its face counted in LDS; returns the face (-1: none) and the arrival slot
-        auto bin_point = [&](int id, int &fi, int &sl) {
-            int64_t f, sp = -1;
-            if (a.records_ready) { // the fused scan already wrote the record: only the face is needed here
-                if (id < a.num) f = a.choices[(int64_t)mesh * a.num + id];
-                else {
-                    const int64_t o = (int64_t)mesh * a.n_gt + (id - a.num);
-                    f = a.other == OTHER_TRI ? (int64_t)a.index[o] : a.choices[(int64_t)mesh * a.num + a.idx_p[o]];
-                }
-            } else {
-                V3 g;
-                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-                float skip_zero = 0.f;
-                if (id < a.num) {
-                    sp = (int64_t)mesh * a.num + id;
-                    f = a.choices[sp];
-                    g = (ld3(a.points + 3 * sp) - ld3(a.gt + 3 * ((int64_t)mesh * a.n_gt + a.idx_g[sp]))) * a.coef_sample;
-                } else {
-                    const int64_t o = (int64_t)mesh * a.n_gt + (id - a.num);
-                    if (a.other == OTHER_TRI) {
-                        f = a.index[o];
-                        g = (ld3(a.closest + 3 * o) - ld3(a.gt + 3 * o)) * a.coef_other;
-                        w = make_float4(a.weights[3 * o], a.weights[3 * o + 1], a.weights[3 * o + 2], 0.f);
-                        skip_zero = 1.f; // the scatter does not touch a corner whose weight is exactly zero
-                    } else {
-                        sp = (int64_t)mesh * a.num + a.idx_p[o];
-                        f = a.choices[sp];
-                        g = (ld3(a.points + 3 * sp) - ld3(a.gt + 3 * o)) * a.coef_other;
-                    }
-                }
-                if (sp >= 0) {
-                    const float u = a.u[sp], v = a.v[sp];
-                    w = make_float4(1.f - u, u * (1.f - v), u * v, 0.f);
-                }
-                a.rec[2 * (p0 + id) + 0] = make_float4(g.x, g.y, g.z, skip_zero);
-                a.rec[2 * (p0 + id) + 1] = w;
-            }
-            const bool on_mesh = f >= 0 && f < a.nf; // else: contributes nowhere
-            fi = on_mesh ? (int)f : -1;
-            sl = on_mesh ? atomicAdd(&off[fi], 1) : 0; // LDS atomic: arrival slot inside the face
-        };
-        int my_f[FIN_ITEMS], my_slot[FIN_ITEMS];
-        if (REGS) {
-#pragma unroll
-            for (int it = 0; it < FIN_ITEMS; ++it) {
-                const int id = tid + it * ORD_THREADS;
-                my_f[it] = -1, my_slot[it] = 0;
-                if (id < a.per) bin_point(id, my_f[it], my_slot[it]);
-            }
-        } else {
-            for (int id = tid; id < a.per; id += ORD_THREADS) {
-                int fi, sl;
-                bin_point(id, fi, sl);
-                a.pface[p0 + id] = fi;
-                a.slot[p0 + id] = sl;
-            }
-        }
-        __syncthreads();
-        // ---- exclusive scan of the counts (consecutive faces per thread) ----
-        const int chunk = (a.nf + ORD_THREADS - 1) / ORD_THREADS;
-        const int f0 = min(a.nf, tid * chunk), f1 = min(a.nf, f0 + chunk);
-        int run = 0;
-        for (int f = f0; f < f1; ++f) {
-            const int c = off[f];
-            off[f] = run;
-            run += c;
-        }
-        int incl = run;
-        for (int d = 1; d < GEOM_WAVE; d <<= 1) {
-            const int t = __shfl_up(incl, d, GEOM_WAVE);
-            if (lane >= d) incl += t;
-        }
-        if (lane == GEOM_WAVE - 1) wave_total[wave] = incl;
-        __syncthreads();
-        int base = incl - run;
-        for (int w = 0; w < wave; ++w) base += wave_total[w];
-        for (int f = f0; f < f1; ++f) off[f] += base;
-        if (tid == ORD_THREADS - 1) off[a.nf] = base + run;
-        __syncthreads();
-        int *g_off = a.off + (int64_t)mesh * (a.nf + 1);
-        for (int f = tid; f <= a.nf; f += ORD_THREADS) g_off[f] = off[f];
-        // ---- ids at offset + slot, then ranked into ascending order ----
-        if (REGS) {
-#pragma unroll
-            for (int it = 0; it < FIN_ITEMS; ++it)
-                if (my_f[it] >= 0) seg[off[my_f[it]] + my_slot[it]] = tid + it * ORD_THREADS;
-        } else {
-            for (int id = tid; id < a.per; id += ORD_THREADS) {
-                const int f = a.pface[p0 + id];
-                if (f >= 0) seg[off[f] + a.slot[p0 + id]] = id;
-            }
-        }
-        __syncthreads();
-        int *g_seg = a.seg + p0;
-        auto place = [&](int id, int f) {
-            const int s0 = off[f], n = off[f + 1] - s0;
-            int rank = 0;
-            for (int j = 0; j < n; ++j) rank += seg[s0 + j] < id ? 1 : 0;
-            g_seg[s0 + rank] = id;
-        };
-        if (REGS) {
-#pragma unroll
-            for (int it = 0; it < FIN_ITEMS; ++it)
-                if (my_f[it] >= 0) place(tid + it * ORD_THREADS, my_f[it]);
-        } else {
-            for (int id = tid; id < a.per; id += ORD_THREADS) {
-                const int f = a.pface[p0 + id];
-                if (f >= 0) place(id, f);
-            }
-        }
-    }
-
+    geom_finalize::surface_finalize_body<REGS, ORD_THREADS>(a, ord_lds, blockIdx.x);
 }
 
 struct VGatherArgs {
@@ -602,9 +426,8 @@ extern "C" int geom_surface_finalize_f32(int b, int nf, int num, const int64_t *
     hipStream_t s = static_cast<hipStream_t>(stream);
     // without ordering the single (loss) workgroup touches only its reduction scratch: independent of nf, so the
     // documented fallback beyond the ordering limit (want_order = 0 + scatter backward) really launches
-    const size_t lds = want_order ? order_lds_bytes(nf, per) + 2 * ORD_WAVES * sizeof(float)
-                                  : ((size_t)ORD_WAVES + 4) * sizeof(int) + 2 * ORD_WAVES * sizeof(float);
-    if (per <= FIN_ITEMS * ORD_THREADS) {
+    const size_t lds = geom_finalize::finalize_lds_ints(nf, per, ORD_THREADS, want_order != 0) * sizeof(int);
+    if (per <= geom_finalize::FIN_REG_POINTS) {
         static const hipError_t opt_in = hipFuncSetAttribute(reinterpret_cast<const void *>(surface_finalize_kernel<true>),
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ORD_LDS_LIMIT + 1024);
         (void)opt_in;

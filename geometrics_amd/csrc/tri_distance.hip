@@ -27,6 +27,7 @@
 #include "nn_scan.h"
 #include "surface_layout.h"
 #include "draw_body.h"
+#include "finalize_body.h"
 
 namespace {
 
@@ -711,6 +712,11 @@ struct SurfaceOut {
 };
 constexpr SurfaceOut NO_SURFACE{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f, 0, 0};
 
+constexpr int TAIL_CTR_STRIDE = 32;
+__host__ __device__ inline int tail_counters(int b) { return 3 * b + 1; }
+// whether the merged-keys region of a workspace (b * n * 8 bytes) holds the counters
+__host__ __device__ inline bool tail_counters_fit(int b, int n) { return (int64_t)tail_counters(b) * TAIL_CTR_STRIDE * 4 <= (int64_t)b * n * 8; }
+
 struct TriGws {
     float4 *sph;   // [b][m_pad]     member spheres, slot order
     float4 *cor;   // [b][m_pad][3]  corners; cor[3j].w = original triangle index (int bits), -1 = padding
@@ -725,6 +731,13 @@ template <bool INDEXED, bool TRUNC, bool FIX6>
 __device__ __forceinline__ void tri_prep_grouped_body(const TriJob &job, const TriGws &ws, const int *__restrict__ order, int j,
                                                       int mesh)
 {
+    // the tile-completion counters of the fused scan's finalize tail (ScanTail, tail_counters(b) lines of 128 bytes) live in
+    // the merged-keys region, which a scan without triangle split never touches: zero before every scan that follows a prep
+    if (ws.split == 1 && j < 4 && tail_counters_fit(job.b, job.n)) {
+        int *done = reinterpret_cast<int *>(ws.keys);
+        const int which = j == 0 ? mesh : j == 1 ? job.b + 2 * mesh : j == 2 ? job.b + 2 * mesh + 1 : 3 * job.b;
+        if (j < 3 || mesh == 0) done[(size_t)which * TAIL_CTR_STRIDE] = 0;
+    }
     if (ws.split > 1 && j < job.n) ws.keys[(size_t)mesh * job.n + j] = KEY_NONE;
     if (j >= ws.m_pad) return; // m_pad is a multiple of 64: whole waves leave together
     int k = -1;
@@ -1066,7 +1079,7 @@ __device__ __forceinline__ void tri_scan_grouped_body(int bid, const float *__re
         const size_t o = (size_t)mesh * n + q;
         dist[o] = acc_d;
         point[o] = acc_k & 7;
-        index[o] = acc_k >> 3;
+        geom::store_agent(index + o, (int)(acc_k >> 3)); // index and sqdist: read by the finalize tail of the same launch
         if (surf.sqdist) { // point-to-surface epilogue (calc_point_to_line on the winner, utils.py:506-550)
             const float *V = surf.verts + (size_t)mesh * surf.nv * 3;
             const int64_t f = acc_k >> 3;
@@ -1076,7 +1089,7 @@ __device__ __forceinline__ void tri_scan_grouped_body(int bid, const float *__re
             V3 w;
             const V3 hit = geom::closest_on_triangle(p, A, B, C, acc_k & 7, w);
             const V3 d = hit - p;
-            surf.sqdist[o] = geom::dot3(d, d);
+            geom::store_agent(surf.sqdist + o, geom::dot3(d, d));
             surf.closest[3 * o + 0] = hit.x, surf.closest[3 * o + 1] = hit.y, surf.closest[3 * o + 2] = hit.z;
             surf.weights[3 * o + 0] = w.x, surf.weights[3 * o + 1] = w.y, surf.weights[3 * o + 2] = w.z;
             if (surf.rec) { // backward record: (closest - p) * coef, corner weights; flag: zero weights are skipped
@@ -1112,13 +1125,117 @@ __global__ __launch_bounds__(HS_WAVES * GEOM_WAVE) void tri_scan_grouped_kernel(
 // build (3 workgroups per CU instead of 2, 13 registers spilled): 55.3.  PMC of this launch: 32.0 M VALU instructions
 // = 40 T lane-ops/s, 0.51 of the 78.6 T spec issue rate and 0.78 of the 51.5 T the chip sustains on un-packed v_fma_f32
 // (MI355X_MICROARCH.md: 103 TFLOP/s measured) -- the fused launch is VALU-issue bound, what is left is instruction count.
+
 #ifdef SCAN_TILE_STAMPS
 __device__ long long scan_tile_stamps[4 * 4096]; // per workgroup {start, end (100 MHz wall clock), kind, hardware id}
+extern "C" int geom_probe_read_role_phases(long long *host)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(scan_role_phases), sizeof(long long) * 256);
+}
 extern "C" int geom_probe_read_scan_stamps(long long *host, int rows)
 {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(scan_tile_stamps), sizeof(long long) * 4 * (size_t)rows);
 }
 #endif
+
+// The FINALIZE of the surface loss (surface_gather.hip: the loss sum + the points ordered by face for the gather backward)
+// as extra workgroups of the scan launch instead of a launch of its own (11.4 us of a 9-workgroup chain behind a 42 us
+// launch whose meshes finish at different times): every tile signs off in its mesh's counter (triangle tiles) and in the
+// launch's counter (every tile) once its stores of the three arrays the roles read are acknowledged (geom::store_agent);
+// role workgroup r < b waits for mesh r's triangle tiles and orders that mesh, the last role waits for every tile and sums
+// the loss.  The roles LEAD the grid (resident from the start, their scan-independent half done before the wait); they
+// can never starve the tiles of slots (b + 1 workgroups against hundreds of slots; tiles wait for nothing), so the launch
+// always drains.  The counters are zeroed by the prep launch and reset by their waiter.  Same finalize body as the stand-alone
+// launch (finalize_body.h): same bits.
+struct ScanTail {
+    geom_finalize::FinalizeArgs fin;
+    int *done;       // tail_counters(b) counters, TAIL_CTR_STRIDE ints apart; nullptr: no tail in this launch
+    int lead;        // workgroups [0, lead) are finalize roles (roles rounded up to a multiple of 8), tiles follow
+    int tiles;       // tile workgroups of the launch (triangle + Chamfer, padding included): what the loss role waits for
+    int roles;       // b + 1 with ordering, 1 (the loss) without
+    int expect_mesh; // triangle tiles per mesh
+    int expect_job;  // Chamfer tiles per (direction, mesh)
+};
+constexpr int SCAN_TAIL_LDS_INTS = 11776; // 46 KB: three workgroups per CU still fit (the BASELINE mesh needs 11 173)
+
+// Completion counters (TAIL_CTR_STRIDE, tail_counters()), ONE 128-byte line each (every tile's sign-off is a memory-side atomic; 2 256 of them plus the
+// pollers on one line slowed every tile of the launch by ~15 %): [0, b) triangle tiles of mesh i; [b, 3b) Chamfer tiles of
+// job j (direction x mesh); [3b] ordering roles that are past their wait (the loss role's stand-in for the triangle tiles).
+
+// which counter a tile signs (-1: a padding workgroup) -- computed in front of the tile's body so that ONE register lives
+// across it (the geometry this takes -- b, n, the tile counts -- pushed scalar registers of the brute-force Chamfer loop
+// into spills when it was evaluated behind the body: 49 -> 59 us)
+__device__ __forceinline__ int scan_tile_counter(int bid, int tri_blocks, int b, int n, int nn_tiles)
+{
+    int job, tile;
+    if (bid < tri_blocks) return geom::xcd_assign(bid, b, (n + TRI_QUERIES - 1) / TRI_QUERIES, job, tile) ? job : -1;
+    return geom::xcd_assign(bid - tri_blocks, 2 * b, nn_tiles, job, tile) ? b + job : -1;
+}
+
+__device__ __forceinline__ void scan_tile_done(int *done, int counter)
+{
+    // every wave: its agent-scope stores (geom::store_agent: the three arrays the role workgroups read) are
+    // acknowledged before the count moves; everything else this tile wrote is read by later launches only
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0 && counter >= 0)
+        __hip_atomic_fetch_add(done + (size_t)counter * TAIL_CTR_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wave 0 of a role workgroup: lane i < count polls counter first + i until it reaches its target, all lanes together (a
+// counter that is already there costs no round trip of its own), then resets it for the next launch on this workspace
+__device__ __forceinline__ void tail_wait_counters(int *done, int first, int count, int expect)
+{
+    for (int c0 = 0; c0 < count; c0 += GEOM_WAVE) {
+        const int i = c0 + (int)threadIdx.x;
+        int *ctr = done + (size_t)(first + i) * TAIL_CTR_STRIDE;
+        bool ok = i >= count;
+        while (true) {
+            if (!ok) ok = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= expect;
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+        if (i < count) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+struct ScanTailWait {
+    int *done;
+    int role, b, ordering, expect_mesh, expect_job; // role == b: the loss role
+    __device__ __forceinline__ void operator()() const
+    {
+        if (threadIdx.x < GEOM_WAVE) {
+            if (role < b) { // mesh `role`'s triangle tiles; then tell the loss role
+                tail_wait_counters(done, role, 1, expect_mesh);
+                if (threadIdx.x == 0)
+                    __hip_atomic_fetch_add(done + (size_t)3 * b * TAIL_CTR_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {        // every tile: the Chamfer jobs, and the triangle tiles directly or through their ordering roles
+                tail_wait_counters(done, b, 2 * b, expect_job);
+                if (ordering) tail_wait_counters(done, 3 * b, 1, b);
+                else tail_wait_counters(done, 0, b, expect_mesh);
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // nothing stale from this XCD's L2
+#ifdef SCAN_TILE_STAMPS
+        if (threadIdx.x == 0) scan_tile_stamps[4 * (size_t)blockIdx.x + 3] = wall_clock64();
+#endif
+    }
+};
+
+// role r of the launch's leading block of workgroups (roles rounded up to a multiple of 8; they are resident from the
+// start: what does not depend on the scans -- zeroing, binning the sampled points by their drawn faces -- is done before
+// the wait)
+__device__ __forceinline__ void scan_tail_role(const ScanTail &t, int role, int *lds_ints)
+{
+    if (role >= t.roles) return; // padding (the tile workgroups keep their blockIdx % 8 = XCD mapping)
+    const int b = t.fin.b;
+    const bool loss_role = role == t.roles - 1;
+    const ScanTailWait wait{t.done, loss_role ? b : role, b, t.roles > 1, t.expect_mesh, t.expect_job};
+    // the variant that keeps the points' faces / arrival slots in the global scratch, not in registers: 16 points per thread
+    // do not fit this launch's 80-register budget (built: 2 454 spilled registers, 55 us to bin 3000 points)
+    geom_finalize::surface_finalize_body<false, 8 * GEOM_WAVE>(t.fin, lds_ints, loss_role ? b : role, wait);
+}
 
 // CULL: the Chamfer tiles take the culled scan (nn_culled_body).  Its tiles are latency chains, not issue-bound loops, so
 // the launch wants THREE workgroups per CU: the two bodies' LDS is overlaid (a workgroup is one or the other: 43 KB instead
@@ -1130,37 +1247,47 @@ __global__ __launch_bounds__(8 * GEOM_WAVE, CULL ? 6 : 1) void surface_scan_kern
                                                                                   TriGws ws, float *__restrict__ dist,
                                                                                   int *__restrict__ point, int *__restrict__ index,
                                                                                   SurfaceOut surf, NNJob job, NNRecords rr,
-                                                                                  int tri_blocks, NNCull cull)
+                                                                                  int tri_blocks, NNCull cull, ScanTail tail)
 {
     static_assert(NNS_THREADS == 8 * GEOM_WAVE, "both bodies are written for 8-wave workgroups");
 #ifdef SCAN_TILE_STAMPS // tools/probe only: when each tile of the launch started and ended, and where (see scan_tile_stamps.py)
     const long long stamp_t0 = wall_clock64();
     struct StampOnExit {
         long long t0;
-        int tri_blocks;
+        int tri_blocks, lead;
         __device__ ~StampOnExit()
         {
             __syncthreads();
             if (threadIdx.x == 0) {
                 long long *row = scan_tile_stamps + 4 * (size_t)blockIdx.x;
-                row[0] = t0, row[1] = wall_clock64(), row[2] = (int)blockIdx.x < tri_blocks ? 0 : 1, row[3] = __smid();
+                row[0] = t0, row[1] = wall_clock64(), row[2] = (int)blockIdx.x < lead ? 2 : ((int)blockIdx.x - lead < tri_blocks ? 0 : 1);
+                if ((int)blockIdx.x >= lead) row[3] = __smid(); // roles: the end of their wait (ScanTailWait)
             }
         }
-    } stamp_on_exit{stamp_t0, tri_blocks};
+    } stamp_on_exit{stamp_t0, tri_blocks, tail.lead};
 #endif
     if constexpr (CULL) {
         __shared__ union Lds {
             TriTileLds<8> tri;
             NNCullLds nn;
+            int fin[SCAN_TAIL_LDS_INTS];
             __device__ Lds() {}
         } lds;
+        if ((int)blockIdx.x < tail.lead) {
+            scan_tail_role(tail, blockIdx.x, lds.fin);
+            return;
+        }
+        const int bid = (int)blockIdx.x - tail.lead; // tile index (tail.lead = 0 without a finalize tail)
+        const int sign = tail.done ? scan_tile_counter(bid, tri_blocks, b, n, tail.expect_job) : -1;
         // (s_setprio(3) on either kind of tile: 41.6 / 43.3 against 42.4 us -- within the noise, not kept)
-        if ((int)blockIdx.x < tri_blocks) tri_scan_grouped_body<false, FIX6, 8>(blockIdx.x, xyz, b, n, m, ws, dist, point, index, surf, lds.tri);
-        else nn_culled_body<FMA>(job, cull, blockIdx.x - tri_blocks, rr, lds.nn);
-    } else {
+        if (bid < tri_blocks) tri_scan_grouped_body<false, FIX6, 8>(bid, xyz, b, n, m, ws, dist, point, index, surf, lds.tri);
+        else nn_culled_body<FMA>(job, cull, bid - tri_blocks, rr, lds.nn);
+        if (tail.done) scan_tile_done(tail.done, sign);
+    } else { // the brute-force Chamfer tiles: no finalize tail (its scalar registers and LDS cost this issue-bound variant 10 us)
         __shared__ TriTileLds<8> lds;
-        if ((int)blockIdx.x < tri_blocks) tri_scan_grouped_body<false, FIX6, 8>(blockIdx.x, xyz, b, n, m, ws, dist, point, index, surf, lds);
-        else nn_scalar_body<FMA>(job, blockIdx.x - tri_blocks, rr);
+        const int bid = blockIdx.x;
+        if (bid < tri_blocks) tri_scan_grouped_body<false, FIX6, 8>(bid, xyz, b, n, m, ws, dist, point, index, surf, lds);
+        else nn_scalar_body<FMA>(job, bid - tri_blocks, rr);
     }
 }
 
@@ -1374,9 +1501,10 @@ extern "C" int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, 
                                      float *sq, float *closest, float *weights, const float *u, const float *v,
                                      float coef_sample, float coef_other, int *order_scratch, unsigned flags,
                                      void *workspace, size_t workspace_bytes, int *records_written,
-                                     const geom_surface_cull *cull, void *stream)
+                                     const geom_surface_cull *cull, geom_surface_tail *tail, void *stream)
 {
     if (records_written) *records_written = 0;
+    if (tail) tail->finalized = 0;
     if (b < 0 || n_gt < 0 || num < 0 || nf < 0 || nv < 0) return GEOM_EINVAL;
     if (b == 0) return 0;
     if (n_gt == 0 || num == 0) return GEOM_EINVAL;
@@ -1420,11 +1548,34 @@ extern "C" int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, 
             const int qtiles = (n_gt + TRI_QUERIES - 1) / TRI_QUERIES;
             const unsigned tri_blocks = geom::xcd_grid(b, qtiles);
             SurfaceOut so{verts, faces, nv, sq, closest, weights, rec, coef_other, (int)cap, num};
-            const dim3 grid(tri_blocks + nn_blocks), block(8 * GEOM_WAVE);
             // the Chamfer tiles take the culled scan when the caller handed over the indices of both clouds (the gt
             // cloud's: static; the sampled points': written by geom_surface_prepare_f32 of the same step)
             const bool culled = cull && cull->gt_index && cull->sample_index;
             if (culled && (((uintptr_t)cull->gt_index | (uintptr_t)cull->sample_index) & 15)) return GEOM_EINVAL;
+            // the finalize pass as extra workgroups of this launch (ScanTail) when the caller asks for it and a mesh's
+            // faces + points fit the launch's LDS; otherwise the caller launches geom_surface_finalize_f32 as before
+            ScanTail st{};
+            if (tail && (!tail->loss || !tail->choices || (tail->want_order && !rec))) return GEOM_EINVAL;
+            if (tail && culled) { // the launch with the culled Chamfer tiles only (three workgroups per CU, latency-bound tiles)
+                const int64_t per64 = (int64_t)num + n_gt;
+                if (per64 <= 0x3fffffff && tail_counters_fit(b, n_gt) &&
+                    geom_finalize::finalize_lds_ints(nf, (int)per64, 8 * GEOM_WAVE, tail->want_order != 0) <= (size_t)SCAN_TAIL_LDS_INTS) {
+                    int *off = order_scratch, *seg = off ? off + (int64_t)b * (nf + 1) : nullptr;
+                    int *pface = seg ? seg + (int64_t)b * cap : nullptr, *slot = pface ? pface + (int64_t)b * cap : nullptr;
+                    st.fin = geom_finalize::FinalizeArgs{tail->choices, u, v, points, gt, idx_g, nullptr, index, closest, weights, sq_pred, sq,
+                                                         tail->scale_sample, tail->scale_other, coef_sample, coef_other, b, nf, num, n_gt,
+                                                         geom_finalize::OTHER_TRI, (int)per64, tail->want_order ? 1 : 0, rec ? 1 : 0,
+                                                         off, seg, pface, slot, rec, tail->loss};
+                    st.done = reinterpret_cast<int *>(gws.keys);
+                    st.tiles = (int)(tri_blocks + nn_blocks);
+                    st.roles = tail->want_order ? b + 1 : 1;
+                    st.lead = (st.roles + geom::NUM_XCD - 1) / geom::NUM_XCD * geom::NUM_XCD;
+                    st.expect_mesh = qtiles;
+                    st.expect_job = nn_tiles;
+                    tail->finalized = 1;
+                }
+            }
+            const dim3 grid(st.lead + tri_blocks + nn_blocks), block(8 * GEOM_WAVE);
             NNCull nc{};
             if (culled) {
                 const float4 *s1 = reinterpret_cast<const float4 *>(cull->gt_index), *s2 = reinterpret_cast<const float4 *>(cull->sample_index);
@@ -1433,7 +1584,7 @@ extern "C" int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, 
             }
 #define GEOM_LAUNCH_SCAN(F6, FM, CU)                                                                                            \
     hipLaunchKernelGGL((surface_scan_kernel<F6, FM, CU>), grid, block, 0, s, gt, b, n_gt, nf, gws, tri_dist, option, index, so, job, \
-                       rr, (int)tri_blocks, nc)
+                       rr, (int)tri_blocks, nc, st)
 #define GEOM_LAUNCH_SCAN2(F6, FM)                                                                                               \
     do {                                                                                                                        \
         if (culled) GEOM_LAUNCH_SCAN(F6, FM, true);                                                                             \

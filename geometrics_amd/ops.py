@@ -194,6 +194,11 @@ class ScanPrep:
         self.tri_ws, self.sample_index = tri_ws, sample_index
 
 
+# The finalize pass of the one-sided surface loss as trailing workgroups of the fused scan launch (csrc/tri_distance.hip:
+# ScanTail) instead of a launch of its own; same outputs bit for bit.  False: always the separate launch (the A/B switch).
+scan_finalize_tail = True
+
+
 class SurfaceLoss(torch.autograd.Function):
     """The whole sampled-surface loss of the reference in one autograd node.
 
@@ -274,11 +279,17 @@ class SurfaceLoss(torch.autograd.Function):
                 tri_args = (nv, verts_c.data_ptr(), nf, faces.data_ptr(), _lib.ptr(tri_order), tri_d.data_ptr(),
                             option.data_ptr(), index.data_ptr(), sq.data_ptr(), closest.data_ptr(), weights.data_ptr())
                 ws_ptr, ws_len = ws.data_ptr(), ws_bytes
+            # one-sided loss: the finalize pass (below) rides in the scan launch as trailing workgroups where the launch is
+            # the fused one and a mesh's faces + points fit its LDS (tail.finalized says so): each mesh is ordered as soon
+            # as ITS triangle tiles are through instead of in a launch of its own behind the slowest tile
+            tail = None
+            if not two_sided and scan_finalize_tail:
+                tail = _lib.SurfaceTail(choices.data_ptr(), scale / sq_pred.numel(), scale / sq.numel(), int(want), out.data_ptr(), 0)
             _lib.check(L.geom_surface_scan_f32(
                 b, n_gt, gt_c.data_ptr(), num, points.data_ptr(), sq_gt.data_ptr(), idx_p.data_ptr(), sq_pred.data_ptr(),
                 idx_g.data_ptr(), *tri_args, u.data_ptr(), v.data_ptr(), coef_s, coef_o, order.data_ptr() if want else None,
                 flags, ws_ptr, ws_len, ctypes.byref(wrote), ctypes.byref(cull) if cull is not None else None,
-                _lib.stream_ptr()), "geom_surface_scan_f32")
+                ctypes.byref(tail) if tail is not None else None, _lib.stream_ptr()), "geom_surface_scan_f32")
             # finalize: the loss reduction AND, when a gradient is wanted, the backward's preparation (points counting-sorted
             # by face in ascending id order; the records too when the scans could not write them) in one launch; the
             # backward is then a single gather launch
@@ -287,11 +298,12 @@ class SurfaceLoss(torch.autograd.Function):
                     idx_g.data_ptr(), idx_p.data_ptr() if two_sided else None, None if two_sided else index.data_ptr(),
                     None if two_sided else closest.data_ptr(), None if two_sided else weights.data_ptr(),
                     sq_pred.data_ptr(), other_sq.data_ptr(), scale / sq_pred.numel(), scale / other_sq.numel(), coef_s, coef_o)
-            code = L.geom_surface_finalize_f32(*args, int(want), wrote.value, order.data_ptr(), out.data_ptr(), _lib.stream_ptr())
-            if code == _lib.EUNSUPPORTED:       # too many faces + points for the in-LDS ordering: loss only, scatter backward
-                want = False
-                code = L.geom_surface_finalize_f32(*args, 0, 0, order.data_ptr(), out.data_ptr(), _lib.stream_ptr())
-            _lib.check(code, "geom_surface_finalize_f32")
+            if tail is None or not tail.finalized:
+                code = L.geom_surface_finalize_f32(*args, int(want), wrote.value, order.data_ptr(), out.data_ptr(), _lib.stream_ptr())
+                if code == _lib.EUNSUPPORTED:       # too many faces + points for the in-LDS ordering: loss only, scatter backward
+                    want = False
+                    code = L.geom_surface_finalize_f32(*args, 0, 0, order.data_ptr(), out.data_ptr(), _lib.stream_ptr())
+                _lib.check(code, "geom_surface_finalize_f32")
             ctx.order = order if want else None
             if two_sided:
                 ctx.save_for_backward(faces, choices, u, v, points, gt_c, idx_g, idx_p)

@@ -455,13 +455,25 @@ int geom_surface_prepare_f32(int b, int nv, const float *verts, int nf, const in
  * order_scratch (may be NULL): the `order` buffer of geom_surface_finalize_f32; the scans then also write every
  * point's gradient record into it (u, v [b,num]: the draws of the sampled points; coef_sample / coef_other as for the
  * finalize) and *records_written = 1; the variants that cannot (split query tiles, brute force, tail truncation)
- * leave *records_written = 0 and the finalize pass forms the records itself. */
+ * leave *records_written = 0 and the finalize pass forms the records itself.
+ * tail (may be NULL): also run geom_surface_finalize_f32's work -- loss = scale_sample * sum(sq_pred) + scale_other *
+ * sum(sq) into *loss and, with want_order, the points ordered by face in order_scratch -- as trailing workgroups of the
+ * fused launch (each mesh is ordered as soon as ITS triangle tiles are through, the loss is summed behind the last tile)
+ * instead of a launch of its own: same outputs, bit for bit.  tail->finalized = 1 when the launch did it (fused route
+ * with the culled Chamfer tiles, nf + num + n_gt <= ~11 700 per mesh); 0: call geom_surface_finalize_f32 as usual. */
+typedef struct geom_surface_tail {
+    const int64_t *choices;         /* [b,num] faces of the sampled points */
+    float scale_sample, scale_other;
+    int want_order;                 /* needs order_scratch */
+    float *loss;                    /* one element */
+    int finalized;                  /* out */
+} geom_surface_tail;
 int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, const float *points, float *sq_gt, int *idx_p,
                           float *sq_pred, int *idx_g, int nv, const float *verts, int nf, const int64_t *faces,
                           const int *tri_order, float *tri_dist, int *option, int *index, float *sq, float *closest,
                           float *weights, const float *u, const float *v, float coef_sample, float coef_other,
                           int *order_scratch, unsigned flags, void *workspace, size_t workspace_bytes,
-                          int *records_written, const geom_surface_cull *cull, void *stream);
+                          int *records_written, const geom_surface_cull *cull, geom_surface_tail *tail, void *stream);
 
 /* ---- surface loss: forward-side finalize + single-launch backward ------------------------------------------
  * geom_surface_finalize_f32 runs once after the two scans of batch_point_to_surface / batch_point_to_point

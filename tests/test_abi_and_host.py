@@ -270,7 +270,7 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     # geom_surface_scan_f32(b, n_gt, gt, num, points, sq_gt, idx_p, sq_pred, idx_g, nv, verts, nf, faces, order, ... )
     scan = lambda b, n_gt, num, gt: L.geom_surface_scan_f32(b, n_gt, gt, num, None, None, None, None, None, 0, None, 0, None, None,
                                                             None, None, None, None, None, None, None, None, 1.0, 1.0, None, 0, None,
-                                                            0, ctypes.byref(one), None, None)
+                                                            0, ctypes.byref(one), None, None, None)
     assert scan(-1, 4, 4, None) == -1 and scan(1, 0, 4, None) == -1 and scan(1, 4, 4, None) == -1
     assert scan(0, 4, 4, None) == 0 and one.value == 0            # empty batch; *records_written cleared
     assert L.geom_surface_prepare_f32(1, 4, None, 4, None, 8, None, None, None, None, None, 8, None, 0, None, 0, None, None, None) == -1

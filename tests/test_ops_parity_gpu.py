@@ -1172,7 +1172,7 @@ def test_fused_surface_scan_equals_the_separate_scans_and_its_records_those_of_t
                                           o["idx_p"].data_ptr(), o["sq_pred"].data_ptr(), o["idx_g"].data_ptr(), *tri,
                                           u.data_ptr(), v.data_ptr(), coef_s, coef_o,
                                           o["order"].data_ptr() if with_records else None, flags, o["ws"].data_ptr(), ws_bytes,
-                                          ctypes.byref(wrote), None, L.stream_ptr()), "geom_surface_scan_f32")
+                                          ctypes.byref(wrote), None, None, L.stream_ptr()), "geom_surface_scan_f32")
         assert wrote.value == int(with_records)
         other = o["sq_gt"] if two_sided else o["sq"]
         L.call("geom_surface_finalize_f32", B, nf, num, choices.data_ptr(), u.data_ptr(), v.data_ptr(), points.data_ptr(), n_gt,
@@ -1403,3 +1403,58 @@ def test_tri_surface_fused_call_equals_scan_plus_point_to_triangle(gpu):
                                                      L.stream_ptr()), "fused")
             for got, want in ((d, d0), (p, p0), (i, i0), (s, s0), (c, c0), (w, w0)):
                 assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+
+
+@pytest.mark.parametrize("culled", [False, True])
+def test_finalize_tail_of_the_scan_launch_equals_the_separate_launch(gpu, culled):
+    """ops.scan_finalize_tail: the loss sum and the face ordering of the points done by trailing workgroups of the fused scan
+    launch (each mesh as soon as its triangle tiles are through) against geom_surface_finalize_f32 in a launch of its own:
+    loss, both distance outputs and the vertex gradient bit for bit -- with a gradient (ordering + loss roles), without one
+    (loss role only), repeated on the same workspace (the completion counters reset themselves), and as a replayed HIP graph."""
+    V, Fc = meshgen.icosphere(4)
+    B, num = 8, 3000
+    verts = dev(meshgen.jittered_batch(V, B), gpu).requires_grad_(True)
+    faces, gt = dev(Fc, gpu), dev(meshgen.gt_cloud(B, num), gpu)
+    gi = ops.GtIndex(gt) if culled else None
+    info = {"faces": faces}
+
+    def run(tail, grad=True, seed=21):
+        ops.scan_finalize_tail = tail
+        try:
+            ops.manual_seed(seed)
+            verts.grad = None
+            if grad:
+                loss = utils.batch_point_to_surface(verts, info, gt, num=num, gt_index=gi)
+                loss.backward()
+                return loss.detach().clone(), verts.grad.clone()
+            with torch.no_grad():
+                return utils.batch_point_to_surface(verts, info, gt, num=num, gt_index=gi).clone(), None
+        finally:
+            ops.scan_finalize_tail = True
+
+    for seed in (21, 22, 23):
+        a, b = run(True, seed=seed), run(False, seed=seed)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    a, b = run(True, grad=False), run(False, grad=False)
+    assert torch.equal(a[0], b[0])
+    # captured: the trailing workgroups spin inside the replayed launch exactly as in the eager one
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run(True)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    ops.manual_seed(31)
+    verts.grad = None
+    with torch.cuda.graph(g):
+        loss = utils.batch_point_to_surface(verts, info, gt, num=num, gt_index=gi)
+        loss.backward()
+    want = None
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        got = (loss.detach().clone(), verts.grad.clone())
+        if want is None:
+            want = got
+    assert bool(torch.isfinite(want[0])) and bool(torch.isfinite(want[1]).all())
+    ops.manual_seed(0, gpu)

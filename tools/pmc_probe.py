@@ -37,5 +37,5 @@ for _ in range(4):
                                       o[2].data_ptr(), o[3].data_ptr(), nv, verts.data_ptr(), nf, faces.data_ptr(),
                                       tri_order.data_ptr(), o[4].data_ptr(), o[5].data_ptr(), o[6].data_ptr(), o[7].data_ptr(),
                                       o[8].data_ptr(), o[9].data_ptr(), uu.data_ptr(), vv.data_ptr(), 1.0, 1.0, order.data_ptr(),
-                                      0, ws.data_ptr(), ws_bytes, ctypes.byref(wrote), L.stream_ptr()), "scan")
+                                      0, ws.data_ptr(), ws_bytes, ctypes.byref(wrote), None, None, L.stream_ptr()), "scan")
     torch.cuda.synchronize()

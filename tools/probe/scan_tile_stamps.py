@@ -14,6 +14,7 @@ import bench                                   # noqa: E402
 from geometrics_amd import _lib, ops           # noqa: E402
 
 plain = "--plain" in sys.argv
+tail = "--tail" in sys.argv          # the finalize pass inside the launch (its role workgroups lead the grid)
 bench.CULLED_CHAMFER = not plain
 dev = torch.device("cuda:0")
 w = bench.Workload(dev, 0, 8)
@@ -28,13 +29,13 @@ with torch.no_grad():
             call()
             call = bench.fused_scan_call(w, pos, prep[3], _lib.FLAG_TRI_WS_READY, share=call)
         else:
-            call = bench.fused_scan_call(w, pos, prep[3], prep=prep)
+            call = bench.fused_scan_call(w, pos, prep[3], prep=prep, tail=tail)
         torch.cuda.synchronize()
         call()
         torch.cuda.synchronize()
 tri_tiles = 8 * ((bench.G_PTS + 63) // 64)
 nn_tiles = 2 * 8 * ((max(bench.G_PTS, bench.S_PTS) + 63) // 64)
-rows = tri_tiles + nn_tiles
+rows = tri_tiles + nn_tiles + (16 if tail else 0)
 buf = np.zeros((rows, 4), dtype=np.int64)
 _lib.check(L.geom_probe_read_scan_stamps(buf.ctypes.data, rows), "geom_probe_read_scan_stamps")
 buf = buf[buf[:, 1] > 0]
@@ -48,6 +49,18 @@ for k, name in ((0, "triangle tiles"), (1, "Chamfer tiles")):
     print("%-15s n %4d   duration us: median %5.1f  p10 %5.1f  p90 %5.1f  max %5.1f   start us: median %5.1f  p90 %5.1f  last %5.1f   last exit %5.1f"
           % (name, len(d), np.median(d), np.percentile(d, 10), np.percentile(d, 90), d.max(), np.median(s), np.percentile(s, 90), s.max(),
              end[kind == k].max()))
+if tail:
+    r = buf[kind == 2]
+    for row in r[np.argsort(r[:, 0])]:
+        print("role workgroup: entry %5.1f  wait over %5.1f  exit %5.1f us" % ((row[0] - t0) / 100.0, (row[3] - t0) / 100.0 if row[3] > 0 else -1, (row[1] - t0) / 100.0))
+    L.geom_probe_read_role_phases.argtypes = [ctypes.c_void_p]
+    rp = np.zeros((16, 16), dtype=np.int64)
+    _lib.check(L.geom_probe_read_role_phases(rp.ctypes.data), "geom_probe_read_role_phases")
+    print("# ordering roles, thread 0's clock (us from the launch's first entry): entry, LDS zeroed, samples binned, wait over, gt points "
+          "binned, offsets scanned, ids dropped, placed")
+    for row in rp:
+        if row[7] > 0:
+            print("   " + " ".join("%6.1f" % ((x - t0) / 100.0) for x in row[:8]))
 grid = np.arange(0.0, end.max(), 2.0)
 print("# tiles in flight (triangle / Chamfer) every 2 us:")
 print(" ".join("%d/%d" % (((start <= t) & (end > t) & (kind == 0)).sum(), ((start <= t) & (end > t) & (kind == 1)).sum()) for t in grid))

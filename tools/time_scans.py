@@ -77,7 +77,7 @@ def fused(flags=0, records=True):
                                       tri_order.data_ptr(), o[4].data_ptr(), o[5].data_ptr(), o[6].data_ptr(), o[7].data_ptr(),
                                       o[8].data_ptr(), o[9].data_ptr(), uu.data_ptr(), vv.data_ptr(), 1.0, 1.0,
                                       order.data_ptr() if records else None, flags, ws.data_ptr(), ws_bytes,
-                                      ctypes.byref(wrote), L.stream_ptr()), "scan")
+                                      ctypes.byref(wrote), None, None, L.stream_ptr()), "scan")
 
 
 print(f"fused scan (prep + NN/tri launch): {timeit(fused):.1f} us   without records {timeit(lambda: fused(0, False)):.1f} us   "
