@@ -56,8 +56,8 @@ __global__ __launch_bounds__(NN_THREADS) void chamfer_nn_kernel(NNJob job)
     const int longer = job.n > job.m ? job.n : job.m;
     int jobid, qtile;
     if (!geom::xcd_assign(blockIdx.x, 2 * job.b, (longer + NN_QUERIES - 1) / NN_QUERIES, jobid, qtile)) return;
-    const int dir = jobid / job.b;
-    const int mesh = jobid - dir * job.b;
+    const int dir = geom::nn_job_dir(jobid, job.b);
+    const int mesh = jobid % job.b;
     const int nq = dir ? job.m : job.n;
     const int nt = dir ? job.n : job.m;
     const int q0 = qtile * NN_QUERIES;

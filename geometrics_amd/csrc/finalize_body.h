@@ -76,11 +76,13 @@ __device__ __forceinline__ float block_sum_virtual(float (&v)[FIN_VIRTUAL / THRE
 struct FinalizeNoWait {
     __device__ __forceinline__ void operator()() const {}
 };
-template <bool REGS, int THREADS, typename Wait = FinalizeNoWait>
+// ITEMS: points per thread the REGS variant keeps in registers (per <= ITEMS * THREADS; beyond: the scratch variant).
+// READY: the caller guarantees a.records_ready (the code that forms records is left out: it is what made the register
+// variant spill inside the fused scan launch).
+template <bool REGS, int THREADS, typename Wait = FinalizeNoWait, int ITEMS = FIN_REG_POINTS / THREADS, bool READY = false>
 __device__ __forceinline__ void surface_finalize_body(const FinalizeArgs &a, int *ord_lds, const int block, Wait wait = Wait())
 {
     constexpr int WAVES = THREADS / GEOM_WAVE;
-    constexpr int ITEMS = FIN_REG_POINTS / THREADS; // points per thread kept in registers; beyond: through the pface / slot scratch
     constexpr int V = FIN_VIRTUAL / THREADS;
     int *off = ord_lds;                       // [nf+1]: counts, then offsets (ordering only)
     int *seg = off + (a.want_order ? a.nf + 1 : 0); // [per]
@@ -132,7 +134,7 @@ __device__ __forceinline__ void surface_finalize_body(const FinalizeArgs &a, int
         // record of point `id` -> global, its face counted in LDS; returns the face (-1: none) and the arrival slot
         auto bin_point = [&](int id, int &fi, int &sl) {
             int64_t f, sp = -1;
-            if (a.records_ready) { // the fused scan already wrote the record: only the face is needed here
+            if (READY || a.records_ready) { // the fused scan already wrote the record: only the face is needed here
                 if (id < a.num) f = a.choices[(int64_t)mesh * a.num + id];
                 else {
                     const int64_t o = (int64_t)mesh * a.n_gt + (id - a.num);
@@ -180,7 +182,7 @@ __device__ __forceinline__ void surface_finalize_body(const FinalizeArgs &a, int
                 if (id < a.per) bin_point(id, my_f[it], my_slot[it]);
             }
         } else if (REGS) {
-            const int early = a.records_ready ? a.num : 0; // ids below: nothing of the scans is read for them
+            const int early = READY || a.records_ready ? a.num : 0; // ids below: nothing of the scans is read for them
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
                 const int id = tid + it * THREADS;
@@ -196,7 +198,7 @@ __device__ __forceinline__ void surface_finalize_body(const FinalizeArgs &a, int
                 if (id >= early && id < a.per) bin_point(id, my_f[it], my_slot[it]);
             }
         } else {
-            const int early = a.records_ready ? a.num : 0;
+            const int early = READY || a.records_ready ? a.num : 0;
             auto bin_range = [&](int lo, int hi) {
                 for (int base = lo + tid; base < hi; base += SCRATCH_CH * THREADS) {
                     int fi[SCRATCH_CH], sl[SCRATCH_CH];
@@ -279,9 +281,25 @@ __device__ __forceinline__ void surface_finalize_body(const FinalizeArgs &a, int
             g_seg[s0 + rank] = id;
         };
         if (REGS) {
+            // segment bounds of all of a thread's ids first (2 * ITEMS LDS reads in flight), then id by id.  (One entry of
+            // EVERY id's segment per round, rounds = the longest segment: 7.5 us instead of 5 -- a crowded face makes all
+            // of its thread's ids wait.)
+            int s0[ITEMS], cnt[ITEMS];
 #pragma unroll
-            for (int it = 0; it < ITEMS; ++it)
-                if (my_f[it] >= 0) place(tid + it * THREADS, my_f[it]);
+            for (int it = 0; it < ITEMS; ++it) {
+                const int f = my_f[it] >= 0 ? my_f[it] : 0;
+                s0[it] = off[f];
+                cnt[it] = my_f[it] >= 0 ? off[f + 1] - s0[it] : 0;
+            }
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                if (cnt[it] == 0) continue;
+                const int id = tid + it * THREADS;
+                int rank = 0;
+                if (cnt[it] > 1) // a face that holds one point (most do): nothing to rank
+                    for (int j = 0; j < cnt[it]; ++j) rank += seg[s0[it] + j] < id ? 1 : 0;
+                g_seg[s0[it] + rank] = id;
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < ORD_CH; ++k)

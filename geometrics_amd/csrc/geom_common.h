@@ -105,4 +105,8 @@ __device__ __forceinline__ bool xcd_assign(int bid, int jobs, int tiles, int &jo
     return job < jobs;
 }
 
+// Job j of a two-directional NN scan over b meshes -> direction (0: cloud 1 queries cloud 2).  Direction 1 comes FIRST in the
+// grid: in the surface loss it is the sampled points' scan, the one the loss (and its in-launch finalize roles) waits for.
+__host__ __device__ __forceinline__ int nn_job_dir(int job, int b) { return 1 - job / b; }
+
 } // namespace geom

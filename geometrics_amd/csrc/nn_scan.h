@@ -59,8 +59,8 @@ __device__ __forceinline__ void nn_scalar_body(const NNJob &job, int bid, const 
     const int longer = job.n > job.m ? job.n : job.m;
     int jobid, qtile;
     if (!geom::xcd_assign(bid, 2 * job.b, (longer + NN_QUERIES - 1) / NN_QUERIES, jobid, qtile)) return;
-    const int dir = jobid / job.b;
-    const int mesh = jobid - dir * job.b;
+    const int dir = geom::nn_job_dir(jobid, job.b);
+    const int mesh = jobid % job.b;
     const int nq = dir ? job.m : job.n;
     const int nt = dir ? job.n : job.m;
     const int q0 = qtile * NN_QUERIES;
@@ -325,8 +325,8 @@ __device__ __forceinline__ void nn_culled_body(const NNJob &job, const NNCull &c
     const int longer = job.n > job.m ? job.n : job.m;
     int jobid, qtile;
     if (!geom::xcd_assign(bid, 2 * job.b, (longer + NN_QUERIES - 1) / NN_QUERIES, jobid, qtile)) return;
-    const int dir = jobid / job.b;
-    const int mesh = jobid - dir * job.b;
+    const int dir = geom::nn_job_dir(jobid, job.b);
+    const int mesh = jobid % job.b;
     const int nq = dir ? job.m : job.n;
     const int nt = dir ? job.n : job.m;
     const int q0 = qtile * NN_QUERIES;

@@ -713,7 +713,7 @@ struct SurfaceOut {
 constexpr SurfaceOut NO_SURFACE{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f, 0, 0};
 
 constexpr int TAIL_CTR_STRIDE = 32;
-__host__ __device__ inline int tail_counters(int b) { return 3 * b + 1; }
+__host__ __device__ inline int tail_counters(int b) { return 2 * b + 1; }
 // whether the merged-keys region of a workspace (b * n * 8 bytes) holds the counters
 __host__ __device__ inline bool tail_counters_fit(int b, int n) { return (int64_t)tail_counters(b) * TAIL_CTR_STRIDE * 4 <= (int64_t)b * n * 8; }
 
@@ -733,10 +733,10 @@ __device__ __forceinline__ void tri_prep_grouped_body(const TriJob &job, const T
 {
     // the tile-completion counters of the fused scan's finalize tail (ScanTail, tail_counters(b) lines of 128 bytes) live in
     // the merged-keys region, which a scan without triangle split never touches: zero before every scan that follows a prep
-    if (ws.split == 1 && j < 4 && tail_counters_fit(job.b, job.n)) {
+    if (ws.split == 1 && j < 3 && tail_counters_fit(job.b, job.n)) {
         int *done = reinterpret_cast<int *>(ws.keys);
-        const int which = j == 0 ? mesh : j == 1 ? job.b + 2 * mesh : j == 2 ? job.b + 2 * mesh + 1 : 3 * job.b;
-        if (j < 3 || mesh == 0) done[(size_t)which * TAIL_CTR_STRIDE] = 0;
+        const int which = j == 0 ? mesh : j == 1 ? job.b + mesh : 2 * job.b;
+        if (j < 2 || (j == 2 && mesh == 0)) done[(size_t)which * TAIL_CTR_STRIDE] = 0;
     }
     if (ws.split > 1 && j < job.n) ws.keys[(size_t)mesh * job.n + j] = KEY_NONE;
     if (j >= ws.m_pad) return; // m_pad is a multiple of 64: whole waves leave together
@@ -1159,8 +1159,9 @@ struct ScanTail {
 constexpr int SCAN_TAIL_LDS_INTS = 11776; // 46 KB: three workgroups per CU still fit (the BASELINE mesh needs 11 173)
 
 // Completion counters (TAIL_CTR_STRIDE, tail_counters()), ONE 128-byte line each (every tile's sign-off is a memory-side atomic; 2 256 of them plus the
-// pollers on one line slowed every tile of the launch by ~15 %): [0, b) triangle tiles of mesh i; [b, 3b) Chamfer tiles of
-// job j (direction x mesh); [3b] ordering roles that are past their wait (the loss role's stand-in for the triangle tiles).
+// pollers on one line slowed every tile of the launch by ~15 %): [0, b) triangle tiles of mesh i; [b, 2b) the Chamfer tiles of
+// mesh i whose queries are the sampled points (the other direction's results are read by nobody inside the launch);
+// [2b] ordering roles that are past their wait (the loss role's stand-in for the triangle tiles).
 
 // which counter a tile signs (-1: a padding workgroup) -- computed in front of the tile's body so that ONE register lives
 // across it (the geometry this takes -- b, n, the tile counts -- pushed scalar registers of the brute-force Chamfer loop
@@ -1169,7 +1170,8 @@ __device__ __forceinline__ int scan_tile_counter(int bid, int tri_blocks, int b,
 {
     int job, tile;
     if (bid < tri_blocks) return geom::xcd_assign(bid, b, (n + TRI_QUERIES - 1) / TRI_QUERIES, job, tile) ? job : -1;
-    return geom::xcd_assign(bid - tri_blocks, 2 * b, nn_tiles, job, tile) ? b + job : -1;
+    // Chamfer tiles: only the direction the loss needs (the sampled points' squared distances) is counted
+    return geom::xcd_assign(bid - tri_blocks, 2 * b, nn_tiles, job, tile) && geom::nn_job_dir(job, b) == 1 ? b + job % b : -1;
 }
 
 __device__ __forceinline__ void scan_tile_done(int *done, int counter)
@@ -1208,10 +1210,10 @@ struct ScanTailWait {
             if (role < b) { // mesh `role`'s triangle tiles; then tell the loss role
                 tail_wait_counters(done, role, 1, expect_mesh);
                 if (threadIdx.x == 0)
-                    __hip_atomic_fetch_add(done + (size_t)3 * b * TAIL_CTR_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(done + (size_t)2 * b * TAIL_CTR_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {        // every tile: the Chamfer jobs, and the triangle tiles directly or through their ordering roles
-                tail_wait_counters(done, b, 2 * b, expect_job);
-                if (ordering) tail_wait_counters(done, 3 * b, 1, b);
+                tail_wait_counters(done, b, b, expect_job);
+                if (ordering) tail_wait_counters(done, 2 * b, 1, b);
                 else tail_wait_counters(done, 0, b, expect_mesh);
             }
         }
@@ -1232,9 +1234,11 @@ __device__ __forceinline__ void scan_tail_role(const ScanTail &t, int role, int 
     const int b = t.fin.b;
     const bool loss_role = role == t.roles - 1;
     const ScanTailWait wait{t.done, loss_role ? b : role, b, t.roles > 1, t.expect_mesh, t.expect_job};
-    // the variant that keeps the points' faces / arrival slots in the global scratch, not in registers: 16 points per thread
-    // do not fit this launch's 80-register budget (built: 2 454 spilled registers, 55 us to bin 3000 points)
-    geom_finalize::surface_finalize_body<false, 8 * GEOM_WAVE>(t.fin, lds_ints, loss_role ? b : role, wait);
+    // the variant that keeps the points' faces / arrival slots in the global scratch (loads batched 6-12 deep), the
+    // record-forming code compiled out.  The register variant does not survive this launch's budget of 80 registers: with 16
+    // points per thread it spilled 2 454 registers (55 us to bin 3000 points), with 12 and the lean binning code it fitted in
+    // one build (12.4 -> 13 us behind the wait: no gain) and spilled again in the next (20 us to bin, 70 us launch)
+    geom_finalize::surface_finalize_body<false, 8 * GEOM_WAVE, ScanTailWait, 16, true>(t.fin, lds_ints, loss_role ? b : role, wait);
 }
 
 // CULL: the Chamfer tiles take the culled scan (nn_culled_body).  Its tiles are latency chains, not issue-bound loops, so
