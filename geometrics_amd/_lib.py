@@ -201,6 +201,8 @@ def lib():
         L.geom_nn_cull_index_floats.argtypes = [_i, _i]
         L.geom_tri_distance_workspace_bytes.restype = ctypes.c_size_t
         L.geom_tri_distance_workspace_bytes.argtypes = [_i, _i, _i]
+        L.geom_surface_tail_counters_offset.restype = ctypes.c_size_t
+        L.geom_surface_tail_counters_offset.argtypes = [_i, _i, _i]
         for name, args in _SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args
@@ -215,7 +217,7 @@ def declared_symbols():
                    "geom_segment_max_workspace_bytes", "geom_zn_gcn_relu_mask_words",
                    "geom_surface_bin_count_words", "geom_surface_bin_list_words", "geom_surface_order_words",
                    "geom_dense_bwd_weight_workspace_floats", "geom_chamfer_nn_culled_workspace_floats",
-                   "geom_nn_cull_index_floats"] + list(_SIGNATURES))
+                   "geom_nn_cull_index_floats", "geom_surface_tail_counters_offset"] + list(_SIGNATURES))
 
 
 def check(code, what):

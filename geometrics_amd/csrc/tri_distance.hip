@@ -1185,36 +1185,51 @@ __device__ __forceinline__ void scan_tile_done(int *done, int counter)
 }
 
 // wave 0 of a role workgroup: lane i < count polls counter first + i until it reaches its target, all lanes together (a
-// counter that is already there costs no round trip of its own), then resets it for the next launch on this workspace
-__device__ __forceinline__ void tail_wait_counters(int *done, int first, int count, int expect)
+// counter that is already there costs no round trip of its own), then resets it for the next launch on this workspace.
+// Returns the largest count seen, or -1 when TAIL_SPIN_LIMIT polls (seconds) went by: a role never hangs the device -- it
+// gives up, and the launch's loss comes out as NaN (scan_tail_role).
+constexpr int TAIL_SPIN_LIMIT = 1 << 21;
+constexpr int TAIL_GAVE_UP = 1 << 20; // added to the ordering roles' count by a role that gave up
+__device__ __forceinline__ int tail_wait_counters(int *done, int first, int count, int expect)
 {
+    int seen = 0;
     for (int c0 = 0; c0 < count; c0 += GEOM_WAVE) {
         const int i = c0 + (int)threadIdx.x;
         int *ctr = done + (size_t)(first + i) * TAIL_CTR_STRIDE;
         bool ok = i >= count;
+        int mine = 0, polls = 0;
         while (true) {
-            if (!ok) ok = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= expect;
+            if (!ok) {
+                mine = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = mine >= expect;
+            }
             if (__all(ok)) break;
+            if (++polls > TAIL_SPIN_LIMIT) return -1;
             __builtin_amdgcn_s_sleep(32);
         }
         if (i < count) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int d = GEOM_WAVE / 2; d > 0; d >>= 1) mine = max(mine, __shfl_xor(mine, d, GEOM_WAVE));
+        seen = max(seen, mine);
     }
+    return seen;
 }
 
 struct ScanTailWait {
     int *done;
+    int *poison; // LDS: set by the loss role when it, or an ordering role, gave up waiting
     int role, b, ordering, expect_mesh, expect_job; // role == b: the loss role
     __device__ __forceinline__ void operator()() const
     {
         if (threadIdx.x < GEOM_WAVE) {
+            int *roles_past = done + (size_t)2 * b * TAIL_CTR_STRIDE;
             if (role < b) { // mesh `role`'s triangle tiles; then tell the loss role
-                tail_wait_counters(done, role, 1, expect_mesh);
+                const int got = tail_wait_counters(done, role, 1, expect_mesh);
                 if (threadIdx.x == 0)
-                    __hip_atomic_fetch_add(done + (size_t)2 * b * TAIL_CTR_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {        // every tile: the Chamfer jobs, and the triangle tiles directly or through their ordering roles
-                tail_wait_counters(done, b, b, expect_job);
-                if (ordering) tail_wait_counters(done, 2 * b, 1, b);
-                else tail_wait_counters(done, 0, b, expect_mesh);
+                    __hip_atomic_fetch_add(roles_past, got < 0 ? TAIL_GAVE_UP + 1 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {        // the Chamfer tiles whose distances are summed, and the triangle tiles directly or through their ordering roles
+                int got = tail_wait_counters(done, b, b, expect_job);
+                if (got >= 0) got = ordering ? tail_wait_counters(done, 2 * b, 1, b) : tail_wait_counters(done, 0, b, expect_mesh);
+                if (threadIdx.x == 0) *poison = got < 0 || got >= TAIL_GAVE_UP;
             }
         }
         __syncthreads();
@@ -1233,12 +1248,17 @@ __device__ __forceinline__ void scan_tail_role(const ScanTail &t, int role, int 
     if (role >= t.roles) return; // padding (the tile workgroups keep their blockIdx % 8 = XCD mapping)
     const int b = t.fin.b;
     const bool loss_role = role == t.roles - 1;
-    const ScanTailWait wait{t.done, loss_role ? b : role, b, t.roles > 1, t.expect_mesh, t.expect_job};
+    int *poison = lds_ints + SCAN_TAIL_LDS_INTS - 1; // behind what the body uses (the host leaves this int free)
+    const ScanTailWait wait{t.done, poison, loss_role ? b : role, b, t.roles > 1, t.expect_mesh, t.expect_job};
     // the variant that keeps the points' faces / arrival slots in the global scratch (loads batched 6-12 deep), the
     // record-forming code compiled out.  The register variant does not survive this launch's budget of 80 registers: with 16
     // points per thread it spilled 2 454 registers (55 us to bin 3000 points), with 12 and the lean binning code it fitted in
     // one build (12.4 -> 13 us behind the wait: no gain) and spilled again in the next (20 us to bin, 70 us launch)
     geom_finalize::surface_finalize_body<false, 8 * GEOM_WAVE, ScanTailWait, 16, true>(t.fin, lds_ints, loss_role ? b : role, wait);
+    if (loss_role) { // a wait that gave up: the results the loss was summed from are not all there -- say so
+        __syncthreads();
+        if (threadIdx.x == 0 && *poison) t.fin.loss[0] = __builtin_nanf("");
+    }
 }
 
 // CULL: the Chamfer tiles take the culled scan (nn_culled_body).  Its tiles are latency chains, not issue-bound loops, so
@@ -1427,6 +1447,16 @@ extern "C" int geom_tri_distance_indexed_f32(int b, int n, const float *xyz, int
     return launch_tri<true>(job, flags, stream);
 }
 
+// where the finalize tail's completion counters sit in a workspace of geom_tri_distance_workspace_bytes(b, n, m) bytes
+// (int32 words, 32 apart: [0, b) triangle tiles per mesh, [b, 2b) Chamfer tiles per mesh, [2b] ordering roles) -- for tests
+// that provoke the roles' give-up path; 0 when the counters do not fit (no tail for such a call)
+extern "C" size_t geom_surface_tail_counters_offset(int b, int n, int m)
+{
+    if (b <= 0 || n <= 0 || m <= 0 || !tail_counters_fit(b, n)) return 0;
+    const int m_pad = ws_pad(m);
+    return ((size_t)b * m_pad * 4 + (size_t)b * (m_pad / GRP) + (size_t)b * 3) * sizeof(float4);
+}
+
 extern "C" size_t geom_tri_distance_workspace_bytes(int b, int n, int m)
 {
     if (b <= 0 || m <= 0 || n < 0) return 0;
@@ -1563,7 +1593,7 @@ extern "C" int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, 
             if (tail && culled) { // the launch with the culled Chamfer tiles only (three workgroups per CU, latency-bound tiles)
                 const int64_t per64 = (int64_t)num + n_gt;
                 if (per64 <= 0x3fffffff && tail_counters_fit(b, n_gt) &&
-                    geom_finalize::finalize_lds_ints(nf, (int)per64, 8 * GEOM_WAVE, tail->want_order != 0) <= (size_t)SCAN_TAIL_LDS_INTS) {
+                    geom_finalize::finalize_lds_ints(nf, (int)per64, 8 * GEOM_WAVE, tail->want_order != 0) < (size_t)SCAN_TAIL_LDS_INTS) {
                     int *off = order_scratch, *seg = off ? off + (int64_t)b * (nf + 1) : nullptr;
                     int *pface = seg ? seg + (int64_t)b * cap : nullptr, *slot = pface ? pface + (int64_t)b * cap : nullptr;
                     st.fin = geom_finalize::FinalizeArgs{tail->choices, u, v, points, gt, idx_g, nullptr, index, closest, weights, sq_pred, sq,

@@ -1458,3 +1458,32 @@ def test_finalize_tail_of_the_scan_launch_equals_the_separate_launch(gpu, culled
             want = got
     assert bool(torch.isfinite(want[0])) and bool(torch.isfinite(want[1]).all())
     ops.manual_seed(0, gpu)
+
+
+def test_finalize_roles_give_up_instead_of_hanging(gpu):
+    """A role workgroup of the fused scan launch waits on a completion counter; if the count can never be reached (here: a
+    counter knocked 100 below zero between the prepare launch and the scan) it gives up after ~2 M polls and the launch's
+    loss comes out as NaN -- the device is not hung, and the next call (fresh workspace) is fine."""
+    import time
+    from geometrics_amd import _lib
+    V, Fc = meshgen.icosphere(4)
+    B, num = 8, 3000
+    verts = dev(meshgen.jittered_batch(V, B), gpu)
+    faces, gt = dev(Fc, gpu), dev(meshgen.gt_cloud(B, num), gpu)
+    gi = ops.GtIndex(gt)
+    off = _lib.lib().geom_surface_tail_counters_offset(B, num, Fc.shape[0])
+    assert off > 0 and off % 4 == 0
+    ops.manual_seed(9)
+    d = ops.draw_samples(verts, faces, num, with_points=True, prepare_scan_for=num, gt_index=gi)
+    assert isinstance(d[4], ops.ScanPrep)
+    counters = d[4].tri_ws.view(torch.int32)[off // 4:]
+    assert int(counters[::32][:2 * B + 1].abs().sum()) == 0          # zeroed by the prepare launch
+    counters[3 * 32] = -100                                          # mesh 3's triangle tiles can never reach their count
+    torch.cuda.synchronize()
+    t0 = time.time()
+    loss, _, _ = ops.SurfaceLoss.apply(verts, faces, gt, d[0], d[1], d[2], False, 3000.0, d[3], d[4], None, gi)
+    assert bool(torch.isnan(loss))                                   # said loudly
+    assert time.time() - t0 < 60
+    ops.manual_seed(9)
+    assert bool(torch.isfinite(utils.batch_point_to_surface(verts, {"faces": faces}, gt, num=num, gt_index=gi)))
+    ops.manual_seed(0, gpu)
