@@ -126,7 +126,7 @@ class SurfaceCull(ctypes.Structure):
 
 
 class SurfaceTail(ctypes.Structure):
-    """struct geom_surface_tail (include/geom_hip.h): the finalize pass as trailing workgroups of the fused scan launch."""
+    """struct geom_surface_tail (include/geom_hip.h): the finalize pass as extra (role) workgroups of the fused scan launch."""
     _fields_ = [("choices", ctypes.c_void_p), ("scale_sample", ctypes.c_float), ("scale_other", ctypes.c_float),
                 ("want_order", ctypes.c_int), ("loss", ctypes.c_void_p), ("finalized", ctypes.c_int)]
 

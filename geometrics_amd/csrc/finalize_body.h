@@ -1,5 +1,5 @@
 // The forward-side FINALIZE body of the surface loss (see surface_gather.hip for what it does and why): shared by the
-// stand-alone launch (surface_finalize_kernel, 1024 threads) and by the trailing workgroups of the fused surface scan
+// stand-alone launch (surface_finalize_kernel, 1024 threads) and by the role workgroups of the fused surface scan
 // (tri_distance.hip: surface_scan_kernel, 512 threads).  THREADS is the workgroup size; the RESULTS do not depend on it:
 //   * the loss is summed by 1024 VIRTUAL threads (a physical thread runs 1024 / THREADS of them) and folded by the same
 //     tree -- same bits from either workgroup shape;
@@ -71,7 +71,7 @@ __device__ __forceinline__ float block_sum_virtual(float (&v)[FIN_VIRTUAL / THRE
 // block = the workgroup's role: [0, b) orders mesh `block`, b reduces the loss (want_order = 0: the loss role only).
 // ord_lds: (nf + 1 + per + THREADS / 64 + 4) ints + 2 * FIN_VWAVES floats (finalize_lds_ints()).
 // wait(): called by every thread of the workgroup (uniformly) in front of the first read of anything the scans of the
-// SAME launch produce -- the stand-alone launch passes a no-op, the fused scan's trailing workgroups their counter wait.
+// SAME launch produce -- the stand-alone launch passes a no-op, the fused scan's role workgroups their counter wait.
 // With ready records the sampled points (their faces are the draws: known before the scans) are binned in front of it.
 struct FinalizeNoWait {
     __device__ __forceinline__ void operator()() const {}

@@ -194,7 +194,7 @@ class ScanPrep:
         self.tri_ws, self.sample_index = tri_ws, sample_index
 
 
-# The finalize pass of the one-sided surface loss as trailing workgroups of the fused scan launch (csrc/tri_distance.hip:
+# The finalize pass of the one-sided surface loss as extra (role) workgroups of the fused scan launch (csrc/tri_distance.hip:
 # ScanTail) instead of a launch of its own; same outputs bit for bit.  False: always the separate launch (the A/B switch).
 scan_finalize_tail = True
 
@@ -279,7 +279,7 @@ class SurfaceLoss(torch.autograd.Function):
                 tri_args = (nv, verts_c.data_ptr(), nf, faces.data_ptr(), _lib.ptr(tri_order), tri_d.data_ptr(),
                             option.data_ptr(), index.data_ptr(), sq.data_ptr(), closest.data_ptr(), weights.data_ptr())
                 ws_ptr, ws_len = ws.data_ptr(), ws_bytes
-            # one-sided loss: the finalize pass (below) rides in the scan launch as trailing workgroups where the launch is
+            # one-sided loss: the finalize pass (below) rides in the scan launch as extra (role) workgroups where the launch is
             # the fused one and a mesh's faces + points fit its LDS (tail.finalized says so): each mesh is ordered as soon
             # as ITS triangle tiles are through instead of in a launch of its own behind the slowest tile
             tail = None

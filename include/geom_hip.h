@@ -457,7 +457,7 @@ int geom_surface_prepare_f32(int b, int nv, const float *verts, int nf, const in
  * finalize) and *records_written = 1; the variants that cannot (split query tiles, brute force, tail truncation)
  * leave *records_written = 0 and the finalize pass forms the records itself.
  * tail (may be NULL): also run geom_surface_finalize_f32's work -- loss = scale_sample * sum(sq_pred) + scale_other *
- * sum(sq) into *loss and, with want_order, the points ordered by face in order_scratch -- as trailing workgroups of the
+ * sum(sq) into *loss and, with want_order, the points ordered by face in order_scratch -- as extra (role) workgroups of the
  * fused launch (each mesh is ordered as soon as ITS triangle tiles are through, the loss is summed behind the last tile)
  * instead of a launch of its own: same outputs, bit for bit.  tail->finalized = 1 when the launch did it (fused route
  * with the culled Chamfer tiles, nf + num + n_gt <= ~11 700 per mesh); 0: call geom_surface_finalize_f32 as usual. */
