@@ -105,7 +105,9 @@ def batch_point_to_point(pred_vert, adj_info, gt_points, num=1000, f1=False, dra
 def batch_point_to_surface(pred_vert, adj_info, gt_points, num=1000, f1=False, draws=None, loss_out=None, gt_index=None):
     """Chamfer (prediction -> gt) + point-to-surface (gt -> mesh) loss (reference utils.py:441-502); `draws`, `loss_out`
     as for batch_point_to_point.  gt_index (optional, an ops.GtIndex built once for `gt_points`): the Chamfer tiles take
-    the culled scan -- same loss, same gradients, bit for bit."""
+    the culled scan and the draw launch generates the samples in face-visiting order (other, equally distributed draws than
+    without the index: sorted uniforms from exponential spacings); on the same draws loss and gradients are those of the plain
+    route, bit for bit (tests/test_ops_parity_gpu.py)."""
     return _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, False, loss_out, gt_index)
 
 
