@@ -28,6 +28,7 @@ constexpr int FIN_VWAVES = FIN_VIRTUAL / GEOM_WAVE;
 constexpr int FIN_REG_POINTS = 8192;            // points per mesh the REGS variant keeps in registers
 constexpr int SCRATCH_CH = 6;                   // the scratch variant: ids per thread whose loads are in flight together (binning)
 constexpr int ORD_CH = 12;                      // ... in the two ordering passes
+constexpr int GROUP_LOOKBACK = 64;              // longest run of one face's samples a role looks back over (beyond: ranking pass)
 
 __device__ __forceinline__ V3 ld3(const float *p) { return geom::mk(p[0], p[1], p[2]); }
 
@@ -174,6 +175,7 @@ __device__ __forceinline__ void surface_finalize_body(const FinalizeArgs &a, int
         };
         int my_f[ITEMS > ORD_CH ? ITEMS : ORD_CH], my_slot[ITEMS];
         constexpr bool NO_WAIT = std::is_same<Wait, FinalizeNoWait>::value;
+        int *ungrouped = wave_total + WAVES + 1; // one of the 4 spare ints behind the wave totals (scratch variant of a role)
         if (REGS && NO_WAIT) {
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
@@ -213,6 +215,25 @@ __device__ __forceinline__ void surface_finalize_body(const FinalizeArgs &a, int
                 }
             };
             bin_range(0, early);
+            // A role workgroup has time in front of its wait.  When a face's sampled points have CONSECUTIVE ids (the
+            // culled route generates them in face-visiting order), a sample's final place inside its face's segment is
+            // its distance to the first id of its run: found here by looking back, packed into the upper half of its slot
+            // word, so that behind the wait only the gt points have to be ranked (5.1 -> 2.x us).  Checked, not assumed:
+            // the last id of every run must see run length == the face's count, else everything takes the ranking pass.
+            if (!NO_WAIT && early > 0) {
+                if (tid == 0) *ungrouped = 0;
+                __syncthreads(); // every sample is counted
+                const int64_t *face_of = a.choices + (int64_t)mesh * a.num;
+                for (int id = tid; id < early; id += THREADS) {
+                    const int64_t f = face_of[id];
+                    if (f < 0 || f >= a.nf) continue;
+                    int r = 0;
+                    while (r < GROUP_LOOKBACK && id - r - 1 >= 0 && face_of[id - r - 1] == f) ++r;
+                    const bool run_ends = id + 1 == early || face_of[id + 1] != f;
+                    if (r == GROUP_LOOKBACK || (run_ends && r + 1 != off[(int)f])) *ungrouped = 1;
+                    a.slot[p0 + id] |= r << 16; // arrival slot (< 65 536: per fits the launch's LDS) below, run position above
+                }
+            }
             FIN_PHASE(2);
             wait();
             FIN_PHASE(3);
@@ -245,6 +266,7 @@ __device__ __forceinline__ void surface_finalize_body(const FinalizeArgs &a, int
         int *g_off = a.off + (int64_t)mesh * (a.nf + 1);
         for (int f = tid; f <= a.nf; f += THREADS) g_off[f] = off[f];
         // ---- ids at offset + slot, then ranked into ascending order ----
+        int placed_below = 0; // ids below: their final place was found in front of the wait (grouped samples of a role)
         if (REGS) {
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it)
@@ -252,6 +274,8 @@ __device__ __forceinline__ void surface_finalize_body(const FinalizeArgs &a, int
         } else {
             // ORD_CH ids per thread and round: their faces / slots requested together (one L2 round trip per round); the
             // first round's faces stay in registers for the ranking pass below
+            placed_below = !NO_WAIT && (READY || a.records_ready) && a.num > 0 && *ungrouped == 0 ? a.num : 0;
+            int *g_place = a.seg + p0;
             for (int base = tid, round = 0; base < a.per; base += ORD_CH * THREADS, ++round) {
                 int f[ORD_CH], sl[ORD_CH];
 #pragma unroll
@@ -262,7 +286,13 @@ __device__ __forceinline__ void surface_finalize_body(const FinalizeArgs &a, int
                 }
 #pragma unroll
                 for (int k = 0; k < ORD_CH; ++k) {
-                    if (f[k] >= 0) seg[off[f[k]] + sl[k]] = base + k * THREADS;
+                    const int id = base + k * THREADS;
+                    if (f[k] >= 0) {
+                        const bool final_place = id < placed_below;
+                        const int at = off[f[k]] + (final_place ? sl[k] >> 16 : sl[k] & 0xffff);
+                        seg[at] = id; // samples too: the gt points of the face are ranked against the whole segment
+                        if (final_place) g_place[at] = id, f[k] = -1;
+                    }
                     if (round == 0) my_f[k] = f[k];
                 }
             }
@@ -310,7 +340,7 @@ __device__ __forceinline__ void surface_finalize_body(const FinalizeArgs &a, int
                 for (int k = 0; k < ORD_CH; ++k) f[k] = base + k * THREADS < a.per ? a.pface[p0 + base + k * THREADS] : -1;
 #pragma unroll
                 for (int k = 0; k < ORD_CH; ++k)
-                    if (f[k] >= 0) place(base + k * THREADS, f[k]);
+                    if (f[k] >= 0 && base + k * THREADS >= placed_below) place(base + k * THREADS, f[k]);
             }
         }
         FIN_PHASE(7);
