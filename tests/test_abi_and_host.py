@@ -125,7 +125,8 @@ def test_layer_parameter_names_and_shapes():
     assert list(dict(layers.BatchZERON_GCN(7, 20).named_parameters())) == ["weight", "bias"]
     p = dict(layers.Batch_Image_ZERON_GCNGCN(963, 192).named_parameters())
     assert list(p) == ["weight1", "bias"] and tuple(p["weight1"].shape) == (1, 963, 192)
-    assert float(p["weight1"].abs().max()) <= 0.3 * 6 / (964 ** 0.5) and float(p["bias"].abs().max()) <= 0.1
+    # (1 + 1e-6): uniform_(-b, b) draws in fp32 and may return fp32(b), one rounding above the double b (seen once in ~30 runs)
+    assert float(p["weight1"].detach().abs().max()) <= 0.3 * 6 / (964 ** 0.5) * (1 + 1e-6) and float(p["bias"].detach().abs().max()) <= 0.1 * (1 + 1e-6)
     for cls in (layers.GCNMax, layers.BatchGCNMax):
         assert list(dict(cls(30, 50).named_parameters())) == ["weight_Ws.0", "weight_Bs.0"]
     assert layers.ZERON_GCN(7, 20, bias=False).bias is None
