@@ -1156,6 +1156,19 @@ struct ScanTail {
     int expect_mesh; // triangle tiles per mesh
     int expect_job;  // Chamfer tiles per (direction, mesh)
 };
+// b + 1 role workgroups lead the launch and wait on slots the tiles need too: at most a quarter of a slot per CU goes to them
+// (64 meshes on the 256 CUs of an MI355X; a partition with fewer CUs takes fewer)
+inline int scan_tail_max_meshes()
+{
+    static int most = 0;
+    if (!most) {
+        int dev = 0, cus = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        most = cus >= 8 ? cus / 4 : 1;
+    }
+    return most;
+}
 constexpr int SCAN_TAIL_LDS_INTS = 11776; // 46 KB: three workgroups per CU still fit (the BASELINE mesh needs 11 173)
 
 // Completion counters (TAIL_CTR_STRIDE, tail_counters()), ONE 128-byte line each (every tile's sign-off is a memory-side atomic; 2 256 of them plus the
@@ -1592,7 +1605,9 @@ extern "C" int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, 
             if (tail && (!tail->loss || !tail->choices || (tail->want_order && !rec))) return GEOM_EINVAL;
             if (tail && culled) { // the launch with the culled Chamfer tiles only (three workgroups per CU, latency-bound tiles)
                 const int64_t per64 = (int64_t)num + n_gt;
-                if (per64 <= 0x3fffffff && tail_counters_fit(b, n_gt) &&
+                // (b <= scan_tail_max_meshes(): the roles wait from the start of the launch on slots the tiles need too -- a few
+                // dozen of 768 cost nothing, hundreds would crowd the tiles out; larger batches finalize in a launch of their own)
+                if (per64 <= 0x3fffffff && b <= scan_tail_max_meshes() && tail_counters_fit(b, n_gt) &&
                     geom_finalize::finalize_lds_ints(nf, (int)per64, 8 * GEOM_WAVE, tail->want_order != 0) < (size_t)SCAN_TAIL_LDS_INTS) {
                     int *off = order_scratch, *seg = off ? off + (int64_t)b * (nf + 1) : nullptr;
                     int *pface = seg ? seg + (int64_t)b * cap : nullptr, *slot = pface ? pface + (int64_t)b * cap : nullptr;

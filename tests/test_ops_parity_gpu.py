@@ -1311,12 +1311,13 @@ def test_culled_chamfer_tiles_inside_the_surface_step(gpu):
 
 
 @pytest.mark.parametrize("level,B,num,n_gt,sorted_route", [(2, 32, 64, 512, True), (3, 6, 1000, 2750, True), (4, 2, 4095, 8200, True),
-                                                          (2, 7, 1531, 2466, True), (3, 6, 4096, 2750, False), (2, 40, 63, 448, False),
+                                                          (2, 7, 1531, 2466, True), (2, 80, 64, 256, True), (3, 6, 4096, 2750, False), (2, 40, 63, 448, False),
                                                           (2, 2, 500, 500, False)])
 def test_sorted_draws_at_ragged_sizes(gpu, level, B, num, n_gt, sorted_route):
     """The visiting-order generation at the ends of its range (64 <= num < 4096 samples, and a step large enough for the
     fused scan route: >= 256 query tiles; outside, the draw launch falls back to independent draws and the scan to
-    brute-force Chamfer tiles), small meshes, gt clouds of another size than the sample count:
+    brute-force Chamfer tiles), small meshes, gt clouds of another size than the sample count, more meshes than the scan
+    launch takes finalize roles for (64):
     samples in visiting order, every face valid, and loss / distances / gradient bit-identical to the brute-force tiles on
     the same samples."""
     from geometrics_amd.tri_distance import face_order
