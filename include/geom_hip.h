@@ -460,7 +460,8 @@ int geom_surface_prepare_f32(int b, int nv, const float *verts, int nf, const in
  * sum(sq) into *loss and, with want_order, the points ordered by face in order_scratch -- as extra (role) workgroups of the
  * fused launch (each mesh is ordered as soon as ITS triangle tiles are through, the loss is summed behind the last tile)
  * instead of a launch of its own: same outputs, bit for bit.  tail->finalized = 1 when the launch did it (fused route
- * with the culled Chamfer tiles, nf + num + n_gt <= ~11 700 per mesh); 0: call geom_surface_finalize_f32 as usual. */
+ * with the culled Chamfer tiles, nf + num + n_gt <= ~11 700 per mesh, at most (CUs / 4) meshes); 0: call
+ * geom_surface_finalize_f32 as usual.  A role that waits in vain gives up after ~2 s and *loss comes out as NaN. */
 size_t geom_surface_tail_counters_offset(int b, int n_gt, int nf); /* byte offset of the tail's completion counters in the
                                                                      * scan workspace (tests of the give-up path); 0: none */
 typedef struct geom_surface_tail {
