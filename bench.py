@@ -868,8 +868,6 @@ def main():
     ap.add_argument("--plain-chamfer", action="store_true", help="brute-force Chamfer tiles instead of the culled scan (same results)")
     ap.add_argument("--separate-finalize", action="store_true", help="the surface loss's finalize pass as a launch of its own instead of "
                     "extra workgroups of the scan launch (same results; the A/B switch of ops.scan_finalize_tail)")
-    ap.add_argument("--riders", action="store_true", help="the first layer's split launch carries the reductions that are already due "
-                    "(same results; layers.carry_due_reductions, measured in profiles/r04_riders.txt and off by default)")
     ap.add_argument("--launch", choices=("graph", "eager"), default="graph",
                     help="replay the whole step as one HIP graph (default) or launch eagerly from python")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-stage event-timed breakdown")
@@ -881,9 +879,6 @@ def main():
     CULLED_CHAMFER = not args.plain_chamfer
     if args.separate_finalize:
         ops.scan_finalize_tail = False
-    if args.riders:
-        from geometrics_amd import layers as _layers
-        _layers.carry_due_reductions = True
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")

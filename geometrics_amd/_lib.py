@@ -16,7 +16,7 @@ FLAG_FIX_REGION6 = 2
 FLAG_TRI_BRUTE_FORCE = 4
 FLAG_NN_FMA = 8
 FLAG_TRI_WS_READY = 16
-ABI_VERSION = 7
+ABI_VERSION = 8
 EUNSUPPORTED = -3
 ADAM_MAX_TENSORS = 64
 COLSUM_MAX_JOBS = 32
@@ -105,7 +105,6 @@ _SIGNATURES = {
     "geom_dense_bwd_input_f32": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "geom_dense_bwd_weight_f32": [_i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "geom_dense_bwd_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
-    "geom_dense_bwd_weight_riders_f32": [_i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_dense_reduce2_f32": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_dense_reduce_adam_f32": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f,
                                    _vp, _vp],
@@ -116,6 +115,8 @@ _SIGNATURES = {
     "geom_zn_gcn_aggregate_ell_head_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp],
     "geom_zn_gcn_aggregate_ell_head_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp],
     "geom_zn_gcn_aggregate_bwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "geom_zn_layer_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "geom_zn_layer_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp],
 }
 
 
@@ -201,6 +202,8 @@ def lib():
         L.geom_nn_cull_index_floats.argtypes = [_i, _i]
         L.geom_tri_distance_workspace_bytes.restype = ctypes.c_size_t
         L.geom_tri_distance_workspace_bytes.argtypes = [_i, _i, _i]
+        L.geom_zn_layer_partial_rows.restype = ctypes.c_int64
+        L.geom_zn_layer_partial_rows.argtypes = [_i, _i]
         L.geom_surface_tail_counters_offset.restype = ctypes.c_size_t
         L.geom_surface_tail_counters_offset.argtypes = [_i, _i, _i]
         for name, args in _SIGNATURES.items():
@@ -217,7 +220,7 @@ def declared_symbols():
                    "geom_segment_max_workspace_bytes", "geom_zn_gcn_relu_mask_words",
                    "geom_surface_bin_count_words", "geom_surface_bin_list_words", "geom_surface_order_words",
                    "geom_dense_bwd_weight_workspace_floats", "geom_chamfer_nn_culled_workspace_floats",
-                   "geom_nn_cull_index_floats", "geom_surface_tail_counters_offset"] + list(_SIGNATURES))
+                   "geom_nn_cull_index_floats", "geom_surface_tail_counters_offset", "geom_zn_layer_partial_rows"] + list(_SIGNATURES))
 
 
 def check(code, what):

@@ -28,7 +28,8 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 # per-file additions.  dense_gemm.hip: keep the MFMA accumulators in (unified) VGPRs -- with the default heuristic hipcc
 # (ROCm 7.2) allocates the accumulators of the pipelined loop as untied AGPR tuples and repairs the rotation with ~85
 # v_accvgpr moves per stage, in front of the first MFMA of every stage
-EXTRA_FLAGS = {"dense_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+EXTRA_FLAGS = {"dense_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "zn_stack.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def sources():

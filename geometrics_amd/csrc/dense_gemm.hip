@@ -44,14 +44,6 @@ constexpr int SPLIT_RB_NARROW = 3; // ... 48 rows for layers of <= 192 inputs (s
 #ifndef DG_SPLIT_KP
 #define DG_SPLIT_KP 1   // measured (profiles/r04_split_kernel_ablation.txt): two waves per SIMD buy nothing -- 66.8 vs 65.7 us
 #endif
-#ifndef DG_RIDER_WGS
-#define DG_RIDER_WGS 512
-#endif
-#ifndef DG_RIDER_DELAY_US
-#define DG_RIDER_DELAY_US 0
-#endif
-constexpr int RIDER_WGS = DG_RIDER_WGS;                   // persistent rider workgroups of dense_split_kernel_with_riders
-constexpr int RIDER_DELAY_TICKS = DG_RIDER_DELAY_US * 100; // ... and how long they wait first (100 MHz wall clock)
 constexpr int SPLIT_KP_WIDE = DG_SPLIT_KP;   // k-parts (waves per SIMD) of the stand-alone weight-gradient launch of a wide layer, see split_stage
 constexpr int LD_TC = 34; // stride of a [row][t] panel: fragment reads hit bank (2*row + t) % 32 -- all distinct
 
@@ -1014,43 +1006,6 @@ __global__ __launch_bounds__(RED_THREADS) void dense_reduce_kernel(ReduceJobs jo
     reduce_body<true>(jobs, adam, blockIdx.x, gridDim.x, part, st);
 }
 
-// The stand-alone split launch of a wide layer (one workgroup per CU, 200 registers: a second workgroup fits beside each)
-// CARRYING reductions that are already due: workgroups [n_split, gridDim) finish the partial sums of layers whose split
-// launches came earlier in the pass (the 192-wide layers' 19 MB of partial tiles at the BASELINE shard, the bias-gradient
-// partial rows) on the second slot of every CU while the MFMA workgroups run -- the end-of-pass reduction launch then reads
-// this layer's partial tiles only.  No optimiser step here (the riders only finish gradients; the end-of-pass launch
-// applies the step to them as one-slot jobs): same sums in the same order as dense_reduce_kernel, same bits.
-// MEASURED AND NOT SHIPPED AS THE DEFAULT (profiles/r04_riders.txt, tools/probe/rider_variants.sh): the end-of-pass launch
-// drops from 13.7 to 8.8 us, the carrier grows from 67.6 to 71.5 -- a rider wave beside an MFMA wave costs the MFMA wave
-// about what the rider would cost alone; fewer, persistent riders are worse (each rider block is a 3.7 us latency chain
-// there), a head start for the MFMA workgroups is worse, a raised wave priority for them changes nothing.  Kept behind
-// layers.carry_due_reductions (off) with its bit-equality tests.
-template <int RB, int NCW, bool A_VEC>
-__global__ __launch_bounds__(DG_THREADS) void dense_split_kernel_with_riders(SplitArgs q, int n_split, ReduceJobs riders)
-{
-    static_assert(DG_THREADS == RED_THREADS, "riders run in the split launch's workgroup shape");
-    __shared__ __attribute__((aligned(16))) float lds[2 * 32 * ld_rc(RB * 16)];
-    static_assert(sizeof(lds) >= RED_THREADS * sizeof(f32x4) + 4 * sizeof(float), "rider scratch fits the split tile's LDS");
-    if ((int)blockIdx.x < n_split) {
-#ifdef DG_SPLIT_PRIO
-        __builtin_amdgcn_s_setprio(DG_SPLIT_PRIO);
-#endif
-        split_dispatch<RB, NCW, A_VEC, 1>(q, lds, blockIdx.x);
-    } else {
-        // at most RIDER_WGS rider workgroups, each taking every (gridDim - n_split)-th rider block
-        const ReduceAdam none{};
-        const int n_blocks = riders.first[riders.n];
-        if (RIDER_DELAY_TICKS > 0) {
-            const uint64_t t0 = wall_clock64();
-            while (wall_clock64() - t0 < (uint64_t)RIDER_DELAY_TICKS) __builtin_amdgcn_s_sleep(64);
-        }
-        for (int blk = blockIdx.x - n_split; blk < n_blocks; blk += gridDim.x - n_split) {
-            reduce_body<false>(riders, none, blk, n_blocks, reinterpret_cast<f32x4 *>(lds), lds + RED_THREADS * 4);
-            __syncthreads();
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1284,41 +1239,6 @@ int build_reduce_jobs(ReduceJobs &jobs, int &n, int &widest, int count, const in
     return 0;
 }
 } // namespace
-
-// geom_dense_bwd_weight_f32 whose launch also CARRIES reductions that are already due (dense_split_kernel_with_riders):
-// the weight gradients of `count` earlier layers out of their workspaces and `ncs` column-sum jobs, arguments as for
-// geom_dense_reduce2_f32.  Every rider's partial sums must be complete in stream order; the riders' results equal those
-// of geom_dense_reduce2_f32 bit for bit.  GEOM_EUNSUPPORTED where the split launch is not the one-workgroup-per-CU form
-// (cin <= 192: those layers take the pair launch, whose CUs are full) -- the caller then launches the two separately.
-extern "C" int geom_dense_bwd_weight_riders_f32(int rows, int cin, int c, const float *x, const float *g, float *workspace,
-                                                int want_colsum, int count, const int *r_rows, const int *r_cin,
-                                                const int *r_c, const float *const *r_workspaces, float *const *r_grad_w,
-                                                int ncs, const float *const *cs_partials, const int *cs_rows,
-                                                const int *cs_cols, float *const *cs_outs, void *stream)
-{
-    if (count + ncs == 0) return geom_dense_bwd_weight_f32(rows, cin, c, x, g, workspace, want_colsum, stream);
-    if (rows <= 0 || cin <= 0 || c <= 0) return GEOM_EINVAL;
-    if (c % 12 != 0 || c > 192 || (int64_t)rows * (cin > c ? cin : c) >= (1LL << 30)) return GEOM_EUNSUPPORTED;
-    if (!x || !g || !workspace || !aligned16(g) || !aligned16(workspace)) return GEOM_EINVAL;
-    const SplitGeo geo = split_geometry(cin, rows, num_cus());
-    if (geo.rb != SPLIT_RB || SPLIT_KP_WIDE != 1) return GEOM_EUNSUPPORTED;
-    if (want_colsum && geo.full_tiles == 0) return GEOM_EUNSUPPORTED;
-    for (int l = 0; l < count; ++l)       // a rider must not be this launch's own workspace
-        if (r_workspaces && r_workspaces[l] == workspace) return GEOM_EINVAL;
-    ReduceJobs riders;
-    int n, widest;
-    const int code = build_reduce_jobs(riders, n, widest, count, r_rows, r_cin, r_c, r_workspaces, r_grad_w, ncs, cs_partials,
-                                       cs_rows, cs_cols, cs_outs);
-    if (code) return code;
-    float *colsum = want_colsum ? workspace + (int64_t)geo.slots * geo.rb * 16 * 192 : nullptr;
-    SplitArgs q{x, cin, g, c, workspace, cin, c, rows, geo.full_tiles, geo.s_full, geo.left_rb, geo.s_left, colsum};
-    const dim3 grid(geo.slots + (riders.first[n] < RIDER_WGS ? riders.first[n] : RIDER_WGS)), block(DG_THREADS);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (cin % 4 == 0 && aligned16(x))
-        hipLaunchKernelGGL((dense_split_kernel_with_riders<SPLIT_RB, 3, true>), grid, block, 0, s, q, geo.slots, riders);
-    else hipLaunchKernelGGL((dense_split_kernel_with_riders<SPLIT_RB, 3, false>), grid, block, 0, s, q, geo.slots, riders);
-    return geom::launch_status();
-}
 
 // Weight gradients of `count` layers out of their workspaces AND `ncs` pending column-sum jobs (cs_outs[i][0..cs_cols[i]) =
 // column sums of cs_partials[i], cs_rows[i] x cs_cols[i] row-major: the per-workgroup bias-gradient partials of the

@@ -73,17 +73,8 @@ def weight_workspace(rows, cin, c, device):
 launch_probe = None
 
 
-def carries_riders(rows, cin, c):
-    """The stand-alone split launch of a wide layer (one workgroup per CU) can carry reductions that are already due on
-    the second slot of every CU (geom_dense_bwd_weight_riders_f32); the pair launches of the narrow layers fill their CUs."""
-    p = plan(rows, cin, c)
-    return p["dw"] == "mfma" and not p["pair"] and cin > 192
-
-
-def backward_weight_partials(x, g, workspace, want_colsum=False, riders=None):
-    """Per-split partial tiles of x.T @ g (and of g's column sums) into `workspace`; `reduce` finishes them.
-    riders = (weight jobs [(rows, cin, c, workspace, grad_w)], column-sum jobs [(partials, rows, cols, out)]) whose partial
-    sums are complete in stream order: finished by extra workgroups of THIS launch (same bits as `reduce`)."""
+def backward_weight_partials(x, g, workspace, want_colsum=False):
+    """Per-split partial tiles of x.T @ g (and of g's column sums) into `workspace`; `reduce` finishes them."""
     rows, cin = x.shape
     c = g.shape[1]
     probe = launch_probe
@@ -91,17 +82,8 @@ def backward_weight_partials(x, g, workspace, want_colsum=False, riders=None):
         if probe is not None:
             start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             start.record()
-        if riders is not None and (riders[0] or riders[1]):
-            red, cs = riders
-            ints = lambda seq: (ctypes.c_int * max(1, len(seq)))(*seq)
-            ptrs = lambda seq: (ctypes.c_void_p * max(1, len(seq)))(*[t.data_ptr() for t in seq])
-            _lib.call("geom_dense_bwd_weight_riders_f32", rows, cin, c, x.data_ptr(), g.data_ptr(), workspace.data_ptr(),
-                      1 if want_colsum else 0, len(red), ints([j[0] for j in red]), ints([j[1] for j in red]),
-                      ints([j[2] for j in red]), ptrs([j[3] for j in red]), ptrs([j[4] for j in red]), len(cs),
-                      ptrs([j[0] for j in cs]), ints([j[1] for j in cs]), ints([j[2] for j in cs]), ptrs([j[3] for j in cs]))
-        else:
-            _lib.call("geom_dense_bwd_weight_f32", rows, cin, c, x.data_ptr(), g.data_ptr(), workspace.data_ptr(),
-                      1 if want_colsum else 0)
+        _lib.call("geom_dense_bwd_weight_f32", rows, cin, c, x.data_ptr(), g.data_ptr(), workspace.data_ptr(),
+                  1 if want_colsum else 0)
         if probe is not None:
             end.record()
             probe.append((rows, cin, c, start, end))

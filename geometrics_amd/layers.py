@@ -315,13 +315,6 @@ def _flush_late(task):
 
 _pending_colsums = {}     # autograd graph-task id -> [(partials, rows, cols, out alias, stream)]
 _pending_reduce = {}      # autograd graph-task id -> [(rows, cin, c, workspace, dW alias, stream, param ref)]: weight-gradient partials
-_pending_ridden = {}      # autograd graph-task id -> [(gradient alias, stream, param ref)]: finished early by riders, see _take_riders
-# Option: the stand-alone split launch of a wide layer (the 963-wide first layer: one workgroup per CU) CARRIES the
-# reductions that are already due when it is issued -- the narrow layers' partial tiles, the bias-gradient partial rows --
-# on the second slot of every CU (csrc/dense_gemm.hip: dense_split_kernel_with_riders); the end-of-pass launch then reads the
-# wide layer's own partial tiles only.  Same sums in the same order: same bits.  Off by default: at the BASELINE shard the
-# end-of-pass launch gets 4.9 us shorter and the carrier 3.9 us longer (profiles/r04_riders.txt).
-carry_due_reductions = False
 # bias parameter -> the live autograd nodes that produce a gradient for it.  A bias shared by two layers (or a layer applied
 # twice) gets its gradients ADDED by the engine inside the pass, which reads them on arrival: more than one live node means
 # immediate reduction for all of them.  Nodes leave the set when their graph is freed.
@@ -389,7 +382,6 @@ def _register_flush(task):
         _flush_registered.discard(stale)
         _pending_colsums.pop(stale, None)
         _pending_reduce.pop(stale, None)
-        _pending_ridden.pop(stale, None)
         _pending_late.pop(stale, None)
     _flush_registered.add(task)
     torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_pass(task))
@@ -402,51 +394,14 @@ def _flush_pass(task):
         _flush_late(task)      # the postponed input-gradient products: behind the reduction launch(es) and the ready-callbacks
 
 
-def _take_riders(rows, cin, c, stream):
-    """The pending reductions of the running backward pass that the split launch of a [rows, cin] x [rows, c] weight
-    gradient on `stream` can carry (dense.carries_riders), taken off the pending lists -- or None.  They are complete in
-    stream order (their producers were issued earlier in this pass on the same stream).  The end of the pass still checks
-    that each gradient landed in its parameter and, when the optimiser's step rides in the end-of-pass launch, hands the
-    finished gradients to it as one-slot jobs (the step needs every parameter in ONE launch: its arrival protocol)."""
-    if not carry_due_reductions or not hasattr(torch._C, "_current_graph_task_id"):
-        return None
-    task = torch._C._current_graph_task_id()
-    if task < 0 or not _dense_kernels.carries_riders(rows, cin, c):
-        return None
-    red = [j for j in _pending_reduce.get(task, []) if j[5] == stream]
-    cs = [j for j in _pending_colsums.get(task, []) if j[4] == stream and j[2] % 4 == 0]
-    # the end-of-pass launch takes the carrier's own job + one one-slot job per rider
-    if not (red or cs) or len(red) + len(cs) + 2 > _lib.DENSE_MAX_REDUCE_JOBS:
-        return None
-    _pending_reduce[task] = [j for j in _pending_reduce.get(task, []) if not any(j is r for r in red)]
-    _pending_colsums[task] = [j for j in _pending_colsums.get(task, []) if not any(j is r for r in cs)]
-    done = _pending_ridden.setdefault(task, [])
-    done.extend((j[4], j[5], j[6]) for j in red)
-    done.extend((j[3], j[4], j[5]) for j in cs)
-    return [j[:5] for j in red], [j[:4] for j in cs]
-
-
 def _flush_parameter_gradients(task):
     _flush_registered.discard(task)
-    ridden = _pending_ridden.pop(task, [])
-    try:
-        _flush_pending_gradients(task, ridden)
-    finally:
-        for out, _stream, ref in ridden:
-            _check_landed(ref, out)
+    _flush_pending_gradients(task)
 
 
-def _flush_pending_gradients(task, ridden=()):
+def _flush_pending_gradients(task):
     red = _pending_reduce.get(task, [])
     cs = list(_pending_colsums.get(task, []))
-    # gradients finished early by riders: when the optimiser's step rides in this launch they join it as ONE-SLOT jobs over
-    # themselves (the launch reads the finished 0.3 MB back instead of 19 MB of partial tiles; x + 0 in place: same bits)
-    handed = []
-    if ridden and red and _backward_optimizer is not None:
-        for out, stream, ref in ridden:
-            flat = out.view(-1)
-            handed.append((flat, 1, flat.numel(), flat, stream, ref))
-    cs += handed
     streams = {j[5] for j in red} | {j[4] for j in cs}
     joint = (red and cs and len(streams) == 1 and all(j[2] % 4 == 0 for j in cs)
              and 2 * len(red) + len(cs) <= _lib.DENSE_MAX_REDUCE_JOBS)
@@ -468,9 +423,6 @@ def _flush_pending_gradients(task, ridden=()):
         slots = [index.get(id(p)) if p is not None else None for p in owners]
         if None in slots or sorted(slots) != list(range(len(opt.params))) or opt.params[0].device != stream.device:
             slots = None
-    if slots is None and handed:      # no step in this launch: the finished gradients need nothing more
-        cs = cs[:len(cs) - len(handed)]
-        m = len(cs)
     with torch.cuda.device(stream.device):
         if slots is None:
             _lib.check(_lib.lib().geom_dense_reduce2_f32(
@@ -894,8 +846,7 @@ class _DenseMM(torch.autograd.Function):
                 late = (g2, w2, _alias(grad_x).view(rows, cin), torch.cuda.current_stream(x.device), weakref.ref(x))
             elif need_x:
                 grad_x = torch.matmul(g2, w2.t()).view(x.shape)
-            _dense_kernels.backward_weight_partials(x2, g2, ws,
-                                                    riders=_take_riders(rows, cin, c, torch.cuda.current_stream(x.device)))
+            _dense_kernels.backward_weight_partials(x2, g2, ws)
         if late is not None:
             task = torch._C._current_graph_task_id()
             _pending_late.setdefault(task, []).append(late)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GEOM_ABI_VERSION 7
+#define GEOM_ABI_VERSION 8
 
 /* argument errors */
 #define GEOM_EINVAL   (-1) /* bad size / null pointer */
@@ -312,15 +312,6 @@ int geom_dense_bwd_f32(int rows, int cin, int c, const float *x, const float *g,
 int geom_dense_reduce2_f32(int count, const int *rows, const int *cin, const int *c, const float *const *workspaces,
                            float *const *grad_w, float *const *grad_bias, int ncs, const float *const *cs_partials,
                            const int *cs_rows, const int *cs_cols, float *const *cs_outs, void *stream);
-/* geom_dense_bwd_weight_f32 whose launch also CARRIES reductions that are already due: the weight gradients of `count` earlier
- * layers (r_* as the first arguments of geom_dense_reduce2_f32) and `ncs` column-sum jobs are finished by extra workgroups on
- * the second slot of every CU while the MFMA workgroups run; results bit-identical to geom_dense_reduce2_f32.  The riders'
- * partial sums must be complete in stream order.  GEOM_EUNSUPPORTED for cin <= 192 (those layers take the pair launch). */
-int geom_dense_bwd_weight_riders_f32(int rows, int cin, int c, const float *x, const float *g, float *workspace,
-                                     int want_colsum, int count, const int *r_rows, const int *r_cin, const int *r_c,
-                                     const float *const *r_workspaces, float *const *r_grad_w, int ncs,
-                                     const float *const *cs_partials, const int *cs_rows, const int *cs_cols,
-                                     float *const *cs_outs, void *stream);
 /* geom_dense_reduce2_f32 + the Adam step (torch.optim.Adam's rule, as geom_adam_step_f32) of the parameters whose gradients
  * the launch finishes: w_p / w_m / w_v[l] = parameter and its two moments for layer l's weight, b_p / b_m / b_v[i] for column-sum
  * job i (entries may be NULL: gradient only); `state` = the optimiser's device-side step state, advanced once by this launch;
@@ -349,6 +340,31 @@ int geom_zn_gcn_aggregate_ell_head_bwd_f32(int b, int nv, int c, int k, int w, c
                                            const float *over_valT, const float *grad_pos, float scale,
                                            const uint16_t *relu_mask, int act, float *grad_support,
                                            float *grad_bias, float *scratch, void *stream);
+
+/* ---- a whole layer boundary in ONE launch (csrc/zn_stack.hip; layers.py:107-116 across two consecutive layers) --------
+ * The aggregation of one layer is fused into the operand load of the product that follows it (forward) / precedes it
+ * (backward); the weight slice of every wave stays in registers, the gathered operand goes through a 13 KB LDS panel.
+ * Shapes: c == 192, k == 64 (split 3), ell_w == 8 with NO row longer than the table, n_out / n_in <= 192 and % 12 == 0;
+ * anything else GEOM_EUNSUPPORTED (callers then use geom_zn_gcn_aggregate_ell_* + a product).
+ *
+ * geom_zn_layer_fwd_f32:  x_out = act([A . s_prev[:, :k] | s_prev[:, k:]] + bias_prev)   [b*nv, 192]  (the bits of
+ *   geom_zn_gcn_aggregate_ell_fwd_f32; relu_mask in that entry point's layout, optional, act == 1 only)
+ *                         s_out = x_out . w    (w [192, n_out] row-major, s_out [b*nv, n_out])
+ *   wt_out (optional) [n_out, 192] receives w transposed -- what geom_zn_layer_bwd_f32 takes as `wt`.
+ * geom_zn_layer_bwd_f32:  g_out = [A^T . g'[:, :k] | g'[:, k:]], g' = grad_out * act'(out)    [b*nv, 192]  (the bits of
+ *   geom_zn_gcn_aggregate_ell_bwd_f32; act' from relu_mask (act 1) / `out` (act 2))
+ *                         grad_in = g_out . wt   (wt [192, n_in] = the layer's weight transposed, grad_in [b*nv, n_in])
+ *   colsum_partial (optional) [geom_zn_layer_partial_rows(b, nv)][192]: per-workgroup column sums of g' (bias-gradient
+ *   partials; finished by geom_dense_reduce2_f32 / geom_colsum_batch_f32).  grad_pos != NULL: head mode -- grad_out is
+ *   [head_scale * grad_pos | 0 ...] by construction and is not read (act 0 or 1 only). */
+int64_t geom_zn_layer_partial_rows(int b, int nv);
+int geom_zn_layer_fwd_f32(int b, int nv, int c, int k, int ell_w, const int *ell_col, const float *ell_val,
+                          const float *s_prev, const float *bias_prev, int act, const float *w, int n_out,
+                          float *x_out, uint16_t *relu_mask, float *s_out, float *wt_out, void *stream);
+int geom_zn_layer_bwd_f32(int b, int nv, int c, int k, int ell_w, const int *ell_col_t, const float *ell_val_t,
+                          const float *grad_out, const float *out, const uint16_t *relu_mask, int act,
+                          const float *grad_pos, float head_scale, const float *wt, int n_in, float *g_out,
+                          float *grad_in, float *colsum_partial, void *stream);
 
 /* Coordinate update of a deformation stage (GEOMetrics.py:121,126,131) when the predicted offsets are the
  * three leading channels of a wider feature tensor: pos[r,:] = base[r,:] + scale*feat[r,:3] for `rows`

@@ -245,113 +245,3 @@ def test_adam_inside_the_backward_pass_equals_the_separate_launch():
     assert oa.step_count == ob.step_count
     for p, q in zip(a.parameters(), b.parameters()):
         assert torch.equal(p, q)
-
-
-def test_split_launch_carries_due_reductions_with_the_same_bits():
-    """geom_dense_bwd_weight_riders_f32: the wide layer's split launch finishing two narrow layers' weight gradients and a
-    column-sum job on its spare slots, against the plain launch + geom_dense_reduce2_f32 -- partial tiles of the carrier
-    and every rider output bit for bit; narrow carriers (the pair launch's shapes) are refused."""
-    import ctypes
-    from geometrics_amd import _lib, dense
-    rows = 5124
-    x1, _, g1 = _operands(rows, 963, 192, 5)
-    riders = []
-    for k, cin in enumerate((192, 96)):
-        x, _, g = _operands(rows, cin, 192, 6 + k)
-        ws = dense.weight_workspace(rows, cin, 192, x.device)
-        dense.backward_weight_partials(x, g, ws)
-        riders.append((rows, cin, 192, ws))
-    partial_rows = torch.randn(321, 192, device="cuda")
-    ws_a = dense.weight_workspace(rows, 963, 192, x1.device)
-    ws_b = torch.zeros_like(ws_a)
-    ws_a.zero_()
-    out_a = [torch.empty(r[1], 192, device="cuda") for r in riders] + [torch.empty(192, device="cuda")]
-    out_b = [torch.empty_like(t) for t in out_a]
-    dense.backward_weight_partials(x1, g1, ws_a, riders=([r + (o,) for r, o in zip(riders, out_a)],
-                                                        [(partial_rows, 321, 192, out_a[2])]))
-    dense.backward_weight_partials(x1, g1, ws_b)
-    ints = lambda seq: (ctypes.c_int * len(seq))(*seq)
-    ptrs = lambda seq: (ctypes.c_void_p * len(seq))(*[t.data_ptr() for t in seq])
-    _lib.call("geom_dense_reduce2_f32", 2, ints([rows, rows]), ints([192, 96]), ints([192, 192]), ptrs([r[3] for r in riders]),
-              ptrs(out_b[:2]), None, 1, ptrs([partial_rows]), ints([321]), ints([192]), ptrs(out_b[2:]))
-    assert torch.equal(ws_a, ws_b)
-    for a, b in zip(out_a, out_b):
-        assert torch.equal(a, b)
-    _close(out_a[2], partial_rows.double().sum(0))
-    gw = torch.empty(963, 192, device="cuda")
-    dense.reduce([(rows, 963, 192, ws_a, gw, None)])
-    _close(gw, x1.double().t() @ g1.double())
-    assert dense.carries_riders(rows, 963, 192) and not dense.carries_riders(rows, 192, 192)
-    xn, _, gn = _operands(rows, 192, 192, 9)
-    wn = dense.weight_workspace(rows, 192, 192, xn.device)
-    with pytest.raises(RuntimeError):
-        dense.backward_weight_partials(xn, gn, wn, riders=([riders[0] + (out_a[0],)], []))
-
-
-@pytest.mark.parametrize("fused_adam", [False, True])
-def test_riders_inside_a_backward_pass_change_no_bit(fused_adam):
-    """layers.carry_due_reductions: a 963-192-192-192 stack whose first layer's split launch finishes the hidden layers'
-    weight gradients and all three bias gradients (and, with the optimiser's step in the backward pass, hands them to the
-    end-of-pass launch as one-slot jobs) against the same iterations with everything reduced at the end of the pass:
-    gradients, parameters and moments bit for bit over several iterations, eager and replayed as a HIP graph."""
-    import contextlib
-    import torch.nn.functional as F
-    from geometrics_amd import layers, meshgen, optim, utils
-    V, Fc = meshgen.icosphere(2)
-    adj = utils.adj_init(torch.from_numpy(Fc).cuda())["adj"]
-    x = torch.randn(4, V.shape[0], 963, device="cuda").requires_grad_(True)
-    target = torch.randn(4, V.shape[0], 192, device="cuda")
-
-    def make():
-        torch.manual_seed(5)
-        stack = torch.nn.ModuleList([layers.Batch_Image_ZERON_GCNGCN(963, 192), layers.Batch_Image_ZERON_GCNGCN(192, 192),
-                                     layers.Batch_Image_ZERON_GCNGCN(192, 192)]).cuda()
-        return stack, optim.FusedAdam(stack.parameters(), lr=1e-3)
-
-    def iteration(stack, opt, carry):
-        layers.carry_due_reductions = carry
-        try:
-            opt.zero_grad()
-            x.grad = None
-            with layers.deferred_parameter_gradients(), (opt.in_backward() if fused_adam else contextlib.nullcontext()):
-                h = x
-                for layer in stack:
-                    h = layer(h, adj, F.relu)
-                ((h - target) ** 2).mean().backward()
-            assert bool(getattr(opt, "_stepped_in_backward", False)) == fused_adam
-            opt.step()
-        finally:
-            layers.carry_due_reductions = False
-
-    def same(a, oa, b, ob):
-        for p, q in zip(a.parameters(), b.parameters()):
-            assert torch.equal(p, q) and torch.equal(p.grad, q.grad)
-        for m1, m2 in zip(oa.exp_avg + oa.exp_avg_sq, ob.exp_avg + ob.exp_avg_sq):
-            assert torch.equal(m1, m2)
-
-    assert 4 * V.shape[0] >= 512
-    a, oa = make()
-    b, ob = make()
-    for _ in range(3):
-        iteration(a, oa, True)
-        gx = x.grad.clone()
-        iteration(b, ob, False)
-        assert torch.equal(gx, x.grad)
-    same(a, oa, b, ob)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        iteration(a, oa, True)
-        iteration(b, ob, False)
-    torch.cuda.current_stream().wait_stream(side)
-    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-    with torch.cuda.graph(ga):
-        iteration(a, oa, True)
-    with torch.cuda.graph(gb):
-        iteration(b, ob, False)
-    for _ in range(3):
-        ga.replay()
-        gb.replay()
-    torch.cuda.synchronize()
-    assert oa.step_count == ob.step_count
-    same(a, oa, b, ob)
