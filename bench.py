@@ -796,7 +796,7 @@ def cpu_baseline(budget_s=12.0):
         done += 1
     # all-cores figure: one independent mesh per thread (the reference has no threading; ctypes releases the GIL)
     import concurrent.futures
-    threads = min(os.cpu_count() or 1, 64)
+    threads = os.cpu_count() or 1      # every host CPU (round 4 capped this at 64 and still called it "all cores")
     def one_mesh(i):
         verts = meshgen.jittered_batch(V, 1, first=i)
         gt = meshgen.gt_cloud(1, G_PTS, first=i)
@@ -816,6 +816,47 @@ def cpu_baseline(budget_s=12.0):
                       % (done, "reference nnsearch (oracle/_ref)" if use_ref else "C restatement of nnsearch"),
             "chamfer_only_meshes_per_s": round(done / t_nn, 2), "tri_only_meshes_per_s": round(done / t_tri, 3),
             "host_cpus": os.cpu_count()}
+
+
+def parity_spot_check(w):
+    """OUTSIDE the timed region: one evaluation of the surface loss on the route the step times (visiting-order draws under the
+    gt index, culled Chamfer tiles, finalize roles in the scan launch) at the positions the timed steps ended on, checked
+    against the CPU oracle on the very (choices, u, v) the generator drew: mismatching NN / triangle indices and region codes
+    (bit-exact is the bar: 0), arg-min distances whose bits differ, the loss against the CPU restatement of utils.py:441-502
+    (1e-5) and the gradient with respect to the positions against its fp32 autograd (max-norm, 1e-4)."""
+    import oracle
+    from oracle import ref_ops
+    oracle.build()
+    pos = w.positions().detach().clone().requires_grad_(True)
+    seen = {}
+    ops.scan_capture = seen
+    try:
+        loss = utils.batch_point_to_surface(pos, w.info, w.gt, num=S_PTS, gt_index=w.gt_index)
+    finally:
+        ops.scan_capture = None
+    loss.backward()
+    torch.cuda.synchronize()
+    cpu = lambda t: t.detach().cpu().numpy()
+    verts, gt, faces = cpu(pos), cpu(w.gt), cpu(w.faces)
+    ch, u, v = cpu(seen["choices"]), cpu(seen["u"]), cpu(seen["v"])
+    pred = ref_ops.sample_points(*(torch.from_numpy(a) for a in (verts, faces, ch, u, v))).numpy()
+    d_gt, i_gt, d_pred, i_pred = oracle.chamfer_nn(gt, pred)
+    t_d, t_opt, t_idx = oracle.tri_scan_indexed(gt, verts, faces)
+    bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    cv = torch.from_numpy(verts).requires_grad_(True)
+    ref = ref_ops.point_to_surface(cv, torch.from_numpy(faces), torch.from_numpy(gt), torch.from_numpy(ch), torch.from_numpy(u),
+                                   torch.from_numpy(v))
+    ref.backward()
+    g, rg = cpu(pos.grad), cv.grad.numpy()
+    return {"meshes": int(verts.shape[0]), "route": "gt_index (culled Chamfer tiles, visiting-order draws), finalize roles %s"
+                                                     % ("on" if ops.scan_finalize_tail else "off"),
+            "idx_mismatches": int((cpu(seen["idx_gt"]) != i_gt).sum() + (cpu(seen["idx_pred"]) != i_pred).sum()
+                                  + (cpu(seen["tri_index"]) != t_idx).sum() + (cpu(seen["tri_option"]) != t_opt).sum()),
+            "sampled_point_bit_mismatches": int((bits(cpu(seen["points"])) != bits(pred)).sum()),
+            "dist_bit_mismatches": int((bits(cpu(seen["sq_pred"])) != bits(d_pred)).sum() + (bits(cpu(seen["tri_dist"])) != bits(t_d)).sum()),
+            "loss": float(loss.item()), "loss_cpu_restatement": float(ref.item()),
+            "loss_rel_err": float(abs(loss.item() - ref.item()) / abs(ref.item())),
+            "grad_pos_max_err_over_scale": float(np.abs(g - rg).max() / np.abs(rg).max())}
 
 
 def self_launch(n, argv):
@@ -979,6 +1020,7 @@ def main():
             extra("whole_batch_single_gpu", lambda: whole_batch_times(dev))
         if world == 1 and not args.no_cpu_baseline:
             extra("cpu_baseline", cpu_baseline)
+            extra("parity_spot_check", lambda: parity_spot_check(w))
         if force_dp:
             line["config"]["forced_dp"] = "1-rank RCCL group: the N > 1 step sequence on one GPU (test hook GEOM_BENCH_FORCE_DP)"
         print(json.dumps(line))

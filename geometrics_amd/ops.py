@@ -197,6 +197,11 @@ class ScanPrep:
 # The finalize pass of the one-sided surface loss as extra (role) workgroups of the fused scan launch (csrc/tri_distance.hip:
 # ScanTail) instead of a launch of its own; same outputs bit for bit.  False: always the separate launch (the A/B switch).
 scan_finalize_tail = True
+# Inspection hook (tests, bench.py's parity spot check): a dict that receives the arg-min outputs of the next SurfaceLoss
+# forward passes as they sit on the device -- idx_gt (nearest sampled point of every gt point), idx_pred (nearest gt point of
+# every sampled point), the draws (choices, u, v) and sampled points it ran on and, one-sided loss, tri_index / tri_option /
+# tri_dist of the point-to-triangle scan.  None: off.
+scan_capture = None
 
 
 class SurfaceLoss(torch.autograd.Function):
@@ -305,6 +310,10 @@ class SurfaceLoss(torch.autograd.Function):
                     code = L.geom_surface_finalize_f32(*args, 0, 0, order.data_ptr(), out.data_ptr(), _lib.stream_ptr())
                 _lib.check(code, "geom_surface_finalize_f32")
             ctx.order = order if want else None
+            if scan_capture is not None:
+                scan_capture.update(idx_gt=idx_p, idx_pred=idx_g, sq_gt=sq_gt, sq_pred=sq_pred, choices=choices, u=u, v=v, points=points)
+                if not two_sided:
+                    scan_capture.update(tri_index=index, tri_option=option, tri_dist=tri_d)
             if two_sided:
                 ctx.save_for_backward(faces, choices, u, v, points, gt_c, idx_g, idx_p)
             else:

@@ -1488,3 +1488,51 @@ def test_finalize_roles_give_up_instead_of_hanging(gpu):
     ops.manual_seed(9)
     assert bool(torch.isfinite(utils.batch_point_to_surface(verts, {"faces": faces}, gt, num=num, gt_index=gi)))
     ops.manual_seed(0, gpu)
+
+
+def test_the_timed_route_against_the_oracle_at_the_config5_shard(gpu):
+    """What bench.py times, checked DIRECTLY (round-4 review: the route was only compared with the brute-force tiles on the
+    same samples, and those with the oracle on other draws): BASELINE config 5's shard -- 8 meshes, 2562 vertices / 5120
+    faces, 3000 + 3000 points -- with the samples the visiting-order generator emits under a gt index (k-d orders, as the
+    bench builds them), the culled Chamfer tiles and the finalize pass inside the scan launch.  The (choices, u, v) it drew
+    go through the CPU restatement of the reference (oracle.ref_ops.point_to_surface, utils.py:441-502, arg-min stages from
+    the C oracle): NN indices of both directions and the winning triangle + its region code bit-exact, the arg-min
+    distances bit for bit, the loss within 1e-5, the gradient row by row against the float64 closed form."""
+    import oracle
+    from geometrics_amd.tri_distance import kd_order
+    V, Fc = meshgen.icosphere(4)
+    B, num = 8, 3000
+    verts_np, gt_np = meshgen.jittered_batch(V, B), meshgen.gt_cloud(B, num)
+    verts = dev(verts_np, gpu).requires_grad_(True)
+    faces, gt = dev(Fc, gpu), dev(gt_np, gpu)
+    gi = ops.GtIndex(gt, torch.stack([kd_order(gt[i]) for i in range(B)]))
+    assert ops.scan_finalize_tail
+    ops.manual_seed(2041)
+    choices, u, v, points, prep = ops.draw_samples(verts, faces, num, with_points=True, prepare_scan_for=num, gt_index=gi)
+    assert isinstance(prep, ops.ScanPrep) and prep.sample_index is not None          # the culled route is what runs
+    seen = {}
+    ops.scan_capture = seen
+    try:
+        loss, sq_gt, sq_pred = ops.SurfaceLoss.apply(verts, faces, gt, choices, u, v, False, 3000.0, points, prep, None, gi)
+    finally:
+        ops.scan_capture = None
+    loss.backward()
+    ch, uu, vv = (t.cpu().numpy() for t in (choices, u, v))
+    # the sampled points themselves: bitwise the reference's barycentric combination of the drawn corners
+    pred = ref_ops.sample_points(torch.from_numpy(verts_np), torch.from_numpy(Fc), torch.from_numpy(ch), torch.from_numpy(uu),
+                                 torch.from_numpy(vv)).numpy()
+    assert np.array_equal(bits(points.cpu().numpy()), bits(pred))
+    d_gt, i_gt, d_pred, i_pred = oracle.chamfer_nn(gt_np, pred)
+    assert np.array_equal(seen["idx_gt"].cpu().numpy(), i_gt) and np.array_equal(seen["idx_pred"].cpu().numpy(), i_pred)
+    assert np.array_equal(bits(sq_pred.cpu().numpy()), bits(d_pred))
+    t_d, t_opt, t_idx = oracle.tri_scan_indexed(gt_np, verts_np, Fc)
+    assert np.array_equal(seen["tri_index"].cpu().numpy(), t_idx) and np.array_equal(seen["tri_option"].cpu().numpy(), t_opt)
+    assert np.array_equal(bits(seen["tri_dist"].cpu().numpy()), bits(t_d))
+    cv = torch.from_numpy(verts_np).requires_grad_(True)
+    ref = ref_ops.point_to_surface(cv, torch.from_numpy(Fc), torch.from_numpy(gt_np), torch.from_numpy(ch), torch.from_numpy(uu),
+                                   torch.from_numpy(vv))
+    close(loss.item(), ref.item(), 1e-5)
+    exact_loss, exact, mass, floor = fp64_surface_gradient(verts_np, Fc, gt_np, ch, uu, vv, two_sided=False)
+    close(loss.item(), exact_loss, 1e-5)
+    rows_close(verts.grad.cpu().numpy(), exact, mass, ROW_RTOL_SURFACE, "timed route, grad_verts at the config-5 shard", floor,
+               ROW_FLOOR_ULPS)
