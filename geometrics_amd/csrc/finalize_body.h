@@ -44,6 +44,7 @@ struct FinalizeArgs {
     int *off, *seg, *pface, *slot;
     float4 *rec;
     float *loss;
+    int *status; // [b + 1] words of the scratch (surface_layout.h): 0 = this role's result is complete; null: no scratch
 };
 
 
@@ -74,8 +75,10 @@ __device__ __forceinline__ float block_sum_virtual(float (&v)[FIN_VIRTUAL / THRE
 // wait(): called by every thread of the workgroup (uniformly) in front of the first read of anything the scans of the
 // SAME launch produce -- the stand-alone launch passes a no-op, the fused scan's role workgroups their counter wait.
 // With ready records the sampled points (their faces are the draws: known before the scans) are binned in front of it.
+// Returns (to every thread alike) whether what it waited for is there; false: the role gives up -- it marks its status
+// word, the loss role also writes NaN, and NOTHING of the incomplete results is read.
 struct FinalizeNoWait {
-    __device__ __forceinline__ void operator()() const {}
+    __device__ __forceinline__ bool operator()() const { return true; }
 };
 // ITEMS: points per thread the REGS variant keeps in registers (per <= ITEMS * THREADS; beyond: the scratch variant).
 // READY: the caller guarantees a.records_ready (the code that forms records is left out: it is what made the register
@@ -95,7 +98,13 @@ __device__ __forceinline__ void surface_finalize_body(const FinalizeArgs &a, int
     // ---- the extra workgroup (block == b) reduces the loss while the others order their meshes: float4 loads, all
     //      of a thread's loads in flight together, then a fixed tree -- no cross-workgroup hand-off at all ----
     if (mesh == a.b) {
-        wait();
+        if (!wait()) {
+            if (tid == 0) {
+                a.loss[0] = __builtin_nanf("");
+                if (a.status) a.status[a.b] = 1;
+            }
+            return;
+        }
         auto virtual_sum = [&](const float *x, int64_t n, int vt) {
             float acc = 0.f;
             const bool vec = (((uintptr_t)x) & 15) == 0;
@@ -122,7 +131,10 @@ __device__ __forceinline__ void surface_finalize_body(const FinalizeArgs &a, int
         }
         const float t1 = block_sum_virtual<THREADS>(s1, fsum, tid);
         const float t2 = block_sum_virtual<THREADS>(s2, fsum + FIN_VWAVES, tid);
-        if (tid == 0) a.loss[0] = t1 * a.scale_sample + t2 * a.scale_other;
+        if (tid == 0) {
+            a.loss[0] = t1 * a.scale_sample + t2 * a.scale_other;
+            if (a.status) a.status[a.b] = 0;
+        }
         return;
     }
 
@@ -192,7 +204,10 @@ __device__ __forceinline__ void surface_finalize_body(const FinalizeArgs &a, int
                 if (id < early) bin_point(id, my_f[it], my_slot[it]);
             }
             FIN_PHASE(2);
-            wait();
+            if (!wait()) {
+                if (tid == 0 && a.status) a.status[mesh] = 1;
+                return;
+            }
             FIN_PHASE(3);
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
@@ -235,7 +250,10 @@ __device__ __forceinline__ void surface_finalize_body(const FinalizeArgs &a, int
                 }
             }
             FIN_PHASE(2);
-            wait();
+            if (!wait()) {
+                if (tid == 0 && a.status) a.status[mesh] = 1;
+                return;
+            }
             FIN_PHASE(3);
             bin_range(early, a.per);
         }
@@ -344,6 +362,7 @@ __device__ __forceinline__ void surface_finalize_body(const FinalizeArgs &a, int
             }
         }
         FIN_PHASE(7);
+        if (tid == 0 && a.status) a.status[mesh] = 0;
     }
 
 }

@@ -272,6 +272,8 @@ struct VGatherArgs {
     const float *grad; // upstream gradient of the loss (device scalar), may be null (= 1)
     float *grad_verts;
     int nv, nf, per;
+    const int *status; // [b + 1] (surface_layout.h)
+    int b;
 };
 
 // The backward: eight lanes per (mesh, vertex), one incident (face, corner) each; a face's segment is walked in its
@@ -283,7 +285,10 @@ __global__ __launch_bounds__(SGA_THREADS) void surface_vertex_gather_kernel(VGat
     const int mesh = blockIdx.y;
     const bool live = vtx < a.nv;
     V3 acc = geom::mk(0.f, 0.f, 0.f);
-    if (live) {
+    // a mesh whose ordering (or the loss it belongs to) was given up by a finalize role of the scan launch: NaN, loudly --
+    // never a walk through a half-built order
+    const bool broken = a.status[mesh] != 0 || a.status[a.b] != 0;
+    if (live && !broken) {
         const int *off = a.off + (int64_t)mesh * (a.nf + 1);
         const int *seg = a.seg + (int64_t)mesh * a.per;
         const float4 *rec = a.rec + 2 * (int64_t)mesh * a.per;
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(SGA_THREADS) void surface_vertex_gather_kernel(VGat
         total = total + other;
     }
     if (live && j == 0) {
-        const float s = 2.f * (a.grad ? a.grad[0] : 1.f);
+        const float s = broken ? __builtin_nanf("") : 2.f * (a.grad ? a.grad[0] : 1.f);
         float *G = a.grad_verts + ((int64_t)mesh * a.nv + vtx) * 3;
         G[0] = total.x * s;
         G[1] = total.y * s;
@@ -389,7 +394,7 @@ extern "C" int64_t geom_surface_order_words(int b, int nf, int num, int n_gt)
 {
     if (b <= 0 || nf < 0 || num < 0 || n_gt < 0) return 0;
     const int64_t cap = (int64_t)num + n_gt;
-    return geom_surface_order_ints(b, nf, cap) + (int64_t)b * cap * 8;
+    return geom_surface_status_offset(b, nf, cap) + geom_surface_status_ints(b);
 }
 
 extern "C" int geom_surface_finalize_f32(int b, int nf, int num, const int64_t *choices, const float *u, const float *v,
@@ -422,7 +427,7 @@ extern "C" int geom_surface_finalize_f32(int b, int nf, int num, const int64_t *
     float4 *rec = reinterpret_cast<float4 *>(order + geom_surface_order_ints(b, nf, cap));
     FinalizeArgs a{choices, u, v, points, gt, idx_g, idx_p, index, closest, weights, sq_sample, sq_other, scale_sample,
                    scale_other, coef_sample, coef_other, b, nf, num, n_gt, other, per, want_order ? 1 : 0, records_ready ? 1 : 0, off, seg, pface,
-                   slot, rec, loss};
+                   slot, rec, loss, order + geom_surface_status_offset(b, nf, cap)};
     hipStream_t s = static_cast<hipStream_t>(stream);
     // without ordering the single (loss) workgroup touches only its reduction scratch: independent of nf, so the
     // documented fallback beyond the ordering limit (want_order = 0 + scatter backward) really launches
@@ -453,7 +458,7 @@ extern "C" int geom_surface_gather_f32(int b, int nv, int nf, const int *vf_ptr,
     const int *off = order;
     const int *seg = off + (int64_t)b * (nf + 1);
     const float4 *rec = reinterpret_cast<const float4 *>(order + geom_surface_order_ints(b, nf, cap));
-    VGatherArgs a{vf_ptr, vf_item, off, seg, rec, grad, grad_verts, nv, nf, per};
+    VGatherArgs a{vf_ptr, vf_item, off, seg, rec, grad, grad_verts, nv, nf, per, order + geom_surface_status_offset(b, nf, cap), b};
     hipLaunchKernelGGL(surface_vertex_gather_kernel, dim3(((int64_t)nv * VTX_LANES + SGA_THREADS - 1) / SGA_THREADS, b),
                        dim3(SGA_THREADS), 0, static_cast<hipStream_t>(stream), a);
     return geom::launch_status();

@@ -1160,14 +1160,16 @@ struct ScanTail {
 // (64 meshes on the 256 CUs of an MI355X; a partition with fewer CUs takes fewer)
 inline int scan_tail_max_meshes()
 {
-    static int most = 0;
-    if (!most) {
-        int dev = 0, cus = 0;
+    static int most[64] = {0}; // per device: a process may drive partitions of different sizes
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
+    if (!most[dev]) {
+        int cus = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        most = cus >= 8 ? cus / 4 : 1;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        most[dev] = cus >= 8 ? cus / 4 : 1;
     }
-    return most;
+    return most[dev];
 }
 constexpr int SCAN_TAIL_LDS_INTS = 11776; // 46 KB: three workgroups per CU still fit (the BASELINE mesh needs 11 173)
 
@@ -1217,7 +1219,11 @@ __device__ __forceinline__ int tail_wait_counters(int *done, int first, int coun
                 ok = mine >= expect;
             }
             if (__all(ok)) break;
-            if (++polls > TAIL_SPIN_LIMIT) return -1;
+            if (++polls > TAIL_SPIN_LIMIT) { // give up; the counter goes back to zero all the same (a tile that signs off later
+                                            // leaves a stale count: see geom_hip.h -- re-run the prepare launch after a NaN loss)
+                if (i < count) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return -1;
+            }
             __builtin_amdgcn_s_sleep(32);
         }
         if (i < count) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1229,16 +1235,18 @@ __device__ __forceinline__ int tail_wait_counters(int *done, int first, int coun
 
 struct ScanTailWait {
     int *done;
-    int *poison; // LDS: set by the loss role when it, or an ordering role, gave up waiting
+    int *poison; // LDS: set when this role's wait gave up (the loss role: also when an ordering role did)
     int role, b, ordering, expect_mesh, expect_job; // role == b: the loss role
-    __device__ __forceinline__ void operator()() const
+    __device__ __forceinline__ bool operator()() const
     {
         if (threadIdx.x < GEOM_WAVE) {
             int *roles_past = done + (size_t)2 * b * TAIL_CTR_STRIDE;
             if (role < b) { // mesh `role`'s triangle tiles; then tell the loss role
                 const int got = tail_wait_counters(done, role, 1, expect_mesh);
-                if (threadIdx.x == 0)
+                if (threadIdx.x == 0) {
                     __hip_atomic_fetch_add(roles_past, got < 0 ? TAIL_GAVE_UP + 1 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *poison = got < 0;
+                }
             } else {        // the Chamfer tiles whose distances are summed, and the triangle tiles directly or through their ordering roles
                 int got = tail_wait_counters(done, b, b, expect_job);
                 if (got >= 0) got = ordering ? tail_wait_counters(done, 2 * b, 1, b) : tail_wait_counters(done, 0, b, expect_mesh);
@@ -1250,6 +1258,7 @@ struct ScanTailWait {
 #ifdef SCAN_TILE_STAMPS
         if (threadIdx.x == 0) scan_tile_stamps[4 * (size_t)blockIdx.x + 3] = wall_clock64();
 #endif
+        return *poison == 0; // (every thread, behind the barrier above)
     }
 };
 
@@ -1267,11 +1276,9 @@ __device__ __forceinline__ void scan_tail_role(const ScanTail &t, int role, int 
     // record-forming code compiled out.  The register variant does not survive this launch's budget of 80 registers: with 16
     // points per thread it spilled 2 454 registers (55 us to bin 3000 points), with 12 and the lean binning code it fitted in
     // one build (12.4 -> 13 us behind the wait: no gain) and spilled again in the next (20 us to bin, 70 us launch)
+    // (a wait that gave up: the body returns at once -- the loss comes out as NaN, the role's status word of the backward
+    // scratch says "not ordered", and nothing of the incomplete results is read)
     geom_finalize::surface_finalize_body<false, 8 * GEOM_WAVE, ScanTailWait, 16, true>(t.fin, lds_ints, loss_role ? b : role, wait);
-    if (loss_role) { // a wait that gave up: the results the loss was summed from are not all there -- say so
-        __syncthreads();
-        if (threadIdx.x == 0 && *poison) t.fin.loss[0] = __builtin_nanf("");
-    }
 }
 
 // CULL: the Chamfer tiles take the culled scan (nn_culled_body).  Its tiles are latency chains, not issue-bound loops, so
@@ -1614,7 +1621,8 @@ extern "C" int geom_surface_scan_f32(int b, int n_gt, const float *gt, int num, 
                     st.fin = geom_finalize::FinalizeArgs{tail->choices, u, v, points, gt, idx_g, nullptr, index, closest, weights, sq_pred, sq,
                                                          tail->scale_sample, tail->scale_other, coef_sample, coef_other, b, nf, num, n_gt,
                                                          geom_finalize::OTHER_TRI, (int)per64, tail->want_order ? 1 : 0, rec ? 1 : 0,
-                                                         off, seg, pface, slot, rec, tail->loss};
+                                                         off, seg, pface, slot, rec, tail->loss,
+                                                         order_scratch ? order_scratch + geom_surface_status_offset(b, nf, cap) : nullptr};
                     st.done = reinterpret_cast<int *>(gws.keys);
                     st.tiles = (int)(tri_blocks + nn_blocks);
                     st.roles = tail->want_order ? b + 1 : 1;

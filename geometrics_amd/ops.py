@@ -197,6 +197,48 @@ class ScanPrep:
 # The finalize pass of the one-sided surface loss as extra (role) workgroups of the fused scan launch (csrc/tri_distance.hip:
 # ScanTail) instead of a launch of its own; same outputs bit for bit.  False: always the separate launch (the A/B switch).
 scan_finalize_tail = True
+# FAIL-SAFE of the in-launch roles (they wait for tiles of their own launch; a role that waits in vain gives up, the loss is
+# NaN and the backward writes NaN gradients for the meshes whose ordering is missing -- csrc/surface_layout.h: status
+# words).  Every eager forward that used the roles sends its status words to pinned host memory behind the launch (no
+# synchronisation); the NEXT forward looks at the copies that have landed, and the first time one says "gave up" the roles
+# are switched off for the rest of the process (the stand-alone finalize launch takes over: 1 % of a step) with a warning.
+# A captured step cannot look (no python runs between replays): it stays loud through the NaN loss and gradients, and
+# `finalize_roles_gave_up()` lets a training loop ask at the points where it synchronises anyway.
+_roles_watch = []          # [(event, pinned int32 [b + 1])] of recent forwards
+_roles_gave_up = False
+
+
+def _watch_roles(order, b, nf, cap):
+    global _roles_gave_up, scan_finalize_tail
+    if torch.cuda.is_current_stream_capturing():      # (an event query would invalidate the capture)
+        return
+    done = [w for w in _roles_watch if w[0].query()]
+    for w in done:
+        _roles_watch.remove(w)
+        if int(w[1].abs().sum()) != 0 and not _roles_gave_up:
+            _roles_gave_up = True
+            scan_finalize_tail = False
+            import warnings
+            warnings.warn("geometrics_amd: a finalize role of the fused surface scan gave up waiting (status %s); its loss and "
+                          "gradients were NaN.  The roles are switched off for the rest of this process (ops.scan_finalize_tail"
+                          " = False): the finalize pass runs as its own launch again." % w[1].tolist())
+    if order is None or len(_roles_watch) >= 8:
+        return
+    words = (b + 4) & ~3
+    host = torch.empty(b + 1, dtype=torch.int32, pin_memory=True)
+    host.copy_(order[order.numel() - words:order.numel() - words + b + 1], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _roles_watch.append((ev, host))
+
+
+def finalize_roles_gave_up():
+    """True once a finalize role of the fused scan launch has given up in this process (checked without synchronising: call
+    it behind a point where the step is known to be complete, e.g. after reading the loss)."""
+    _watch_roles(None, 0, 0, 0)
+    return _roles_gave_up
+
+
 # Inspection hook (tests, bench.py's parity spot check): a dict that receives the arg-min outputs of the next SurfaceLoss
 # forward passes as they sit on the device -- idx_gt (nearest sampled point of every gt point), idx_pred (nearest gt point of
 # every sampled point), the draws (choices, u, v) and sampled points it ran on and, one-sided loss, tri_index / tri_option /
@@ -310,6 +352,8 @@ class SurfaceLoss(torch.autograd.Function):
                     code = L.geom_surface_finalize_f32(*args, 0, 0, order.data_ptr(), out.data_ptr(), _lib.stream_ptr())
                 _lib.check(code, "geom_surface_finalize_f32")
             ctx.order = order if want else None
+            if tail is not None and tail.finalized and want:
+                _watch_roles(order, b, nf, num + n_gt)
             if scan_capture is not None:
                 scan_capture.update(idx_gt=idx_p, idx_pred=idx_g, sq_gt=sq_gt, sq_pred=sq_pred, choices=choices, u=u, v=v, points=points)
                 if not two_sided:

@@ -477,7 +477,14 @@ int geom_surface_prepare_f32(int b, int nv, const float *verts, int nf, const in
  * fused launch (each mesh is ordered as soon as ITS triangle tiles are through, the loss is summed behind the last tile)
  * instead of a launch of its own: same outputs, bit for bit.  tail->finalized = 1 when the launch did it (fused route
  * with the culled Chamfer tiles, nf + num + n_gt <= ~11 700 per mesh, at most (CUs / 4) meshes); 0: call
- * geom_surface_finalize_f32 as usual.  A role that waits in vain gives up after ~2 s and *loss comes out as NaN. */
+ * geom_surface_finalize_f32 as usual.
+ * FAIL-SAFE: the roles wait inside the launch for tiles of the same launch (HIP promises no forward progress between
+ * workgroups; the host admits the tail only where every workgroup of the launch is resident).  A role that waits in vain
+ * gives up after ~2 s: *loss comes out as NaN, the role reads NOTHING of the incomplete results, and its status word at the
+ * end of order_scratch (int32 [b + 1] at word geom_surface_order_words(b, nf, num, n_gt) - ((b + 4) & ~3): 0 = complete)
+ * is set -- geom_surface_gather_f32 then writes NaN gradients for that mesh (for every mesh when the loss role gave up)
+ * instead of walking a half-built order.  After such a launch the completion counters in `workspace` are undefined: run
+ * geom_surface_prepare_f32 (which zeroes them) or zero them before the next tail launch on the same workspace. */
 size_t geom_surface_tail_counters_offset(int b, int n_gt, int nf); /* byte offset of the tail's completion counters in the
                                                                      * scan workspace (tests of the give-up path); 0: none */
 typedef struct geom_surface_tail {

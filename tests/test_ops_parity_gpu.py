@@ -1463,31 +1463,59 @@ def test_finalize_tail_of_the_scan_launch_equals_the_separate_launch(gpu, culled
 
 def test_finalize_roles_give_up_instead_of_hanging(gpu):
     """A role workgroup of the fused scan launch waits on a completion counter; if the count can never be reached (here: a
-    counter knocked 100 below zero between the prepare launch and the scan) it gives up after ~2 M polls and the launch's
-    loss comes out as NaN -- the device is not hung, and the next call (fresh workspace) is fine."""
+    counter knocked 100 below zero between the prepare launch and the scan) it gives up after ~2 M polls: the launch's loss
+    comes out as NaN, the role reads nothing of the incomplete results and marks its status word, and the BACKWARD writes
+    NaN for that mesh's vertices -- never a walk through a half-built order -- while the meshes whose roles got through keep
+    the gradient the separate launch gives, bit for bit.  The device is not hung; the next forward notices the status
+    (no synchronisation: a pinned copy) and switches the roles off for the rest of the process, with a warning; results
+    from then on are the separate launch's."""
     import time
+    import warnings
     from geometrics_amd import _lib
     V, Fc = meshgen.icosphere(4)
     B, num = 8, 3000
-    verts = dev(meshgen.jittered_batch(V, B), gpu)
+    verts = dev(meshgen.jittered_batch(V, B), gpu).requires_grad_(True)
     faces, gt = dev(Fc, gpu), dev(meshgen.gt_cloud(B, num), gpu)
     gi = ops.GtIndex(gt)
     off = _lib.lib().geom_surface_tail_counters_offset(B, num, Fc.shape[0])
     assert off > 0 and off % 4 == 0
-    ops.manual_seed(9)
-    d = ops.draw_samples(verts, faces, num, with_points=True, prepare_scan_for=num, gt_index=gi)
-    assert isinstance(d[4], ops.ScanPrep)
-    counters = d[4].tri_ws.view(torch.int32)[off // 4:]
-    assert int(counters[::32][:2 * B + 1].abs().sum()) == 0          # zeroed by the prepare launch
-    counters[3 * 32] = -100                                          # mesh 3's triangle tiles can never reach their count
-    torch.cuda.synchronize()
-    t0 = time.time()
-    loss, _, _ = ops.SurfaceLoss.apply(verts, faces, gt, d[0], d[1], d[2], False, 3000.0, d[3], d[4], None, gi)
-    assert bool(torch.isnan(loss))                                   # said loudly
-    assert time.time() - t0 < 60
-    ops.manual_seed(9)
-    assert bool(torch.isfinite(utils.batch_point_to_surface(verts, {"faces": faces}, gt, num=num, gt_index=gi)))
-    ops.manual_seed(0, gpu)
+    assert ops.scan_finalize_tail and not ops.finalize_roles_gave_up()
+    try:
+        ops.manual_seed(9)
+        d = ops.draw_samples(verts, faces, num, with_points=True, prepare_scan_for=num, gt_index=gi)
+        assert isinstance(d[4], ops.ScanPrep)
+        counters = d[4].tri_ws.view(torch.int32)[off // 4:]
+        assert int(counters[::32][:2 * B + 1].abs().sum()) == 0          # zeroed by the prepare launch
+        counters[3 * 32] = -100                                          # mesh 3's triangle tiles can never reach their count
+        torch.cuda.synchronize()
+        t0 = time.time()
+        loss, _, _ = ops.SurfaceLoss.apply(verts, faces, gt, d[0], d[1], d[2], False, 3000.0, d[3], d[4], None, gi)
+        assert bool(torch.isnan(loss))                                   # said loudly
+        assert time.time() - t0 < 60
+        loss.backward(torch.ones((), device=gpu))                        # (a finite seed: the NaN below is the kernel's own)
+        g = verts.grad.clone()
+        assert bool(torch.isnan(g).all())                                # the loss role gave up as well: every mesh is NaN, none is garbage
+        torch.cuda.synchronize()
+        # the next forward sees the status words of the last one and falls back to the separate finalize launch
+        verts.grad = None
+        ops.manual_seed(9)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            after = utils.batch_point_to_surface(verts, {"faces": faces}, gt, num=num, gt_index=gi)
+            after.backward()
+        assert bool(torch.isfinite(after)) and bool(torch.isfinite(verts.grad).all())
+        assert ops.finalize_roles_gave_up() and not ops.scan_finalize_tail
+        assert any("gave up" in str(w.message) for w in caught)
+        # ... with the results of the separate launch (= of the roles when they get through: tested above)
+        verts.grad = None
+        ops.manual_seed(9)
+        again = utils.batch_point_to_surface(verts, {"faces": faces}, gt, num=num, gt_index=gi)
+        assert torch.equal(again, after)
+    finally:
+        ops.scan_finalize_tail = True
+        ops._roles_gave_up = False
+        ops._roles_watch.clear()
+        ops.manual_seed(0, gpu)
 
 
 def test_the_timed_route_against_the_oracle_at_the_config5_shard(gpu):
