@@ -281,7 +281,8 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     fin = lambda b, order, loss: L.geom_surface_finalize_f32(b, 8, 4, None, None, None, None, 4, None, None, None, None, None, None,
                                                              p, p, 1.0, 1.0, 1.0, 1.0, 0, 0, order, loss, None)
     assert fin(1, None, p) == -1 and fin(1, p16, None) == -1 and fin(-1, p16, p) == -1 and fin(0, p16, p) == 0
-    assert L.geom_surface_order_words(2, 10, 5, 7) == ((2 * 11 + 3 * 2 * 12 + 3) // 4 * 4) + 2 * 12 * 8
+    # off | seg | pface | slot (padded to 4 words) | two float4 records per point | status words [b + 1] (padded to 4)
+    assert L.geom_surface_order_words(2, 10, 5, 7) == ((2 * 11 + 3 * 2 * 12 + 3) // 4 * 4) + 2 * 12 * 8 + 4
     assert L.geom_surface_gather_f32(1, 4, 8, None, None, 4, 4, 1, None, None, None, None) == -1
     assert L.geom_surface_gather_f32(0, 4, 8, None, None, 4, 4, 1, None, None, None, None) == 0
     assert L.geom_adam_step_f32(_lib.ADAM_MAX_TENSORS + 1, None, None, None, None, None, 1e-3, .9, .999, 1e-8, 1.0, None, 1, None) == -2   # > 64 tensors per launch
