@@ -170,8 +170,14 @@ def lib():
                 "geometrics_amd: %s is missing -- build it with `python -m geometrics_amd.build` "
                 "(hipcc, gfx950). There is no CPU/PyTorch fallback." % LIB_PATH)
         _refuse_stale_library()
-        # GEOM_LIB_OVERRIDE: an instrumented build of the same sources (tools/probe: tile stamps, counters) -- never the product
-        L = ctypes.CDLL(os.environ.get("GEOM_LIB_OVERRIDE") or LIB_PATH)
+        # GEOM_LIB_OVERRIDE: an instrumented build of the same sources (tools/probe: tile stamps, counters) -- never the product.
+        # Said loudly: a variable that leaks into a training environment would put a probe build behind production calls.
+        override = os.environ.get("GEOM_LIB_OVERRIDE")
+        if override:
+            import sys
+            print("geometrics_amd: GEOM_LIB_OVERRIDE is set -- loading %s instead of the product library (probe builds only; "
+                  "its ABI version is checked, its sources are not)" % override, file=sys.stderr)
+        L = ctypes.CDLL(override or LIB_PATH)
         L.geom_abi_version.restype = _i
         L.geom_strerror.restype = ctypes.c_char_p
         L.geom_strerror.argtypes = [_i]

@@ -244,7 +244,7 @@ class deferred_parameter_gradients:
 # its collective waits for, so that the all-reduce travels while the product runs.  Same safeguards as the other deferrals
 # (leaf without hooks or an existing .grad, a single consumer, an engine-run pass); opt-in, nothing else uses it.
 late_input_gradient_products = False
-_pending_late = {}        # autograd graph-task id -> [(g2, w2, grad_x alias, stream, input ref)]
+_pending_late = {}        # autograd graph-task id -> [(g2, w2, product buffer, stream, input ref)]
 parameter_gradients_ready = []   # callables run by the end-of-pass callback right after the reduction launch(es)
 
 
@@ -278,14 +278,19 @@ class late_input_gradients:
 
 
 def _may_postpone_input_gradient(x):
-    """A leaf nobody can observe before backward() returns: no hooks, no gradient to accumulate into, an engine-run
-    first-order pass, deferral of the parameter gradients active (the flush this rides on)."""
+    """A leaf whose gradient nobody observes before backward() returns: no tensor hooks (they would not see the postponed
+    part), an engine-run first-order pass, deferral of the parameter gradients active (the flush this rides on).  The
+    postponing node returns NO gradient for the leaf to the engine; the end-of-pass callback launches the product into a
+    buffer of its own and then SETS the leaf's .grad to it -- or adds it to what is there: whatever other consumers of the
+    leaf contributed through the engine during the pass (or an earlier pass left behind) is kept, so any number of
+    consumers is correct.  (Round 4 handed the engine the not-yet-written buffer instead; a second consumer's gradient was
+    added to uninitialised memory and then overwritten: round-4 advice.)  Only under .backward(): torch.autograd.grad(...,
+    inputs=[leaf]) collects what the ENGINE carries and fails loudly ("not used in the graph") for such a leaf."""
     if not (late_input_gradient_products and defer_parameter_gradients) or not hasattr(torch._C, "_current_graph_task_id"):
         return False
     if torch._C._current_graph_task_id() < 0 or torch.is_grad_enabled():
         return False
-    return (x.is_leaf and x.grad is None and not x._backward_hooks
-            and not getattr(x, "_post_accumulate_grad_hooks", None))
+    return (x.is_leaf and not x._backward_hooks and not getattr(x, "_post_accumulate_grad_hooks", None))
 
 
 _late_collect = [None]
@@ -302,15 +307,21 @@ def _flush_late(task):
     for hook in list(parameter_gradients_ready):
         hook()
     for g2, w2, out, stream, x_ref in _pending_late.pop(task, []):
-        launch = _late_product(g2, w2, out, stream)
-        if _late_collect[0] is None:
-            launch()
-            _check_landed(x_ref, out)
-            continue
-        _late_collect[0].append(launch)
+        jobs = [_late_product(g2, w2, out, stream)]
         x = x_ref()
-        if x is not None and x.grad is not None and x.grad.data_ptr() != out.data_ptr():      # the engine kept a clone
-            _late_collect[0].append(lambda x=x, out=out: x.grad.copy_(out.view_as(x.grad)))
+        if x is not None:
+            if x.grad is None:
+                x.grad = out.view(x.shape)       # the product's own buffer becomes the leaf's gradient: no copy
+            else:                                # other consumers of the leaf (or an earlier pass) were there first: add
+                def add(x=x, out=out, stream=stream):
+                    with torch.cuda.stream(stream), torch.no_grad():
+                        x.grad.add_(out.view_as(x.grad))
+                jobs.append(add)
+        if _late_collect[0] is None:
+            for job in jobs:
+                job()
+        else:
+            _late_collect[0].extend(jobs)
 
 
 _pending_colsums = {}     # autograd graph-task id -> [(partials, rows, cols, out alias, stream)]
@@ -842,8 +853,10 @@ class _DenseMM(torch.autograd.Function):
             _dense_kernels.backward_pair(x2, g2, w2, grad_x.view(rows, cin), ws)
         else:
             if need_x and _may_postpone_input_gradient(x):
-                grad_x = torch.empty_like(x)      # written by the end-of-pass callback, behind the reduction launch
-                late = (g2, w2, _alias(grad_x).view(rows, cin), torch.cuda.current_stream(x.device), weakref.ref(x))
+                # no gradient for x through the engine: the end-of-pass callback launches the product behind the reduction
+                # launch and makes its buffer the leaf's .grad (_flush_late)
+                late = (g2, w2, torch.empty(rows, cin, dtype=x.dtype, device=x.device), torch.cuda.current_stream(x.device),
+                        weakref.ref(x))
             elif need_x:
                 grad_x = torch.matmul(g2, w2.t()).view(x.shape)
             _dense_kernels.backward_weight_partials(x2, g2, ws)

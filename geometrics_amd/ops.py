@@ -177,6 +177,9 @@ class GtIndex:
         self.index = torch.empty(max(int(_lib.lib().geom_nn_cull_index_floats(b, n)), 4), dtype=torch.float32, device=gt.device)
         self.shape, self.device = (b, n), gt.device
         self.source = (gt.data_ptr(), gt._version)
+        # the index HOLDS the cloud's memory: while it lives the allocator cannot hand that address to another cloud (a
+        # recycled address at version 0 would pass the check below and be scanned through the OLD cloud's index)
+        self._cloud = gt
         with torch.cuda.device(gt.device):
             _lib.call("geom_nn_cull_index_f32", b, n, gt.data_ptr(), order.data_ptr(), self.index.data_ptr())
 

@@ -801,6 +801,26 @@ def test_late_input_gradient_is_the_same_product_issued_behind_the_reduction_lau
     assert torch.equal(seen[0], now_x) and torch.equal(hook_x, now_x)
     acc_x, _ = run(True, lambda: setattr(x, "grad", torch.ones_like(x)))     # accumulation reads it at once too
     assert torch.equal(acc_x, now_x + 1.0)
+    # (round-4 advice) a leaf with SEVERAL consumers: the postponing node gives the engine no gradient for the leaf at all;
+    # the end-of-pass callback adds its product to whatever the other consumers contributed through the engine
+    twin = layers.Batch_Image_ZERON_GCNGCN(963, 192).to(gpu)
+
+    def both(late):
+        x.grad = None
+        for p_ in list(stack.parameters()) + list(twin.parameters()):
+            p_.grad = None
+        with layers.deferred_parameter_gradients(), layers.late_input_gradients(enabled=late):
+            (stack[0](x, adj, F.relu) + twin(x, adj, F.relu)).backward(g_out)
+        return x.grad.clone()
+    close(both(True).cpu().numpy(), both(False).cpu().numpy(), 1e-6)     # (two postponed products are added in another order)
+
+    def with_torch_op(late):                              # ... and a consumer this module cannot see: a plain torch op on the leaf
+        x.grad = None
+        with layers.deferred_parameter_gradients(), layers.late_input_gradients(enabled=late):
+            ((stack[0](x, adj, F.relu) * g_out).sum() + (x * 2.0).sum()).backward()
+        return x.grad.clone()
+    close(with_torch_op(True).cpu().numpy(), with_torch_op(False).cpu().numpy(), 1e-6)
+    assert float((with_torch_op(True) - 2.0).abs().max()) > 0.0 and not layers._pending_late
 
 
 def test_weight_gradients_of_equal_layers_come_from_one_batched_product(gpu):
