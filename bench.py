@@ -51,8 +51,19 @@ PROFILE_TAG = "r04"           # the committed profiles these figures are read fr
 PMC_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_counters.json")
 
 
+DP_SEQUENCE_DEFAULT = "captured"
+
+
 class Workload:
-    def __init__(self, dev, first_mesh, batch, seed=3041, force_dp=False, activation=F.relu, lr=1e-4):
+    def __init__(self, dev, first_mesh, batch, seed=3041, force_dp=False, activation=F.relu, lr=1e-4, dp_sequence=None):
+        # N > 1 only: "two_graphs" (graph A, the collective issued by the host between the replays, graph B beside it) or
+        # "captured" (ONE graph per step with the collective inside it, on RCCL's stream forked off the capture: one replay per
+        # step, the two cross-stream dependencies become graph edges) -- GEOM_DP_SEQUENCE; measured in profiles/r05_dp_fixed_cost.txt
+        self.dp_sequence = dp_sequence or os.environ.get("GEOM_DP_SEQUENCE", DP_SEQUENCE_DEFAULT)
+        if self.dp_sequence not in ("two_graphs", "captured"):
+            raise ValueError("dp_sequence must be 'two_graphs' or 'captured'")
+        if torch.distributed.is_initialized() and torch.distributed.get_backend() != "nccl":
+            self.dp_sequence = "two_graphs"     # only RCCL's collectives can be captured (the gloo test hook blocks the host)
         self.act = activation          # the reference's F.relu (GEOMetrics.py); F.elu only in the smooth-activation parity test
         V, Fc = meshgen.icosphere(V_LEVEL)
         self.batch, self.nv, self.nf = batch, V.shape[0], Fc.shape[0]
@@ -224,6 +235,34 @@ class Workload:
         if not self.pending:
             raise RuntimeError("capture() of a data-parallel step needs at least one warm-up step: the captured step opens "
                                "with the Adam update of the step before it")
+        if self.dp_sequence == "captured":
+            # ONE graph: [Adam of the previous step, forward, backward, reduction launch -> bucket, all-reduce on RCCL's stream
+            # (forked off the capture behind the reduction launch), the postponed product beside it, join]
+            g = torch.cuda.CUDAGraph()
+            cap = torch.cuda.Stream()
+            cap.wait_stream(torch.cuda.current_stream())
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            try:
+                with torch.cuda.stream(cap):
+                    g.capture_begin(capture_error_mode="relaxed")
+                    try:
+                        self.forward_backward()
+                        self.exchange()
+                    finally:
+                        g.capture_end()
+                torch.cuda.current_stream().wait_stream(cap)
+                self.pending = True       # capturing executed nothing: the update at the head of the graph is still owed
+                self.graphs = (g,)
+                return
+            except Exception as exc:      # a stack whose collective cannot be captured: the two-graph sequence, said loudly
+                print("bench.py: the collective could not be captured into the step graph (%s: %s); two graphs per step with "
+                      "the all-reduce between them" % (type(exc).__name__, str(exc)[:200]), file=sys.stderr)
+                from geometrics_amd import _lib
+                _lib.clear_hip_error()
+                torch.cuda.synchronize()
+                self.dp_sequence, self.pending, self.work = "two_graphs", True, None
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
@@ -255,7 +294,7 @@ class Workload:
             self.step()
         else:
             self.graphs[0].replay()
-            if self.dp:
+            if self.dp and len(self.graphs) == 2:
                 self.exchange(self.graphs[1])
 
 
@@ -990,10 +1029,13 @@ def main():
                        "meshes_per_gpu": per_gpu, "global_batch": per_gpu * world, "parallelism": "dp%d" % world,
                        "launch": launch, "gemm_selection": "tunableop file" if tuned else "library default",
                        "clock_warmup_ms": args.clock_warmup_ms,
-                       "dp_sequence": None if world == 1 else
-                       "per step: graph A [Adam on the bucket the previous step all-reduced, forward, backward, reduction launch "
-                       "-> bucket] ; ONE async all-reduce (gradients + loss, 1.04 MB) beside graph B [first layer's input "
-                       "gradient] ; the launch stream waits for the collective"},
+                       "dp_sequence": None if world == 1 and not force_dp else
+                       ("per step ONE graph: [Adam on the bucket the previous step all-reduced, forward, backward, reduction launch "
+                        "-> bucket, the all-reduce (gradients + loss, 1.04 MB) on RCCL's stream inside the capture, the first layer's "
+                        "input gradient beside it, join]" if w.dp_sequence == "captured" else
+                        "per step: graph A [Adam on the bucket the previous step all-reduced, forward, backward, reduction launch "
+                        "-> bucket] ; ONE async all-reduce (gradients + loss, 1.04 MB) beside graph B [first layer's input "
+                        "gradient] ; the launch stream waits for the collective")},
             "final_loss": round(w.mean_loss(), 6),
         }
         if not args.steps_only:

@@ -49,7 +49,7 @@ def run(rank, world, port, total_meshes, steps, out, activation="relu", lr=1e-4)
         torch.distributed.destroy_process_group()
 
 
-def run_rccl_single(port, total_meshes, steps, out):
+def run_rccl_single(port, total_meshes, steps, out, sequence="two_graphs"):
     """ONE rank, backend "nccl" (= RCCL) on cuda:0, bench.Workload forced onto its N > 1 sequence: graph A (Adam of the
     previous step, forward, backward, reduction launch -> bucket) -> RCCL all-reduce of the flat bucket from the side
     stream, beside graph B (the first layer's postponed input gradient)."""
@@ -62,10 +62,14 @@ def run_rccl_single(port, total_meshes, steps, out):
     torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1)
     assert torch.distributed.get_backend() == "nccl"
     gemm_tuning.enable()
-    wl = bench.Workload(dev, 0, total_meshes, force_dp=True)
+    wl = bench.Workload(dev, 0, total_meshes, force_dp=True, dp_sequence=sequence)
     assert wl.bucket is not None and wl.bucket.force
     wl.capture()
-    assert len(wl.graphs) == 2 and wl.graphs[1] is not None and wl.pending   # graph A opens with the Adam step still owed; B = the postponed product
+    assert wl.dp_sequence == sequence and wl.pending                  # (a captured sequence that fell back would say so here)
+    if sequence == "two_graphs":
+        assert len(wl.graphs) == 2 and wl.graphs[1] is not None       # graph A opens with the Adam step still owed; B = the postponed product
+    else:
+        assert len(wl.graphs) == 1                                    # the collective is a node of the step's one graph
     losses = []
     for _ in range(steps):
         wl.run()

@@ -38,6 +38,24 @@ def test_bench_gpus_2_typed_without_a_launcher_spawns_its_ranks(gpu):
     assert "all-reduce over 2 ranks" in line["config"]["workload"]
 
 
+@pytest.mark.timeout(900)
+def test_bench_gpus_8_rehearsal_with_eight_ranks_on_one_gpu(gpu):
+    """What the driver will type on an 8-GPU node, rehearsed on one: `python bench.py --gpus 8` spawns EIGHT ranks (free
+    port, teardown by PID), each builds its 8-mesh shard of BASELINE config 5's 64 meshes, captures its step graphs and reads
+    the TunableOp selections concurrently; the collective spans all eight (`ranks_seen`), the line reports the whole job.
+    The ranks share cuda:0 and gloo carries the all-reduce (GEOM_DIST_BACKEND hook: RCCL needs a GPU per rank), so the
+    numbers mean nothing -- the plumbing is what must not fail the first time eight GPUs are there."""
+    line = _run(["--gpus", "8", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--steps-only", "--clock-warmup-ms", "0"],
+                {"GEOM_DIST_BACKEND": "gloo"}, timeout=840)
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8
+    assert line["config"]["global_batch"] == 64 and line["config"]["meshes_per_gpu"] == 8 and line["config"]["parallelism"] == "dp8"
+    assert line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
+    r = line["ms_per_step_ranks"]
+    assert r["min"] <= r["rank0"] <= r["max"] == line["ms_per_step"]
+    assert "all-reduce over 8 ranks" in line["config"]["workload"]
+    assert line["config"]["dp_sequence"].startswith("per step: graph A")      # gloo cannot be captured: the two-graph sequence
+
+
 @pytest.mark.timeout(600)
 def test_bench_single_gpu_line_has_the_contract_fields(gpu):
     line = _run(["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--steps-only", "--clock-warmup-ms", "0"])
@@ -64,6 +82,7 @@ def test_bench_whole_n_gt_1_path_with_rccl_on_one_gpu(gpu):
     (the probes capture thread-locally, so that the watchdog's event polling cannot invalidate their captures)."""
     line = _run(["--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--clock-warmup-ms", "0"], {"GEOM_BENCH_FORCE_DP": "1"})
     assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and "forced_dp" in line["config"]
+    assert line["config"]["dp_sequence"].startswith("per step ONE graph")     # the collective was captured into the step graph
     assert line["config"]["launch"] == "hipgraph" and line["value"] > 0
     assert line.get("roofline_error") is None and line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
     assert "surface_scan_kernel (both arg-min scans of the surface loss)" in line["other_kernels"]

@@ -98,6 +98,25 @@ def test_two_rank_relu_step_tracks_the_single_process_16_mesh_step_up_to_relu_un
 
 
 @pytest.mark.timeout(600)
+def test_rccl_all_reduce_captured_inside_the_step_graph_equals_the_single_graph_step(gpu):
+    """The sequence an N > 1 job runs since round 5: ONE graph per step with the RCCL all-reduce INSIDE it (issued while the
+    step is captured: RCCL's stream is forked off the capture behind the reduction launch and joined behind the postponed
+    input-gradient product) -- one replay per step instead of replay / collective / replay / wait.  1-rank group with backend
+    "nccl" on cuda:0 (the sum is the identity): parameters, gradients and losses of 5 replayed steps equal the plain
+    single-graph step bit for bit, i.e. the captured collective is ordered behind the launch that fills the bucket and in
+    front of the Adam step that reads it."""
+    port = _free_port()
+    rccl = _collect(dist_step_worker.run_rccl_single, lambda n: [(port, 8, 5)], 1, ("captured",))
+    port2 = _free_port()
+    plain = _collect(dist_step_worker.run, lambda n: [(0, 1, port2, 8, 5)], 1)
+    assert rccl["steps_taken"] == plain["steps_taken"] == 5 + WARM
+    assert rccl["overlap"]
+    assert rccl["losses"] == plain["losses"]
+    np.testing.assert_array_equal(rccl["grads"], plain["grads"])
+    np.testing.assert_array_equal(rccl["params"], plain["params"])
+
+
+@pytest.mark.timeout(600)
 def test_rccl_all_reduce_between_the_two_graph_replays_equals_the_single_graph_step(gpu):
     """RCCL itself, once: a 1-rank process group with backend "nccl" on cuda:0 and bench.Workload forced onto its N > 1
     sequence (graph A: Adam of the previous step on the bucket views (grad_scale = 1), forward, backward, reduction launch
@@ -106,7 +125,7 @@ def test_rccl_all_reduce_between_the_two_graph_replays_equals_the_single_graph_s
     will run and what the gloo tests cannot exercise (gloo blocks the host); with one
     rank the sum is the identity, so parameters, gradients and losses must equal the plain single-graph step bit for bit."""
     port = _free_port()
-    rccl = _collect(dist_step_worker.run_rccl_single, lambda n: [(port, 8, 5)], 1)
+    rccl = _collect(dist_step_worker.run_rccl_single, lambda n: [(port, 8, 5)], 1, ("two_graphs",))
     port2 = _free_port()
     plain = _collect(dist_step_worker.run, lambda n: [(0, 1, port2, 8, 5)], 1)
     assert rccl["steps_taken"] == plain["steps_taken"] == 5 + WARM

@@ -1,7 +1,7 @@
-"""The N > 1 step sequence on ONE GPU (1-rank RCCL group): graph A = [Adam on the bucket the previous step all-reduced,
-forward, backward, reduction launch -> bucket], the RCCL all-reduce issued from a side stream, graph B = [first layer's
-input gradient] beside it.  Prints ms per step beside the N = 1 single-graph step -- the fixed
-cost the data-parallel path adds before any link time.  GPU box only:  python tools/time_force_dp.py"""
+"""The N > 1 step sequences on ONE GPU (1-rank RCCL group) beside the N = 1 single-graph step: "two_graphs" (graph A, the
+all-reduce issued by the host, graph B beside it) and "captured" (one graph per step with the collective inside it) -- the
+fixed cost the data-parallel path adds before any link time (profiles/r05_dp_fixed_cost.txt).
+GPU box only:  python tools/time_force_dp.py"""
 import os
 import sys
 import time
@@ -16,10 +16,19 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1)
 gemm_tuning.enable()
-for force in (False, True):
-    wl = bench.Workload(dev, 0, 8, force_dp=force)
-    wl.capture()
-    t = bench.time_steps(wl.run, 300, 30)
-    print("force_dp=%s: %d graph(s), overlap=%s, %.4f ms per step" % (force, len(wl.graphs), bool(wl.dp and wl.graphs[1] is not None and not wl.packed_late),
-                                                                      t / 300 * 1e3), flush=True)
+for rep in range(2):
+    for force, seq in ((False, None), (True, "two_graphs"), (True, "captured")):
+        wl = bench.Workload(dev, 0, 8, force_dp=force, dp_sequence=seq)
+        try:
+            wl.capture()
+        except Exception as exc:
+            print("force_dp=%s %s: capture failed: %s: %s" % (force, seq, type(exc).__name__, str(exc)[:200]), flush=True)
+            from geometrics_amd import _lib
+            _lib.clear_hip_error()
+            continue
+        t = bench.time_steps(wl.run, 300, 30)
+        wl.finish()
+        print("force_dp=%-5s %-10s: %d graph(s) per step, %.4f ms per step, loss %.6f" % (force, seq or "-", len(wl.graphs), t / 300 * 1e3, wl.mean_loss()),
+              flush=True)
+        del wl
 torch.distributed.destroy_process_group()
