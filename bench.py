@@ -778,6 +778,132 @@ def training_shape_times(dev, batch=16):
                                   if csr.ell_w else "generic CSR"}
 
 
+def driver_step_times(dev, batch=16, profile_replays=0):
+    """The step the reference's driver really runs (GEOMetrics.py:110-174) at its own sizes: batch 16 on the 482-vertex /
+    960-face template (meshgen.uv_sphere: the size and the two 32-neighbour poles of 482.obj), three poolings from four
+    feature maps each (64x56^2, 128x28^2, 256x14^2, 512x7^2 -- what the three VGG encoders return; they are inputs here: the
+    encoders are the reference's torch/MIOpen code and out of scope), three deformation blocks 963 / 1155 / 1155 -> 192 x 13
+    -> 3, three surface losses (3000 sampled vs 3000 gt points), the edge and Laplacian terms, backward to every parameter
+    and feature map, Adam over all ~170 parameter tensors.  HIP-graph replay bracketed by HIP events.  The F1 bookkeeping
+    of GEOMetrics.py:137 (monitoring, synchronises the host) is not part of the captured step.
+    profile_replays > 0: only replay the captured step that many times (tools/profile_driver_step.py under rocprofv3)."""
+    from geometrics_amd import models
+    V, Fc = meshgen.uv_sphere()
+    nv = V.shape[0]
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    faces = to(Fc)
+    info = utils.adj_init(faces)
+    initial = to(V)
+    gt = to(meshgen.gt_cloud(batch, G_PTS, first=700))
+    torch.manual_seed(3041)
+    blocks = [models.BatchMeshDeformationBlock(c, nv).to(dev).train() for c in (963, 1155, 1155)]
+    maps = [[torch.randn(batch, c, d, d, device=dev, requires_grad=True) for c, d in ((64, 56), (128, 28), (256, 14), (512, 7))]
+            for _ in range(3)]
+    img_info = torch.tensor([[30.0 + 10 * i, 25.0, 1.1] for i in range(batch)], device=dev)
+    params = [p for m in blocks for p in m.parameters()]
+    opt = optim.FusedAdam(params, lr=1e-4)
+    gt_index = ops.GtIndex(gt) if CULLED_CHAMFER else None
+    lap = utils.batch_get_lap_info
+
+    def predict():
+        base = initial.unsqueeze(0).expand(batch, nv, 3)
+        f = utils.batched_pooling(maps[0], base, img_info.clone())
+        f, p1 = blocks[0](base, f, info["adj"])
+        p1 = base + p1
+        f = torch.cat((f, utils.batched_pooling(maps[1], p1.clone(), img_info.clone())), dim=-1)
+        f, p2 = blocks[1](p1.clone(), f, info["adj"])
+        p2 = p2 + p1
+        f = torch.cat((f, utils.batched_pooling(maps[2], p2.clone(), img_info.clone())), dim=-1)
+        _, p3 = blocks[2](p2.clone(), f, info["adj"])
+        return p1, p2, p3 + p2
+
+    def losses(p1, p2, p3):
+        surf = lambda p: utils.batch_point_to_surface(p.clone(), info, gt, num=S_PTS, gt_index=gt_index)
+        surface = surf(p1) * .2 + surf(p2) * .2 + surf(p3) * 2
+        edge = (utils.batch_calc_edge(p1.clone(), info) + utils.batch_calc_edge(p2.clone(), info) + utils.batch_calc_edge(p3.clone(), info)) * 300
+        l1 = torch.mean(torch.sum((lap(initial, info) - lap(p1, info)) ** 2, 2)) * 1500
+        l2 = torch.mean(torch.sum((lap(p1, info) - lap(p2, info)) ** 2, 2)) * 1500 + torch.mean(torch.sum((p1 - p2) ** 2, 2)) * 100
+        l3 = torch.mean(torch.sum((lap(p2, info) - lap(p3, info)) ** 2, 2)) * 1500 + torch.mean(torch.sum((p2 - p3) ** 2, 2)) * 100
+        return edge + surface + .2 * (l1 * .3 + l2 + l3)
+
+    def zero():
+        opt.zero_grad()
+        for group in maps:
+            for m in group:
+                m.grad = None
+
+    last = {}
+
+    def step():
+        zero()
+        with layers.deferred_parameter_gradients():
+            loss = losses(*predict())
+            loss.backward()
+        opt.step()
+        last["loss"] = loss.detach()
+
+    if profile_replays:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            step()
+        for _ in range(profile_replays):
+            g.replay()
+        torch.cuda.synchronize()
+        return {"final_loss": float(last["loss"])}
+
+    t_step = event_time_us(step, iters=5, warm=3)
+    final = float(last["loss"])
+    # stages in isolation (forward + backward of each on the step's own tensors; they do not add up to the step: the step's
+    # stages share launches -- one end-of-pass reduction, one Adam launch per 64 tensors)
+    base = initial.unsqueeze(0).expand(batch, nv, 3).contiguous()
+    pos = (base + 0.01 * torch.randn_like(base)).requires_grad_(True)
+
+    def pool_fb():
+        zero()
+        pos.grad = None
+        utils.batched_pooling(maps[1], pos, img_info.clone()).sum().backward()
+    feats = [torch.randn(batch, nv, c, device=dev, requires_grad=True) for c in (960, 1152)]   # + the 3 coordinates the block prepends
+
+    def block_fb(i):
+        def run():
+            zero()
+            feats[min(i, 1)].grad = None
+            with layers.deferred_parameter_gradients():
+                f, c = blocks[i](base, feats[min(i, 1)], info["adj"])
+                (f.sum() + c.sum()).backward()
+        return run
+
+    def surf_fb():
+        pos.grad = None
+        utils.batch_point_to_surface(pos, info, gt, num=S_PTS, gt_index=gt_index).backward()
+
+    def reg_fb():
+        pos.grad = None
+        (utils.batch_calc_edge(pos, info) * 300 + torch.mean(torch.sum((lap(initial, info) - lap(pos, info)) ** 2, 2)) * 1500).backward()
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    stages = {"one batched_pooling (4 maps) fwd+bwd": event_time_us(pool_fb, iters=5, warm=2),
+              "deformation block 963-192x13-3 fwd+bwd": event_time_us(block_fb(0), iters=5, warm=2),
+              "deformation block 1155-192x13-3 fwd+bwd": event_time_us(block_fb(1), iters=5, warm=2),
+              "one surface loss fwd+bwd": event_time_us(surf_fb, iters=10, warm=2),
+              "edge + Laplacian terms of one stage fwd+bwd": event_time_us(reg_fb, iters=10, warm=2),
+              "Adam over %d tensors" % len(params): event_time_us(lambda: opt.step(), iters=10, warm=2)}
+    return {"workload": "the driver's own step (GEOMetrics.py:110-174): batch %d, %d vertices / %d faces, 3 x pooling of 4 feature maps, "
+                        "deformation blocks 963 / 1155 / 1155 -> 192 x 13 -> 3, 3 surface losses (3000 vs 3000 points), edge + "
+                        "Laplacian terms, backward, Adam over %d tensors; HIP-graph replay; image encoders and the F1 "
+                        "bookkeeping not included" % (batch, nv, Fc.shape[0], len(params)),
+            "ms_per_step": round(t_step / 1e3, 4), "meshes_per_s": round(batch / (t_step * 1e-6), 1), "final_loss": round(final, 5),
+            "stages_us": {k: round(v, 1) for k, v in stages.items()}}
+
+
 def whole_batch_times(dev, meshes=64, steps=20, warmup=5):
     """BASELINE config 5's WHOLE batch (64 meshes) on this one GPU, same step, HIP-graph replay: the strong-scaling anchor
     for the 8-GPU target (64 meshes / 8 GPUs = the 8-mesh shard that `value` is quoted on).  Reported beside the headline."""
@@ -1027,7 +1153,7 @@ def main():
                                    % (per_gpu, "flat-bucket grad all-reduce over %d ranks (%s), " % (world, torch.distributed.get_backend())
                                       if world > 1 else "single process (no collective), "),
                        "meshes_per_gpu": per_gpu, "global_batch": per_gpu * world, "parallelism": "dp%d" % world,
-                       "launch": launch, "gemm_selection": "tunableop file" if tuned else "library default",
+                       "launch": launch, "gemm_selection": gemm_tuning.status,
                        "clock_warmup_ms": args.clock_warmup_ms,
                        "dp_sequence": None if world == 1 and not force_dp else
                        ("per step ONE graph: [Adam on the bucket the previous step all-reduced, forward, backward, reduction launch "
@@ -1059,6 +1185,7 @@ def main():
         if world == 1 and not force_dp and not args.steps_only:
             extra("components_us", lambda: component_times(w))
             extra("reference_training_shape", lambda: training_shape_times(dev))
+            extra("driver_step", lambda: driver_step_times(dev))
             extra("whole_batch_single_gpu", lambda: whole_batch_times(dev))
         if world == 1 and not args.no_cpu_baseline:
             extra("cpu_baseline", cpu_baseline)

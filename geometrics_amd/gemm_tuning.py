@@ -21,9 +21,17 @@ import torch
 TUNING_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "tunableop_gfx950.csv")
 
 
+# what the last enable() did: "tunableop file" | "library default (no tuning file)" | "library default (tuning file rejected)"
+status = "library default (enable() not called)"
+
+
 def enable(filename=TUNING_FILE):
-    """Use the recorded GEMM selections.  Returns True when the file was found and loaded."""
+    """Use the recorded GEMM selections.  Returns True when the file was found and loaded; `status` says which of the three
+    outcomes it was (bench.py prints it as config.gemm_selection; a rejected file is a ~2x slower library product, so
+    tests/test_bench_contract_gpu.py asserts that the shipped file loads on the GPU box)."""
+    global status
     if not (torch.cuda.is_available() and os.path.exists(filename)):
+        status = "library default (no tuning file)"
         return False
     tun = torch.cuda.tunable
     tun.enable(True)
@@ -43,7 +51,9 @@ def enable(filename=TUNING_FILE):
         print("geometrics_amd.gemm_tuning: could not load %s (%s: %s); library default GEMM selection in use"
               % (filename, type(exc).__name__, exc), file=sys.stderr)
         tun.enable(False)
+        status = "library default (tuning file rejected)"
         return False
+    status = "tunableop file" if ok else "library default (tuning file rejected)"
     if not ok:
         print("geometrics_amd.gemm_tuning: %s was not accepted by TunableOp (library version mismatch?); "
               "library default GEMM selection in use" % filename, file=sys.stderr)

@@ -41,3 +41,19 @@ def test_bench_line_carries_the_contract(gpu):
     assert line["value"] > 10 * cpu["value"]                  # north_star: >= 10x the reference CPU Chamfer + tri path
     shape = line["reference_training_shape"]
     assert shape["step_us"] > 0 and "482" in shape["workload"]
+    # the shipped library-GEMM selections LOADED on this box (a rejected file is a silent ~2x on a third of the step)
+    assert line["config"]["gemm_selection"] == "tunableop file", line["config"]["gemm_selection"]
+    # the line checks itself: the timed route against the CPU oracle, outside the timed region
+    spot = line["parity_spot_check"]
+    assert spot["idx_mismatches"] == 0 and spot["dist_bit_mismatches"] == 0 and spot["sampled_point_bit_mismatches"] == 0
+    assert spot["loss_rel_err"] <= 1e-5 and spot["grad_pos_max_err_over_scale"] <= 1e-4
+    drv = line["driver_step"]
+    assert drv["ms_per_step"] > 0 and "GEOMetrics.py:110-174" in drv["workload"] and len(drv["stages_us"]) >= 5
+
+
+def test_the_shipped_gemm_selections_load_here(gpu):
+    from geometrics_amd import gemm_tuning
+    try:
+        assert gemm_tuning.enable() and gemm_tuning.status == "tunableop file"
+    finally:
+        gemm_tuning.disable()
