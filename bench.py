@@ -114,14 +114,12 @@ class Workload:
         self._splitting = None        # (graph A, graph B) while capture() records the step: the pass is cut behind the reduction launch
 
     def positions(self):
-        h = self.feat
-        # (layers.weight_gradient_batching() is for deep stacks -- the deformation block's twelve equal layers; for the two
-        # equal layers here it was measured at +3 us per step: -8 on the products, +11 from the changed launch order)
-        for layer in self.stack[:-1]:
-            h = layer(h, self.info["adj"], self.act)
-        # base + 0.01 * h[..., :3] inside the last layer's aggregation launches (forward: positions from its epilogue;
-        # backward: [0.01 * grad_pos | 0] synthesised, never written or read)
-        return self.stack[-1].forward_positions(h, self.info["adj"], self.act, self.base, 0.01)
+        # the three layers as a stack: the boundaries between the 192-wide layers are single launches where fused.plan says so
+        # (csrc/zn_stack.hip: aggregation + the next layer's product); base + 0.01 * h[..., :3] comes out of the last layer's
+        # aggregation launches (forward: positions from its epilogue; backward: [0.01 * grad_pos | 0] synthesised, never
+        # written or read).  (layers.weight_gradient_batching() is for deep stacks -- the deformation block's twelve equal
+        # layers; for the two equal layers here it was measured at +3 us per step.)
+        return layers.zero_n_stack_positions(self.feat, self.info["adj"], list(self.stack), self.act, self.base, 0.01)
 
     # N = 1: one step = forward_backward(step_in_backward=True): ONE graph, Adam inside the end-of-pass reduction launch.
     # N > 1: one step = [Adam on the bucket all-reduced by the PREVIOUS step] -> forward -> backward (weight-gradient

@@ -6,6 +6,8 @@ second's product (forward), and the aggregation backward of a layer is the opera
 Shapes: 192-wide layers, k = 64, a neighbour table of width 8 without long rows -- the hidden layers of the BASELINE stack;
 `supported()` says whether a layer pair qualifies, everything else takes the two separate operators.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -14,6 +16,25 @@ from . import _lib
 def supported(csr, c, k, n_out):
     return bool(csr.ell_w == 8 and csr.over is None and csr.over_t is None and c == 192 and k == 64
                 and 0 < n_out <= 192 and n_out % 12 == 0)
+
+
+# tests / tools: {"fwd": bool, "bwd": bool} overrides `plan`
+force = None
+
+
+def plan(rows):
+    """Which boundaries take the single launch.  Launch against launch in a loop (tools/time_fused_layer.py,
+    profiles/r05_fused_boundary.txt) the boundary is ahead of aggregation + library product from ~6 meshes of 2562 vertices
+    forward and ~10 backward; INSIDE the step (tools/probe/fused_plan_sweep.sh: the whole step replayed with the plan off /
+    forward / both) it is not -- its weight slice and tables arrive cold and its 27 us there lose to 10 + 14.4 us at the
+    8-mesh shard (+3 us per boundary), it breaks even at 12-16 meshes, and wins from 32 (1512 vs 1567 us per step; at 64
+    meshes, both directions: 2777 vs 2996 us, -7.3 %).  The thresholds follow the in-step measurement."""
+    if force is not None:
+        return dict(force)
+    env = os.environ.get("GEOM_FUSED_PLAN")       # tools: "off" | "fwd" | "all"
+    if env:
+        return {"fwd": env in ("fwd", "all"), "bwd": env == "all"}
+    return {"fwd": rows >= 70000, "bwd": rows >= 70000}
 
 
 def partial_rows(b, nv):

@@ -21,6 +21,7 @@ from torch.nn.parameter import Parameter
 
 from . import _lib
 from . import dense as _dense_kernels
+from . import fused as _fused
 
 _ACT_NONE, _ACT_RELU, _ACT_ELU = 0, 1, 2
 
@@ -485,6 +486,17 @@ def _queue_colsum(partials, rows, cols, out, param=None):
                  None if param is None else weakref.ref(param)))
 
 
+def _finish_colsum(partials, rows, cols, grad_bias, bias, defer):
+    """Per-workgroup column sums -> the bias gradient: queued for the end-of-pass launch, or one launch now."""
+    if defer:
+        _queue_colsum(partials, rows, cols, grad_bias, bias)
+        return
+    with torch.cuda.device(partials.device):
+        _lib.check(_lib.lib().geom_colsum_batch_f32(
+            1, (ctypes.c_void_p * 1)(partials.data_ptr()), (ctypes.c_int * 1)(rows), (ctypes.c_int * 1)(cols),
+            (ctypes.c_void_p * 1)(grad_bias.data_ptr()), _lib.stream_ptr()), "geom_colsum_batch_f32")
+
+
 def aggregate_backward(g, csr, k, act, out, mask, want_bias, bias=None, arena=None):
     """grad_support = [A^T . g'[..., :k] | g'[..., k:]] with g' = g * act'(out) (relu' from the sign mask when there is
     one), and the bias gradient = column sums of g' out of the same launch (+ a fixed-order reduction: at once, or -- given
@@ -566,9 +578,10 @@ class _ZeroNAggregateHead(torch.autograd.Function):
     read back; the aggregation backward synthesises it from grad_pos."""
 
     @staticmethod
-    def forward(ctx, support, bias, base, csr, k, act, scale):
+    def forward(ctx, support, bias, base, csr, k, act, scale, down=None):
         s = _lib.require(support, "support", torch.float32, 3)
         base_c = _lib.require(base, "base", torch.float32, 3, 3)
+        ctx.down = down        # a _StackLink: the boundary launch that produced `support` (zero_n_stack_positions)
         b, nv, c = s.shape
         bias_c = None if bias is None else _lib.require(bias, "bias", torch.float32, 1)
         out = torch.empty_like(s)
@@ -604,6 +617,19 @@ class _ZeroNAggregateHead(torch.autograd.Function):
                 else torch.empty(c, dtype=torch.float32, device=gp.device)
             scratch = torch.empty(_lib.lib().geom_zn_gcn_bwd_scratch_floats(b, nv, c), dtype=torch.float32, device=gp.device)
             defer = _may_defer(bias)
+        down = ctx.down
+        if (down is not None and down.wt is not None and down.wanted and ctx.needs_input_grad[0]
+                and _fused.plan(b * nv)["bwd"]):
+            # this aggregation backward AND the input gradient of the product below it in one launch (csrc/zn_stack.hip);
+            # the boundary below picks its input gradient up from the link instead of computing it
+            rows = _fused.partial_rows(b, nv)
+            partial = torch.empty(rows, c, dtype=torch.float32, device=gp.device) if grad_bias is not None else None
+            _fused.layer_backward(None, None, mask, csr, k, ctx.act, down.wt, g_out=grad_support, grad_in=down.take_dx(b, nv),
+                                  colsum_partial=partial, grad_pos=gp, head_scale=ctx.scale, shape=(b, nv, c))
+            down.g_ptr = grad_support.data_ptr()
+            if grad_bias is not None:
+                _finish_colsum(partial, rows, c, grad_bias, bias, defer)
+            return grad_support, grad_bias, (gp if ctx.needs_input_grad[2] else None), None, None, None, None, None
         over = csr.over_t or (None, None, None)
         with torch.cuda.device(gp.device):
             _lib.call("geom_zn_gcn_aggregate_ell_head_bwd_f32", b, nv, c, k, csr.ell_w, csr.ell_col_t.data_ptr(),
@@ -613,10 +639,10 @@ class _ZeroNAggregateHead(torch.autograd.Function):
         if defer:
             _queue_colsum(scratch, int(_lib.lib().geom_zn_gcn_bwd_partial_rows(b, nv, c, k, csr.ell_w)), c, grad_bias, bias)
         return (grad_support if ctx.needs_input_grad[0] else None), grad_bias, (gp if ctx.needs_input_grad[2] else None), \
-            None, None, None, None
+            None, None, None, None, None
 
 
-def zero_n_aggregate_head(support, adj, bias, k, activation, base, scale):
+def zero_n_aggregate_head(support, adj, bias, k, activation, base, scale, down=None):
     """base + scale * zero_n_aggregate(...)[..., :3] for a [B,V,C] support: fused (see _ZeroNAggregateHead) for split-3
     layers on a bounded-degree mesh with ReLU or no activation, the two separate operators otherwise."""
     act = _ACT_NONE if activation is None else _activation_code(activation)
@@ -629,7 +655,7 @@ def zero_n_aggregate_head(support, adj, bias, k, activation, base, scale):
     if not fused:
         from .ops import VertexHead
         return VertexHead.apply(base, zero_n_aggregate(support, adj, bias, k, activation), scale)
-    return _ZeroNAggregateHead.apply(support, bias, base, csr, k, act, scale)
+    return _ZeroNAggregateHead.apply(support, bias, base, csr, k, act, scale, down)
 
 
 def zero_n_aggregate(support, adj, bias, k, activation=None):
@@ -816,6 +842,23 @@ def _flush_reduce(task):
         _check_landed(job[6], job[4])
 
 
+def _finish_weight_gradient(w_ref, w, rows, cin, c, ws):
+    """The weight gradient whose split partial sums are in `ws`: queued for the reduction launch at the end of the pass where
+    deferral is allowed (its buffer handed to autograd now), reduced at once otherwise."""
+    param = w_ref()
+    grad_w = _gradient_buffer(param, w)
+    if param is not None and _may_defer(param):
+        task = torch._C._current_graph_task_id()
+        jobs = _pending_reduce.get(task)
+        if jobs is None:
+            jobs = _pending_reduce[task] = []
+        _register_flush(task)
+        jobs.append((rows, cin, c, ws, _alias(grad_w).view(cin, c), torch.cuda.current_stream(w.device), w_ref))
+    else:
+        _dense_kernels.reduce([(rows, cin, c, ws, grad_w.view(cin, c), None)])
+    return grad_w
+
+
 class _DenseMM(torch.autograd.Function):
     """support = input @ W with both gradients on the matrix-core kernels where `dense.plan` puts them: the input
     gradient and the split partial sums of the weight gradient in ONE launch (two workgroups per CU) for the 192-wide
@@ -864,18 +907,7 @@ class _DenseMM(torch.autograd.Function):
             task = torch._C._current_graph_task_id()
             _pending_late.setdefault(task, []).append(late)
             _register_flush(task)
-        param = ctx.w_ref()
-        grad_w = _gradient_buffer(param, w)
-        if param is not None and _may_defer(param):
-            task = torch._C._current_graph_task_id()
-            jobs = _pending_reduce.get(task)
-            if jobs is None:
-                jobs = _pending_reduce[task] = []
-            _register_flush(task)
-            jobs.append((rows, cin, c, ws, _alias(grad_w).view(cin, c), torch.cuda.current_stream(w.device), ctx.w_ref))
-        else:
-            _dense_kernels.reduce([(rows, cin, c, ws, grad_w.view(cin, c), None)])
-        return grad_x, grad_w
+        return grad_x, _finish_weight_gradient(ctx.w_ref, w, rows, cin, c, ws)
 
 
 def _dense(x, w):
@@ -891,6 +923,163 @@ def _dense(x, w):
     if plain or arena is None:
         return torch.matmul(x, w.squeeze(0) if w.dim() == 3 else w)   # [1,Cin,Cout]: one GEMM, not B broadcast bmm's
     return _Dense.apply(x, w, arena)
+
+
+# ---- a stack of layers with its layer BOUNDARIES as single launches (csrc/zn_stack.hip) -----------------------------------
+# Between two consecutive 192-wide layers the aggregation of the first is the operand load of the second's product, and in the
+# backward pass the aggregation backward of a layer is the operand load of its own input-gradient product.  The boundary
+# launch does both; which boundaries take it is `fused.plan`'s decision (measured: it pays from ~6 meshes of 2562 vertices
+# forward, ~10 backward).  The values are those of the separate operators: the aggregation's bit for bit, the products within
+# fp32 summation order.
+class _StackLink:
+    """What two neighbouring launches of a stack hand each other outside autograd's edges: the boundary's forward launch
+    leaves its weight transposed (`wt`); the launch ABOVE it in the backward pass (the next boundary's or the head's fused
+    backward) computes this boundary's input gradient with it and leaves it in `dx`, stamped with the address of the support
+    gradient it was computed from -- the boundary uses it only when that very tensor arrives as its incoming gradient (an
+    engine that summed several consumers' gradients hands over another tensor, and the product is computed here as usual)."""
+    __slots__ = ("wt", "dx", "g_ptr", "wanted")
+
+    def __init__(self):
+        self.wt = self.dx = None
+        self.g_ptr = 0
+        self.wanted = False
+
+    def take_dx(self, b, nv):
+        self.dx = torch.empty(b, nv, self.wt.shape[1], dtype=torch.float32, device=self.wt.device)
+        return self.dx
+
+
+class _FusedBoundary(torch.autograd.Function):
+    """support_next = act([A . S[..., :k] | S[..., k:]] + bias) @ W_next -- layer L's aggregation and layer L+1's product."""
+
+    @staticmethod
+    def forward(ctx, support, bias, w_next, csr, k, act, up, down):
+        s = _lib.require(support, "support", torch.float32, 3)
+        b, nv, c = s.shape
+        bias_c = None if bias is None else _lib.require(bias, "bias", torch.float32, 1)
+        w2 = w_next.reshape(w_next.shape[-2:])
+        need = any(ctx.needs_input_grad[:3])
+        mask = None
+        if need and act == _ACT_RELU:
+            mask = torch.empty(_lib.lib().geom_zn_gcn_relu_mask_words(b, nv, c, k), dtype=torch.int16, device=s.device)
+        if need:
+            up.wt = torch.empty(w2.shape[1], c, dtype=torch.float32, device=s.device)
+            up.wanted = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        x, s_next = _fused.layer_forward(s, bias_c, csr, k, act, w2, mask=mask, wt_out=up.wt)
+        ctx.csr, ctx.k, ctx.act, ctx.up, ctx.down = csr, k, act, up, down
+        ctx.bias_ref = None if bias is None else weakref.ref(bias)
+        ctx.w_ref = weakref.ref(w_next)
+        if bias is not None and ctx.needs_input_grad[1]:
+            _register_bias_user(bias, ctx)
+        if ctx.needs_input_grad[2]:
+            _register_bias_user(w_next, ctx)
+        ctx.masked = mask is not None
+        ctx.save_for_backward(x, w_next, *([mask] if mask is not None else []))
+        return s_next
+
+    @staticmethod
+    def backward(ctx, grad_next):
+        x, w = ctx.saved_tensors[:2]
+        mask = ctx.saved_tensors[2] if ctx.masked else None
+        b, nv, c = x.shape
+        rows = b * nv
+        w2 = w.reshape(w.shape[-2:])
+        n_out = w2.shape[1]
+        g2 = grad_next.reshape(rows, n_out).contiguous()
+        x2 = x.view(rows, c)
+        need_s, need_b, need_w = ctx.needs_input_grad[:3]
+        need_b = need_b and ctx.bias_ref is not None
+        up, down, csr, k, act = ctx.up, ctx.down, ctx.csr, ctx.k, ctx.act
+        # ---- layer L+1's product: dW partials, and dX unless the launch above left it in the link
+        dx, up.dx = (up.dx if up.dx is not None and up.g_ptr == g2.data_ptr() else None), None
+        plan = _dense_kernels.plan(rows, c, n_out)
+        grad_w = ws = None
+        split = need_w and plan["dw"] == "mfma" and w2.is_contiguous()
+        if split:
+            ws = _dense_kernels.weight_workspace(rows, c, n_out, x.device)
+        if dx is None and (need_s or need_b):
+            if split and plan["pair"]:
+                dx = torch.empty_like(x)
+                _dense_kernels.backward_pair(x2, g2, w2, dx.view(rows, c), ws)
+            else:
+                dx = torch.matmul(g2, w2.t()).view(x.shape)
+                if split:
+                    _dense_kernels.backward_weight_partials(x2, g2, ws)
+        elif split:
+            _dense_kernels.backward_weight_partials(x2, g2, ws)
+        if split:
+            grad_w = _finish_weight_gradient(ctx.w_ref, w, rows, c, n_out, ws)
+        elif need_w:
+            grad_w = torch.mm(x2.t(), g2).view(w.shape)
+        if not (need_s or need_b):
+            return None, None, grad_w, None, None, None, None, None
+        # ---- layer L's aggregation: with the input gradient of ITS product in the same launch when the boundary below wants it
+        bias = ctx.bias_ref() if ctx.bias_ref is not None else None
+        out = x if (act != _ACT_NONE and mask is None) else None
+        if down is not None and down.wt is not None and down.wanted and _fused.plan(rows)["bwd"]:
+            grad_bias = partial = None
+            prows = _fused.partial_rows(b, nv)
+            if need_b:
+                grad_bias = _gradient_buffer(bias, bias) if bias is not None and bias.shape == (c,) \
+                    else torch.empty(c, dtype=torch.float32, device=x.device)
+                partial = torch.empty(prows, c, dtype=torch.float32, device=x.device)
+            grad_support, _ = _fused.layer_backward(dx, out, mask, csr, k, act, down.wt, grad_in=down.take_dx(b, nv),
+                                                    colsum_partial=partial)
+            down.g_ptr = grad_support.data_ptr()
+            if need_b:
+                _finish_colsum(partial, prows, c, grad_bias, bias, _may_defer(bias))
+        else:
+            grad_support, grad_bias = aggregate_backward(dx, csr, k, act, out, mask, need_b, bias)
+        return (grad_support if need_s else None), grad_bias, grad_w, None, None, None, None, None
+
+
+def _boundary_fuses(x, csr, prev, layer, act, activation):
+    """Whether the boundary between `prev` and `layer` takes the single launch."""
+    if not (use_matrix_core_products and current_slabs() is None and isinstance(csr, _Csr)):
+        return False
+    if activation is not None and act == _ACT_NONE:          # a foreign callable: applied by the caller between the operators
+        return False
+    w = layer._weight()
+    c = prev._weight().shape[-1]
+    if w.dtype != torch.float32 or w.shape[-2] != c or not w.is_contiguous() or prev.split != 3 or c % 3:
+        return False
+    rows = x.numel() // x.shape[-1]
+    return _fused.supported(csr, c, c // 3, w.shape[-1]) and _fused.plan(rows)["fwd"]
+
+
+def _stack_supports(x, adj, stack, head):
+    """The front of a stack up to the support of its last layer: (support, link of the last boundary, csr)."""
+    act = _ACT_NONE if head["activation"] is None else _activation_code(head["activation"])
+    activation = head["activation"]
+    batched = torch.is_tensor(x) and x.dim() == 3 and x.is_cuda and x.dtype == torch.float32 \
+        and not (torch.is_tensor(adj) and adj.dim() == 3)
+    csr = adjacency_csr(adj) if batched else None
+    s = _dense(x, stack[0]._weight())
+    link = None
+    for prev, layer in zip(stack[:-1], stack[1:]):
+        if batched and _boundary_fuses(x, csr, prev, layer, act, activation):
+            up = _StackLink()
+            s = _FusedBoundary.apply(s, prev.bias, layer._weight(), csr, s.shape[-1] // prev.split, act, up, link)
+            link = up
+        else:
+            h = zero_n_aggregate(s, adj, prev.bias, s.shape[-1] // prev.split, activation)
+            s = _dense(h, layer._weight())
+            link = None
+    return s, link
+
+
+def zero_n_stack(x, adj, stack, activation):
+    """stack[-1](... stack[1](stack[0](x, adj, activation), adj, activation) ...): consecutive 0N-GCN layers applied to one
+    adjacency (GEOMetrics.py:117-131 runs such runs per deformation stage), their boundaries as single launches where
+    `fused.plan` says so.  Same values as calling the layers one by one."""
+    s, _ = _stack_supports(x, adj, stack, {"activation": activation})
+    return zero_n_aggregate(s, adj, stack[-1].bias, s.shape[-1] // stack[-1].split, activation)
+
+
+def zero_n_stack_positions(x, adj, stack, activation, base, scale):
+    """base + scale * zero_n_stack(x, adj, stack, activation)[..., :3] -- the coordinate update of a deformation stage."""
+    s, link = _stack_supports(x, adj, stack, {"activation": activation})
+    return zero_n_aggregate_head(s, adj, stack[-1].bias, s.shape[-1] // stack[-1].split, activation, base, scale, down=link)
 
 
 def _uniform(t, bound):

@@ -106,3 +106,72 @@ def test_unsupported_shapes_are_refused(gpu):
     assert L.geom_zn_layer_fwd_f32(1, 4, 96, 32, 8, p, p, p, None, 0, p, 96, p, None, p, None, None) == _lib.EUNSUPPORTED
     assert L.geom_zn_layer_fwd_f32(1, 4, 192, 64, 16, p, p, p, None, 0, p, 192, p, None, p, None, None) == _lib.EUNSUPPORTED
     assert L.geom_zn_layer_fwd_f32(1, 4, 192, 64, 8, p, p, p, None, 0, p, 100, p, None, p, None, None) == _lib.EUNSUPPORTED
+
+
+# ---- the stack operator (layers.zero_n_stack_positions): boundaries as single launches, against the layer-by-layer route ----
+def _stack_run(force, b, level, act_fn, seed=5):
+    import torch.nn.functional as F  # noqa: F401
+    from geometrics_amd import fused, layers
+    nv, csr = _mesh(level)
+    torch.manual_seed(seed)
+    stack = torch.nn.ModuleList([layers.Batch_Image_ZERON_GCNGCN(i, o) for i, o in ((99, C), (C, C), (C, C))]).cuda()
+    for layer in stack:
+        layer.bias.data.uniform_(-0.05, 0.05)
+    g = torch.Generator(device="cpu").manual_seed(seed + 1)
+    x = torch.randn(b, nv, 99, generator=g).cuda().requires_grad_(True)
+    base = torch.randn(b, nv, 3, generator=g).cuda().requires_grad_(True)
+    seed_grad = torch.randn(b, nv, 3, generator=g).cuda()
+    fused.force = force
+    try:
+        if force is None:      # the layer-by-layer route: the reference's call sequence
+            h = x
+            for layer in stack[:-1]:
+                h = layer(h, csr, act_fn)
+            pos = stack[-1].forward_positions(h, csr, act_fn, base, 0.01)
+        else:
+            pos = layers.zero_n_stack_positions(x, csr, list(stack), act_fn, base, 0.01)
+        pos.backward(seed_grad)
+    finally:
+        fused.force = None
+    torch.cuda.synchronize()
+    grads = [x.grad, base.grad] + [p.grad for p in stack.parameters()]
+    return pos.detach(), [t.detach().clone() for t in grads]
+
+
+@pytest.mark.parametrize("mode", ["fwd", "fwd+bwd"])
+@pytest.mark.parametrize("act", ["relu", "elu", "none"])
+@pytest.mark.parametrize("b,level", [(2, 3), (3, 2)])
+def test_the_stack_operator_matches_the_layer_by_layer_route(gpu, b, level, act, mode):
+    """Same parameters and inputs through (a) the layers one by one and (b) the stack operator with its boundary launches
+    forced on (forward only / forward and backward): positions and every gradient agree within the fp32 summation order of
+    the products.  (The smooth activation checks the whole chain; under ReLU a unit whose pre-activation is within rounding
+    of 0 may switch, so hidden-layer gradients get the looser bound there -- the bound of tests/test_bench_step_gpu.py.)"""
+    import torch.nn.functional as F
+    act_fn = {"relu": F.relu, "elu": F.elu, "none": None}[act]
+    want_pos, want = _stack_run(None, b, level, act_fn)
+    got_pos, got = _stack_run({"fwd": True, "bwd": mode == "fwd+bwd"}, b, level, act_fn)
+    tol = 2e-3 if act == "relu" else 2e-5
+    assert (got_pos - want_pos).abs().max().item() <= 2e-6 * want_pos.abs().max().item()
+    for gt, wt_ in zip(got, want):
+        assert gt.shape == wt_.shape
+        scale = wt_.abs().max().item() + 1e-30
+        assert (gt - wt_).abs().max().item() <= tol * scale, (act, mode, gt.shape, (gt - wt_).abs().max().item() / scale)
+
+
+def test_the_stack_operator_uses_the_boundary_launch(gpu):
+    """The route is the fused one when forced (the link of the last boundary is there and carries the transposed weight)."""
+    import torch.nn.functional as F
+    from geometrics_amd import fused, layers
+    nv, csr = _mesh(3)
+    stack = torch.nn.ModuleList([layers.Batch_Image_ZERON_GCNGCN(i, o) for i, o in ((48, C), (C, C), (C, C))]).cuda()
+    x = torch.randn(2, nv, 48, device="cuda")
+    fused.force = {"fwd": True, "bwd": True}
+    try:
+        s, link = layers._stack_supports(x, csr, list(stack), {"activation": F.relu})
+        assert link is not None and torch.equal(link.wt, stack[-1].weight1[0].t())
+        fused.force = {"fwd": False, "bwd": False}
+        s2, link2 = layers._stack_supports(x, csr, list(stack), {"activation": F.relu})
+        assert link2 is None
+    finally:
+        fused.force = None
+    assert (s - s2).abs().max().item() <= 2e-5 * s2.abs().max().item()
