@@ -16,7 +16,7 @@ FLAG_FIX_REGION6 = 2
 FLAG_TRI_BRUTE_FORCE = 4
 FLAG_NN_FMA = 8
 FLAG_TRI_WS_READY = 16
-ABI_VERSION = 8
+ABI_VERSION = 9
 EUNSUPPORTED = -3
 ADAM_MAX_TENSORS = 64
 COLSUM_MAX_JOBS = 32
@@ -115,6 +115,7 @@ _SIGNATURES = {
     "geom_zn_gcn_aggregate_ell_head_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp],
     "geom_zn_gcn_aggregate_ell_head_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp],
     "geom_zn_gcn_aggregate_bwd_f32": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "geom_gemm_f32": [_i, _i, _i, _vp, ctypes.c_int64, _i, _vp, ctypes.c_int64, _i, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _vp],
     "geom_zn_layer_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_zn_layer_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp],
 }
@@ -210,6 +211,8 @@ def lib():
         L.geom_tri_distance_workspace_bytes.argtypes = [_i, _i, _i]
         L.geom_zn_layer_partial_rows.restype = ctypes.c_int64
         L.geom_zn_layer_partial_rows.argtypes = [_i, _i]
+        L.geom_gemm_workspace_floats.restype = ctypes.c_int64
+        L.geom_gemm_workspace_floats.argtypes = [_i, _i, _i]
         L.geom_surface_tail_counters_offset.restype = ctypes.c_size_t
         L.geom_surface_tail_counters_offset.argtypes = [_i, _i, _i]
         for name, args in _SIGNATURES.items():
@@ -226,7 +229,8 @@ def declared_symbols():
                    "geom_segment_max_workspace_bytes", "geom_zn_gcn_relu_mask_words",
                    "geom_surface_bin_count_words", "geom_surface_bin_list_words", "geom_surface_order_words",
                    "geom_dense_bwd_weight_workspace_floats", "geom_chamfer_nn_culled_workspace_floats",
-                   "geom_nn_cull_index_floats", "geom_surface_tail_counters_offset", "geom_zn_layer_partial_rows"] + list(_SIGNATURES))
+                   "geom_nn_cull_index_floats", "geom_surface_tail_counters_offset", "geom_zn_layer_partial_rows",
+                   "geom_gemm_workspace_floats"] + list(_SIGNATURES))
 
 
 def check(code, what):

@@ -59,6 +59,13 @@ struct Pack<4> {
     __device__ __forceinline__ float &at(int i) { return (&v.x)[i]; }
 };
 template <>
+struct Pack<2> {
+    float2 v;
+    __device__ __forceinline__ void load(const float *p) { v = *reinterpret_cast<const float2 *>(p); }
+    __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float2 *>(p) = v; }
+    __device__ __forceinline__ float &at(int i) { return (&v.x)[i]; }
+};
+template <>
 struct Pack<1> {
     float v;
     __device__ __forceinline__ void load(const float *p) { v = *p; }
@@ -567,11 +574,219 @@ void launch_ell_shape(const EllArgs &a, int w, dim3 grid, size_t lds, hipStream_
     else hipLaunchKernelGGL((zn_aggregate_ell_kernel<ACT, BACKWARD, 16, 9>), grid, block, lds, s, a, rpb, iters, partial);
 }
 
+// ---------------------------------------------------------------------------------------
+// ELL table, ANY width and split: the unbatched ZERON_GCN layers of the mesh encoder (reference layers.py:34-41 with
+// models.py:299-348's widths: c = 60 ... 300, k = c / 10 = 6 ... 30 -- neither k % 4 == 0 nor c % k == 0 holds for most).
+// The thread layout of the generic CSR kernel at the top of this file (one thread = VEC consecutive columns of a row, the
+// group that straddles column k is mixed) with the neighbour entries from the fixed-stride table instead of the
+// rowptr -> (col, val) chain: two dependent round trips per gathering thread instead of three, the table read issued with
+// the thread's own elements.  VEC = 4 / 2 / 1 by the divisibility of c (150, 210, 250 are even, not multiples of 4).
+// Workgroups run several row tiles (forward: keeps the grid at a few thousand workgroups; backward: at most ~1024
+// bias-gradient partials to reduce -- 3072 partial rows of 300 columns cost an 8 us reduction launch per layer).
+// Summation order = table order = CSR order: bit-identical to the generic kernel.
+// ---------------------------------------------------------------------------------------
+template <int VEC, int ACT, bool BACKWARD, int W>
+__global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_any_kernel(EllArgs a, int groups, int rows_in_flight, int rows_per_block,
+                                                                            float *colsum_partial)
+{
+    extern __shared__ float lds_colsum[]; // [rows_in_flight][c], backward with colsum only
+    const int g = threadIdx.x % groups;
+    const int rl = threadIdx.x / groups;
+    const int c0 = g * VEC;
+    const bool active = rl < rows_in_flight;
+    const int r_begin = blockIdx.x * rows_per_block;
+    const int r_end = min(r_begin + rows_per_block, a.nv);
+    const int64_t mesh_row0 = (int64_t)blockIdx.y * a.nv;
+    const bool gathers = c0 < a.k;
+    const bool pass = c0 + VEC > a.k; // pass-through columns in the group (all, or the tail of the straddling group)
+
+    Pack<VEC> colsum;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) colsum.at(i) = 0.f;
+
+    if (active) {
+        for (int r = r_begin + rl; r < r_end; r += rows_in_flight) {
+            const int64_t row = mesh_row0 + r;
+            Pack<VEC> acc, own;
+            int nb[W];
+            float w[W];
+            int e0 = 0, e1 = 0;
+            if (gathers) { // round trip 1: the row's table entries (with the thread's own elements below)
+#pragma unroll
+                for (int n = 0; n < W; n += 4) {
+                    const int4 ci = *reinterpret_cast<const int4 *>(a.col + (size_t)r * W + n);
+                    const float4 wi = *reinterpret_cast<const float4 *>(a.val + (size_t)r * W + n);
+                    nb[n] = ci.x, nb[n + 1] = ci.y, nb[n + 2] = ci.z, nb[n + 3] = ci.w;
+                    w[n] = wi.x, w[n + 1] = wi.y, w[n + 2] = wi.z, w[n + 3] = wi.w;
+                }
+                if (a.over_ptr) e0 = a.over_ptr[r], e1 = a.over_ptr[r + 1];
+            }
+            if (BACKWARD || pass) {
+                own.load(a.x + row * a.c + c0);
+                if (BACKWARD && ACT != ACT_NONE) {
+                    Pack<VEC> o;
+                    o.load(a.saved + row * a.c + c0);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) own.at(i) = act_bwd<ACT>(own.at(i), o.at(i));
+                }
+            }
+            if (gathers) {
+                Pack<VEC> sv[W], ov[W];
+#pragma unroll
+                for (int n = 0; n < W; ++n) { // round trip 2: the neighbour rows
+                    const int64_t nrow = mesh_row0 + (nb[n] >= 0 ? nb[n] : r);
+                    sv[n].load(a.x + nrow * a.c + c0);
+                    if (BACKWARD && ACT != ACT_NONE) ov[n].load(a.saved + nrow * a.c + c0);
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc.at(i) = 0.f;
+#pragma unroll
+                for (int n = 0; n < W; ++n) {
+                    if (nb[n] >= 0) { // table order == CSR order of the row
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            float v = sv[n].at(i);
+                            if (BACKWARD && ACT != ACT_NONE) v = act_bwd<ACT>(v, ov[n].at(i));
+                            acc.at(i) += w[n] * v;
+                        }
+                    }
+                }
+                for (int e = e0; e < e1; e += GCN_NB) { // a row longer than the table: its CSR tail, still in order
+                    int64_t tb[GCN_NB];
+                    float tw[GCN_NB];
+#pragma unroll
+                    for (int j = 0; j < GCN_NB; ++j) {
+                        const bool in = e + j < e1;
+                        tb[j] = in ? mesh_row0 + a.over_col[e + j] : row;
+                        tw[j] = in ? a.over_val[e + j] : 0.f;
+                    }
+                    Pack<VEC> tv[GCN_NB], to[GCN_NB];
+#pragma unroll
+                    for (int j = 0; j < GCN_NB; ++j) {
+                        tv[j].load(a.x + tb[j] * a.c + c0);
+                        if (BACKWARD && ACT != ACT_NONE) to[j].load(a.saved + tb[j] * a.c + c0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < GCN_NB; ++j) {
+                        if (e + j < e1) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) {
+                                float v = tv[j].at(i);
+                                if (BACKWARD && ACT != ACT_NONE) v = act_bwd<ACT>(v, to[j].at(i));
+                                acc.at(i) += tw[j] * v;
+                            }
+                        }
+                    }
+                }
+                if (pass) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i)
+                        if (c0 + i >= a.k) acc.at(i) = own.at(i);
+                }
+            } else {
+                acc = own;
+            }
+            if (BACKWARD) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) colsum.at(i) += own.at(i);
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    float v = acc.at(i);
+                    if (a.bias) v += a.bias[c0 + i];
+                    acc.at(i) = act_fwd<ACT>(v);
+                }
+            }
+            acc.store(a.y + row * a.c + c0);
+        }
+    }
+
+    if (BACKWARD && colsum_partial) { // block partial of the bias gradient, fixed summation order
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) lds_colsum[rl * a.c + c0 + i] = colsum.at(i);
+        }
+        __syncthreads();
+        if (active && rl == 0) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float t = 0.f;
+                for (int l = 0; l < rows_in_flight; ++l) t += lds_colsum[l * a.c + c0 + i];
+                colsum_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * a.c + c0 + i] = t;
+            }
+        }
+    }
+}
+
+inline int ell_any_vec(int c) { return c % 4 == 0 ? 4 : c % 2 == 0 ? 2 : 1; }
+inline bool ell_any_supported(int c, int w) { return (w == 8 || w == 16) && c > 0 && c / ell_any_vec(c) <= GCN_THREADS; }
+
+inline GcnGeometry ell_any_geometry(int b, int nv, int c, bool backward)
+{
+    GcnGeometry g;
+    g.groups = c / ell_any_vec(c);
+    g.rows_in_flight = GCN_THREADS / g.groups;
+    // row tiles per workgroup: forward -- at most ~4096 workgroups; backward -- at most ~1024 (= bias-gradient partials)
+    const int64_t tiles = ((int64_t)b * nv + g.rows_in_flight - 1) / g.rows_in_flight;
+    int64_t iters = backward ? (tiles + 1023) / 1024 : (tiles + 4095) / 4096;
+    const int64_t lo = backward ? GCN_BWD_ITERS : 1, hi = backward ? 64 : 8;
+    iters = iters < lo ? lo : iters > hi ? hi : iters;
+    g.rows_per_block = g.rows_in_flight * (int)iters;
+    g.chunks = (nv + g.rows_per_block - 1) / g.rows_per_block;
+    g.blocks = (int64_t)g.chunks * b;
+    return g;
+}
+
+template <int VEC, int ACT, bool BACKWARD>
+void launch_ell_any_w(const EllArgs &a, int w, const GcnGeometry &geo, dim3 grid, size_t lds, hipStream_t s, float *partial)
+{
+    if (w == 8) hipLaunchKernelGGL((zn_aggregate_ell_any_kernel<VEC, ACT, BACKWARD, 8>), grid, dim3(GCN_THREADS), lds, s, a, geo.groups, geo.rows_in_flight, geo.rows_per_block, partial);
+    else hipLaunchKernelGGL((zn_aggregate_ell_any_kernel<VEC, ACT, BACKWARD, 16>), grid, dim3(GCN_THREADS), lds, s, a, geo.groups, geo.rows_in_flight, geo.rows_per_block, partial);
+}
+
+template <int ACT, bool BACKWARD>
+void launch_ell_any_vec(const EllArgs &a, int w, const GcnGeometry &geo, dim3 grid, size_t lds, hipStream_t s, float *partial)
+{
+    switch (ell_any_vec(a.c)) {
+    case 4: launch_ell_any_w<4, ACT, BACKWARD>(a, w, geo, grid, lds, s, partial); break;
+    case 2: launch_ell_any_w<2, ACT, BACKWARD>(a, w, geo, grid, lds, s, partial); break;
+    default: launch_ell_any_w<1, ACT, BACKWARD>(a, w, geo, grid, lds, s, partial); break;
+    }
+}
+
+template <bool BACKWARD>
+int dispatch_ell_any(EllArgs a, int b, int w, int act, float *grad_bias, float *scratch, void *stream)
+{
+    if (!ell_any_supported(a.c, w) || a.head_in || a.mask) return GEOM_EUNSUPPORTED;
+    if (b == 0 || a.nv == 0) return 0;
+    if (!a.col || !a.val || !a.y || !a.x) return GEOM_EINVAL;
+    if (BACKWARD && act != ACT_NONE && !a.saved) return GEOM_EINVAL;
+    if (grad_bias && !scratch) return GEOM_EINVAL;
+    if (a.over_ptr && (!a.over_col || !a.over_val)) return GEOM_EINVAL;
+    if ((((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.saved | (uintptr_t)a.col | (uintptr_t)a.val) % 16) != 0) return GEOM_EINVAL;
+    if (b > 65535) return GEOM_ETOOBIG;
+    const GcnGeometry geo = ell_any_geometry(b, a.nv, a.c, BACKWARD);
+    float *partial = scratch;
+    const size_t lds = (BACKWARD && partial) ? (size_t)geo.rows_in_flight * a.c * sizeof(float) : 0;
+    const dim3 grid((unsigned)geo.chunks, (unsigned)b);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (act) {
+    case ACT_NONE: launch_ell_any_vec<ACT_NONE, BACKWARD>(a, w, geo, grid, lds, s, partial); break;
+    case ACT_RELU: launch_ell_any_vec<ACT_RELU, BACKWARD>(a, w, geo, grid, lds, s, partial); break;
+    case ACT_ELU: launch_ell_any_vec<ACT_ELU, BACKWARD>(a, w, geo, grid, lds, s, partial); break;
+    default: return GEOM_EINVAL;
+    }
+    if (BACKWARD && partial && grad_bias)
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((a.c + CS_COLS - 1) / CS_COLS), dim3(CS_COLS * CS_LANES), 0, s, (int)geo.blocks, a.c,
+                           partial, grad_bias);
+    return geom::launch_status();
+}
+
 template <bool BACKWARD>
 int dispatch_ell(EllArgs a, int b, int w, int act, float *grad_bias, float *scratch, void *stream)
 {
     if (b < 0 || a.nv < 0 || a.c < 0 || a.k < 0 || a.k > a.c) return GEOM_EINVAL;
-    if (!ell_supported(a.c, a.k, w)) return GEOM_EUNSUPPORTED;
+    if (!ell_supported(a.c, a.k, w)) return dispatch_ell_any<BACKWARD>(a, b, w, act, grad_bias, scratch, stream); // any width / split
     if (b == 0 || a.nv == 0) return 0;
     if (!a.col || !a.val || !a.y || (!a.x && !(BACKWARD && a.head_in))) return GEOM_EINVAL;
     if (a.head_in) { // head mode: split 3, ReLU with the sign mask or no activation; the forward also needs head_out
@@ -650,7 +865,7 @@ extern "C" int64_t geom_zn_gcn_bwd_partial_rows(int b, int nv, int c, int k, int
 {
     if (b <= 0 || nv <= 0 || c <= 0 || k < 0 || k > c) return 0;
     if (ell_w) {
-        if (!ell_supported(c, k, ell_w)) return 0;
+        if (!ell_supported(c, k, ell_w)) return ell_any_supported(c, ell_w) ? ell_any_geometry(b, nv, c, true).blocks : 0;
         const int per = ell_rows_per_block(k) * 2; // two row tiles per workgroup in the backward
         return (int64_t)((nv + per - 1) / per) * b;
     }

@@ -126,3 +126,36 @@ def backward_weight(x, g, want_bias=False):
     gb = torch.empty(c, dtype=torch.float32, device=x.device) if want_bias else None
     reduce([(rows, cin, c, ws, gw, gb)])
     return gw, gb
+
+
+# ---- any-shape products (csrc/dense_any.hip): the layers whose widths the 192-column kernels do not take -------------------
+def any_supported(rows, cin, c):
+    """Every 2-D fp32 product below 2 GiB per operand; worth it from a few hundred rows (launch-bound below)."""
+    return rows >= 256 and cin > 0 and c > 0 and rows * max(cin, c) * 4 < 2 ** 31 - 1
+
+
+def _row_major(t):
+    return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]
+
+
+def gemm(a, b, trans_a=False, trans_b=False, out=None, workspace=None):
+    """out = op(a) @ op(b), exact fp32 on the matrix cores; a, b 2-D with unit stride along their rows (any row pitch).
+    trans_a: a is [k, m] (x^T . g);  trans_b: b is [n, k] (g . w^T).  `workspace`: geom_gemm_workspace_floats floats for the
+    split over the summed index (allocated here when the plan wants one and none is given)."""
+    if not (_row_major(a) and _row_major(b)):
+        raise ValueError("gemm operands must be 2-D with contiguous rows")
+    k, m = (a.shape if trans_a else a.shape[::-1])
+    n, kb = (b.shape if trans_b else b.shape[::-1])
+    if k != kb:
+        raise ValueError("gemm: summed extents differ (%d vs %d)" % (k, kb))
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    elif not _row_major(out) or tuple(out.shape) != (m, n):
+        raise ValueError("gemm: out must be [%d, %d] with contiguous rows" % (m, n))
+    need = int(_lib.lib().geom_gemm_workspace_floats(m, n, k))
+    if need and (workspace is None or workspace.numel() < need):
+        workspace = torch.empty(need, dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.call("geom_gemm_f32", m, n, k, a.data_ptr(), a.stride(0), 1 if trans_a else 0, b.data_ptr(), b.stride(0),
+                  0 if trans_b else 1, out.data_ptr(), out.stride(0), _lib.ptr(workspace) if need else None, need)
+    return out

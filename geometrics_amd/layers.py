@@ -216,6 +216,7 @@ def _gradient_buffer(param, like):
         return hit[1].detach()           # a fresh tensor object over the target's memory (autograd adopts it as .grad)
     return torch.zeros_like(like) if _zero_fill_deferred else torch.empty_like(like)
 use_matrix_core_products = True       # the layers' dense gradients on csrc/dense_gemm.hip where dense.plan says so
+use_any_shape_products = True         # every other width: csrc/dense_any.hip (False: the library's products)
 
 
 class deferred_parameter_gradients:
@@ -910,6 +911,36 @@ class _DenseMM(torch.autograd.Function):
         return grad_x, _finish_weight_gradient(ctx.w_ref, w, rows, cin, c, ws)
 
 
+class _DenseAny(torch.autograd.Function):
+    """support = input @ W and both gradients on the any-shape matrix-core kernel (csrc/dense_any.hip): the layers whose
+    widths the 192-column kernels do not take -- the mesh encoder's 3 / 60 / ... / 300-wide ZERON_GCN layers, whose weight
+    gradients (18 432 summed rows against a 300 x 300 output) the library runs without a split, 73-97 us each."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x2 = x.reshape(-1, x.shape[-1])
+        w2 = w.reshape(w.shape[-2:])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        ctx.save_for_backward(x2, w)
+        ctx.x_shape = x.shape
+        return _dense_kernels.gemm(x2, w2).view(x.shape[:-1] + (w2.shape[1],))
+
+    @staticmethod
+    def backward(ctx, grad):
+        x2, w = ctx.saved_tensors
+        w2 = w.reshape(w.shape[-2:])
+        g2 = grad.reshape(-1, grad.shape[-1])
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        grad_x = grad_w = None
+        if ctx.needs_input_grad[0]:
+            grad_x = _dense_kernels.gemm(g2, w2, trans_b=True).view(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            grad_w = _dense_kernels.gemm(x2, g2, trans_a=True).view(w.shape)
+        return grad_x, grad_w
+
+
 def _dense(x, w):
     """input @ weight of a 0N-GCN layer; w = the layer's weight parameter ([Cin, Cout] or [1, Cin, Cout])."""
     arena = current_slabs()
@@ -920,6 +951,8 @@ def _dense(x, w):
         rows = x.numel() // x.shape[-1]
         if w.requires_grad and _dense_kernels.plan(rows, x.shape[-1], w.shape[-1])["dw"] == "mfma":
             return _DenseMM.apply(x, w)
+        if use_any_shape_products and w.is_contiguous() and _dense_kernels.any_supported(rows, x.shape[-1], w.shape[-1]):
+            return _DenseAny.apply(x, w)
     if plain or arena is None:
         return torch.matmul(x, w.squeeze(0) if w.dim() == 3 else w)   # [1,Cin,Cout]: one GEMM, not B broadcast bmm's
     return _Dense.apply(x, w, arena)
@@ -1170,7 +1203,7 @@ class _MaxPoolBase(Module):
         _uniform(self.weight_Ws[0], 6.0 / math.sqrt(self.weight_Ws[0].size(0) + self.weight_Ws[0].size(1)))
 
     def _pre_activation(self, r_s, adj):
-        support = torch.matmul(r_s, self.weight_Ws[0])
+        support = _dense(r_s, self.weight_Ws[0])
         return zero_n_aggregate(support, adj, self.weight_Bs[0], support.shape[-1] // 10)
 
 
@@ -1179,7 +1212,7 @@ class GCNMax(_MaxPoolBase):
     `adj` (r_s = the concatenated [sum(V), Cin] features) it returns one row per mesh, [B, print_length]."""
 
     def forward(self, r_s, adj, activation):
-        support = torch.matmul(r_s, self.weight_Ws[0])
+        support = _dense(r_s, self.weight_Ws[0])
         acted = zero_n_aggregate(support, adj, self.weight_Bs[0], support.shape[-1] // 10, activation)
         if hasattr(adj, "offsets"):
             from .ops import SegmentMax

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GEOM_ABI_VERSION 8
+#define GEOM_ABI_VERSION 9
 
 /* argument errors */
 #define GEOM_EINVAL   (-1) /* bad size / null pointer */
@@ -365,6 +365,21 @@ int geom_zn_layer_bwd_f32(int b, int nv, int c, int k, int ell_w, const int *ell
                           const float *grad_out, const float *out, const uint16_t *relu_mask, int act,
                           const float *grad_pos, float head_scale, const float *wt, int n_in, float *g_out,
                           float *grad_in, float *colsum_partial, void *stream);
+
+/* Any-shape product on the fp32 matrix cores (csrc/dense_any.hip): c [m, n] (row pitch ldc) = op(a) . op(b), exact fp32
+ * (v_mfma_f32_16x16x4_f32), any sizes / pitches / 4-byte alignments -- `torch.mm(input, weight)` of the layers whose widths
+ * the 192-column kernels above do not take (the mesh encoder's ZERON_GCN layers, reference layers.py:30, models.py:299-348)
+ * and the two gradients autograd derives from it:
+ *   a_km == 0: a is [m, k] (row pitch lda);  a_km != 0: a is [k, m] (the transposed operand of x^T . g)
+ *   b_kn != 0: b is [k, n] (row pitch ldb);  b_kn == 0: b is [n, k] (the transposed operand of g . w^T)
+ *   forward  x . w   : (rows, c, cin,  x, cin, 0,  w, c, 1)      input gradient  g . w^T : (rows, cin, c,  g, c, 0,  w, c, 0)
+ *   weight gradient x^T . g : (cin, c, rows,  x, cin, 1,  g, c, 1)
+ * A long sum against few output tiles is split over the summed index into partial tiles in `workspace`
+ * (geom_gemm_workspace_floats(m, n, k) floats; NULL / too small: one pass) and added up in split order by a second launch:
+ * bit-reproducible.  Operands and result must each stay below 2 GiB (GEOM_ETOOBIG). */
+int64_t geom_gemm_workspace_floats(int m, int n, int k);
+int geom_gemm_f32(int m, int n, int k, const float *a, int64_t lda, int a_km, const float *b, int64_t ldb, int b_kn,
+                  float *c, int64_t ldc, float *workspace, int64_t workspace_floats, void *stream);
 
 /* Coordinate update of a deformation stage (GEOMetrics.py:121,126,131) when the predicted offsets are the
  * three leading channels of a wider feature tensor: pos[r,:] = base[r,:] + scale*feat[r,:3] for `rows`
