@@ -23,6 +23,7 @@ namespace {
 constexpr int PL_THREADS = 256;
 constexpr int PL_WAVES = PL_THREADS / GEOM_WAVE;
 constexpr int PL_VERTS = GEOM_WAVE; // vertices per workgroup
+constexpr int PL_MAX_CHUNKS = 32;   // grid.z of the pooling launches (more 64-channel chunks than this: a workgroup walks several)
 // reference constants (utils.py:321, 329-335)
 constexpr float PL_SCALE = 0.57f, PL_FOCAL = 248.f, PL_HALF = 224.f / 2.0f, PL_NORM = 223.f;
 
@@ -32,6 +33,7 @@ struct PoolArgs {
     float *grad_blocks[GEOM_POOL_MAX_LEVELS];
     int channels[GEOM_POOL_MAX_LEVELS], dims[GEOM_POOL_MAX_LEVELS];
     int levels, b, nv, ctot;
+    int chunks; // 64-channel chunks of all maps together
 };
 
 struct Projection {
@@ -74,6 +76,25 @@ __device__ __forceinline__ Texel texel(float xs, float ys, int dim)
     return t;
 }
 
+// which 64-channel chunk of which map a workgroup owns (grid.z runs over the chunks of all maps in order): 15 chunks for the
+// reference's four VGG maps -- 8 vertex tiles x 16 meshes alone are 128 workgroups walking 960 channels each (100 us
+// forward, 186 us backward at the reference's training shape); with the chunks side by side the launch fills the chip
+struct Chunk {
+    int level, cc, off; // map, first channel inside it, first output column of the map
+};
+
+__device__ __forceinline__ Chunk chunk_of(const PoolArgs &a, int z)
+{
+    Chunk c{0, 0, 0};
+    while (c.level + 1 < a.levels && z >= (a.channels[c.level] + GEOM_WAVE - 1) / GEOM_WAVE) {
+        z -= (a.channels[c.level] + GEOM_WAVE - 1) / GEOM_WAVE;
+        c.off += a.channels[c.level];
+        ++c.level;
+    }
+    c.cc = z * GEOM_WAVE;
+    return c;
+}
+
 __global__ __launch_bounds__(PL_THREADS) void pool_fwd_kernel(PoolArgs a, float *out)
 {
     __shared__ float tile[PL_VERTS][GEOM_WAVE + 1];
@@ -81,32 +102,32 @@ __global__ __launch_bounds__(PL_THREADS) void pool_fwd_kernel(PoolArgs a, float 
     const int lane = threadIdx.x & (GEOM_WAVE - 1), wave = threadIdx.x >> 6;
     const int v = min(v0 + lane, a.nv - 1);
     const Projection pr = project(a, mesh, v);
-    int off = 0;
-    for (int l = 0; l < a.levels; ++l) {
-        const int dim = a.dims[l], C = a.channels[l];
+    for (int z = blockIdx.z; z < a.chunks; z += gridDim.z) { // (one chunk per workgroup up to PL_MAX_CHUNKS chunks)
+        const Chunk ck = chunk_of(a, z);
+        const int dim = a.dims[ck.level], C = a.channels[ck.level], cc = ck.cc;
         const Texel t = texel(pr.xs, pr.ys, dim);
-        const float *blk = a.blocks[l] + (size_t)mesh * C * dim * dim;
-        for (int cc = 0; cc < C; cc += GEOM_WAVE) {
-            const int nch = min(GEOM_WAVE, C - cc);
-            for (int c = wave; c < nch; c += PL_WAVES) {
-                const float *plane = blk + (size_t)(cc + c) * dim * dim;
-                const float s1 = (t.A * plane[t.i11]) * t.G, s2 = (t.H * plane[t.i12]) * t.A;
-                const float s3 = (t.G * plane[t.i21]) * t.B, s4 = (t.B * plane[t.i22]) * t.H;
-                tile[lane][c] = ((s1 + s2) + s3) + s4;
-            }
-            __syncthreads();
-            for (int i = threadIdx.x; i < PL_VERTS * nch; i += PL_THREADS) {
-                const int vv = i / nch, ch = i - vv * nch;
-                if (v0 + vv < a.nv) out[((size_t)mesh * a.nv + v0 + vv) * a.ctot + off + cc + ch] = tile[vv][ch];
-            }
-            __syncthreads();
+        const float *blk = a.blocks[ck.level] + (size_t)mesh * C * dim * dim;
+        const int nch = min(GEOM_WAVE, C - cc);
+        for (int c = wave; c < nch; c += PL_WAVES) {
+            const float *plane = blk + (size_t)(cc + c) * dim * dim;
+            const float s1 = (t.A * plane[t.i11]) * t.G, s2 = (t.H * plane[t.i12]) * t.A;
+            const float s3 = (t.G * plane[t.i21]) * t.B, s4 = (t.B * plane[t.i22]) * t.H;
+            tile[lane][c] = ((s1 + s2) + s3) + s4;
         }
-        off += C;
+        __syncthreads();
+        for (int i = threadIdx.x; i < PL_VERTS * nch; i += PL_THREADS) {
+            const int vv = i / nch, ch = i - vv * nch;
+            if (v0 + vv < a.nv) out[((size_t)mesh * a.nv + v0 + vv) * a.ctot + ck.off + cc + ch] = tile[vv][ch];
+        }
+        __syncthreads();
     }
 }
 
-// d loss / d verts: vertex-tiled like the forward (the gradient w.r.t. a vertex sums over all channels)
-__global__ __launch_bounds__(PL_THREADS) void pool_bwd_verts_kernel(PoolArgs a, const float *grad_out, float *grad_verts)
+// d loss / d verts: vertex-tiled like the forward (the gradient w.r.t. a vertex sums over all channels).  A workgroup owns
+// one 64-channel chunk and leaves its share of d loss / d (xs, ys) per vertex in `partial` [chunk][mesh][vertex][2];
+// pool_bwd_verts_finish_kernel adds the chunks up in chunk order (fixed: bit-reproducible) and chains the sum through the
+// clamp, the perspective divide and the camera matrix.
+__global__ __launch_bounds__(PL_THREADS) void pool_bwd_verts_kernel(PoolArgs a, const float *grad_out, float *partial)
 {
     __shared__ float tile[PL_VERTS][GEOM_WAVE + 1];
     __shared__ float part[PL_WAVES][2][PL_VERTS];
@@ -115,37 +136,34 @@ __global__ __launch_bounds__(PL_THREADS) void pool_bwd_verts_kernel(PoolArgs a, 
     const bool live = v0 + lane < a.nv;
     const int v = min(v0 + lane, a.nv - 1);
     const Projection pr = project(a, mesh, v);
-    float g_xs = 0.f, g_ys = 0.f; // this wave's share of d loss / d (xs, ys) of the lane's vertex
-    int off = 0;
-    for (int l = 0; l < a.levels; ++l) {
-        const int dim = a.dims[l], C = a.channels[l];
+    float ax = 0.f, ay = 0.f; // this wave's share of d loss / d (xs, ys) of the lane's vertex over the workgroup's chunks
+    for (int z = blockIdx.z; z < a.chunks; z += gridDim.z) {
+        const Chunk ck = chunk_of(a, z);
+        const int dim = a.dims[ck.level], C = a.channels[ck.level], cc = ck.cc;
         const Texel t = texel(pr.xs, pr.ys, dim);
-        const float *blk = a.blocks[l] + (size_t)mesh * C * dim * dim;
-        float gx = 0.f, gy = 0.f;
-        for (int cc = 0; cc < C; cc += GEOM_WAVE) {
-            const int nch = min(GEOM_WAVE, C - cc);
-            for (int i = threadIdx.x; i < PL_VERTS * nch; i += PL_THREADS) {
-                const int vv = i / nch, ch = i - vv * nch;
-                tile[vv][ch] = v0 + vv < a.nv ? grad_out[((size_t)mesh * a.nv + v0 + vv) * a.ctot + off + cc + ch] : 0.f;
-            }
-            __syncthreads();
-            if (live) {
-                for (int c = wave; c < nch; c += PL_WAVES) {
-                    const size_t po = (size_t)(cc + c) * dim * dim;
-                    const float g = tile[lane][c];
-                    const float c11 = blk[po + t.i11], c12 = blk[po + t.i12], c21 = blk[po + t.i21], c22 = blk[po + t.i22];
-                    gx += g * (((-c11 * t.G) - (t.H * c12)) + ((t.G * c21) + (c22 * t.H)));
-                    gy += g * (((-t.A * c11) + (c12 * t.A)) + ((-c21 * t.B) + (t.B * c22)));
-                }
-            }
-            __syncthreads();
+        const float *blk = a.blocks[ck.level] + (size_t)mesh * C * dim * dim;
+        const int nch = min(GEOM_WAVE, C - cc);
+        for (int i = threadIdx.x; i < PL_VERTS * nch; i += PL_THREADS) {
+            const int vv = i / nch, ch = i - vv * nch;
+            tile[vv][ch] = v0 + vv < a.nv ? grad_out[((size_t)mesh * a.nv + v0 + vv) * a.ctot + ck.off + cc + ch] : 0.f;
         }
-        if (t.in_x) g_xs += gx * dim;
-        if (t.in_y) g_ys += gy * dim;
-        off += C;
+        __syncthreads();
+        float gx = 0.f, gy = 0.f;
+        if (live) {
+            for (int c = wave; c < nch; c += PL_WAVES) {
+                const size_t po = (size_t)(cc + c) * dim * dim;
+                const float g = tile[lane][c];
+                const float c11 = blk[po + t.i11], c12 = blk[po + t.i12], c21 = blk[po + t.i21], c22 = blk[po + t.i22];
+                gx += g * (((-c11 * t.G) - (t.H * c12)) + ((t.G * c21) + (c22 * t.H)));
+                gy += g * (((-t.A * c11) + (c12 * t.A)) + ((-c21 * t.B) + (t.B * c22)));
+            }
+        }
+        if (t.in_x) ax += gx * dim; // the clamp passes the gradient only inside the map
+        if (t.in_y) ay += gy * dim;
+        __syncthreads();
     }
-    part[wave][0][lane] = g_xs;
-    part[wave][1][lane] = g_ys;
+    part[wave][0][lane] = ax;
+    part[wave][1][lane] = ay;
     __syncthreads();
     if (wave == 0 && live) {
         float sx = 0.f, sy = 0.f;
@@ -153,18 +171,32 @@ __global__ __launch_bounds__(PL_THREADS) void pool_bwd_verts_kernel(PoolArgs a, 
             sx += part[w][0][lane];
             sy += part[w][1][lane];
         }
-        // xs = h/223, ys = w/223; h = (-Y)/(-Z)*F + 112, w = X/(-Z)*F + 112
-        const float gh = sx / PL_NORM, gw = sy / PL_NORM;
-        const float d = -pr.Z;
-        const float gX = gw * (PL_FOCAL / d);
-        const float gY = -gh * (PL_FOCAL / d);
-        const float gZ = (gh * ((-pr.Y) * PL_FOCAL) + gw * (pr.X * PL_FOCAL)) / (d * d); // d(.)/dd * dd/dZ, dd/dZ = -1 twice
-        const float *M = a.cam_mat + (size_t)mesh * 9;
-        float *gv = grad_verts + ((size_t)mesh * a.nv + v) * 3;
-        gv[0] = PL_SCALE * ((gX * M[0] + gY * M[3]) + gZ * M[6]);
-        gv[1] = PL_SCALE * ((gX * M[1] + gY * M[4]) + gZ * M[7]);
-        gv[2] = PL_SCALE * ((gX * M[2] + gY * M[5]) + gZ * M[8]);
+        float *o = partial + (((size_t)blockIdx.z * a.b + mesh) * a.nv + v) * 2;
+        o[0] = sx, o[1] = sy;
     }
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_verts_finish_kernel(PoolArgs a, const float *partial, int chunks, float *grad_verts)
+{
+    const int mesh = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= a.nv) return;
+    const Projection pr = project(a, mesh, v);
+    float sx = 0.f, sy = 0.f;
+    for (int z = 0; z < chunks; ++z) {
+        const float *p = partial + (((size_t)z * a.b + mesh) * a.nv + v) * 2;
+        sx += p[0], sy += p[1];
+    }
+    // xs = h/223, ys = w/223; h = (-Y)/(-Z)*F + 112, w = X/(-Z)*F + 112
+    const float gh = sx / PL_NORM, gw = sy / PL_NORM;
+    const float d = -pr.Z;
+    const float gX = gw * (PL_FOCAL / d);
+    const float gY = -gh * (PL_FOCAL / d);
+    const float gZ = (gh * ((-pr.Y) * PL_FOCAL) + gw * (pr.X * PL_FOCAL)) / (d * d); // d(.)/dd * dd/dZ, dd/dZ = -1 twice
+    const float *M = a.cam_mat + (size_t)mesh * 9;
+    float *gv = grad_verts + ((size_t)mesh * a.nv + v) * 3;
+    gv[0] = PL_SCALE * ((gX * M[0] + gY * M[3]) + gZ * M[6]);
+    gv[1] = PL_SCALE * ((gX * M[1] + gY * M[4]) + gZ * M[7]);
+    gv[2] = PL_SCALE * ((gX * M[2] + gY * M[5]) + gZ * M[8]);
 }
 
 // d loss / d maps as a GATHER (no floating-point atomics anywhere).
@@ -189,6 +221,7 @@ struct BinSpace {
     float *ent_w;   // per (mesh, level): 4*nv weights
     int off_stride; // ints per mesh in `offsets`
     int level_off[GEOM_POOL_MAX_LEVELS]; // start of level l inside a mesh's offsets block
+    float *vert_partial; // [PL_MAX_CHUNKS][b][nv][2]
 };
 
 __global__ __launch_bounds__(BIN_THREADS) void pool_bin_kernel(PoolArgs a, BinSpace ws)
@@ -297,11 +330,12 @@ int fill_args(PoolArgs &a, int b, int nv, const float *verts, const float *cam_m
     if (b < 0 || nv < 0 || levels < 0 || levels > GEOM_POOL_MAX_LEVELS) return GEOM_EINVAL;
     if (!verts || !cam_mat || !cam_pos || (levels > 0 && (!blocks || !channels || !dims))) return GEOM_EINVAL;
     if (b > 65535) return GEOM_ETOOBIG;
-    a.verts = verts, a.cam_mat = cam_mat, a.cam_pos = cam_pos, a.levels = levels, a.b = b, a.nv = nv, a.ctot = 0;
+    a.verts = verts, a.cam_mat = cam_mat, a.cam_pos = cam_pos, a.levels = levels, a.b = b, a.nv = nv, a.ctot = 0, a.chunks = 0;
     for (int l = 0; l < levels; ++l) {
         if (!blocks[l] || channels[l] <= 0 || dims[l] <= 0) return GEOM_EINVAL;
         a.blocks[l] = blocks[l], a.grad_blocks[l] = nullptr, a.channels[l] = channels[l], a.dims[l] = dims[l];
         a.ctot += channels[l];
+        a.chunks += (channels[l] + GEOM_WAVE - 1) / GEOM_WAVE;
     }
     return 0;
 }
@@ -316,8 +350,8 @@ extern "C" int geom_pool_features_fwd_f32(int b, int nv, const float *verts, con
     if (int rc = fill_args(a, b, nv, verts, cam_mat, cam_pos, levels, blocks, channels, dims)) return rc;
     if (b == 0 || nv == 0 || levels == 0) return 0;
     if (!out) return GEOM_EINVAL;
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3((nv + PL_VERTS - 1) / PL_VERTS, b), dim3(PL_THREADS), 0,
-                       static_cast<hipStream_t>(stream), a, out);
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3((nv + PL_VERTS - 1) / PL_VERTS, b, a.chunks < PL_MAX_CHUNKS ? a.chunks : PL_MAX_CHUNKS),
+                       dim3(PL_THREADS), 0, static_cast<hipStream_t>(stream), a, out);
     return geom::launch_status();
 }
 
@@ -337,7 +371,10 @@ static size_t pool_ws_layout(int b, int nv, int levels, const int *dims, BinSpac
         ws->ent_w = reinterpret_cast<float *>(p + off_bytes + ent * sizeof(int));
         ws->off_stride = per_mesh;
     }
-    return off_bytes + ent * (sizeof(int) + sizeof(float));
+    const size_t lists = (off_bytes + ent * (sizeof(int) + sizeof(float)) + 15) / 16 * 16;
+    if (ws) ws->vert_partial = reinterpret_cast<float *>(static_cast<char *>(base) + lists);
+    // + the per-chunk shares of d loss / d (xs, ys) of every vertex (pool_bwd_verts_kernel)
+    return lists + (size_t)PL_MAX_CHUNKS * b * nv * 2 * sizeof(float);
 }
 
 extern "C" size_t geom_pool_features_bwd_workspace_bytes(int b, int nv, int levels, const int *dims)
@@ -364,16 +401,20 @@ extern "C" int geom_pool_features_bwd_f32(int b, int nv, const float *verts, con
         if (dims[l] * dims[l] > BIN_MAX_TEXELS) return GEOM_EUNSUPPORTED;
         tasks += dims[l] * dims[l] * ((channels[l] + GEOM_WAVE - 1) / GEOM_WAVE);
     }
+    if (!any_map && !grad_verts) return 0;
+    BinSpace ws;
+    const size_t need = pool_ws_layout(b, nv, levels, dims, &ws, workspace);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return GEOM_EINVAL;
     if (any_map) {
-        BinSpace ws;
-        const size_t need = pool_ws_layout(b, nv, levels, dims, &ws, workspace);
-        if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return GEOM_EINVAL;
         hipLaunchKernelGGL(pool_bin_kernel, dim3(levels, b), dim3(BIN_THREADS), 0, s, a, ws);
         hipLaunchKernelGGL(pool_gather_kernel, dim3((tasks + PL_WAVES - 1) / PL_WAVES, b), dim3(PL_THREADS), 0, s, a, ws,
                            grad_out, tasks);
     }
-    if (grad_verts)
-        hipLaunchKernelGGL(pool_bwd_verts_kernel, dim3((nv + PL_VERTS - 1) / PL_VERTS, b), dim3(PL_THREADS), 0, s, a,
-                           grad_out, grad_verts);
+    if (grad_verts) {
+        const int zc = a.chunks < PL_MAX_CHUNKS ? a.chunks : PL_MAX_CHUNKS;
+        hipLaunchKernelGGL(pool_bwd_verts_kernel, dim3((nv + PL_VERTS - 1) / PL_VERTS, b, zc), dim3(PL_THREADS), 0, s, a, grad_out,
+                           ws.vert_partial);
+        hipLaunchKernelGGL(pool_bwd_verts_finish_kernel, dim3((nv + 255) / 256, b), dim3(256), 0, s, a, ws.vert_partial, zc, grad_verts);
+    }
     return geom::launch_status();
 }

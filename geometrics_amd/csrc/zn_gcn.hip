@@ -763,7 +763,9 @@ int dispatch_ell_any(EllArgs a, int b, int w, int act, float *grad_bias, float *
     if (BACKWARD && act != ACT_NONE && !a.saved) return GEOM_EINVAL;
     if (grad_bias && !scratch) return GEOM_EINVAL;
     if (a.over_ptr && (!a.over_col || !a.over_val)) return GEOM_EINVAL;
-    if ((((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.saved | (uintptr_t)a.col | (uintptr_t)a.val) % 16) != 0) return GEOM_EINVAL;
+    // the table rows are read 16 bytes at a time; the operands VEC floats at a time (rows of c floats: VEC divides c)
+    if ((((uintptr_t)a.col | (uintptr_t)a.val) % 16) != 0) return GEOM_EINVAL;
+    if ((((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.saved) % (4 * ell_any_vec(a.c))) != 0) return GEOM_EINVAL;
     if (b > 65535) return GEOM_ETOOBIG;
     const GcnGeometry geo = ell_any_geometry(b, a.nv, a.c, BACKWARD);
     float *partial = scratch;

@@ -790,6 +790,23 @@ def _flush_dense_products(jobs):
         i = j
 
 
+def _takes_any_shape_kernel(rows, cin, c):
+    """Shapes whose products run on csrc/dense_any.hip: whatever the 192-column kernels (dense.plan) do not take."""
+    return (use_any_shape_products and use_matrix_core_products and _dense_kernels.plan(rows, cin, c)["dw"] != "mfma"
+            and _dense_kernels.any_supported(rows, cin, c))
+
+
+def _forward_product(x, w2):
+    """x [..., cin] @ w2 [cin, c]: ONE rule for which kernel computes it, whichever autograd node wraps it (the routes of a
+    layer must agree bit for bit in the forward: tests compare them)."""
+    rows = x.numel() // x.shape[-1] if x.shape[-1] else 0
+    if (x.is_cuda and x.dtype == torch.float32 and w2.dtype == torch.float32 and w2.is_contiguous()
+            and _takes_any_shape_kernel(rows, x.shape[-1], w2.shape[-1])):
+        x2 = x.reshape(-1, x.shape[-1])
+        return _dense_kernels.gemm(x2 if x2.is_contiguous() else x2.contiguous(), w2).view(x.shape[:-1] + (w2.shape[1],))
+    return torch.matmul(x, w2)
+
+
 class _Dense(torch.autograd.Function):
     """support = input @ W for [.., Cin] x [Cin, Cout] (W may carry the reference's leading 1: [1, Cin, Cout]) with the
     weight gradient postponed to the end of the backward pass (used only inside weight_gradient_batching();
@@ -802,7 +819,7 @@ class _Dense(torch.autograd.Function):
         ctx.w_ref = weakref.ref(w)
         if ctx.needs_input_grad[1]:
             _register_bias_user(w, ctx)
-        return torch.matmul(x, w.reshape(w.shape[-2:]))
+        return _forward_product(x, w.reshape(w.shape[-2:]))
 
     @staticmethod
     def backward(ctx, grad):
@@ -924,7 +941,7 @@ class _DenseAny(torch.autograd.Function):
             x2 = x2.contiguous()
         ctx.save_for_backward(x2, w)
         ctx.x_shape = x.shape
-        return _dense_kernels.gemm(x2, w2).view(x.shape[:-1] + (w2.shape[1],))
+        return _forward_product(x2, w2).view(x.shape[:-1] + (w2.shape[1],))
 
     @staticmethod
     def backward(ctx, grad):
@@ -951,10 +968,11 @@ def _dense(x, w):
         rows = x.numel() // x.shape[-1]
         if w.requires_grad and _dense_kernels.plan(rows, x.shape[-1], w.shape[-1])["dw"] == "mfma":
             return _DenseMM.apply(x, w)
-        if use_any_shape_products and w.is_contiguous() and _dense_kernels.any_supported(rows, x.shape[-1], w.shape[-1]):
+        if w.is_contiguous() and _takes_any_shape_kernel(rows, x.shape[-1], w.shape[-1]):
             return _DenseAny.apply(x, w)
     if plain or arena is None:
-        return torch.matmul(x, w.squeeze(0) if w.dim() == 3 else w)   # [1,Cin,Cout]: one GEMM, not B broadcast bmm's
+        # ([1,Cin,Cout]: one GEMM, not B broadcast bmm's; the same kernel as the differentiable routes pick for the shape)
+        return _forward_product(x, w.squeeze(0) if w.dim() == 3 else w)
     return _Dense.apply(x, w, arena)
 
 

@@ -498,7 +498,9 @@ class PoolFeatures(torch.autograd.Function):
         gptrs = (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in gblks])
         gverts = torch.empty_like(v) if ctx.needs_input_grad[0] else None
         ws, ws_bytes = None, 0
-        if any(need_blocks):   # texel -> (vertex, weight) lists for the gather formulation of the map gradient
+        if any(need_blocks) or gverts is not None:
+            # texel -> (vertex, weight) lists for the gather formulation of the map gradient + the per-chunk partial sums
+            # of the vertex gradient
             ws_bytes = _lib.lib().geom_pool_features_bwd_workspace_bytes(b, nv, n, dims)
             ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=v.device)
         with torch.cuda.device(v.device):

@@ -431,8 +431,9 @@ int geom_vertex_bn_bwd_f32(int b, int nv, int c, const float *x, const float *gr
  * HOST arrays of `levels` <= GEOM_POOL_MAX_LEVELS entries.  Backward: grad_blocks[l] (entries or the array
  * may be NULL) and grad_verts [b,nv,3] (may be NULL) are fully overwritten (nothing to zero-initialise).  The
  * map gradient is computed as a gather over texel -> (vertex, weight) lists built in `workspace` (device,
- * 16-byte aligned, >= geom_pool_features_bwd_workspace_bytes(...) bytes; may be NULL when no map gradient
- * is requested); dims[l] <= 64, else GEOM_EUNSUPPORTED. */
+ * 16-byte aligned, >= geom_pool_features_bwd_workspace_bytes(...) bytes), which also holds the per-channel-chunk
+ * partial sums of the vertex gradient (added up in chunk order by a finishing launch): required whenever a
+ * gradient is requested (ABI 9; GEOM_EINVAL otherwise); dims[l] <= 64, else GEOM_EUNSUPPORTED. */
 size_t geom_pool_features_bwd_workspace_bytes(int b, int nv, int levels, const int *dims);
 #define GEOM_POOL_MAX_LEVELS 8
 int geom_pool_features_fwd_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos,
