@@ -47,7 +47,7 @@ VALU_ISSUE_TERA_LANE_OPS = FP32_PEAK_TFLOPS / 2.0
 VALU_MEASURED_TERA_LANE_OPS = 103.0 / 2.0
 TRI_ALGO_FLOP_PER_PAIR = 60.0    # hoisted op count of the reference's decision tree per (point, triangle)
 NN_FLOP_PER_PAIR = 8.0           # 3 sub, 3 mul, 2 add
-PROFILE_TAG = "r04"           # the committed profiles these figures are read from / compared with
+PROFILE_TAG = "r05"           # the committed profiles these figures are read from / compared with
 PMC_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_counters.json")
 
 
@@ -102,7 +102,7 @@ class Workload:
         self.opt = optim.FusedAdam(self.stack.parameters(), lr=lr)
         self.loss = None
         self.graphs = None
-        # N > 1 choreography: the all-reduce is issued right behind the end-of-pass reduction launch and
+        # N > 1 choreography (LAB_NOTES.md section 8): the all-reduce is issued right behind the end-of-pass reduction launch and
         # travels on RCCL's stream while the first layer's input-gradient product (postponed behind the reduction:
         # layers.late_input_gradients) runs on the launch stream; the Adam step on the reduced bucket opens the NEXT step
         # (`pending`), inside its graph: no eager launch between two replays
@@ -159,7 +159,7 @@ class Workload:
         """Called inside the backward pass (end-of-pass callback), right behind the reduction launch that wrote the bucket
         and in front of the postponed input-gradient product.  While capture() records the step: END graph A here and BEGIN
         graph B -- the collective is issued between their replays.  (ONE graph with an event-record node at this place
-        would be the natural form; measured and rejected)"""
+        would be the natural form; measured and rejected in round 4, LAB_NOTES.md section 8; round 5 captures the collective itself instead.)"""
         if self._splitting is not None:
             ga, gb = self._splitting
             ga.capture_end()

@@ -30,7 +30,7 @@
 //     (-ffp-contract=off) -- bit-identical to the reference CPU nnsearch (my_lib.c:13-16).
 //
 // The pair scan is FP32-VALU bound (~9.3 lane-ops per pair); HBM traffic is the
-// compulsory 20 B per point.  See DESIGN.md "Kernels".  (Measured and rejected: packed v_pk_add_f32 /
+// compulsory 20 B per point.  See LAB_NOTES.md section 4.  (Measured and rejected: packed v_pk_add_f32 /
 // v_pk_mul_f32 on two targets per lane with an x|y|z-per-group LDS layout -- bit-identical results, 96 packed
 // instructions in the loop, but 38.6 us instead of 34.8: on gfx950 the packed ops do not issue at twice the
 // scalar rate for this instruction mix.)

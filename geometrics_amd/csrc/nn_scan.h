@@ -182,7 +182,7 @@ __device__ __forceinline__ void nn_scalar_body(const NNJob &job, int bid, const 
 //   3. a wave's pending runs are fetched global -> LDS without passing through registers (LDS-DMA, five runs per
 //      instruction, all in flight), then each takes the lanes' own test
 //          |q - c_run|^2 > (s_q + R_run)^2  for every lane  =>  no target of the run can beat or tie any lane's best
-//      (s_q = sqrt(bound_q) and R_run with the margins of the culled triangle scan) and, if some lane admits
+//      (s_q = sqrt(bound_q) and R_run with the margins of the culled triangle scan, LAB_NOTES.md 5b) and, if some lane admits
 //      it, the brute-force scan's arithmetic -- two targets per packed instruction (v_pk_add/mul/fma_f32 are IEEE per
 //      component: the same bits) -- group minimum first;
 //   4. closing phase, thread <-> (query, member of a run): the minimum over the waves' partial results and the exact

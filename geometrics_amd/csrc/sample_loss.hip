@@ -1,7 +1,7 @@
 // HBM-bound stages around the two scans: face areas, fused gather + barycentric sampling
 // (forward / backward), Chamfer gather-loss gradient, point-to-surface loss (forward /
 // backward) and a deterministic sum.  One thread per point; every operand is read once
-// and every result written once (algorithmic bytes in DESIGN.md "Kernels").
+// and every result written once (algorithmic bytes in DESIGN.md section 4).
 //
 // Reference stages replaced (all eager PyTorch op chains there):
 //   utils.py:596-602   face areas                     -> face_areas_kernel

@@ -9,7 +9,7 @@ kernel (csrc/zn_gcn.hip) -> one per-vertex BN + ReLU (+ residual average) kernel
 A BatchNorm output that feeds the next layer AND a later residual average is handed out as two tensor objects over
 the same memory (`tap`), so that its two upstream gradients meet inside the BN backward kernel instead of in a separate
 accumulation pass; the block input's leading columns (the first residual) are tapped the same way (`_InputTap`).
-(Measured and rejected: aggregation + BatchNorm in ONE launch -- DESIGN section 4.)
+(Measured and rejected: aggregation + BatchNorm in ONE launch -- LAB_NOTES.md section 4.)
 Data-parallel note: by default every rank normalises with the statistics of its own shard (fused kernel, no collective,
 graph-capturable: DDP semantics).  `VertexBatchNorm.sync_across_ranks = True` switches to the statistics of the GLOBAL
 batch (`_SyncVertexBN`: per-vertex mean, then centred second moment, all-reduced), i.e. N shards normalise exactly as the

@@ -123,7 +123,7 @@ def rows_close(actual, exact, mass, rtol, what="", floor=None, floor_ulps=0.0):
     bound = rtol * mass + (0.0 if floor is None else floor_ulps * np.asarray(floor, np.float64)) + 1e-30
     worst = float((err / bound).max())
     log = os.environ.get("GEOM_MARGIN_LOG")
-    if log:                       # margins of a run, for choosing / reporting the bounds (DESIGN quotes them)
+    if log:                       # margins of a run, for choosing / reporting the bounds (LAB_NOTES.md quotes them)
         with open(log, "a") as f:
             f.write("%s: worst element at %.3g of its bound (rtol %g, floor %g ulp), max abs err %.3g, max |exact| %.3g\n"
                     % (what, worst, rtol, floor_ulps, err.max(), np.abs(exact).max()))
