@@ -33,6 +33,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; }; // 16 bytes at 4-byte alignment (963-float rows)
 
 constexpr int DG_THREADS = 256;
@@ -583,6 +584,37 @@ struct SplitArgs {
 // two waves on a SIMD issue into each other's gaps.  A wave then runs KS = 8 / KP k-steps per stage: loads of the stage
 // after next in its first KS/2 steps, LDS stores in the following ones, barrier behind step KS - 2, the first fragments of
 // the next stage requested in the last step.
+// X fragments of one k-step with WIDE LDS reads: the tile's rows are dealt to the MFMA row-blocks so that a lane's RB
+// fragment values are neighbours in the [t][r] panel -- lane x of row-blocks 4q .. 4q+3 holds rows 64q + 4x + {0,1,2,3} (one
+// ds_read_b128), a remaining pair rows 2x + {0,1} (ds_read_b64), a remaining single row x.  Which row an accumulator holds
+// is only a matter of where the epilogue stores it (split_row); every output element is still the same sum in the same
+// order.  6 row-blocks: 2 LDS reads per k-step instead of 6 -- on this chip an LDS read is not hidden behind the MFMAs, it
+// takes issue cycles away from them (profiles/r05_mfma_corun.txt).
+template <int RB>
+__device__ __forceinline__ int split_row(int i, int x)
+{
+    constexpr int N4 = RB / 4, N2 = (RB % 4) / 2;
+    if (i < 4 * N4) return 64 * (i >> 2) + 4 * x + (i & 3);
+    if (i < 4 * N4 + 2 * N2) return 64 * N4 + 2 * x + (i - 4 * N4);
+    return 64 * N4 + 32 * N2 + x;
+}
+
+template <int RB>
+__device__ __forceinline__ void split_frags(float (&f)[RB], const float *row, int x)
+{
+    constexpr int N4 = RB / 4, N2 = (RB % 4) / 2, N1 = RB % 2;
+#pragma unroll
+    for (int q = 0; q < N4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(row + 64 * q + 4 * x);
+        f[4 * q] = v[0], f[4 * q + 1] = v[1], f[4 * q + 2] = v[2], f[4 * q + 3] = v[3];
+    }
+    if constexpr (N2 == 1) {
+        const f32x2 v = *reinterpret_cast<const f32x2 *>(row + 64 * N4 + 2 * x);
+        f[4 * N4] = v[0], f[4 * N4 + 1] = v[1];
+    }
+    if constexpr (N1 == 1) f[RB - 1] = row[64 * N4 + 32 * N2 + x];
+}
+
 template <int RB, int RA, int A_FLOATS, int SET, int KP, class PA, class Tail>
 __device__ __forceinline__ void split_stage(const float *cur, float *wr, f32x4 (&acc)[RB][3], float (&fa)[2][RB], f3u (&bq)[2][DG_KS / KP],
                                             PA &pa, const StageIO &io, unsigned b_lane, unsigned b_step, int kpart, Tail tail)
@@ -600,9 +632,7 @@ __device__ __forceinline__ void split_stage(const float *cur, float *wr, f32x4 (
         { // X fragments of this wave's next k-step (of the next stage after the last one): global k-step KP * s' + kpart
             const float *src = s + 1 < KS ? cur : wr;
             const int sn = (s + 1 < KS ? KP * (s + 1) : 0) + kpart;
-            const float *pa_l = src + g * ld_rc(RA) + x;
-#pragma unroll
-            for (int i = 0; i < RB; ++i) fa[(s + 1) & 1][i] = pa_l[4 * sn * ld_rc(RA) + i * 16];
+            split_frags<RB>(fa[(s + 1) & 1], src + (4 * sn + g) * ld_rc(RA), x);
         }
 #endif
 #ifdef DG_PROBE_NO_ISSUE
@@ -717,11 +747,7 @@ __device__ __forceinline__ void split_body(const SplitArgs &q, float *lds, int i
         aim();
         io.st_tmax = t_end;
         __syncthreads();
-        {
-            const float *pa_l = lds + g * ld_rc(RA) + x;
-#pragma unroll
-            for (int i = 0; i < RB; ++i) fa[0][i] = pa_l[4 * kpart * ld_rc(RA) + i * 16];
-        }
+        split_frags<RB>(fa[0], lds + (4 * kpart + g) * ld_rc(RA), x);
         int buf = 0;
         auto tail = [&]() {
             io.st_t0 = t_begin + l_st * DG_BK;
@@ -798,7 +824,7 @@ __device__ __forceinline__ void split_body(const SplitArgs &q, float *lds, int i
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int u = 0; u < 3; ++u) e[3 * r + u] = acc[i][u][r];
-        f32x4 *d = reinterpret_cast<f32x4 *>(dst + (i * 16 + x) * CW + j0);
+        f32x4 *d = reinterpret_cast<f32x4 *>(dst + split_row<RB>(i, x) * CW + j0);
         d[0] = (f32x4){e[0], e[1], e[2], e[3]};
         d[1] = (f32x4){e[4], e[5], e[6], e[7]};
         d[2] = (f32x4){e[8], e[9], e[10], e[11]};
