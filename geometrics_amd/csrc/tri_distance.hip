@@ -1281,13 +1281,15 @@ __device__ __forceinline__ void scan_tail_role(const ScanTail &t, int role, int 
     geom_finalize::surface_finalize_body<false, 8 * GEOM_WAVE, ScanTailWait, 16, true>(t.fin, lds_ints, loss_role ? b : role, wait);
 }
 
-// CULL: the Chamfer tiles take the culled scan (nn_culled_body).  Its tiles are latency chains, not issue-bound loops, so
-// the launch wants THREE workgroups per CU: the two bodies' LDS is overlaid (a workgroup is one or the other: 43 KB instead
-// of 27 + 43) and the register budget is capped at 80 (6 waves per SIMD; the triangle body spills a dozen registers to
-// scratch there, measured harmless).  The brute-force variant keeps two workgroups per CU: it IS issue-bound, and capping
-// its registers only added spills (round 2: 55.3 against 48 us).
+// CULL: the Chamfer tiles take the culled scan (nn_culled_body).  Its tiles are latency chains, not issue-bound loops; the two
+// bodies' LDS is overlaid (a workgroup is one or the other: 46 KB instead of 27 + 43).  Register budget: 5 waves per SIMD =
+// 96 registers -- the triangle body wants 104 on its own, fits 96 without a spill, and at the round-4 cap of 80 (6 waves per
+// SIMD, three workgroups per CU) it spilled 13 registers and re-read 12 MB of scratch per launch.  A/B on one box, alternating
+// (tools/probe/scan_cap_ab.sh): 49.8 / 49.2 / 48.5 us at 96 registers against 50.7 / 49.4 / 49.2 at 80 -- the third workgroup
+// per CU bought nothing once the Chamfer tiles were culled.  The brute-force variant keeps two workgroups per CU: it IS
+// issue-bound, and capping its registers only added spills (round 2: 55.3 against 48 us).
 template <bool FIX6, bool FMA, bool CULL>
-__global__ __launch_bounds__(8 * GEOM_WAVE, CULL ? 6 : 1) void surface_scan_kernel(const float *__restrict__ xyz, int b, int n, int m,
+__global__ __launch_bounds__(8 * GEOM_WAVE, CULL ? 5 : 1) void surface_scan_kernel(const float *__restrict__ xyz, int b, int n, int m,
                                                                                   TriGws ws, float *__restrict__ dist,
                                                                                   int *__restrict__ point, int *__restrict__ index,
                                                                                   SurfaceOut surf, NNJob job, NNRecords rr,
