@@ -14,6 +14,7 @@ bash tools/profile_driver_step.sh > $OUT/profile_driver_step.log 2>&1    # the r
 python tools/shorten_stats.py $(ls /tmp/enc/*/e_kernel_stats.csv /tmp/enc/e_kernel_stats.csv 2>/dev/null | head -1) $OUT/r05_encoder_kernel_stats.csv
 python tools/time_encoder.py 2>&1 | grep -v "amdgpu.ids\|Warning\|run_backward" > $OUT/r05_encoder_step.txt
 python tools/time_force_dp.py 2>&1 | grep -v amdgpu.ids > $OUT/time_force_dp.txt
+cp $OUT/r05_pmc_counters.json $OUT/r05_step_kernel_stats.csv profiles/     # (on the box: the bench line reads its counter-derived fields from the profiles of THESE sources)
 python bench.py > $OUT/r05_bench_default_run.json 2> $OUT/bench_default.err
 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_form.json 2>/dev/null
 ls -la $OUT
