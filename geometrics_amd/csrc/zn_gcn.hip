@@ -590,114 +590,135 @@ __global__ __launch_bounds__(GCN_THREADS) void zn_aggregate_ell_any_kernel(EllAr
                                                                             float *colsum_partial)
 {
     extern __shared__ float lds_colsum[]; // [rows_in_flight][c], backward with colsum only
+    const int r_begin = blockIdx.x * rows_per_block;
+    const int r_end = min(r_begin + rows_per_block, a.nv);
+    const int64_t mesh_row0 = (int64_t)blockIdx.y * a.nv;
+
+    // ---- the aggregated columns: COMPACT gather threads.  Item (row, j): group j < kgs of the row (kgs = the groups that hold
+    // an aggregated column, the straddling one included); every lane of a wave gathers -- with the gathers left to the few
+    // lanes of a row-major layout that own aggregated columns (8 of 75 at c = 300) a wave issued its 12 memory instructions
+    // for 128 useful bytes each, and the launch took 18.7 us against 10.9 for the copy alone (tools/probe/agg_any_probe.py)
+    const int kgs = (a.k + VEC - 1) / VEC;
+    for (int item = threadIdx.x; item < (r_end - r_begin) * kgs; item += GCN_THREADS) {
+        const int r = r_begin + item / kgs, c0 = (item % kgs) * VEC;
+        const int64_t row = mesh_row0 + r;
+        int nb[W];
+        float w[W];
+#pragma unroll
+        for (int n = 0; n < W; n += 4) { // round trip 1: the row's table entries
+            const int4 ci = *reinterpret_cast<const int4 *>(a.col + (size_t)r * W + n);
+            const float4 wi = *reinterpret_cast<const float4 *>(a.val + (size_t)r * W + n);
+            nb[n] = ci.x, nb[n + 1] = ci.y, nb[n + 2] = ci.z, nb[n + 3] = ci.w;
+            w[n] = wi.x, w[n + 1] = wi.y, w[n + 2] = wi.z, w[n + 3] = wi.w;
+        }
+        int e0 = 0, e1 = 0;
+        if (a.over_ptr) e0 = a.over_ptr[r], e1 = a.over_ptr[r + 1];
+        Pack<VEC> sv[W], ov[W];
+#pragma unroll
+        for (int n = 0; n < W; ++n) { // round trip 2: the neighbour rows
+            const int64_t nrow = mesh_row0 + (nb[n] >= 0 ? nb[n] : r);
+            sv[n].load(a.x + nrow * a.c + c0);
+            if (BACKWARD && ACT != ACT_NONE) ov[n].load(a.saved + nrow * a.c + c0);
+        }
+        Pack<VEC> acc;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc.at(i) = 0.f;
+#pragma unroll
+        for (int n = 0; n < W; ++n) {
+            if (nb[n] >= 0) { // table order == CSR order of the row
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    float v = sv[n].at(i);
+                    if (BACKWARD && ACT != ACT_NONE) v = act_bwd<ACT>(v, ov[n].at(i));
+                    acc.at(i) += w[n] * v;
+                }
+            }
+        }
+        for (int e = e0; e < e1; e += GCN_NB) { // a row longer than the table: its CSR tail, still in order
+            int64_t tb[GCN_NB];
+            float tw[GCN_NB];
+#pragma unroll
+            for (int j = 0; j < GCN_NB; ++j) {
+                const bool in = e + j < e1;
+                tb[j] = in ? mesh_row0 + a.over_col[e + j] : row;
+                tw[j] = in ? a.over_val[e + j] : 0.f;
+            }
+            Pack<VEC> tv[GCN_NB], to[GCN_NB];
+#pragma unroll
+            for (int j = 0; j < GCN_NB; ++j) {
+                tv[j].load(a.x + tb[j] * a.c + c0);
+                if (BACKWARD && ACT != ACT_NONE) to[j].load(a.saved + tb[j] * a.c + c0);
+            }
+#pragma unroll
+            for (int j = 0; j < GCN_NB; ++j) {
+                if (e + j < e1) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        float v = tv[j].at(i);
+                        if (BACKWARD && ACT != ACT_NONE) v = act_bwd<ACT>(v, to[j].at(i));
+                        acc.at(i) += tw[j] * v;
+                    }
+                }
+            }
+        }
+        if (!BACKWARD) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float v = acc.at(i);
+                if (a.bias && c0 + i < a.k) v += a.bias[c0 + i];
+                acc.at(i) = act_fwd<ACT>(v);
+            }
+        }
+        if (c0 + VEC <= a.k) {
+            acc.store(a.y + row * a.c + c0);
+        } else { // the straddling group: its aggregated elements only (the others belong to the pass-through threads below)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if (c0 + i < a.k) a.y[row * a.c + c0 + i] = acc.at(i);
+        }
+    }
+
+    // ---- everything else, row-major: thread (rl, g) owns VEC consecutive columns of rows rl, rl + rows_in_flight, ...: the
+    // pass-through columns (copy + bias + activation / derivative) and, in the backward, the bias-gradient terms of ALL columns
     const int g = threadIdx.x % groups;
     const int rl = threadIdx.x / groups;
     const int c0 = g * VEC;
     const bool active = rl < rows_in_flight;
-    const int r_begin = blockIdx.x * rows_per_block;
-    const int r_end = min(r_begin + rows_per_block, a.nv);
-    const int64_t mesh_row0 = (int64_t)blockIdx.y * a.nv;
-    const bool gathers = c0 < a.k;
     const bool pass = c0 + VEC > a.k; // pass-through columns in the group (all, or the tail of the straddling group)
 
     Pack<VEC> colsum;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) colsum.at(i) = 0.f;
 
-    if (active) {
+    if (active && (BACKWARD || pass)) {
         for (int r = r_begin + rl; r < r_end; r += rows_in_flight) {
             const int64_t row = mesh_row0 + r;
-            Pack<VEC> acc, own;
-            int nb[W];
-            float w[W];
-            int e0 = 0, e1 = 0;
-            if (gathers) { // round trip 1: the row's table entries (with the thread's own elements below)
-#pragma unroll
-                for (int n = 0; n < W; n += 4) {
-                    const int4 ci = *reinterpret_cast<const int4 *>(a.col + (size_t)r * W + n);
-                    const float4 wi = *reinterpret_cast<const float4 *>(a.val + (size_t)r * W + n);
-                    nb[n] = ci.x, nb[n + 1] = ci.y, nb[n + 2] = ci.z, nb[n + 3] = ci.w;
-                    w[n] = wi.x, w[n + 1] = wi.y, w[n + 2] = wi.z, w[n + 3] = wi.w;
-                }
-                if (a.over_ptr) e0 = a.over_ptr[r], e1 = a.over_ptr[r + 1];
-            }
-            if (BACKWARD || pass) {
-                own.load(a.x + row * a.c + c0);
-                if (BACKWARD && ACT != ACT_NONE) {
+            Pack<VEC> own;
+            own.load(a.x + row * a.c + c0);
+            if (BACKWARD) {
+                if (ACT != ACT_NONE) {
                     Pack<VEC> o;
                     o.load(a.saved + row * a.c + c0);
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) own.at(i) = act_bwd<ACT>(own.at(i), o.at(i));
                 }
-            }
-            if (gathers) {
-                Pack<VEC> sv[W], ov[W];
-#pragma unroll
-                for (int n = 0; n < W; ++n) { // round trip 2: the neighbour rows
-                    const int64_t nrow = mesh_row0 + (nb[n] >= 0 ? nb[n] : r);
-                    sv[n].load(a.x + nrow * a.c + c0);
-                    if (BACKWARD && ACT != ACT_NONE) ov[n].load(a.saved + nrow * a.c + c0);
-                }
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) acc.at(i) = 0.f;
-#pragma unroll
-                for (int n = 0; n < W; ++n) {
-                    if (nb[n] >= 0) { // table order == CSR order of the row
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) {
-                            float v = sv[n].at(i);
-                            if (BACKWARD && ACT != ACT_NONE) v = act_bwd<ACT>(v, ov[n].at(i));
-                            acc.at(i) += w[n] * v;
-                        }
-                    }
-                }
-                for (int e = e0; e < e1; e += GCN_NB) { // a row longer than the table: its CSR tail, still in order
-                    int64_t tb[GCN_NB];
-                    float tw[GCN_NB];
-#pragma unroll
-                    for (int j = 0; j < GCN_NB; ++j) {
-                        const bool in = e + j < e1;
-                        tb[j] = in ? mesh_row0 + a.over_col[e + j] : row;
-                        tw[j] = in ? a.over_val[e + j] : 0.f;
-                    }
-                    Pack<VEC> tv[GCN_NB], to[GCN_NB];
-#pragma unroll
-                    for (int j = 0; j < GCN_NB; ++j) {
-                        tv[j].load(a.x + tb[j] * a.c + c0);
-                        if (BACKWARD && ACT != ACT_NONE) to[j].load(a.saved + tb[j] * a.c + c0);
-                    }
-#pragma unroll
-                    for (int j = 0; j < GCN_NB; ++j) {
-                        if (e + j < e1) {
-#pragma unroll
-                            for (int i = 0; i < VEC; ++i) {
-                                float v = tv[j].at(i);
-                                if (BACKWARD && ACT != ACT_NONE) v = act_bwd<ACT>(v, to[j].at(i));
-                                acc.at(i) += tw[j] * v;
-                            }
-                        }
-                    }
-                }
-                if (pass) {
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i)
-                        if (c0 + i >= a.k) acc.at(i) = own.at(i);
-                }
-            } else {
-                acc = own;
-            }
-            if (BACKWARD) {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) colsum.at(i) += own.at(i);
             } else {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
-                    float v = acc.at(i);
+                    float v = own.at(i);
                     if (a.bias) v += a.bias[c0 + i];
-                    acc.at(i) = act_fwd<ACT>(v);
+                    own.at(i) = act_fwd<ACT>(v);
                 }
             }
-            acc.store(a.y + row * a.c + c0);
+            if (c0 >= a.k) {
+                own.store(a.y + row * a.c + c0);
+            } else if (pass) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    if (c0 + i >= a.k) a.y[row * a.c + c0 + i] = own.at(i);
+            }
         }
     }
 
@@ -726,10 +747,11 @@ inline GcnGeometry ell_any_geometry(int b, int nv, int c, bool backward)
     GcnGeometry g;
     g.groups = c / ell_any_vec(c);
     g.rows_in_flight = GCN_THREADS / g.groups;
-    // row tiles per workgroup: forward -- at most ~4096 workgroups; backward -- at most ~1024 (= bias-gradient partials)
+    // row tiles per workgroup: at most ~1024 workgroups in either direction (backward: = bias-gradient partials to reduce;
+    // forward: a 300-column copy alone ran at 3.3 TB/s as 3072 two-tile workgroups and at 4.0 as 1024 six-tile ones)
     const int64_t tiles = ((int64_t)b * nv + g.rows_in_flight - 1) / g.rows_in_flight;
-    int64_t iters = backward ? (tiles + 1023) / 1024 : (tiles + 4095) / 4096;
-    const int64_t lo = backward ? GCN_BWD_ITERS : 1, hi = backward ? 64 : 8;
+    int64_t iters = (tiles + 1023) / 1024;
+    const int64_t lo = backward ? GCN_BWD_ITERS : 1, hi = 64;
     iters = iters < lo ? lo : iters > hi ? hi : iters;
     g.rows_per_block = g.rows_in_flight * (int)iters;
     g.chunks = (nv + g.rows_per_block - 1) / g.rows_per_block;
