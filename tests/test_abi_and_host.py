@@ -306,3 +306,52 @@ def test_dense_plan_routes_each_product_by_shape():
     assert dense.plan(20496, 192, 64)["dw"] == "lib"                # not whole 12-column groups per wave
     assert dense.plan(2 ** 21, 963, 192)["dw"] == "lib"             # beyond the kernels' 32-bit byte offsets
     assert dense.supported(963, 192, 20496) and not dense.supported(963, 200, 20496)
+
+
+# ---- round 5: host-side plans of the boundary launches and the any-shape product (no device needed) -------------------------
+def test_fused_plan_thresholds_and_overrides(monkeypatch):
+    from geometrics_amd import fused
+    monkeypatch.delenv("GEOM_FUSED_PLAN", raising=False)
+    assert fused.force is None
+    assert fused.plan(8 * 2562) == {"fwd": False, "bwd": False}          # the BASELINE shard keeps the separate operators
+    assert fused.plan(32 * 2562) == {"fwd": True, "bwd": True} and fused.plan(64 * 2562)["bwd"]
+    monkeypatch.setenv("GEOM_FUSED_PLAN", "fwd")
+    assert fused.plan(10) == {"fwd": True, "bwd": False}
+    monkeypatch.setenv("GEOM_FUSED_PLAN", "off")
+    assert fused.plan(10 ** 6) == {"fwd": False, "bwd": False}
+    fused.force = {"fwd": True, "bwd": True}
+    try:
+        assert fused.plan(1) == {"fwd": True, "bwd": True}                  # tests force it whatever the environment says
+    finally:
+        fused.force = None
+
+    class Csr:
+        ell_w, over, over_t = 8, None, None
+    assert fused.supported(Csr, 192, 64, 192) and fused.supported(Csr, 192, 64, 96)
+    assert not fused.supported(Csr, 192, 64, 100) and not fused.supported(Csr, 96, 32, 96) and not fused.supported(Csr, 192, 48, 192)
+    Csr.over = (1, 2, 3)
+    assert not fused.supported(Csr, 192, 64, 192)                           # long rows: the table kernel with its CSR tail
+
+
+def test_which_kernel_takes_a_product():
+    import torch
+    from geometrics_amd import dense, layers
+    # the 192-column kernels where they apply, the any-shape kernel for every other width, the library for tiny inputs
+    assert dense.plan(20496, 963, 192)["dw"] == "mfma" and not dense.plan(20496, 963, 192)["pair"]
+    assert dense.plan(20496, 192, 192)["pair"]
+    assert dense.plan(18432, 300, 300)["dw"] == "lib" and dense.any_supported(18432, 300, 300)
+    assert layers._takes_any_shape_kernel(18432, 300, 300) and layers._takes_any_shape_kernel(7712, 192, 3)
+    assert not layers._takes_any_shape_kernel(20496, 192, 192)              # dense_gemm.hip's pair launch
+    assert not layers._takes_any_shape_kernel(100, 60, 60)                  # launch-bound: the library
+    keep = layers.use_any_shape_products
+    layers.use_any_shape_products = False
+    try:
+        assert not layers._takes_any_shape_kernel(18432, 300, 300)
+    finally:
+        layers.use_any_shape_products = keep
+    with pytest.raises(ValueError):
+        dense.gemm(torch.zeros(4, 3), torch.zeros(5, 2))                    # summed extents differ: refused before any launch
+    with pytest.raises(ValueError):
+        dense.gemm(torch.zeros(4, 6)[:, ::2], torch.zeros(3, 2))            # rows must have unit stride
+    link = layers._StackLink()
+    assert link.wt is None and link.dx is None and link.g_ptr == 0 and not link.wanted
