@@ -175,3 +175,49 @@ def test_the_stack_operator_uses_the_boundary_launch(gpu):
     finally:
         fused.force = None
     assert (s - s2).abs().max().item() <= 2e-5 * s2.abs().max().item()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("act", ["elu", "none"])     # none: the head's fused backward (aggregation backward + input gradient) too
+def test_the_plan_switches_the_boundary_launches_on_by_itself_at_a_large_shard(gpu, act):
+    """32 meshes of 2562 vertices = 81 984 rows: above fused.plan's threshold, so the stack operator takes the boundary
+    launches in BOTH directions without being forced (what bench.py's 64-mesh whole-batch figure runs); positions and every
+    gradient against the layer-by-layer route with the plan forced off."""
+    import torch.nn.functional as F
+    from geometrics_amd import fused
+    assert fused.plan(32 * 2562) == {"fwd": True, "bwd": True}
+    b, level = 32, 4
+    act_fn = F.elu if act == "elu" else None
+    want_pos, want = _stack_run({"fwd": False, "bwd": False}, b, level, act_fn)
+    nv, csr = _mesh(level)
+    from geometrics_amd import layers
+    torch.manual_seed(5)
+    stack = torch.nn.ModuleList([layers.Batch_Image_ZERON_GCNGCN(i, o) for i, o in ((99, C), (C, C), (C, C))]).cuda()
+    s, link = layers._stack_supports(torch.randn(b, nv, 99, device="cuda"), csr, list(stack), {"activation": F.relu})
+    assert link is not None and link.wt is not None                         # the un-forced plan took the boundary launch
+    del s, link, stack
+    got_pos, got = _stack_auto(b, level, act_fn)
+    assert (got_pos - want_pos).abs().max().item() <= 2e-6 * want_pos.abs().max().item()
+    for gt, wt_ in zip(got, want):
+        scale = wt_.abs().max().item() + 1e-30
+        assert (gt - wt_).abs().max().item() <= 2e-5 * scale, (gt.shape, (gt - wt_).abs().max().item() / scale)
+
+
+def _stack_auto(b, level, act_fn, seed=5):
+    """_stack_run through layers.zero_n_stack_positions with fused.force left alone (the plan decides)."""
+    from geometrics_amd import fused, layers
+    nv, csr = _mesh(level)
+    torch.manual_seed(seed)
+    stack = torch.nn.ModuleList([layers.Batch_Image_ZERON_GCNGCN(i, o) for i, o in ((99, C), (C, C), (C, C))]).cuda()
+    for layer in stack:
+        layer.bias.data.uniform_(-0.05, 0.05)
+    g = torch.Generator(device="cpu").manual_seed(seed + 1)
+    x = torch.randn(b, nv, 99, generator=g).cuda().requires_grad_(True)
+    base = torch.randn(b, nv, 3, generator=g).cuda().requires_grad_(True)
+    seed_grad = torch.randn(b, nv, 3, generator=g).cuda()
+    assert fused.force is None
+    pos = layers.zero_n_stack_positions(x, csr, list(stack), act_fn, base, 0.01)
+    pos.backward(seed_grad)
+    torch.cuda.synchronize()
+    grads = [x.grad, base.grad] + [p.grad for p in stack.parameters()]
+    return pos.detach(), [t.detach().clone() for t in grads]
