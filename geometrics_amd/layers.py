@@ -786,7 +786,13 @@ def _flush_dense_products(jobs):
                 torch.bmm(xb.transpose(1, 2), gb, out=ob)
             else:
                 for xx, gg, oo, _ in group:
-                    torch.mm(xx.t(), gg, out=oo)
+                    # (a layer of its own width -- the block's 192 -> 3 coordinate head: 7712 summed rows against a 192 x 3 output
+                    # is 75 us in the library, which runs it without a split; the any-shape kernel splits the sum)
+                    if (_takes_any_shape_kernel(xx.shape[0], xx.shape[1], gg.shape[1]) and xx.stride(1) == 1 and gg.stride(1) == 1
+                            and oo.stride(1) == 1):
+                        _dense_kernels.gemm(xx, gg, trans_a=True, out=oo)
+                    else:
+                        torch.mm(xx.t(), gg, out=oo)
         i = j
 
 
