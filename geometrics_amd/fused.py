@@ -28,13 +28,15 @@ def plan(rows):
     forward and ~10 backward; INSIDE the step (tools/probe/fused_plan_sweep.sh: the whole step replayed with the plan off /
     forward / both) it is not -- its weight slice and tables arrive cold and its 27 us there lose to 10 + 14.4 us at the
     8-mesh shard (+3 us per boundary), it breaks even at 12-16 meshes, and wins from 32 (1512 vs 1567 us per step; at 64
-    meshes, both directions: 2777 vs 2996 us, -7.3 %).  The thresholds follow the in-step measurement."""
+    meshes, both directions: 2777 vs 2996 us, -7.3 %).  A finer sweep (20 / 24 / 28 / 32 / 40 / 48 meshes, both directions against
+    none): 1020 vs 1110, 1209 vs 1212, 1370 vs 1411, 1535 vs 1584, 1883 vs 2067, 2282 vs 2466 us per step -- ahead or level from
+    20 meshes on.  The threshold follows the in-step measurement: both directions from 50 000 rows."""
     if force is not None:
         return dict(force)
     env = os.environ.get("GEOM_FUSED_PLAN")       # tools: "off" | "fwd" | "all"
     if env:
         return {"fwd": env in ("fwd", "all"), "bwd": env == "all"}
-    return {"fwd": rows >= 70000, "bwd": rows >= 70000}
+    return {"fwd": rows >= 50000, "bwd": rows >= 50000}
 
 
 def partial_rows(b, nv):
