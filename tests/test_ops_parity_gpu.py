@@ -969,6 +969,38 @@ def test_batched_pooling_matches_reference_fixture(gpu):
     assert (np.abs(g["grad_verts"]).sum(-1) == 0).any()
 
 
+def test_pooling_with_more_channel_chunks_than_grid_slices(gpu):
+    """The pooling launches give every workgroup one 64-channel chunk up to 32 chunks; beyond that a workgroup walks several
+    (and sums their shares of the vertex gradient).  Two maps of 1280 channels = 40 chunks against the same maps pooled in
+    halves of 640 (10 + 10 chunks per call): features per channel bit for bit, map gradients and the vertex gradient (= the sum
+    of the halves') within fp32 round-off."""
+    torch.manual_seed(12)
+    V, _ = meshgen.icosphere(2)
+    b, nv = 2, V.shape[0]
+    verts = dev(meshgen.jittered_batch(V, b), gpu, grad=True)
+    img_info = torch.tensor([[35.0, 20.0, 1.2], [60.0, 30.0, 1.0]], device=gpu)
+    big = [torch.randn(b, 1280, d, d, device=gpu, requires_grad=True) for d in (14, 7)]
+    grad_out = torch.randn(b, nv, 2560, device=gpu)
+    feats = utils.batched_pooling(big, verts, img_info.clone())
+    assert feats.shape == (b, nv, 2560)
+    feats.backward(grad_out)
+    gv_big, gmaps_big = verts.grad.clone(), [m.grad.clone() for m in big]
+    verts.grad = None
+    gv_sum = torch.zeros_like(gv_big)
+    for half in range(2):
+        sl = slice(640 * half, 640 * (half + 1))
+        parts = [m.detach()[:, sl].contiguous().requires_grad_(True) for m in big]
+        f = utils.batched_pooling(parts, verts, img_info.clone())
+        cols = torch.cat([torch.arange(1280 * i + 640 * half, 1280 * i + 640 * (half + 1)) for i in range(2)]).to(gpu)
+        assert torch.equal(f, feats.detach()[..., cols])
+        f.backward(grad_out[..., cols].contiguous())
+        for i in range(2):      # (a texel's contributions are listed in arrival order: same terms, fp32 summation order may differ)
+            close(parts[i].grad.cpu().numpy(), gmaps_big[i][:, sl].cpu().numpy(), 2e-6)
+        gv_sum += verts.grad
+        verts.grad = None
+    close(gv_big.cpu().numpy(), gv_sum.cpu().numpy(), 2e-5)
+
+
 def test_in_kernel_sampler_stream(gpu):
     """The Philox stream of the sampler: reproducible after manual_seed, fresh numbers on every call (also
     when the call is replayed from a HIP graph), uniform u/v, area-weighted faces."""
