@@ -124,3 +124,54 @@ def test_layer_through_autograd_matches_the_library_route(gpu):
             layers.use_any_shape_products = True
     for a, b in zip(res[True], res[False]):
         assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+
+
+def test_capturable_and_allocation_free(gpu):
+    """The entry point allocates nothing and synchronises nothing: a product captured into a HIP graph (workspace supplied by
+    the caller, as in a captured training step) replays to the bits of the eager call -- forward and split weight gradient."""
+    from geometrics_amd import _lib, dense
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x, w, gr = torch.randn(9000, 150, generator=g).cuda(), torch.randn(150, 210, generator=g).cuda(), torch.randn(9000, 210, generator=g).cuda()
+    want_f, want_w = dense.gemm(x, w), dense.gemm(x, gr, trans_a=True)
+    out_f, out_w = torch.zeros_like(want_f), torch.zeros_like(want_w)
+    ws = torch.empty(int(_lib.lib().geom_gemm_workspace_floats(150, 210, 9000)), device="cuda")
+    assert ws.numel() > 0
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph):
+            dense.gemm(x, w, out=out_f)
+            dense.gemm(x, gr, trans_a=True, out=out_w, workspace=ws)
+    torch.cuda.current_stream().wait_stream(side)
+    out_f.zero_(), out_w.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_f, want_f) and torch.equal(out_w, want_w)
+
+
+def test_layer_with_odd_width_and_a_strided_input(gpu):
+    """ZERON_GCN at a width that is neither a multiple of 4 nor of 2 (75 columns, k = 7: scalar column groups in the table
+    aggregation, scalar stores in the product) fed with a NON-contiguous input view: forward and every gradient against a
+    float64 restatement of the layer (reference layers.py:34-41)."""
+    import numpy as np
+    import torch.nn.functional as F
+    from geometrics_amd import layers, meshgen, utils
+    V, Fc = meshgen.icosphere(3)
+    adj = utils.normalize_adj(utils.calc_adj(torch.from_numpy(np.ascontiguousarray(Fc)).cuda()))
+    torch.manual_seed(8)
+    layer = layers.ZERON_GCN(33, 75).cuda()
+    base = torch.randn(33, V.shape[0], device="cuda")
+    x = base.t().requires_grad_(True)                       # [V, 33] with strides (1, V): not contiguous
+    assert not x.is_contiguous()
+    seed = torch.randn(V.shape[0], 75, device="cuda")
+    out = layer(x, adj, F.elu)
+    out.backward(seed)
+    xd = base.t().double().cpu().requires_grad_(True)
+    wd, bd = layer.weight.detach().double().cpu().requires_grad_(True), layer.bias.detach().double().cpu().requires_grad_(True)
+    s = xd @ wd
+    k = 75 // 10
+    ref = F.elu(torch.cat((adj.double().cpu() @ s[:, :k], s[:, k:]), dim=1) + bd)
+    ref.backward(seed.double().cpu())
+    for got, want in ((out, ref), (x.grad, xd.grad), (layer.weight.grad, wd.grad), (layer.bias.grad, bd.grad)):
+        assert (got.detach().double().cpu() - want.detach()).abs().max().item() <= 2e-5 * want.detach().abs().max().item()
