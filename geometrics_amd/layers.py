@@ -788,11 +788,7 @@ def _flush_dense_products(jobs):
                 for xx, gg, oo, _ in group:
                     # (a layer of its own width -- the block's 192 -> 3 coordinate head: 7712 summed rows against a 192 x 3 output
                     # is 75 us in the library, which runs it without a split; the any-shape kernel splits the sum)
-                    if (_takes_any_shape_kernel(xx.shape[0], xx.shape[1], gg.shape[1]) and xx.stride(1) == 1 and gg.stride(1) == 1
-                            and oo.stride(1) == 1):
-                        _dense_kernels.gemm(xx, gg, trans_a=True, out=oo)
-                    else:
-                        torch.mm(xx.t(), gg, out=oo)
+                    _weight_gradient_product(xx, gg, out=oo)
         i = j
 
 
@@ -811,6 +807,16 @@ def _forward_product(x, w2):
         x2 = x.reshape(-1, x.shape[-1])
         return _dense_kernels.gemm(x2 if x2.is_contiguous() else x2.contiguous(), w2).view(x.shape[:-1] + (w2.shape[1],))
     return torch.matmul(x, w2)
+
+
+def _weight_gradient_product(x2, g2, out=None):
+    """x2^T @ g2 ([rows, cin]^T x [rows, c]): the any-shape kernel's split product where _takes_any_shape_kernel says so (the
+    library runs a long sum against a small output without a split: 75 us for the 192 -> 3 head at 7712 rows), else the library."""
+    if (x2.is_cuda and x2.dtype == torch.float32 and g2.dtype == torch.float32 and x2.dim() == 2 and g2.dim() == 2
+            and x2.stride(1) == 1 and g2.stride(1) == 1 and (out is None or (out.dim() == 2 and out.stride(1) == 1))
+            and _takes_any_shape_kernel(x2.shape[0], x2.shape[1], g2.shape[1])):
+        return _dense_kernels.gemm(x2, g2, trans_a=True, out=out)
+    return torch.mm(x2.t(), g2) if out is None else torch.mm(x2.t(), g2, out=out)
 
 
 class _Dense(torch.autograd.Function):
@@ -848,7 +854,7 @@ class _Dense(torch.autograd.Function):
                     torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_dense(task))
                 jobs.append((x2, g2, _alias(grad_w).view(w2.shape), torch.cuda.current_stream(w.device), ctx.w_ref))
             else:
-                grad_w = torch.mm(x2.t(), g2).view(w.shape)
+                grad_w = _weight_gradient_product(x2, g2).view(w.shape)
         return grad_x, grad_w, None
 
 
@@ -910,7 +916,7 @@ class _DenseMM(torch.autograd.Function):
         plan = _dense_kernels.plan(rows, cin, c)
         if not x2.is_contiguous() or not w2.is_contiguous() or not (need_w and plan["dw"] == "mfma"):
             grad_x = torch.matmul(g2, w2.t()).view(x.shape) if need_x else None
-            grad_w = torch.mm(x2.t(), g2).view(w.shape) if need_w else None
+            grad_w = _weight_gradient_product(x2, g2).view(w.shape) if need_w else None
             return grad_x, grad_w
         ws = _dense_kernels.weight_workspace(rows, cin, c, x.device)
         grad_x = None
@@ -1067,7 +1073,7 @@ class _FusedBoundary(torch.autograd.Function):
         if split:
             grad_w = _finish_weight_gradient(ctx.w_ref, w, rows, c, n_out, ws)
         elif need_w:
-            grad_w = torch.mm(x2.t(), g2).view(w.shape)
+            grad_w = _weight_gradient_product(x2, g2).view(w.shape)
         if not (need_s or need_b):
             return None, None, grad_w, None, None, None, None, None
         # ---- layer L's aggregation: with the input gradient of ITS product in the same launch when the boundary below wants it
