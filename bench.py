@@ -35,7 +35,12 @@ from geometrics_amd.chamfer_distance import chamfer_nn  # noqa: E402
 from geometrics_amd.tri_distance import kd_order, tri_distance_indexed  # noqa: E402
 
 V_LEVEL, S_PTS, G_PTS, FEAT, HID = 4, 3000, 3000, 963, 192
-CULLED_CHAMFER = True   # --plain-chamfer: the brute-force Chamfer tiles (same results; the A/B switch of the culled scan)
+# The reference draws a FRESH 3000-point ground-truth subset per item per fetch (utils.py:180-182), so anything derived from the
+# ground-truth cloud belongs inside the step.  The culled Chamfer tiles need an index of the cloud (ops.GtIndex: a k-d visiting
+# order + run spheres, built outside the step): with that build counted the route loses (one index launch 4.3-4.9 us against the
+# 3.6 us the culled tiles save), so the HEADLINE runs the brute-force tiles on a ground-truth tensor that may change every replay.
+# --gt-index: the culled route, for jobs whose ground-truth clouds are static (same results bit for bit).
+CULLED_CHAMFER = False
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector peak == f32 MFMA dense peak
 
@@ -71,8 +76,9 @@ class Workload:
         self.faces = to(Fc)
         self.base = to(meshgen.jittered_batch(V, batch, first=first_mesh))
         self.gt = to(meshgen.gt_cloud(batch, G_PTS, first=first_mesh))
-        # static per ground-truth cloud (what a data loader computes once per object): a k-d visiting order and the index
-        # of the culled Chamfer scan.  Results do not depend on it (tests: bit-identical with and without).
+        # --gt-index only: static per ground-truth cloud -- a k-d visiting order and the index of the culled Chamfer scan.
+        # Results do not depend on it (tests: bit-identical with and without).  Default: none, the step reads self.gt as is,
+        # and a replay after self.gt.copy_(other clouds) is a step on those clouds (tests/test_bench_step_gpu.py).
         self.gt_index = None
         if CULLED_CHAMFER:
             self.gt_index = ops.GtIndex(self.gt, torch.stack([kd_order(self.gt[i]) for i in range(batch)]))
@@ -719,6 +725,87 @@ def component_times(w):
     return {k: round(v, 1) for k, v in out.items()}
 
 
+# algorithmic work per mesh at BASELINE size (V = 2562, F = 5120, S = G = 3000, fp32, each operand once)
+NN_PAIRS_PER_MESH = 2 * S_PTS * G_PTS                 # both directions: 18.0 M (point, point) pairs
+TRI_PAIRS_PER_MESH = G_PTS * 5120                     # 15.36 M (point, triangle) pairs
+LOSS_BYTES_PER_MESH = 1.4e6                           # sample 0.42 + NN 0.12 + Chamfer loss 0.20 + tri 0.16 + p2tri loss 0.47 MB
+CHAMFER_BYTES_PER_MESH = 0.42e6 + 0.117e6 + 0.41e6    # sample + NN + the two-direction Chamfer loss (config 2)
+GCN_CUSTOM_BYTES_PER_MESH = 24.5e6                    # 3 layers x 4.09 MB x (fwd + bwd): aggregation + epilogue traffic
+GCN_GEMM_FLOP_PER_MESH = 3 * 2.0 * 2562 * (FEAT * HID + 2 * HID * HID)   # X.W, G.W^T, X^T.G of the three layers: 3.98 GFLOP
+
+
+def step_level_roofline(meshes_per_s):
+    """SURVEY 8(d)'s step-level figures for the full step (config 5): algorithmic bytes (loss path + the custom 0N-GCN kernels;
+    the dense products' operand traffic is not in it, by the survey's definition) and algorithmic lane-ops of the two arg-min
+    scans per mesh, times the measured meshes per second, against 8 TB/s and 78.6 T lane-op/s.  The products: executed
+    flops against the fp32 MFMA peak."""
+    return {"achieved_hbm": round((LOSS_BYTES_PER_MESH + GCN_CUSTOM_BYTES_PER_MESH) * meshes_per_s / (HBM_PEAK_GBS * 1e9), 4),
+            "achieved_valu": round((NN_PAIRS_PER_MESH * NN_FLOP_PER_PAIR + TRI_PAIRS_PER_MESH * TRI_ALGO_FLOP_PER_PAIR) * meshes_per_s
+                                   / (VALU_ISSUE_TERA_LANE_OPS * 1e12), 4),
+            "achieved_mfma": round(GCN_GEMM_FLOP_PER_MESH * meshes_per_s / (FP32_PEAK_TFLOPS * 1e12), 4),
+            "formulas": "SURVEY 8(d): hbm = (1.4 + 24.5 MB) x meshes/s / 8 TB/s; valu = (18.0 M x 8 + 15.36 M x 60 lane-ops) x meshes/s "
+                        "/ 78.6 T; mfma = 3.98 GFLOP x meshes/s / 157.3 T (the scans are VALU-bound and the products MFMA-bound: "
+                        "no single roof bounds the step)"}
+
+
+def baseline_configs(dev):
+    """BASELINE.json configs 2, 3 and 4 as such ("on 1 MI355X"), at B = 1 and at the 8-mesh shard of config 5; HIP-graph replay
+    bracketed by HIP events, inputs resident, fresh draws every pass.
+      2  2562-vertex icosphere, 3000 sampled vs 3000 gt points, Chamfer forward + backward (utils.batch_point_to_point)
+      3  the same + tri_distance (3000 points vs 5120 faces) fused with Chamfer (utils.batch_point_to_surface), forward + backward
+      4  3-layer 0N-GCN stack 963-192-192-192 on the 2562-vertex adjacency, forward + backward (to features and parameters)
+    Per entry: microseconds per pass, meshes/s, the dominant kernel's roof and the pass's fraction of it by SURVEY 8(d)'s
+    algorithmic counts (pair evaluations for the scans, executed flops for the products)."""
+    V, Fc = meshgen.icosphere(V_LEVEL)
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    faces = to(Fc)
+    info = utils.adj_init(faces)
+    out = {}
+    for b in (1, 8):
+        base = to(meshgen.jittered_batch(V, b, first=300)).requires_grad_(True)
+        gt = to(meshgen.gt_cloud(b, G_PTS, first=300))
+
+        def chamfer_fb():
+            base.grad = None
+            utils.batch_point_to_point(base, info, gt, num=S_PTS).backward()
+
+        def surface_fb():
+            base.grad = None
+            utils.batch_point_to_surface(base, info, gt, num=S_PTS).backward()
+        torch.manual_seed(3041)
+        stack = torch.nn.ModuleList([layers.Batch_Image_ZERON_GCNGCN(i, o) for i, o in ((FEAT, HID), (HID, HID), (HID, HID))]).to(dev)
+        feat = torch.randn(b, V.shape[0], FEAT, device=dev, requires_grad=True)
+
+        def stack_fb():
+            feat.grad = None
+            for p_ in stack.parameters():
+                p_.grad = None
+            with layers.deferred_parameter_gradients():
+                layers.zero_n_stack(feat, info["adj"], list(stack), F.relu).sum().backward()
+        t2 = event_time_us(chamfer_fb, iters=10, warm=3)
+        t3 = event_time_us(surface_fb, iters=10, warm=3)
+        t4 = event_time_us(stack_fb, iters=10, warm=3)
+        per_s = lambda t: b / (t * 1e-6)
+        valu = lambda ops_per_mesh, t: round(ops_per_mesh * per_s(t) / (VALU_ISSUE_TERA_LANE_OPS * 1e12), 4)
+        out["B=%d" % b] = {
+            "config2_chamfer_fwd_bwd": {"us": round(t2, 1), "meshes_per_s": round(per_s(t2), 1), "dominant_kernel": "Chamfer NN tiles "
+                                        "(surface_scan_kernel, two-sided)", "bound": "valu", "frac": valu(NN_PAIRS_PER_MESH * NN_FLOP_PER_PAIR, t2),
+                                        "achieved_hbm": round(CHAMFER_BYTES_PER_MESH * per_s(t2) / (HBM_PEAK_GBS * 1e9), 5)},
+            "config3_chamfer_tri_fused_fwd_bwd": {"us": round(t3, 1), "meshes_per_s": round(per_s(t3), 1),
+                                                  "dominant_kernel": "surface_scan_kernel (point-to-triangle + Chamfer tiles)", "bound": "valu",
+                                                  "frac": valu(NN_PAIRS_PER_MESH * NN_FLOP_PER_PAIR + TRI_PAIRS_PER_MESH * TRI_ALGO_FLOP_PER_PAIR, t3),
+                                                  "achieved_hbm": round(LOSS_BYTES_PER_MESH * per_s(t3) / (HBM_PEAK_GBS * 1e9), 5)},
+            "config4_zero_n_stack_fwd_bwd": {"us": round(t4, 1), "meshes_per_s": round(per_s(t4), 1),
+                                             "dominant_kernel": "the 963-wide products (library forward / input gradient, dense_split_kernel)",
+                                             "bound": "mfma", "frac": round(GCN_GEMM_FLOP_PER_MESH * per_s(t4) / (FP32_PEAK_TFLOPS * 1e12), 4),
+                                             "achieved_hbm": round(GCN_CUSTOM_BYTES_PER_MESH * per_s(t4) / (HBM_PEAK_GBS * 1e9), 4)}}
+        del stack, feat
+    out["note"] = ("frac = SURVEY 8(d)'s algorithmic work of the pass x meshes/s over the roof of its dominant kernel (78.6 T lane-op/s "
+                   "un-fused fp32 VALU; 157.3 TFLOP/s fp32 MFMA); at B = 1 every pass is a chain of launches of a few microseconds "
+                   "each on a mostly idle chip")
+    return out
+
+
 def training_shape_times(dev, batch=16):
     """The shape the reference really trains at (GEOMetrics.py:25,44,50,66-68): batch 16, a 482-vertex / 960-face
     template with two 32-neighbour poles (meshgen.uv_sphere: same size and degree extremes as 482.obj), 3000 sampled
@@ -776,7 +863,7 @@ def training_shape_times(dev, batch=16):
                                   if csr.ell_w else "generic CSR"}
 
 
-def driver_step_times(dev, batch=16, profile_replays=0):
+def driver_step_times(dev, batch=16, profile_replays=0, zero_edit=False):
     """The step the reference's driver really runs (GEOMetrics.py:110-174) at its own sizes: batch 16 on the 482-vertex /
     960-face template (meshgen.uv_sphere: the size and the two 32-neighbour poles of 482.obj), three poolings from four
     feature maps each (64x56^2, 128x28^2, 256x14^2, 512x7^2 -- what the three VGG encoders return; they are inputs here: the
@@ -784,7 +871,12 @@ def driver_step_times(dev, batch=16, profile_replays=0):
     -> 3, three surface losses (3000 sampled vs 3000 gt points), the edge and Laplacian terms, backward to every parameter
     and feature map, Adam over all ~170 parameter tensors.  HIP-graph replay bracketed by HIP events.  The F1 bookkeeping
     of GEOMetrics.py:137 (monitoring, synchronises the host) is not part of the captured step.
-    profile_replays > 0: only replay the captured step that many times (tools/profile_driver_step.py under rocprofv3)."""
+    profile_replays > 0: only replay the captured step that many times (tools/profile_driver_step.py under rocprofv3).
+    zero_edit: what an UNMODIFIED GEOMetrics.py gets through overlay/ -- the overlay's hot-path names ARE these functions and
+    classes (tests/test_overlay.py asserts identity), called the way the driver calls them and with nothing it does not have:
+    eager launches from python, torch.optim.Adam, no gt_index, no deferred_parameter_gradients, no HIP graph, the f1=True
+    bookkeeping of the third loss and the four .item() reads of its progress message (host synchronisations) included;
+    wall clock over whole steps."""
     from geometrics_amd import models
     V, Fc = meshgen.uv_sphere()
     nv = V.shape[0]
@@ -839,6 +931,44 @@ def driver_step_times(dev, batch=16, profile_replays=0):
             loss.backward()
         opt.step()
         last["loss"] = loss.detach()
+
+    if zero_edit:
+        adam = torch.optim.Adam(params, lr=1e-4)          # GEOMetrics.py:73
+        p2s = utils.batch_point_to_surface
+
+        def driver_step():
+            adam.zero_grad()
+            p1, p2, p3 = predict()
+            s1 = p2s(p1.clone(), info, gt, num=S_PTS)
+            s2 = p2s(p2.clone(), info, gt, num=S_PTS)
+            s3, f1 = p2s(p3.clone(), info, gt, num=S_PTS, f1=True)
+            surface = s1 * .2 + s2 * .2 + s3 * 2
+            edge = utils.batch_calc_edge(p1.clone(), info) * 300
+            edge += utils.batch_calc_edge(p2.clone(), info) * 300
+            edge += utils.batch_calc_edge(p3.clone(), info) * 300
+            l1 = torch.mean(torch.sum((lap(initial, info) - lap(p1, info)) ** 2, 2)) * 1500
+            l2 = torch.mean(torch.sum((lap(p1, info) - lap(p2, info)) ** 2, 2)) * 1500
+            l2 += torch.mean(torch.sum((p1 - p2) ** 2, 2)) * 100
+            l3 = torch.mean(torch.sum((lap(p2, info) - lap(p3, info)) ** 2, 2)) * 1500
+            l3 += torch.mean(torch.sum((p2 - p3) ** 2, 2)) * 100
+            lap_loss = .2 * (l1 * .3 + l2 + l3)
+            loss = edge + surface + lap_loss
+            loss.backward()
+            adam.step()
+            return loss.item(), surface.item(), edge.item(), lap_loss.item(), float(f1)     # the driver's progress message
+        for _ in range(3):
+            driver_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            out = driver_step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        return {"workload": "the same step through the overlay's public names only, as an unmodified GEOMetrics.py:110-174 issues it: "
+                            "eager launches, torch.optim.Adam, no gt_index / deferral / HIP graph, f1=True + the four .item() reads per step",
+                "ms_per_step": round(dt * 1e3, 4), "meshes_per_s": round(batch / dt, 1), "final_loss": round(out[0], 5), "f1": round(out[4], 3),
+                "timing": "wall clock over %d whole steps (host launch overhead and synchronisations are the point)" % n}
 
     if profile_replays:
         side = torch.cuda.Stream()
@@ -919,6 +1049,28 @@ def whole_batch_times(dev, meshes=64, steps=20, warmup=5):
     out = {"workload": "config 5 whole batch on ONE GPU: %d meshes per step (strong-scaling anchor; the headline is the "
                        "8-mesh weak-scaling shard)" % meshes,
            "ms_per_step": round(dt * 1e3, 4), "meshes_per_s": round(meshes / dt, 1), "final_loss": round(w.mean_loss(), 6)}
+    del w
+    torch.cuda.empty_cache()
+    return out
+
+
+def strong_scaling_point(dev, rank, world, force_dp, steps, warmup, global_batch=64):
+    """N > 1, run by EVERY rank behind the weak-scaling region: BASELINE config 5's whole batch (64 meshes) split over the
+    ranks (64 / N per GPU), same step, same timing rules (barrier + synchronize on both sides, MAX over ranks) -- so that
+    one `--gpus N` run prints the weak AND the strong number.  At N = 1 the same figure is `whole_batch_single_gpu`."""
+    first, count = gdist.shard_range(global_batch, rank, world)
+    torch.cuda.empty_cache()
+    w = Workload(dev, first, count, force_dp=force_dp)
+    w.capture()
+    gdist.barrier()
+    elapsed = time_steps(w.run, steps, warmup)
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+    w.finish()
+    out = {"global_batch": global_batch, "meshes_per_gpu": count, "scaling": "strong", "ms_per_step": round(elapsed / steps * 1e3, 4),
+           "meshes_per_s": round(global_batch * steps / elapsed, 1), "final_loss": round(w.mean_loss(), 6)}
     del w
     torch.cuda.empty_cache()
     return out
@@ -1011,8 +1163,9 @@ def parity_spot_check(w):
                                    torch.from_numpy(v))
     ref.backward()
     g, rg = cpu(pos.grad), cv.grad.numpy()
-    return {"meshes": int(verts.shape[0]), "route": "gt_index (culled Chamfer tiles, visiting-order draws), finalize roles %s"
-                                                     % ("on" if ops.scan_finalize_tail else "off"),
+    return {"meshes": int(verts.shape[0]), "route": "%s, finalize roles %s"
+                                                     % ("gt_index (culled Chamfer tiles, visiting-order draws)" if w.gt_index is not None
+                                                        else "brute-force Chamfer tiles, independent draws", "on" if ops.scan_finalize_tail else "off"),
             "idx_mismatches": int((cpu(seen["idx_gt"]) != i_gt).sum() + (cpu(seen["idx_pred"]) != i_pred).sum()
                                   + (cpu(seen["tri_index"]) != t_idx).sum() + (cpu(seen["tri_option"]) != t_opt).sum()),
             "sampled_point_bit_mismatches": int((bits(cpu(seen["points"])) != bits(pred)).sum()),
@@ -1066,10 +1219,16 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--meshes-per-gpu", type=int, default=8)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="STRONG scaling: this many meshes in total, split evenly over the ranks (64 = BASELINE config 5's batch); "
+                         "the line then says scaling: strong.  Default 0: weak scaling, --meshes-per-gpu on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clock-warmup-ms", type=float, default=250.0,
                     help="neutral GEMM load in front of the warm-up steps so that short runs are not timed on the clock ramp (0: off)")
-    ap.add_argument("--plain-chamfer", action="store_true", help="brute-force Chamfer tiles instead of the culled scan (same results)")
+    ap.add_argument("--gt-index", action="store_true", help="culled Chamfer tiles on an index of the ground-truth clouds built OUTSIDE the "
+                    "step (static clouds only; same results bit for bit).  Default: brute-force tiles, everything that depends on the "
+                    "ground truth is inside the step")
+    ap.add_argument("--plain-chamfer", action="store_true", help="(the default since round 6; kept for older command lines)")
     ap.add_argument("--separate-finalize", action="store_true", help="the surface loss's finalize pass as a launch of its own instead of "
                     "extra workgroups of the scan launch (same results; the A/B switch of ops.scan_finalize_tail)")
     ap.add_argument("--launch", choices=("graph", "eager"), default="graph",
@@ -1080,7 +1239,7 @@ def main():
                          "what tools/pmc_traffic.sh runs together with --launch eager")
     args = ap.parse_args()
     global CULLED_CHAMFER
-    CULLED_CHAMFER = not args.plain_chamfer
+    CULLED_CHAMFER = bool(args.gt_index) and not args.plain_chamfer
     if args.separate_finalize:
         ops.scan_finalize_tail = False
 
@@ -1107,6 +1266,10 @@ def main():
 
     tuned = gemm_tuning.enable()      # pin the measured-fastest library GEMM per shape (no tuning at run time)
     per_gpu = args.meshes_per_gpu
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch %d does not split evenly over %d ranks" % (args.global_batch, world))
+        per_gpu = args.global_batch // world
     first, count = gdist.shard_range(per_gpu * world, rank, world)
     w = Workload(dev, first, count, force_dp=force_dp)
     launch = "eager"
@@ -1122,8 +1285,17 @@ def main():
             from geometrics_amd import _lib
             _lib.clear_hip_error()
     gdist.barrier()          # ranks finish their setup at different times: condition the devices together, so that
+    # the same K steps behind the same W warm-up steps WITHOUT the conditioning load first (what --clock-warmup-ms 0 prints):
+    # reported beside the headline as ms_per_step_unconditioned
+    unconditioned = time_steps(w.run, args.steps, args.warmup) if args.clock_warmup_ms > 0 else None
     settle_clocks(dev, args.clock_warmup_ms)   # nobody idles at the barrier in front of the timed region and cools down again
     elapsed = time_steps(w.run, args.steps, args.warmup)
+    if unconditioned is None:
+        unconditioned = elapsed
+    if world > 1:
+        tu = torch.tensor([unconditioned], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tu, op=torch.distributed.ReduceOp.MAX)
+        unconditioned = float(tu.item())
     # [max, -min] of the ranks' own clocks in one MAX all-reduce; ranks_seen = an all-reduce of ones through the SAME group the
     # gradient bucket uses, so the line shows how many ranks the collective really spanned
     own = elapsed
@@ -1134,6 +1306,13 @@ def main():
         torch.distributed.all_reduce(seen, op=torch.distributed.ReduceOp.SUM)
     elapsed, fastest = float(t[0].item()), -float(t[1].item())
     ranks_seen = int(round(float(seen.item())))
+    strong = None
+    if (world > 1 or force_dp) and not args.global_batch and 64 % world == 0 and not args.steps_only:
+        try:
+            strong = strong_scaling_point(dev, rank, world, force_dp, args.steps, args.warmup)
+        except Exception as exc:          # every rank fails or none does (same code, same sizes): the headline still goes out
+            print("bench.py: strong-scaling point failed on rank %d (%s: %s)" % (rank, type(exc).__name__, exc), file=sys.stderr)
+            strong = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
 
     if rank == 0:
         total_meshes = per_gpu * world * args.steps
@@ -1141,8 +1320,9 @@ def main():
             "metric": "meshes/sec (sample+Chamfer+tri_dist+0N-GCN fwd+bwd), 2562 verts/3000 pts",
             "value": round(total_meshes / elapsed, 2), "unit": "meshes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "ranks_seen": ranks_seen,
+            "ms_per_step_unconditioned": round(unconditioned / args.steps * 1e3, 4),
             "ms_per_step_ranks": {"max": round(elapsed / args.steps * 1e3, 4), "min": round(fastest / args.steps * 1e3, 4),
                                   "rank0": round(own / args.steps * 1e3, 4)},
             "config": {"workload": "BASELINE config 5 shard: %d independent 2562-vert/5120-face meshes per GPU, full "
@@ -1162,6 +1342,10 @@ def main():
                         "gradient] ; the launch stream waits for the collective")},
             "final_loss": round(w.mean_loss(), 6),
         }
+        if strong is not None:
+            line["strong_scaling"] = strong
+        if per_gpu == 8:
+            line["step_level"] = step_level_roofline(total_meshes / elapsed / world)     # per GPU
         if not args.steps_only:
             try:
                 roofline, others = kernel_rooflines(w)
@@ -1182,9 +1366,15 @@ def main():
                 line[key] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         if world == 1 and not force_dp and not args.steps_only:
             extra("components_us", lambda: component_times(w))
+            extra("configs", lambda: baseline_configs(dev))
             extra("reference_training_shape", lambda: training_shape_times(dev))
             extra("driver_step", lambda: driver_step_times(dev))
+            extra("driver_step_zero_edit", lambda: driver_step_times(dev, zero_edit=True))
             extra("whole_batch_single_gpu", lambda: whole_batch_times(dev))
+            if isinstance(line.get("whole_batch_single_gpu"), dict) and "ms_per_step" in line["whole_batch_single_gpu"]:
+                wb = line["whole_batch_single_gpu"]        # N = 1: the strong-scaling point IS the whole batch on this GPU
+                line["strong_scaling"] = {"global_batch": 64, "meshes_per_gpu": 64, "scaling": "strong", "ms_per_step": wb["ms_per_step"],
+                                          "meshes_per_s": wb["meshes_per_s"], "final_loss": wb["final_loss"]}
         if world == 1 and not args.no_cpu_baseline:
             extra("cpu_baseline", cpu_baseline)
             extra("parity_spot_check", lambda: parity_spot_check(w))

@@ -568,14 +568,16 @@ __global__ __launch_bounds__(ZS_THREADS, 2) void zs_layer_kernel(ZsArgs a)
 
 int zs_cus()
 {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
+    static int cus[64]; // per device: partitions / devices of different sizes get a grid sized for themselves
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+        int n = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        cus[dev] = n > 0 ? n : 256;
     }
-    return cus;
+    return cus[dev];
 }
 
 struct ZsGeo {
@@ -636,7 +638,7 @@ extern "C" int geom_zn_layer_fwd_f32(int b, int nv, int c, int k, int ell_w, con
     if (b == 0 || nv == 0) return 0;
     if (!ell_col || !ell_val || !s_prev || !w || !x_out || !s_out) return GEOM_EINVAL;
     if (!zs_aligned16(ell_col) || !zs_aligned16(ell_val) || !zs_aligned16(s_prev) || !zs_aligned16(x_out) || !zs_aligned16(s_out) ||
-        (bias_prev && !zs_aligned16(bias_prev)))
+        (bias_prev && !zs_aligned16(bias_prev)) || ((uintptr_t)w & 3) || ((uintptr_t)wt_out & 3))
         return GEOM_EINVAL;
     if (relu_mask && act != ZS_ACT_RELU) return GEOM_EINVAL;
     const int rows = b * nv;
@@ -676,7 +678,7 @@ extern "C" int geom_zn_layer_bwd_f32(int b, int nv, int c, int k, int ell_w, con
     if (act == ZS_ACT_RELU && !relu_mask) return GEOM_EINVAL;
     if (act == ZS_ACT_ELU && (!out || grad_pos)) return grad_pos ? GEOM_EUNSUPPORTED : GEOM_EINVAL;
     if (!zs_aligned16(ell_col_t) || !zs_aligned16(ell_val_t) || !zs_aligned16(grad_out) || !zs_aligned16(out) || !zs_aligned16(g_out) ||
-        !zs_aligned16(grad_in))
+        !zs_aligned16(grad_in) || ((uintptr_t)wt & 3) || ((uintptr_t)grad_pos & 3) || ((uintptr_t)colsum_partial & 3))
         return GEOM_EINVAL;
     const int rows = b * nv;
     const ZsGeo geo = zs_geometry(rows);

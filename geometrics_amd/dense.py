@@ -144,6 +144,13 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, workspace=None):
     split over the summed index (allocated here when the plan wants one and none is given)."""
     if not (_row_major(a) and _row_major(b)):
         raise ValueError("gemm operands must be 2-D with contiguous rows")
+    for name, t in (("a", a), ("b", b), ("out", out), ("workspace", workspace)):     # raw pointers go to the kernel: no silent casts
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise ValueError("gemm: %s must be a float32 tensor on a HIP device (got %s on %s)" % (name, t.dtype, t.device))
+        if t.device != a.device:
+            raise ValueError("gemm: %s is on %s, a on %s" % (name, t.device, a.device))
     k, m = (a.shape if trans_a else a.shape[::-1])
     n, kb = (b.shape if trans_b else b.shape[::-1])
     if k != kb:

@@ -619,15 +619,18 @@ class _ZeroNAggregateHead(torch.autograd.Function):
             scratch = torch.empty(_lib.lib().geom_zn_gcn_bwd_scratch_floats(b, nv, c), dtype=torch.float32, device=gp.device)
             defer = _may_defer(bias)
         down = ctx.down
+        # (the launch below takes THIS layer's aggregation backward: it must be a shape the boundary kernel serves -- 192 wide,
+        # k = 64, table width 8 without long rows -- and `wt` the transposed weight of a 192-row product; else: the separate operators)
         if (down is not None and down.wt is not None and down.wanted and ctx.needs_input_grad[0]
-                and _fused.plan(b * nv)["bwd"]):
+                and _fused.plan(b * nv)["bwd"] and down.wt.dim() == 2 and down.wt.shape[0] == c
+                and _fused.supported(csr, c, k, down.wt.shape[1])):
             # this aggregation backward AND the input gradient of the product below it in one launch (csrc/zn_stack.hip);
             # the boundary below picks its input gradient up from the link instead of computing it
             rows = _fused.partial_rows(b, nv)
             partial = torch.empty(rows, c, dtype=torch.float32, device=gp.device) if grad_bias is not None else None
             _fused.layer_backward(None, None, mask, csr, k, ctx.act, down.wt, g_out=grad_support, grad_in=down.take_dx(b, nv),
                                   colsum_partial=partial, grad_pos=gp, head_scale=ctx.scale, shape=(b, nv, c))
-            down.g_ptr = grad_support.data_ptr()
+            down.stamp(grad_support)
             if grad_bias is not None:
                 _finish_colsum(partial, rows, c, grad_bias, bias, defer)
             return grad_support, grad_bias, (gp if ctx.needs_input_grad[2] else None), None, None, None, None, None
@@ -802,8 +805,8 @@ def _forward_product(x, w2):
     """x [..., cin] @ w2 [cin, c]: ONE rule for which kernel computes it, whichever autograd node wraps it (the routes of a
     layer must agree bit for bit in the forward: tests compare them)."""
     rows = x.numel() // x.shape[-1] if x.shape[-1] else 0
-    if (x.is_cuda and x.dtype == torch.float32 and w2.dtype == torch.float32 and w2.is_contiguous()
-            and _takes_any_shape_kernel(rows, x.shape[-1], w2.shape[-1])):
+    if (x.is_cuda and x.dtype == torch.float32 and w2.dtype == torch.float32 and w2.dim() == 2 and w2.is_contiguous()
+            and x.shape[-1] == w2.shape[0] and _takes_any_shape_kernel(rows, x.shape[-1], w2.shape[-1])):
         x2 = x.reshape(-1, x.shape[-1])
         return _dense_kernels.gemm(x2 if x2.is_contiguous() else x2.contiguous(), w2).view(x.shape[:-1] + (w2.shape[1],))
     return torch.matmul(x, w2)
@@ -1000,12 +1003,28 @@ class _StackLink:
     backward) computes this boundary's input gradient with it and leaves it in `dx`, stamped with the address of the support
     gradient it was computed from -- the boundary uses it only when that very tensor arrives as its incoming gradient (an
     engine that summed several consumers' gradients hands over another tensor, and the product is computed here as usual)."""
-    __slots__ = ("wt", "dx", "g_ptr", "wanted")
+    __slots__ = ("wt", "dx", "g_ref", "g_version", "wanted")
 
     def __init__(self):
-        self.wt = self.dx = None
-        self.g_ptr = 0
+        self.wt = self.dx = self.g_ref = None
+        self.g_version = -1
         self.wanted = False
+
+    def stamp(self, g):
+        """`dx` was computed from the support gradient `g`: remember the tensor itself (held, so that its address cannot be
+        recycled) and its version counter (an engine that accumulates another consumer's gradient IN PLACE keeps the address
+        and bumps the version)."""
+        self.g_ref, self.g_version = g, g._version
+
+    def claim_dx(self, g):
+        """The precomputed input gradient if `g` is the very tensor (same memory, same version) it was computed from."""
+        dx, ref, ver = self.dx, self.g_ref, self.g_version
+        self.dx = self.g_ref = None
+        if dx is None or ref is None:
+            return None
+        same = (g.data_ptr() == ref.data_ptr() and g.shape.numel() == ref.shape.numel() and g._version == ver
+                and ref._version == ver)
+        return dx if same else None
 
     def take_dx(self, b, nv):
         self.dx = torch.empty(b, nv, self.wt.shape[1], dtype=torch.float32, device=self.wt.device)
@@ -1054,7 +1073,7 @@ class _FusedBoundary(torch.autograd.Function):
         need_b = need_b and ctx.bias_ref is not None
         up, down, csr, k, act = ctx.up, ctx.down, ctx.csr, ctx.k, ctx.act
         # ---- layer L+1's product: dW partials, and dX unless the launch above left it in the link
-        dx, up.dx = (up.dx if up.dx is not None and up.g_ptr == g2.data_ptr() else None), None
+        dx = up.claim_dx(g2)
         plan = _dense_kernels.plan(rows, c, n_out)
         grad_w = ws = None
         split = need_w and plan["dw"] == "mfma" and w2.is_contiguous()
@@ -1088,7 +1107,7 @@ class _FusedBoundary(torch.autograd.Function):
                 partial = torch.empty(prows, c, dtype=torch.float32, device=x.device)
             grad_support, _ = _fused.layer_backward(dx, out, mask, csr, k, act, down.wt, grad_in=down.take_dx(b, nv),
                                                     colsum_partial=partial)
-            down.g_ptr = grad_support.data_ptr()
+            down.stamp(grad_support)
             if need_b:
                 _finish_colsum(partial, prows, c, grad_bias, bias, _may_defer(bias))
         else:

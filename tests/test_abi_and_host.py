@@ -354,4 +354,4 @@ def test_which_kernel_takes_a_product():
     with pytest.raises(ValueError):
         dense.gemm(torch.zeros(4, 6)[:, ::2], torch.zeros(3, 2))            # rows must have unit stride
     link = layers._StackLink()
-    assert link.wt is None and link.dx is None and link.g_ptr == 0 and not link.wanted
+    assert link.wt is None and link.dx is None and link.g_ref is None and not link.wanted
