@@ -16,7 +16,7 @@ FLAG_FIX_REGION6 = 2
 FLAG_TRI_BRUTE_FORCE = 4
 FLAG_NN_FMA = 8
 FLAG_TRI_WS_READY = 16
-ABI_VERSION = 9
+ABI_VERSION = 10
 EUNSUPPORTED = -3
 ADAM_MAX_TENSORS = 64
 COLSUM_MAX_JOBS = 32
@@ -118,7 +118,32 @@ _SIGNATURES = {
     "geom_gemm_f32": [_i, _i, _i, _vp, ctypes.c_int64, _i, _vp, ctypes.c_int64, _i, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _vp],
     "geom_zn_layer_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_zn_layer_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp],
+    "geom_deform_layer_fwd_f32": [_vp, _vp],
+    "geom_deform_layer_bwd_f32": [_vp, _vp],
 }
+
+
+class DeformFwd(ctypes.Structure):
+    """struct geom_deform_fwd (include/geom_hip.h): a hidden layer of the deformation block, forward."""
+    _fields_ = [("b", _i), ("nv", _i), ("c", _i), ("k", _i), ("ell_w", _i),
+                ("s_in", _vp), ("bias", _vp), ("ell_col", _vp), ("ell_val", _vp),
+                ("over_ptr", _vp), ("over_col", _vp), ("over_val", _vp),
+                ("bn_w", _vp), ("bn_b", _vp), ("run_mean", _vp), ("run_var", _vp),
+                ("training", _i), ("momentum", _f), ("eps", _f), ("relu", _i),
+                ("res", _vp), ("res_ld", _i), ("scale", _f),
+                ("z_out", _vp), ("x_out", _vp), ("save_mean", _vp), ("save_invstd", _vp),
+                ("w_next", _vp), ("s_out", _vp), ("wt_out", _vp), ("vpx", _i)]
+
+
+class DeformBwd(ctypes.Structure):
+    """struct geom_deform_bwd (include/geom_hip.h): a hidden layer of the deformation block, backward."""
+    _fields_ = [("b", _i), ("nv", _i), ("c", _i), ("k", _i), ("ell_w", _i),
+                ("dz_up", _vp), ("ell_col_t", _vp), ("ell_val_t", _vp),
+                ("over_ptr_t", _vp), ("over_col_t", _vp), ("over_val_t", _vp),
+                ("ds_up", _vp), ("wt_up", _vp), ("g", _vp), ("g2", _vp),
+                ("z", _vp), ("bn_w", _vp), ("bn_b", _vp), ("save_mean", _vp), ("save_invstd", _vp),
+                ("relu", _i), ("has_res", _i), ("scale", _f),
+                ("grad_res", _vp), ("dz", _vp), ("grad_bn_w", _vp), ("grad_bn_b", _vp), ("colsum", _vp), ("vpx", _i)]
 
 
 class SurfaceCull(ctypes.Structure):

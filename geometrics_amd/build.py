@@ -29,7 +29,8 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 # (ROCm 7.2) allocates the accumulators of the pipelined loop as untied AGPR tuples and repairs the rotation with ~85
 # v_accvgpr moves per stage, in front of the first MFMA of every stage
 EXTRA_FLAGS = {"dense_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-               "zn_stack.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+               "zn_stack.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "deform_block.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def sources():

@@ -1,0 +1,475 @@
+// A hidden layer of the mesh deformation block in ONE launch per direction (reference models.py:237-297
+// with layers.py:107-116): the block follows every 0N-GCN layer with BatchNorm1d(verts) + ReLU, and every second one with the
+// residual average `(features + x) / 2`.  As separate operators a hidden layer is three launches each way at the reference's
+// training shape (16 meshes x 482 vertices = 7 712 rows, 192 wide): product 9.3 us, aggregation 7.3 us, per-vertex
+// BatchNorm 6-7 us (profiles/r05_driver_step_timeline.txt), every one of them a latency chain on a mostly idle chip, with the
+// 5.9 MB activation written and re-read between them.
+//
+//   forward  (geom_deform_layer_fwd_f32), one workgroup per VERTEX v, its B <= 16 batch rows = one 16-row MFMA tile:
+//       Z   = [A . S[:, :64] | S[:, 64:]] + bias          the layer's aggregation (zn_gcn.hip's order: same bits)
+//       X'  = ReLU(BatchNorm_v(Z))  (+ residual, * scale)  statistics over the vertex's B * 192 values: tile-local
+//       S'  = X' . W_next                                  the NEXT layer's product, exact fp32 on v_mfma_f32_16x16x4_f32
+//     writes Z (the BatchNorm backward needs it), X' (the next layer's weight gradient and the residuals need it), S'.
+//   backward (geom_deform_layer_bwd_f32), same tiling:
+//       G   = [A^T . dZ_up[:, :64] | dZ_up[:, 64:]]        aggregation backward of the layer ABOVE (written: its dW needs it)
+//       dX  = G . W_up^T  (+ a second upstream gradient)   its input-gradient product
+//       dZ  = BatchNorm_v backward (ReLU mask, residual scale) of THIS layer: the two reductions are tile-local again
+//     writes G, dZ, the residual's gradient, the BatchNorm parameter gradients and the vertex's bias-gradient column sums.
+//
+// Why this tiling: BatchNorm1d(verts) normalises a vertex over (batch, channel), so the natural tile is "all batch rows of one
+// vertex" -- exactly M = 16 of the fp32 MFMA -- and the only cross-tile dependencies of a layer are the two gathers
+// (neighbours' support rows forward, neighbours' dZ rows backward), which is where the launch boundaries sit.  The weight
+// operand follows zn_stack.hip: a wave owns 48 output columns and holds its 192 x 48 slice in 144 registers, requested at
+// kernel start so that it lands under the gather round trips; the activation tile goes through the same conflict-free
+// [k-quarter][row][52] LDS panel, one ds_read_b128 per 12 MFMAs.  482 workgroups of 4 waves, two resident per CU: while one
+// waits for its gathers the other runs its 144 MFMAs per wave.
+#include "geom_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+struct __attribute__((packed, aligned(4))) f3u { float x, y, z; };
+
+constexpr int DB_THREADS = 256;
+constexpr int DB_C = 192;            // layer width
+constexpr int DB_K = 64;             // aggregated columns (split 3)
+constexpr int DB_W = 8;              // neighbour-table width
+constexpr int DB_LDR = 52;           // floats per (quarter, row) line of the operand panel: 48 used, pitch 13 x 16 B
+constexpr int DB_SUB = 16 * DB_LDR;  // one k-quarter of the panel
+constexpr int DB_PANEL = 4 * DB_SUB;
+constexpr int DB_LDC = DB_C + 4;     // row pitch of the output staging tile
+constexpr int DB_CST = 16 * DB_LDC;
+constexpr int DB_RED = 16;           // floats of reduction scratch
+constexpr unsigned DB_OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t db_rsrc(const void *p, int64_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, p ? (int)bytes : 0, 0x00020000);
+}
+__device__ __forceinline__ float4 db_ld4(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void db_st4(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)},
+                                           r, off, 0, 0);
+}
+
+// workgroup w -> vertex: contiguous vertex runs per XCD (workgroup w runs on XCD w % 8; a support row is gathered by its ~7
+// neighbours, which are mostly near it in the numbering, so a run's rows stay in one L2)
+__device__ __forceinline__ int db_vertex(int w, int vpx, int nv)
+{
+    const int v = (w & 7) * vpx + (w >> 3);
+    return ((w >> 3) < vpx && v < nv) ? v : -1;
+}
+
+// fixed-order block reduction of two values: wave shuffles, then the four wave partials in order
+__device__ __forceinline__ void db_sum2(float &a, float &b, float *red)
+{
+    for (int off = GEOM_WAVE / 2; off > 0; off >>= 1) {
+        a += __shfl_down(a, off, GEOM_WAVE);
+        b += __shfl_down(b, off, GEOM_WAVE);
+    }
+    const int lane = threadIdx.x & (GEOM_WAVE - 1), wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[2 * wave] = a, red[2 * wave + 1] = b;
+    __syncthreads();
+    a = ((red[0] + red[2]) + red[4]) + red[6];
+    b = ((red[1] + red[3]) + red[5]) + red[7];
+}
+
+// the wave's 192 x 48 slice of a [192][192] row-major matrix: lane (x, g), step (jp, c): k = 48 g + 4 jp + c, columns
+// 48 wave + 3 x .. + 2 (zn_stack.hip's layout)
+__device__ __forceinline__ void db_load_slice(f3u (&bw)[12][4], const float *m, int wave, int x, int g)
+{
+    const __amdgpu_buffer_rsrc_t r_b = db_rsrc(m, (int64_t)DB_C * DB_C * 4);
+    const unsigned b0 = ((unsigned)(48 * g) * DB_C + (unsigned)(wave * 48 + 3 * x)) * 4u;
+#pragma unroll
+    for (int jp = 0; jp < 12; ++jp)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(r_b, b0 + (unsigned)(4 * jp + c) * DB_C * 4u, 0, 0);
+            bw[jp][c] = f3u{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z)};
+        }
+}
+
+// C tile [16 rows][192] = panel [16][192] . slice, into the staging tile (natural [row][col] layout, pitch DB_LDC)
+__device__ __forceinline__ void db_product(const f3u (&bw)[12][4], const float *panel, float *stage, int wave, int x, int g)
+{
+    const float *pa = panel + g * DB_SUB + x * DB_LDR;
+    f32x4 acc[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 af = *reinterpret_cast<const f32x4 *>(pa);
+#pragma unroll
+    for (int jp = 0; jp < 12; ++jp) {
+        f32x4 an = af;
+        if (jp + 1 < 12) an = *reinterpret_cast<const f32x4 *>(pa + 4 * (jp + 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[jp][c].x, af[c], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[jp][c].y, af[c], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[jp][c].z, af[c], acc[2], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        af = an;
+    }
+    // accumulator u of lane (x, g) holds C[row x][48 wave + 12 g + 3 r + u], r = 0..3: twelve consecutive columns
+    float e[12];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) e[3 * r + u] = acc[u][r];
+    float *dst = stage + x * DB_LDC + wave * 48 + 12 * g;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) *reinterpret_cast<f32x4 *>(dst + 4 * v) = (f32x4){e[4 * v], e[4 * v + 1], e[4 * v + 2], e[4 * v + 3]};
+}
+
+// the transposed copy of the slice a wave holds (workgroup 0 of the forward launch: what the backward loads as W^T)
+__device__ __forceinline__ void db_store_transposed(const f3u (&bw)[12][4], float *wt, int wave, int x, int g)
+{
+    const int jc = wave * 48 + 3 * x;
+#pragma unroll
+    for (int jp = 0; jp < 12; ++jp)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = 48 * g + 4 * jp + c;
+            wt[(int64_t)(jc + 0) * DB_C + k] = bw[jp][c].x;
+            wt[(int64_t)(jc + 1) * DB_C + k] = bw[jp][c].y;
+            wt[(int64_t)(jc + 2) * DB_C + k] = bw[jp][c].z;
+        }
+}
+
+// The aggregated float4 of thread (row rl, group j) of vertex v: sum over the vertex's table entries, then its CSR tail, of
+// val * src[mesh rl][neighbour][4 j ..] -- the order and arithmetic of zn_aggregate_ell_kernel (a padded slot adds -0.0: no
+// value changes, signed zeros included).  `rowbase` = byte offset of mesh rl's first row, DB_OOB-safe: rows beyond the batch
+// pass mesh_on = false and read zeros.
+__device__ __forceinline__ float4 db_aggregate(__amdgpu_buffer_rsrc_t r_src, bool mesh_on, unsigned rowbase, int v, int c0,
+                                               const int *ell_col, const float *ell_val, const int *over_ptr, const int *over_col,
+                                               const float *over_val, float4 *own, int n_own)
+{
+    // round trip 1: the vertex's table entries (the same for every thread of the workgroup)
+    const int4 ci0 = *reinterpret_cast<const int4 *>(ell_col + (size_t)v * DB_W), ci1 = *reinterpret_cast<const int4 *>(ell_col + (size_t)v * DB_W + 4);
+    const float4 wi0 = *reinterpret_cast<const float4 *>(ell_val + (size_t)v * DB_W), wi1 = *reinterpret_cast<const float4 *>(ell_val + (size_t)v * DB_W + 4);
+    int e0 = 0, e1 = 0;
+    if (over_ptr) e0 = over_ptr[v], e1 = over_ptr[v + 1];
+    const int nb[DB_W] = {ci0.x, ci0.y, ci0.z, ci0.w, ci1.x, ci1.y, ci1.z, ci1.w};
+    const float wv[DB_W] = {wi0.x, wi0.y, wi0.z, wi0.w, wi1.x, wi1.y, wi1.z, wi1.w};
+    // round trip 2: the neighbour rows + the thread's own pass-through elements
+    float4 sv[DB_W];
+#pragma unroll
+    for (int n = 0; n < DB_W; ++n) {
+        const unsigned off = rowbase + (unsigned)(nb[n] >= 0 ? nb[n] : v) * (DB_C * 4) + 4 * c0;
+        sv[n] = db_ld4(r_src, mesh_on ? off : DB_OOB);
+    }
+    const unsigned own_off = rowbase + (unsigned)v * (DB_C * 4) + 4 * c0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        if (i < n_own) own[i] = db_ld4(r_src, mesh_on ? own_off + 4 * DB_K * (i + 1) : DB_OOB);
+    float4 facc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int n = 0; n < DB_W; ++n) {
+        const bool in = nb[n] >= 0;
+        const float tx = wv[n] * sv[n].x, ty = wv[n] * sv[n].y, tz = wv[n] * sv[n].z, tw = wv[n] * sv[n].w;
+        facc.x += in ? tx : -0.0f, facc.y += in ? ty : -0.0f, facc.z += in ? tz : -0.0f, facc.w += in ? tw : -0.0f;
+    }
+    for (int e = e0; e < e1; e += DB_W) { // a vertex with more entries than the table (the 33-entry poles of 482.obj): uniform branch
+        float4 tv[DB_W];
+        float tw8[DB_W];
+#pragma unroll
+        for (int n = 0; n < DB_W; ++n) {
+            const bool in = e + n < e1;
+            const int col = in ? over_col[e + n] : v;
+            tw8[n] = in ? over_val[e + n] : 0.f;
+            tv[n] = db_ld4(r_src, mesh_on ? rowbase + (unsigned)col * (DB_C * 4) + 4 * c0 : DB_OOB);
+        }
+#pragma unroll
+        for (int n = 0; n < DB_W; ++n) {
+            const bool in = e + n < e1;
+            const float tx = tw8[n] * tv[n].x, ty = tw8[n] * tv[n].y, tz = tw8[n] * tv[n].z, tw = tw8[n] * tv[n].w;
+            facc.x += in ? tx : -0.0f, facc.y += in ? ty : -0.0f, facc.z += in ? tz : -0.0f, facc.w += in ? tw : -0.0f;
+        }
+    }
+    return facc;
+}
+
+__device__ __forceinline__ void db_to_panel(float *panel, int rl, int c0, const float4 (&x)[3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int col = c0 + DB_K * i;
+        *reinterpret_cast<float4 *>(panel + (col / 48) * DB_SUB + rl * DB_LDR + col % 48) = x[i];
+    }
+}
+
+template <bool PRODUCT>
+__global__ __launch_bounds__(DB_THREADS, 2) void db_fwd_kernel(geom_deform_fwd a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[DB_PANEL + DB_CST + DB_RED];
+    const int v = db_vertex(blockIdx.x, a.vpx, a.nv);
+    if (v < 0) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int x = lane & 15, g = lane >> 4; // matrix-core coordinates
+    const int rl = tid >> 4, j = tid & 15;  // batch row (mesh) and float4 group of the gather / BatchNorm thread
+    const int c0 = 4 * j;
+    f3u bw[12][4];
+    if (PRODUCT) db_load_slice(bw, a.w_next, wave, x, g); // requested first: lands under the two gather round trips
+
+    const bool mesh_on = rl < a.b;
+    const int64_t op_bytes = (int64_t)a.b * a.nv * DB_C * 4;
+    const __amdgpu_buffer_rsrc_t r_src = db_rsrc(a.s_in, op_bytes);
+    const unsigned rowbase = (unsigned)rl * (unsigned)a.nv * (DB_C * 4);
+    const unsigned own_off = mesh_on ? rowbase + (unsigned)v * (DB_C * 4) + 4 * c0 : DB_OOB;
+    // the vertex's BatchNorm parameters, the bias and the residual travel with the gathers
+    const float gamma = a.bn_w ? a.bn_w[v] : 1.f, beta = a.bn_b ? a.bn_b[v] : 0.f;
+    const bool updates = a.training && tid == 0;
+    const float old_mean = (updates && a.run_mean) ? a.run_mean[v] : 0.f, old_var = (updates && a.run_var) ? a.run_var[v] : 0.f;
+    float4 bias4[3], rv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        bias4[i] = a.bias ? *reinterpret_cast<const float4 *>(a.bias + c0 + DB_K * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (a.res) {
+        const __amdgpu_buffer_rsrc_t r_res = db_rsrc(a.res, ((int64_t)a.b * a.nv - 1) * a.res_ld * 4 + DB_C * 4);
+        const unsigned roff = ((unsigned)rl * (unsigned)a.nv + (unsigned)v) * (unsigned)a.res_ld * 4u + 4 * c0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rv[i] = db_ld4(r_res, mesh_on ? roff + 4 * DB_K * i : DB_OOB);
+    }
+    float4 z[3];
+    z[0] = db_aggregate(r_src, mesh_on, rowbase, v, c0, a.ell_col, a.ell_val, a.over_ptr, a.over_col, a.over_val, &z[1], 2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) z[i].x += bias4[i].x, z[i].y += bias4[i].y, z[i].z += bias4[i].z, z[i].w += bias4[i].w;
+
+    // ---- BatchNorm1d(verts): one statistic per vertex over its b * 192 values (two-pass: mean, then the centred second moment)
+    float *red = lds + DB_PANEL + DB_CST;
+    const int n = a.b * DB_C;
+    float mean, invstd;
+    if (a.training) {
+        float s = 0.f, dummy = 0.f;
+        if (mesh_on) s = (((z[0].x + z[0].y) + (z[0].z + z[0].w)) + ((z[1].x + z[1].y) + (z[1].z + z[1].w))) + ((z[2].x + z[2].y) + (z[2].z + z[2].w));
+        db_sum2(s, dummy, red);
+        mean = s / n;
+        float q = 0.f;
+        if (mesh_on) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float d0 = z[i].x - mean, d1 = z[i].y - mean, d2 = z[i].z - mean, d3 = z[i].w - mean;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        }
+        dummy = 0.f;
+        db_sum2(q, dummy, red);
+        const float var = q / n; // biased, as used for normalisation
+        invstd = 1.f / sqrtf(var + a.eps);
+        if (tid == 0) {
+            a.save_mean[v] = mean, a.save_invstd[v] = invstd;
+            if (a.run_mean) a.run_mean[v] = (1.f - a.momentum) * old_mean + a.momentum * mean;
+            if (a.run_var) a.run_var[v] = (1.f - a.momentum) * old_var + a.momentum * (n > 1 ? q / (n - 1) : var);
+        }
+    } else {
+        mean = a.run_mean[v];
+        invstd = 1.f / sqrtf(a.run_var[v] + a.eps);
+    }
+    auto finish = [&](float zz, float r) {
+        float y = (zz - mean) * invstd * gamma + beta;
+        if (a.relu) y = y > 0.f ? y : 0.f;
+        if (a.res) y = (r + y) * a.scale;
+        return mesh_on ? y : 0.f;
+    };
+    float4 xo[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        xo[i] = make_float4(finish(z[i].x, rv[i].x), finish(z[i].y, rv[i].y), finish(z[i].z, rv[i].z), finish(z[i].w, rv[i].w));
+    const __amdgpu_buffer_rsrc_t r_z = db_rsrc(a.z_out, op_bytes), r_x = db_rsrc(a.x_out, op_bytes);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (a.z_out) db_st4(r_z, own_off == DB_OOB ? DB_OOB : own_off + 4 * DB_K * i, z[i]);
+        db_st4(r_x, own_off == DB_OOB ? DB_OOB : own_off + 4 * DB_K * i, xo[i]);
+    }
+    if (!PRODUCT) return;
+
+    // ---- the next layer's product on the tile
+    db_to_panel(lds, rl, c0, xo);
+    if (a.wt_out && blockIdx.x == 0) db_store_transposed(bw, a.wt_out, wave, x, g);
+    __syncthreads();
+    float *stage = lds + DB_PANEL;
+    db_product(bw, lds, stage, wave, x, g);
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t r_s = db_rsrc(a.s_out, op_bytes);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { // the tile leaves in memory order: 768 contiguous bytes per mesh row
+        const int idx = tid + DB_THREADS * t, r = idx / 48, c4 = idx % 48;
+        const f32x4 val = *reinterpret_cast<const f32x4 *>(stage + r * DB_LDC + 4 * c4);
+        const unsigned off = r < a.b ? ((unsigned)r * (unsigned)a.nv + (unsigned)v) * (DB_C * 4) + 16u * c4 : DB_OOB;
+        db_st4(r_s, off, make_float4(val[0], val[1], val[2], val[3]));
+    }
+}
+
+template <bool PRODUCT>
+__global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_kernel(geom_deform_bwd a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[DB_PANEL + DB_CST + DB_RED];
+    const int v = db_vertex(blockIdx.x, a.vpx, a.nv);
+    if (v < 0) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int x = lane & 15, g = lane >> 4;
+    const int rl = tid >> 4, j = tid & 15;
+    const int c0 = 4 * j;
+    f3u bw[12][4];
+    if (PRODUCT) db_load_slice(bw, a.wt_up, wave, x, g);
+
+    const bool mesh_on = rl < a.b;
+    const int64_t op_bytes = (int64_t)a.b * a.nv * DB_C * 4;
+    const unsigned rowbase = (unsigned)rl * (unsigned)a.nv * (DB_C * 4);
+    const unsigned own_off = mesh_on ? rowbase + (unsigned)v * (DB_C * 4) + 4 * c0 : DB_OOB;
+    auto at = [&](int i) { return own_off == DB_OOB ? DB_OOB : own_off + 4 * DB_K * i; };
+    // everything this layer's BatchNorm backward reads is requested with the gathers
+    const __amdgpu_buffer_rsrc_t r_z = db_rsrc(a.z, op_bytes), r_g2 = db_rsrc(a.g2, op_bytes), r_g = db_rsrc(a.g, op_bytes);
+    const float mean = a.save_mean[v], invstd = a.save_invstd[v];
+    const float gamma = a.bn_w ? a.bn_w[v] : 1.f, beta = a.bn_b ? a.bn_b[v] : 0.f;
+    float4 zv[3], g2v[3], go[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        zv[i] = db_ld4(r_z, at(i));
+        g2v[i] = a.g2 ? db_ld4(r_g2, at(i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!PRODUCT) go[i] = db_ld4(r_g, at(i));
+    }
+    float *stage = lds + DB_PANEL;
+    if (PRODUCT) {
+        // ---- aggregation backward of the layer above: G = [A^T . dZ_up[:, :64] | dZ_up[:, 64:]]
+        const __amdgpu_buffer_rsrc_t r_src = db_rsrc(a.dz_up, op_bytes), r_ds = db_rsrc(a.ds_up, op_bytes);
+        float4 gs[3];
+        gs[0] = db_aggregate(r_src, mesh_on, rowbase, v, c0, a.ell_col_t, a.ell_val_t, a.over_ptr_t, a.over_col_t, a.over_val_t, &gs[1], 2);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) db_st4(r_ds, at(i), gs[i]); // the layer above's weight gradient reads it (X^T . G)
+        db_to_panel(lds, rl, c0, gs);                           // (rows beyond the batch read zeros: zero rows of the tile)
+        __syncthreads();
+        db_product(bw, lds, stage, wave, x, g);                 // dX = G . W_up^T
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(stage + rl * DB_LDC + c0 + DB_K * i);
+            go[i] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+    }
+    // ---- this layer: residual scale, ReLU mask, BatchNorm backward
+    float sum_g = 0.f, sum_gx = 0.f;
+    float4 xh[3];
+    const __amdgpu_buffer_rsrc_t r_gr = db_rsrc(a.grad_res, op_bytes), r_dz = db_rsrc(a.dz, op_bytes);
+    auto one = [&](float zz, float &gg, float second, float &xhat) {
+        xhat = (zz - mean) * invstd;
+        gg += second;
+        if (a.has_res) gg *= a.scale;
+        const float pass = gg;
+        if (a.relu && !(xhat * gamma + beta > 0.f)) gg = 0.f;
+        if (!mesh_on) gg = 0.f;
+        sum_g += gg;
+        sum_gx += gg * xhat;
+        return pass;
+    };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float4 r = make_float4(one(zv[i].x, go[i].x, g2v[i].x, xh[i].x), one(zv[i].y, go[i].y, g2v[i].y, xh[i].y),
+                                     one(zv[i].z, go[i].z, g2v[i].z, xh[i].z), one(zv[i].w, go[i].w, g2v[i].w, xh[i].w));
+        if (a.has_res && a.grad_res) db_st4(r_gr, at(i), r);
+    }
+    float *red = lds + DB_PANEL + DB_CST;
+    db_sum2(sum_g, sum_gx, red);
+    if (tid == 0) {
+        if (a.grad_bn_b) a.grad_bn_b[v] = sum_g;
+        if (a.grad_bn_w) a.grad_bn_w[v] = sum_gx;
+    }
+    const int n = a.b * DB_C;
+    const float kk = gamma * invstd, mg = sum_g / n, mgx = sum_gx / n;
+    float4 dz[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        dz[i] = make_float4(kk * (go[i].x - mg - xh[i].x * mgx), kk * (go[i].y - mg - xh[i].y * mgx),
+                            kk * (go[i].z - mg - xh[i].z * mgx), kk * (go[i].w - mg - xh[i].w * mgx));
+        if (!mesh_on) dz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        db_st4(r_dz, at(i), dz[i]);
+    }
+    // ---- bias gradient of this layer: the vertex's column sums of dZ over its meshes, in mesh order (lanes 16 apart hold the
+    // wave's four meshes, the four waves' sums through LDS); the host adds the vertices up
+    if (a.colsum) {
+        __syncthreads(); // (the staging tile may still be read above)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float4 t = dz[i];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const int src = (lane & 15) + 16 * k;
+                t.x += __shfl(dz[i].x, src), t.y += __shfl(dz[i].y, src), t.z += __shfl(dz[i].z, src), t.w += __shfl(dz[i].w, src);
+            }
+            if ((lane >> 4) == 0) *reinterpret_cast<float4 *>(stage + wave * DB_C + c0 + DB_K * i) = t;
+        }
+        __syncthreads();
+        if (tid < DB_C) a.colsum[(size_t)v * DB_C + tid] = ((stage[tid] + stage[DB_C + tid]) + stage[2 * DB_C + tid]) + stage[3 * DB_C + tid];
+    }
+}
+
+inline bool db_aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+int db_check_shape(int b, int nv, int c, int k, int ell_w)
+{
+    if (b < 0 || nv < 0 || c <= 0 || k < 0) return GEOM_EINVAL;
+    if (c != DB_C || k != DB_K || ell_w != DB_W || b > 16) return GEOM_EUNSUPPORTED;
+    if ((int64_t)b * nv * DB_C >= (1LL << 29)) return GEOM_EUNSUPPORTED; // 32-bit byte offsets
+    return 0;
+}
+
+} // namespace
+
+extern "C" int geom_deform_layer_fwd_f32(const geom_deform_fwd *args, void *stream)
+{
+    if (!args) return GEOM_EINVAL;
+    geom_deform_fwd a = *args;
+    const int code = db_check_shape(a.b, a.nv, a.c, a.k, a.ell_w);
+    if (code) return code;
+    if (a.b == 0 || a.nv == 0) return 0;
+    if (!a.s_in || !a.ell_col || !a.ell_val || !a.x_out) return GEOM_EINVAL;
+    if (a.training ? (!a.save_mean || !a.save_invstd) : (!a.run_mean || !a.run_var)) return GEOM_EINVAL;
+    if (a.w_next && !a.s_out) return GEOM_EINVAL;
+    if (a.over_ptr && (!a.over_col || !a.over_val)) return GEOM_EINVAL;
+    if (a.res && (a.res_ld < DB_C || (a.res_ld & 3))) return GEOM_EINVAL;
+    if (!db_aligned16(a.s_in) || !db_aligned16(a.ell_col) || !db_aligned16(a.ell_val) || !db_aligned16(a.x_out) || !db_aligned16(a.z_out) ||
+        !db_aligned16(a.s_out) || !db_aligned16(a.bias) || !db_aligned16(a.res) || ((uintptr_t)a.w_next & 3) || ((uintptr_t)a.wt_out & 3))
+        return GEOM_EINVAL;
+    if (!a.res) a.scale = 1.f;
+    a.vpx = (a.nv + 7) / 8;
+    const dim3 grid(8 * a.vpx), block(DB_THREADS);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a.w_next) hipLaunchKernelGGL((db_fwd_kernel<true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((db_fwd_kernel<false>), grid, block, 0, s, a);
+    return geom::launch_status();
+}
+
+extern "C" int geom_deform_layer_bwd_f32(const geom_deform_bwd *args, void *stream)
+{
+    if (!args) return GEOM_EINVAL;
+    geom_deform_bwd a = *args;
+    const int code = db_check_shape(a.b, a.nv, a.c, a.k, a.ell_w);
+    if (code) return code;
+    if (a.b == 0 || a.nv == 0) return 0;
+    if (!a.z || !a.save_mean || !a.save_invstd || !a.dz) return GEOM_EINVAL;
+    const bool product = a.dz_up != nullptr;
+    if (product ? (!a.ell_col_t || !a.ell_val_t || !a.ds_up || !a.wt_up) : !a.g) return GEOM_EINVAL;
+    if (a.over_ptr_t && (!a.over_col_t || !a.over_val_t)) return GEOM_EINVAL;
+    if (!db_aligned16(a.dz_up) || !db_aligned16(a.ell_col_t) || !db_aligned16(a.ell_val_t) || !db_aligned16(a.ds_up) || !db_aligned16(a.g) ||
+        !db_aligned16(a.g2) || !db_aligned16(a.z) || !db_aligned16(a.grad_res) || !db_aligned16(a.dz) || !db_aligned16(a.colsum) ||
+        ((uintptr_t)a.wt_up & 3))
+        return GEOM_EINVAL;
+    if (!a.has_res) a.scale = 1.f;
+    a.vpx = (a.nv + 7) / 8;
+    const dim3 grid(8 * a.vpx), block(DB_THREADS);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (product) hipLaunchKernelGGL((db_bwd_kernel<true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((db_bwd_kernel<false>), grid, block, 0, s, a);
+    return geom::launch_status();
+}

@@ -1,0 +1,177 @@
+"""The hidden layers of the mesh deformation block as ONE launch per layer and direction (csrc/deform_block.hip).
+
+reference: models.py:237-297 -- `x = F.relu(self.bnK(self.gcK(features, adj, F.relu)))` thirteen times (gcK: layers.py:107-116,
+bnK = nn.BatchNorm1d(verts)), `features = features + x; features /= 2` after every second layer.  As separate operators a
+hidden layer is product -> aggregation -> per-vertex BatchNorm (three launches each way, the activation written and re-read
+between them); here layer i's launch computes
+
+    Z_i = aggregate(S_i) + bias_i ;  X_{i+1} = ReLU(BN_i(Z_i)) (+ residual, / 2) ;  S_{i+1} = X_{i+1} . W_{i+1}
+
+and its backward launch the aggregation backward + input-gradient product of layer i + 1 and the BatchNorm backward of layer i.
+The chain is one autograd node: its input is the FIRST layer's raw support S_1 = cat(features, pooled) . W_1 (that product and
+its gradients stay with layers._dense), its output the block's final features X_14; the coordinate head gc15 stays the
+existing layer.  Weight gradients of the twelve equal layers: one strided-batched product over the stacked activations and
+support gradients; bias gradients: per-vertex column sums out of the backward launches, added up by one reduction.
+
+`serves()` says when the launches apply (192-wide block, k = 64, b <= 16, bounded-degree table of width 8, training mode,
+local BatchNorm statistics, fp32 on a HIP device); everything else takes the separate operators (models.py).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from . import layers as _layers
+
+# models.py:252-292: which earlier activation a layer's output is averaged with.  Key: layer; value: "lead" (the leading 192
+# columns of the block input) or j = X_j, the INPUT of layer j (X_{j} = output of layer j - 1).
+RESIDUALS = {2: "lead", 4: 3, 6: 5, 8: 7, 10: 9, 12: 11, 13: 13}
+LAYERS = 13
+
+enabled = True      # tests / A-B timing: False keeps the separate operators
+
+
+def serves(block, features, pooled, csr):
+    """Whether the fused launches serve this call of `block` (a models.BatchMeshDeformationBlock)."""
+    if not enabled or block.hidden != 192 or not block.training or not torch.is_grad_enabled():
+        return False
+    if not (features.is_cuda and features.dtype == torch.float32 and pooled.dtype == torch.float32 and features.dim() == 3):
+        return False
+    if features.shape[0] > 16 or features.shape[0] * features.shape[1] * 192 >= 2 ** 29:
+        return False
+    if csr.ell_w != 8:
+        return False
+    for i in range(1, LAYERS + 1):
+        gc, bn = getattr(block, "gc%d" % i), getattr(block, "bn%d" % i)
+        if gc.bias is None or gc.weight1.shape[-1] != 192 or (i > 1 and gc.weight1.shape[-2] != 192) or bn._synchronised():
+            return False
+    return True
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def layer_forward(s_in, bias, csr, bn_w, bn_b, run_mean, run_var, training, momentum, eps, relu, res, scale, z_out, x_out,
+                  save_mean, save_invstd, w_next=None, s_out=None, wt_out=None):
+    """One forward launch (geom_deform_layer_fwd_f32); see include/geom_hip.h for the operands."""
+    b, nv, c = s_in.shape
+    over = csr.over or (None, None, None)
+    a = _lib.DeformFwd(b, nv, c, 64, csr.ell_w, _p(s_in), _p(bias), _p(csr.ell_col), _p(csr.ell_val), _p(over[0]), _p(over[1]),
+                       _p(over[2]), _p(bn_w), _p(bn_b), _p(run_mean), _p(run_var), int(training), float(momentum), float(eps),
+                       int(relu), _p(res), res.stride(1) if res is not None else 0, float(scale), _p(z_out), _p(x_out),
+                       _p(save_mean), _p(save_invstd), _p(w_next), _p(s_out), _p(wt_out), 0)
+    with torch.cuda.device(s_in.device):
+        _lib.call("geom_deform_layer_fwd_f32", ctypes.addressof(a))
+
+
+def layer_backward(shape, csr, z, bn_w, bn_b, save_mean, save_invstd, relu, has_res, scale, dz, grad_bn_w, grad_bn_b,
+                   dz_up=None, ds_up=None, wt_up=None, g=None, g2=None, grad_res=None, colsum=None):
+    """One backward launch (geom_deform_layer_bwd_f32)."""
+    b, nv, c = shape
+    over = csr.over_t or (None, None, None)
+    a = _lib.DeformBwd(b, nv, c, 64, csr.ell_w, _p(dz_up), _p(csr.ell_col_t), _p(csr.ell_val_t), _p(over[0]), _p(over[1]),
+                       _p(over[2]), _p(ds_up), _p(wt_up), _p(g), _p(g2), _p(z), _p(bn_w), _p(bn_b), _p(save_mean),
+                       _p(save_invstd), int(relu), int(has_res), float(scale), _p(grad_res), _p(dz), _p(grad_bn_w),
+                       _p(grad_bn_b), _p(colsum), 0)
+    with torch.cuda.device(z.device):
+        _lib.call("geom_deform_layer_bwd_f32", ctypes.addressof(a))
+
+
+class _HiddenChain(torch.autograd.Function):
+    """X_14 = the thirteen hidden layers applied to S_1 (see the module docstring).  apply(s1, lead, csr, stats, momentum,
+    eps, *biases[13], *weights[12] (gc2..gc13), *bn_weights[13], *bn_biases[13]); stats = [(running_mean, running_var)] * 13.
+    Returns the final features TWICE (two tensor objects over one memory: one for the coordinate head, one for the caller;
+    their gradients meet inside the first backward launch instead of in an add pass)."""
+
+    @staticmethod
+    def forward(ctx, s1, lead, csr, stats, momentum, eps, *params):
+        L = LAYERS
+        biases, weights = params[:L], params[L:2 * L - 1]
+        bn_w, bn_b = params[2 * L - 1:3 * L - 1], params[3 * L - 1:4 * L - 1]
+        s1 = _lib.require(s1, "s1", torch.float32, 3, 192)
+        lead = _lib.require(lead, "lead", torch.float32, 3, 192)
+        b, nv, c = s1.shape
+        dev = s1.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        xs = torch.empty(L, b, nv, c, **f32)          # xs[i - 1] = X_{i+1}, the output of layer i
+        zs = torch.empty(L, b, nv, c, **f32)          # zs[i - 1] = Z_i, what BN_i normalised
+        means, invstds = torch.empty(L, nv, **f32), torch.empty(L, nv, **f32)
+        wts = torch.empty(L - 1, c, c, **f32)         # wts[i - 1] = W_{i+1} transposed
+        s_buf = (torch.empty(b, nv, c, **f32), torch.empty(b, nv, c, **f32))
+        s_cur = s1
+        w2 = [w.reshape(c, c) if w.is_contiguous() else w.reshape(c, c).contiguous() for w in weights]
+        for i in range(1, L + 1):
+            src = RESIDUALS.get(i)
+            res = None if src is None else (lead if src == "lead" else xs[src - 2])
+            nxt = i < L
+            layer_forward(s_cur, biases[i - 1], csr, bn_w[i - 1], bn_b[i - 1], stats[i - 1][0], stats[i - 1][1], True, momentum, eps,
+                          True, res, 0.5, zs[i - 1], xs[i - 1], means[i - 1], invstds[i - 1],
+                          w_next=w2[i - 1] if nxt else None, s_out=s_buf[i & 1] if nxt else None, wt_out=wts[i - 1] if nxt else None)
+            s_cur = s_buf[i & 1]
+        ctx.csr = csr
+        ctx.save_for_backward(xs, zs, means, invstds, wts, *bn_w, *bn_b)
+        out = xs[L - 1]
+        return out, _layers._alias(out)
+
+    @staticmethod
+    def backward(ctx, g_a, g_b):
+        L = LAYERS
+        saved = ctx.saved_tensors
+        xs, zs, means, invstds, wts = saved[:5]
+        bn_w, bn_b = saved[5:5 + L], saved[5 + L:5 + 2 * L]
+        csr = ctx.csr
+        _, b, nv, c = xs.shape
+        dev = xs.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        if g_a is None and g_b is None:
+            return (None,) * (6 + 4 * L - 1)
+        g_top, g_top2 = (g_a, g_b) if g_a is not None else (g_b, None)
+        g_top = g_top.contiguous()
+        g_top2 = None if g_top2 is None else g_top2.contiguous()
+        dzs = torch.empty(L, b, nv, c, **f32)         # dzs[i - 1] = dZ_i
+        dss = torch.empty(L - 1, b, nv, c, **f32)     # dss[i - 2] = dS_i = gradient of layer i's raw support, i = 2..L
+        g_bnw, g_bnb = torch.empty(L, nv, **f32), torch.empty(L, nv, **f32)
+        colsum = torch.empty(L, nv, c, **f32)
+        pending = {}                                   # j -> gradient that reaches X_j through a residual average
+        g_lead = None
+        for i in range(L, 0, -1):
+            src = RESIDUALS.get(i)
+            grad_res = torch.empty(b, nv, c, **f32) if src is not None else None
+            common = dict(relu=True, has_res=src is not None, scale=0.5, dz=dzs[i - 1], grad_bn_w=g_bnw[i - 1], grad_bn_b=g_bnb[i - 1],
+                          grad_res=grad_res, colsum=colsum[i - 1])
+            if i == L:
+                layer_backward((b, nv, c), csr, zs[i - 1], bn_w[i - 1], bn_b[i - 1], means[i - 1], invstds[i - 1], g=g_top, g2=g_top2,
+                               **common)
+            else:
+                layer_backward((b, nv, c), csr, zs[i - 1], bn_w[i - 1], bn_b[i - 1], means[i - 1], invstds[i - 1], dz_up=dzs[i],
+                               ds_up=dss[i - 1], wt_up=wts[i - 1], g2=pending.pop(i + 1, None), **common)
+            if src == "lead":
+                g_lead = grad_res
+            elif src is not None:
+                if src in pending:
+                    pending[src] = pending[src] + grad_res
+                else:
+                    pending[src] = grad_res
+        assert not pending, "a residual gradient was left without its layer"
+        # dS_1 = aggregation backward of the first layer: the existing operator (no activation between S_1 and Z_1)
+        g_s1, _ = _layers.aggregate_backward(dzs[0], csr, 64, _layers._ACT_NONE, None, None, False)
+        rows = b * nv
+        g_w = torch.bmm(xs[:L - 1].view(L - 1, rows, c).transpose(1, 2), dss.view(L - 1, rows, c))     # dW_i = X_i^T . dS_i, i = 2..L
+        g_bias = colsum.sum(dim=1)                                                                      # [L, 192]
+        grads = [g_bias[i] for i in range(L)] + [g_w[i].view(1, c, c) for i in range(L - 1)] \
+            + [g_bnw[i] for i in range(L)] + [g_bnb[i] for i in range(L)]
+        return (g_s1, g_lead, None, None, None, None, *grads)
+
+
+def hidden_chain(block, s1, lead, csr):
+    """The thirteen hidden layers of `block` applied to the first layer's raw support; returns (features, features) -- see
+    _HiddenChain."""
+    L = LAYERS
+    gcs = [getattr(block, "gc%d" % i) for i in range(1, L + 1)]
+    bns = [getattr(block, "bn%d" % i) for i in range(1, L + 1)]
+    for bn in bns:
+        bn._pending_batches += 1
+    stats = [(bn.running_mean, bn.running_var) for bn in bns]
+    params = [g.bias for g in gcs] + [g.weight1 for g in gcs[1:]] + [bn.weight for bn in bns] + [bn.bias for bn in bns]
+    return _HiddenChain.apply(s1, lead, csr, stats, bns[0].momentum, bns[0].eps, *params)

@@ -4,8 +4,10 @@ the same state_dict keys (`gcN.weight1`, `gcN.bias`, `bnN.weight/bias/running_me
 num_batches_tracked`), so the reference's checkpoints load unchanged.
 
 Per layer pair the reference runs GEMM, dense adjacency product, cat, bias add, a two-pass
-BatchNorm1d(verts), ReLU, add and divide as separate eager ops; here it is GEMM -> one aggregation
-kernel (csrc/zn_gcn.hip) -> one per-vertex BN + ReLU (+ residual average) kernel (csrc/vertex_bn.hip).
+BatchNorm1d(verts), ReLU, add and divide as separate eager ops.  At the block's own width (192, batch <= 16: the
+reference's training shape) every hidden layer is ONE launch per direction -- aggregation + BatchNorm1d(verts) + ReLU +
+residual average + the next layer's product (geometrics_amd/deform.py, csrc/deform_block.hip); every other shape takes
+GEMM -> one aggregation kernel (csrc/zn_gcn.hip) -> one per-vertex BN + ReLU (+ residual average) kernel (csrc/vertex_bn.hip).
 A BatchNorm output that feeds the next layer AND a later residual average is handed out as two tensor objects over
 the same memory (`tap`), so that its two upstream gradients meet inside the BN backward kernel instead of in a separate
 accumulation pass; the block input's leading columns (the first residual) are tapped the same way (`_InputTap`).
@@ -256,7 +258,18 @@ class BatchMeshDeformationBlock(nn.Module):
 
     def forward(self, features, pooled, adj):
         import contextlib
+        from . import deform as _deform
         batching = _layers.weight_gradient_batching(depth=14) if self.batch_weight_gradients else contextlib.nullcontext()
+        csr = _layers.adjacency_csr(adj) if (torch.is_tensor(adj) and adj.dim() == 2 and features.is_cuda) else None
+        if csr is not None and _deform.serves(self, features, pooled, csr):
+            # ONE launch per hidden layer and direction (csrc/deform_block.hip): aggregation + BatchNorm1d(verts) + ReLU +
+            # residual average + the next layer's product; the first layer's product and the coordinate head stay the layers'
+            with batching:
+                full, lead = _InputTap.apply(features, pooled, self.hidden)
+                s1 = _layers._dense(full, self.gc1.weight1)
+                feats, feats_out = _deform.hidden_chain(self, s1, lead, csr)
+                coords = self.gc15(feats, adj, _identity)
+            return feats_out, coords
         with batching:
             full, lead = _InputTap.apply(features, pooled, self.hidden)
             x = self._layer(1, full, adj)

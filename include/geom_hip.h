@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GEOM_ABI_VERSION 9
+#define GEOM_ABI_VERSION 10
 
 /* argument errors */
 #define GEOM_EINVAL   (-1) /* bad size / null pointer */
@@ -365,6 +365,59 @@ int geom_zn_layer_bwd_f32(int b, int nv, int c, int k, int ell_w, const int *ell
                           const float *grad_out, const float *out, const uint16_t *relu_mask, int act,
                           const float *grad_pos, float head_scale, const float *wt, int n_in, float *g_out,
                           float *grad_in, float *colsum_partial, void *stream);
+
+/* ---- a hidden layer of the mesh deformation block in ONE launch per direction (csrc/deform_block.hip) -------------------
+ * reference: models.py:237-297 (BatchMeshDeformationBlock.forward: gcK -> F.relu(bnK(.)) with bnK = nn.BatchNorm1d(verts),
+ * `features = features + x; features /= 2` after every second layer) on top of layers.py:107-116.  One workgroup per vertex
+ * (its b <= 16 batch rows are one 16-row tile of the fp32 matrix core; BatchNorm1d(verts) statistics are tile-local).
+ * Shapes: c == 192, k == 64 (split 3), ell_w == 8 (rows longer than the table continue in the CSR tail over_*), b <= 16;
+ * anything else GEOM_EUNSUPPORTED (callers then run the separate operators: product, geom_zn_gcn_aggregate_ell_*,
+ * geom_vertex_bn_*).  All arrays [b, nv, 192] row-major fp32, 16-byte aligned, caller-allocated.
+ *
+ * geom_deform_layer_fwd_f32:
+ *     z_out = [A . s_in[:, :k] | s_in[:, k:]] + bias                 (the bits of geom_zn_gcn_aggregate_ell_fwd_f32, act 0)
+ *     x_out = relu?(BatchNorm_v(z_out)) ; with res: (res + .) * scale  (nn.BatchNorm1d(verts) semantics of geom_vertex_bn_fwd_f32:
+ *             training: batch statistics, biased variance, running stats updated with the unbiased one; else running stats)
+ *     s_out = x_out . w_next            (w_next [192,192] row-major; NULL: no product -- the last hidden layer)
+ *     wt_out (optional) [192,192] = w_next transposed -- what geom_deform_layer_bwd_f32 takes as wt_up.
+ * geom_deform_layer_bwd_f32:  (dz_up != NULL)
+ *     ds_up = [A^T . dz_up[:, :k] | dz_up[:, k:]]                    (aggregation backward of the layer ABOVE; its weight
+ *                                                                     gradient is x^T . ds_up)
+ *     g     = ds_up . wt_up   (+ g2 if given)                         (gradient of THIS layer's output x_out)
+ *   (dz_up == NULL: g is read from memory instead, + g2)
+ *     with has_res: g *= scale, grad_res = g (the residual's gradient);  relu: g masked where BatchNorm_v(z) <= 0
+ *     dz = BatchNorm_v backward(g; z, save_mean, save_invstd, bn_w);  grad_bn_w[v] / grad_bn_b[v] = the vertex's sums
+ *     colsum (optional) [nv,192]: the vertex's column sums of dz over its meshes (the layer's bias gradient = their sum over
+ *     the vertices, in vertex order).
+ * `vpx` is filled in by the library. */
+typedef struct geom_deform_fwd {
+    int b, nv, c, k, ell_w;
+    const float *s_in, *bias;
+    const int *ell_col; const float *ell_val;
+    const int *over_ptr, *over_col; const float *over_val;      /* CSR tail of rows longer than the table, or NULL */
+    const float *bn_w, *bn_b;                                   /* [nv] or NULL (1 / 0) */
+    float *run_mean, *run_var;                                  /* [nv] */
+    int training; float momentum, eps;
+    int relu;
+    const float *res; int res_ld; float scale;                  /* optional residual [b,nv,res_ld >= 192] */
+    float *z_out, *x_out, *save_mean, *save_invstd;
+    const float *w_next; float *s_out, *wt_out;
+    int vpx;
+} geom_deform_fwd;
+typedef struct geom_deform_bwd {
+    int b, nv, c, k, ell_w;
+    const float *dz_up;
+    const int *ell_col_t; const float *ell_val_t;
+    const int *over_ptr_t, *over_col_t; const float *over_val_t;
+    float *ds_up; const float *wt_up;
+    const float *g, *g2;
+    const float *z, *bn_w, *bn_b, *save_mean, *save_invstd;
+    int relu, has_res; float scale;
+    float *grad_res, *dz, *grad_bn_w, *grad_bn_b, *colsum;
+    int vpx;
+} geom_deform_bwd;
+int geom_deform_layer_fwd_f32(const geom_deform_fwd *args, void *stream);
+int geom_deform_layer_bwd_f32(const geom_deform_bwd *args, void *stream);
 
 /* Any-shape product on the fp32 matrix cores (csrc/dense_any.hip): c [m, n] (row pitch ldc) = op(a) . op(b), exact fp32
  * (v_mfma_f32_16x16x4_f32), any sizes / pitches / 4-byte alignments -- `torch.mm(input, weight)` of the layers whose widths

@@ -1,0 +1,252 @@
+"""-m gpu: the hidden layers of the mesh deformation block as one launch per layer and direction (csrc/deform_block.hip,
+geometrics_amd/deform.py; reference models.py:237-297 on layers.py:107-116).
+
+* a single forward / backward launch against the separate operators it replaces (aggregation bits identical; the per-vertex
+  BatchNorm and the products within fp32 summation order of a float64 evaluation);
+* the whole block (13 fused hidden layers) against a FLOAT64 restatement of the reference block on the host: features,
+  coordinates, running statistics, every parameter gradient and both input gradients;
+* the same against the block on the separate operators (`deform.enabled = False`), batch 16 on the 482-vertex template with its
+  two 33-entry poles (table + CSR tail) and batch 5 on a pole-free icosphere (rows beyond the batch are zero rows of the tile);
+* the step inside a HIP graph; shapes the launches do not serve fall back to the separate operators."""
+import numpy as np
+import pytest
+import torch
+
+from geometrics_amd import deform, layers, meshgen, models, utils
+
+pytestmark = pytest.mark.gpu
+
+
+def _mesh(name, gpu):
+    V, Fc = meshgen.uv_sphere() if name == "uv_sphere_482" else meshgen.icosphere(2)
+    adj = utils.adj_init(torch.from_numpy(Fc).to(gpu))["adj"]
+    return V.shape[0], adj, layers.adjacency_csr(adj)
+
+
+def _maxrel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+
+
+def _bn64(z, gamma, beta, eps):
+    """nn.BatchNorm1d(verts) on [B,V,C] in training mode, float64: one statistic per vertex over (B, C)."""
+    mean = z.mean(dim=(0, 2), keepdim=True)
+    var = ((z - mean) ** 2).mean(dim=(0, 2), keepdim=True)
+    return (z - mean) / torch.sqrt(var + eps) * gamma.view(1, -1, 1) + beta.view(1, -1, 1), mean.flatten(), var.flatten()
+
+
+@pytest.mark.parametrize("mesh,batch", [("uv_sphere_482", 16), ("icosphere_162", 5)])
+def test_one_forward_launch_against_the_separate_operators(gpu, mesh, batch):
+    nv, adj, csr = _mesh(mesh, gpu)
+    torch.manual_seed(3)
+    c = 192
+    s = torch.randn(batch, nv, c, device=gpu)
+    bias = torch.randn(c, device=gpu) * 0.1
+    gamma, beta = torch.rand(nv, device=gpu) + 0.5, torch.randn(nv, device=gpu) * 0.2
+    res = torch.randn(batch, nv, c, device=gpu)
+    w = torch.randn(c, c, device=gpu) / 14
+    rm, rv = torch.zeros(nv, device=gpu), torch.ones(nv, device=gpu)
+    z, x, s_next = (torch.empty_like(s) for _ in range(3))
+    mean, invstd = torch.empty(nv, device=gpu), torch.empty(nv, device=gpu)
+    wt = torch.empty(c, c, device=gpu)
+    deform.layer_forward(s, bias, csr, gamma, beta, rm, rv, True, 0.1, 1e-5, True, res, 0.5, z, x, mean, invstd, w_next=w, s_out=s_next,
+                         wt_out=wt)
+    # aggregation: the bits of the stand-alone operator
+    z_ref = layers.zero_n_aggregate(s, adj, bias, 64, None)
+    assert torch.equal(z, z_ref)
+    assert torch.equal(wt, w.t().contiguous())
+    # BatchNorm + ReLU + residual average, and the product, against float64
+    y64, m64, v64 = _bn64(z.double().cpu(), gamma.double().cpu(), beta.double().cpu(), 1e-5)
+    x64 = (res.double().cpu() + torch.relu(y64)) * 0.5
+    assert _maxrel(x, x64) <= 2e-6
+    assert _maxrel(mean, m64) <= 1e-5 and _maxrel(invstd, 1.0 / torch.sqrt(v64 + 1e-5)) <= 1e-5
+    n = batch * c
+    assert _maxrel(rm, 0.1 * m64) <= 1e-5 and _maxrel(rv, 0.9 + 0.1 * v64 * n / (n - 1)) <= 1e-5
+    s64 = x.double().cpu() @ w.double().cpu()
+    bound = (c + 8) * 2.0 ** -24 * (x.double().cpu().abs() @ w.double().cpu().abs())
+    assert bool(((s_next.double().cpu() - s64).abs() <= bound + 1e-30).all())
+    # no product: the last hidden layer
+    x2 = torch.empty_like(s)
+    deform.layer_forward(s, bias, csr, gamma, beta, rm.clone(), rv.clone(), True, 0.1, 1e-5, True, None, 0.5, None, x2, mean, invstd)
+    assert _maxrel(x2, torch.relu(y64)) <= 2e-6
+
+
+@pytest.mark.parametrize("mesh,batch", [("uv_sphere_482", 16), ("icosphere_162", 5)])
+def test_one_backward_launch_against_the_separate_operators(gpu, mesh, batch):
+    nv, adj, csr = _mesh(mesh, gpu)
+    torch.manual_seed(4)
+    c = 192
+    shape = (batch, nv, c)
+    dz_up, z, g2 = (torch.randn(*shape, device=gpu) for _ in range(3))
+    wt = torch.randn(c, c, device=gpu) / 14
+    gamma, beta = torch.rand(nv, device=gpu) + 0.5, torch.randn(nv, device=gpu) * 0.2
+    z64 = z.double().cpu()
+    mean64 = z64.mean(dim=(0, 2))
+    var64 = ((z64 - mean64.view(1, -1, 1)) ** 2).mean(dim=(0, 2))
+    mean, invstd = mean64.float().to(gpu), (1.0 / torch.sqrt(var64 + 1e-5)).float().to(gpu)
+    ds, dz, gres = (torch.empty(*shape, device=gpu) for _ in range(3))
+    gbw, gbb = torch.empty(nv, device=gpu), torch.empty(nv, device=gpu)
+    colsum = torch.empty(nv, c, device=gpu)
+    deform.layer_backward(shape, csr, z, gamma, beta, mean, invstd, True, True, 0.5, dz, gbw, gbb, dz_up=dz_up, ds_up=ds, wt_up=wt, g2=g2,
+                          grad_res=gres, colsum=colsum)
+    ds_ref, _ = layers.aggregate_backward(dz_up, csr, 64, layers._ACT_NONE, None, None, False)
+    assert torch.equal(ds, ds_ref)
+    # float64 from here: dX = dS . W^T (wt IS the transposed weight), + g2, residual scale, ReLU mask, BatchNorm backward
+    gx = (ds.double().cpu() @ wt.double().cpu() + g2.double().cpu()) * 0.5
+    assert _maxrel(gres, gx) <= 2e-6
+    m, i = mean.double().cpu().view(1, -1, 1), invstd.double().cpu().view(1, -1, 1)
+    xh = (z64 - m) * i
+    ga, be = gamma.double().cpu().view(1, -1, 1), beta.double().cpu().view(1, -1, 1)
+    # (an element whose normalised value sits within rounding of the ReLU kink may fall on either side in float64: the mask is
+    # formed in fp32, operation by operation as the kernel forms it -- and as the forward launch formed its ReLU)
+    on = ((((z - mean.view(1, -1, 1)) * invstd.view(1, -1, 1)) * gamma.view(1, -1, 1) + beta.view(1, -1, 1)) > 0).cpu()
+    gy = torch.where(on, gx, torch.zeros_like(gx))
+    sg, sgx = gy.sum(dim=(0, 2)), (gy * xh).sum(dim=(0, 2))
+    n = batch * c
+    dz64 = ga * i * (gy - sg.view(1, -1, 1) / n - xh * sgx.view(1, -1, 1) / n)
+    assert _maxrel(gbb, sg) <= 1e-4 and _maxrel(gbw, sgx) <= 1e-4
+    assert _maxrel(dz, dz64) <= 1e-4
+    assert _maxrel(colsum, dz64.sum(dim=0)) <= 1e-4
+    # no product: the gradient of the output is read from memory (+ the second one)
+    g = torch.randn(*shape, device=gpu)
+    dz2 = torch.empty(*shape, device=gpu)
+    deform.layer_backward(shape, csr, z, gamma, beta, mean, invstd, True, False, 0.5, dz2, gbw, gbb, g=g, g2=g2)
+    gy = torch.where(on, (g + g2).double().cpu(), torch.zeros_like(gx))
+    sg, sgx = gy.sum(dim=(0, 2)), (gy * xh).sum(dim=(0, 2))
+    assert _maxrel(dz2, ga * i * (gy - sg.view(1, -1, 1) / n - xh * sgx.view(1, -1, 1) / n)) <= 1e-4
+
+
+def _block64(block, feats, pooled, adj):
+    """models.py:237-297 restated in float64 on the host (dense adjacency, torch ops): returns (features, coords)."""
+    p = {k: v.detach().double().cpu().requires_grad_(v.requires_grad) for k, v in block.named_parameters()}
+    adj = adj.double().cpu()
+
+    def gc(i, x):
+        sup = x @ p["gc%d.weight1" % i][0]
+        k = sup.shape[-1] // 3
+        return torch.cat((adj @ sup[..., :k], sup[..., k:]), dim=-1) + p["gc%d.bias" % i]
+
+    def layer(i, x):
+        y, _, _ = _bn64(gc(i, x), p["bn%d.weight" % i], p["bn%d.bias" % i], 1e-5)
+        return torch.relu(y)
+    f = torch.cat((feats, pooled), dim=-1)
+    x = layer(1, f)
+    x = layer(2, x)
+    f = (f[..., :block.hidden] + x) / 2
+    for i in (3, 5, 7, 9, 11):
+        x = layer(i, f)
+        x = layer(i + 1, x)
+        f = (f + x) / 2
+    x = layer(13, f)
+    f = (f + x) / 2
+    return f, gc(15, f), p
+
+
+@pytest.mark.parametrize("mesh,batch", [("uv_sphere_482", 16), ("icosphere_162", 5)])
+def test_the_fused_block_against_float64_and_against_the_separate_operators(gpu, mesh, batch):
+    import copy
+    nv, adj, csr = _mesh(mesh, gpu)
+    torch.manual_seed(5)
+    block = models.BatchMeshDeformationBlock(3 + 200, nv).to(gpu).train()
+    with torch.no_grad():
+        for i in range(1, 14):
+            getattr(block, "bn%d" % i).weight.uniform_(0.5, 1.5)
+            getattr(block, "bn%d" % i).bias.uniform_(-0.3, 0.3)
+    twin = copy.deepcopy(block)
+    feats = torch.randn(batch, nv, 3, device=gpu)
+    pooled = torch.randn(batch, nv, 200, device=gpu)
+    g_f, g_c = torch.randn(batch, nv, 192, device=gpu), torch.randn(batch, nv, 3, device=gpu)
+
+    def run(blk, fused):
+        deform.enabled = fused
+        try:
+            f, p = feats.clone().requires_grad_(True), pooled.clone().requires_grad_(True)
+            assert deform.serves(blk, f, p, csr) == fused
+            out_f, coords = blk(f, p, adj)
+            ((out_f * g_f).sum() + (coords * g_c).sum()).backward()
+        finally:
+            deform.enabled = True
+        return out_f, coords, f.grad, p.grad
+    out_f, coords, gf, gp = run(block, True)
+    ref_f, ref_c, rgf, rgp = run(twin, False)
+    f64, p64 = feats.double().cpu().requires_grad_(True), pooled.double().cpu().requires_grad_(True)
+    e_f, e_c, params64 = _block64(block, f64, p64, adj)
+    ((e_f * g_f.double().cpu()).sum() + (e_c * g_c.double().cpu()).sum()).backward()
+    # forward: 2e-5 of scale against float64 (the bar of the reference-fixture test of the block)
+    assert _maxrel(out_f, e_f) <= 2e-5 and _maxrel(coords, e_c) <= 2e-5
+    assert _maxrel(out_f, ref_f) <= 2e-5 and _maxrel(coords, ref_c) <= 2e-5
+    # gradients: ReLU kinks + 13 BatchNorms deep, fp32 against float64: the separate operators' own distance from float64 is
+    # the yardstick (the fused launches may not be further away than 3x that, nor than 1e-3 of scale)
+    worst = {}
+    named = dict(block.named_parameters())
+    twin_named = dict(twin.named_parameters())
+    for name, p in named.items():
+        if name.startswith("bn14"):
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0
+            continue
+        e = params64[name].grad
+        err, base = _maxrel(p.grad, e), _maxrel(twin_named[name].grad, e)
+        worst[name] = (err, base)
+        assert err <= max(3 * base, 2e-4), "%s: fused %.2e vs separate %.2e of scale from float64" % (name, err, base)
+    for got, sep, e in ((gf, rgf, f64.grad), (gp, rgp, p64.grad)):
+        assert _maxrel(got, e) <= max(3 * _maxrel(sep, e), 2e-4)
+    for i in range(1, 14):
+        a, b = getattr(block, "bn%d" % i), getattr(twin, "bn%d" % i)
+        assert _maxrel(a.running_mean, b.running_mean) <= 1e-4 and _maxrel(a.running_var, b.running_var) <= 1e-4
+    sd = block.state_dict()
+    assert int(sd["bn1.num_batches_tracked"]) == 1 and int(sd["bn14.num_batches_tracked"]) == 0
+
+
+def test_the_fused_block_replays_inside_a_hip_graph(gpu):
+    nv, adj, csr = _mesh("uv_sphere_482", gpu)
+    torch.manual_seed(6)
+    block = models.BatchMeshDeformationBlock(3 + 197, nv).to(gpu).train()
+    feats = torch.randn(16, nv, 3, device=gpu, requires_grad=True)
+    pooled = torch.randn(16, nv, 197, device=gpu, requires_grad=True)
+    params = list(block.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        feats.grad = pooled.grad = None
+        f, c = block(feats, pooled, adj)
+        (f.sum() + c.sum()).backward()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    eager = [p.grad.clone() for p in params if p.grad is not None] + [feats.grad.clone()]
+    for i in range(1, 14):      # the running statistics move with every step: rewind so that the replay starts where the eager step did
+        getattr(block, "bn%d" % i).running_mean.zero_(), getattr(block, "bn%d" % i).running_var.fill_(1.0)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        step()
+    g.replay()
+    torch.cuda.synchronize()
+    replayed = [p.grad for p in params if p.grad is not None] + [feats.grad]
+    assert len(eager) == len(replayed)
+    for a, b in zip(eager, replayed):
+        assert torch.equal(a, b)          # same launches, fixed reduction orders: bit-reproducible
+
+
+def test_shapes_the_launches_do_not_serve_take_the_separate_operators(gpu):
+    nv, adj, csr = _mesh("icosphere_162", gpu)
+    block = models.BatchMeshDeformationBlock(200, nv).to(gpu).train()
+    narrow = models.BatchMeshDeformationBlock(200, nv, hidden=48).to(gpu).train()
+    f, p = torch.randn(4, nv, 3, device=gpu), torch.randn(4, nv, 197, device=gpu)
+    assert deform.serves(block, f, p, csr)
+    assert not deform.serves(narrow, f, p, csr)                                        # another width
+    assert not deform.serves(block, torch.randn(17, nv, 3, device=gpu), torch.randn(17, nv, 197, device=gpu), csr)   # more than one tile of meshes
+    block.eval()
+    assert not deform.serves(block, f, p, csr)                                         # running statistics: the library route
+    with torch.no_grad():
+        out_f, coords = block(f, p, adj)
+    assert out_f.shape == (4, nv, 192) and coords.shape == (4, nv, 3)
+    block.train()
+    big = torch.randn(17, nv, 3, device=gpu, requires_grad=True)
+    out_f, coords = block(big, torch.randn(17, nv, 197, device=gpu), adj)
+    (out_f.sum() + coords.sum()).backward()
+    assert torch.isfinite(big.grad).all()
