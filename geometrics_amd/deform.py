@@ -29,6 +29,9 @@ RESIDUALS = {2: "lead", 4: 3, 6: 5, 8: 7, 10: 9, 12: 11, 13: 13}
 LAYERS = 13
 
 enabled = True      # tests / A-B timing: False keeps the separate operators
+relu = True         # tests only: False drops the ReLU of every hidden layer (a smooth chain: every launch of the backward can then
+#                     be held to a tight float64 bound -- under ReLU a pre-activation within rounding of zero may fall on either
+#                     side in any two fp32 evaluations and switch a whole unit's term)
 
 
 def serves(block, features, pooled, csr):
@@ -106,10 +109,10 @@ class _HiddenChain(torch.autograd.Function):
             res = None if src is None else (lead if src == "lead" else xs[src - 2])
             nxt = i < L
             layer_forward(s_cur, biases[i - 1], csr, bn_w[i - 1], bn_b[i - 1], stats[i - 1][0], stats[i - 1][1], True, momentum, eps,
-                          True, res, 0.5, zs[i - 1], xs[i - 1], means[i - 1], invstds[i - 1],
+                          relu, res, 0.5, zs[i - 1], xs[i - 1], means[i - 1], invstds[i - 1],
                           w_next=w2[i - 1] if nxt else None, s_out=s_buf[i & 1] if nxt else None, wt_out=wts[i - 1] if nxt else None)
             s_cur = s_buf[i & 1]
-        ctx.csr = csr
+        ctx.csr, ctx.relu = csr, relu
         ctx.save_for_backward(xs, zs, means, invstds, wts, *bn_w, *bn_b)
         out = xs[L - 1]
         return out, _layers._alias(out)
@@ -138,7 +141,7 @@ class _HiddenChain(torch.autograd.Function):
         for i in range(L, 0, -1):
             src = RESIDUALS.get(i)
             grad_res = torch.empty(b, nv, c, **f32) if src is not None else None
-            common = dict(relu=True, has_res=src is not None, scale=0.5, dz=dzs[i - 1], grad_bn_w=g_bnw[i - 1], grad_bn_b=g_bnb[i - 1],
+            common = dict(relu=ctx.relu, has_res=src is not None, scale=0.5, dz=dzs[i - 1], grad_bn_w=g_bnw[i - 1], grad_bn_b=g_bnb[i - 1],
                           grad_res=grad_res, colsum=colsum[i - 1])
             if i == L:
                 layer_backward((b, nv, c), csr, zs[i - 1], bn_w[i - 1], bn_b[i - 1], means[i - 1], invstds[i - 1], g=g_top, g2=g_top2,

@@ -116,8 +116,8 @@ def test_one_backward_launch_against_the_separate_operators(gpu, mesh, batch):
     assert _maxrel(dz2, ga * i * (gy - sg.view(1, -1, 1) / n - xh * sgx.view(1, -1, 1) / n)) <= 1e-4
 
 
-def _block64(block, feats, pooled, adj):
-    """models.py:237-297 restated in float64 on the host (dense adjacency, torch ops): returns (features, coords)."""
+def _block64(block, feats, pooled, adj, relu=True):
+    """models.py:237-297 restated in float64 on the host (dense adjacency, torch ops): returns (features, coords, parameters)."""
     p = {k: v.detach().double().cpu().requires_grad_(v.requires_grad) for k, v in block.named_parameters()}
     adj = adj.double().cpu()
 
@@ -128,7 +128,7 @@ def _block64(block, feats, pooled, adj):
 
     def layer(i, x):
         y, _, _ = _bn64(gc(i, x), p["bn%d.weight" % i], p["bn%d.bias" % i], 1e-5)
-        return torch.relu(y)
+        return torch.relu(y) if relu else y
     f = torch.cat((feats, pooled), dim=-1)
     x = layer(1, f)
     x = layer(2, x)
@@ -142,8 +142,20 @@ def _block64(block, feats, pooled, adj):
     return f, gc(15, f), p
 
 
+def _l2rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm()) / max(float(b.norm()), 1e-30)
+
+
 @pytest.mark.parametrize("mesh,batch", [("uv_sphere_482", 16), ("icosphere_162", 5)])
-def test_the_fused_block_against_float64_and_against_the_separate_operators(gpu, mesh, batch):
+@pytest.mark.parametrize("relu", [False, True])
+def test_the_fused_block_against_float64_and_against_the_separate_operators(gpu, mesh, batch, relu):
+    """relu=False (deform.relu, tests only): the chain without its ReLUs is smooth, and EVERY gradient -- 13 fused backward
+    launches deep -- is held to a max-norm bound against float64.  relu=True: the block as the reference runs it; a
+    pre-activation within rounding of zero falls on either side in any two fp32 evaluations (expected: about one element in
+    the block's 19 M per pass) and switches one unit's term, which moves single entries of a gradient by 1e-3 .. 1e-2 of its
+    scale whatever the implementation -- so there the gradients are held in the L2 norm (a wrong mask, a dropped residual
+    or a transposed tile is an O(1) error in it; one switched unit is ~1e-3), the forward in max-norm as before."""
     import copy
     nv, adj, csr = _mesh(mesh, gpu)
     torch.manual_seed(5)
@@ -158,38 +170,33 @@ def test_the_fused_block_against_float64_and_against_the_separate_operators(gpu,
     g_f, g_c = torch.randn(batch, nv, 192, device=gpu), torch.randn(batch, nv, 3, device=gpu)
 
     def run(blk, fused):
-        deform.enabled = fused
+        deform.enabled, deform.relu = fused, relu
         try:
             f, p = feats.clone().requires_grad_(True), pooled.clone().requires_grad_(True)
             assert deform.serves(blk, f, p, csr) == fused
             out_f, coords = blk(f, p, adj)
             ((out_f * g_f).sum() + (coords * g_c).sum()).backward()
         finally:
-            deform.enabled = True
+            deform.enabled, deform.relu = True, True
         return out_f, coords, f.grad, p.grad
     out_f, coords, gf, gp = run(block, True)
-    ref_f, ref_c, rgf, rgp = run(twin, False)
     f64, p64 = feats.double().cpu().requires_grad_(True), pooled.double().cpu().requires_grad_(True)
-    e_f, e_c, params64 = _block64(block, f64, p64, adj)
+    e_f, e_c, params64 = _block64(block, f64, p64, adj, relu)
     ((e_f * g_f.double().cpu()).sum() + (e_c * g_c.double().cpu()).sum()).backward()
     # forward: 2e-5 of scale against float64 (the bar of the reference-fixture test of the block)
     assert _maxrel(out_f, e_f) <= 2e-5 and _maxrel(coords, e_c) <= 2e-5
-    assert _maxrel(out_f, ref_f) <= 2e-5 and _maxrel(coords, ref_c) <= 2e-5
-    # gradients: ReLU kinks + 13 BatchNorms deep, fp32 against float64: the separate operators' own distance from float64 is
-    # the yardstick (the fused launches may not be further away than 3x that, nor than 1e-3 of scale)
-    worst = {}
     named = dict(block.named_parameters())
-    twin_named = dict(twin.named_parameters())
-    for name, p in named.items():
-        if name.startswith("bn14"):
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0
-            continue
-        e = params64[name].grad
-        err, base = _maxrel(p.grad, e), _maxrel(twin_named[name].grad, e)
-        worst[name] = (err, base)
-        assert err <= max(3 * base, 2e-4), "%s: fused %.2e vs separate %.2e of scale from float64" % (name, err, base)
-    for got, sep, e in ((gf, rgf, f64.grad), (gp, rgp, p64.grad)):
-        assert _maxrel(got, e) <= max(3 * _maxrel(sep, e), 2e-4)
+    pairs = [(n, p.grad, params64[n].grad) for n, p in named.items() if not n.startswith("bn14")]
+    pairs += [("features", gf, f64.grad), ("pooled", gp, p64.grad)]
+    assert all(named[n].grad is None for n in named if n.startswith("bn14"))
+    if not relu:
+        for name, got, want in pairs:
+            assert _maxrel(got, want) <= 5e-5, "%s: %.2e of scale from float64" % (name, _maxrel(got, want))
+        return
+    ref_f, ref_c, rgf, rgp = run(twin, False)          # the separate operators on the same parameters
+    assert _maxrel(out_f, ref_f) <= 2e-5 and _maxrel(coords, ref_c) <= 2e-5
+    for name, got, want in pairs:
+        assert _l2rel(got, want) <= 5e-3, "%s: %.2e from float64 in the L2 norm" % (name, _l2rel(got, want))
     for i in range(1, 14):
         a, b = getattr(block, "bn%d" % i), getattr(twin, "bn%d" % i)
         assert _maxrel(a.running_mean, b.running_mean) <= 1e-4 and _maxrel(a.running_var, b.running_var) <= 1e-4

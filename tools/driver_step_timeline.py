@@ -54,6 +54,17 @@ if n:
     by = rows_ * 192 * 4 * 2 + 482 * 8 * 8
     lines.append("#   zn_aggregate_ell_kernel forward (%d launches): %.1f us for %.1f MB = %.2f TB/s = %.2f of HBM (a latency chain at 7712 rows: "
                  "two dependent gather round trips + launch + drain)" % (n, us, by / 1e6, by / us / 1e6, by / us / 1e6 / 8.0))
+n, us = per("db_fwd_kernel<true>")
+if n:
+    fl, by = 2.0 * rows_ * 192 * 192, rows_ * 192 * 4 * 4 + 192 * 192 * 4
+    lines.append("#   db_fwd_kernel<true> (aggregation + BatchNorm1d(verts) + ReLU + residual + next product in one launch, %d launches): %.1f us; "
+                 "the product alone = %.1f TFLOP/s = %.2f of the fp32 MFMA peak; 23.7 MB of tensors (S in, Z / X' / S' out) = %.2f TB/s"
+                 % (n, us, fl / us / 1e6, fl / us / 1e6 / 157.3, by / us / 1e6))
+n, us = per("db_bwd_kernel<true>")
+if n:
+    fl = 2.0 * rows_ * 192 * 192
+    lines.append("#   db_bwd_kernel<true> (aggregation backward + input-gradient product + BatchNorm backward, %d launches): %.1f us; the "
+                 "product alone = %.1f TFLOP/s = %.2f of the fp32 MFMA peak" % (n, us, fl / us / 1e6, fl / us / 1e6 / 157.3))
 n, us = per("pool_bwd_verts_kernel")
 if n:
     by = maps_bytes + rows_ * 960 * 4
