@@ -119,6 +119,7 @@ _SIGNATURES = {
     "geom_zn_layer_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_zn_layer_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp],
     "geom_deform_layer_fwd_f32": [_vp, _vp],
+    "geom_deform_pack_weights_f32": [_i, _vp, _vp, _vp, _vp],
     "geom_deform_layer_bwd_f32": [_vp, _vp],
 }
 
@@ -132,7 +133,7 @@ class DeformFwd(ctypes.Structure):
                 ("training", _i), ("momentum", _f), ("eps", _f), ("relu", _i),
                 ("res", _vp), ("res_ld", _i), ("scale", _f),
                 ("z_out", _vp), ("x_out", _vp), ("save_mean", _vp), ("save_invstd", _vp),
-                ("w_next", _vp), ("s_out", _vp), ("wt_out", _vp), ("vpx", _i)]
+                ("w_next", _vp), ("s_out", _vp), ("vpx", _i)]
 
 
 class DeformBwd(ctypes.Structure):

@@ -82,23 +82,28 @@ __device__ __forceinline__ void db_sum2(float &a, float &b, float *red)
     b = ((red[1] + red[3]) + red[5]) + red[7];
 }
 
-// the wave's 192 x 48 slice of a [192][192] row-major matrix: lane (x, g), step (jp, c): k = 48 g + 4 jp + c, columns
-// 48 wave + 3 x .. + 2 (zn_stack.hip's layout)
-__device__ __forceinline__ void db_load_slice(f3u (&bw)[12][4], const float *m, int wave, int x, int g)
+// The wave's 192 x 48 slice of a weight, from the PACKED copy geom_deform_pack_weights_f32 makes once per step: element
+// e = (4 jp + c) * 3 + u of lane (x, g) of wave w is W[k = 48 g + 4 jp + c][48 w + 3 x + u] (zn_stack.hip's operand layout),
+// stored [wave][e / 4][lane][e % 4] -- every load instruction of a wave reads 1 KB of consecutive bytes (36 b128 loads per
+// lane instead of 48 12-byte loads whose 192-byte runs straddle cache lines: 1.67 x fewer L2 bytes -- all 482 workgroups
+// read the same 147 KB, the L2 of an XCD is what they queue at).
+struct DbSlice {
+    f32x4 q[36];
+    __device__ __forceinline__ float at(int jp, int c, int u) const { const int e = (4 * jp + c) * 3 + u; return q[e >> 2][e & 3]; }
+};
+__device__ __forceinline__ void db_load_slice(DbSlice &bw, const float *packed, int wave, int lane)
 {
-    const __amdgpu_buffer_rsrc_t r_b = db_rsrc(m, (int64_t)DB_C * DB_C * 4);
-    const unsigned b0 = ((unsigned)(48 * g) * DB_C + (unsigned)(wave * 48 + 3 * x)) * 4u;
+    const __amdgpu_buffer_rsrc_t r_b = db_rsrc(packed, (int64_t)DB_C * DB_C * 4);
+    const unsigned b0 = ((unsigned)(wave * 36) * 64u + (unsigned)lane) * 16u;
 #pragma unroll
-    for (int jp = 0; jp < 12; ++jp)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(r_b, b0 + (unsigned)(4 * jp + c) * DB_C * 4u, 0, 0);
-            bw[jp][c] = f3u{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z)};
-        }
+    for (int i = 0; i < 36; ++i) {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r_b, b0 + (unsigned)i * 1024u, 0, 0);
+        bw.q[i] = (f32x4){__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+    }
 }
 
 // C tile [16 rows][192] = panel [16][192] . slice, into the staging tile (natural [row][col] layout, pitch DB_LDC)
-__device__ __forceinline__ void db_product(const f3u (&bw)[12][4], const float *panel, float *stage, int wave, int x, int g)
+__device__ __forceinline__ void db_product(const DbSlice &bw, const float *panel, float *stage, int wave, int x, int g)
 {
     const float *pa = panel + g * DB_SUB + x * DB_LDR;
     f32x4 acc[3];
@@ -112,9 +117,9 @@ __device__ __forceinline__ void db_product(const f3u (&bw)[12][4], const float *
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[jp][c].x, af[c], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[jp][c].y, af[c], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[jp][c].z, af[c], acc[2], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.at(jp, c, 0), af[c], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.at(jp, c, 1), af[c], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.at(jp, c, 2), af[c], acc[2], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         af = an;
@@ -130,28 +135,37 @@ __device__ __forceinline__ void db_product(const f3u (&bw)[12][4], const float *
     for (int v = 0; v < 3; ++v) *reinterpret_cast<f32x4 *>(dst + 4 * v) = (f32x4){e[4 * v], e[4 * v + 1], e[4 * v + 2], e[4 * v + 3]};
 }
 
-// the transposed copy of the slice a wave holds (workgroup 0 of the forward launch: what the backward loads as W^T)
-__device__ __forceinline__ void db_store_transposed(const f3u (&bw)[12][4], float *wt, int wave, int x, int g)
+// geom_deform_pack_weights_f32: thread = one element of one packed copy (2 * count copies of 36 864 floats)
+struct DbPackArgs {
+    const float *w[GEOM_DEFORM_MAX_PACK];
+    float *fwd, *bwd;
+    int count;
+};
+__global__ __launch_bounds__(256) void db_pack_kernel(DbPackArgs a)
 {
-    const int jc = wave * 48 + 3 * x;
-#pragma unroll
-    for (int jp = 0; jp < 12; ++jp)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int k = 48 * g + 4 * jp + c;
-            wt[(int64_t)(jc + 0) * DB_C + k] = bw[jp][c].x;
-            wt[(int64_t)(jc + 1) * DB_C + k] = bw[jp][c].y;
-            wt[(int64_t)(jc + 2) * DB_C + k] = bw[jp][c].z;
-        }
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int m = idx / (DB_C * DB_C), r = idx - m * (DB_C * DB_C);
+    const int layer = m >> 1, dir = m & 1;
+    if (layer >= a.count) return;
+    const int wave = r / 9216, rem = r - wave * 9216;
+    const int i = rem >> 8, lane = (rem & 255) >> 2, t = rem & 3;
+    const int e = 4 * i + t, jp = e / 12, c = (e / 3) & 3, u = e % 3;
+    const int g = lane >> 4, x = lane & 15;
+    const int k = 48 * g + 4 * jp + c, col = 48 * wave + 3 * x + u;
+    const float *w = a.w[layer];
+    float *out = dir ? a.bwd : a.fwd;
+    if (out) out[(size_t)layer * DB_C * DB_C + r] = dir ? w[col * DB_C + k] : w[k * DB_C + col]; // bwd: the slice of W^T
 }
 
 // The aggregated float4 of thread (row rl, group j) of vertex v: sum over the vertex's table entries, then its CSR tail, of
 // val * src[mesh rl][neighbour][4 j ..] -- the order and arithmetic of zn_aggregate_ell_kernel (a padded slot adds -0.0: no
 // value changes, signed zeros included).  `rowbase` = byte offset of mesh rl's first row, DB_OOB-safe: rows beyond the batch
 // pass mesh_on = false and read zeros.
+template <bool SLICE>
 __device__ __forceinline__ float4 db_aggregate(__amdgpu_buffer_rsrc_t r_src, bool mesh_on, unsigned rowbase, int v, int c0,
                                                const int *ell_col, const float *ell_val, const int *over_ptr, const int *over_col,
-                                               const float *over_val, float4 *own, int n_own)
+                                               const float *over_val, float4 *own, int n_own, DbSlice &bw, const float *packed,
+                                               int wave, int lane)
 {
     // round trip 1: the vertex's table entries (the same for every thread of the workgroup)
     const int4 ci0 = *reinterpret_cast<const int4 *>(ell_col + (size_t)v * DB_W), ci1 = *reinterpret_cast<const int4 *>(ell_col + (size_t)v * DB_W + 4);
@@ -171,6 +185,9 @@ __device__ __forceinline__ float4 db_aggregate(__amdgpu_buffer_rsrc_t r_src, boo
 #pragma unroll
     for (int i = 0; i < 2; ++i)
         if (i < n_own) own[i] = db_ld4(r_src, mesh_on ? own_off + 4 * DB_K * (i + 1) : DB_OOB);
+    __builtin_amdgcn_sched_barrier(0);
+    if (SLICE) db_load_slice(bw, packed, wave, lane); // behind the gathers (in-order memory counter: see the callers)
+    __builtin_amdgcn_sched_barrier(0);
     float4 facc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int n = 0; n < DB_W; ++n) {
@@ -217,9 +234,6 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_fwd_kernel(geom_deform_fwd a
     const int x = lane & 15, g = lane >> 4; // matrix-core coordinates
     const int rl = tid >> 4, j = tid & 15;  // batch row (mesh) and float4 group of the gather / BatchNorm thread
     const int c0 = 4 * j;
-    f3u bw[12][4];
-    if (PRODUCT) db_load_slice(bw, a.w_next, wave, x, g); // requested first: lands under the two gather round trips
-
     const bool mesh_on = rl < a.b;
     const int64_t op_bytes = (int64_t)a.b * a.nv * DB_C * 4;
     const __amdgpu_buffer_rsrc_t r_src = db_rsrc(a.s_in, op_bytes);
@@ -241,8 +255,13 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_fwd_kernel(geom_deform_fwd a
 #pragma unroll
         for (int i = 0; i < 3; ++i) rv[i] = db_ld4(r_res, mesh_on ? roff + 4 * DB_K * i : DB_OOB);
     }
+    // The weight slice is requested BEHIND the gathers: the vector-memory counter retires in order, so a wave that asked for
+    // its 36 KB of weights first would wait for them in front of every gather (the table entries come by scalar loads, which
+    // have a counter of their own); in this order the statistics run while the slice is still on its way.
+    DbSlice bw;
     float4 z[3];
-    z[0] = db_aggregate(r_src, mesh_on, rowbase, v, c0, a.ell_col, a.ell_val, a.over_ptr, a.over_col, a.over_val, &z[1], 2);
+    z[0] = db_aggregate<PRODUCT>(r_src, mesh_on, rowbase, v, c0, a.ell_col, a.ell_val, a.over_ptr, a.over_col, a.over_val, &z[1], 2, bw,
+                                 a.w_next, wave, lane);
 #pragma unroll
     for (int i = 0; i < 3; ++i) z[i].x += bias4[i].x, z[i].y += bias4[i].y, z[i].z += bias4[i].z, z[i].w += bias4[i].w;
 
@@ -296,7 +315,6 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_fwd_kernel(geom_deform_fwd a
 
     // ---- the next layer's product on the tile
     db_to_panel(lds, rl, c0, xo);
-    if (a.wt_out && blockIdx.x == 0) db_store_transposed(bw, a.wt_out, wave, x, g);
     __syncthreads();
     float *stage = lds + DB_PANEL;
     db_product(bw, lds, stage, wave, x, g);
@@ -321,9 +339,6 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_kernel(geom_deform_bwd a
     const int x = lane & 15, g = lane >> 4;
     const int rl = tid >> 4, j = tid & 15;
     const int c0 = 4 * j;
-    f3u bw[12][4];
-    if (PRODUCT) db_load_slice(bw, a.wt_up, wave, x, g);
-
     const bool mesh_on = rl < a.b;
     const int64_t op_bytes = (int64_t)a.b * a.nv * DB_C * 4;
     const unsigned rowbase = (unsigned)rl * (unsigned)a.nv * (DB_C * 4);
@@ -345,7 +360,9 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_kernel(geom_deform_bwd a
         // ---- aggregation backward of the layer above: G = [A^T . dZ_up[:, :64] | dZ_up[:, 64:]]
         const __amdgpu_buffer_rsrc_t r_src = db_rsrc(a.dz_up, op_bytes), r_ds = db_rsrc(a.ds_up, op_bytes);
         float4 gs[3];
-        gs[0] = db_aggregate(r_src, mesh_on, rowbase, v, c0, a.ell_col_t, a.ell_val_t, a.over_ptr_t, a.over_col_t, a.over_val_t, &gs[1], 2);
+        DbSlice bw;
+        gs[0] = db_aggregate<true>(r_src, mesh_on, rowbase, v, c0, a.ell_col_t, a.ell_val_t, a.over_ptr_t, a.over_col_t, a.over_val_t, &gs[1], 2,
+                                   bw, a.wt_up, wave, lane);
 #pragma unroll
         for (int i = 0; i < 3; ++i) db_st4(r_ds, at(i), gs[i]); // the layer above's weight gradient reads it (X^T . G)
         db_to_panel(lds, rl, c0, gs);                           // (rows beyond the batch read zeros: zero rows of the tile)
@@ -439,7 +456,7 @@ extern "C" int geom_deform_layer_fwd_f32(const geom_deform_fwd *args, void *stre
     if (a.over_ptr && (!a.over_col || !a.over_val)) return GEOM_EINVAL;
     if (a.res && (a.res_ld < DB_C || (a.res_ld & 3))) return GEOM_EINVAL;
     if (!db_aligned16(a.s_in) || !db_aligned16(a.ell_col) || !db_aligned16(a.ell_val) || !db_aligned16(a.x_out) || !db_aligned16(a.z_out) ||
-        !db_aligned16(a.s_out) || !db_aligned16(a.bias) || !db_aligned16(a.res) || ((uintptr_t)a.w_next & 3) || ((uintptr_t)a.wt_out & 3))
+        !db_aligned16(a.s_out) || !db_aligned16(a.bias) || !db_aligned16(a.res) || !db_aligned16(a.w_next))
         return GEOM_EINVAL;
     if (!a.res) a.scale = 1.f;
     a.vpx = (a.nv + 7) / 8;
@@ -463,7 +480,7 @@ extern "C" int geom_deform_layer_bwd_f32(const geom_deform_bwd *args, void *stre
     if (a.over_ptr_t && (!a.over_col_t || !a.over_val_t)) return GEOM_EINVAL;
     if (!db_aligned16(a.dz_up) || !db_aligned16(a.ell_col_t) || !db_aligned16(a.ell_val_t) || !db_aligned16(a.ds_up) || !db_aligned16(a.g) ||
         !db_aligned16(a.g2) || !db_aligned16(a.z) || !db_aligned16(a.grad_res) || !db_aligned16(a.dz) || !db_aligned16(a.colsum) ||
-        ((uintptr_t)a.wt_up & 3))
+        !db_aligned16(a.wt_up))
         return GEOM_EINVAL;
     if (!a.has_res) a.scale = 1.f;
     a.vpx = (a.nv + 7) / 8;
@@ -471,5 +488,24 @@ extern "C" int geom_deform_layer_bwd_f32(const geom_deform_bwd *args, void *stre
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (product) hipLaunchKernelGGL((db_bwd_kernel<true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((db_bwd_kernel<false>), grid, block, 0, s, a);
+    return geom::launch_status();
+}
+
+// fwd[l] / bwd[l] (each count x 36 864 floats, either may be NULL) = the register-slice order of w[l] / w[l]^T that
+// geom_deform_layer_fwd_f32 (w_next) / geom_deform_layer_bwd_f32 (wt_up) read; w = HOST array of count <= GEOM_DEFORM_MAX_PACK
+// device pointers to [192,192] row-major matrices.  One launch for all layers of a block, once per step.
+extern "C" int geom_deform_pack_weights_f32(int count, const float *const *w, float *fwd, float *bwd, void *stream)
+{
+    if (count < 0 || count > GEOM_DEFORM_MAX_PACK) return GEOM_EINVAL;
+    if (count == 0 || (!fwd && !bwd)) return 0;
+    if (!w || !db_aligned16(fwd) || !db_aligned16(bwd)) return GEOM_EINVAL;
+    DbPackArgs a{};
+    for (int i = 0; i < count; ++i) {
+        if (!w[i] || ((uintptr_t)w[i] & 3)) return GEOM_EINVAL;
+        a.w[i] = w[i];
+    }
+    a.fwd = fwd, a.bwd = bwd, a.count = count;
+    const int total = count * 2 * DB_C * DB_C;
+    hipLaunchKernelGGL(db_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return geom::launch_status();
 }

@@ -55,22 +55,38 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def pack_weights(weights):
+    """(fwd, bwd) [len(weights), 36864] each: every [192,192] weight (and its transpose) in the order a wave of the layer
+    launches keeps its slice in registers -- ONE launch for all layers of a block (geom_deform_pack_weights_f32)."""
+    n = len(weights)
+    w2 = [w.reshape(192, 192) if w.is_contiguous() else w.reshape(192, 192).contiguous() for w in weights]
+    dev = w2[0].device
+    fwd = torch.empty(n, 192 * 192, dtype=torch.float32, device=dev)
+    bwd = torch.empty(n, 192 * 192, dtype=torch.float32, device=dev)
+    ptrs = (ctypes.c_void_p * n)(*[w.data_ptr() for w in w2])
+    with torch.cuda.device(dev):
+        _lib.call("geom_deform_pack_weights_f32", n, ptrs, fwd.data_ptr(), bwd.data_ptr())
+    return fwd, bwd
+
+
 def layer_forward(s_in, bias, csr, bn_w, bn_b, run_mean, run_var, training, momentum, eps, relu, res, scale, z_out, x_out,
-                  save_mean, save_invstd, w_next=None, s_out=None, wt_out=None):
-    """One forward launch (geom_deform_layer_fwd_f32); see include/geom_hip.h for the operands."""
+                  save_mean, save_invstd, w_next=None, s_out=None):
+    """One forward launch (geom_deform_layer_fwd_f32); w_next = the next layer's weight PACKED (pack_weights()[0][l]); see
+    include/geom_hip.h for the operands."""
     b, nv, c = s_in.shape
     over = csr.over or (None, None, None)
     a = _lib.DeformFwd(b, nv, c, 64, csr.ell_w, _p(s_in), _p(bias), _p(csr.ell_col), _p(csr.ell_val), _p(over[0]), _p(over[1]),
                        _p(over[2]), _p(bn_w), _p(bn_b), _p(run_mean), _p(run_var), int(training), float(momentum), float(eps),
                        int(relu), _p(res), res.stride(1) if res is not None else 0, float(scale), _p(z_out), _p(x_out),
-                       _p(save_mean), _p(save_invstd), _p(w_next), _p(s_out), _p(wt_out), 0)
+                       _p(save_mean), _p(save_invstd), _p(w_next), _p(s_out), 0)
     with torch.cuda.device(s_in.device):
         _lib.call("geom_deform_layer_fwd_f32", ctypes.addressof(a))
 
 
 def layer_backward(shape, csr, z, bn_w, bn_b, save_mean, save_invstd, relu, has_res, scale, dz, grad_bn_w, grad_bn_b,
                    dz_up=None, ds_up=None, wt_up=None, g=None, g2=None, grad_res=None, colsum=None):
-    """One backward launch (geom_deform_layer_bwd_f32)."""
+    """One backward launch (geom_deform_layer_bwd_f32); wt_up = the layer above's weight, TRANSPOSED and packed
+    (pack_weights()[1][l])."""
     b, nv, c = shape
     over = csr.over_t or (None, None, None)
     a = _lib.DeformBwd(b, nv, c, 64, csr.ell_w, _p(dz_up), _p(csr.ell_col_t), _p(csr.ell_val_t), _p(over[0]), _p(over[1]),
@@ -100,17 +116,16 @@ class _HiddenChain(torch.autograd.Function):
         xs = torch.empty(L, b, nv, c, **f32)          # xs[i - 1] = X_{i+1}, the output of layer i
         zs = torch.empty(L, b, nv, c, **f32)          # zs[i - 1] = Z_i, what BN_i normalised
         means, invstds = torch.empty(L, nv, **f32), torch.empty(L, nv, **f32)
-        wts = torch.empty(L - 1, c, c, **f32)         # wts[i - 1] = W_{i+1} transposed
         s_buf = (torch.empty(b, nv, c, **f32), torch.empty(b, nv, c, **f32))
         s_cur = s1
-        w2 = [w.reshape(c, c) if w.is_contiguous() else w.reshape(c, c).contiguous() for w in weights]
+        w2, wts = pack_weights(weights)               # w2[i - 1] / wts[i - 1] = W_{i+1} / its transpose, in register-slice order
         for i in range(1, L + 1):
             src = RESIDUALS.get(i)
             res = None if src is None else (lead if src == "lead" else xs[src - 2])
             nxt = i < L
             layer_forward(s_cur, biases[i - 1], csr, bn_w[i - 1], bn_b[i - 1], stats[i - 1][0], stats[i - 1][1], True, momentum, eps,
                           relu, res, 0.5, zs[i - 1], xs[i - 1], means[i - 1], invstds[i - 1],
-                          w_next=w2[i - 1] if nxt else None, s_out=s_buf[i & 1] if nxt else None, wt_out=wts[i - 1] if nxt else None)
+                          w_next=w2[i - 1] if nxt else None, s_out=s_buf[i & 1] if nxt else None)
             s_cur = s_buf[i & 1]
         ctx.csr, ctx.relu = csr, relu
         ctx.save_for_backward(xs, zs, means, invstds, wts, *bn_w, *bn_b)

@@ -378,12 +378,13 @@ int geom_zn_layer_bwd_f32(int b, int nv, int c, int k, int ell_w, const int *ell
  *     z_out = [A . s_in[:, :k] | s_in[:, k:]] + bias                 (the bits of geom_zn_gcn_aggregate_ell_fwd_f32, act 0)
  *     x_out = relu?(BatchNorm_v(z_out)) ; with res: (res + .) * scale  (nn.BatchNorm1d(verts) semantics of geom_vertex_bn_fwd_f32:
  *             training: batch statistics, biased variance, running stats updated with the unbiased one; else running stats)
- *     s_out = x_out . w_next            (w_next [192,192] row-major; NULL: no product -- the last hidden layer)
- *     wt_out (optional) [192,192] = w_next transposed -- what geom_deform_layer_bwd_f32 takes as wt_up.
+ *     s_out = x_out . w_next            (w_next: the next layer's weight in the register-slice order
+ *                                        geom_deform_pack_weights_f32 writes as fwd[l]; NULL: no product -- the last hidden layer)
  * geom_deform_layer_bwd_f32:  (dz_up != NULL)
  *     ds_up = [A^T . dz_up[:, :k] | dz_up[:, k:]]                    (aggregation backward of the layer ABOVE; its weight
  *                                                                     gradient is x^T . ds_up)
- *     g     = ds_up . wt_up   (+ g2 if given)                         (gradient of THIS layer's output x_out)
+ *     g     = ds_up . W_up^T  (+ g2 if given)                         (gradient of THIS layer's output x_out; wt_up = the packed
+ *                                                                     bwd[l] copy of W_up from geom_deform_pack_weights_f32)
  *   (dz_up == NULL: g is read from memory instead, + g2)
  *     with has_res: g *= scale, grad_res = g (the residual's gradient);  relu: g masked where BatchNorm_v(z) <= 0
  *     dz = BatchNorm_v backward(g; z, save_mean, save_invstd, bn_w);  grad_bn_w[v] / grad_bn_b[v] = the vertex's sums
@@ -401,7 +402,7 @@ typedef struct geom_deform_fwd {
     int relu;
     const float *res; int res_ld; float scale;                  /* optional residual [b,nv,res_ld >= 192] */
     float *z_out, *x_out, *save_mean, *save_invstd;
-    const float *w_next; float *s_out, *wt_out;
+    const float *w_next; float *s_out;
     int vpx;
 } geom_deform_fwd;
 typedef struct geom_deform_bwd {
@@ -416,6 +417,11 @@ typedef struct geom_deform_bwd {
     float *grad_res, *dz, *grad_bn_w, *grad_bn_b, *colsum;
     int vpx;
 } geom_deform_bwd;
+#define GEOM_DEFORM_MAX_PACK 16
+/* fwd[l] / bwd[l] ([count, 36864] floats each; either may be NULL): w[l] / w[l]^T ([192,192] row-major device matrices, `w` a
+ * HOST array of count <= GEOM_DEFORM_MAX_PACK pointers) in the order a wave of the layer launches keeps its weight slice in
+ * registers; one launch for all layers of a block, once per step (the weights change with every optimiser step). */
+int geom_deform_pack_weights_f32(int count, const float *const *w, float *fwd, float *bwd, void *stream);
 int geom_deform_layer_fwd_f32(const geom_deform_fwd *args, void *stream);
 int geom_deform_layer_bwd_f32(const geom_deform_bwd *args, void *stream);
 

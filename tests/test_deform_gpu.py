@@ -48,13 +48,11 @@ def test_one_forward_launch_against_the_separate_operators(gpu, mesh, batch):
     rm, rv = torch.zeros(nv, device=gpu), torch.ones(nv, device=gpu)
     z, x, s_next = (torch.empty_like(s) for _ in range(3))
     mean, invstd = torch.empty(nv, device=gpu), torch.empty(nv, device=gpu)
-    wt = torch.empty(c, c, device=gpu)
-    deform.layer_forward(s, bias, csr, gamma, beta, rm, rv, True, 0.1, 1e-5, True, res, 0.5, z, x, mean, invstd, w_next=w, s_out=s_next,
-                         wt_out=wt)
+    packed, _ = deform.pack_weights([w])
+    deform.layer_forward(s, bias, csr, gamma, beta, rm, rv, True, 0.1, 1e-5, True, res, 0.5, z, x, mean, invstd, w_next=packed[0], s_out=s_next)
     # aggregation: the bits of the stand-alone operator
     z_ref = layers.zero_n_aggregate(s, adj, bias, 64, None)
     assert torch.equal(z, z_ref)
-    assert torch.equal(wt, w.t().contiguous())
     # BatchNorm + ReLU + residual average, and the product, against float64
     y64, m64, v64 = _bn64(z.double().cpu(), gamma.double().cpu(), beta.double().cpu(), 1e-5)
     x64 = (res.double().cpu() + torch.relu(y64)) * 0.5
@@ -87,8 +85,9 @@ def test_one_backward_launch_against_the_separate_operators(gpu, mesh, batch):
     ds, dz, gres = (torch.empty(*shape, device=gpu) for _ in range(3))
     gbw, gbb = torch.empty(nv, device=gpu), torch.empty(nv, device=gpu)
     colsum = torch.empty(nv, c, device=gpu)
-    deform.layer_backward(shape, csr, z, gamma, beta, mean, invstd, True, True, 0.5, dz, gbw, gbb, dz_up=dz_up, ds_up=ds, wt_up=wt, g2=g2,
-                          grad_res=gres, colsum=colsum)
+    _, packed_t = deform.pack_weights([wt.t().contiguous()])      # the launch reads the layer's weight transposed, packed
+    deform.layer_backward(shape, csr, z, gamma, beta, mean, invstd, True, True, 0.5, dz, gbw, gbb, dz_up=dz_up, ds_up=ds, wt_up=packed_t[0],
+                          g2=g2, grad_res=gres, colsum=colsum)
     ds_ref, _ = layers.aggregate_backward(dz_up, csr, 64, layers._ACT_NONE, None, None, False)
     assert torch.equal(ds, ds_ref)
     # float64 from here: dX = dS . W^T (wt IS the transposed weight), + g2, residual scale, ReLU mask, BatchNorm backward
@@ -257,3 +256,21 @@ def test_shapes_the_launches_do_not_serve_take_the_separate_operators(gpu):
     out_f, coords = block(big, torch.randn(17, nv, 197, device=gpu), adj)
     (out_f.sum() + coords.sum()).backward()
     assert torch.isfinite(big.grad).all()
+
+
+def test_packed_weight_slices_hold_the_matrix_and_its_transpose(gpu):
+    """geom_deform_pack_weights_f32: [wave][e / 4][lane][e % 4] with element e = (4 jp + c) * 3 + u of lane (x, g) =
+    W[48 g + 4 jp + c][48 wave + 3 x + u] (and the same of W^T): a permutation of the matrix, checked index by index."""
+    torch.manual_seed(8)
+    ws = [torch.randn(1, 192, 192, device=gpu), torch.randn(192, 192, device=gpu)]
+    fwd, bwd = deform.pack_weights(ws)
+    r = np.arange(192 * 192)
+    wave, rem = r // 9216, r % 9216
+    i, lane, t = rem >> 8, (rem & 255) >> 2, rem & 3
+    e = 4 * i + t
+    jp, c, u = e // 12, (e // 3) & 3, e % 3
+    g, x = lane >> 4, lane & 15
+    k, col = 48 * g + 4 * jp + c, 48 * wave + 3 * x + u
+    for n, w in enumerate(ws):
+        m = w.reshape(192, 192).cpu().numpy()
+        assert np.array_equal(fwd[n].cpu().numpy(), m[k, col]) and np.array_equal(bwd[n].cpu().numpy(), m[col, k])
