@@ -128,7 +128,7 @@ class DeformFwd(ctypes.Structure):
     """struct geom_deform_fwd (include/geom_hip.h): a hidden layer of the deformation block, forward."""
     _fields_ = [("b", _i), ("nv", _i), ("c", _i), ("k", _i), ("ell_w", _i),
                 ("s_in", _vp), ("bias", _vp), ("ell_col", _vp), ("ell_val", _vp),
-                ("over_ptr", _vp), ("over_col", _vp), ("over_val", _vp),
+                ("tail_col", _vp), ("tail_val", _vp),
                 ("bn_w", _vp), ("bn_b", _vp), ("run_mean", _vp), ("run_var", _vp),
                 ("training", _i), ("momentum", _f), ("eps", _f), ("relu", _i),
                 ("res", _vp), ("res_ld", _i), ("scale", _f),
@@ -140,7 +140,7 @@ class DeformBwd(ctypes.Structure):
     """struct geom_deform_bwd (include/geom_hip.h): a hidden layer of the deformation block, backward."""
     _fields_ = [("b", _i), ("nv", _i), ("c", _i), ("k", _i), ("ell_w", _i),
                 ("dz_up", _vp), ("ell_col_t", _vp), ("ell_val_t", _vp),
-                ("over_ptr_t", _vp), ("over_col_t", _vp), ("over_val_t", _vp),
+                ("tail_col_t", _vp), ("tail_val_t", _vp),
                 ("ds_up", _vp), ("wt_up", _vp), ("g", _vp), ("g2", _vp),
                 ("z", _vp), ("bn_w", _vp), ("bn_b", _vp), ("save_mean", _vp), ("save_invstd", _vp),
                 ("relu", _i), ("has_res", _i), ("scale", _f),

@@ -36,6 +36,7 @@ constexpr int DB_THREADS = 256;
 constexpr int DB_C = 192;            // layer width
 constexpr int DB_K = 64;             // aggregated columns (split 3)
 constexpr int DB_W = 8;              // neighbour-table width
+constexpr int DB_TAIL = GEOM_DEFORM_TAIL; // width of the tail table (entries of a row beyond the neighbour table)
 constexpr int DB_LDR = 52;           // floats per (quarter, row) line of the operand panel: 48 used, pitch 13 x 16 B
 constexpr int DB_SUB = 16 * DB_LDR;  // one k-quarter of the panel
 constexpr int DB_PANEL = 4 * DB_SUB;
@@ -43,6 +44,20 @@ constexpr int DB_LDC = DB_C + 4;     // row pitch of the output staging tile
 constexpr int DB_CST = 16 * DB_LDC;
 constexpr int DB_RED = 16;           // floats of reduction scratch
 constexpr unsigned DB_OOB = 0x80000000u;
+
+#ifdef DB_PROBE_STAMPS
+// probe build (tools/probe/db_stamps.sh): shader-clock stamps of wave 0 of every workgroup at the phase boundaries
+constexpr int DB_STAMP_SLOTS = 16;
+__device__ unsigned long long db_stamps[1024 * DB_STAMP_SLOTS];
+#define DB_STAMP(i)                                                                                            \
+    do {                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (threadIdx.x == 0) db_stamps[blockIdx.x * DB_STAMP_SLOTS + (i)] = __builtin_amdgcn_s_memtime();     \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    } while (0)
+#else
+#define DB_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t db_rsrc(const void *p, int64_t bytes)
 {
@@ -159,19 +174,27 @@ __global__ __launch_bounds__(256) void db_pack_kernel(DbPackArgs a)
 
 // The aggregated float4 of thread (row rl, group j) of vertex v: sum over the vertex's table entries, then its CSR tail, of
 // val * src[mesh rl][neighbour][4 j ..] -- the order and arithmetic of zn_aggregate_ell_kernel (a padded slot adds -0.0: no
-// value changes, signed zeros included).  `rowbase` = byte offset of mesh rl's first row, DB_OOB-safe: rows beyond the batch
-// pass mesh_on = false and read zeros.
+// value changes, signed zeros included).  `rowbase` = byte offset of mesh rl's first row; rows beyond the batch pass
+// mesh_on = false and read zeros.
+// The tail (a vertex with more entries than the table: the 33-entry poles of 482.obj) comes as a second, 32-wide table row
+// [nv][DB_TAIL] (-1 = padding) that lanes 0..31 of every wave load with ONE vector load in the round trip of the table's
+// scalar loads, so a pole's extra neighbour rows are requested TOGETHER with its table rows: the launch ends with its slowest
+// workgroup, and a pole that walked its tail eight entries per dependent round trip took 3 x the time of every other vertex
+// (26 000 cycles in the gather phase against 8 500: tools/probe/db_stamps.py).
 template <bool SLICE>
 __device__ __forceinline__ float4 db_aggregate(__amdgpu_buffer_rsrc_t r_src, bool mesh_on, unsigned rowbase, int v, int c0,
-                                               const int *ell_col, const float *ell_val, const int *over_ptr, const int *over_col,
-                                               const float *over_val, float4 *own, int n_own, DbSlice &bw, const float *packed,
-                                               int wave, int lane)
+                                               const int *ell_col, const float *ell_val, const int *tail_col, const float *tail_val,
+                                               float4 *own, DbSlice &bw, const float *packed, int wave, int lane)
 {
-    // round trip 1: the vertex's table entries (the same for every thread of the workgroup)
+    // round trip 1: the vertex's table entries (scalar loads: the same for every thread of the workgroup) + its tail row
+    int tcol = -1;
+    float tval = 0.f;
+    if (tail_col) {
+        tcol = tail_col[(size_t)v * DB_TAIL + (lane & (DB_TAIL - 1))];
+        tval = tail_val[(size_t)v * DB_TAIL + (lane & (DB_TAIL - 1))];
+    }
     const int4 ci0 = *reinterpret_cast<const int4 *>(ell_col + (size_t)v * DB_W), ci1 = *reinterpret_cast<const int4 *>(ell_col + (size_t)v * DB_W + 4);
     const float4 wi0 = *reinterpret_cast<const float4 *>(ell_val + (size_t)v * DB_W), wi1 = *reinterpret_cast<const float4 *>(ell_val + (size_t)v * DB_W + 4);
-    int e0 = 0, e1 = 0;
-    if (over_ptr) e0 = over_ptr[v], e1 = over_ptr[v + 1];
     const int nb[DB_W] = {ci0.x, ci0.y, ci0.z, ci0.w, ci1.x, ci1.y, ci1.z, ci1.w};
     const float wv[DB_W] = {wi0.x, wi0.y, wi0.z, wi0.w, wi1.x, wi1.y, wi1.z, wi1.w};
     // round trip 2: the neighbour rows + the thread's own pass-through elements
@@ -183,35 +206,42 @@ __device__ __forceinline__ float4 db_aggregate(__amdgpu_buffer_rsrc_t r_src, boo
     }
     const unsigned own_off = rowbase + (unsigned)v * (DB_C * 4) + 4 * c0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-        if (i < n_own) own[i] = db_ld4(r_src, mesh_on ? own_off + 4 * DB_K * (i + 1) : DB_OOB);
-    __builtin_amdgcn_sched_barrier(0);
-    if (SLICE) db_load_slice(bw, packed, wave, lane); // behind the gathers (in-order memory counter: see the callers)
-    __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < 2; ++i) own[i] = db_ld4(r_src, mesh_on ? own_off + 4 * DB_K * (i + 1) : DB_OOB);
     float4 facc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int n = 0; n < DB_W; ++n) {
-        const bool in = nb[n] >= 0;
-        const float tx = wv[n] * sv[n].x, ty = wv[n] * sv[n].y, tz = wv[n] * sv[n].z, tw = wv[n] * sv[n].w;
-        facc.x += in ? tx : -0.0f, facc.y += in ? ty : -0.0f, facc.z += in ? tz : -0.0f, facc.w += in ? tw : -0.0f;
-    }
-    for (int e = e0; e < e1; e += DB_W) { // a vertex with more entries than the table (the 33-entry poles of 482.obj): uniform branch
-        float4 tv[DB_W];
-        float tw8[DB_W];
+    auto table_terms = [&]() {
 #pragma unroll
         for (int n = 0; n < DB_W; ++n) {
-            const bool in = e + n < e1;
-            const int col = in ? over_col[e + n] : v;
-            tw8[n] = in ? over_val[e + n] : 0.f;
-            tv[n] = db_ld4(r_src, mesh_on ? rowbase + (unsigned)col * (DB_C * 4) + 4 * c0 : DB_OOB);
-        }
-#pragma unroll
-        for (int n = 0; n < DB_W; ++n) {
-            const bool in = e + n < e1;
-            const float tx = tw8[n] * tv[n].x, ty = tw8[n] * tv[n].y, tz = tw8[n] * tv[n].z, tw = tw8[n] * tv[n].w;
+            const bool in = nb[n] >= 0;
+            const float tx = wv[n] * sv[n].x, ty = wv[n] * sv[n].y, tz = wv[n] * sv[n].z, tw = wv[n] * sv[n].w;
             facc.x += in ? tx : -0.0f, facc.y += in ? ty : -0.0f, facc.z += in ? tz : -0.0f, facc.w += in ? tw : -0.0f;
         }
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    const bool has_tail = tail_col && __builtin_amdgcn_readfirstlane(tcol) >= 0; // (uniform: entry 0 of the tail row)
+    if (!has_tail) { // every vertex of an icosphere, all but the two poles of 482.obj
+        if (SLICE) db_load_slice(bw, packed, wave, lane); // behind the gathers (in-order memory counter: see the callers)
+        __builtin_amdgcn_sched_barrier(0);
+        table_terms();
+        return facc;
     }
+    // the tail rows, all in flight at once; the weight slice behind them (its registers hold the tail's rows until then)
+    float4 tv[DB_TAIL];
+#pragma unroll
+    for (int n = 0; n < DB_TAIL; ++n) {
+        const int col = __builtin_amdgcn_readlane(tcol, n);
+        tv[n] = db_ld4(r_src, (mesh_on && col >= 0) ? rowbase + (unsigned)col * (DB_C * 4) + 4 * c0 : DB_OOB);
+    }
+    table_terms(); // summation order: the table's slots, then the tail, in CSR order
+#pragma unroll
+    for (int n = 0; n < DB_TAIL; ++n) {
+        const bool in = __builtin_amdgcn_readlane(tcol, n) >= 0;
+        const float wn = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tval), n));
+        const float tx = wn * tv[n].x, ty = wn * tv[n].y, tz = wn * tv[n].z, tw = wn * tv[n].w;
+        facc.x += in ? tx : -0.0f, facc.y += in ? ty : -0.0f, facc.z += in ? tz : -0.0f, facc.w += in ? tw : -0.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (SLICE) db_load_slice(bw, packed, wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
     return facc;
 }
 
@@ -234,6 +264,7 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_fwd_kernel(geom_deform_fwd a
     const int x = lane & 15, g = lane >> 4; // matrix-core coordinates
     const int rl = tid >> 4, j = tid & 15;  // batch row (mesh) and float4 group of the gather / BatchNorm thread
     const int c0 = 4 * j;
+    DB_STAMP(0);
     const bool mesh_on = rl < a.b;
     const int64_t op_bytes = (int64_t)a.b * a.nv * DB_C * 4;
     const __amdgpu_buffer_rsrc_t r_src = db_rsrc(a.s_in, op_bytes);
@@ -260,11 +291,11 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_fwd_kernel(geom_deform_fwd a
     // have a counter of their own); in this order the statistics run while the slice is still on its way.
     DbSlice bw;
     float4 z[3];
-    z[0] = db_aggregate<PRODUCT>(r_src, mesh_on, rowbase, v, c0, a.ell_col, a.ell_val, a.over_ptr, a.over_col, a.over_val, &z[1], 2, bw,
-                                 a.w_next, wave, lane);
+    z[0] = db_aggregate<PRODUCT>(r_src, mesh_on, rowbase, v, c0, a.ell_col, a.ell_val, a.tail_col, a.tail_val, &z[1], bw, a.w_next, wave, lane);
 #pragma unroll
     for (int i = 0; i < 3; ++i) z[i].x += bias4[i].x, z[i].y += bias4[i].y, z[i].z += bias4[i].z, z[i].w += bias4[i].w;
 
+    DB_STAMP(1); // gathers arrived (z holds the aggregated row)
     // ---- BatchNorm1d(verts): one statistic per vertex over its b * 192 values (two-pass: mean, then the centred second moment)
     float *red = lds + DB_PANEL + DB_CST;
     const int n = a.b * DB_C;
@@ -295,6 +326,7 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_fwd_kernel(geom_deform_fwd a
         mean = a.run_mean[v];
         invstd = 1.f / sqrtf(a.run_var[v] + a.eps);
     }
+    DB_STAMP(2); // statistics done
     auto finish = [&](float zz, float r) {
         float y = (zz - mean) * invstd * gamma + beta;
         if (a.relu) y = y > 0.f ? y : 0.f;
@@ -315,10 +347,18 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_fwd_kernel(geom_deform_fwd a
 
     // ---- the next layer's product on the tile
     db_to_panel(lds, rl, c0, xo);
+    DB_STAMP(3); // outputs requested, panel written
     __syncthreads();
+    DB_STAMP(4);
     float *stage = lds + DB_PANEL;
+#ifdef DB_PROBE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // probe: separate the wait for the weight slice from the MFMAs
+    DB_STAMP(5);
+#endif
     db_product(bw, lds, stage, wave, x, g);
+    DB_STAMP(6); // MFMAs issued + staged
     __syncthreads();
+    DB_STAMP(7);
     const __amdgpu_buffer_rsrc_t r_s = db_rsrc(a.s_out, op_bytes);
 #pragma unroll
     for (int t = 0; t < 3; ++t) { // the tile leaves in memory order: 768 contiguous bytes per mesh row
@@ -327,6 +367,7 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_fwd_kernel(geom_deform_fwd a
         const unsigned off = r < a.b ? ((unsigned)r * (unsigned)a.nv + (unsigned)v) * (DB_C * 4) + 16u * c4 : DB_OOB;
         db_st4(r_s, off, make_float4(val[0], val[1], val[2], val[3]));
     }
+    DB_STAMP(8);
 }
 
 template <bool PRODUCT>
@@ -339,6 +380,7 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_kernel(geom_deform_bwd a
     const int x = lane & 15, g = lane >> 4;
     const int rl = tid >> 4, j = tid & 15;
     const int c0 = 4 * j;
+    DB_STAMP(0);
     const bool mesh_on = rl < a.b;
     const int64_t op_bytes = (int64_t)a.b * a.nv * DB_C * 4;
     const unsigned rowbase = (unsigned)rl * (unsigned)a.nv * (DB_C * 4);
@@ -361,14 +403,21 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_kernel(geom_deform_bwd a
         const __amdgpu_buffer_rsrc_t r_src = db_rsrc(a.dz_up, op_bytes), r_ds = db_rsrc(a.ds_up, op_bytes);
         float4 gs[3];
         DbSlice bw;
-        gs[0] = db_aggregate<true>(r_src, mesh_on, rowbase, v, c0, a.ell_col_t, a.ell_val_t, a.over_ptr_t, a.over_col_t, a.over_val_t, &gs[1], 2,
-                                   bw, a.wt_up, wave, lane);
+        gs[0] = db_aggregate<true>(r_src, mesh_on, rowbase, v, c0, a.ell_col_t, a.ell_val_t, a.tail_col_t, a.tail_val_t, &gs[1], bw, a.wt_up, wave, lane);
 #pragma unroll
         for (int i = 0; i < 3; ++i) db_st4(r_ds, at(i), gs[i]); // the layer above's weight gradient reads it (X^T . G)
         db_to_panel(lds, rl, c0, gs);                           // (rows beyond the batch read zeros: zero rows of the tile)
+        DB_STAMP(1); // gathers arrived, G stored + in the panel
         __syncthreads();
+        DB_STAMP(2);
+#ifdef DB_PROBE_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DB_STAMP(3);
+#endif
         db_product(bw, lds, stage, wave, x, g);                 // dX = G . W_up^T
+        DB_STAMP(4);
         __syncthreads();
+        DB_STAMP(5);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const f32x4 t = *reinterpret_cast<const f32x4 *>(stage + rl * DB_LDC + c0 + DB_K * i);
@@ -397,7 +446,9 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_kernel(geom_deform_bwd a
         if (a.has_res && a.grad_res) db_st4(r_gr, at(i), r);
     }
     float *red = lds + DB_PANEL + DB_CST;
+    DB_STAMP(6);
     db_sum2(sum_g, sum_gx, red);
+    DB_STAMP(7);
     if (tid == 0) {
         if (a.grad_bn_b) a.grad_bn_b[v] = sum_g;
         if (a.grad_bn_w) a.grad_bn_w[v] = sum_gx;
@@ -429,6 +480,7 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_kernel(geom_deform_bwd a
         __syncthreads();
         if (tid < DB_C) a.colsum[(size_t)v * DB_C + tid] = ((stage[tid] + stage[DB_C + tid]) + stage[2 * DB_C + tid]) + stage[3 * DB_C + tid];
     }
+    DB_STAMP(8);
 }
 
 inline bool db_aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
@@ -443,6 +495,13 @@ int db_check_shape(int b, int nv, int c, int k, int ell_w)
 
 } // namespace
 
+#ifdef DB_PROBE_STAMPS
+extern "C" int geom_db_probe_read(unsigned long long *dst, int n)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(db_stamps), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 extern "C" int geom_deform_layer_fwd_f32(const geom_deform_fwd *args, void *stream)
 {
     if (!args) return GEOM_EINVAL;
@@ -453,7 +512,7 @@ extern "C" int geom_deform_layer_fwd_f32(const geom_deform_fwd *args, void *stre
     if (!a.s_in || !a.ell_col || !a.ell_val || !a.x_out) return GEOM_EINVAL;
     if (a.training ? (!a.save_mean || !a.save_invstd) : (!a.run_mean || !a.run_var)) return GEOM_EINVAL;
     if (a.w_next && !a.s_out) return GEOM_EINVAL;
-    if (a.over_ptr && (!a.over_col || !a.over_val)) return GEOM_EINVAL;
+    if (a.tail_col && !a.tail_val) return GEOM_EINVAL;
     if (a.res && (a.res_ld < DB_C || (a.res_ld & 3))) return GEOM_EINVAL;
     if (!db_aligned16(a.s_in) || !db_aligned16(a.ell_col) || !db_aligned16(a.ell_val) || !db_aligned16(a.x_out) || !db_aligned16(a.z_out) ||
         !db_aligned16(a.s_out) || !db_aligned16(a.bias) || !db_aligned16(a.res) || !db_aligned16(a.w_next))
@@ -477,7 +536,7 @@ extern "C" int geom_deform_layer_bwd_f32(const geom_deform_bwd *args, void *stre
     if (!a.z || !a.save_mean || !a.save_invstd || !a.dz) return GEOM_EINVAL;
     const bool product = a.dz_up != nullptr;
     if (product ? (!a.ell_col_t || !a.ell_val_t || !a.ds_up || !a.wt_up) : !a.g) return GEOM_EINVAL;
-    if (a.over_ptr_t && (!a.over_col_t || !a.over_val_t)) return GEOM_EINVAL;
+    if (a.tail_col_t && !a.tail_val_t) return GEOM_EINVAL;
     if (!db_aligned16(a.dz_up) || !db_aligned16(a.ell_col_t) || !db_aligned16(a.ell_val_t) || !db_aligned16(a.ds_up) || !db_aligned16(a.g) ||
         !db_aligned16(a.g2) || !db_aligned16(a.z) || !db_aligned16(a.grad_res) || !db_aligned16(a.dz) || !db_aligned16(a.colsum) ||
         !db_aligned16(a.wt_up))

@@ -42,7 +42,7 @@ def serves(block, features, pooled, csr):
         return False
     if features.shape[0] > 16 or features.shape[0] * features.shape[1] * 192 >= 2 ** 29:
         return False
-    if csr.ell_w != 8:
+    if csr.ell_w != 8 or _tail_tables(csr) is False:
         return False
     for i in range(1, LAYERS + 1):
         gc, bn = getattr(block, "gc%d" % i), getattr(block, "bn%d" % i)
@@ -53,6 +53,38 @@ def serves(block, features, pooled, csr):
 
 def _p(t):
     return None if t is None else t.data_ptr()
+
+
+TAIL = 32      # GEOM_DEFORM_TAIL: entries of an adjacency row beyond the 8-wide neighbour table that the launches take
+
+
+def _tail_tables(csr):
+    """(tail_col, tail_val, tail_col_t, tail_val_t): the entries of every row beyond the neighbour table as a second,
+    TAIL-wide table [nv, TAIL] (col -1 = padding) for A and A^T, or Nones where no row is longer; False when a row has more
+    than 8 + TAIL entries (the launches then do not serve the adjacency).  Cached on the csr object."""
+    cached = getattr(csr, "_deform_tail", None)
+    if cached is not None:
+        return cached
+    out = []
+    for over in (csr.over, csr.over_t):
+        if over is None:
+            out += [None, None]
+            continue
+        ptr, col, val = over
+        lens = (ptr[1:] - ptr[:-1]).long()
+        if int(lens.max()) > TAIL:
+            csr._deform_tail = False
+            return False
+        nv = lens.numel()
+        rows = torch.repeat_interleave(torch.arange(nv, device=col.device), lens)
+        slot = torch.arange(col.numel(), device=col.device) - ptr[:-1].long()[rows]
+        tcol = torch.full((nv, TAIL), -1, dtype=torch.int32, device=col.device)
+        tval = torch.zeros((nv, TAIL), dtype=torch.float32, device=col.device)
+        tcol[rows, slot] = col
+        tval[rows, slot] = val
+        out += [tcol.contiguous(), tval.contiguous()]
+    csr._deform_tail = tuple(out)
+    return csr._deform_tail
 
 
 def pack_weights(weights):
@@ -74,9 +106,9 @@ def layer_forward(s_in, bias, csr, bn_w, bn_b, run_mean, run_var, training, mome
     """One forward launch (geom_deform_layer_fwd_f32); w_next = the next layer's weight PACKED (pack_weights()[0][l]); see
     include/geom_hip.h for the operands."""
     b, nv, c = s_in.shape
-    over = csr.over or (None, None, None)
-    a = _lib.DeformFwd(b, nv, c, 64, csr.ell_w, _p(s_in), _p(bias), _p(csr.ell_col), _p(csr.ell_val), _p(over[0]), _p(over[1]),
-                       _p(over[2]), _p(bn_w), _p(bn_b), _p(run_mean), _p(run_var), int(training), float(momentum), float(eps),
+    tail = _tail_tables(csr)
+    a = _lib.DeformFwd(b, nv, c, 64, csr.ell_w, _p(s_in), _p(bias), _p(csr.ell_col), _p(csr.ell_val), _p(tail[0]), _p(tail[1]),
+                       _p(bn_w), _p(bn_b), _p(run_mean), _p(run_var), int(training), float(momentum), float(eps),
                        int(relu), _p(res), res.stride(1) if res is not None else 0, float(scale), _p(z_out), _p(x_out),
                        _p(save_mean), _p(save_invstd), _p(w_next), _p(s_out), 0)
     with torch.cuda.device(s_in.device):
@@ -88,9 +120,9 @@ def layer_backward(shape, csr, z, bn_w, bn_b, save_mean, save_invstd, relu, has_
     """One backward launch (geom_deform_layer_bwd_f32); wt_up = the layer above's weight, TRANSPOSED and packed
     (pack_weights()[1][l])."""
     b, nv, c = shape
-    over = csr.over_t or (None, None, None)
-    a = _lib.DeformBwd(b, nv, c, 64, csr.ell_w, _p(dz_up), _p(csr.ell_col_t), _p(csr.ell_val_t), _p(over[0]), _p(over[1]),
-                       _p(over[2]), _p(ds_up), _p(wt_up), _p(g), _p(g2), _p(z), _p(bn_w), _p(bn_b), _p(save_mean),
+    tail = _tail_tables(csr)
+    a = _lib.DeformBwd(b, nv, c, 64, csr.ell_w, _p(dz_up), _p(csr.ell_col_t), _p(csr.ell_val_t), _p(tail[2]), _p(tail[3]),
+                       _p(ds_up), _p(wt_up), _p(g), _p(g2), _p(z), _p(bn_w), _p(bn_b), _p(save_mean),
                        _p(save_invstd), int(relu), int(has_res), float(scale), _p(grad_res), _p(dz), _p(grad_bn_w),
                        _p(grad_bn_b), _p(colsum), 0)
     with torch.cuda.device(z.device):

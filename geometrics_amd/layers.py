@@ -29,7 +29,8 @@ _ACT_NONE, _ACT_RELU, _ACT_ELU = 0, 1, 2
 # --------------------------------------------------------------- CSR cache ----
 class _Csr:
     __slots__ = ("rowptr", "col", "val", "rowptr_t", "col_t", "val_t", "nv", "nnz",
-                 "ell_w", "ell_col", "ell_val", "ell_col_t", "ell_val_t", "inv_deg", "over", "over_t")
+                 "ell_w", "ell_col", "ell_val", "ell_col_t", "ell_val_t", "inv_deg", "over", "over_t",
+                 "_deform_tail")      # (geometrics_amd.deform: the rows' entries beyond the table as a second fixed-width table)
 
 
 _csr_cache = {}   # id(adjacency tensor) -> (weakref, version, _Csr)

@@ -370,7 +370,8 @@ int geom_zn_layer_bwd_f32(int b, int nv, int c, int k, int ell_w, const int *ell
  * reference: models.py:237-297 (BatchMeshDeformationBlock.forward: gcK -> F.relu(bnK(.)) with bnK = nn.BatchNorm1d(verts),
  * `features = features + x; features /= 2` after every second layer) on top of layers.py:107-116.  One workgroup per vertex
  * (its b <= 16 batch rows are one 16-row tile of the fp32 matrix core; BatchNorm1d(verts) statistics are tile-local).
- * Shapes: c == 192, k == 64 (split 3), ell_w == 8 (rows longer than the table continue in the CSR tail over_*), b <= 16;
+ * Shapes: c == 192, k == 64 (split 3), ell_w == 8 (rows longer than the table continue in the tail table: tail_col / tail_val
+ * [nv, GEOM_DEFORM_TAIL], entries 8, 9, ... of the row in CSR order, col -1 = padding; NULL: no row is longer), b <= 16;
  * anything else GEOM_EUNSUPPORTED (callers then run the separate operators: product, geom_zn_gcn_aggregate_ell_*,
  * geom_vertex_bn_*).  All arrays [b, nv, 192] row-major fp32, 16-byte aligned, caller-allocated.
  *
@@ -395,7 +396,7 @@ typedef struct geom_deform_fwd {
     int b, nv, c, k, ell_w;
     const float *s_in, *bias;
     const int *ell_col; const float *ell_val;
-    const int *over_ptr, *over_col; const float *over_val;      /* CSR tail of rows longer than the table, or NULL */
+    const int *tail_col; const float *tail_val;                 /* [nv, GEOM_DEFORM_TAIL] or NULL */
     const float *bn_w, *bn_b;                                   /* [nv] or NULL (1 / 0) */
     float *run_mean, *run_var;                                  /* [nv] */
     int training; float momentum, eps;
@@ -409,7 +410,7 @@ typedef struct geom_deform_bwd {
     int b, nv, c, k, ell_w;
     const float *dz_up;
     const int *ell_col_t; const float *ell_val_t;
-    const int *over_ptr_t, *over_col_t; const float *over_val_t;
+    const int *tail_col_t; const float *tail_val_t;
     float *ds_up; const float *wt_up;
     const float *g, *g2;
     const float *z, *bn_w, *bn_b, *save_mean, *save_invstd;
@@ -418,6 +419,7 @@ typedef struct geom_deform_bwd {
     int vpx;
 } geom_deform_bwd;
 #define GEOM_DEFORM_MAX_PACK 16
+#define GEOM_DEFORM_TAIL 32
 /* fwd[l] / bwd[l] ([count, 36864] floats each; either may be NULL): w[l] / w[l]^T ([192,192] row-major device matrices, `w` a
  * HOST array of count <= GEOM_DEFORM_MAX_PACK pointers) in the order a wave of the layer launches keeps its weight slice in
  * registers; one launch for all layers of a block, once per step (the weights change with every optimiser step). */
