@@ -895,26 +895,32 @@ def driver_step_times(dev, batch=16, profile_replays=0, zero_edit=False):
     gt_index = ops.GtIndex(gt) if CULLED_CHAMFER else None
     lap = utils.batch_get_lap_info
 
+    # the driver clones positions and camera parameters in front of every call (GEOMetrics.py:118-137: in-place safety for its
+    # own utils); these operators never write their inputs, so only the zero-edit step keeps the copies
+    clone = (lambda t: t.clone()) if zero_edit else (lambda t: t)
+
     def predict():
         base = initial.unsqueeze(0).expand(batch, nv, 3)
-        f = utils.batched_pooling(maps[0], base, img_info.clone())
+        f = utils.batched_pooling(maps[0], base, clone(img_info))
         f, p1 = blocks[0](base, f, info["adj"])
         p1 = base + p1
-        f = torch.cat((f, utils.batched_pooling(maps[1], p1.clone(), img_info.clone())), dim=-1)
-        f, p2 = blocks[1](p1.clone(), f, info["adj"])
+        f = torch.cat((f, utils.batched_pooling(maps[1], clone(p1), clone(img_info))), dim=-1)
+        f, p2 = blocks[1](clone(p1), f, info["adj"])
         p2 = p2 + p1
-        f = torch.cat((f, utils.batched_pooling(maps[2], p2.clone(), img_info.clone())), dim=-1)
-        _, p3 = blocks[2](p2.clone(), f, info["adj"])
+        f = torch.cat((f, utils.batched_pooling(maps[2], clone(p2), clone(img_info))), dim=-1)
+        _, p3 = blocks[2](clone(p2), f, info["adj"])
         return p1, p2, p3 + p2
 
     def losses(p1, p2, p3):
-        surf = lambda p: utils.batch_point_to_surface(p.clone(), info, gt, num=S_PTS, gt_index=gt_index)
-        surface = surf(p1) * .2 + surf(p2) * .2 + surf(p3) * 2
-        edge = (utils.batch_calc_edge(p1.clone(), info) + utils.batch_calc_edge(p2.clone(), info) + utils.batch_calc_edge(p3.clone(), info)) * 300
-        l1 = torch.mean(torch.sum((lap(initial, info) - lap(p1, info)) ** 2, 2)) * 1500
-        l2 = torch.mean(torch.sum((lap(p1, info) - lap(p2, info)) ** 2, 2)) * 1500 + torch.mean(torch.sum((p1 - p2) ** 2, 2)) * 100
-        l3 = torch.mean(torch.sum((lap(p2, info) - lap(p3, info)) ** 2, 2)) * 1500 + torch.mean(torch.sum((p2 - p3) ** 2, 2)) * 100
-        return edge + surface + .2 * (l1 * .3 + l2 + l3)
+        # GEOMetrics.py:134-161 with its weights folded into the operators: surface_loss_k * (.2, .2, 2); per stage
+        # 300 * edge(p_k) + .2 * (1500 * lap term [* .3 for stage 1] + 100 * displacement term) as ONE node per stage
+        # (utils.stage_regularisers; the zero-edit step below keeps the driver's own expressions)
+        surf = lambda p, wgt: utils.batch_point_to_surface(p, info, gt, num=S_PTS, gt_index=gt_index, weight=wgt)
+        surface = surf(p1, .2) + surf(p2, .2) + surf(p3, 2.0)
+        reg = (utils.stage_regularisers(initial, p1, info, lap_weight=.2 * .3 * 1500, edge_weight=300)
+               + utils.stage_regularisers(p1, p2, info, lap_weight=.2 * 1500, move_weight=.2 * 100, edge_weight=300)
+               + utils.stage_regularisers(p2, p3, info, lap_weight=.2 * 1500, move_weight=.2 * 100, edge_weight=300))
+        return surface + reg
 
     def zero():
         opt.zero_grad()
@@ -1014,7 +1020,7 @@ def driver_step_times(dev, batch=16, profile_replays=0, zero_edit=False):
 
     def reg_fb():
         pos.grad = None
-        (utils.batch_calc_edge(pos, info) * 300 + torch.mean(torch.sum((lap(initial, info) - lap(pos, info)) ** 2, 2)) * 1500).backward()
+        utils.stage_regularisers(initial, pos, info, lap_weight=1500, edge_weight=300).backward()
     for p in params:
         if p.grad is None:
             p.grad = torch.zeros_like(p)

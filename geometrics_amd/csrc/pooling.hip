@@ -418,3 +418,51 @@ extern "C" int geom_pool_features_bwd_f32(int b, int nv, const float *verts, con
     }
     return geom::launch_status();
 }
+
+// ---- camera from (azimuth deg, elevation deg, distance): reference utils.py:286-313 -----------------------------------------
+// The reference (and this package's torch mirror of it) forms the camera of every image with ~35 tiny eager launches --
+// scale, remainder, sin, cos, stack, two cross products, three normalisations -- three times per training step; here one
+// thread per image evaluates the same fp32 expressions in the same order (-ffp-contract=off: no fused multiply-adds).
+namespace {
+// torch.remainder (the `%` of the reference line): the result takes the divisor's sign
+__device__ __forceinline__ float fmodf_floor(float a, float b)
+{
+    float r = fmodf(a, b);
+    if (r != 0.f && ((r < 0.f) != (b < 0.f))) r += b;
+    return r;
+}
+__global__ __launch_bounds__(64) void camera_info_kernel(int b, const float *param, float *cam_mat, float *cam_pos)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= b) return;
+    const float pi = 3.14159265358979323846f;
+    const float theta = fmodf_floor(pi * param[3 * i] / 180.0f, 360.0f), phi = fmodf_floor(pi * param[3 * i + 1] / 180.0f, 360.0f);
+    const float dist = param[3 * i + 2];
+    const float cam_y = dist * sinf(phi), flat = dist * cosf(phi);
+    const float z[3] = {flat * cosf(theta), cam_y, flat * sinf(theta)};          // camera position = the z axis (unnormalised)
+    // x = up x z with up = (0, 1, 0);  y = z x x   (torch.cross: a x b = (a1 b2 - a2 b1, a2 b0 - a0 b2, a0 b1 - a1 b0))
+    const float x[3] = {1.0f * z[2] - 0.0f * z[1], 0.0f * z[0] - 0.0f * z[2], 0.0f * z[1] - 1.0f * z[0]};
+    const float y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]};
+    const float *rows[3] = {x, y, z};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float *a = rows[r];
+        const float n = sqrtf((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cam_mat[9 * i + 3 * r + k] = a[k] / n;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cam_pos[3 * i + k] = z[k];
+}
+} // namespace
+
+// cam_mat [b,3,3] (rows = the camera's x, y, z axes, normalised), cam_pos [b,3] from param [b,3] = (azimuth deg, elevation deg,
+// distance): what geom_pool_features_* take.  One launch.
+extern "C" int geom_camera_info_f32(int b, const float *param, float *cam_mat, float *cam_pos, void *stream)
+{
+    if (b < 0) return GEOM_EINVAL;
+    if (b == 0) return 0;
+    if (!param || !cam_mat || !cam_pos) return GEOM_EINVAL;
+    hipLaunchKernelGGL(camera_info_kernel, dim3((b + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), b, param, cam_mat, cam_pos);
+    return geom::launch_status();
+}

@@ -79,7 +79,138 @@ __global__ __launch_bounds__(RG_THREADS) void edge_sqlen_bwd_kernel(int b, int n
 
 inline dim3 rg_grid(int64_t count) { return dim3((unsigned)((count + RG_THREADS - 1) / RG_THREADS)); }
 
+// ---- the regularisers of ONE deformation stage in one launch per direction ------------------------------------------------
+// The reference's driver adds, per stage (GEOMetrics.py:147-161), the edge term of the new positions, the squared difference
+// of the Laplacian coordinates of the previous and the new positions and (stages 2, 3) their squared displacement:
+//     w_edge * mean_faces(|e1|^2 + |e2|^2 + |e3|^2) / 3 ... + w_lap * mean_v |lap(prev) - lap(cur)|^2 + w_move * mean_v |prev - cur|^2
+// -- as torch expressions on top of the kernels above that is ~20 launches forward and ~25 backward per stage for 7 712 x 3
+// floats.  lap is linear, so lap(prev) - lap(cur) = lap(prev - cur): the forward launch forms d = prev - cur, its Laplacian
+// coordinates (saved for the backward) and all three sums' per-workgroup partials; the backward launch is a gather per vertex:
+// the transposed Laplacian of the saved coordinates, the displacement, and the edge term's gradient over the vertex's incident
+// (face, corner) list -- no float atomics, a fixed summation order.
+struct StageRegArgs {
+    const float *prev, *cur;   // prev [b,nv,3] or [nv,3] (prev_stride = 0); cur [b,nv,3]
+    int64_t prev_stride;       // floats between two meshes of prev
+    int b, nv, nf;
+    const int64_t *faces;
+    const int *rowptr, *col;
+    const float *inv_deg;
+    const int *vf_ptr, *vf_item; // vertex -> incident (face * 4 + corner), backward
+    float c_lap, c_move, c_edge; // the weights divided by the means' counts
+    float *lapd;                 // [b,nv,3]: lap(prev - cur)
+    float *partial;              // forward: one partial sum per workgroup
+    const float *gout;           // backward: the gradient of the scalar (device)
+    float *grad_prev, *grad_cur; // backward ([b,nv,3]; grad_prev may be null)
+};
+
+__device__ __forceinline__ V3 rg_d(const StageRegArgs &a, int mesh, int j)
+{
+    return ld3(a.prev + (size_t)mesh * a.prev_stride + 3 * (size_t)j) - ld3(a.cur + ((size_t)mesh * a.nv + j) * 3);
+}
+
+__global__ __launch_bounds__(RG_THREADS) void stage_reg_fwd_kernel(StageRegArgs a)
+{
+    __shared__ float red[RG_THREADS / GEOM_WAVE];
+    const int64_t i = (int64_t)blockIdx.x * RG_THREADS + threadIdx.x;
+    float t = 0.f;
+    if (i < (int64_t)a.b * a.nv) {
+        const int mesh = (int)(i / a.nv), v = (int)(i - (int64_t)mesh * a.nv);
+        V3 s = geom::mk(0.f, 0.f, 0.f);
+        for (int e = a.rowptr[v]; e < a.rowptr[v + 1]; ++e) s = s + rg_d(a, mesh, a.col[e]);
+        const V3 self = rg_d(a, mesh, v);
+        const V3 lap = self - (s - self) * a.inv_deg[v];
+        a.lapd[3 * i + 0] = lap.x, a.lapd[3 * i + 1] = lap.y, a.lapd[3 * i + 2] = lap.z;
+        t = a.c_lap * geom::dot3(lap, lap) + a.c_move * geom::dot3(self, self);
+    }
+    if (a.c_edge != 0.f && i < (int64_t)a.b * a.nf) {
+        const int mesh = (int)(i / a.nf), f = (int)(i - (int64_t)mesh * a.nf);
+        const float *V = a.cur + (size_t)mesh * a.nv * 3;
+        const V3 p1 = ld3(V + 3 * a.faces[3 * (size_t)f + 0]), p2 = ld3(V + 3 * a.faces[3 * (size_t)f + 1]), p3 = ld3(V + 3 * a.faces[3 * (size_t)f + 2]);
+        const V3 e1 = p2 - p1, e2 = p3 - p1, e3 = p2 - p3;
+        t += a.c_edge * ((geom::dot3(e1, e1) + geom::dot3(e2, e2)) + geom::dot3(e3, e3));
+    }
+    for (int off = GEOM_WAVE / 2; off > 0; off >>= 1) t += __shfl_down(t, off, GEOM_WAVE);
+    if ((threadIdx.x & (GEOM_WAVE - 1)) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) a.partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+__global__ __launch_bounds__(RG_THREADS) void stage_reg_bwd_kernel(StageRegArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * RG_THREADS + threadIdx.x;
+    if (i >= (int64_t)a.b * a.nv) return;
+    const int mesh = (int)(i / a.nv), v = (int)(i - (int64_t)mesh * a.nv);
+    const float go = a.gout[0];
+    const float *Y = a.lapd + (size_t)mesh * a.nv * 3;
+    V3 s = geom::mk(0.f, 0.f, 0.f);
+    for (int e = a.rowptr[v]; e < a.rowptr[v + 1]; ++e) {
+        const int j = a.col[e];
+        s = s + ld3(Y + 3 * j) * a.inv_deg[j];
+    }
+    const V3 y = ld3(Y + 3 * v);
+    const V3 lty = y - (s - y * a.inv_deg[v]);                                  // transposed Laplacian (laplacian_kernel<true>)
+    const V3 g = (lty * (2.f * a.c_lap) + rg_d(a, mesh, v) * (2.f * a.c_move)) * go; // d total / d (prev - cur)[v]
+    V3 ge = geom::mk(0.f, 0.f, 0.f);
+    if (a.c_edge != 0.f) {
+        const float *V = a.cur + (size_t)mesh * a.nv * 3;
+        for (int e = a.vf_ptr[v]; e < a.vf_ptr[v + 1]; ++e) {                  // the vertex's (face, corner) list, ascending faces
+            const int item = a.vf_item[e], f = item >> 2, corner = item & 3;
+            const V3 p1 = ld3(V + 3 * a.faces[3 * (size_t)f + 0]), p2 = ld3(V + 3 * a.faces[3 * (size_t)f + 1]), p3 = ld3(V + 3 * a.faces[3 * (size_t)f + 2]);
+            const V3 e1 = p2 - p1, e2 = p3 - p1, e3 = p2 - p3;
+            ge = ge + (corner == 0 ? (e1 + e2) * -1.f : corner == 1 ? e1 + e3 : e2 - e3);
+        }
+        ge = ge * (2.f * a.c_edge * go);
+    }
+    if (a.grad_prev) a.grad_prev[3 * i + 0] = g.x, a.grad_prev[3 * i + 1] = g.y, a.grad_prev[3 * i + 2] = g.z;
+    a.grad_cur[3 * i + 0] = ge.x - g.x, a.grad_cur[3 * i + 1] = ge.y - g.y, a.grad_cur[3 * i + 2] = ge.z - g.z;
+}
+
 } // namespace
+
+// partial [geom_stage_regularisers_blocks(b, nv, nf)] per-workgroup sums of
+//   c_edge * sum_faces(|e1|^2+|e2|^2+|e3|^2)(cur) + c_lap * sum_v |lap(prev - cur)|^2 + c_move * sum_v |prev - cur|^2
+// (the caller folds the means' 1 / counts into the c_*; finish with geom_sum_f32), lapd [b,nv,3] = lap(prev - cur) for the
+// backward.  prev: [b,nv,3] (prev_batched != 0) or ONE [nv,3] mesh for the whole batch (the template, GEOMetrics.py:156).
+extern "C" int64_t geom_stage_regularisers_blocks(int b, int nv, int nf)
+{
+    const int64_t n = (int64_t)b * (nv > nf ? nv : nf);
+    return (n + RG_THREADS - 1) / RG_THREADS;
+}
+extern "C" int geom_stage_regularisers_fwd_f32(int b, int nv, const float *prev, int prev_batched, const float *cur, int nf,
+                                               const int64_t *faces, const int *rowptr, const int *col, const float *inv_deg,
+                                               float c_lap, float c_move, float c_edge, float *lapd, float *partial, void *stream)
+{
+    if (b < 0 || nv < 0 || nf < 0) return GEOM_EINVAL;
+    if (b == 0 || nv == 0) return 0;
+    if (!prev || !cur || !rowptr || !col || !inv_deg || !lapd || !partial || (nf > 0 && !faces)) return GEOM_EINVAL;
+    StageRegArgs a{};
+    a.prev = prev, a.cur = cur, a.prev_stride = prev_batched ? (int64_t)nv * 3 : 0, a.b = b, a.nv = nv, a.nf = nf, a.faces = faces;
+    a.rowptr = rowptr, a.col = col, a.inv_deg = inv_deg, a.c_lap = c_lap, a.c_move = c_move, a.c_edge = nf > 0 ? c_edge : 0.f;
+    a.lapd = lapd, a.partial = partial;
+    hipLaunchKernelGGL(stage_reg_fwd_kernel, dim3((unsigned)geom_stage_regularisers_blocks(b, nv, nf)), dim3(RG_THREADS), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return geom::launch_status();
+}
+// grad_cur [b,nv,3] (and grad_prev [b,nv,3] when given: batched prev only) of gout[0] * that sum; vf_ptr [nv+1] / vf_item: every
+// vertex's incident corners as face * 4 + corner, ascending (the edge term's gradient as a gather: no atomics).
+extern "C" int geom_stage_regularisers_bwd_f32(int b, int nv, const float *prev, int prev_batched, const float *cur, int nf,
+                                               const int64_t *faces, const int *rowptr, const int *col, const float *inv_deg,
+                                               const int *vf_ptr, const int *vf_item, float c_lap, float c_move, float c_edge,
+                                               const float *lapd, const float *gout, float *grad_prev, float *grad_cur, void *stream)
+{
+    if (b < 0 || nv < 0 || nf < 0) return GEOM_EINVAL;
+    if (b == 0 || nv == 0) return 0;
+    if (!prev || !cur || !rowptr || !col || !inv_deg || !lapd || !gout || !grad_cur) return GEOM_EINVAL;
+    if (nf > 0 && c_edge != 0.f && (!faces || !vf_ptr || !vf_item)) return GEOM_EINVAL;
+    if (grad_prev && !prev_batched) return GEOM_EUNSUPPORTED;
+    StageRegArgs a{};
+    a.prev = prev, a.cur = cur, a.prev_stride = prev_batched ? (int64_t)nv * 3 : 0, a.b = b, a.nv = nv, a.nf = nf, a.faces = faces;
+    a.rowptr = rowptr, a.col = col, a.inv_deg = inv_deg, a.vf_ptr = vf_ptr, a.vf_item = vf_item;
+    a.c_lap = c_lap, a.c_move = c_move, a.c_edge = nf > 0 ? c_edge : 0.f;
+    a.lapd = const_cast<float *>(lapd), a.gout = gout, a.grad_prev = grad_prev, a.grad_cur = grad_cur;
+    hipLaunchKernelGGL(stage_reg_bwd_kernel, rg_grid((int64_t)b * nv), dim3(RG_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    return geom::launch_status();
+}
 
 extern "C" int geom_laplacian_f32(int b, int nv, const int *rowptr, const int *col, const float *inv_deg,
                                   const float *x, int transpose, float *out, void *stream)

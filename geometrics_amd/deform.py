@@ -208,7 +208,15 @@ class _HiddenChain(torch.autograd.Function):
         g_s1, _ = _layers.aggregate_backward(dzs[0], csr, 64, _layers._ACT_NONE, None, None, False)
         rows = b * nv
         g_w = torch.bmm(xs[:L - 1].view(L - 1, rows, c).transpose(1, 2), dss.view(L - 1, rows, c))     # dW_i = X_i^T . dS_i, i = 2..L
-        g_bias = colsum.sum(dim=1)                                                                      # [L, 192]
+        # bias gradients: the vertices' column sums added up in vertex order, all 13 layers in ONE launch (torch's reduction over
+        # the middle axis of [13, 482, 192] took 38 us; geom_colsum_batch_f32 is the reduction the aggregation backward's
+        # partials go through: fixed order, ~5 us)
+        g_bias = torch.empty(L, c, **f32)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().geom_colsum_batch_f32(
+                L, (ctypes.c_void_p * L)(*[colsum[i].data_ptr() for i in range(L)]), (ctypes.c_int * L)(*([nv] * L)),
+                (ctypes.c_int * L)(*([c] * L)), (ctypes.c_void_p * L)(*[g_bias[i].data_ptr() for i in range(L)]),
+                _lib.stream_ptr()), "geom_colsum_batch_f32")
         grads = [g_bias[i] for i in range(L)] + [g_w[i].view(1, c, c) for i in range(L - 1)] \
             + [g_bnw[i] for i in range(L)] + [g_bnb[i] for i in range(L)]
         return (g_s1, g_lead, None, None, None, None, *grads)

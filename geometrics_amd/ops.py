@@ -457,6 +457,77 @@ class EdgeSqLenSum(torch.autograd.Function):
         return grad_verts, None
 
 
+_incidence_cache = {}     # id(faces tensor) -> (weakref, version, nv, vf_ptr, vf_item)
+
+
+def vertex_faces(faces, nv):
+    """(vf_ptr [nv+1], vf_item) int32: every vertex's incident corners as face * 4 + corner, ascending -- what the edge
+    term's gradient gathers over (geom_stage_regularisers_bwd_f32).  Cached per faces TENSOR OBJECT and in-place version."""
+    import weakref
+    key = id(faces)
+    hit = _incidence_cache.get(key)
+    if hit is not None and hit[0]() is faces and hit[1] == faces._version and hit[2] == nv:
+        return hit[3], hit[4]
+    with torch.no_grad():
+        f = faces.reshape(-1).long()                                  # corner c of face i sits at 3 i + c
+        item = (torch.arange(f.numel(), device=f.device) // 3) * 4 + torch.arange(f.numel(), device=f.device) % 3
+        order = torch.argsort(f * (4 * faces.shape[0] + 4) + item)    # by vertex, then ascending (face, corner)
+        counts = torch.bincount(f, minlength=nv)
+        vf_ptr = torch.zeros(nv + 1, dtype=torch.int64, device=f.device)
+        vf_ptr[1:] = torch.cumsum(counts, 0)
+        vf_ptr, vf_item = vf_ptr.to(torch.int32).contiguous(), item[order].to(torch.int32).contiguous()
+    _incidence_cache[key] = (weakref.ref(faces, lambda _ref, k=key: _incidence_cache.pop(k, None)), faces._version, nv, vf_ptr, vf_item)
+    return vf_ptr, vf_item
+
+
+class StageRegularisers(torch.autograd.Function):
+    """The regularisers of ONE deformation stage as one scalar (GEOMetrics.py:147-161 on utils.py:636-662):
+        w_edge * mean over (mesh, face) of (|e1|^2 + |e2|^2 + |e3|^2)(cur) / 3
+      + w_lap  * mean over (mesh, vertex) of |lap(prev) - lap(cur)|^2      + w_move * mean over (mesh, vertex) of |prev - cur|^2
+    ONE launch forward (+ the fixed-order sum of its partials), ONE backward (csrc/regularizers.hip) instead of ~45 eager
+    launches; prev [B,V,3] or the [V,3] template."""
+
+    @staticmethod
+    def forward(ctx, prev, cur, faces, rowptr, col, inv_deg, w_lap, w_move, w_edge):
+        c = _f32(cur, "cur", 3, 3)
+        b, nv, _ = c.shape
+        batched = prev.dim() == 3
+        p = _f32(prev, "prev", 3 if batched else 2, 3)
+        if batched and p.shape != c.shape or not batched and p.shape[0] != nv:
+            raise RuntimeError("prev must be [B,V,3] like cur or one [V,3] mesh")
+        faces = _lib.require(faces, "faces", torch.int64, 2, 3)
+        nf = faces.shape[0]
+        c_lap, c_move = float(w_lap) / (b * nv), float(w_move) / (b * nv)
+        c_edge = float(w_edge) / (3.0 * b * nf) if nf else 0.0
+        lapd = torch.empty_like(c)
+        partial = torch.empty(int(_lib.lib().geom_stage_regularisers_blocks(b, nv, nf)), dtype=torch.float32, device=c.device)
+        with torch.cuda.device(c.device):
+            _lib.call("geom_stage_regularisers_fwd_f32", b, nv, p.data_ptr(), int(batched), c.data_ptr(), nf, faces.data_ptr(),
+                      rowptr.data_ptr(), col.data_ptr(), inv_deg.data_ptr(), c_lap, c_move, c_edge, lapd.data_ptr(), partial.data_ptr())
+        ctx.save_for_backward(p, c, faces, rowptr, col, inv_deg, lapd)
+        ctx.coef, ctx.batched = (c_lap, c_move, c_edge), batched
+        return device_sum(partial)
+
+    @staticmethod
+    def backward(ctx, grad):
+        p, c, faces, rowptr, col, inv_deg, lapd = ctx.saved_tensors
+        b, nv, _ = c.shape
+        c_lap, c_move, c_edge = ctx.coef
+        g = grad.contiguous()
+        vf_ptr, vf_item = vertex_faces(faces, nv) if c_edge != 0.0 else (None, None)
+        want_prev = ctx.needs_input_grad[0]
+        grad_cur = torch.empty_like(c)
+        grad_prev = torch.empty_like(c) if want_prev else None
+        with torch.cuda.device(c.device):
+            _lib.call("geom_stage_regularisers_bwd_f32", b, nv, p.data_ptr(), int(ctx.batched), c.data_ptr(), faces.shape[0],
+                      faces.data_ptr(), rowptr.data_ptr(), col.data_ptr(), inv_deg.data_ptr(), _lib.ptr(vf_ptr), _lib.ptr(vf_item),
+                      c_lap, c_move, c_edge, lapd.data_ptr(), g.data_ptr(), _lib.ptr(grad_prev if ctx.batched else None),
+                      grad_cur.data_ptr())
+        if want_prev and not ctx.batched:      # a template that asks for its gradient: the sum over the batch of -grad_cur's lap/move part
+            raise RuntimeError("StageRegularisers: the gradient with respect to an unbatched [V,3] prev is not implemented")
+        return grad_prev, (grad_cur if ctx.needs_input_grad[1] else None), None, None, None, None, None, None, None
+
+
 class PoolFeatures(torch.autograd.Function):
     """Bilinear pooling of the image feature maps at the projected vertex positions (reference
     batched_pooling, utils.py:316-389): one kernel forward, one backward (texel scatters + closed-form

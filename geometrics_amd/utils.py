@@ -76,7 +76,7 @@ def _f_score(sq_to_pred, sq_to_gt, num):
     return float(f.mean())
 
 
-def _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, two_sided, loss_out=None, gt_index=None):
+def _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, two_sided, loss_out=None, gt_index=None, weight=1.0):
     faces = adj_info["faces"]
     points = tri_ws = None
     if draws is None:   # one kernel draws AND gathers the points (and, for the one-sided loss, prepares the triangle
@@ -88,7 +88,7 @@ def _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, two_sided, los
                                                              prepare_scan_for=gt_points.shape[1], gt_index=gt_index)
     else:
         choices, u, v = draws
-    loss, sq_gt, sq_pred = ops.SurfaceLoss.apply(pred_vert, faces, gt_points, choices, u, v, two_sided, LOSS_SCALE,
+    loss, sq_gt, sq_pred = ops.SurfaceLoss.apply(pred_vert, faces, gt_points, choices, u, v, two_sided, LOSS_SCALE * weight,
                                                  points, tri_ws, loss_out, gt_index)
     if f1:
         return loss, _f_score(sq_gt, sq_pred, num)
@@ -102,13 +102,15 @@ def batch_point_to_point(pred_vert, adj_info, gt_points, num=1000, f1=False, dra
     return _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, True, loss_out)
 
 
-def batch_point_to_surface(pred_vert, adj_info, gt_points, num=1000, f1=False, draws=None, loss_out=None, gt_index=None):
+def batch_point_to_surface(pred_vert, adj_info, gt_points, num=1000, f1=False, draws=None, loss_out=None, gt_index=None,
+                           weight=1.0):
     """Chamfer (prediction -> gt) + point-to-surface (gt -> mesh) loss (reference utils.py:441-502); `draws`, `loss_out`
     as for batch_point_to_point.  gt_index (optional, an ops.GtIndex built once for `gt_points`): the Chamfer tiles take
     the culled scan and the draw launch generates the samples in face-visiting order (other, equally distributed draws than
     without the index: sorted uniforms from exponential spacings); on the same draws loss and gradients are those of the plain
-    route, bit for bit (tests/test_ops_parity_gpu.py)."""
-    return _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, False, loss_out, gt_index)
+    route, bit for bit (tests/test_ops_parity_gpu.py).  weight (not a reference argument): a factor folded into the loss's
+    own scale -- `weight * loss` without the multiply launches forward and backward (GEOMetrics.py:138: .2 / .2 / 2)."""
+    return _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, False, loss_out, gt_index, weight)
 
 
 def calc_point_to_line(p, triangles, point_options):
@@ -177,10 +179,33 @@ def batch_get_lap_info(positions, adj_info):
     return ops.Laplacian.apply(positions, csr.rowptr, csr.col, csr.inv_deg)
 
 
+def stage_regularisers(prev, cur, adj_info, lap_weight=1.0, move_weight=0.0, edge_weight=0.0):
+    """edge_weight * batch_calc_edge(cur) + lap_weight * mean(sum((lap(prev) - lap(cur))^2, 2)) + move_weight *
+    mean(sum((prev - cur)^2, 2)) with lap = batch_get_lap_info: the three regularisers the reference's driver adds per
+    deformation stage (GEOMetrics.py:147-161), as ONE autograd node with one launch per direction (ops.StageRegularisers) --
+    the same value as the driver's expressions built from batch_calc_edge / batch_get_lap_info (tests).  prev: [B,V,3] or
+    the [V,3] template.  Not a name of the reference: a driver that wants its regulariser glue off the launch count calls it."""
+    from .layers import adjacency_csr
+    csr = adjacency_csr(adj_info["adj_orig"])
+    return ops.StageRegularisers.apply(prev, cur, adj_info["faces"], csr.rowptr, csr.col, csr.inv_deg, lap_weight, move_weight,
+                                       edge_weight)
+
+
 # ------------------------------------------------ image-feature pooling (SURVEY 8f, row 3) ----
 def batch_camera_info(param):
     """Camera rotation rows [B,3,3] and position [B,3] from (azimuth deg, elevation deg, distance)
-    (reference utils.py:286-313)."""
+    (reference utils.py:286-313).  fp32 parameters on a HIP device that need no gradient: ONE launch
+    (geom_camera_info_f32: the same expressions in the same order); anything else: the torch ops below."""
+    if (torch.is_tensor(param) and param.is_cuda and param.dtype == torch.float32 and param.dim() == 2 and param.shape[1] >= 3
+            and not (param.requires_grad and torch.is_grad_enabled())):
+        from . import _lib
+        p3 = param[:, :3].contiguous()
+        b = p3.shape[0]
+        cam_mat = torch.empty(b, 3, 3, dtype=torch.float32, device=param.device)
+        cam_pos = torch.empty(b, 3, dtype=torch.float32, device=param.device)
+        with torch.cuda.device(param.device):
+            _lib.call("geom_camera_info_f32", b, p3.data_ptr(), cam_mat.data_ptr(), cam_pos.data_ptr())
+        return cam_mat, cam_pos
     theta = (math.pi * param[:, 0] / 180.0) % 360.0
     phi = (math.pi * param[:, 1] / 180.0) % 360.0
     cam_y = param[:, 2] * torch.sin(phi)

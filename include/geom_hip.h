@@ -418,6 +418,28 @@ typedef struct geom_deform_bwd {
     float *grad_res, *dz, *grad_bn_w, *grad_bn_b, *colsum;
     int vpx;
 } geom_deform_bwd;
+/* The regularisers of ONE deformation stage (GEOMetrics.py:147-161: edge term of the new positions + squared difference of
+ * the Laplacian coordinates of the previous and the new positions + their squared displacement) in one launch per direction
+ * (csrc/regularizers.hip).  forward: partial[geom_stage_regularisers_blocks(b, nv, nf)] = per-workgroup sums of
+ *     c_edge * sum_faces(|e1|^2 + |e2|^2 + |e3|^2)(cur) + c_lap * sum_v |lap(prev - cur)|^2 + c_move * sum_v |prev - cur|^2
+ * (finish with geom_sum_f32; fold the means' 1 / counts into the c_*), lapd [b,nv,3] = lap(prev - cur) for the backward.
+ * prev [b,nv,3] (prev_batched != 0) or one [nv,3] mesh for the whole batch; (rowptr, col, inv_deg) as geom_laplacian_f32.
+ * backward: grad_cur (and grad_prev, batched prev only) of gout[0] * that sum; (vf_ptr [nv+1], vf_item) = every vertex's
+ * incident corners as face * 4 + corner, ascending: the edge gradient is a gather, no float atomics. */
+int64_t geom_stage_regularisers_blocks(int b, int nv, int nf);
+int geom_stage_regularisers_fwd_f32(int b, int nv, const float *prev, int prev_batched, const float *cur, int nf,
+                                    const int64_t *faces, const int *rowptr, const int *col, const float *inv_deg,
+                                    float c_lap, float c_move, float c_edge, float *lapd, float *partial, void *stream);
+int geom_stage_regularisers_bwd_f32(int b, int nv, const float *prev, int prev_batched, const float *cur, int nf,
+                                    const int64_t *faces, const int *rowptr, const int *col, const float *inv_deg,
+                                    const int *vf_ptr, const int *vf_item, float c_lap, float c_move, float c_edge,
+                                    const float *lapd, const float *gout, float *grad_prev, float *grad_cur, void *stream);
+
+/* Camera of every image from param [b,3] = (azimuth deg, elevation deg, distance) (reference utils.py:286-313: ~35 tiny
+ * torch launches per call, three calls per training step): cam_mat [b,3,3] (rows = the camera's normalised x, y, z axes),
+ * cam_pos [b,3] -- the operands of geom_pool_features_*; the same fp32 expressions in the same order, one launch. */
+int geom_camera_info_f32(int b, const float *param, float *cam_mat, float *cam_pos, void *stream);
+
 #define GEOM_DEFORM_MAX_PACK 16
 #define GEOM_DEFORM_TAIL 32
 /* fwd[l] / bwd[l] ([count, 36864] floats each; either may be NULL): w[l] / w[l]^T ([192,192] row-major device matrices, `w` a

@@ -482,6 +482,49 @@ def test_regularisers_match_reference_fixture(gpu):
     close(v2.grad.cpu().numpy(), g["grad_verts_edge"], 1e-4)
 
 
+@pytest.mark.parametrize("mesh", ["uv_sphere_482", "icosphere_162"])
+@pytest.mark.parametrize("template_prev", [False, True])
+def test_stage_regularisers_against_the_drivers_expressions(gpu, mesh, template_prev):
+    """utils.stage_regularisers (one launch per direction) against the expressions the reference's driver builds per
+    deformation stage (GEOMetrics.py:147-161) from batch_calc_edge / batch_get_lap_info (utils.py:636-662), evaluated in
+    FLOAT64 on the host through the oracle's restatements: the value (1e-6) and the gradients with respect to both position
+    tensors (1e-5 of scale); on the 482-vertex template (two 33-entry adjacency rows, faces of very different sizes) and an
+    icosphere; prev = another batch of positions (stages 2, 3) or the [V,3] template (stage 1)."""
+    V, Fc = meshgen.uv_sphere() if mesh == "uv_sphere_482" else meshgen.icosphere(2)
+    faces = torch.from_numpy(Fc).to(gpu)
+    info = utils.adj_init(faces)
+    nv, b = V.shape[0], 5
+    torch.manual_seed(13)
+    base = torch.from_numpy(V).to(gpu)
+    cur = (base.unsqueeze(0) + 0.05 * torch.randn(b, nv, 3, device=gpu)).requires_grad_(True)
+    prev = base if template_prev else (base.unsqueeze(0) + 0.05 * torch.randn(b, nv, 3, device=gpu)).requires_grad_(True)
+    w_lap, w_move, w_edge = 300.0, 20.0, 300.0
+    loss = utils.stage_regularisers(prev, cur, info, lap_weight=w_lap, move_weight=w_move, edge_weight=w_edge)
+    loss.backward()
+    adj_orig = info["adj_orig"].double().cpu()
+    c64 = cur.detach().double().cpu().requires_grad_(True)
+    p64 = prev.detach().double().cpu().requires_grad_(not template_prev)
+    lap = lambda x: ref_ops.lap_info(x, adj_orig)
+    ref = (w_edge * ref_ops.calc_edge(c64, faces.cpu()) + w_lap * torch.mean(torch.sum((lap(p64) - lap(c64)) ** 2, 2 if not template_prev else -1))
+           + w_move * torch.mean(torch.sum((p64 - c64) ** 2, -1)))
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-6 * abs(ref.item()), (loss.item(), ref.item())
+    close(cur.grad.cpu().numpy(), c64.grad.numpy(), 1e-5)
+    if not template_prev:
+        close(prev.grad.cpu().numpy(), p64.grad.numpy(), 1e-5)
+    # ... and the composition of the separate operators on the device gives the same number
+    eager = (utils.batch_calc_edge(cur.detach(), info) * w_edge
+             + torch.mean(torch.sum((utils.batch_get_lap_info(prev.detach(), info) - utils.batch_get_lap_info(cur.detach(), info)) ** 2, -1)) * w_lap
+             + torch.mean(torch.sum((prev.detach() - cur.detach()) ** 2, -1)) * w_move)
+    assert abs(loss.item() - eager.item()) <= 1e-5 * abs(eager.item())
+    # the weighted surface loss is the loss times its weight
+    gt = torch.from_numpy(np.ascontiguousarray(meshgen.gt_cloud(b, 500, first=3))).to(gpu)
+    ch, u, v = ops.draw_samples(cur.detach(), faces, 400)
+    a = utils.batch_point_to_surface(cur.detach(), info, gt, num=400, draws=(ch, u, v))
+    w = utils.batch_point_to_surface(cur.detach(), info, gt, num=400, draws=(ch, u, v), weight=0.2)
+    assert abs(w.item() - 0.2 * a.item()) <= 1e-6 * abs(a.item())
+
+
 def test_laplacian_on_the_reference_template_mesh(gpu):
     """482.obj has two degree-32 poles: long CSR rows, and the dense product as the checker."""
     g = golden("adj_482")
@@ -967,6 +1010,20 @@ def test_batched_pooling_matches_reference_fixture(gpu):
     close(verts.grad.cpu().numpy(), g["grad_verts"], 2e-4)
     # clamped vertices exist in the fixture (zero position gradient through the clamp) and are reproduced
     assert (np.abs(g["grad_verts"]).sum(-1) == 0).any()
+
+
+def test_camera_kernel_against_the_torch_expressions(gpu):
+    """utils.batch_camera_info on device parameters is ONE launch (geom_camera_info_f32) evaluating the reference's
+    expressions (utils.py:286-313) in the same order; against the torch-op form of the same lines (what a parameter tensor
+    that requires a gradient still takes), negative and > 360 degree angles included (the `%` is torch.remainder)."""
+    torch.manual_seed(12)
+    param = torch.stack((torch.rand(64) * 1200 - 400, torch.rand(64) * 160 - 80, torch.rand(64) * 2 + 0.5), dim=1).to(gpu)
+    cam_mat, cam_pos = utils.batch_camera_info(param)
+    ref_mat, ref_pos = utils.batch_camera_info(param.clone().requires_grad_(True))       # the torch expressions
+    close(cam_mat.cpu().numpy(), ref_mat.detach().cpu().numpy(), 2e-6)
+    close(cam_pos.cpu().numpy(), ref_pos.detach().cpu().numpy(), 2e-6)
+    eye = torch.matmul(cam_mat, cam_mat.transpose(1, 2)).cpu()
+    assert float((eye - torch.eye(3)).abs().max()) < 1e-5                                 # orthonormal rows
 
 
 def test_pooling_with_more_channel_chunks_than_grid_slices(gpu):

@@ -10,3 +10,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ds -o t -- python $
 cd $ROOT
 python tools/shorten_stats.py $(ls /tmp/ds/*/t_kernel_stats.csv /tmp/ds/t_kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_driver_step_kernel_stats.csv
 python tools/driver_step_timeline.py /tmp/ds $OUT/${TAG}_driver_step_timeline.txt
+python tools/driver_step_sequence.py /tmp/ds $OUT/${TAG}_driver_step_sequence.txt

@@ -1,0 +1,17 @@
+"""Dev helper: bench.driver_step_times (HIP-graph replay of the reference driver's step) with the fused deformation-block
+launches on and off:   python tools/time_driver_step.py [--zero-edit]"""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from geometrics_amd import deform, gemm_tuning
+dev = torch.device("cuda:0")
+gemm_tuning.enable()
+bench.settle_clocks(dev, 250)
+for fused in (True, False, True):
+    deform.enabled = fused
+    r = bench.driver_step_times(dev)
+    print("fused hidden layers %-5s  ms_per_step %.4f  %s" % (fused, r["ms_per_step"], json.dumps(r["stages_us"])))
+deform.enabled = True
+if "--zero-edit" in sys.argv:
+    print(json.dumps(bench.driver_step_times(dev, zero_edit=True)))
