@@ -34,16 +34,24 @@ def read(names):
     buf = np.zeros(1024 * 16, dtype=np.uint64)
     assert L.geom_db_probe_read(buf.ctypes.data, buf.size) == 0
     st = buf.reshape(1024, 16)[:grid].astype(np.int64)
-    live = st[:, 0] > 0
+    end = len(names)
+    live = (st[:, end] > st[:, 0]) & (st[:, 0] > 0)          # workgroups that ran (the grid is padded to 8 * ceil(nv / 8))
+    # the counters of different XCDs are not synchronised: offsets are taken inside each XCD (workgroup w runs on XCD w % 8)
+    xcd = (np.arange(grid) % 8)[live]
     st = st[live]
-    t0 = st[:, 0].min()
-    print("  workgroups %d, launch span (first start -> last end) %.2f us (100 MHz clock)" % (len(st), (st[:, len(names)].max() - t0) / 100.0))
-    print("  start offsets: mean %.2f us, max %.2f us" % ((st[:, 0] - t0).mean() / 100.0, (st[:, 0] - t0).max() / 100.0))
+    for x in range(8):
+        st[xcd == x] -= st[xcd == x][:, 0].min()
+    t0 = 0
+    # s_memtime counts shader-engine clocks (the 144 MFMAs of a wave = 4 608 issue cycles show as ~5 000): cycles, not time
+    print("  workgroups %d, first start -> last end %d cycles" % (len(st), st[:, end].max() - t0))
+    so = st[:, 0] - t0
+    print("  start offsets: mean %d  p90 %d  max %d cycles;  end offsets: p10 %d  mean %d  max %d" % (
+        so.mean(), np.percentile(so, 90), so.max(), np.percentile(st[:, end] - t0, 10), (st[:, end] - t0).mean(), (st[:, end] - t0).max()))
     for i, n in enumerate(names):
-        d = (st[:, i + 1] - st[:, i]) / 100.0
-        print("  %-46s mean %6.2f  p90 %6.2f  max %6.2f us" % (n, d.mean(), np.percentile(d, 90), d.max()))
-    d = (st[:, len(names)] - st[:, 0]) / 100.0
-    print("  %-46s mean %6.2f  p90 %6.2f  max %6.2f us" % ("workgroup total", d.mean(), np.percentile(d, 90), d.max()))
+        d = st[:, i + 1] - st[:, i]
+        print("  %-46s mean %6d  p90 %6d  max %6d cycles" % (n, d.mean(), np.percentile(d, 90), d.max()))
+    d = st[:, end] - st[:, 0]
+    print("  %-46s mean %6d  p90 %6d  max %6d cycles" % ("workgroup total", d.mean(), np.percentile(d, 90), d.max()))
 
 
 def fwd():
