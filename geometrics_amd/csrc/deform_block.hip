@@ -19,10 +19,10 @@
 // Why this tiling: BatchNorm1d(verts) normalises a vertex over (batch, channel), so the natural tile is "all batch rows of one
 // vertex" -- exactly M = 16 of the fp32 MFMA -- and the only cross-tile dependencies of a layer are the two gathers
 // (neighbours' support rows forward, neighbours' dZ rows backward), which is where the launch boundaries sit.  The weight
-// operand follows zn_stack.hip: a wave owns 48 output columns and holds its 192 x 48 slice in 144 registers (from a copy
-// packed in that order once per step), the activation tile goes through the same conflict-free [k-quarter][row][52] LDS
-// panel, one ds_read_b128 per 12 MFMAs.  One workgroup of 4 waves per CU walks a run of vertices with the NEXT vertex's rows in
-// flight under the current vertex's statistics and MFMAs (see db_fwd_kernel).
+// operand follows zn_stack.hip: a wave owns 48 output columns and holds its 192 x 48 slice in 144 registers, requested at
+// kernel start so that it lands under the gather round trips; the activation tile goes through the same conflict-free
+// [k-quarter][row][52] LDS panel, one ds_read_b128 per 12 MFMAs.  482 workgroups of 4 waves, two resident per CU: while one
+// waits for its gathers the other runs its 144 MFMAs per wave.
 #include "geom_common.h"
 
 namespace {
@@ -74,6 +74,14 @@ __device__ __forceinline__ void db_st4(__amdgpu_buffer_rsrc_t r, unsigned off, f
                                            r, off, 0, 0);
 }
 
+// workgroup w -> vertex: contiguous vertex runs per XCD (workgroup w runs on XCD w % 8; a support row is gathered by its ~7
+// neighbours, which are mostly near it in the numbering, so a run's rows stay in one L2)
+__device__ __forceinline__ int db_vertex(int w, int vpx, int nv)
+{
+    const int v = (w & 7) * vpx + (w >> 3);
+    return ((w >> 3) < vpx && v < nv) ? v : -1;
+}
+
 // fixed-order block reduction of two values: wave shuffles, then the four wave partials in order
 __device__ __forceinline__ void db_sum2(float &a, float &b, float *red)
 {
@@ -104,11 +112,7 @@ __device__ __forceinline__ void db_load_slice(DbSlice &bw, const float *packed, 
     const unsigned b0 = ((unsigned)(wave * 36) * 64u + (unsigned)lane) * 16u;
 #pragma unroll
     for (int i = 0; i < 36; ++i) {
-#ifdef DB_PROBE_HOT_SLICE
-        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r_b, b0 + (unsigned)(i & 1) * 1024u, 0, 0); // probe: 2 KB per wave (L1 hits)
-#else
         const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r_b, b0 + (unsigned)i * 1024u, 0, 0);
-#endif
         bw.q[i] = (f32x4){__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
     }
 }
@@ -128,9 +132,6 @@ __device__ __forceinline__ void db_product(const DbSlice &bw, const float *panel
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-#ifdef DB_PROBE_FEW_MFMA
-            if (jp >= 2) continue; // probe: a sixth of the MFMAs (wrong results)
-#endif
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.at(jp, c, 0), af[c], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.at(jp, c, 1), af[c], acc[1], 0, 0, 0);
             acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.at(jp, c, 2), af[c], acc[2], 0, 0, 0);
@@ -171,70 +172,76 @@ __global__ __launch_bounds__(256) void db_pack_kernel(DbPackArgs a)
     if (out) out[(size_t)layer * DB_C * DB_C + r] = dir ? w[col * DB_C + k] : w[k * DB_C + col]; // bwd: the slice of W^T
 }
 
-// ---- a vertex's operand rows: requested (db_issue) and summed (db_accumulate) in two steps -----------------------------------
-// A workgroup walks SEVERAL vertices and keeps the next vertex's rows in flight while it finishes the current one (see the
-// kernels), so requesting and consuming are separate.  The aggregated float4 of thread (row rl, group j) of vertex v is the sum
-// over the vertex's table entries, then its CSR tail, of val * src[mesh rl][neighbour][4 j ..] -- the order and arithmetic of
-// zn_aggregate_ell_kernel (a padded slot adds -0.0: no value changes, signed zeros included).  Rows beyond the batch pass
+// The aggregated float4 of thread (row rl, group j) of vertex v: sum over the vertex's table entries, then its CSR tail, of
+// val * src[mesh rl][neighbour][4 j ..] -- the order and arithmetic of zn_aggregate_ell_kernel (a padded slot adds -0.0: no
+// value changes, signed zeros included).  `rowbase` = byte offset of mesh rl's first row; rows beyond the batch pass
 // mesh_on = false and read zeros.
 // The tail (a vertex with more entries than the table: the 33-entry poles of 482.obj) comes as a second, 32-wide table row
 // [nv][DB_TAIL] (-1 = padding) that lanes 0..31 of every wave load with ONE vector load in the round trip of the table's
-// scalar loads; a pole's extra neighbour rows are then requested all at once (a pole that walked its tail eight entries per
-// dependent round trip took 3 x the time of every other vertex: tools/probe/db_stamps.py).
-struct DbGather {
-    int nb[DB_W];
-    float wv[DB_W];
-    float4 sv[DB_W], own[2];
-    int tcol;
-    float tval;
-};
-
-__device__ __forceinline__ void db_issue(DbGather &g, __amdgpu_buffer_rsrc_t r_src, bool mesh_on, unsigned rowbase, int v, int c0,
-                                         const int *ell_col, const float *ell_val, const int *tail_col, const float *tail_val, int lane)
+// scalar loads, so a pole's extra neighbour rows are requested TOGETHER with its table rows: the launch ends with its slowest
+// workgroup, and a pole that walked its tail eight entries per dependent round trip took 3 x the time of every other vertex
+// (26 000 cycles in the gather phase against 8 500: tools/probe/db_stamps.py).
+template <bool SLICE>
+__device__ __forceinline__ float4 db_aggregate(__amdgpu_buffer_rsrc_t r_src, bool mesh_on, unsigned rowbase, int v, int c0,
+                                               const int *ell_col, const float *ell_val, const int *tail_col, const float *tail_val,
+                                               float4 *own, DbSlice &bw, const float *packed, int wave, int lane)
 {
-    g.tcol = -1, g.tval = 0.f;
+    // round trip 1: the vertex's table entries (scalar loads: the same for every thread of the workgroup) + its tail row
+    int tcol = -1;
+    float tval = 0.f;
     if (tail_col) {
-        g.tcol = tail_col[(size_t)v * DB_TAIL + (lane & (DB_TAIL - 1))];
-        g.tval = tail_val[(size_t)v * DB_TAIL + (lane & (DB_TAIL - 1))];
+        tcol = tail_col[(size_t)v * DB_TAIL + (lane & (DB_TAIL - 1))];
+        tval = tail_val[(size_t)v * DB_TAIL + (lane & (DB_TAIL - 1))];
     }
-    // the vertex's table entries: the same for every thread of the workgroup (scalar loads: a counter of their own)
     const int4 ci0 = *reinterpret_cast<const int4 *>(ell_col + (size_t)v * DB_W), ci1 = *reinterpret_cast<const int4 *>(ell_col + (size_t)v * DB_W + 4);
     const float4 wi0 = *reinterpret_cast<const float4 *>(ell_val + (size_t)v * DB_W), wi1 = *reinterpret_cast<const float4 *>(ell_val + (size_t)v * DB_W + 4);
-    g.nb[0] = ci0.x, g.nb[1] = ci0.y, g.nb[2] = ci0.z, g.nb[3] = ci0.w, g.nb[4] = ci1.x, g.nb[5] = ci1.y, g.nb[6] = ci1.z, g.nb[7] = ci1.w;
-    g.wv[0] = wi0.x, g.wv[1] = wi0.y, g.wv[2] = wi0.z, g.wv[3] = wi0.w, g.wv[4] = wi1.x, g.wv[5] = wi1.y, g.wv[6] = wi1.z, g.wv[7] = wi1.w;
+    const int nb[DB_W] = {ci0.x, ci0.y, ci0.z, ci0.w, ci1.x, ci1.y, ci1.z, ci1.w};
+    const float wv[DB_W] = {wi0.x, wi0.y, wi0.z, wi0.w, wi1.x, wi1.y, wi1.z, wi1.w};
+    // round trip 2: the neighbour rows + the thread's own pass-through elements
+    float4 sv[DB_W];
 #pragma unroll
     for (int n = 0; n < DB_W; ++n) {
-        const unsigned off = rowbase + (unsigned)(g.nb[n] >= 0 ? g.nb[n] : v) * (DB_C * 4) + 4 * c0;
-        g.sv[n] = db_ld4(r_src, mesh_on ? off : DB_OOB);
+        const unsigned off = rowbase + (unsigned)(nb[n] >= 0 ? nb[n] : v) * (DB_C * 4) + 4 * c0;
+        sv[n] = db_ld4(r_src, mesh_on ? off : DB_OOB);
     }
     const unsigned own_off = rowbase + (unsigned)v * (DB_C * 4) + 4 * c0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) g.own[i] = db_ld4(r_src, mesh_on ? own_off + 4 * DB_K * (i + 1) : DB_OOB);
-}
-
-__device__ __forceinline__ float4 db_accumulate(const DbGather &g, __amdgpu_buffer_rsrc_t r_src, bool mesh_on, unsigned rowbase, int c0)
-{
+    for (int i = 0; i < 2; ++i) own[i] = db_ld4(r_src, mesh_on ? own_off + 4 * DB_K * (i + 1) : DB_OOB);
     float4 facc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto table_terms = [&]() {
 #pragma unroll
-    for (int n = 0; n < DB_W; ++n) {
-        const bool in = g.nb[n] >= 0;
-        const float tx = g.wv[n] * g.sv[n].x, ty = g.wv[n] * g.sv[n].y, tz = g.wv[n] * g.sv[n].z, tw = g.wv[n] * g.sv[n].w;
-        facc.x += in ? tx : -0.0f, facc.y += in ? ty : -0.0f, facc.z += in ? tz : -0.0f, facc.w += in ? tw : -0.0f;
+        for (int n = 0; n < DB_W; ++n) {
+            const bool in = nb[n] >= 0;
+            const float tx = wv[n] * sv[n].x, ty = wv[n] * sv[n].y, tz = wv[n] * sv[n].z, tw = wv[n] * sv[n].w;
+            facc.x += in ? tx : -0.0f, facc.y += in ? ty : -0.0f, facc.z += in ? tz : -0.0f, facc.w += in ? tw : -0.0f;
+        }
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    const bool has_tail = tail_col && __builtin_amdgcn_readfirstlane(tcol) >= 0; // (uniform: entry 0 of the tail row)
+    if (!has_tail) { // every vertex of an icosphere, all but the two poles of 482.obj
+        if (SLICE) db_load_slice(bw, packed, wave, lane); // behind the gathers (in-order memory counter: see the callers)
+        __builtin_amdgcn_sched_barrier(0);
+        table_terms();
+        return facc;
     }
-    if (__builtin_amdgcn_readfirstlane(g.tcol) < 0) return facc; // (uniform) no tail: every vertex of an icosphere, all but two of 482.obj
+    // the tail rows, all in flight at once; the weight slice behind them (its registers hold the tail's rows until then)
     float4 tv[DB_TAIL];
 #pragma unroll
     for (int n = 0; n < DB_TAIL; ++n) {
-        const int col = __builtin_amdgcn_readlane(g.tcol, n);
+        const int col = __builtin_amdgcn_readlane(tcol, n);
         tv[n] = db_ld4(r_src, (mesh_on && col >= 0) ? rowbase + (unsigned)col * (DB_C * 4) + 4 * c0 : DB_OOB);
     }
+    table_terms(); // summation order: the table's slots, then the tail, in CSR order
 #pragma unroll
-    for (int n = 0; n < DB_TAIL; ++n) { // summation order: the table's slots (above), then the tail, in CSR order
-        const bool in = __builtin_amdgcn_readlane(g.tcol, n) >= 0;
-        const float wn = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(g.tval), n));
+    for (int n = 0; n < DB_TAIL; ++n) {
+        const bool in = __builtin_amdgcn_readlane(tcol, n) >= 0;
+        const float wn = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(tval), n));
         const float tx = wn * tv[n].x, ty = wn * tv[n].y, tz = wn * tv[n].z, tw = wn * tv[n].w;
         facc.x += in ? tx : -0.0f, facc.y += in ? ty : -0.0f, facc.z += in ? tz : -0.0f, facc.w += in ? tw : -0.0f;
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (SLICE) db_load_slice(bw, packed, wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
     return facc;
 }
 
@@ -247,325 +254,233 @@ __device__ __forceinline__ void db_to_panel(float *panel, int rl, int c0, const 
     }
 }
 
-// Workgroup w of G -> its run of vertices [first, first + count): balanced contiguous runs, dealt so that the workgroups of one
-// XCD (w % 8) hold neighbouring runs (a support row is gathered by its ~7 neighbours, mostly near it in the numbering: a
-// run's rows stay in one L2).  G is a multiple of 8 (the host rounds it).
-__device__ __forceinline__ void db_run(int w, int G, int nv, int &first, int &count)
-{
-    const int r = (w & 7) * (G >> 3) + (w >> 3);
-    first = (int)(((int64_t)r * nv) / G);
-    count = (int)(((int64_t)(r + 1) * nv) / G) - first;
-}
-
-// ---- forward --------------------------------------------------------------------------------------------------------------
-// One workgroup = 4 waves, ONE per SIMD, walking its run of vertices (two at the reference's training shape: 482 vertices on
-// 248 workgroups): the weight slice is loaded once per workgroup, and while vertex i goes through statistics, stores and its
-// 144 MFMAs per wave, the rows of vertex i + 1 are already in flight -- requested in front of vertex i's work, consumed behind
-// it.  (First form: one vertex per workgroup, two workgroups per CU.  They start together and reach every phase together, so
-// nothing overlapped: 15.3 us per launch, of which the MFMAs of the two co-resident waves of a SIMD 5.6 and the weight slices
-// of 482 workgroups 1.3-1.8: tools/probe/db_variants.sh.)
-struct DbFwdLoads {
-    DbGather g;
-    float4 rv[3];
-    float gamma, beta, old_mean, old_var;
-};
-
 template <bool PRODUCT>
-__global__ __launch_bounds__(DB_THREADS, 1) void db_fwd_kernel(geom_deform_fwd a)
+__global__ __launch_bounds__(DB_THREADS, 2) void db_fwd_kernel(geom_deform_fwd a)
 {
     __shared__ __attribute__((aligned(16))) float lds[DB_PANEL + DB_CST + DB_RED];
-    int first, count;
-    db_run(blockIdx.x, gridDim.x, a.nv, first, count);
-    if (count <= 0) return;
+    const int v = db_vertex(blockIdx.x, a.vpx, a.nv);
+    if (v < 0) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int x = lane & 15, g = lane >> 4; // matrix-core coordinates
     const int rl = tid >> 4, j = tid & 15;  // batch row (mesh) and float4 group of the gather / BatchNorm thread
     const int c0 = 4 * j;
+    DB_STAMP(0);
     const bool mesh_on = rl < a.b;
     const int64_t op_bytes = (int64_t)a.b * a.nv * DB_C * 4;
     const __amdgpu_buffer_rsrc_t r_src = db_rsrc(a.s_in, op_bytes);
-    const __amdgpu_buffer_rsrc_t r_res = db_rsrc(a.res, a.res ? ((int64_t)a.b * a.nv - 1) * a.res_ld * 4 + DB_C * 4 : 0);
-    const __amdgpu_buffer_rsrc_t r_z = db_rsrc(a.z_out, op_bytes), r_x = db_rsrc(a.x_out, op_bytes), r_s = db_rsrc(a.s_out, op_bytes);
     const unsigned rowbase = (unsigned)rl * (unsigned)a.nv * (DB_C * 4);
-    const int n = a.b * DB_C;
-    float *stage = lds + DB_PANEL, *red = lds + DB_PANEL + DB_CST;
-    float4 bias4[3];
+    const unsigned own_off = mesh_on ? rowbase + (unsigned)v * (DB_C * 4) + 4 * c0 : DB_OOB;
+    // the vertex's BatchNorm parameters, the bias and the residual travel with the gathers
+    const float gamma = a.bn_w ? a.bn_w[v] : 1.f, beta = a.bn_b ? a.bn_b[v] : 0.f;
+    const bool updates = a.training && tid == 0;
+    const float old_mean = (updates && a.run_mean) ? a.run_mean[v] : 0.f, old_var = (updates && a.run_var) ? a.run_var[v] : 0.f;
+    float4 bias4[3], rv[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) bias4[i] = a.bias ? *reinterpret_cast<const float4 *>(a.bias + c0 + DB_K * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-
-    auto issue = [&](DbFwdLoads &L, int v) { // everything vertex v reads, requested in one go
-        db_issue(L.g, r_src, mesh_on, rowbase, v, c0, a.ell_col, a.ell_val, a.tail_col, a.tail_val, lane);
+    for (int i = 0; i < 3; ++i) {
+        bias4[i] = a.bias ? *reinterpret_cast<const float4 *>(a.bias + c0 + DB_K * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (a.res) {
+        const __amdgpu_buffer_rsrc_t r_res = db_rsrc(a.res, ((int64_t)a.b * a.nv - 1) * a.res_ld * 4 + DB_C * 4);
         const unsigned roff = ((unsigned)rl * (unsigned)a.nv + (unsigned)v) * (unsigned)a.res_ld * 4u + 4 * c0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) L.rv[i] = a.res ? db_ld4(r_res, mesh_on ? roff + 4 * DB_K * i : DB_OOB) : make_float4(0.f, 0.f, 0.f, 0.f);
-        L.gamma = a.bn_w ? a.bn_w[v] : 1.f, L.beta = a.bn_b ? a.bn_b[v] : 0.f;
-        const bool updates = a.training && tid == 0;
-        L.old_mean = (updates && a.run_mean) ? a.run_mean[v] : 0.f, L.old_var = (updates && a.run_var) ? a.run_var[v] : 0.f;
-    };
-    DbSlice bw;
-    auto finish = [&](const DbFwdLoads &L, int v) {
-        const unsigned own_off = mesh_on ? rowbase + (unsigned)v * (DB_C * 4) + 4 * c0 : DB_OOB;
-        float4 z[3];
-        z[0] = db_accumulate(L.g, r_src, mesh_on, rowbase, c0);
-        z[1] = L.g.own[0], z[2] = L.g.own[1];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) z[i].x += bias4[i].x, z[i].y += bias4[i].y, z[i].z += bias4[i].z, z[i].w += bias4[i].w;
-        DB_STAMP(1);
-        // ---- BatchNorm1d(verts): one statistic per vertex over its b * 192 values (two-pass: mean, then the centred second moment)
-        float mean, invstd;
-        if (a.training) {
-            float s = 0.f, dummy = 0.f;
-            if (mesh_on) s = (((z[0].x + z[0].y) + (z[0].z + z[0].w)) + ((z[1].x + z[1].y) + (z[1].z + z[1].w))) + ((z[2].x + z[2].y) + (z[2].z + z[2].w));
-            db_sum2(s, dummy, red);
-            mean = s / n;
-            float q = 0.f;
-            if (mesh_on) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const float d0 = z[i].x - mean, d1 = z[i].y - mean, d2 = z[i].z - mean, d3 = z[i].w - mean;
-                    q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-                }
-            }
-            dummy = 0.f;
-            db_sum2(q, dummy, red);
-            const float var = q / n; // biased, as used for normalisation
-            invstd = 1.f / sqrtf(var + a.eps);
-            if (tid == 0) {
-                a.save_mean[v] = mean, a.save_invstd[v] = invstd;
-                if (a.run_mean) a.run_mean[v] = (1.f - a.momentum) * L.old_mean + a.momentum * mean;
-                if (a.run_var) a.run_var[v] = (1.f - a.momentum) * L.old_var + a.momentum * (n > 1 ? q / (n - 1) : var);
-            }
-        } else {
-            mean = a.run_mean[v];
-            invstd = 1.f / sqrtf(a.run_var[v] + a.eps);
-        }
-        DB_STAMP(2);
-        auto one = [&](float zz, float r) {
-            float y = (zz - mean) * invstd * L.gamma + L.beta;
-            if (a.relu) y = y > 0.f ? y : 0.f;
-            if (a.res) y = (r + y) * a.scale;
-            return mesh_on ? y : 0.f;
-        };
-        float4 xo[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            xo[i] = make_float4(one(z[i].x, L.rv[i].x), one(z[i].y, L.rv[i].y), one(z[i].z, L.rv[i].z), one(z[i].w, L.rv[i].w));
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            if (a.z_out) db_st4(r_z, own_off == DB_OOB ? DB_OOB : own_off + 4 * DB_K * i, z[i]);
-            db_st4(r_x, own_off == DB_OOB ? DB_OOB : own_off + 4 * DB_K * i, xo[i]);
-        }
-        if (!PRODUCT) return;
-        // ---- the next layer's product on the tile
-        db_to_panel(lds, rl, c0, xo);
-        DB_STAMP(3);
-        __syncthreads();
-        DB_STAMP(4);
-        db_product(bw, lds, stage, wave, x, g);
-        DB_STAMP(5);
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 3; ++t) { // the tile leaves in memory order: 768 contiguous bytes per mesh row
-            const int idx = tid + DB_THREADS * t, r = idx / 48, c4 = idx % 48;
-            const f32x4 val = *reinterpret_cast<const f32x4 *>(stage + r * DB_LDC + 4 * c4);
-            const unsigned off = r < a.b ? ((unsigned)r * (unsigned)a.nv + (unsigned)v) * (DB_C * 4) + 16u * c4 : DB_OOB;
-            db_st4(r_s, off, make_float4(val[0], val[1], val[2], val[3]));
-        }
-        DB_STAMP(6);
-    };
-
-    DB_STAMP(0);
-    DbFwdLoads La, Lb; // used alternately (two vertices per trip, so that they are compile-time names)
-    issue(La, first);
-    __builtin_amdgcn_sched_barrier(0);
-    // the weight slice BEHIND the first vertex's rows: the vector-memory counter retires in order, a wave that asked for its
-    // 36 KB of weights first would wait for them in front of its first gather
-    if (PRODUCT) db_load_slice(bw, a.w_next, wave, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    int it = 0;
-    for (; it + 1 < count; it += 2) {
-        issue(Lb, first + it + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        finish(La, first + it);
-        __builtin_amdgcn_sched_barrier(0);
-        if (it + 2 < count) issue(La, first + it + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        finish(Lb, first + it + 1);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < 3; ++i) rv[i] = db_ld4(r_res, mesh_on ? roff + 4 * DB_K * i : DB_OOB);
     }
-    if (it < count) finish(La, first + it);
+    // The weight slice is requested BEHIND the gathers: the vector-memory counter retires in order, so a wave that asked for
+    // its 36 KB of weights first would wait for them in front of every gather (the table entries come by scalar loads, which
+    // have a counter of their own); in this order the statistics run while the slice is still on its way.
+    DbSlice bw;
+    float4 z[3];
+    z[0] = db_aggregate<PRODUCT>(r_src, mesh_on, rowbase, v, c0, a.ell_col, a.ell_val, a.tail_col, a.tail_val, &z[1], bw, a.w_next, wave, lane);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) z[i].x += bias4[i].x, z[i].y += bias4[i].y, z[i].z += bias4[i].z, z[i].w += bias4[i].w;
+
+    DB_STAMP(1); // gathers arrived (z holds the aggregated row)
+    // ---- BatchNorm1d(verts): one statistic per vertex over its b * 192 values (two-pass: mean, then the centred second moment)
+    float *red = lds + DB_PANEL + DB_CST;
+    const int n = a.b * DB_C;
+    float mean, invstd;
+    if (a.training) {
+        float s = 0.f, dummy = 0.f;
+        if (mesh_on) s = (((z[0].x + z[0].y) + (z[0].z + z[0].w)) + ((z[1].x + z[1].y) + (z[1].z + z[1].w))) + ((z[2].x + z[2].y) + (z[2].z + z[2].w));
+        db_sum2(s, dummy, red);
+        mean = s / n;
+        float q = 0.f;
+        if (mesh_on) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float d0 = z[i].x - mean, d1 = z[i].y - mean, d2 = z[i].z - mean, d3 = z[i].w - mean;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        }
+        dummy = 0.f;
+        db_sum2(q, dummy, red);
+        const float var = q / n; // biased, as used for normalisation
+        invstd = 1.f / sqrtf(var + a.eps);
+        if (tid == 0) {
+            a.save_mean[v] = mean, a.save_invstd[v] = invstd;
+            if (a.run_mean) a.run_mean[v] = (1.f - a.momentum) * old_mean + a.momentum * mean;
+            if (a.run_var) a.run_var[v] = (1.f - a.momentum) * old_var + a.momentum * (n > 1 ? q / (n - 1) : var);
+        }
+    } else {
+        mean = a.run_mean[v];
+        invstd = 1.f / sqrtf(a.run_var[v] + a.eps);
+    }
+    DB_STAMP(2); // statistics done
+    auto finish = [&](float zz, float r) {
+        float y = (zz - mean) * invstd * gamma + beta;
+        if (a.relu) y = y > 0.f ? y : 0.f;
+        if (a.res) y = (r + y) * a.scale;
+        return mesh_on ? y : 0.f;
+    };
+    float4 xo[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        xo[i] = make_float4(finish(z[i].x, rv[i].x), finish(z[i].y, rv[i].y), finish(z[i].z, rv[i].z), finish(z[i].w, rv[i].w));
+    const __amdgpu_buffer_rsrc_t r_z = db_rsrc(a.z_out, op_bytes), r_x = db_rsrc(a.x_out, op_bytes);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (a.z_out) db_st4(r_z, own_off == DB_OOB ? DB_OOB : own_off + 4 * DB_K * i, z[i]);
+        db_st4(r_x, own_off == DB_OOB ? DB_OOB : own_off + 4 * DB_K * i, xo[i]);
+    }
+    if (!PRODUCT) return;
+
+    // ---- the next layer's product on the tile
+    db_to_panel(lds, rl, c0, xo);
+    DB_STAMP(3); // outputs requested, panel written
+    __syncthreads();
+    DB_STAMP(4);
+    float *stage = lds + DB_PANEL;
+#ifdef DB_PROBE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // probe: separate the wait for the weight slice from the MFMAs
+    DB_STAMP(5);
+#endif
+    db_product(bw, lds, stage, wave, x, g);
+    DB_STAMP(6); // MFMAs issued + staged
+    __syncthreads();
     DB_STAMP(7);
+    const __amdgpu_buffer_rsrc_t r_s = db_rsrc(a.s_out, op_bytes);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { // the tile leaves in memory order: 768 contiguous bytes per mesh row
+        const int idx = tid + DB_THREADS * t, r = idx / 48, c4 = idx % 48;
+        const f32x4 val = *reinterpret_cast<const f32x4 *>(stage + r * DB_LDC + 4 * c4);
+        const unsigned off = r < a.b ? ((unsigned)r * (unsigned)a.nv + (unsigned)v) * (DB_C * 4) + 16u * c4 : DB_OOB;
+        db_st4(r_s, off, make_float4(val[0], val[1], val[2], val[3]));
+    }
+    DB_STAMP(8);
 }
 
-// ---- backward -------------------------------------------------------------------------------------------------------------
-struct DbBwdLoads {
-    DbGather g;
-    float4 zv[3], g2v[3], gv[3];
-    float mean, invstd, gamma, beta;
-};
-
 template <bool PRODUCT>
-__global__ __launch_bounds__(DB_THREADS, 1) void db_bwd_kernel(geom_deform_bwd a)
+__global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_kernel(geom_deform_bwd a)
 {
     __shared__ __attribute__((aligned(16))) float lds[DB_PANEL + DB_CST + DB_RED];
-    int first, count;
-    db_run(blockIdx.x, gridDim.x, a.nv, first, count);
-    if (count <= 0) return;
+    const int v = db_vertex(blockIdx.x, a.vpx, a.nv);
+    if (v < 0) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int x = lane & 15, g = lane >> 4;
     const int rl = tid >> 4, j = tid & 15;
     const int c0 = 4 * j;
+    DB_STAMP(0);
     const bool mesh_on = rl < a.b;
     const int64_t op_bytes = (int64_t)a.b * a.nv * DB_C * 4;
     const unsigned rowbase = (unsigned)rl * (unsigned)a.nv * (DB_C * 4);
+    const unsigned own_off = mesh_on ? rowbase + (unsigned)v * (DB_C * 4) + 4 * c0 : DB_OOB;
+    auto at = [&](int i) { return own_off == DB_OOB ? DB_OOB : own_off + 4 * DB_K * i; };
+    // everything this layer's BatchNorm backward reads is requested with the gathers
     const __amdgpu_buffer_rsrc_t r_z = db_rsrc(a.z, op_bytes), r_g2 = db_rsrc(a.g2, op_bytes), r_g = db_rsrc(a.g, op_bytes);
-    const __amdgpu_buffer_rsrc_t r_src = db_rsrc(a.dz_up, op_bytes), r_ds = db_rsrc(a.ds_up, op_bytes);
-    const __amdgpu_buffer_rsrc_t r_gr = db_rsrc(a.grad_res, op_bytes), r_dz = db_rsrc(a.dz, op_bytes);
-    const int n = a.b * DB_C;
-    float *stage = lds + DB_PANEL, *red = lds + DB_PANEL + DB_CST;
-
-    auto issue = [&](DbBwdLoads &L, int v) { // the layer above's gradient rows AND everything this layer's BatchNorm backward reads
-        if (PRODUCT) db_issue(L.g, r_src, mesh_on, rowbase, v, c0, a.ell_col_t, a.ell_val_t, a.tail_col_t, a.tail_val_t, lane);
-        const unsigned own_off = mesh_on ? rowbase + (unsigned)v * (DB_C * 4) + 4 * c0 : DB_OOB;
+    const float mean = a.save_mean[v], invstd = a.save_invstd[v];
+    const float gamma = a.bn_w ? a.bn_w[v] : 1.f, beta = a.bn_b ? a.bn_b[v] : 0.f;
+    float4 zv[3], g2v[3], go[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const unsigned off = own_off == DB_OOB ? DB_OOB : own_off + 4 * DB_K * i;
-            L.zv[i] = db_ld4(r_z, off);
-            L.g2v[i] = a.g2 ? db_ld4(r_g2, off) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!PRODUCT) L.gv[i] = db_ld4(r_g, off);
-        }
-        L.mean = a.save_mean[v], L.invstd = a.save_invstd[v];
-        L.gamma = a.bn_w ? a.bn_w[v] : 1.f, L.beta = a.bn_b ? a.bn_b[v] : 0.f;
-    };
-    DbSlice bw;
-    auto finish = [&](const DbBwdLoads &L, int v) {
-        const unsigned own_off = mesh_on ? rowbase + (unsigned)v * (DB_C * 4) + 4 * c0 : DB_OOB;
-        auto at = [&](int i) { return own_off == DB_OOB ? DB_OOB : own_off + 4 * DB_K * i; };
-        float4 go[3];
-        if (PRODUCT) {
-            // ---- aggregation backward of the layer above: G = [A^T . dZ_up[:, :64] | dZ_up[:, 64:]]
-            float4 gs[3];
-            gs[0] = db_accumulate(L.g, r_src, mesh_on, rowbase, c0);
-            gs[1] = L.g.own[0], gs[2] = L.g.own[1];
+    for (int i = 0; i < 3; ++i) {
+        zv[i] = db_ld4(r_z, at(i));
+        g2v[i] = a.g2 ? db_ld4(r_g2, at(i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!PRODUCT) go[i] = db_ld4(r_g, at(i));
+    }
+    float *stage = lds + DB_PANEL;
+    if (PRODUCT) {
+        // ---- aggregation backward of the layer above: G = [A^T . dZ_up[:, :64] | dZ_up[:, 64:]]
+        const __amdgpu_buffer_rsrc_t r_src = db_rsrc(a.dz_up, op_bytes), r_ds = db_rsrc(a.ds_up, op_bytes);
+        float4 gs[3];
+        DbSlice bw;
+        gs[0] = db_aggregate<true>(r_src, mesh_on, rowbase, v, c0, a.ell_col_t, a.ell_val_t, a.tail_col_t, a.tail_val_t, &gs[1], bw, a.wt_up, wave, lane);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) db_st4(r_ds, at(i), gs[i]); // the layer above's weight gradient reads it (X^T . G)
-            db_to_panel(lds, rl, c0, gs);                           // (rows beyond the batch read zeros: zero rows of the tile)
-            DB_STAMP(1);
-            __syncthreads();
-            DB_STAMP(2);
-            db_product(bw, lds, stage, wave, x, g);                 // dX = G . W_up^T
-            DB_STAMP(3);
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const f32x4 t = *reinterpret_cast<const f32x4 *>(stage + rl * DB_LDC + c0 + DB_K * i);
-                go[i] = make_float4(t[0], t[1], t[2], t[3]);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) go[i] = L.gv[i];
-        }
-        // ---- this layer: residual scale, ReLU mask, BatchNorm backward
-        float sum_g = 0.f, sum_gx = 0.f;
-        float4 xh[3];
-        auto one = [&](float zz, float &gg, float second, float &xhat) {
-            xhat = (zz - L.mean) * L.invstd;
-            gg += second;
-            if (a.has_res) gg *= a.scale;
-            const float pass = gg;
-            if (a.relu && !(xhat * L.gamma + L.beta > 0.f)) gg = 0.f;
-            if (!mesh_on) gg = 0.f;
-            sum_g += gg;
-            sum_gx += gg * xhat;
-            return pass;
-        };
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float4 r = make_float4(one(L.zv[i].x, go[i].x, L.g2v[i].x, xh[i].x), one(L.zv[i].y, go[i].y, L.g2v[i].y, xh[i].y),
-                                         one(L.zv[i].z, go[i].z, L.g2v[i].z, xh[i].z), one(L.zv[i].w, go[i].w, L.g2v[i].w, xh[i].w));
-            if (a.has_res && a.grad_res) db_st4(r_gr, at(i), r);
-        }
+        for (int i = 0; i < 3; ++i) db_st4(r_ds, at(i), gs[i]); // the layer above's weight gradient reads it (X^T . G)
+        db_to_panel(lds, rl, c0, gs);                           // (rows beyond the batch read zeros: zero rows of the tile)
+        DB_STAMP(1); // gathers arrived, G stored + in the panel
+        __syncthreads();
+        DB_STAMP(2);
+#ifdef DB_PROBE_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DB_STAMP(3);
+#endif
+        db_product(bw, lds, stage, wave, x, g);                 // dX = G . W_up^T
         DB_STAMP(4);
-        db_sum2(sum_g, sum_gx, red);
+        __syncthreads();
         DB_STAMP(5);
-        if (tid == 0) {
-            if (a.grad_bn_b) a.grad_bn_b[v] = sum_g;
-            if (a.grad_bn_w) a.grad_bn_w[v] = sum_gx;
-        }
-        const float kk = L.gamma * L.invstd, mg = sum_g / n, mgx = sum_gx / n;
-        float4 dz[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            dz[i] = make_float4(kk * (go[i].x - mg - xh[i].x * mgx), kk * (go[i].y - mg - xh[i].y * mgx),
-                                kk * (go[i].z - mg - xh[i].z * mgx), kk * (go[i].w - mg - xh[i].w * mgx));
-            if (!mesh_on) dz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            db_st4(r_dz, at(i), dz[i]);
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(stage + rl * DB_LDC + c0 + DB_K * i);
+            go[i] = make_float4(t[0], t[1], t[2], t[3]);
         }
-        // ---- bias gradient of this layer: the vertex's column sums of dZ over its meshes, in mesh order (lanes 16 apart hold the
-        // wave's four meshes, the four waves' sums through LDS); the host adds the vertices up
-        if (a.colsum) {
-            __syncthreads(); // (the staging tile is read above)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                float4 t = dz[i];
-#pragma unroll
-                for (int k = 1; k < 4; ++k) {
-                    const int src = (lane & 15) + 16 * k;
-                    t.x += __shfl(dz[i].x, src), t.y += __shfl(dz[i].y, src), t.z += __shfl(dz[i].z, src), t.w += __shfl(dz[i].w, src);
-                }
-                if ((lane >> 4) == 0) *reinterpret_cast<float4 *>(stage + wave * DB_C + c0 + DB_K * i) = t;
-            }
-            __syncthreads();
-            if (tid < DB_C) a.colsum[(size_t)v * DB_C + tid] = ((stage[tid] + stage[DB_C + tid]) + stage[2 * DB_C + tid]) + stage[3 * DB_C + tid];
-        }
-        __syncthreads(); // the next vertex writes the panel / the staging tile
-        DB_STAMP(6);
+    }
+    // ---- this layer: residual scale, ReLU mask, BatchNorm backward
+    float sum_g = 0.f, sum_gx = 0.f;
+    float4 xh[3];
+    const __amdgpu_buffer_rsrc_t r_gr = db_rsrc(a.grad_res, op_bytes), r_dz = db_rsrc(a.dz, op_bytes);
+    auto one = [&](float zz, float &gg, float second, float &xhat) {
+        xhat = (zz - mean) * invstd;
+        gg += second;
+        if (a.has_res) gg *= a.scale;
+        const float pass = gg;
+        if (a.relu && !(xhat * gamma + beta > 0.f)) gg = 0.f;
+        if (!mesh_on) gg = 0.f;
+        sum_g += gg;
+        sum_gx += gg * xhat;
+        return pass;
     };
-
-    DB_STAMP(0);
-    DbBwdLoads La, Lb;
-    issue(La, first);
-    __builtin_amdgcn_sched_barrier(0);
-    if (PRODUCT) db_load_slice(bw, a.wt_up, wave, lane); // behind the first vertex's rows (in-order memory counter)
-    __builtin_amdgcn_sched_barrier(0);
-    int it = 0;
-    for (; it + 1 < count; it += 2) {
-        issue(Lb, first + it + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        finish(La, first + it);
-        __builtin_amdgcn_sched_barrier(0);
-        if (it + 2 < count) issue(La, first + it + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        finish(Lb, first + it + 1);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float4 r = make_float4(one(zv[i].x, go[i].x, g2v[i].x, xh[i].x), one(zv[i].y, go[i].y, g2v[i].y, xh[i].y),
+                                     one(zv[i].z, go[i].z, g2v[i].z, xh[i].z), one(zv[i].w, go[i].w, g2v[i].w, xh[i].w));
+        if (a.has_res && a.grad_res) db_st4(r_gr, at(i), r);
     }
-    if (it < count) finish(La, first + it);
+    float *red = lds + DB_PANEL + DB_CST;
+    DB_STAMP(6);
+    db_sum2(sum_g, sum_gx, red);
     DB_STAMP(7);
-}
-
-int db_cus()
-{
-    static int cus[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (!cus[dev]) {
-        hipDeviceProp_t prop;
-        int n = 0;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        cus[dev] = n > 0 ? n : 256;
+    if (tid == 0) {
+        if (a.grad_bn_b) a.grad_bn_b[v] = sum_g;
+        if (a.grad_bn_w) a.grad_bn_w[v] = sum_gx;
     }
-    return cus[dev];
-}
-
-// workgroups of a layer launch over nv vertices: one per CU where there are that many PAIRS of vertices (the next vertex's rows
-// travel under the current vertex's work), a multiple of 8 (db_run deals runs to XCDs)
-int db_grid(int nv)
-{
-    const int cus = db_cus() & ~7;
-    int g = (((nv + 1) / 2) + 7) & ~7;
-    if (g > cus) g = cus;
-    if (g < 8) g = 8;
-    return g;
+    const int n = a.b * DB_C;
+    const float kk = gamma * invstd, mg = sum_g / n, mgx = sum_gx / n;
+    float4 dz[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        dz[i] = make_float4(kk * (go[i].x - mg - xh[i].x * mgx), kk * (go[i].y - mg - xh[i].y * mgx),
+                            kk * (go[i].z - mg - xh[i].z * mgx), kk * (go[i].w - mg - xh[i].w * mgx));
+        if (!mesh_on) dz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        db_st4(r_dz, at(i), dz[i]);
+    }
+    // ---- bias gradient of this layer: the vertex's column sums of dZ over its meshes, in mesh order (lanes 16 apart hold the
+    // wave's four meshes, the four waves' sums through LDS); the host adds the vertices up
+    if (a.colsum) {
+        __syncthreads(); // (the staging tile may still be read above)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float4 t = dz[i];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const int src = (lane & 15) + 16 * k;
+                t.x += __shfl(dz[i].x, src), t.y += __shfl(dz[i].y, src), t.z += __shfl(dz[i].z, src), t.w += __shfl(dz[i].w, src);
+            }
+            if ((lane >> 4) == 0) *reinterpret_cast<float4 *>(stage + wave * DB_C + c0 + DB_K * i) = t;
+        }
+        __syncthreads();
+        if (tid < DB_C) a.colsum[(size_t)v * DB_C + tid] = ((stage[tid] + stage[DB_C + tid]) + stage[2 * DB_C + tid]) + stage[3 * DB_C + tid];
+    }
+    DB_STAMP(8);
 }
 
 inline bool db_aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
@@ -603,8 +518,8 @@ extern "C" int geom_deform_layer_fwd_f32(const geom_deform_fwd *args, void *stre
         !db_aligned16(a.s_out) || !db_aligned16(a.bias) || !db_aligned16(a.res) || !db_aligned16(a.w_next))
         return GEOM_EINVAL;
     if (!a.res) a.scale = 1.f;
-    a.vpx = 0;
-    const dim3 grid(db_grid(a.nv)), block(DB_THREADS);
+    a.vpx = (a.nv + 7) / 8;
+    const dim3 grid(8 * a.vpx), block(DB_THREADS);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.w_next) hipLaunchKernelGGL((db_fwd_kernel<true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((db_fwd_kernel<false>), grid, block, 0, s, a);
@@ -627,8 +542,8 @@ extern "C" int geom_deform_layer_bwd_f32(const geom_deform_bwd *args, void *stre
         !db_aligned16(a.wt_up))
         return GEOM_EINVAL;
     if (!a.has_res) a.scale = 1.f;
-    a.vpx = 0;
-    const dim3 grid(db_grid(a.nv)), block(DB_THREADS);
+    a.vpx = (a.nv + 7) / 8;
+    const dim3 grid(8 * a.vpx), block(DB_THREADS);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (product) hipLaunchKernelGGL((db_bwd_kernel<true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((db_bwd_kernel<false>), grid, block, 0, s, a);
