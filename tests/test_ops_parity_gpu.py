@@ -203,6 +203,64 @@ def test_layers_match_reference_fixture(gpu, name):
         close(p.grad.cpu().numpy(), g["grad." + pn], 1e-4)
 
 
+def _layer_gradient_masses(x, adj, w, b, split, gp):
+    """float64 |.|-chain of a 0N-GCN layer's backward: what every gradient element's terms add up to in absolute value --
+    the scale an fp32 evaluation's round-off is proportional to whatever cancels (helpers.rows_close).  gp = |grad_out * act'|."""
+    k = w.shape[-1] // split
+    aw, ax, aadj = w.abs(), x.abs(), adj.abs()
+    gs = torch.cat((aadj.transpose(-1, -2) @ gp[..., :k], gp[..., k:]), dim=-1)          # |A|^T on the aggregated slice
+    mass_x = gs @ aw.t()
+    mass_w = ax.reshape(-1, ax.shape[-1]).t() @ gs.reshape(-1, gs.shape[-1])
+    mass_b = gp.reshape(-1, gp.shape[-1]).sum(0)
+    return mass_x, mass_w, mass_b
+
+
+@pytest.mark.parametrize("name", ["BatchZERON_GCN", "Batch_Image_ZERON_GCNGCN", "Batch_Image_ZERON_GCNGCN_out3", "ZERON_GCN"])
+@pytest.mark.parametrize("mesh", ["icosphere_162", "uv_sphere_482"])
+def test_layer_gradients_element_by_element_against_float64(gpu, name, mesh):
+    """The max-norm bound of the fixture test above would pass a wrong low-magnitude row of an aggregation backward.  Here every
+    ELEMENT of grad_x, grad_weight and grad_bias is held to (terms + 8) * 2^-24 of the sum of the absolute values of ITS OWN
+    terms, against the float64 evaluation of the reference formulation (oracle.ref_ops.zero_n_layer, layers.py:34-41 /
+    107-116) on the same parameters -- on an icosphere and on the 482-vertex template with its 33-entry rows (table + CSR tail).
+    ReLU: outputs whose float64 pre-activation lies within round-off of zero get a zero upstream gradient (both evaluations
+    then differentiate through the same branch)."""
+    cls, dims, act = CASES[name]
+    V, Fc = meshgen.icosphere(2) if mesh == "icosphere_162" else meshgen.uv_sphere()
+    adj = utils.adj_init(dev(Fc, gpu))["adj"]
+    torch.manual_seed(21)
+    layer = cls(*dims).to(gpu)
+    batched = name != "ZERON_GCN"
+    x = torch.randn(*((3,) if batched else ()), V.shape[0], dims[0], device=gpu, requires_grad=True)
+    out = layer(x, adj, act)
+    wname = "weight1" if hasattr(layer, "weight1") else "weight"
+    w64 = getattr(layer, wname).detach().double().cpu().reshape(dims[0], dims[1]).requires_grad_(True)
+    b64 = layer.bias.detach().double().cpu().requires_grad_(True)
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    adj64 = adj.double().cpu()
+    pre = ref_ops.zero_n_layer(x64, adj64, w64, b64, layer.split, lambda t: t)
+    knife = pre.detach().abs() < 1e-5 * float(pre.detach().abs().max())
+    ref = act(pre)
+    assert float(((out.detach().double().cpu() - ref.detach()).abs() * (~knife)).max()) <= 1e-5 * float(ref.detach().abs().max())
+    gout = torch.randn(out.shape, dtype=torch.float64) * (~knife)
+    out.backward(gout.float().to(gpu))
+    ref.backward(gout)
+    # act' in float64 (0 / 1 for ReLU, elu' = 1 or exp(pre), identity 1): the |.|-chain starts from |grad_out * act'|
+    if act is F.relu:
+        dact = (pre.detach() > 0).double()
+    elif act is F.elu:
+        dact = torch.where(pre.detach() > 0, torch.ones_like(pre.detach()), pre.detach().exp())
+    else:
+        dact = torch.ones_like(pre.detach())
+    gp = (gout.float().double() * dact).abs()
+    mass_x, mass_w, mass_b = _layer_gradient_masses(x64.detach(), adj64, w64.detach(), b64.detach(), layer.split, gp)
+    rows = x64.numel() // dims[0]
+    eps = 2.0 ** -24
+    rows_close(x.grad.cpu().numpy(), x64.grad.numpy(), mass_x.numpy(), (dims[1] + 40 + 8) * eps, name + " grad_x on " + mesh)
+    rows_close(getattr(layer, wname).grad.reshape(dims[0], dims[1]).cpu().numpy(), w64.grad.numpy(), mass_w.numpy(), (rows + 8) * eps,
+               name + " grad_weight on " + mesh)
+    rows_close(layer.bias.grad.cpu().numpy(), b64.grad.numpy(), mass_b.numpy(), (rows + 8) * eps, name + " grad_bias on " + mesh)
+
+
 def test_config4_stack_at_baseline_size(gpu):
     """963 -> 192 -> 192 -> 192 on the 2562-vertex adjacency, fwd + bwd, vs the dense restatement."""
     V, Fc = meshgen.icosphere(4)
