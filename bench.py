@@ -231,7 +231,7 @@ class Workload:
         torch.cuda.synchronize()
         if not self.dp:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=side):      # the stream the warm-up steps ran on (their AccumulateGrad nodes live there)
                 self.forward_backward(step_in_backward=True)
                 self.update()
             self.graphs = (g,)
@@ -346,13 +346,20 @@ def event_time_us(fn, iters=30, warm=5):
     """Average duration of fn's launches: `iters` launches are captured into one HIP graph and the
     replay is bracketed by HIP events on the launch (= torch current) stream, so host launch overhead
     is excluded and what is measured is kernel time."""
-    for _ in range(warm):
-        fn()
+    # warm-up and capture on ONE side stream: autograd creates a leaf's AccumulateGrad node on the stream of its first backward
+    # and keeps it while a graph is alive; warming up on the default stream and capturing on torch's internal one left every
+    # captured backward with a stream-mismatch warning (and a cross-stream wait inside the graph)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     # thread_local: in a multi-rank run RCCL's watchdog thread polls its events while this thread captures; under the default
     # ("global") mode that poll invalidates the capture
-    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
         for _ in range(iters):
             fn()
     for _ in range(3):      # a few milliseconds of the same load first: the engine clock is still ramping up behind a sync

@@ -14,8 +14,8 @@ accumulation pass; the block input's leading columns (the first residual) are ta
 (Measured and rejected: aggregation + BatchNorm in ONE launch -- LAB_NOTES.md section 4.)
 Data-parallel note: by default every rank normalises with the statistics of its own shard (fused kernel, no collective,
 graph-capturable: DDP semantics).  `VertexBatchNorm.sync_across_ranks = True` switches to the statistics of the GLOBAL
-batch (`_SyncVertexBN`: per-vertex mean, then centred second moment, all-reduced), i.e. N shards normalise exactly as the
-single-GPU reference does over its whole batch -- eager only, the all-reduces sit inside forward / backward.
+batch (`_SyncVertexBN`: per-rank mean and centred second moment combined by ONE all-reduce forward, one backward), i.e. N
+shards normalise exactly as the single-GPU reference does over its whole batch -- capturable into the step's HIP graph with RCCL.
 """
 import torch
 import torch.nn.functional as F
@@ -120,31 +120,39 @@ class _InputTap(torch.autograd.Function):
 
 
 class _SyncVertexBN(torch.autograd.Function):
-    """nn.BatchNorm1d(verts) over the GLOBAL batch of a data-parallel job: the per-vertex sums of x and x^2 (forward) and
-    of g and g*x_hat (backward) are all-reduced across the ranks, so N shards of B/N meshes normalise exactly as ONE
-    process holding all B meshes -- the reference's semantics (it is single-GPU: models.py:237-297 sees the whole
-    batch).  Plain torch ops + small all-reduces ([V] floats: mean and centred second moment forward, [V, 2] backward);
-    opt-in (`VertexBatchNorm.sync_across_ranks = True`), used only when a process group with more than one rank is active."""
+    """nn.BatchNorm1d(verts) over the GLOBAL batch of a data-parallel job: N shards of B/N meshes normalise exactly as ONE
+    process holding all B meshes -- the reference's semantics (it is single-GPU: models.py:237-297 sees the whole batch).
+    ONE all-reduce forward, ONE backward, both of per-vertex scalars; only tensor ops and collectives, no host reads: with
+    the nccl (= RCCL) backend the whole thing is captured into a step's HIP graph like the gradient bucket's all-reduce.
+
+    Forward statistics without the E[x^2] - mean^2 cancellation and without a second round trip: every rank forms its OWN
+    mean and centred second moment M2 (two local passes, as the fused kernel does), and the ranks exchange
+    (n mean, M2, n mean^2, n) per vertex -- the global moment is sum(M2) + [sum(n mean^2) - N mean_g^2], whose bracket is the
+    BETWEEN-rank spread of the means; the packed statistics travel and are combined in float64 (a few KB), so that bracket
+    is exact for the fp32 means that went in (activations with a mean of 30 and unit spread: tests/test_dist_gloo.py)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
         import torch.distributed as dist
-        # two-pass statistics, like the fused kernel: the global mean first, then the CENTRED second moment (E[x^2] - mean^2
-        # cancels catastrophically for activations whose mean is large against their spread)
-        count = torch.tensor([x.shape[0] * x.shape[2]], dtype=x.dtype, device=x.device)
-        packed = torch.cat((x.sum(dim=(0, 2)), count))
+        nv = x.shape[1]
+        n_local = float(x.shape[0] * x.shape[2])
+        mean_l = x.mean(dim=(0, 2))
+        m2_l = ((x - mean_l.view(1, -1, 1)) ** 2).sum(dim=(0, 2))
+        mean64 = mean_l.double()
+        packed = torch.cat((n_local * mean64, m2_l.double(), n_local * mean64 * mean64,
+                            torch.full((1,), n_local, dtype=torch.float64, device=x.device)))
         dist.all_reduce(packed)
         n = packed[-1]
-        mean = packed[:-1] / n
-        centred = ((x - mean.view(1, -1, 1)) ** 2).sum(dim=(0, 2))
-        dist.all_reduce(centred)
-        var = centred / n                                                                   # biased, as used for normalisation
+        s1, m2, q = packed[:nv], packed[nv:2 * nv], packed[2 * nv:3 * nv]
+        mean_g = s1 / n
+        var_g = (m2 + (q - n * mean_g * mean_g)).clamp_min(0.0) / n                         # biased, as used for normalisation
+        mean, var = mean_g.to(x.dtype), var_g.to(x.dtype)
         invstd = torch.rsqrt(var + eps)
         with torch.no_grad():
             running_mean.mul_(1 - momentum).add_(momentum * mean)
-            running_var.mul_(1 - momentum).add_(momentum * var * (n / (n - 1).clamp_min(1.0)))
+            running_var.mul_(1 - momentum).add_(momentum * (var_g * (n / (n - 1).clamp_min(1.0))).to(x.dtype))
         xhat = (x - mean.view(1, -1, 1)) * invstd.view(1, -1, 1)
-        ctx.save_for_backward(xhat, weight, invstd, n)
+        ctx.save_for_backward(xhat, weight, invstd, n.to(x.dtype))
         return xhat * weight.view(1, -1, 1) + bias.view(1, -1, 1)
 
     @staticmethod
@@ -175,25 +183,28 @@ class VertexBatchNorm(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self._pending_batches = 0   # counted on the host; folded into the buffer when the state is saved
 
-    # False (default): local-shard statistics on the fused kernel -- torch DDP's semantics, no collective inside forward /
-    # backward, HIP-graph capturable.  True: under torch.distributed with > 1 rank the statistics are those of the GLOBAL
-    # batch (the reference is single-GPU and normalises over its whole batch: exact N-shard == 1-process equivalence), at
-    # the price of three blocking all-reduces per layer and step ISSUED INSIDE forward / backward: that path cannot be
-    # captured into a HIP graph and is for eager multi-rank training only.
+    # False (default): local-shard statistics on the fused kernels -- torch DDP's semantics, no collective inside forward /
+    # backward.  True: under torch.distributed with > 1 rank the statistics are those of the GLOBAL batch (the reference is
+    # single-GPU and normalises over its whole batch: exact N-shard == 1-process equivalence), at the price of two small
+    # all-reduces per layer and step (one forward, one backward: _SyncVertexBN) and of the separate operators instead of the
+    # one-launch layers; tensor ops and collectives only, so with RCCL the step is still captured into ONE HIP graph
+    # (tests/test_dist_step_gpu.py).
     sync_across_ranks = False
 
     _warned_local_statistics = False
 
+    _sync_single_rank_groups = False    # tests: take the synchronised route in a 1-rank group too (RCCL capture on one GPU)
+
     def _synchronised(self):
         many = (self.training and torch.distributed.is_available() and torch.distributed.is_initialized()
-                and torch.distributed.get_world_size() > 1)
+                and (torch.distributed.get_world_size() > 1 or VertexBatchNorm._sync_single_rank_groups))
         if many and not self.sync_across_ranks and not VertexBatchNorm._warned_local_statistics:
             VertexBatchNorm._warned_local_statistics = True       # once per process: the default changed in round 3
             import warnings
             warnings.warn("geometrics_amd VertexBatchNorm: %d ranks are active and sync_across_ranks is False -- every rank "
                           "normalises with the statistics of its OWN shard (DDP semantics), which is not what the single-GPU "
                           "reference computes over its whole batch; set VertexBatchNorm.sync_across_ranks = True for "
-                          "global-batch statistics (eager only)" % torch.distributed.get_world_size(), stacklevel=3)
+                          "global-batch statistics" % torch.distributed.get_world_size(), stacklevel=3)
         return many and self.sync_across_ranks
 
     MAX_VALUES_PER_VERTEX = 4096   # b * c held in the registers of one workgroup (csrc/vertex_bn.hip)

@@ -106,3 +106,106 @@ def run_serial(shards, total_meshes, steps, warm, out):
             losses.append(float(tail) / sum(wl.batch for wl in wls))
     out.put({"params": _flat(wls[0].stack.parameters()), "grads": _flat(summed) / shards, "losses": losses,
              "steps_taken": wls[0].opt.step_count})
+
+
+# ---- the deformation block under data parallelism with GLOBAL-batch BatchNorm statistics (VertexBatchNorm.sync_across_ranks) ----
+def _block_case(total, nv_level=2, width=40):
+    import numpy as np
+    from geometrics_amd import meshgen
+    V, Fc = meshgen.icosphere(nv_level)
+    g = torch.Generator().manual_seed(77)
+    feats = torch.randn(total, V.shape[0], 3, generator=g)
+    pooled = torch.randn(total, V.shape[0], 189 + width, generator=g) + 3.0      # a mean well away from zero
+    g_f = torch.randn(total, V.shape[0], 192, generator=g)
+    g_c = torch.randn(total, V.shape[0], 3, generator=g)
+    return V, Fc, feats, pooled, g_f, g_c
+
+
+def _block_pass(block, adj, feats, pooled, g_f, g_c, scale):
+    f, p = feats.clone().requires_grad_(True), pooled.clone().requires_grad_(True)
+    out_f, coords = block(f, p, adj)
+    (((out_f * g_f).sum() + (coords * g_c).sum()) * scale).backward()
+    return out_f.detach(), coords.detach(), f.grad, p.grad
+
+
+def run_sync_bn_block(rank, world, port, total, out):
+    """`world` ranks (gloo, sharing cuda:0), each with total / world meshes, VertexBatchNorm.sync_across_ranks = True; rank 0
+    reports outputs / input gradients of all ranks (gathered) + its parameter gradients all-reduced, and the running statistics."""
+    import os
+    import numpy as np
+    import torch.distributed as dist
+    from geometrics_amd import models, utils
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    V, Fc, feats, pooled, g_f, g_c = _block_case(total)
+    adj = utils.adj_init(torch.from_numpy(Fc).to(dev))["adj"]
+    torch.manual_seed(5)
+    block = models.BatchMeshDeformationBlock(feats.shape[-1] + pooled.shape[-1], V.shape[0]).to(dev).train()
+    models.VertexBatchNorm.sync_across_ranks = True
+    per = total // world
+    sl = slice(rank * per, (rank + 1) * per)
+    res = _block_pass(block, adj, *(t[sl].to(dev) for t in (feats, pooled, g_f, g_c)), 1.0)
+    grads = torch.cat([p.grad.flatten() for n, p in block.named_parameters() if p.grad is not None])
+    if world > 1:
+        dist.all_reduce(grads)                       # the job's gradient all-reduce (sum over the shards)
+        gathered = []
+        for t in res:
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t.contiguous())
+            gathered.append(torch.cat(parts))
+        res = gathered
+    if rank == 0:
+        stats = torch.cat([torch.cat((getattr(block, "bn%d" % i).running_mean, getattr(block, "bn%d" % i).running_var)) for i in range(1, 14)])
+        out.put({"res": [t.cpu().numpy() for t in res], "grads": grads.cpu().numpy(), "stats": stats.cpu().numpy()})
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_sync_bn_capture(port, total, out):
+    """1-rank RCCL group on cuda:0 with the synchronised route forced on: the block's forward + backward (two small all-reduces
+    per layer inside) captured into ONE HIP graph and replayed, against the same pass run eagerly."""
+    import os
+    import torch.distributed as dist
+    from geometrics_amd import models, utils
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    dev = torch.device("cuda:0")
+    V, Fc, feats, pooled, g_f, g_c = _block_case(total)
+    adj = utils.adj_init(torch.from_numpy(Fc).to(dev))["adj"]
+    torch.manual_seed(5)
+    block = models.BatchMeshDeformationBlock(feats.shape[-1] + pooled.shape[-1], V.shape[0]).to(dev).train()
+    models.VertexBatchNorm.sync_across_ranks = True
+    models.VertexBatchNorm._sync_single_rank_groups = True
+    args = [t.to(dev) for t in (feats, pooled, g_f, g_c)]
+    f, p = args[0].clone().requires_grad_(True), args[1].clone().requires_grad_(True)
+    assert block.bn1._synchronised()
+    keep = {}
+
+    def step():
+        for q in block.parameters():
+            q.grad = None
+        f.grad = p.grad = None
+        out_f, coords = block(f, p, adj)
+        ((out_f * args[2]).sum() + (coords * args[3]).sum()).backward()
+        keep["out"] = (out_f.detach(), coords.detach())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    eager = [t.clone() for t in keep["out"]] + [f.grad.clone(), p.grad.clone()] + [q.grad.clone() for q in block.parameters() if q.grad is not None]
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side, capture_error_mode="relaxed"):
+        step()
+    g.replay()
+    torch.cuda.synchronize()
+    replay = list(keep["out"]) + [f.grad, p.grad] + [q.grad for q in block.parameters() if q.grad is not None]
+    same = all(torch.equal(a, b) for a, b in zip(eager, replay))
+    out.put({"same": bool(same), "count": len(eager), "finite": bool(all(torch.isfinite(t).all() for t in replay))})
+    dist.destroy_process_group()

@@ -133,3 +133,32 @@ def test_rccl_all_reduce_between_the_two_graph_replays_equals_the_single_graph_s
     assert rccl["losses"] == plain["losses"]
     np.testing.assert_array_equal(rccl["grads"], plain["grads"])
     np.testing.assert_array_equal(rccl["params"], plain["params"])
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_block_with_global_batchnorm_statistics_equals_the_whole_batch_in_one_process(gpu):
+    """VertexBatchNorm.sync_across_ranks: two ranks with 4 meshes each run the deformation block (13 BatchNorm1d(verts) layers,
+    reference models.py:237-297) and must produce what ONE process produces over all 8 meshes -- the reference is single-GPU
+    and normalises over its whole batch: outputs, both input gradients, the summed parameter gradients and the running
+    statistics; fp32 against fp32 with other summation orders (and activations whose mean is 3 against a unit spread: the
+    statistics are exchanged as per-rank (n mean, M2, n mean^2) in float64, models._SyncVertexBN)."""
+    port = _free_port()
+    two = _collect(dist_step_worker.run_sync_bn_block, lambda n: [(r, n, port, 8) for r in range(n)], 2)
+    one = _collect(dist_step_worker.run_sync_bn_block, lambda n: [(0, 1, _free_port(), 8)], 1)
+    rel = lambda a, b: float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-30)
+    for a, b in zip(two["res"][:2], one["res"][:2]):
+        assert rel(a, b) <= 2e-5                                    # features, coordinates
+    l2 = lambda a, b: float(np.linalg.norm((a - b).ravel())) / max(float(np.linalg.norm(b.ravel())), 1e-30)
+    for a, b in zip(two["res"][2:], one["res"][2:]):
+        assert l2(a, b) <= 5e-3                                     # input gradients (ReLU kinks: see tests/test_deform_gpu.py)
+    assert l2(two["grads"], one["grads"]) <= 5e-3
+    assert rel(two["stats"], one["stats"]) <= 1e-4
+
+
+@pytest.mark.timeout(600)
+def test_block_with_global_batchnorm_statistics_is_captured_into_one_hip_graph(gpu):
+    """The synchronised route is tensor ops + RCCL collectives only: forward + backward of the block (26 small all-reduces inside)
+    captured into ONE HIP graph in a 1-rank RCCL group on cuda:0 and replayed, bit for bit the eager pass."""
+    got = _collect(dist_step_worker.run_sync_bn_capture, lambda n: [(_free_port(), 4)], 1)
+    assert got["finite"] and got["count"] > 50
+    assert got["same"]
