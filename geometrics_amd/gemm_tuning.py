@@ -30,6 +30,9 @@ def enable(filename=TUNING_FILE):
     outcomes it was (bench.py prints it as config.gemm_selection; a rejected file is a ~2x slower library product, so
     tests/test_bench_contract_gpu.py asserts that the shipped file loads on the GPU box)."""
     global status
+    if os.environ.get("GEOM_TUNING") == "reject":      # tools / tests: behave as after a library update (the file is refused)
+        status = "library default (tuning file rejected)"
+        return False
     if not (torch.cuda.is_available() and os.path.exists(filename)):
         status = "library default (no tuning file)"
         return False

@@ -10,6 +10,7 @@ the tensor's identity + version) and replaces the reference's dense `adj @ suppo
 """
 import ctypes
 import math
+import os
 import threading
 import weakref
 
@@ -302,7 +303,11 @@ _late_collect = [None]
 def _late_product(g2, w2, out, stream):
     def launch():
         with torch.cuda.stream(stream), torch.no_grad():
-            torch.mm(g2, w2.t(), out=out)
+            if (_own_products_preferred() and use_matrix_core_products and w2.is_contiguous() and g2.is_contiguous() and g2.shape[0] >= 512
+                    and w2.shape[1] % 16 == 0 and _dense_kernels.supported(w2.shape[0], w2.shape[1], g2.shape[0])):
+                _dense_kernels.backward_input(g2, w2, out=out)
+            else:
+                torch.mm(g2, w2.t(), out=out)
     return launch
 
 
@@ -802,6 +807,49 @@ def _takes_any_shape_kernel(rows, cin, c):
             and _dense_kernels.any_supported(rows, cin, c))
 
 
+# The library's products of this path are fast only with the recorded selections of geometrics_amd/tuning (TunableOp: validated
+# against the PyTorch / hipBLASLt build, so a library update REJECTS the file and the default heuristic runs the 963-wide
+# products at 85 us instead of 62).  When gemm_tuning.enable() was called and the file was rejected, the forward products and
+# the wide input gradient of the 192-column layers take this package's own matrix-core kernels instead (csrc/dense_gemm.hip:
+# within a few per cent of the tuned library, measured by tools/time_dense.py and bench.py --own-products): the headline does
+# not hang on a version-locked file.  None = that rule; True / False force it (tests, A/B).
+own_dense_products = None
+
+
+def _own_products_preferred():
+    if own_dense_products is not None:
+        return bool(own_dense_products)
+    env = os.environ.get("GEOM_OWN_PRODUCTS")
+    if env is not None:
+        return env not in ("", "0")
+    from . import gemm_tuning
+    return gemm_tuning.status == "library default (tuning file rejected)"
+
+
+def _own_kernel_takes(x, w2):
+    return (use_matrix_core_products and x.is_cuda and x.dtype == torch.float32 and w2.dtype == torch.float32 and w2.dim() == 2
+            and w2.is_contiguous() and x.shape[-1] == w2.shape[0] and w2.shape[1] % 16 == 0
+            and _dense_kernels.supported(w2.shape[0], w2.shape[1], x.numel() // max(x.shape[-1], 1))
+            and x.numel() // max(x.shape[-1], 1) >= 512)
+
+
+def _library_or_own_forward(x, w2):
+    """x @ w2 by the library, or by geom_dense_fwd_f32 when the library runs untuned (see above)."""
+    if _own_products_preferred() and _own_kernel_takes(x, w2):
+        x2 = x.reshape(-1, x.shape[-1])
+        return _dense_kernels.forward(x2 if x2.is_contiguous() else x2.contiguous(), w2).view(x.shape[:-1] + (w2.shape[1],))
+    return torch.matmul(x, w2)
+
+
+def _library_or_own_input_gradient(g2, w2):
+    """g2 @ w2^T ([rows, c] x [cin, c]^T) by the library, or by geom_dense_bwd_input_f32 when the library runs untuned."""
+    if (_own_products_preferred() and use_matrix_core_products and g2.is_cuda and g2.dtype == torch.float32 and g2.dim() == 2
+            and g2.is_contiguous() and w2.is_contiguous() and w2.dim() == 2 and g2.shape[1] == w2.shape[1] and g2.shape[0] >= 512
+            and w2.shape[1] % 16 == 0 and _dense_kernels.supported(w2.shape[0], w2.shape[1], g2.shape[0])):
+        return _dense_kernels.backward_input(g2, w2)
+    return torch.matmul(g2, w2.t())
+
+
 def _forward_product(x, w2):
     """x [..., cin] @ w2 [cin, c]: ONE rule for which kernel computes it, whichever autograd node wraps it (the routes of a
     layer must agree bit for bit in the forward: tests compare them)."""
@@ -810,7 +858,7 @@ def _forward_product(x, w2):
             and x.shape[-1] == w2.shape[0] and _takes_any_shape_kernel(rows, x.shape[-1], w2.shape[-1])):
         x2 = x.reshape(-1, x.shape[-1])
         return _dense_kernels.gemm(x2 if x2.is_contiguous() else x2.contiguous(), w2).view(x.shape[:-1] + (w2.shape[1],))
-    return torch.matmul(x, w2)
+    return _library_or_own_forward(x, w2)
 
 
 def _weight_gradient_product(x2, g2, out=None):
@@ -906,7 +954,7 @@ class _DenseMM(torch.autograd.Function):
         ctx.w_ref = weakref.ref(w)
         if ctx.needs_input_grad[1]:
             _register_bias_user(w, ctx)
-        return torch.matmul(x, w.reshape(w.shape[-2:]))
+        return _library_or_own_forward(x, w.reshape(w.shape[-2:]))
 
     @staticmethod
     def backward(ctx, grad):
@@ -919,7 +967,7 @@ class _DenseMM(torch.autograd.Function):
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         plan = _dense_kernels.plan(rows, cin, c)
         if not x2.is_contiguous() or not w2.is_contiguous() or not (need_w and plan["dw"] == "mfma"):
-            grad_x = torch.matmul(g2, w2.t()).view(x.shape) if need_x else None
+            grad_x = _library_or_own_input_gradient(g2, w2).view(x.shape) if need_x else None
             grad_w = _weight_gradient_product(x2, g2).view(w.shape) if need_w else None
             return grad_x, grad_w
         ws = _dense_kernels.weight_workspace(rows, cin, c, x.device)
@@ -935,7 +983,7 @@ class _DenseMM(torch.autograd.Function):
                 late = (g2, w2, torch.empty(rows, cin, dtype=x.dtype, device=x.device), torch.cuda.current_stream(x.device),
                         weakref.ref(x))
             elif need_x:
-                grad_x = torch.matmul(g2, w2.t()).view(x.shape)
+                grad_x = _library_or_own_input_gradient(g2, w2).view(x.shape)
             _dense_kernels.backward_weight_partials(x2, g2, ws)
         if late is not None:
             task = torch._C._current_graph_task_id()

@@ -110,7 +110,7 @@ def run_serial(shards, total_meshes, steps, warm, out):
 
 # ---- the deformation block under data parallelism with GLOBAL-batch BatchNorm statistics (VertexBatchNorm.sync_across_ranks) ----
 def _block_case(total, nv_level=2, width=40):
-    import numpy as np
+    import torch
     from geometrics_amd import meshgen
     V, Fc = meshgen.icosphere(nv_level)
     g = torch.Generator().manual_seed(77)
@@ -122,6 +122,7 @@ def _block_case(total, nv_level=2, width=40):
 
 
 def _block_pass(block, adj, feats, pooled, g_f, g_c, scale):
+    import torch
     f, p = feats.clone().requires_grad_(True), pooled.clone().requires_grad_(True)
     out_f, coords = block(f, p, adj)
     (((out_f * g_f).sum() + (coords * g_c).sum()) * scale).backward()
@@ -132,7 +133,7 @@ def run_sync_bn_block(rank, world, port, total, out):
     """`world` ranks (gloo, sharing cuda:0), each with total / world meshes, VertexBatchNorm.sync_across_ranks = True; rank 0
     reports outputs / input gradients of all ranks (gathered) + its parameter gradients all-reduced, and the running statistics."""
     import os
-    import numpy as np
+    import torch
     import torch.distributed as dist
     from geometrics_amd import models, utils
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -168,6 +169,7 @@ def run_sync_bn_capture(port, total, out):
     """1-rank RCCL group on cuda:0 with the synchronised route forced on: the block's forward + backward (two small all-reduces
     per layer inside) captured into ONE HIP graph and replayed, against the same pass run eagerly."""
     import os
+    import torch
     import torch.distributed as dist
     from geometrics_amd import models, utils
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
