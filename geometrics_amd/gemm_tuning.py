@@ -63,6 +63,43 @@ def enable(filename=TUNING_FILE):
     return ok
 
 
+def tune_once(fn, max_ms=30, max_iters=30):
+    """The shipped selections were refused (another PyTorch / hipBLASLt build than they were recorded with): let TunableOp
+    pick the library's solutions for THIS build, once, from one eager pass of the workload -- `fn()` runs every product of the
+    step; each untuned shape is timed for at most `max_ms` milliseconds -- and replay them from then on (in memory, for the life
+    of the process; nothing is written).  A second or so at start-up instead of products on the default heuristic for the whole
+    run (the 963-wide ones: 85 us instead of 62); call it BEFORE capturing HIP graphs.  Returns True when tuning ran."""
+    global status
+    if not torch.cuda.is_available():
+        return False
+    tun = torch.cuda.tunable
+    try:
+        tun.enable(True)
+        tun.tuning_enable(True)
+        tun.record_untuned_enable(False)
+        tun.set_max_tuning_duration(int(max_ms))
+        tun.set_max_tuning_iterations(int(max_iters))
+        scratch = tempfile.mkdtemp(prefix="geom_tunableop_")
+        atexit.register(shutil.rmtree, scratch, True)
+        tun.set_filename(os.path.join(scratch, "selections.csv"))
+        if hasattr(tun, "write_file_on_exit"):
+            tun.write_file_on_exit(False)
+        fn()
+        torch.cuda.synchronize()
+    except Exception as exc:
+        print("geometrics_amd.gemm_tuning: start-up tuning failed (%s: %s); library default GEMM selection in use"
+              % (type(exc).__name__, exc), file=sys.stderr)
+        try:
+            tun.tuning_enable(False)
+            tun.enable(False)
+        except Exception:
+            pass
+        return False
+    tun.tuning_enable(False)
+    status = "tuned at start-up (the shipped selections were rejected by this library build)"
+    return True
+
+
 def disable():
     if torch.cuda.is_available():
         torch.cuda.tunable.enable(False)
