@@ -1286,10 +1286,9 @@ def main():
     first, count = gdist.shard_range(per_gpu * world, rank, world)
     w = Workload(dev, first, count, force_dp=force_dp)
     if not tuned and gemm_tuning.status == "library default (tuning file rejected)" and os.environ.get("GEOM_RETUNE", "1") != "0":
-        # the shipped selections belong to another library build: pick this build's once, from one eager step (~1 s), instead of
-        # running every library product of the run on the default heuristic.  (The same step on every rank: collectives match.)
-        gemm_tuning.tune_once(w.step)
-        w.finish()
+        # the shipped selections belong to another library build: pick this build's once (~1 s), instead of running every
+        # library product of the run on the default heuristic
+        gemm_tuning.tune_products([(count, w.nv, FEAT, HID), (count, w.nv, HID, HID)], dev)
     launch = "eager"
     if args.launch == "graph":
         try:

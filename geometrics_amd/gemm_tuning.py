@@ -63,16 +63,19 @@ def enable(filename=TUNING_FILE):
     return ok
 
 
-def tune_once(fn, max_ms=30, max_iters=30):
+def tune_products(shapes, device=None, max_ms=30, max_iters=30):
     """The shipped selections were refused (another PyTorch / hipBLASLt build than they were recorded with): let TunableOp
-    pick the library's solutions for THIS build, once, from one eager pass of the workload -- `fn()` runs every product of the
-    step; each untuned shape is timed for at most `max_ms` milliseconds -- and replay them from then on (in memory, for the life
-    of the process; nothing is written).  A second or so at start-up instead of products on the default heuristic for the whole
-    run (the 963-wide ones: 85 us instead of 62); call it BEFORE capturing HIP graphs.  Returns True when tuning ran."""
+    pick the library's solutions for THIS build, once, for the products the layers hand to the library -- shapes = [(meshes,
+    vertices, cin, cout)]: the forward `x[B,V,cin] @ w` and the input gradient `g[B*V,cout] @ w^T`, issued exactly as
+    geometrics_amd.layers issues them -- each shape timed for at most `max_ms` milliseconds, and replay them from then on (in
+    memory, for the life of the process; nothing is written).  Under a second at start-up instead of products on the default
+    heuristic for the whole run (the 963-wide ones: 85 us instead of 62); call it BEFORE capturing HIP graphs.  Plain products
+    on the current stream only: tuning inside a backward pass of the real step crashed the process (ROCm 7.2 / PyTorch 2.10)."""
     global status
     if not torch.cuda.is_available():
         return False
     tun = torch.cuda.tunable
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     try:
         tun.enable(True)
         tun.tuning_enable(True)
@@ -84,7 +87,14 @@ def tune_once(fn, max_ms=30, max_iters=30):
         tun.set_filename(os.path.join(scratch, "selections.csv"))
         if hasattr(tun, "write_file_on_exit"):
             tun.write_file_on_exit(False)
-        fn()
+        with torch.no_grad():
+            for meshes, nv, cin, cout in shapes:
+                x = torch.randn(meshes, nv, cin, device=dev)
+                w = torch.randn(cin, cout, device=dev)
+                g = torch.randn(meshes * nv, cout, device=dev)
+                torch.matmul(x, w)
+                torch.matmul(g, w.t())
+                torch.mm(g, w.t(), out=torch.empty(meshes * nv, cin, device=dev))
         torch.cuda.synchronize()
     except Exception as exc:
         print("geometrics_amd.gemm_tuning: start-up tuning failed (%s: %s); library default GEMM selection in use"

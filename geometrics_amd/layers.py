@@ -823,7 +823,7 @@ def _own_products_preferred():
     if env is not None:
         return env not in ("", "0")
     from . import gemm_tuning
-    return gemm_tuning.status == "library default (tuning file rejected)"
+    return gemm_tuning.status == "library default (tuning file rejected)"      # (not: "tuned at start-up", gemm_tuning.tune_products)
 
 
 def _own_kernel_takes(x, w2):
