@@ -86,3 +86,23 @@ def test_bench_whole_n_gt_1_path_with_rccl_on_one_gpu(gpu):
     assert line["config"]["launch"] == "hipgraph" and line["value"] > 0
     assert line.get("roofline_error") is None and line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
     assert "surface_scan_kernel (both arg-min scans of the surface loss)" in line["other_kernels"]
+
+
+@pytest.mark.timeout(600)
+def test_a_rejected_selections_file_costs_less_than_three_per_cent(gpu):
+    """The library products of the step are fast only with recorded solution selections, and TunableOp validates the shipped
+    file against the PyTorch / hipBLASLt build: after a library update it is REFUSED.  bench.py then lets TunableOp pick this
+    build's solutions at start-up (gemm_tuning.tune_products, under a second) instead of running on the default heuristic
+    (0.506 ms per step against 0.448: measured).  GEOM_TUNING=reject simulates the refusal: the line must say so, and the step
+    must be within 3 % of the step on the shipped file -- the headline does not hang on a version-locked file."""
+    args = ["--steps", "200", "--warmup", "20", "--no-cpu-baseline", "--steps-only"]
+    shipped = _run(args)
+    refused = _run(args, {"GEOM_TUNING": "reject"})
+    untuned = _run(args, {"GEOM_TUNING": "reject", "GEOM_RETUNE": "0", "GEOM_OWN_PRODUCTS": "0"})
+    assert shipped["config"]["gemm_selection"] == "tunableop file"
+    assert refused["config"]["gemm_selection"].startswith("tuned at start-up")
+    assert untuned["config"]["gemm_selection"] == "library default (tuning file rejected)"
+    assert refused["ms_per_step"] <= 1.03 * shipped["ms_per_step"], (refused["ms_per_step"], shipped["ms_per_step"])
+    assert untuned["ms_per_step"] > 1.05 * shipped["ms_per_step"]          # what the fallback is worth
+    # same arithmetic whichever library kernel runs a product: fp32, the losses agree to summation order
+    assert abs(refused["final_loss"] - shipped["final_loss"]) <= 1e-2 * abs(shipped["final_loss"])
