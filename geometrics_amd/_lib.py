@@ -119,6 +119,8 @@ _SIGNATURES = {
     "geom_zn_layer_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_zn_layer_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp],
     "geom_camera_info_f32": [_i, _vp, _vp, _vp, _vp],
+    "geom_split_bf16_planes_f32": [_i, _i, _vp, _vp, _vp],
+    "geom_gemm_split_bf16_f32": [_i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "geom_stage_regularisers_fwd_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp],
     "geom_stage_regularisers_bwd_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "geom_deform_layer_fwd_f32": [_vp, _vp],
@@ -238,6 +240,8 @@ def lib():
         L.geom_nn_cull_index_floats.argtypes = [_i, _i]
         L.geom_tri_distance_workspace_bytes.restype = ctypes.c_size_t
         L.geom_tri_distance_workspace_bytes.argtypes = [_i, _i, _i]
+        L.geom_split_bf16_kpad.restype = _i
+        L.geom_split_bf16_kpad.argtypes = [_i]
         L.geom_stage_regularisers_blocks.restype = ctypes.c_int64
         L.geom_stage_regularisers_blocks.argtypes = [_i, _i, _i]
         L.geom_zn_layer_partial_rows.restype = ctypes.c_int64
@@ -261,7 +265,7 @@ def declared_symbols():
                    "geom_surface_bin_count_words", "geom_surface_bin_list_words", "geom_surface_order_words",
                    "geom_dense_bwd_weight_workspace_floats", "geom_chamfer_nn_culled_workspace_floats",
                    "geom_nn_cull_index_floats", "geom_surface_tail_counters_offset", "geom_zn_layer_partial_rows",
-                   "geom_gemm_workspace_floats", "geom_stage_regularisers_blocks"] + list(_SIGNATURES))
+                   "geom_gemm_workspace_floats", "geom_stage_regularisers_blocks", "geom_split_bf16_kpad"] + list(_SIGNATURES))
 
 
 def check(code, what):

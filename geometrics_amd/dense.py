@@ -166,3 +166,30 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, workspace=None):
         _lib.call("geom_gemm_f32", m, n, k, a.data_ptr(), a.stride(0), 1 if trans_a else 0, b.data_ptr(), b.stride(0),
                   0 if trans_b else 1, out.data_ptr(), out.stride(0), _lib.ptr(workspace) if need else None, need)
     return out
+
+
+# ---- EXPERIMENT: exact fp32 products on the bf16 matrix cores (csrc/dense_split_bf16.hip); on no default route -----------------
+def split_bf16_planes(w):
+    """w [k, 192] fp32 -> planes [3, 192, kpad] (bf16 bit patterns as int16): w == plane 0 + plane 1 + plane 2 exactly."""
+    if not (w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.is_contiguous()):
+        raise ValueError("split_bf16_planes: a contiguous 2-D float32 tensor on a HIP device")
+    k, n = w.shape
+    kpad = int(_lib.lib().geom_split_bf16_kpad(k))
+    planes = torch.empty(3, n, kpad, dtype=torch.int16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.call("geom_split_bf16_planes_f32", k, n, w.data_ptr(), planes.data_ptr())
+    return planes
+
+
+def gemm_split_bf16(a, planes, terms=6, out=None):
+    """a [m, k] @ w [k, 192] with w given as split_bf16_planes(w): exact products, fp32 accumulation, on the bf16 matrix cores."""
+    if not (a.is_cuda and a.dtype == torch.float32 and a.dim() == 2 and a.is_contiguous()):
+        raise ValueError("gemm_split_bf16: a contiguous 2-D float32 tensor on a HIP device")
+    m, k = a.shape
+    n = planes.shape[1]
+    if planes.shape[2] != int(_lib.lib().geom_split_bf16_kpad(k)):
+        raise ValueError("gemm_split_bf16: the planes belong to another k")
+    out = torch.empty(m, n, dtype=torch.float32, device=a.device) if out is None else out
+    with torch.cuda.device(a.device):
+        _lib.call("geom_gemm_split_bf16_f32", m, k, n, a.data_ptr(), planes.data_ptr(), out.data_ptr(), int(terms))
+    return out

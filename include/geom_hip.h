@@ -418,6 +418,15 @@ typedef struct geom_deform_bwd {
     float *grad_res, *dz, *grad_bn_w, *grad_bn_b, *colsum;
     int vpx;
 } geom_deform_bwd;
+/* EXPERIMENT (csrc/dense_split_bf16.hip; on no default route): c [m, 192] = a [m, k] . w [k, 192] on the BF16 matrix cores with
+ * exact fp32 products -- every fp32 operand is the exact sum of three bf16 numbers, the products a_i b_j are exact in fp32,
+ * terms = 6 keeps those with i + j <= 2 (the rest is below 2^-24 of |a b|), 9 keeps all; fp32 accumulation, the leading
+ * term and the small terms in separate accumulators.  w comes pre-split: planes [3][192][kpad] bf16, kpad =
+ * geom_split_bf16_kpad(k), from geom_split_bf16_planes_f32 (once per weight update).  n != 192: GEOM_EUNSUPPORTED. */
+int geom_split_bf16_kpad(int k);
+int geom_split_bf16_planes_f32(int k, int n, const float *w, uint16_t *planes, void *stream);
+int geom_gemm_split_bf16_f32(int m, int k, int n, const float *a, const uint16_t *planes, float *c, int terms, void *stream);
+
 /* The regularisers of ONE deformation stage (GEOMetrics.py:147-161: edge term of the new positions + squared difference of
  * the Laplacian coordinates of the previous and the new positions + their squared displacement) in one launch per direction
  * (csrc/regularizers.hip).  forward: partial[geom_stage_regularisers_blocks(b, nv, nf)] = per-workgroup sums of

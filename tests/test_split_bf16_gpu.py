@@ -1,0 +1,54 @@
+"""-m gpu: the split-bf16 product (csrc/dense_split_bf16.hip, an EXPERIMENT on no default route): exact fp32 products on the bf16
+matrix cores.  Held to the promotion rule of the round-5 review: its per-element error against float64 must be NO WORSE than the
+native fp32 matrix-core product's on the same inputs (not merely inside the (K + 8) eps sum|a||b| bound)."""
+import numpy as np
+import pytest
+import torch
+
+from geometrics_amd import dense
+
+pytestmark = pytest.mark.gpu
+
+
+def _planes_value(planes):
+    """bf16 bit patterns (int16) -> float64 values."""
+    bits = planes.cpu().numpy().astype(np.uint16).astype(np.uint32) << 16
+    return bits.view(np.float32).astype(np.float64)
+
+
+def test_planes_sum_to_the_weight_exactly(gpu):
+    torch.manual_seed(1)
+    w = torch.randn(963, 192, device=gpu) * 0.05
+    planes = dense.split_bf16_planes(w)
+    assert planes.shape == (3, 192, 992)
+    v = _planes_value(planes)
+    total = v[0] + v[1] + v[2]                                    # [192, 992]
+    assert np.array_equal(total[:, :963].T, w.cpu().numpy().astype(np.float64))
+    assert float(np.abs(total[:, 963:]).max()) == 0.0
+
+
+@pytest.mark.parametrize("rows,k", [(20496, 963), (7712, 1155), (333, 963), (96, 40)])
+@pytest.mark.parametrize("terms", [6, 9])
+def test_split_product_is_no_further_from_float64_than_the_native_fp32_product(gpu, rows, k, terms):
+    torch.manual_seed(2)
+    a = torch.randn(rows, k, device=gpu)
+    w = torch.randn(k, 192, device=gpu) * 0.05
+    planes = dense.split_bf16_planes(w)
+    c = dense.gemm_split_bf16(a, planes, terms=terms)
+    native = dense.forward(a, w) if rows >= 512 else torch.matmul(a, w)      # v_mfma_f32_16x16x4_f32 (csrc/dense_gemm.hip)
+    sample = slice(0, min(rows, 2048))
+    a64, w64 = a[sample].double().cpu(), w.double().cpu()
+    exact = a64 @ w64
+    mass = a64.abs() @ w64.abs()
+    err_split = (c[sample].double().cpu() - exact).abs()
+    err_native = (native[sample].double().cpu() - exact).abs()
+    # inside the bound any fp32 summation order satisfies ...
+    assert bool((err_split <= (k + 8) * 2.0 ** -24 * mass + 1e-30).all())
+    # ... and no worse than the native product: in the worst element and on average
+    assert float((err_split / mass).max()) <= float((err_native / mass).max()) * 1.05, (float((err_split / mass).max()), float((err_native / mass).max()))
+    assert float(err_split.pow(2).mean().sqrt()) <= float(err_native.pow(2).mean().sqrt()) * 1.05
+    # whole tensor against a float64 product of a row sample beyond the first tile rows
+    if rows > 2048:
+        tail = slice(rows - 300, rows)
+        ex = a[tail].double().cpu() @ w64
+        assert float((c[tail].double().cpu() - ex).abs().max()) <= (k + 8) * 2.0 ** -24 * float((a[tail].double().cpu().abs() @ w64.abs()).max())
