@@ -1089,6 +1089,45 @@ def strong_scaling_point(dev, rank, world, force_dp, steps, warmup, global_batch
     return out
 
 
+def split_bf16_experiment(dev, rows=20496, k=FEAT):
+    """EXPERIMENT, on no route of the step (round-5 review item 5): the first layer's forward product with EXACT fp32 products on
+    the bf16 matrix cores (every fp32 operand = the exact sum of three bf16 numbers; six exact a_i b_j products per element pair,
+    fp32 accumulation: csrc/dense_split_bf16.hip) beside the library's and this package's fp32 matrix-core product on the same
+    operands (rotated over three buffers: a step does not find its X in the infinity cache either); errors against float64 on
+    a 2048-row sample.  dtype of the experiment: bf16 x 3 operands, fp32 accumulate -- the step's dtype stays f32."""
+    from geometrics_amd import dense
+    xs = [torch.randn(rows, k, device=dev) for _ in range(3)]
+    w = torch.randn(k, HID, device=dev) * 0.05
+    planes = dense.split_bf16_planes(w)
+    outs = [torch.empty(rows, HID, device=dev) for _ in range(3)]
+    turn = [0]
+
+    def rotating(fn):
+        def call():
+            i = turn[0] = (turn[0] + 1) % 3
+            fn(xs[i], outs[i])
+        return call
+    t_lib = event_time_us(rotating(lambda x, o: torch.mm(x, w, out=o)), iters=30)
+    t_own = event_time_us(rotating(lambda x, o: dense.forward(x, w, out=o)), iters=30)
+    t_s6 = event_time_us(rotating(lambda x, o: dense.gemm_split_bf16(x, planes, 6, out=o)), iters=30)
+    t_s9 = event_time_us(rotating(lambda x, o: dense.gemm_split_bf16(x, planes, 9, out=o)), iters=30)
+    a64, w64 = xs[0][:2048].double().cpu(), w.double().cpu()
+    exact = a64 @ w64
+    rms = lambda c: float((c[:2048].double().cpu() - exact).pow(2).mean().sqrt())
+    e_split, e_native = rms(dense.gemm_split_bf16(xs[0], planes, 6)), rms(dense.forward(xs[0], w))
+    fl = 2.0 * rows * k * HID
+    return {"product": "[%d, %d] x [%d, %d] forward (layer 1), fp32 in / fp32 out" % (rows, k, k, HID),
+            "dtype": "bf16 x 3-way split operands (exact products), fp32 accumulate -- experiment only, the step computes in f32 MFMA",
+            "us": {"library fp32 (selection in use)": round(t_lib, 1), "fp32 matrix cores (dense_gemm.hip)": round(t_own, 1),
+                   "split bf16, 6 terms": round(t_s6, 1), "split bf16, 9 terms": round(t_s9, 1)},
+            "fp32_equivalent_tflops_split6": round(fl / t_s6 / 1e6, 1),
+            "rms_error_vs_float64": {"split bf16 (6 terms)": e_split, "native fp32 MFMA": e_native, "ratio": round(e_split / e_native, 3)},
+            "verdict": "more accurate than the native fp32 matrix-core chain (the leading accumulator is rounded 31 times instead of 241) "
+                       "and NOT faster at this shape: 6 -> 9 terms (+50 % MFMAs) costs ~9 us of ~86, the launch is bound by operand "
+                       "delivery (every workgroup re-reads the 1.1 MB of weight planes through L2, X is split in registers), not by "
+                       "matrix-core issue; not promoted"}
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -1384,6 +1423,7 @@ def main():
         if world == 1 and not force_dp and not args.steps_only:
             extra("components_us", lambda: component_times(w))
             extra("configs", lambda: baseline_configs(dev))
+            extra("split_bf16_experiment", lambda: split_bf16_experiment(dev))
             extra("reference_training_shape", lambda: training_shape_times(dev))
             extra("driver_step", lambda: driver_step_times(dev))
             extra("driver_step_zero_edit", lambda: driver_step_times(dev, zero_edit=True))

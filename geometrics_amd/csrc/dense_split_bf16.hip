@@ -13,7 +13,7 @@
 //
 // Shape of the kernel: one workgroup = 4 waves = a 96-row x 192-column output tile (213.5 -> 214 workgroups at 20 496 rows: one
 // round on 256 CUs), wave (wy, wx) = 48 rows x 96 columns = 3 x 6 tiles of v_mfma_f32_16x16x32_bf16, two accumulators per
-// tile.  Per 32-k block: the 96 x 32 fp32 piece of X is loaded with 4-byte loads (963-float rows are never 16-byte aligned),
+// tile.  Per 32-k block: the 96 x 32 fp32 piece of X is loaded with dword-aligned 16-byte buffer loads,
 // split in registers and written as three bf16 planes to LDS; W comes pre-split and transposed ([plane][column][k], bf16:
 // geom_split_bf16_planes_f32, once per weight update) so that a lane's 8 consecutive k are one 16-byte read; LDS rows are
 // padded to 80 bytes (16 rows x 16 B cover all 64 banks); double-buffered, the next block's global loads travel under the
@@ -81,43 +81,61 @@ __global__ __launch_bounds__(SB_THREADS, 1) void split_bf16_gemm_kernel(SbArgs p
     const int row0 = blockIdx.x * SB_TM;
     const int nkb = p.kpad / SB_KB;
 
-    // ---- global -> register staging of one k-block
-    // X: thread (r = tid / 16, kp = tid % 16) owns k = 2 kp, 2 kp + 1 of rows r, r + 16, .. r + 80 (12 four-byte loads)
-    const int ar = tid >> 4, akp = tid & 15;
+    // ---- global -> register staging of one k-block (buffer loads: 32-bit offsets against wave-uniform descriptors, rows beyond
+    // the matrix read zeros; the offsets are formed once and advance by a constant per block)
+    // X: thread (r = tid / 8, k4 = tid % 8) owns k = 4 k4 .. 4 k4 + 3 of rows r, r + 32, r + 64: three 16-byte loads (a
+    // multi-dword buffer load needs dword alignment only: the 963-float rows are 4-byte aligned), eight lanes per 128-byte row piece
+    const int ar = tid >> 3, ak4 = tid & 7;
+    const __amdgpu_buffer_rsrc_t r_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.a), 0, (int)((int64_t)p.m * p.k * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(p.bt), 0, (int)((int64_t)3 * SB_N * p.kpad * 2), 0x00020000);
+    unsigned a_off[3], b_off[9], b_lds[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int row = row0 + ar + 32 * i;
+        a_off[i] = row < p.m ? (unsigned)(((int64_t)row * p.k + 4 * ak4) * 4) : 0x80000000u;
+    }
     // W planes: 3 x 192 x 64 B per block = 2 304 chunks of 16 B, nine per thread: chunk q = tid + 256 t -> (plane, column, piece)
-    float av[12];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int q = tid + SB_THREADS * t, plane = q / 768, rem = q - plane * 768, col = rem >> 2, piece = rem & 3;
+        b_off[t] = (unsigned)((((int64_t)plane * SB_N + col) * p.kpad + 8 * piece) * 2);
+        b_lds[t] = 3 * SB_A_PLANE + plane * SB_B_PLANE + col * SB_PITCH + 16 * piece;
+    }
+    u32x4 av[3];
     u32x4 bv[9];
     auto load_block = [&](int kb) {
+        const int kk = kb * SB_KB + 4 * ak4;
+        const bool whole = kk + 3 < p.k; // (only the last block has a tail: 963 = 30 x 32 + 3)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int row = row0 + ar + 16 * i;
-            const int kk = kb * SB_KB + 2 * akp;
-            const float *src = p.a + (size_t)row * p.k + kk;
-            av[2 * i] = (row < p.m && kk < p.k) ? src[0] : 0.f;
-            av[2 * i + 1] = (row < p.m && kk + 1 < p.k) ? src[1] : 0.f;
+        for (int i = 0; i < 3; ++i) {
+            const unsigned off = a_off[i] + (unsigned)kb * (SB_KB * 4);
+            if (whole) {
+                av[i] = __builtin_amdgcn_raw_buffer_load_b128(r_a, off, 0, 0);
+            } else { // the tail: element by element (a 16-byte load would run into the next row)
+                av[i].x = kk + 0 < p.k ? __builtin_amdgcn_raw_buffer_load_b32(r_a, off, 0, 0) : 0u;
+                av[i].y = kk + 1 < p.k ? __builtin_amdgcn_raw_buffer_load_b32(r_a, off + 4, 0, 0) : 0u;
+                av[i].z = kk + 2 < p.k ? __builtin_amdgcn_raw_buffer_load_b32(r_a, off + 8, 0, 0) : 0u;
+                av[i].w = 0u;
+            }
         }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int q = tid + SB_THREADS * t, plane = q / 768, rem = q - plane * 768, col = rem >> 2, piece = rem & 3;
-            bv[t] = *reinterpret_cast<const u32x4 *>(p.bt + ((size_t)plane * SB_N + col) * p.kpad + kb * SB_KB + 8 * piece);
-        }
+        for (int t = 0; t < 9; ++t) bv[t] = __builtin_amdgcn_raw_buffer_load_b128(r_b, b_off[t] + (unsigned)kb * (SB_KB * 2), 0, 0);
     };
     auto store_block = [&](unsigned char *buf) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            unsigned x0, x1, x2, y0, y1, y2;
-            split3(av[2 * i], x0, x1, x2);
-            split3(av[2 * i + 1], y0, y1, y2);
-            unsigned char *dst = buf + (ar + 16 * i) * SB_PITCH + 4 * akp;
-            *reinterpret_cast<unsigned *>(dst) = x0 | (y0 << 16);
-            *reinterpret_cast<unsigned *>(dst + SB_A_PLANE) = x1 | (y1 << 16);
-            *reinterpret_cast<unsigned *>(dst + 2 * SB_A_PLANE) = x2 | (y2 << 16);
+        for (int i = 0; i < 3; ++i) {
+            unsigned e[4][3];
+            split3(__uint_as_float(av[i].x), e[0][0], e[0][1], e[0][2]);
+            split3(__uint_as_float(av[i].y), e[1][0], e[1][1], e[1][2]);
+            split3(__uint_as_float(av[i].z), e[2][0], e[2][1], e[2][2]);
+            split3(__uint_as_float(av[i].w), e[3][0], e[3][1], e[3][2]);
+            unsigned char *dst = buf + (ar + 32 * i) * SB_PITCH + 8 * ak4;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                *reinterpret_cast<uint2 *>(dst + pl * SB_A_PLANE) = make_uint2(e[0][pl] | (e[1][pl] << 16), e[2][pl] | (e[3][pl] << 16));
         }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int q = tid + SB_THREADS * t, plane = q / 768, rem = q - plane * 768, col = rem >> 2, piece = rem & 3;
-            *reinterpret_cast<u32x4 *>(buf + 3 * SB_A_PLANE + plane * SB_B_PLANE + col * SB_PITCH + 16 * piece) = bv[t];
-        }
+        for (int t = 0; t < 9; ++t) *reinterpret_cast<u32x4 *>(buf + b_lds[t]) = bv[t];
     };
 
     f32x4 hi[3][6], lo[3][6];
@@ -132,33 +150,47 @@ __global__ __launch_bounds__(SB_THREADS, 1) void split_bf16_gemm_kernel(SbArgs p
     for (int kb = 0; kb < nkb; ++kb) {
         unsigned char *cur = lds + (kb & 1) * SB_BUF, *nxt = lds + ((kb + 1) & 1) * SB_BUF;
         if (kb + 1 < nkb) load_block(kb + 1); // in flight under this block's MFMAs
-        // ---- this block's products: A fragments of the wave's 3 row tiles x 3 planes, then column tile by column tile
+        // ---- this block's products: A fragments of the wave's 3 row tiles x 3 planes, then column tile by column tile with the
+        // NEXT tile's W fragments requested in front of this tile's MFMAs; per term the three row tiles in turn, so that an
+        // accumulator is touched every third MFMA (a dependent MFMA waits for its predecessor's passes)
         bf16x8 af[3][3];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
                 af[r][pl] = *reinterpret_cast<const bf16x8 *>(cur + pl * SB_A_PLANE + (48 * wy + 16 * r + lr) * SB_PITCH + 16 * lg);
+        const unsigned char *bbase = cur + 3 * SB_A_PLANE + (96 * wx + lr) * SB_PITCH + 16 * lg;
+        bf16x8 bf[3], bn[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bf[pl] = *reinterpret_cast<const bf16x8 *>(bbase + pl * SB_B_PLANE);
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            bf16x8 bf[3];
+            if (c + 1 < 6) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                bf[pl] = *reinterpret_cast<const bf16x8 *>(cur + 3 * SB_A_PLANE + pl * SB_B_PLANE + (96 * wx + 16 * c + lr) * SB_PITCH + 16 * lg);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                hi[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][0], bf[0], hi[r][c], 0, 0, 0);
-                lo[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][0], bf[1], lo[r][c], 0, 0, 0);
-                lo[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][1], bf[0], lo[r][c], 0, 0, 0);
-                lo[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][1], bf[1], lo[r][c], 0, 0, 0);
-                lo[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][0], bf[2], lo[r][c], 0, 0, 0);
-                lo[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][2], bf[0], lo[r][c], 0, 0, 0);
-                if (p.terms == 9) {
-                    lo[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][1], bf[2], lo[r][c], 0, 0, 0);
-                    lo[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][2], bf[1], lo[r][c], 0, 0, 0);
-                    lo[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][2], bf[2], lo[r][c], 0, 0, 0);
-                }
+                for (int pl = 0; pl < 3; ++pl) bn[pl] = *reinterpret_cast<const bf16x8 *>(bbase + pl * SB_B_PLANE + 16 * (c + 1) * SB_PITCH);
             }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) hi[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][0], bf[0], hi[r][c], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) lo[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][0], bf[1], lo[r][c], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) lo[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][1], bf[0], lo[r][c], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) lo[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][1], bf[1], lo[r][c], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) lo[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][0], bf[2], lo[r][c], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) lo[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][2], bf[0], lo[r][c], 0, 0, 0);
+            if (p.terms == 9) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) lo[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][1], bf[2], lo[r][c], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) lo[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][2], bf[1], lo[r][c], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) lo[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[r][2], bf[2], lo[r][c], 0, 0, 0);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bf[pl] = bn[pl];
         }
         if (kb + 1 < nkb) store_block(nxt);
         __syncthreads();
