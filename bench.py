@@ -52,7 +52,7 @@ VALU_ISSUE_TERA_LANE_OPS = FP32_PEAK_TFLOPS / 2.0
 VALU_MEASURED_TERA_LANE_OPS = 103.0 / 2.0
 TRI_ALGO_FLOP_PER_PAIR = 60.0    # hoisted op count of the reference's decision tree per (point, triangle)
 NN_FLOP_PER_PAIR = 8.0           # 3 sub, 3 mul, 2 add
-PROFILE_TAG = "r05"           # the committed profiles these figures are read from / compared with
+PROFILE_TAG = "r06"           # the committed profiles these figures are read from / compared with
 PMC_FILE = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_counters.json")
 
 
