@@ -807,9 +807,13 @@ def baseline_configs(dev):
                                              "bound": "mfma", "frac": round(GCN_GEMM_FLOP_PER_MESH * per_s(t4) / (FP32_PEAK_TFLOPS * 1e12), 4),
                                              "achieved_hbm": round(GCN_CUSTOM_BYTES_PER_MESH * per_s(t4) / (HBM_PEAK_GBS * 1e9), 4)}}
         del stack, feat
-    out["note"] = ("frac = SURVEY 8(d)'s algorithmic work of the pass x meshes/s over the roof of its dominant kernel (78.6 T lane-op/s "
-                   "un-fused fp32 VALU; 157.3 TFLOP/s fp32 MFMA); at B = 1 every pass is a chain of launches of a few microseconds "
-                   "each on a mostly idle chip")
+    out["note"] = ("frac = SURVEY 8(d)'s ALGORITHMIC work of the pass (all 15.36 M (point, triangle) pairs x 60 and 18 M (point, point) "
+                   "pairs x 8 lane-ops per mesh; executed flops for the products) x meshes/s over the roof of its dominant kernel (78.6 T "
+                   "lane-op/s un-fused fp32 VALU; 157.3 TFLOP/s fp32 MFMA).  Above 1 for config 3 at B = 8: the point-to-triangle scan "
+                   "is CULLED (bounding spheres per 16 triangles: ~4 x fewer executed lane-ops than the brute-force count the survey "
+                   "prices), so the algorithmic rate exceeds the issue roof -- the executed-instruction utilisation of that launch is "
+                   "other_kernels.surface_scan (0.28-0.31).  At B = 1 every pass is a chain of launches of a few microseconds each on a "
+                   "mostly idle chip")
     return out
 
 

@@ -112,7 +112,11 @@ __device__ __forceinline__ void db_load_slice(DbSlice &bw, const float *packed, 
     const unsigned b0 = ((unsigned)(wave * 36) * 64u + (unsigned)lane) * 16u;
 #pragma unroll
     for (int i = 0; i < 36; ++i) {
+#ifdef DB_PROBE_HOT_SLICE
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r_b, b0 + (unsigned)(i & 1) * 1024u, 0, 0); // probe: 2 KB per wave (L1 hits)
+#else
         const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r_b, b0 + (unsigned)i * 1024u, 0, 0);
+#endif
         bw.q[i] = (f32x4){__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
     }
 }
@@ -132,6 +136,9 @@ __device__ __forceinline__ void db_product(const DbSlice &bw, const float *panel
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+#ifdef DB_PROBE_FEW_MFMA
+            if (jp >= 2) continue; // probe: a sixth of the MFMAs (wrong results)
+#endif
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.at(jp, c, 0), af[c], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.at(jp, c, 1), af[c], acc[1], 0, 0, 0);
             acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.at(jp, c, 2), af[c], acc[2], 0, 0, 0);
