@@ -912,13 +912,18 @@ def driver_step_times(dev, batch=16, profile_replays=0, zero_edit=False):
 
     def predict():
         base = initial.unsqueeze(0).expand(batch, nv, 3)
-        f = utils.batched_pooling(maps[0], base, clone(img_info))
+        # (the edited driver tells the pooling how many columns will be concatenated in front of its features -- 3 coordinates,
+        # + the 192 previous features -- and uses utils.concat_features: no torch.cat of the 35 MB input, no slicing copies of its
+        # gradient; the zero-edit step keeps torch.cat)
+        cat = (lambda a, b_: torch.cat((a, b_), dim=-1)) if zero_edit else utils.concat_features
+        room = (lambda n: 0) if zero_edit else (lambda n: n)
+        f = utils.batched_pooling(maps[0], base, clone(img_info), headroom=room(3))
         f, p1 = blocks[0](base, f, info["adj"])
         p1 = base + p1
-        f = torch.cat((f, utils.batched_pooling(maps[1], clone(p1), clone(img_info))), dim=-1)
+        f = cat(f, utils.batched_pooling(maps[1], clone(p1), clone(img_info), headroom=room(3 + HID)))
         f, p2 = blocks[1](clone(p1), f, info["adj"])
         p2 = p2 + p1
-        f = torch.cat((f, utils.batched_pooling(maps[2], clone(p2), clone(img_info))), dim=-1)
+        f = cat(f, utils.batched_pooling(maps[2], clone(p2), clone(img_info), headroom=room(3 + HID)))
         _, p3 = blocks[2](clone(p2), f, info["adj"])
         return p1, p2, p3 + p2
 

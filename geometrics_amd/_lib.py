@@ -99,6 +99,8 @@ _SIGNATURES = {
     "geom_vertex_bn_bwd_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "geom_pool_features_fwd_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_pool_features_bwd_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
+    "geom_pool_features_fwd_ld_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp],
+    "geom_pool_features_bwd_ld_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "geom_colsum_batch_f32": [_i, _vp, _vp, _vp, _vp, _vp],
     "geom_adam_step_f32": [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _i, _vp],
     "geom_dense_fwd_f32": [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
@@ -146,7 +148,7 @@ class DeformBwd(ctypes.Structure):
     _fields_ = [("b", _i), ("nv", _i), ("c", _i), ("k", _i), ("ell_w", _i),
                 ("dz_up", _vp), ("ell_col_t", _vp), ("ell_val_t", _vp),
                 ("tail_col_t", _vp), ("tail_val_t", _vp),
-                ("ds_up", _vp), ("wt_up", _vp), ("g", _vp), ("g2", _vp),
+                ("ds_up", _vp), ("wt_up", _vp), ("g", _vp), ("g2", _vp), ("g_ld", _i), ("g2_ld", _i),
                 ("z", _vp), ("bn_w", _vp), ("bn_b", _vp), ("save_mean", _vp), ("save_invstd", _vp),
                 ("relu", _i), ("has_res", _i), ("scale", _f),
                 ("grad_res", _vp), ("dz", _vp), ("grad_bn_w", _vp), ("grad_bn_b", _vp), ("colsum", _vp), ("vpx", _i)]

@@ -394,15 +394,22 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_kernel(geom_deform_bwd a
     const unsigned own_off = mesh_on ? rowbase + (unsigned)v * (DB_C * 4) + 4 * c0 : DB_OOB;
     auto at = [&](int i) { return own_off == DB_OOB ? DB_OOB : own_off + 4 * DB_K * i; };
     // everything this layer's BatchNorm backward reads is requested with the gathers
-    const __amdgpu_buffer_rsrc_t r_z = db_rsrc(a.z, op_bytes), r_g2 = db_rsrc(a.g2, op_bytes), r_g = db_rsrc(a.g, op_bytes);
+    // g / g2 may be column slices of wider row-major buffers (row pitch g_ld / g2_ld floats; dword-aligned 16-byte buffer loads):
+    // the next block's input gradient is read in place instead of through a slicing copy
+    const int g_ld = a.g_ld ? a.g_ld : DB_C, g2_ld = a.g2_ld ? a.g2_ld : DB_C;
+    const __amdgpu_buffer_rsrc_t r_z = db_rsrc(a.z, op_bytes);
+    const __amdgpu_buffer_rsrc_t r_g2 = db_rsrc(a.g2, ((int64_t)a.b * a.nv - 1) * g2_ld * 4 + DB_C * 4);
+    const __amdgpu_buffer_rsrc_t r_g = db_rsrc(a.g, ((int64_t)a.b * a.nv - 1) * g_ld * 4 + DB_C * 4);
+    const unsigned g_off = mesh_on ? (((unsigned)rl * (unsigned)a.nv + (unsigned)v) * (unsigned)g_ld + (unsigned)c0) * 4u : DB_OOB;
+    const unsigned g2_off = mesh_on ? (((unsigned)rl * (unsigned)a.nv + (unsigned)v) * (unsigned)g2_ld + (unsigned)c0) * 4u : DB_OOB;
     const float mean = a.save_mean[v], invstd = a.save_invstd[v];
     const float gamma = a.bn_w ? a.bn_w[v] : 1.f, beta = a.bn_b ? a.bn_b[v] : 0.f;
     float4 zv[3], g2v[3], go[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         zv[i] = db_ld4(r_z, at(i));
-        g2v[i] = a.g2 ? db_ld4(r_g2, at(i)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!PRODUCT) go[i] = db_ld4(r_g, at(i));
+        g2v[i] = a.g2 ? db_ld4(r_g2, g2_off == DB_OOB ? DB_OOB : g2_off + 4 * DB_K * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!PRODUCT) go[i] = db_ld4(r_g, g_off == DB_OOB ? DB_OOB : g_off + 4 * DB_K * i);
     }
     float *stage = lds + DB_PANEL;
     if (PRODUCT) {
@@ -544,8 +551,10 @@ extern "C" int geom_deform_layer_bwd_f32(const geom_deform_bwd *args, void *stre
     const bool product = a.dz_up != nullptr;
     if (product ? (!a.ell_col_t || !a.ell_val_t || !a.ds_up || !a.wt_up) : !a.g) return GEOM_EINVAL;
     if (a.tail_col_t && !a.tail_val_t) return GEOM_EINVAL;
-    if (!db_aligned16(a.dz_up) || !db_aligned16(a.ell_col_t) || !db_aligned16(a.ell_val_t) || !db_aligned16(a.ds_up) || !db_aligned16(a.g) ||
-        !db_aligned16(a.g2) || !db_aligned16(a.z) || !db_aligned16(a.grad_res) || !db_aligned16(a.dz) || !db_aligned16(a.colsum) ||
+    if ((a.g_ld && a.g_ld < DB_C) || (a.g2_ld && a.g2_ld < DB_C)) return GEOM_EINVAL;
+    if ((int64_t)a.b * a.nv * (a.g_ld > a.g2_ld ? a.g_ld : a.g2_ld) >= (1LL << 29)) return GEOM_EUNSUPPORTED;
+    if (!db_aligned16(a.dz_up) || !db_aligned16(a.ell_col_t) || !db_aligned16(a.ell_val_t) || !db_aligned16(a.ds_up) || ((uintptr_t)a.g & 3) ||
+        ((uintptr_t)a.g2 & 3) || !db_aligned16(a.z) || !db_aligned16(a.grad_res) || !db_aligned16(a.dz) || !db_aligned16(a.colsum) ||
         !db_aligned16(a.wt_up))
         return GEOM_EINVAL;
     if (!a.has_res) a.scale = 1.f;

@@ -34,6 +34,7 @@ struct PoolArgs {
     int channels[GEOM_POOL_MAX_LEVELS], dims[GEOM_POOL_MAX_LEVELS];
     int levels, b, nv, ctot;
     int chunks; // 64-channel chunks of all maps together
+    int ld;     // floats between two vertex rows of the pooled features / of their gradient (>= ctot: a column slice of a wider buffer)
 };
 
 struct Projection {
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(PL_THREADS) void pool_fwd_kernel(PoolArgs a, float 
         __syncthreads();
         for (int i = threadIdx.x; i < PL_VERTS * nch; i += PL_THREADS) {
             const int vv = i / nch, ch = i - vv * nch;
-            if (v0 + vv < a.nv) out[((size_t)mesh * a.nv + v0 + vv) * a.ctot + ck.off + cc + ch] = tile[vv][ch];
+            if (v0 + vv < a.nv) out[((size_t)mesh * a.nv + v0 + vv) * a.ld + ck.off + cc + ch] = tile[vv][ch];
         }
         __syncthreads();
     }
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(PL_THREADS) void pool_bwd_verts_kernel(PoolArgs a, 
         const int nch = min(GEOM_WAVE, C - cc);
         for (int i = threadIdx.x; i < PL_VERTS * nch; i += PL_THREADS) {
             const int vv = i / nch, ch = i - vv * nch;
-            tile[vv][ch] = v0 + vv < a.nv ? grad_out[((size_t)mesh * a.nv + v0 + vv) * a.ctot + ck.off + cc + ch] : 0.f;
+            tile[vv][ch] = v0 + vv < a.nv ? grad_out[((size_t)mesh * a.nv + v0 + vv) * a.ld + ck.off + cc + ch] : 0.f;
         }
         __syncthreads();
         float gx = 0.f, gy = 0.f;
@@ -307,20 +308,20 @@ __global__ __launch_bounds__(PL_THREADS) void pool_gather_kernel(PoolArgs a, Bin
     const int *ev = ws.ent_v + ((size_t)mesh * a.levels + l) * 4 * a.nv;
     const float *ew = ws.ent_w + ((size_t)mesh * a.levels + l) * 4 * a.nv;
     const int e0 = offs[tx], e1 = offs[tx + 1];
-    const float *g = grad_out + (size_t)mesh * a.nv * a.ctot + off + (c < C ? c : 0);
+    const float *g = grad_out + (size_t)mesh * a.nv * a.ld + off + (c < C ? c : 0);
     float acc = 0.f;
     int e = e0;
     for (; e + 4 <= e1; e += 4) { // four rows in flight
         const int v0 = ev[e], v1 = ev[e + 1], v2 = ev[e + 2], v3 = ev[e + 3];
         const float w0 = ew[e], w1 = ew[e + 1], w2 = ew[e + 2], w3 = ew[e + 3];
-        const float g0 = g[(size_t)v0 * a.ctot], g1 = g[(size_t)v1 * a.ctot];
-        const float g2 = g[(size_t)v2 * a.ctot], g3 = g[(size_t)v3 * a.ctot];
+        const float g0 = g[(size_t)v0 * a.ld], g1 = g[(size_t)v1 * a.ld];
+        const float g2 = g[(size_t)v2 * a.ld], g3 = g[(size_t)v3 * a.ld];
         acc += g0 * w0;
         acc += g1 * w1;
         acc += g2 * w2;
         acc += g3 * w3;
     }
-    for (; e < e1; ++e) acc += g[(size_t)ev[e] * a.ctot] * ew[e];
+    for (; e < e1; ++e) acc += g[(size_t)ev[e] * a.ld] * ew[e];
     if (c < C) a.grad_blocks[l][((size_t)mesh * C + c) * texels + tx] = acc;
 }
 
@@ -337,10 +338,30 @@ int fill_args(PoolArgs &a, int b, int nv, const float *verts, const float *cam_m
         a.ctot += channels[l];
         a.chunks += (channels[l] + GEOM_WAVE - 1) / GEOM_WAVE;
     }
+    a.ld = a.ctot;
     return 0;
 }
 
 } // namespace
+
+// out_ld: floats between two vertex rows of `out` (0 = the pooled width: a contiguous [b,nv,sum channels] tensor; larger: the
+// features are written as a column slice of a wider row-major buffer -- the deformation block's concatenated input)
+extern "C" int geom_pool_features_fwd_ld_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos,
+                                             int levels, const float *const *blocks, const int *channels, const int *dims,
+                                             float *out, int64_t out_ld, void *stream)
+{
+    PoolArgs a;
+    if (int rc = fill_args(a, b, nv, verts, cam_mat, cam_pos, levels, blocks, channels, dims)) return rc;
+    if (b == 0 || nv == 0 || levels == 0) return 0;
+    if (!out) return GEOM_EINVAL;
+    if (out_ld) {
+        if (out_ld < a.ctot || out_ld > INT_MAX) return GEOM_EINVAL;
+        a.ld = (int)out_ld;
+    }
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3((nv + PL_VERTS - 1) / PL_VERTS, b, a.chunks < PL_MAX_CHUNKS ? a.chunks : PL_MAX_CHUNKS),
+                       dim3(PL_THREADS), 0, static_cast<hipStream_t>(stream), a, out);
+    return geom::launch_status();
+}
 
 extern "C" int geom_pool_features_fwd_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos,
                                           int levels, const float *const *blocks, const int *channels, const int *dims,
@@ -383,15 +404,34 @@ extern "C" size_t geom_pool_features_bwd_workspace_bytes(int b, int nv, int leve
     return pool_ws_layout(b, nv, levels, dims, nullptr, nullptr);
 }
 
+extern "C" int geom_pool_features_bwd_ld_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos,
+                                             int levels, const float *const *blocks, const int *channels, const int *dims,
+                                             const float *grad_out, int64_t grad_ld, float *const *grad_blocks, float *grad_verts,
+                                             void *workspace, size_t workspace_bytes, void *stream);
 extern "C" int geom_pool_features_bwd_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos,
                                           int levels, const float *const *blocks, const int *channels, const int *dims,
                                           const float *grad_out, float *const *grad_blocks, float *grad_verts,
                                           void *workspace, size_t workspace_bytes, void *stream)
 {
+    return geom_pool_features_bwd_ld_f32(b, nv, verts, cam_mat, cam_pos, levels, blocks, channels, dims, grad_out, 0, grad_blocks,
+                                         grad_verts, workspace, workspace_bytes, stream);
+}
+
+// grad_ld: floats between two vertex rows of `grad_out` (0 = the pooled width; larger: the gradient is read in place out of a
+// column slice of a wider buffer -- the input gradient of the deformation block's first product)
+extern "C" int geom_pool_features_bwd_ld_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos,
+                                             int levels, const float *const *blocks, const int *channels, const int *dims,
+                                             const float *grad_out, int64_t grad_ld, float *const *grad_blocks, float *grad_verts,
+                                             void *workspace, size_t workspace_bytes, void *stream)
+{
     PoolArgs a;
     if (int rc = fill_args(a, b, nv, verts, cam_mat, cam_pos, levels, blocks, channels, dims)) return rc;
     if (b == 0 || nv == 0 || levels == 0) return 0;
     if (!grad_out) return GEOM_EINVAL;
+    if (grad_ld) {
+        if (grad_ld < a.ctot || grad_ld > INT_MAX) return GEOM_EINVAL;
+        a.ld = (int)grad_ld;
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     bool any_map = false;
     int tasks = 0;

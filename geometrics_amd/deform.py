@@ -115,14 +115,29 @@ def layer_forward(s_in, bias, csr, bn_w, bn_b, run_mean, run_var, training, mome
         _lib.call("geom_deform_layer_fwd_f32", ctypes.addressof(a))
 
 
+def _rows192(t, shape):
+    """(tensor, row pitch in floats) of a [B,V,192] gradient as the backward launch reads it: in place when it is row-major
+    with contiguous rows at any pitch (a column slice of a wider buffer), a contiguous copy otherwise."""
+    if t is None:
+        return None, 0
+    b, nv, c = shape
+    ok = (t.dim() == 3 and tuple(t.shape) == (b, nv, c) and t.is_cuda and t.dtype == torch.float32 and t.stride(2) == 1
+          and t.stride(1) >= c and t.stride(0) == nv * t.stride(1) and t.data_ptr() % 4 == 0)
+    if not ok:
+        t = t.contiguous()
+    return t, t.stride(1)
+
+
 def layer_backward(shape, csr, z, bn_w, bn_b, save_mean, save_invstd, relu, has_res, scale, dz, grad_bn_w, grad_bn_b,
                    dz_up=None, ds_up=None, wt_up=None, g=None, g2=None, grad_res=None, colsum=None):
     """One backward launch (geom_deform_layer_bwd_f32); wt_up = the layer above's weight, TRANSPOSED and packed
     (pack_weights()[1][l])."""
     b, nv, c = shape
     tail = _tail_tables(csr)
+    g, g_ld = _rows192(g, shape)
+    g2, g2_ld = _rows192(g2, shape)
     a = _lib.DeformBwd(b, nv, c, 64, csr.ell_w, _p(dz_up), _p(csr.ell_col_t), _p(csr.ell_val_t), _p(tail[2]), _p(tail[3]),
-                       _p(ds_up), _p(wt_up), _p(g), _p(g2), _p(z), _p(bn_w), _p(bn_b), _p(save_mean),
+                       _p(ds_up), _p(wt_up), _p(g), _p(g2), g_ld, g2_ld, _p(z), _p(bn_w), _p(bn_b), _p(save_mean),
                        _p(save_invstd), int(relu), int(has_res), float(scale), _p(grad_res), _p(dz), _p(grad_bn_w),
                        _p(grad_bn_b), _p(colsum), 0)
     with torch.cuda.device(z.device):
@@ -176,9 +191,7 @@ class _HiddenChain(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         if g_a is None and g_b is None:
             return (None,) * (6 + 4 * L - 1)
-        g_top, g_top2 = (g_a, g_b) if g_a is not None else (g_b, None)
-        g_top = g_top.contiguous()
-        g_top2 = None if g_top2 is None else g_top2.contiguous()
+        g_top, g_top2 = (g_a, g_b) if g_a is not None else (g_b, None)      # (read in place at any row pitch: layer_backward)
         dzs = torch.empty(L, b, nv, c, **f32)         # dzs[i - 1] = dZ_i
         dss = torch.empty(L - 1, b, nv, c, **f32)     # dss[i - 2] = dS_i = gradient of layer i's raw support, i = 2..L
         g_bnw, g_bnb = torch.empty(L, nv, **f32), torch.empty(L, nv, **f32)

@@ -96,10 +96,22 @@ class _InputTap(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, features, pooled, width):
-        full = torch.cat((features, pooled), dim=-1)
+        from . import ops as _ops
+        nf = features.shape[-1]
+        # `pooled` allocated with room for the coordinates in front (utils.batched_pooling(headroom=...), utils.concat_features):
+        # they are copied into the free columns and the wide buffer IS the input -- no 35 MB concatenation
+        ctx.in_place = (features.dim() == 3 and features.is_cuda and features.dtype == torch.float32 and pooled.dtype == torch.float32
+                        and features.shape[:2] == pooled.shape[:2] and _ops.headroom_of(pooled) == nf)
+        if ctx.in_place:
+            buf = _ops._headroom[pooled.untyped_storage().data_ptr()][0]()
+            buf[..., :nf].copy_(features)
+            _ops._register_headroom(buf, 0)
+            full = buf
+        else:
+            full = torch.cat((features, pooled), dim=-1)
         if width > full.shape[-1]:
             raise RuntimeError("the block input has %d columns, fewer than the %d hidden ones" % (full.shape[-1], width))
-        ctx.nf, ctx.width = features.shape[-1], width
+        ctx.nf, ctx.width = nf, width
         ctx.shapes = (features.shape, pooled.shape)
         return full, full[..., :width].contiguous()
 
@@ -113,9 +125,16 @@ class _InputTap(torch.autograd.Function):
             if g_res is not None and lead:
                 gf[..., :lead] += g_res[..., :lead]
         if ctx.needs_input_grad[1]:
-            gp = g_full[..., nf:].contiguous() if g_full is not None else g_res.new_zeros(ctx.shapes[1])
-            if g_res is not None and width > nf:
-                gp[..., :width - nf] += g_res[..., nf:width]
+            if g_full is not None and ctx.in_place and g_full.is_contiguous():
+                # the consumers (pooling backward, the previous block's last layer) read their column slices of the ONE input
+                # gradient in place; the residual's share is added into it (nothing else reads g_full)
+                gp = g_full[..., nf:]
+                if g_res is not None and width > nf:
+                    gp[..., :width - nf].add_(g_res[..., nf:width])
+            else:
+                gp = g_full[..., nf:].contiguous() if g_full is not None else g_res.new_zeros(ctx.shapes[1])
+                if g_res is not None and width > nf:
+                    gp[..., :width - nf] += g_res[..., nf:width]
         return gf, gp, None
 
 

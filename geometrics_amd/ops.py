@@ -457,29 +457,6 @@ class EdgeSqLenSum(torch.autograd.Function):
         return grad_verts, None
 
 
-_incidence_cache = {}     # id(faces tensor) -> (weakref, version, nv, vf_ptr, vf_item)
-
-
-def vertex_faces(faces, nv):
-    """(vf_ptr [nv+1], vf_item) int32: every vertex's incident corners as face * 4 + corner, ascending -- what the edge
-    term's gradient gathers over (geom_stage_regularisers_bwd_f32).  Cached per faces TENSOR OBJECT and in-place version."""
-    import weakref
-    key = id(faces)
-    hit = _incidence_cache.get(key)
-    if hit is not None and hit[0]() is faces and hit[1] == faces._version and hit[2] == nv:
-        return hit[3], hit[4]
-    with torch.no_grad():
-        f = faces.reshape(-1).long()                                  # corner c of face i sits at 3 i + c
-        item = (torch.arange(f.numel(), device=f.device) // 3) * 4 + torch.arange(f.numel(), device=f.device) % 3
-        order = torch.argsort(f * (4 * faces.shape[0] + 4) + item)    # by vertex, then ascending (face, corner)
-        counts = torch.bincount(f, minlength=nv)
-        vf_ptr = torch.zeros(nv + 1, dtype=torch.int64, device=f.device)
-        vf_ptr[1:] = torch.cumsum(counts, 0)
-        vf_ptr, vf_item = vf_ptr.to(torch.int32).contiguous(), item[order].to(torch.int32).contiguous()
-    _incidence_cache[key] = (weakref.ref(faces, lambda _ref, k=key: _incidence_cache.pop(k, None)), faces._version, nv, vf_ptr, vf_item)
-    return vf_ptr, vf_item
-
-
 class StageRegularisers(torch.autograd.Function):
     """The regularisers of ONE deformation stage as one scalar (GEOMetrics.py:147-161 on utils.py:636-662):
         w_edge * mean over (mesh, face) of (|e1|^2 + |e2|^2 + |e3|^2)(cur) / 3
@@ -528,13 +505,75 @@ class StageRegularisers(torch.autograd.Function):
         return grad_prev, (grad_cur if ctx.needs_input_grad[1] else None), None, None, None, None, None, None, None
 
 
+# ---- feature buffers with HEADROOM: concatenation without torch.cat ------------------------------------------------------------
+# The driver builds a deformation block's input as cat(positions, cat(previous features, pooled features)) (GEOMetrics.py:118-131,
+# models.py:241): two copies of ~35 MB forward per stage, and slicing copies of the same size when the gradient of the
+# concatenation is taken apart again.  A pooling call that is told how many columns will be put IN FRONT of its output
+# (`headroom`) allocates the wide buffer itself and writes its features at that column offset (geom_pool_features_fwd_ld_f32); the
+# later "concatenations" (`concat_in_front`) only copy the narrow operand into the free columns and widen the view, and in the
+# backward pass every consumer reads its column slice of the ONE wide gradient in place.
+_headroom = {}     # storage address -> (weak reference to the wide buffer, columns still free in front of the view handed out)
+
+
+def _register_headroom(buf, free):
+    import weakref
+    key = buf.untyped_storage().data_ptr()
+    _headroom[key] = (weakref.ref(buf, lambda _r, k=key: _headroom.pop(k, None)), free)
+
+
+def headroom_of(t):
+    """Free columns in front of `t` [B,V,C] inside a wide buffer made by PoolFeatures(headroom=...) / concat_in_front, or 0."""
+    if not (torch.is_tensor(t) and t.dim() == 3 and t.is_cuda and t.stride(2) == 1):
+        return 0
+    hit = _headroom.get(t.untyped_storage().data_ptr())
+    if hit is None or hit[0]() is None:
+        return 0
+    buf, free = hit[0](), hit[1]
+    ld = buf.shape[2]
+    if t.stride(1) != ld or t.stride(0) != t.shape[1] * ld or t.shape[:2] != buf.shape[:2] or t.storage_offset() != free:
+        return 0
+    return free if free + t.shape[2] == ld else 0
+
+
+class _ConcatInFront(torch.autograd.Function):
+    """cat((front, wide_view), -1) where wide_view has headroom: `front` is copied into the free columns right in front of the
+    view and the view grows to cover them -- no copy of the wide operand; backward: the two column slices of the gradient,
+    as views."""
+
+    @staticmethod
+    def forward(ctx, front, view):
+        hit = _headroom[view.untyped_storage().data_ptr()]
+        buf, free = hit[0](), hit[1]
+        cf = front.shape[2]
+        buf[..., free - cf:free].copy_(front)
+        out = buf[..., free - cf:]
+        _register_headroom(buf, free - cf)
+        ctx.cf = cf
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[..., :ctx.cf], g[..., ctx.cf:]
+
+
+def concat_in_front(front, view):
+    """torch.cat((front, view), dim=-1) for [B,V,*] tensors -- without touching `view` when it was allocated with headroom for
+    `front` (PoolFeatures(headroom=...)); a plain torch.cat otherwise."""
+    if (torch.is_tensor(front) and front.dim() == 3 and front.is_cuda and front.dtype == torch.float32 and view.dtype == torch.float32
+            and front.shape[:2] == view.shape[:2] and 0 < front.shape[2] <= headroom_of(view)):
+        return _ConcatInFront.apply(front, view)
+    return torch.cat((front, view), dim=-1)
+
+
 class PoolFeatures(torch.autograd.Function):
     """Bilinear pooling of the image feature maps at the projected vertex positions (reference
     batched_pooling, utils.py:316-389): one kernel forward, one backward (texel scatters + closed-form
     chain to the vertex positions)."""
 
     @staticmethod
-    def forward(ctx, verts, cam_mat, cam_pos, *blocks):
+    def forward(ctx, verts, cam_mat, cam_pos, headroom, *blocks):
+        """headroom: columns left free IN FRONT of the pooled features (0: a plain contiguous result; see concat_in_front)."""
+        headroom = int(headroom or 0)
         import ctypes
         v = _f32(verts, "verts_pos", 3, 3)
         cam_mat = _f32(cam_mat, "cam_mat", 3, 3)
@@ -548,10 +587,16 @@ class PoolFeatures(torch.autograd.Function):
         ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in blks])
         chans = (ctypes.c_int * n)(*[t.shape[1] for t in blks])
         dims = (ctypes.c_int * n)(*[t.shape[2] for t in blks])
-        out = torch.empty(b, nv, sum(t.shape[1] for t in blks), dtype=torch.float32, device=v.device)
+        ctot = sum(t.shape[1] for t in blks)
+        if headroom > 0:      # the features as the trailing columns of a wider buffer: see concat_in_front
+            buf = torch.empty(b, nv, headroom + ctot, dtype=torch.float32, device=v.device)
+            out = buf[..., headroom:]
+            _register_headroom(buf, headroom)
+        else:
+            out = torch.empty(b, nv, ctot, dtype=torch.float32, device=v.device)
         with torch.cuda.device(v.device):
-            _lib.call("geom_pool_features_fwd_f32", b, nv, v.data_ptr(), cam_mat.data_ptr(), cam_pos.data_ptr(), n,
-                      ptrs, chans, dims, out.data_ptr())
+            _lib.call("geom_pool_features_fwd_ld_f32", b, nv, v.data_ptr(), cam_mat.data_ptr(), cam_pos.data_ptr(), n,
+                      ptrs, chans, dims, out.data_ptr(), headroom + ctot if headroom > 0 else 0)
         ctx.save_for_backward(v, cam_mat, cam_pos, *blks)
         ctx.meta = (ptrs, chans, dims, n)
         return out
@@ -562,9 +607,15 @@ class PoolFeatures(torch.autograd.Function):
         v, cam_mat, cam_pos = ctx.saved_tensors[:3]
         blks = ctx.saved_tensors[3:]
         ptrs, chans, dims, n = ctx.meta
-        g = grad_out.contiguous()
         b, nv, _ = v.shape
-        need_blocks = [ctx.needs_input_grad[3 + i] for i in range(n)]
+        ctot = grad_out.shape[2]
+        # the gradient in place when it is a column slice of a wider row-major buffer (the block's input gradient), else contiguous
+        if grad_out.stride(2) == 1 and grad_out.stride(1) >= ctot and grad_out.stride(0) == nv * grad_out.stride(1) and grad_out.is_cuda \
+                and grad_out.dtype == torch.float32:
+            g, g_ld = grad_out, grad_out.stride(1)
+        else:
+            g, g_ld = grad_out.contiguous(), ctot
+        need_blocks = [ctx.needs_input_grad[4 + i] for i in range(n)]
         gblks = [torch.empty_like(t) if need else None for t, need in zip(blks, need_blocks)]
         gptrs = (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in gblks])
         gverts = torch.empty_like(v) if ctx.needs_input_grad[0] else None
@@ -575,9 +626,9 @@ class PoolFeatures(torch.autograd.Function):
             ws_bytes = _lib.lib().geom_pool_features_bwd_workspace_bytes(b, nv, n, dims)
             ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=v.device)
         with torch.cuda.device(v.device):
-            _lib.call("geom_pool_features_bwd_f32", b, nv, v.data_ptr(), cam_mat.data_ptr(), cam_pos.data_ptr(), n,
-                      ptrs, chans, dims, g.data_ptr(), gptrs, _lib.ptr(gverts), _lib.ptr(ws), ws_bytes)
-        return (gverts, None, None) + tuple(gblks)
+            _lib.call("geom_pool_features_bwd_ld_f32", b, nv, v.data_ptr(), cam_mat.data_ptr(), cam_pos.data_ptr(), n,
+                      ptrs, chans, dims, g.data_ptr(), g_ld if g_ld != ctot else 0, gptrs, _lib.ptr(gverts), _lib.ptr(ws), ws_bytes)
+        return (gverts, None, None, None) + tuple(gblks)
 
 
 class SegmentMax(torch.autograd.Function):

@@ -220,9 +220,19 @@ def batch_camera_info(param):
     return torch.stack(rows, dim=1), cam_pos
 
 
-def batched_pooling(blocks, verts_pos, img_info):
+def batched_pooling(blocks, verts_pos, img_info, headroom=0):
     """[B,V,sum C] image features bilinearly pooled from the encoder maps `blocks` (each [B,C,d,d]) at the
     pixels the vertices project to (reference utils.py:316-389).  Differentiable in the maps and in the
-    vertex positions; one HIP kernel per direction instead of ~40 eager ops per call."""
+    vertex positions; one HIP kernel per direction instead of ~40 eager ops per call.
+    headroom (not a reference argument): how many columns the caller is going to concatenate IN FRONT of the result
+    (GEOMetrics.py:123,128: the previous features; models.py:241: the 3 coordinates) -- the features are then written as the
+    trailing columns of a buffer that wide and `concat_features` / the deformation block fill the front in place of torch.cat."""
     cam_mat, cam_pos = batch_camera_info(img_info)
-    return ops.PoolFeatures.apply(verts_pos, cam_mat.detach(), cam_pos.detach(), *blocks)
+    return ops.PoolFeatures.apply(verts_pos, cam_mat.detach(), cam_pos.detach(), int(headroom), *blocks)
+
+
+def concat_features(front, pooled):
+    """torch.cat((front, pooled), dim=-1) (GEOMetrics.py:123,128) -- without copying `pooled` when it came from
+    batched_pooling(..., headroom=...) with room for `front` (and, in the backward pass, without the slicing copies of the
+    concatenation's gradient); a plain torch.cat otherwise."""
+    return ops.concat_in_front(front, pooled)

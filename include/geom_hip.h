@@ -413,6 +413,7 @@ typedef struct geom_deform_bwd {
     const int *tail_col_t; const float *tail_val_t;
     float *ds_up; const float *wt_up;
     const float *g, *g2;
+    int g_ld, g2_ld;            /* floats between two rows of g / g2 (0 = 192): column slices of wider buffers are read in place */
     const float *z, *bn_w, *bn_b, *save_mean, *save_invstd;
     int relu, has_res; float scale;
     float *grad_res, *dz, *grad_bn_w, *grad_bn_b, *colsum;
@@ -535,6 +536,17 @@ int geom_pool_features_bwd_f32(int b, int nv, const float *verts, const float *c
                                int levels, const float *const *blocks, const int *channels, const int *dims,
                                const float *grad_out, float *const *grad_blocks, float *grad_verts,
                                void *workspace, size_t workspace_bytes, void *stream);
+/* The same two with a ROW PITCH: out_ld / grad_ld = floats between two vertex rows (0 = the pooled width, i.e. the calls
+ * above).  Larger: the features are written into / their gradient is read out of a column slice of a wider row-major buffer --
+ * the deformation block's concatenated input [positions | previous features | pooled] and the input gradient of its first
+ * product -- so that neither `torch.cat` (utils.py / models.py:241) nor the slicing copies of its backward are launched. */
+int geom_pool_features_fwd_ld_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos, int levels,
+                                  const float *const *blocks, const int *channels, const int *dims, float *out, int64_t out_ld,
+                                  void *stream);
+int geom_pool_features_bwd_ld_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos, int levels,
+                                  const float *const *blocks, const int *channels, const int *dims, const float *grad_out,
+                                  int64_t grad_ld, float *const *grad_blocks, float *grad_verts, void *workspace,
+                                  size_t workspace_bytes, void *stream);
 
 /* ---- culled Chamfer scan inside the surface step (optional; NULL everywhere = the brute-force tiles) ------------------
  * The culled scan (geom_chamfer_nn_culled_f32) needs both clouds listed in a spatially coherent order, as an INDEX

@@ -274,3 +274,51 @@ def test_packed_weight_slices_hold_the_matrix_and_its_transpose(gpu):
     for n, w in enumerate(ws):
         m = w.reshape(192, 192).cpu().numpy()
         assert np.array_equal(fwd[n].cpu().numpy(), m[k, col]) and np.array_equal(bwd[n].cpu().numpy(), m[col, k])
+
+
+def test_block_input_assembled_in_place_equals_the_concatenations(gpu):
+    """The driver builds a block's input as cat(positions, cat(previous features, pooled)) (GEOMetrics.py:123-129, models.py:241).
+    With `utils.batched_pooling(..., headroom=3 + 192)` + `utils.concat_features` the pooled features are written straight into
+    the wide buffer, the fronts are copied into its free columns, and in the backward pass the pooling and the previous layer
+    read their column slices of the ONE input gradient in place (row pitch 1155).  Against the same computation with plain
+    torch.cat: features, coordinates and every gradient (maps, positions, previous features, parameters) bit for bit."""
+    import copy
+    from geometrics_amd import ops
+    nv, adj, csr = _mesh("uv_sphere_482", gpu)
+    torch.manual_seed(14)
+    b = 16
+    block = models.BatchMeshDeformationBlock(3 + 192 + 96, nv).to(gpu).train()
+    twin = copy.deepcopy(block)
+    maps = [torch.randn(b, c, d, d, device=gpu) for c, d in ((64, 14), (32, 7))]
+    pos = (torch.from_numpy(meshgen.uv_sphere()[0]).to(gpu).unsqueeze(0) + 0.02 * torch.randn(b, nv, 3, device=gpu))
+    prev = torch.randn(b, nv, 192, device=gpu)
+    img = torch.tensor([[30.0 + 7 * i, 20.0, 1.2] for i in range(b)], device=gpu)
+    g_f, g_c = torch.randn(b, nv, 192, device=gpu), torch.randn(b, nv, 3, device=gpu)
+
+    def run(blk, in_place):
+        ms = [m.clone().requires_grad_(True) for m in maps]
+        p, f_prev = pos.clone().requires_grad_(True), prev.clone().requires_grad_(True)
+        pooled = utils.batched_pooling(ms, p, img, headroom=3 + 192 if in_place else 0)
+        assert (ops.headroom_of(pooled) == 195) == in_place
+        f = utils.concat_features(f_prev, pooled) if in_place else torch.cat((f_prev, pooled), dim=-1)
+        assert f.shape == (b, nv, 192 + 96) and (ops.headroom_of(f) == 3) == in_place
+        out_f, coords = blk(p, f, adj)
+        ((out_f * g_f).sum() + (coords * g_c).sum()).backward()
+        return [out_f.detach(), coords.detach(), p.grad, f_prev.grad] + [m.grad for m in ms] + [q.grad for q in blk.parameters() if q.grad is not None]
+    got = run(block, True)
+    want = run(twin, False)
+    assert len(got) == len(want) and len(got) > 60
+    for a, w in zip(got, want):
+        assert torch.equal(a, w)
+    # pooling alone: the pitched forward and a pitched upstream gradient give the plain call's bits
+    ms = [m.clone().requires_grad_(True) for m in maps]
+    p = pos.clone().requires_grad_(True)
+    wide = utils.batched_pooling(ms, p, img, headroom=5)
+    plain = utils.batched_pooling([m.detach() for m in ms], p.detach(), img)
+    assert torch.equal(wide, plain) and not wide.is_contiguous()
+    g_wide = torch.randn(b, nv, 5 + 96, device=gpu)
+    wide.backward(g_wide[..., 5:])
+    ms2 = [m.clone().requires_grad_(True) for m in maps]
+    p2 = pos.clone().requires_grad_(True)
+    utils.batched_pooling(ms2, p2, img).backward(g_wide[..., 5:].contiguous())
+    assert torch.equal(p.grad, p2.grad) and all(torch.equal(x.grad, y.grad) for x, y in zip(ms, ms2))
