@@ -917,25 +917,30 @@ def driver_step_times(dev, batch=16, profile_replays=0, zero_edit=False):
         # gradient; the zero-edit step keeps torch.cat)
         cat = (lambda a, b_: torch.cat((a, b_), dim=-1)) if zero_edit else utils.concat_features
         room = (lambda n: 0) if zero_edit else (lambda n: n)
+        # a stage's positions have six consumers (pooling, next block, next stage's sum, surface loss, two regularisers):
+        # utils.fan_out hands each its own handle and sums their six gradients in one launch instead of five
+        fan = (lambda t, n: (t,) * n) if zero_edit else utils.fan_out
         f = utils.batched_pooling(maps[0], base, clone(img_info), headroom=room(3))
         f, p1 = blocks[0](base, f, info["adj"])
-        p1 = base + p1
-        f = cat(f, utils.batched_pooling(maps[1], clone(p1), clone(img_info), headroom=room(3 + HID)))
-        f, p2 = blocks[1](clone(p1), f, info["adj"])
-        p2 = p2 + p1
-        f = cat(f, utils.batched_pooling(maps[2], clone(p2), clone(img_info), headroom=room(3 + HID)))
-        _, p3 = blocks[2](clone(p2), f, info["adj"])
-        return p1, p2, p3 + p2
+        p1 = fan(base + p1, 6)
+        f = cat(f, utils.batched_pooling(maps[1], clone(p1[0]), clone(img_info), headroom=room(3 + HID)))
+        f, p2 = blocks[1](clone(p1[1]), f, info["adj"])
+        p2 = fan(p2 + p1[2], 6)
+        f = cat(f, utils.batched_pooling(maps[2], clone(p2[0]), clone(img_info), headroom=room(3 + HID)))
+        _, p3 = blocks[2](clone(p2[1]), f, info["adj"])
+        p3 = fan(p3 + p2[2], 2)
+        return p1[3:], p2[3:], p3
 
     def losses(p1, p2, p3):
         # GEOMetrics.py:134-161 with its weights folded into the operators: surface_loss_k * (.2, .2, 2); per stage
         # 300 * edge(p_k) + .2 * (1500 * lap term [* .3 for stage 1] + 100 * displacement term) as ONE node per stage
         # (utils.stage_regularisers; the zero-edit step below keeps the driver's own expressions)
+        # p1, p2: (surface-loss handle, regulariser handle as `cur`, regulariser handle as `prev`); p3: (surface, cur)
         surf = lambda p, wgt: utils.batch_point_to_surface(p, info, gt, num=S_PTS, gt_index=gt_index, weight=wgt)
-        surface = surf(p1, .2) + surf(p2, .2) + surf(p3, 2.0)
-        reg = (utils.stage_regularisers(initial, p1, info, lap_weight=.2 * .3 * 1500, edge_weight=300)
-               + utils.stage_regularisers(p1, p2, info, lap_weight=.2 * 1500, move_weight=.2 * 100, edge_weight=300)
-               + utils.stage_regularisers(p2, p3, info, lap_weight=.2 * 1500, move_weight=.2 * 100, edge_weight=300))
+        surface = surf(p1[0], .2) + surf(p2[0], .2) + surf(p3[0], 2.0)
+        reg = (utils.stage_regularisers(initial, p1[1], info, lap_weight=.2 * .3 * 1500, edge_weight=300)
+               + utils.stage_regularisers(p1[2], p2[1], info, lap_weight=.2 * 1500, move_weight=.2 * 100, edge_weight=300)
+               + utils.stage_regularisers(p2[2], p3[1], info, lap_weight=.2 * 1500, move_weight=.2 * 100, edge_weight=300))
         return surface + reg
 
     def zero():
@@ -960,7 +965,7 @@ def driver_step_times(dev, batch=16, profile_replays=0, zero_edit=False):
 
         def driver_step():
             adam.zero_grad()
-            p1, p2, p3 = predict()
+            p1, p2, p3 = (h[0] for h in predict())
             s1 = p2s(p1.clone(), info, gt, num=S_PTS)
             s2 = p2s(p2.clone(), info, gt, num=S_PTS)
             s3, f1 = p2s(p3.clone(), info, gt, num=S_PTS, f1=True)

@@ -121,6 +121,7 @@ _SIGNATURES = {
     "geom_zn_layer_fwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_zn_layer_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp],
     "geom_camera_info_f32": [_i, _vp, _vp, _vp, _vp],
+    "geom_sum_tensors_f32": [_i, _vp, ctypes.c_int64, _vp, _vp],
     "geom_split_bf16_planes_f32": [_i, _i, _vp, _vp, _vp],
     "geom_gemm_split_bf16_f32": [_i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "geom_stage_regularisers_fwd_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp],

@@ -274,3 +274,38 @@ extern "C" int geom_edge_sqlen_bwd_f32(int b, int nv, const float *verts, int nf
                        static_cast<hipStream_t>(stream), b, nv, verts, nf, faces, coef_dev, coef_host, grad_verts);
     return geom::launch_status();
 }
+
+// out[i] = ((t0[i] + t1[i]) + t2[i]) + ...   for up to GEOM_SUM_MAX_TENSORS equally sized fp32 tensors: the gradients that reach one
+// tensor through several consumers (a stage's positions feed the pooling, the next block, two regularisers, the surface loss
+// and the next stage's sum: autograd adds them with one launch per consumer), in ONE launch and a fixed order.
+namespace {
+struct SumArgs {
+    const float *t[GEOM_SUM_MAX_TENSORS];
+    int count;
+};
+__global__ __launch_bounds__(RG_THREADS) void sum_tensors_kernel(SumArgs a, int64_t n, float *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * RG_THREADS + threadIdx.x;
+    if (i >= n) return;
+    float s = a.t[0][i];
+#pragma unroll
+    for (int k = 1; k < GEOM_SUM_MAX_TENSORS; ++k)
+        if (k < a.count) s += a.t[k][i];
+    out[i] = s;
+}
+} // namespace
+
+extern "C" int geom_sum_tensors_f32(int count, const float *const *tensors, int64_t n, float *out, void *stream)
+{
+    if (count <= 0 || count > GEOM_SUM_MAX_TENSORS || n < 0) return GEOM_EINVAL;
+    if (n == 0) return 0;
+    if (!tensors || !out) return GEOM_EINVAL;
+    SumArgs a{};
+    for (int k = 0; k < count; ++k) {
+        if (!tensors[k]) return GEOM_EINVAL;
+        a.t[k] = tensors[k];
+    }
+    a.count = count;
+    hipLaunchKernelGGL(sum_tensors_kernel, rg_grid(n), dim3(RG_THREADS), 0, static_cast<hipStream_t>(stream), a, n, out);
+    return geom::launch_status();
+}

@@ -457,6 +457,38 @@ class EdgeSqLenSum(torch.autograd.Function):
         return grad_verts, None
 
 
+class FanOut(torch.autograd.Function):
+    """n tensor objects over x's memory, one per consumer: their gradients meet in ONE launch (geom_sum_tensors_f32, fixed
+    order) instead of autograd's n - 1 accumulation launches.  A stage's positions have six consumers in the reference's
+    driver (GEOMetrics.py:118-161)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        from .layers import _alias
+        xc = x if x.is_contiguous() else x.contiguous()
+        ctx.n = n
+        return tuple(_alias(xc) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes
+        given = [g.contiguous() for g in grads if g is not None]
+        if not given:
+            return None, None
+        if len(given) == 1:
+            return given[0], None
+        out = torch.empty_like(given[0])
+        if not (out.is_cuda and out.dtype == torch.float32) or len(given) > 8:
+            total = given[0]
+            for g in given[1:]:
+                total = total + g
+            return total, None
+        ptrs = (ctypes.c_void_p * len(given))(*[g.data_ptr() for g in given])
+        with torch.cuda.device(out.device):
+            _lib.call("geom_sum_tensors_f32", len(given), ptrs, out.numel(), out.data_ptr())
+        return out, None
+
+
 class StageRegularisers(torch.autograd.Function):
     """The regularisers of ONE deformation stage as one scalar (GEOMetrics.py:147-161 on utils.py:636-662):
         w_edge * mean over (mesh, face) of (|e1|^2 + |e2|^2 + |e3|^2)(cur) / 3

@@ -231,6 +231,12 @@ def batched_pooling(blocks, verts_pos, img_info, headroom=0):
     return ops.PoolFeatures.apply(verts_pos, cam_mat.detach(), cam_pos.detach(), int(headroom), *blocks)
 
 
+def fan_out(x, n):
+    """n handles on the same tensor, one per consumer (not a reference name): results are those of using `x` n times; the n
+    gradients are summed by one launch in a fixed order instead of n - 1 accumulation launches."""
+    return ops.FanOut.apply(x, int(n)) if n > 1 else (x,)
+
+
 def concat_features(front, pooled):
     """torch.cat((front, pooled), dim=-1) (GEOMetrics.py:123,128) -- without copying `pooled` when it came from
     batched_pooling(..., headroom=...) with room for `front` (and, in the backward pass, without the slicing copies of the

@@ -445,6 +445,12 @@ int geom_stage_regularisers_bwd_f32(int b, int nv, const float *prev, int prev_b
                                     const int *vf_ptr, const int *vf_item, float c_lap, float c_move, float c_edge,
                                     const float *lapd, const float *gout, float *grad_prev, float *grad_cur, void *stream);
 
+/* out = ((t[0] + t[1]) + t[2]) + ... element by element, count <= GEOM_SUM_MAX_TENSORS contiguous fp32 tensors of n elements (HOST
+ * array of device pointers): the gradients that reach one tensor through several consumers, summed by ONE launch in a fixed order
+ * instead of one accumulation launch per consumer (python: utils.fan_out). */
+#define GEOM_SUM_MAX_TENSORS 8
+int geom_sum_tensors_f32(int count, const float *const *tensors, int64_t n, float *out, void *stream);
+
 /* Camera of every image from param [b,3] = (azimuth deg, elevation deg, distance) (reference utils.py:286-313: ~35 tiny
  * torch launches per call, three calls per training step): cam_mat [b,3,3] (rows = the camera's normalised x, y, z axes),
  * cam_pos [b,3] -- the operands of geom_pool_features_*; the same fp32 expressions in the same order, one launch. */

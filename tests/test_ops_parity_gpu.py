@@ -1731,3 +1731,26 @@ def test_the_timed_route_against_the_oracle_at_the_config5_shard(gpu):
     close(loss.item(), exact_loss, 1e-5)
     rows_close(verts.grad.cpu().numpy(), exact, mass, ROW_RTOL_SURFACE, "timed route, grad_verts at the config-5 shard", floor,
                ROW_FLOOR_ULPS)
+
+
+def test_fan_out_sums_its_handles_gradients_in_one_launch(gpu):
+    """utils.fan_out(x, n): n handles on one tensor whose gradients meet in ONE launch (geom_sum_tensors_f32: ((g0 + g1) + g2) + ...)
+    -- the same values as using x n times (autograd's pairwise accumulation in the same order gives the same bits for three
+    handles; for more the order of autograd's adds is its own, so the comparison is to fp32 round-off)."""
+    torch.manual_seed(15)
+    x = torch.randn(16, 482, 3, device=gpu, requires_grad=True)
+    ws = [torch.randn(16, 482, 3, device=gpu) for _ in range(6)]
+    hs = utils.fan_out(x, 6)
+    assert all(h.data_ptr() == x.data_ptr() for h in hs) and len({id(h) for h in hs}) == 6
+    sum((h * w).sum() for h, w in zip(hs, ws)).backward()
+    expect = ((((ws[0] + ws[1]) + ws[2]) + ws[3]) + ws[4]) + ws[5]
+    assert torch.equal(x.grad, expect)
+    y = x.detach().clone().requires_grad_(True)
+    sum((y * w).sum() for w in ws).backward()
+    assert float((x.grad - y.grad).abs().max()) <= 1e-6 * float(y.grad.abs().max())
+    a, = utils.fan_out(x, 1)
+    assert a is x
+    hs = utils.fan_out(x, 3)                      # a handle nobody uses contributes nothing
+    x.grad = None
+    ((hs[0] * ws[0]).sum() + (hs[2] * ws[2]).sum()).backward()
+    assert torch.equal(x.grad, ws[0] + ws[2])
