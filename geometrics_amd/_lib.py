@@ -141,7 +141,7 @@ class DeformFwd(ctypes.Structure):
                 ("training", _i), ("momentum", _f), ("eps", _f), ("relu", _i),
                 ("res", _vp), ("res_ld", _i), ("scale", _f),
                 ("z_out", _vp), ("x_out", _vp), ("save_mean", _vp), ("save_invstd", _vp),
-                ("w_next", _vp), ("s_out", _vp), ("vpx", _i)]
+                ("w_next", _vp), ("s_out", _vp), ("w_head", _vp), ("s_head", _vp), ("vpx", _i)]
 
 
 class DeformBwd(ctypes.Structure):
@@ -152,7 +152,8 @@ class DeformBwd(ctypes.Structure):
                 ("ds_up", _vp), ("wt_up", _vp), ("g", _vp), ("g2", _vp), ("g_ld", _i), ("g2_ld", _i),
                 ("z", _vp), ("bn_w", _vp), ("bn_b", _vp), ("save_mean", _vp), ("save_invstd", _vp),
                 ("relu", _i), ("has_res", _i), ("scale", _f),
-                ("grad_res", _vp), ("dz", _vp), ("grad_bn_w", _vp), ("grad_bn_b", _vp), ("colsum", _vp), ("vpx", _i)]
+                ("grad_res", _vp), ("dz", _vp), ("grad_bn_w", _vp), ("grad_bn_b", _vp), ("colsum", _vp),
+                ("ds_head", _vp), ("w_head", _vp), ("x_top", _vp), ("dw_head", _vp), ("vpx", _i)]
 
 
 class SurfaceCull(ctypes.Structure):

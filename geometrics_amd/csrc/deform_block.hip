@@ -350,7 +350,31 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_fwd_kernel(geom_deform_fwd a
         if (a.z_out) db_st4(r_z, own_off == DB_OOB ? DB_OOB : own_off + 4 * DB_K * i, z[i]);
         db_st4(r_x, own_off == DB_OOB ? DB_OOB : own_off + 4 * DB_K * i, xo[i]);
     }
-    if (!PRODUCT) return;
+    if (!PRODUCT) {
+        // ---- the coordinate head's product (models.py:219,295: gc15 = 192 -> 3) inside the last hidden layer's launch:
+        // s_head[row][o] = sum_c X[row][c] W_head[c][o]; a row's 192 columns sit in the 16 lanes of its group
+        if (a.w_head && a.s_head) {
+            float h[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float xv[4] = {xo[i].x, xo[i].y, xo[i].z, xo[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float *wr = a.w_head + (size_t)(c0 + DB_K * i + e) * 3;
+                    h[0] += xv[e] * wr[0], h[1] += xv[e] * wr[1], h[2] += xv[e] * wr[2];
+                }
+            }
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) {
+                h[0] += __shfl_xor(h[0], m, GEOM_WAVE), h[1] += __shfl_xor(h[1], m, GEOM_WAVE), h[2] += __shfl_xor(h[2], m, GEOM_WAVE);
+            }
+            if (j == 0 && mesh_on) {
+                float *dst = a.s_head + ((size_t)rl * a.nv + v) * 3;
+                dst[0] = h[0], dst[1] = h[1], dst[2] = h[2];
+            }
+        }
+        return;
+    }
 
     // ---- the next layer's product on the tile
     db_to_panel(lds, rl, c0, xo);
@@ -409,7 +433,47 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_kernel(geom_deform_bwd a
     for (int i = 0; i < 3; ++i) {
         zv[i] = db_ld4(r_z, at(i));
         g2v[i] = a.g2 ? db_ld4(r_g2, g2_off == DB_OOB ? DB_OOB : g2_off + 4 * DB_K * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!PRODUCT) go[i] = db_ld4(r_g, g_off == DB_OOB ? DB_OOB : g_off + 4 * DB_K * i);
+        if (!PRODUCT) go[i] = a.g ? db_ld4(r_g, g_off == DB_OOB ? DB_OOB : g_off + 4 * DB_K * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (!PRODUCT && a.ds_head) {
+        // ---- the coordinate head (gc15, 192 -> 3) inside the first backward launch: its input gradient dS_head . W_head^T is
+        // added to g, and the vertex's partial of its weight gradient X^T . dS_head goes out with the column sums
+        float dsh[3] = {0.f, 0.f, 0.f};
+        if (mesh_on) {
+            const float *src = a.ds_head + ((size_t)rl * a.nv + v) * 3;
+            dsh[0] = src[0], dsh[1] = src[1], dsh[2] = src[2];
+        }
+        const __amdgpu_buffer_rsrc_t r_xt = db_rsrc(a.x_top, op_bytes);
+        float *wsum = lds + DB_PANEL; // [4 waves][192 * 3]
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float4 xt = a.dw_head ? db_ld4(r_xt, at(i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float xv[4] = {xt.x, xt.y, xt.z, xt.w};
+            float add[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = c0 + DB_K * i + e;
+                const float *wr = a.w_head + (size_t)col * 3;
+                add[e] = (dsh[0] * wr[0] + dsh[1] * wr[1]) + dsh[2] * wr[2];
+                if (a.dw_head) { // rows of a wave: lanes 16 apart, in mesh order; the four waves through LDS
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) {
+                        const float t = xv[e] * dsh[o];
+                        float acc = t;
+#pragma unroll
+                        for (int k = 1; k < 4; ++k) acc += __shfl(t, (lane & 15) + 16 * k, GEOM_WAVE);
+                        if ((lane >> 4) == 0) wsum[wave * (DB_C * 3) + col * 3 + o] = acc;
+                    }
+                }
+            }
+            go[i].x += add[0], go[i].y += add[1], go[i].z += add[2], go[i].w += add[3];
+        }
+        if (a.dw_head) {
+            __syncthreads();
+            for (int t = tid; t < DB_C * 3; t += DB_THREADS)
+                a.dw_head[(size_t)v * (DB_C * 3) + t] = ((wsum[t] + wsum[DB_C * 3 + t]) + wsum[2 * DB_C * 3 + t]) + wsum[3 * DB_C * 3 + t];
+            __syncthreads();
+        }
     }
     float *stage = lds + DB_PANEL;
     if (PRODUCT) {
@@ -526,6 +590,7 @@ extern "C" int geom_deform_layer_fwd_f32(const geom_deform_fwd *args, void *stre
     if (!a.s_in || !a.ell_col || !a.ell_val || !a.x_out) return GEOM_EINVAL;
     if (a.training ? (!a.save_mean || !a.save_invstd) : (!a.run_mean || !a.run_var)) return GEOM_EINVAL;
     if (a.w_next && !a.s_out) return GEOM_EINVAL;
+    if ((a.w_head != nullptr) != (a.s_head != nullptr) || (a.w_head && a.w_next)) return GEOM_EINVAL; // the head rides in the launch without a product
     if (a.tail_col && !a.tail_val) return GEOM_EINVAL;
     if (a.res && (a.res_ld < DB_C || (a.res_ld & 3))) return GEOM_EINVAL;
     if (!db_aligned16(a.s_in) || !db_aligned16(a.ell_col) || !db_aligned16(a.ell_val) || !db_aligned16(a.x_out) || !db_aligned16(a.z_out) ||
@@ -549,7 +614,8 @@ extern "C" int geom_deform_layer_bwd_f32(const geom_deform_bwd *args, void *stre
     if (a.b == 0 || a.nv == 0) return 0;
     if (!a.z || !a.save_mean || !a.save_invstd || !a.dz) return GEOM_EINVAL;
     const bool product = a.dz_up != nullptr;
-    if (product ? (!a.ell_col_t || !a.ell_val_t || !a.ds_up || !a.wt_up) : !a.g) return GEOM_EINVAL;
+    if (product ? (!a.ell_col_t || !a.ell_val_t || !a.ds_up || !a.wt_up) : (!a.g && !a.ds_head)) return GEOM_EINVAL;
+    if (a.ds_head && (product || !a.w_head || (a.dw_head && !a.x_top) || !db_aligned16(a.x_top))) return GEOM_EINVAL;
     if (a.tail_col_t && !a.tail_val_t) return GEOM_EINVAL;
     if ((a.g_ld && a.g_ld < DB_C) || (a.g2_ld && a.g2_ld < DB_C)) return GEOM_EINVAL;
     if ((int64_t)a.b * a.nv * (a.g_ld > a.g2_ld ? a.g_ld : a.g2_ld) >= (1LL << 29)) return GEOM_EUNSUPPORTED;

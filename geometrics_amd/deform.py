@@ -102,7 +102,7 @@ def pack_weights(weights):
 
 
 def layer_forward(s_in, bias, csr, bn_w, bn_b, run_mean, run_var, training, momentum, eps, relu, res, scale, z_out, x_out,
-                  save_mean, save_invstd, w_next=None, s_out=None):
+                  save_mean, save_invstd, w_next=None, s_out=None, w_head=None, s_head=None):
     """One forward launch (geom_deform_layer_fwd_f32); w_next = the next layer's weight PACKED (pack_weights()[0][l]); see
     include/geom_hip.h for the operands."""
     b, nv, c = s_in.shape
@@ -110,7 +110,7 @@ def layer_forward(s_in, bias, csr, bn_w, bn_b, run_mean, run_var, training, mome
     a = _lib.DeformFwd(b, nv, c, 64, csr.ell_w, _p(s_in), _p(bias), _p(csr.ell_col), _p(csr.ell_val), _p(tail[0]), _p(tail[1]),
                        _p(bn_w), _p(bn_b), _p(run_mean), _p(run_var), int(training), float(momentum), float(eps),
                        int(relu), _p(res), res.stride(1) if res is not None else 0, float(scale), _p(z_out), _p(x_out),
-                       _p(save_mean), _p(save_invstd), _p(w_next), _p(s_out), 0)
+                       _p(save_mean), _p(save_invstd), _p(w_next), _p(s_out), _p(w_head), _p(s_head), 0)
     with torch.cuda.device(s_in.device):
         _lib.call("geom_deform_layer_fwd_f32", ctypes.addressof(a))
 
@@ -129,7 +129,8 @@ def _rows192(t, shape):
 
 
 def layer_backward(shape, csr, z, bn_w, bn_b, save_mean, save_invstd, relu, has_res, scale, dz, grad_bn_w, grad_bn_b,
-                   dz_up=None, ds_up=None, wt_up=None, g=None, g2=None, grad_res=None, colsum=None):
+                   dz_up=None, ds_up=None, wt_up=None, g=None, g2=None, grad_res=None, colsum=None, ds_head=None, w_head=None,
+                   x_top=None, dw_head=None):
     """One backward launch (geom_deform_layer_bwd_f32); wt_up = the layer above's weight, TRANSPOSED and packed
     (pack_weights()[1][l])."""
     b, nv, c = shape
@@ -139,7 +140,7 @@ def layer_backward(shape, csr, z, bn_w, bn_b, save_mean, save_invstd, relu, has_
     a = _lib.DeformBwd(b, nv, c, 64, csr.ell_w, _p(dz_up), _p(csr.ell_col_t), _p(csr.ell_val_t), _p(tail[2]), _p(tail[3]),
                        _p(ds_up), _p(wt_up), _p(g), _p(g2), g_ld, g2_ld, _p(z), _p(bn_w), _p(bn_b), _p(save_mean),
                        _p(save_invstd), int(relu), int(has_res), float(scale), _p(grad_res), _p(dz), _p(grad_bn_w),
-                       _p(grad_bn_b), _p(colsum), 0)
+                       _p(grad_bn_b), _p(colsum), _p(ds_head), _p(w_head), _p(x_top), _p(dw_head), 0)
     with torch.cuda.device(z.device):
         _lib.call("geom_deform_layer_bwd_f32", ctypes.addressof(a))
 
@@ -151,7 +152,10 @@ class _HiddenChain(torch.autograd.Function):
     their gradients meet inside the first backward launch instead of in an add pass)."""
 
     @staticmethod
-    def forward(ctx, s1, lead, csr, stats, momentum, eps, *params):
+    def forward(ctx, s1, lead, csr, stats, momentum, eps, w_head, *params):
+        """w_head: the coordinate head's weight ([1,192,3] / [192,3]: models.py:219 gc15) or None.  Given, the head's product
+        rides in the last layer's launch and the SECOND output is its raw support [B,V,3] (the caller aggregates it and adds
+        the bias) instead of a second handle on the features."""
         L = LAYERS
         biases, weights = params[:L], params[L:2 * L - 1]
         bn_w, bn_b = params[2 * L - 1:3 * L - 1], params[3 * L - 1:4 * L - 1]
@@ -170,14 +174,23 @@ class _HiddenChain(torch.autograd.Function):
             src = RESIDUALS.get(i)
             res = None if src is None else (lead if src == "lead" else xs[src - 2])
             nxt = i < L
+            head = w_head is not None and not nxt
+            if head:
+                wh = w_head.reshape(c, 3)
+                wh = wh if wh.is_contiguous() else wh.contiguous()
+                s_head = torch.empty(b, nv, 3, **f32)
             layer_forward(s_cur, biases[i - 1], csr, bn_w[i - 1], bn_b[i - 1], stats[i - 1][0], stats[i - 1][1], True, momentum, eps,
                           relu, res, 0.5, zs[i - 1], xs[i - 1], means[i - 1], invstds[i - 1],
-                          w_next=w2[i - 1] if nxt else None, s_out=s_buf[i & 1] if nxt else None)
+                          w_next=w2[i - 1] if nxt else None, s_out=s_buf[i & 1] if nxt else None,
+                          w_head=wh if head else None, s_head=s_head if head else None)
             s_cur = s_buf[i & 1]
-        ctx.csr, ctx.relu = csr, relu
+        ctx.csr, ctx.relu, ctx.head = csr, relu, w_head is not None
+        ctx.head_shape = None if w_head is None else tuple(w_head.shape)
         ctx.set_materialize_grads(False)      # a handle nobody uses (the last block's features) arrives as None, not as 5.9 MB of zeros
-        ctx.save_for_backward(xs, zs, means, invstds, wts, *bn_w, *bn_b)
+        ctx.save_for_backward(xs, zs, means, invstds, wts, *bn_w, *bn_b, *([wh] if w_head is not None else []))
         out = xs[L - 1]
+        if w_head is not None:
+            return out, s_head
         return out, _layers._alias(out)
 
     @staticmethod
@@ -190,9 +203,18 @@ class _HiddenChain(torch.autograd.Function):
         _, b, nv, c = xs.shape
         dev = xs.device
         f32 = dict(dtype=torch.float32, device=dev)
+        n_in = 7 + 4 * L - 1
         if g_a is None and g_b is None:
-            return (None,) * (6 + 4 * L - 1)
-        g_top, g_top2 = (g_a, g_b) if g_a is not None else (g_b, None)      # (read in place at any row pitch: layer_backward)
+            return (None,) * n_in
+        ds_head = w_head = dw_head = None
+        if ctx.head:                       # g_b is the gradient of the head's raw support [B,V,3]
+            w_head = saved[5 + 2 * L]
+            if g_b is not None:
+                ds_head = g_b.contiguous()
+                dw_head = torch.empty(nv, c * 3, **f32) if ctx.needs_input_grad[6] else None
+            g_top, g_top2 = g_a, None
+        else:
+            g_top, g_top2 = (g_a, g_b) if g_a is not None else (g_b, None)      # (read in place at any row pitch: layer_backward)
         dzs = torch.empty(L, b, nv, c, **f32)         # dzs[i - 1] = dZ_i
         dss = torch.empty(L - 1, b, nv, c, **f32)     # dss[i - 2] = dS_i = gradient of layer i's raw support, i = 2..L
         g_bnw, g_bnb = torch.empty(L, nv, **f32), torch.empty(L, nv, **f32)
@@ -206,7 +228,8 @@ class _HiddenChain(torch.autograd.Function):
                           grad_res=grad_res, colsum=colsum[i - 1])
             if i == L:
                 layer_backward((b, nv, c), csr, zs[i - 1], bn_w[i - 1], bn_b[i - 1], means[i - 1], invstds[i - 1], g=g_top, g2=g_top2,
-                               **common)
+                               ds_head=ds_head, w_head=w_head if ds_head is not None else None, x_top=xs[L - 1] if dw_head is not None else None,
+                               dw_head=dw_head, **common)
             else:
                 layer_backward((b, nv, c), csr, zs[i - 1], bn_w[i - 1], bn_b[i - 1], means[i - 1], invstds[i - 1], dz_up=dzs[i],
                                ds_up=dss[i - 1], wt_up=wts[i - 1], g2=pending.pop(i + 1, None), **common)
@@ -226,19 +249,28 @@ class _HiddenChain(torch.autograd.Function):
         # the middle axis of [13, 482, 192] took 38 us; geom_colsum_batch_f32 is the reduction the aggregation backward's
         # partials go through: fixed order, ~5 us)
         g_bias = torch.empty(L, c, **f32)
+        jobs = [(colsum[i], c, g_bias[i]) for i in range(L)]
+        g_head = None
+        if dw_head is not None:            # the head's weight gradient: the vertices' [192, 3] partials added up by the same launch
+            g_head = torch.empty(c * 3, **f32)
+            jobs.append((dw_head, c * 3, g_head))
+        n = len(jobs)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().geom_colsum_batch_f32(
-                L, (ctypes.c_void_p * L)(*[colsum[i].data_ptr() for i in range(L)]), (ctypes.c_int * L)(*([nv] * L)),
-                (ctypes.c_int * L)(*([c] * L)), (ctypes.c_void_p * L)(*[g_bias[i].data_ptr() for i in range(L)]),
+                n, (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in jobs]), (ctypes.c_int * n)(*([nv] * n)),
+                (ctypes.c_int * n)(*[j[1] for j in jobs]), (ctypes.c_void_p * n)(*[j[2].data_ptr() for j in jobs]),
                 _lib.stream_ptr()), "geom_colsum_batch_f32")
         grads = [g_bias[i] for i in range(L)] + [g_w[i].view(1, c, c) for i in range(L - 1)] \
             + [g_bnw[i] for i in range(L)] + [g_bnb[i] for i in range(L)]
-        return (g_s1, g_lead, None, None, None, None, *grads)
+        g_wh = None
+        if g_head is not None:
+            g_wh = g_head.view(ctx.head_shape)
+        return (g_s1, g_lead, None, None, None, None, g_wh, *grads)
 
 
-def hidden_chain(block, s1, lead, csr):
+def hidden_chain(block, s1, lead, csr, head=None):
     """The thirteen hidden layers of `block` applied to the first layer's raw support; returns (features, features) -- see
-    _HiddenChain."""
+    _HiddenChain -- or, with head = the block's coordinate layer (192 -> 3), (features, raw support of the head)."""
     L = LAYERS
     gcs = [getattr(block, "gc%d" % i) for i in range(1, L + 1)]
     bns = [getattr(block, "bn%d" % i) for i in range(1, L + 1)]
@@ -246,4 +278,7 @@ def hidden_chain(block, s1, lead, csr):
         bn._pending_batches += 1
     stats = [(bn.running_mean, bn.running_var) for bn in bns]
     params = [g.bias for g in gcs] + [g.weight1 for g in gcs[1:]] + [bn.weight for bn in bns] + [bn.bias for bn in bns]
-    return _HiddenChain.apply(s1, lead, csr, stats, bns[0].momentum, bns[0].eps, *params)
+    w_head = None
+    if head is not None and tuple(head.weight1.shape[-2:]) == (192, 3):
+        w_head = head.weight1
+    return _HiddenChain.apply(s1, lead, csr, stats, bns[0].momentum, bns[0].eps, w_head, *params)

@@ -297,8 +297,13 @@ class BatchMeshDeformationBlock(nn.Module):
             with batching:
                 full, lead = _InputTap.apply(features, pooled, self.hidden)
                 s1 = _layers._dense(full, self.gc1.weight1)
-                feats, feats_out = _deform.hidden_chain(self, s1, lead, csr)
-                coords = self.gc15(feats, adj, _identity)
+                if tuple(self.gc15.weight1.shape[-2:]) == (192, 3) and self.gc15.bias is not None:
+                    # the coordinate head's product (and its two gradients) ride in the last / first layer launch
+                    feats_out, s15 = _deform.hidden_chain(self, s1, lead, csr, head=self.gc15)
+                    coords = _layers.zero_n_aggregate(s15, adj, self.gc15.bias, 3 // self.gc15.split, None)
+                else:
+                    feats, feats_out = _deform.hidden_chain(self, s1, lead, csr)
+                    coords = self.gc15(feats, adj, _identity)
             return feats_out, coords
         with batching:
             full, lead = _InputTap.apply(features, pooled, self.hidden)

@@ -386,7 +386,7 @@ int geom_zn_layer_bwd_f32(int b, int nv, int c, int k, int ell_w, const int *ell
  *                                                                     gradient is x^T . ds_up)
  *     g     = ds_up . W_up^T  (+ g2 if given)                         (gradient of THIS layer's output x_out; wt_up = the packed
  *                                                                     bwd[l] copy of W_up from geom_deform_pack_weights_f32)
- *   (dz_up == NULL: g is read from memory instead, + g2)
+ *   (dz_up == NULL: g is read from memory instead, + g2, + the coordinate head's input gradient when ds_head is given)
  *     with has_res: g *= scale, grad_res = g (the residual's gradient);  relu: g masked where BatchNorm_v(z) <= 0
  *     dz = BatchNorm_v backward(g; z, save_mean, save_invstd, bn_w);  grad_bn_w[v] / grad_bn_b[v] = the vertex's sums
  *     colsum (optional) [nv,192]: the vertex's column sums of dz over its meshes (the layer's bias gradient = their sum over
@@ -404,6 +404,8 @@ typedef struct geom_deform_fwd {
     const float *res; int res_ld; float scale;                  /* optional residual [b,nv,res_ld >= 192] */
     float *z_out, *x_out, *save_mean, *save_invstd;
     const float *w_next; float *s_out;
+    const float *w_head; float *s_head;                         /* optional, only with w_next == NULL: s_head [b,nv,3] = x_out . w_head
+                                                                 * (w_head [192,3] row-major: the block's coordinate head gc15) */
     int vpx;
 } geom_deform_fwd;
 typedef struct geom_deform_bwd {
@@ -417,6 +419,9 @@ typedef struct geom_deform_bwd {
     const float *z, *bn_w, *bn_b, *save_mean, *save_invstd;
     int relu, has_res; float scale;
     float *grad_res, *dz, *grad_bn_w, *grad_bn_b, *colsum;
+    const float *ds_head, *w_head, *x_top; float *dw_head;      /* optional, only with dz_up == NULL: g += ds_head [b,nv,3] . w_head^T
+                                                                 * (g may then be NULL); dw_head [nv,192,3] = per-vertex partials of
+                                                                 * x_top^T . ds_head (x_top [b,nv,192]: the layer's output) */
     int vpx;
 } geom_deform_bwd;
 /* EXPERIMENT (csrc/dense_split_bf16.hip; on no default route): c [m, 192] = a [m, k] . w [k, 192] on the BF16 matrix cores with
