@@ -592,9 +592,9 @@ extern "C" int geom_deform_layer_fwd_f32(const geom_deform_fwd *args, void *stre
     if (a.w_next && !a.s_out) return GEOM_EINVAL;
     if ((a.w_head != nullptr) != (a.s_head != nullptr) || (a.w_head && a.w_next)) return GEOM_EINVAL; // the head rides in the launch without a product
     if (a.tail_col && !a.tail_val) return GEOM_EINVAL;
-    if (a.res && (a.res_ld < DB_C || (a.res_ld & 3))) return GEOM_EINVAL;
+    if (a.res && a.res_ld < DB_C) return GEOM_EINVAL; // (any pitch: a column slice of the block's 1155-wide input is read in place)
     if (!db_aligned16(a.s_in) || !db_aligned16(a.ell_col) || !db_aligned16(a.ell_val) || !db_aligned16(a.x_out) || !db_aligned16(a.z_out) ||
-        !db_aligned16(a.s_out) || !db_aligned16(a.bias) || !db_aligned16(a.res) || !db_aligned16(a.w_next))
+        !db_aligned16(a.s_out) || !db_aligned16(a.bias) || ((uintptr_t)a.res & 3) || !db_aligned16(a.w_next))
         return GEOM_EINVAL;
     if (!a.res) a.scale = 1.f;
     a.vpx = (a.nv + 7) / 8;

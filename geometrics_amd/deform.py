@@ -160,7 +160,7 @@ class _HiddenChain(torch.autograd.Function):
         biases, weights = params[:L], params[L:2 * L - 1]
         bn_w, bn_b = params[2 * L - 1:3 * L - 1], params[3 * L - 1:4 * L - 1]
         s1 = _lib.require(s1, "s1", torch.float32, 3, 192)
-        lead = _lib.require(lead, "lead", torch.float32, 3, 192)
+        lead, _ = _rows192(lead, tuple(s1.shape))       # in place when it is the leading columns of the block's wide input
         b, nv, c = s1.shape
         dev = s1.device
         f32 = dict(dtype=torch.float32, device=dev)

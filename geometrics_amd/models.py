@@ -95,9 +95,10 @@ class _InputTap(torch.autograd.Function):
     added to the first layer's input gradient; here the narrow gradient is added into the two input gradients directly."""
 
     @staticmethod
-    def forward(ctx, features, pooled, width):
+    def forward(ctx, features, pooled, width, lead_view=False):
         from . import ops as _ops
         nf = features.shape[-1]
+        ctx.lead_view = bool(lead_view)
         # `pooled` allocated with room for the coordinates in front (utils.batched_pooling(headroom=...), utils.concat_features):
         # they are copied into the free columns and the wide buffer IS the input -- no 35 MB concatenation
         ctx.in_place = (features.dim() == 3 and features.is_cuda and features.dtype == torch.float32 and pooled.dtype == torch.float32
@@ -113,7 +114,10 @@ class _InputTap(torch.autograd.Function):
             raise RuntimeError("the block input has %d columns, fewer than the %d hidden ones" % (full.shape[-1], width))
         ctx.nf, ctx.width = nf, width
         ctx.shapes = (features.shape, pooled.shape)
-        return full, full[..., :width].contiguous()
+        # the first residual = the input's leading columns: handed to the one-launch layers as a VIEW (they read any row pitch);
+        # the separate operators' vector BatchNorm kernel wants 16-byte rows: a contiguous copy
+        lead = full[..., :width]
+        return full, (lead if ctx.lead_view else lead.contiguous())
 
     @staticmethod
     def backward(ctx, g_full, g_res):
@@ -135,7 +139,7 @@ class _InputTap(torch.autograd.Function):
                 gp = g_full[..., nf:].contiguous() if g_full is not None else g_res.new_zeros(ctx.shapes[1])
                 if g_res is not None and width > nf:
                     gp[..., :width - nf] += g_res[..., nf:width]
-        return gf, gp, None
+        return gf, gp, None, None
 
 
 class _SyncVertexBN(torch.autograd.Function):
@@ -295,7 +299,7 @@ class BatchMeshDeformationBlock(nn.Module):
             # ONE launch per hidden layer and direction (csrc/deform_block.hip): aggregation + BatchNorm1d(verts) + ReLU +
             # residual average + the next layer's product; the first layer's product and the coordinate head stay the layers'
             with batching:
-                full, lead = _InputTap.apply(features, pooled, self.hidden)
+                full, lead = _InputTap.apply(features, pooled, self.hidden, True)
                 s1 = _layers._dense(full, self.gc1.weight1)
                 if tuple(self.gc15.weight1.shape[-2:]) == (192, 3) and self.gc15.bias is not None:
                     # the coordinate head's product (and its two gradients) ride in the last / first layer launch
