@@ -937,11 +937,11 @@ def driver_step_times(dev, batch=16, profile_replays=0, zero_edit=False):
         # (utils.stage_regularisers; the zero-edit step below keeps the driver's own expressions)
         # p1, p2: (surface-loss handle, regulariser handle as `cur`, regulariser handle as `prev`); p3: (surface, cur)
         surf = lambda p, wgt: utils.batch_point_to_surface(p, info, gt, num=S_PTS, gt_index=gt_index, weight=wgt)
-        surface = surf(p1[0], .2) + surf(p2[0], .2) + surf(p3[0], 2.0)
-        reg = (utils.stage_regularisers(initial, p1[1], info, lap_weight=.2 * .3 * 1500, edge_weight=300)
-               + utils.stage_regularisers(p1[2], p2[1], info, lap_weight=.2 * 1500, move_weight=.2 * 100, edge_weight=300)
-               + utils.stage_regularisers(p2[2], p3[1], info, lap_weight=.2 * 1500, move_weight=.2 * 100, edge_weight=300))
-        return surface + reg
+        return utils.sum_losses(
+            surf(p1[0], .2), surf(p2[0], .2), surf(p3[0], 2.0),
+            utils.stage_regularisers(initial, p1[1], info, lap_weight=.2 * .3 * 1500, edge_weight=300),
+            utils.stage_regularisers(p1[2], p2[1], info, lap_weight=.2 * 1500, move_weight=.2 * 100, edge_weight=300),
+            utils.stage_regularisers(p2[2], p3[1], info, lap_weight=.2 * 1500, move_weight=.2 * 100, edge_weight=300))
 
     def zero():
         opt.zero_grad()

@@ -489,6 +489,32 @@ class FanOut(torch.autograd.Function):
         return out, None
 
 
+class SumScalars(torch.autograd.Function):
+    """((t0 + t1) + t2) + ... of up to 8 zero-dimensional fp32 tensors in ONE launch (geom_sum_tensors_f32); backward: every term
+    receives the incoming gradient itself (no launch).  The driver's `loss = edge_loss + surface_loss + lap_loss + ...`
+    (GEOMetrics.py:164) costs a launch per `+` forward and one per term backward."""
+
+    @staticmethod
+    def forward(ctx, *terms):
+        import ctypes
+        ts = [t.reshape(()) for t in terms]
+        out = torch.empty((), dtype=torch.float32, device=ts[0].device)
+        ctx.n = len(ts)
+        if not all(t.is_cuda and t.dtype == torch.float32 for t in ts) or len(ts) > 8:
+            total = ts[0]
+            for t in ts[1:]:
+                total = total + t
+            return total
+        ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        with torch.cuda.device(out.device):
+            _lib.call("geom_sum_tensors_f32", len(ts), ptrs, 1, out.data_ptr())
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        return (grad,) * ctx.n
+
+
 class StageRegularisers(torch.autograd.Function):
     """The regularisers of ONE deformation stage as one scalar (GEOMetrics.py:147-161 on utils.py:636-662):
         w_edge * mean over (mesh, face) of (|e1|^2 + |e2|^2 + |e3|^2)(cur) / 3

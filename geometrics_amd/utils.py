@@ -237,6 +237,11 @@ def fan_out(x, n):
     return ops.FanOut.apply(x, int(n)) if n > 1 else (x,)
 
 
+def sum_losses(*terms):
+    """t0 + t1 + ... for scalar loss terms (not a reference name): one launch forward, none backward."""
+    return ops.SumScalars.apply(*terms) if len(terms) > 1 else terms[0]
+
+
 def concat_features(front, pooled):
     """torch.cat((front, pooled), dim=-1) (GEOMetrics.py:123,128) -- without copying `pooled` when it came from
     batched_pooling(..., headroom=...) with room for `front` (and, in the backward pass, without the slicing copies of the

@@ -1754,3 +1754,14 @@ def test_fan_out_sums_its_handles_gradients_in_one_launch(gpu):
     x.grad = None
     ((hs[0] * ws[0]).sum() + (hs[2] * ws[2]).sum()).backward()
     assert torch.equal(x.grad, ws[0] + ws[2])
+
+
+def test_sum_losses_is_one_launch_and_the_same_sum(gpu):
+    torch.manual_seed(16)
+    ts = [torch.randn((), device=gpu, requires_grad=True) for _ in range(6)]
+    total = utils.sum_losses(*ts)
+    expect = ((((ts[0] + ts[1]) + ts[2]) + ts[3]) + ts[4]) + ts[5]
+    assert torch.equal(total.detach(), expect.detach())
+    (total * 3.0).backward()
+    assert all(float(t.grad) == 3.0 for t in ts)
+    assert utils.sum_losses(ts[0]) is ts[0]
