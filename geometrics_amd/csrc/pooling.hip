@@ -284,45 +284,191 @@ __global__ __launch_bounds__(BIN_THREADS) void pool_bin_kernel(PoolArgs a, BinSp
     }
 }
 
-// tasks per mesh are enumerated level by level: texel-major, then 64-channel chunk
-__global__ __launch_bounds__(PL_THREADS) void pool_gather_kernel(PoolArgs a, BinSpace ws, const float *grad_out,
-                                                                 int tasks_per_mesh)
+// What this kernel has to avoid is not traffic but INSTRUCTIONS and TAILS.  The lists are short and skewed: at the training
+// shape 0.6 entries per texel at 56 x 56 and 40 at 7 x 7, two thirds of the texels empty, the fullest 7 x 7 texel 135 entries
+// (tools/time_pool_gather.py).  Round 5's form gave every (texel, 64-channel chunk) its own wave -- 94 080 waves per 16 meshes,
+// each mostly index arithmetic: 59 us per call, 55 us with the gradient-row loads removed (tools/probe/pg_variants.sh); with
+// waves <-> chunks instead, the fullest texel's wave walked 135 rows x 2 chunks alone (42 us).  Here
+//   * a workgroup owns a RUN of T consecutive texels of one map (gather_plan: 64 texels at 56 x 56 down to one at 7 x 7: about
+//     40 entries) x up to 256 channels: a lane holds VEC = 1 / 2 / 4 consecutive channels, a gradient row arrives as ONE
+//     load of up to 16 bytes per lane;
+//   * the lists of a run are ONE contiguous range of the workspace (they are texel-major): the four waves take a quarter
+//     of the ENTRIES each -- whatever the texels --, up to 64 (vertex, weight) pairs per load, eight rows in flight;
+//   * a wave's sums for the texels strictly inside its quarter go to the LDS tile as they are; its first and its last texel
+//     may continue in a neighbour's quarter: those two partial sums are added wave after wave (list order: the result does
+//     not depend on how the entries were split);
+//   * every per-map constant comes precomputed in the launch arguments: no integer division anywhere;
+//   * the tile leaves as runs of T floats per channel (256 bytes at 56 x 56).
+constexpr int PG_TILE = 4096; // floats of a run's sums: T texels x 64 VEC channels (+ VEC per texel row of padding)
+
+struct GatherPlan {
+    int first_task[GEOM_POOL_MAX_LEVELS + 1]; // tasks (= runs) of level l: [first_task[l], first_task[l + 1])
+    int log_t[GEOM_POOL_MAX_LEVELS];          // T = 1 << log_t texels per run
+    int vec[GEOM_POOL_MAX_LEVELS];            // channels per lane
+    int parts[GEOM_POOL_MAX_LEVELS];          // 64 * vec-channel slices of the map (grid.z walks them)
+    int col0[GEOM_POOL_MAX_LEVELS];           // first column of the map inside the pooled features
+    int max_parts;
+};
+
+static void gather_plan(const PoolArgs &a, GatherPlan &p)
 {
+    int task = 0, col = 0;
+    p.max_parts = 1;
+    for (int l = 0; l < a.levels; ++l) {
+        const int texels = a.dims[l] * a.dims[l], C = a.channels[l];
+        // (rows of the pitched gradient are only 4-byte aligned: any vector width is legal for the buffer loads; a lane's
+        // channels must not straddle the map's last channel)
+        const int vec = (C >= 256 && C % 4 == 0) ? 4 : (C >= 128 && C % 2 == 0) ? 2 : 1;
+        const int W = GEOM_WAVE * vec;
+        int log_t = 0;
+        while ((2 << log_t) * W <= PG_TILE && (2 << log_t) * 48 <= texels) ++log_t;
+        p.first_task[l] = task, p.log_t[l] = log_t, p.vec[l] = vec, p.parts[l] = (C + W - 1) / W, p.col0[l] = col;
+        if (p.parts[l] > p.max_parts) p.max_parts = p.parts[l];
+        task += (texels + (1 << log_t) - 1) >> log_t;
+        col += C;
+    }
+    p.first_task[a.levels] = task;
+}
+
+typedef unsigned pg_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned pg_u32x2 __attribute__((ext_vector_type(2)));
+
+template <int VEC> struct PgRow {
+    float x[VEC];
+};
+
+template <int VEC> __device__ __forceinline__ PgRow<VEC> pg_load(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    PgRow<VEC> o;
+    if constexpr (VEC == 4) {
+        const pg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        o.x[0] = __uint_as_float(v.x), o.x[1] = __uint_as_float(v.y), o.x[2] = __uint_as_float(v.z), o.x[3] = __uint_as_float(v.w);
+    } else if constexpr (VEC == 2) {
+        const pg_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+        o.x[0] = __uint_as_float(v.x), o.x[1] = __uint_as_float(v.y);
+    } else {
+        o.x[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    }
+    return o;
+}
+
+template <int VEC>
+__device__ __forceinline__ void pg_run(const PoolArgs &a, const BinSpace &ws, const GatherPlan &p, const float *grad_out, int l,
+                                       int run, int part, float *tile)
+{
+    constexpr int W = GEOM_WAVE * VEC, ST = W + VEC; // channels of the slice, floats per texel row of the tile
     const int lane = threadIdx.x & (GEOM_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int task = blockIdx.x * PL_WAVES + wave;
     const int mesh = blockIdx.y;
-    if (task >= tasks_per_mesh) return;
-    int l = 0, off = 0;
-    for (;; ++l) {
-        const int n = a.dims[l] * a.dims[l] * ((a.channels[l] + GEOM_WAVE - 1) / GEOM_WAVE);
-        if (task < n) break;
-        task -= n;
-        off += a.channels[l];
-    }
-    if (!a.grad_blocks[l]) return; // wave-uniform
     const int dim = a.dims[l], C = a.channels[l], texels = dim * dim;
-    const int chunks = (C + GEOM_WAVE - 1) / GEOM_WAVE;
-    const int tx = task / chunks, c = (task - tx * chunks) * GEOM_WAVE + lane;
-    const int *offs = ws.offsets + (size_t)mesh * ws.off_stride + ws.level_off[l];
+    const int log_t = p.log_t[l], T = 1 << log_t;
+    const int tx0 = run << log_t, nt = min(T, texels - tx0); // texels of this run
+    const int *offs = ws.offsets + (size_t)mesh * ws.off_stride + ws.level_off[l] + tx0;
     const int *ev = ws.ent_v + ((size_t)mesh * a.levels + l) * 4 * a.nv;
     const float *ew = ws.ent_w + ((size_t)mesh * a.levels + l) * 4 * a.nv;
-    const int e0 = offs[tx], e1 = offs[tx + 1];
-    const float *g = grad_out + (size_t)mesh * a.nv * a.ld + off + (c < C ? c : 0);
-    float acc = 0.f;
-    int e = e0;
-    for (; e + 4 <= e1; e += 4) { // four rows in flight
-        const int v0 = ev[e], v1 = ev[e + 1], v2 = ev[e + 2], v3 = ev[e + 3];
-        const float w0 = ew[e], w1 = ew[e + 1], w2 = ew[e + 2], w3 = ew[e + 3];
-        const float g0 = g[(size_t)v0 * a.ld], g1 = g[(size_t)v1 * a.ld];
-        const float g2 = g[(size_t)v2 * a.ld], g3 = g[(size_t)v3 * a.ld];
-        acc += g0 * w0;
-        acc += g1 * w1;
-        acc += g2 * w2;
-        acc += g3 * w3;
+    // where the list of texel `lane` ends (lanes past the run: the end of the run's range)
+    const int ends = offs[min(lane + 1, nt)];
+    const int E0 = offs[0], E1 = __builtin_amdgcn_readlane(ends, GEOM_WAVE - 1);
+    for (int i = threadIdx.x; i < (ST << log_t); i += PL_THREADS) tile[i] = 0.f; // (texels nothing projects into stay zero)
+    __syncthreads();
+    const int n = E1 - E0;
+    const int ea = E0 + ((n * wave) >> 2), ez = E0 + ((n * (wave + 1)) >> 2); // this wave's quarter of the entries
+    const int c = part * W + lane * VEC;                                          // the lane's first channel
+    const __amdgpu_buffer_rsrc_t r_g = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(grad_out + (size_t)mesh * a.nv * a.ld), 0, (int)((((size_t)a.nv - 1) * a.ld + a.ctot) * 4), 0x00020000);
+    const unsigned col_off = c < C ? (unsigned)(p.col0[l] + c) * 4u : 0x80000000u; // (out of range: the load returns zeros)
+    // the texel the quarter starts in = the number of lists that end at or before its first entry
+    const int t_first = __builtin_popcountll(__ballot(lane < nt && ends <= ea));
+    int cur = t_first, next = __builtin_amdgcn_readlane(ends, min(cur, GEOM_WAVE - 1));
+    PgRow<VEC> acc, first;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc.x[q] = 0.f, first.x[q] = 0.f;
+    for (int eb = ea; eb < ez; eb += GEOM_WAVE) {
+        const int nb = min(GEOM_WAVE, ez - eb);
+        const int my = eb + min(lane, nb - 1);
+        const int vr = ev[my];
+        const float wr = ew[my];
+        for (int k0 = 0; k0 < nb; k0 += 8) {
+            PgRow<VEC> gv[8];
+            float wv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = min(k0 + j, nb - 1);
+                const int v = __builtin_amdgcn_readlane(vr, k);
+                wv[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wr), k));
+#ifdef PG_PROBE_NO_ROWS
+                for (int q = 0; q < VEC; ++q) gv[j].x[q] = (float)v;
+#else
+                gv[j] = pg_load<VEC>(r_g, col_off + (unsigned)v * (unsigned)a.ld * 4u);
+#endif
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (k0 + j < nb) {
+                    const int e = eb + k0 + j;
+                    while (e >= next) { // (wave-uniform) the list of `cur` is done
+                        if (cur == t_first) {
+                            first = acc;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < VEC; ++q) tile[cur * ST + lane * VEC + q] = acc.x[q];
+                        }
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) acc.x[q] = 0.f;
+                        ++cur;
+                        next = __builtin_amdgcn_readlane(ends, cur);
+                    }
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) acc.x[q] += gv[j].x[q] * wv[j];
+                }
+            }
+        }
     }
-    for (; e < e1; ++e) acc += g[(size_t)ev[e] * a.ld] * ew[e];
-    if (c < C) a.grad_blocks[l][((size_t)mesh * C + c) * texels + tx] = acc;
+    // the quarter's first and last texel: added in wave (= list) order
+    for (int w = 0; w < PL_WAVES; ++w) {
+        if (w == wave && ea < ez) {
+            if (cur != t_first) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) tile[t_first * ST + lane * VEC + q] += first.x[q];
+            }
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) tile[cur * ST + lane * VEC + q] += acc.x[q];
+        }
+        __syncthreads();
+    }
+    // out: per channel a run of nt consecutive texels
+    float *out = a.grad_blocks[l] + ((size_t)mesh * C + part * W) * texels + tx0;
+    const int nch = min(W, C - part * W);
+    for (int i = threadIdx.x; i < (W << log_t); i += PL_THREADS) {
+        const int t = i & (T - 1), ch = i >> log_t;
+#ifdef PG_PROBE_NO_STORE
+        if (tile[t * ST + ch] == 1.2345f)
+#endif
+        if (t < nt && ch < nch) out[(size_t)ch * texels + t] = tile[t * ST + ch];
+    }
+}
+
+__global__ __launch_bounds__(PL_THREADS) void pool_gather_kernel(PoolArgs a, BinSpace ws, GatherPlan p, const float *grad_out)
+{
+    __shared__ __attribute__((aligned(16))) float tile[PG_TILE + GEOM_WAVE];
+    // workgroups go to the eight XCDs round robin (gridDim.x is a multiple of 8: XCD = blockIdx.x % 8): give an XCD CONSECUTIVE
+    // runs -- the 2 x 2 texels a vertex touches then meet in one L2 (its gradient row is fetched from HBM once, not per XCD),
+    // and so do the short runs of a small map that share a 128-byte line of the output
+    const int task = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (task >= p.first_task[a.levels]) return;
+    int l = 0;
+    while (l + 1 < a.levels && task >= p.first_task[l + 1]) ++l;
+    const int part = blockIdx.z;
+    if (!a.grad_blocks[l] || part >= p.parts[l]) return; // workgroup-uniform
+#ifdef PG_PROBE_BARE
+    return;
+#endif
+    const int run = task - p.first_task[l];
+    switch (p.vec[l]) {
+    case 4: pg_run<4>(a, ws, p, grad_out, l, run, part, tile); break;
+    case 2: pg_run<2>(a, ws, p, grad_out, l, run, part, tile); break;
+    default: pg_run<1>(a, ws, p, grad_out, l, run, part, tile); break;
+    }
 }
 
 int fill_args(PoolArgs &a, int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos, int levels,
@@ -434,12 +580,11 @@ extern "C" int geom_pool_features_bwd_ld_f32(int b, int nv, const float *verts, 
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     bool any_map = false;
-    int tasks = 0;
     for (int l = 0; l < levels; ++l) {
         a.grad_blocks[l] = grad_blocks ? grad_blocks[l] : nullptr;
         any_map = any_map || a.grad_blocks[l];
         if (dims[l] * dims[l] > BIN_MAX_TEXELS) return GEOM_EUNSUPPORTED;
-        tasks += dims[l] * dims[l] * ((channels[l] + GEOM_WAVE - 1) / GEOM_WAVE);
+
     }
     if (!any_map && !grad_verts) return 0;
     BinSpace ws;
@@ -447,8 +592,11 @@ extern "C" int geom_pool_features_bwd_ld_f32(int b, int nv, const float *verts, 
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return GEOM_EINVAL;
     if (any_map) {
         hipLaunchKernelGGL(pool_bin_kernel, dim3(levels, b), dim3(BIN_THREADS), 0, s, a, ws);
-        hipLaunchKernelGGL(pool_gather_kernel, dim3((tasks + PL_WAVES - 1) / PL_WAVES, b), dim3(PL_THREADS), 0, s, a, ws,
-                           grad_out, tasks);
+        GatherPlan plan;
+        gather_plan(a, plan);
+        if (plan.max_parts > 65535 || (size_t)nv * a.ld * 4 > (size_t)INT_MAX) return GEOM_ETOOBIG;
+        hipLaunchKernelGGL(pool_gather_kernel, dim3((plan.first_task[levels] + 7) / 8 * 8, b, plan.max_parts), dim3(PL_THREADS), 0, s, a, ws, plan,
+                           grad_out);
     }
     if (grad_verts) {
         const int zc = a.chunks < PL_MAX_CHUNKS ? a.chunks : PL_MAX_CHUNKS;

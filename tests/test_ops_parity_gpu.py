@@ -1116,6 +1116,37 @@ def test_pooling_with_more_channel_chunks_than_grid_slices(gpu):
     close(gv_big.cpu().numpy(), gv_sum.cpu().numpy(), 2e-5)
 
 
+def test_pooling_map_gradient_per_element_at_the_training_shape(gpu):
+    """d loss / d maps at the reference's training shape (482 vertices, the four VGG maps 64 x 56^2 ... 512 x 7^2), every
+    element against float64.  The pooling is LINEAR in the maps: feats[b, v, c] = sum_t P_b[v, t] map[b, c, t], and pooling
+    identity maps (channel t = the one-hot map of texel t) returns P itself with the weights as the kernel forms them -- so
+    the gradient is P^T g in float64, with the per-element bound 8 eps * sum |P||g| (a texel's list holds 1 ... ~60 terms).
+    Exercises all four run lengths of the gather (64 / 16 / 4 / 1 texels per workgroup), ragged last runs and -- on a buffer
+    with headroom -- the pitched read of the gradient."""
+    torch.manual_seed(31)
+    b, chans, dims = 3, (64, 128, 256, 512), (56, 28, 14, 7)
+    V, _ = meshgen.icosphere(2)
+    V = np.concatenate([V, 0.6 * V, 0.3 * V], 0)[:482]                 # 482 vertices at three radii
+    verts = dev(meshgen.jittered_batch(V, b), gpu)
+    img_info = torch.tensor([[35.0, 20.0, 1.2], [200.0, -10.0, 1.0], [310.0, 45.0, 1.4]], device=gpu)
+    maps = [torch.randn(b, c, d, d, device=gpu, requires_grad=True) for c, d in zip(chans, dims)]
+    for headroom in (0, 195):
+        feats = utils.batched_pooling(maps, verts, img_info.clone(), headroom=headroom)
+        g = torch.randn_like(feats)
+        grads = torch.autograd.grad(feats, maps, g)
+        col = 0
+        for c, d, got in zip(chans, dims, grads):
+            eye = torch.eye(d * d, device=gpu).view(1, d * d, d, d).expand(b, -1, -1, -1).contiguous()
+            P = utils.batched_pooling([eye], verts, img_info.clone()).double()                      # [b, nv, d*d]
+            gl = g[..., col:col + c].double()
+            ref = torch.einsum("bvt,bvc->bct", P, gl).view(b, c, d, d)
+            bound = 8 * np.finfo(np.float32).eps * torch.einsum("bvt,bvc->bct", P.abs(), gl.abs()).view(b, c, d, d) + 1e-30
+            err = (got.double() - ref).abs()
+            assert bool((err <= bound).all()), "map %d x %d: err/bound up to %.3g" % (d, d, float((err / bound).max()))
+            assert bool((ref == 0).any()) or d < 28          # texels nothing projects into are written as zeros
+            col += c
+
+
 def test_in_kernel_sampler_stream(gpu):
     """The Philox stream of the sampler: reproducible after manual_seed, fresh numbers on every call (also
     when the call is replayed from a HIP graph), uniform u/v, area-weighted faces."""
