@@ -61,6 +61,10 @@ struct Texel {
     int i11, i12, i21, i22;
     float A, B, G, H; // x2-x, x-x1, y2-y, y-y1
     bool in_x, in_y;  // clamp passes the gradient
+    // the four texels as TWO 8-byte reads: (x1, yb), (x1, yb + 1) and (x2, yb), (x2, yb + 1) are neighbours in the [dim x dim]
+    // plane; yb = y1 except in the last column (there y1 = y2 = dim - 1 and the pair starts one texel earlier)
+    int p1, p2;        // index of the pair in row x1 / x2
+    bool y1_hi, y2_hi; // y1 / y2 is the pair's second element
 };
 
 __device__ __forceinline__ Texel texel(float xs, float ys, int dim)
@@ -74,7 +78,34 @@ __device__ __forceinline__ Texel texel(float xs, float ys, int dim)
     t.i11 = ix1 * dim + iy1, t.i12 = ix1 * dim + iy2, t.i21 = ix2 * dim + iy1, t.i22 = ix2 * dim + iy2;
     t.in_x = rx >= 0.f && rx <= hi;
     t.in_y = ry >= 0.f && ry <= hi;
+    const int yb = min(iy1, max(dim - 2, 0));
+    t.p1 = ix1 * dim + yb, t.p2 = ix2 * dim + yb;
+    t.y1_hi = iy1 != yb, t.y2_hi = iy2 != yb;
     return t;
+}
+
+typedef unsigned pl_u32x2 __attribute__((ext_vector_type(2)));
+
+// a mesh's planes of one map as a buffer (the pair reads are 4-byte aligned only: buffer loads take that)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float *blk, int C, int texels)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(blk), 0, (int)((size_t)C * texels * 4), 0x00020000);
+}
+
+struct Quad {
+    float c11, c12, c21, c22;
+};
+
+// the four texels of channel `ch` of a map of 2 x 2 or more: two 8-byte reads
+__device__ __forceinline__ Quad quad_of(__amdgpu_buffer_rsrc_t r, const Texel &t, int ch, int texels)
+{
+    Quad q;
+    const unsigned base = (unsigned)ch * (unsigned)texels;
+    const pl_u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(r, (base + (unsigned)t.p1) * 4u, 0, 0);
+    const pl_u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(r, (base + (unsigned)t.p2) * 4u, 0, 0);
+    q.c11 = __uint_as_float(t.y1_hi ? a.y : a.x), q.c12 = __uint_as_float(t.y2_hi ? a.y : a.x);
+    q.c21 = __uint_as_float(t.y1_hi ? b.y : b.x), q.c22 = __uint_as_float(t.y2_hi ? b.y : b.x);
+    return q;
 }
 
 // which 64-channel chunk of which map a workgroup owns (grid.z runs over the chunks of all maps in order): 15 chunks for the
@@ -96,29 +127,96 @@ __device__ __forceinline__ Chunk chunk_of(const PoolArgs &a, int z)
     return c;
 }
 
-__global__ __launch_bounds__(PL_THREADS) void pool_fwd_kernel(PoolArgs a, float *out)
+// The four texels of a wave's channels c = wave, wave + 4, ... of one chunk, EIGHT channels' reads in flight.  With lanes <->
+// vertices every read is a gather of 64 addresses, and the loop over a wave's 16 channels was a chain of 16 dependent round
+// trips (issue two reads, wait, use them): 23 us per call at the training shape whatever the traffic -- XCD-aware mapping of
+// the work moved it by 1 us.  (Also built: the 64 planes of a 14 x 14 / 7 x 7 chunk copied to LDS and looked up there -- 47 us:
+// a workgroup serves only 64 vertices per staged chunk, the copy's round trip and two barriers are not amortised.)
+constexpr int PL_INFLIGHT = 8;
+
+template <class Body>
+__device__ __forceinline__ void chunk_quads(const PoolArgs &a, const Chunk &ck, int mesh, const Texel &t, int nch, Body body)
+{
+    const int dim = a.dims[ck.level], C = a.channels[ck.level], texels = dim * dim;
+    const __amdgpu_buffer_rsrc_t r_blk = plane_rsrc(a.blocks[ck.level] + (size_t)mesh * C * texels, C, texels);
+    const int wave = threadIdx.x >> 6;
+    if (texels == 1) { // a 1 x 1 map: its one value four times (the weights are zero: the coordinate is integral)
+        for (int c = wave; c < nch; c += PL_WAVES) {
+            const float x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_blk, (unsigned)(ck.cc + c) * 4u, 0, 0));
+            body(c, Quad{x, x, x, x});
+        }
+        return;
+    }
+    for (int c = wave; c < nch; c += PL_WAVES * PL_INFLIGHT) {
+        Quad q[PL_INFLIGHT];
+#pragma unroll
+        for (int j = 0; j < PL_INFLIGHT; ++j) {
+#ifdef PL_PROBE_NO_LOADS
+            q[j] = Quad{t.A, t.B, t.G, (float)(c + j)};
+#else
+            q[j] = quad_of(r_blk, t, ck.cc + min(c + PL_WAVES * j, nch - 1), texels);
+#endif
+        }
+#pragma unroll
+        for (int j = 0; j < PL_INFLIGHT; ++j)
+            if (c + PL_WAVES * j < nch) body(c + PL_WAVES * j, q[j]);
+    }
+}
+
+// Which (vertex tile, mesh, chunk slice) a workgroup of the 1-D pooling launches owns.  Workgroups go to the eight XCDs round
+// robin (XCD = blockIdx.x % 8; the grid is a multiple of 8): an XCD is given CONSECUTIVE work items, ordered tile-fastest, so the
+// vertex tiles of one (mesh, chunk) -- which all read the same 64 planes -- run on one XCD, one after the other, and the planes
+// come out of HBM once.  (As a 3-D grid with the tiles in x, the eight tiles of a mesh went to eight XCDs and every L2 fetched
+// every map: 29 us forward at the training shape, 24 with paired reads, against ~10 for the bytes.)
+struct PoolWork {
+    int v0, mesh, z;
+    bool live;
+};
+
+__device__ __forceinline__ PoolWork pool_work(const PoolArgs &a, int zc)
+{
+    const int tiles = (a.nv + PL_VERTS - 1) / PL_VERTS;
+    const int w = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    PoolWork k;
+    k.live = w < tiles * a.b * zc;
+    const int r = w / tiles;
+    k.v0 = (w - r * tiles) * PL_VERTS, k.mesh = r / zc, k.z = r - k.mesh * zc; // (chunks inside a mesh: every XCD gets maps of every size)
+    return k;
+}
+
+static inline unsigned pool_grid(int nv, int b, int zc)
+{
+    const size_t n = (size_t)((nv + PL_VERTS - 1) / PL_VERTS) * b * zc;
+    return (unsigned)((n + 7) / 8 * 8);
+}
+
+__global__ __launch_bounds__(PL_THREADS) void pool_fwd_kernel(PoolArgs a, float *out, int zc)
 {
     __shared__ float tile[PL_VERTS][GEOM_WAVE + 1];
-    const int mesh = blockIdx.y, v0 = blockIdx.x * PL_VERTS;
-    const int lane = threadIdx.x & (GEOM_WAVE - 1), wave = threadIdx.x >> 6;
+    const PoolWork k = pool_work(a, zc);
+    if (!k.live) return;
+    const int mesh = k.mesh, v0 = k.v0;
+    const int lane = threadIdx.x & (GEOM_WAVE - 1);
     const int v = min(v0 + lane, a.nv - 1);
     const Projection pr = project(a, mesh, v);
-    for (int z = blockIdx.z; z < a.chunks; z += gridDim.z) { // (one chunk per workgroup up to PL_MAX_CHUNKS chunks)
+    for (int z = k.z; z < a.chunks; z += zc) { // (one chunk per workgroup up to PL_MAX_CHUNKS chunks)
         const Chunk ck = chunk_of(a, z);
         const int dim = a.dims[ck.level], C = a.channels[ck.level], cc = ck.cc;
         const Texel t = texel(pr.xs, pr.ys, dim);
-        const float *blk = a.blocks[ck.level] + (size_t)mesh * C * dim * dim;
         const int nch = min(GEOM_WAVE, C - cc);
-        for (int c = wave; c < nch; c += PL_WAVES) {
-            const float *plane = blk + (size_t)(cc + c) * dim * dim;
-            const float s1 = (t.A * plane[t.i11]) * t.G, s2 = (t.H * plane[t.i12]) * t.A;
-            const float s3 = (t.G * plane[t.i21]) * t.B, s4 = (t.B * plane[t.i22]) * t.H;
+        chunk_quads(a, ck, mesh, t, nch, [&](int c, const Quad &q) {
+            const float s1 = (t.A * q.c11) * t.G, s2 = (t.H * q.c12) * t.A;
+            const float s3 = (t.G * q.c21) * t.B, s4 = (t.B * q.c22) * t.H;
             tile[lane][c] = ((s1 + s2) + s3) + s4;
-        }
+        });
         __syncthreads();
-        for (int i = threadIdx.x; i < PL_VERTS * nch; i += PL_THREADS) {
-            const int vv = i / nch, ch = i - vv * nch;
-            if (v0 + vv < a.nv) out[((size_t)mesh * a.nv + v0 + vv) * a.ld + ck.off + cc + ch] = tile[vv][ch];
+        // a wave writes one vertex's 64 channels per round (lanes <-> channels: 256 contiguous bytes, no index arithmetic)
+        float *o = out + ((size_t)mesh * a.nv + v0) * a.ld + ck.off + cc + lane;
+        for (int vv = threadIdx.x >> 6; vv < min(PL_VERTS, a.nv - v0); vv += PL_WAVES) {
+#ifdef PL_PROBE_NO_STORE
+            if (tile[vv][lane] == 1.2345f)
+#endif
+            if (lane < nch) o[(size_t)vv * a.ld] = tile[vv][lane];
         }
         __syncthreads();
     }
@@ -128,37 +226,34 @@ __global__ __launch_bounds__(PL_THREADS) void pool_fwd_kernel(PoolArgs a, float 
 // one 64-channel chunk and leaves its share of d loss / d (xs, ys) per vertex in `partial` [chunk][mesh][vertex][2];
 // pool_bwd_verts_finish_kernel adds the chunks up in chunk order (fixed: bit-reproducible) and chains the sum through the
 // clamp, the perspective divide and the camera matrix.
-__global__ __launch_bounds__(PL_THREADS) void pool_bwd_verts_kernel(PoolArgs a, const float *grad_out, float *partial)
+__global__ __launch_bounds__(PL_THREADS) void pool_bwd_verts_kernel(PoolArgs a, const float *grad_out, float *partial, int zc)
 {
     __shared__ float tile[PL_VERTS][GEOM_WAVE + 1];
     __shared__ float part[PL_WAVES][2][PL_VERTS];
-    const int mesh = blockIdx.y, v0 = blockIdx.x * PL_VERTS;
+    const PoolWork k = pool_work(a, zc);
+    if (!k.live) return;
+    const int mesh = k.mesh, v0 = k.v0;
     const int lane = threadIdx.x & (GEOM_WAVE - 1), wave = threadIdx.x >> 6;
     const bool live = v0 + lane < a.nv;
     const int v = min(v0 + lane, a.nv - 1);
     const Projection pr = project(a, mesh, v);
     float ax = 0.f, ay = 0.f; // this wave's share of d loss / d (xs, ys) of the lane's vertex over the workgroup's chunks
-    for (int z = blockIdx.z; z < a.chunks; z += gridDim.z) {
+    for (int z = k.z; z < a.chunks; z += zc) {
         const Chunk ck = chunk_of(a, z);
         const int dim = a.dims[ck.level], C = a.channels[ck.level], cc = ck.cc;
         const Texel t = texel(pr.xs, pr.ys, dim);
-        const float *blk = a.blocks[ck.level] + (size_t)mesh * C * dim * dim;
         const int nch = min(GEOM_WAVE, C - cc);
-        for (int i = threadIdx.x; i < PL_VERTS * nch; i += PL_THREADS) {
-            const int vv = i / nch, ch = i - vv * nch;
-            tile[vv][ch] = v0 + vv < a.nv ? grad_out[((size_t)mesh * a.nv + v0 + vv) * a.ld + ck.off + cc + ch] : 0.f;
-        }
+        const float *gi = grad_out + ((size_t)mesh * a.nv + v0) * a.ld + ck.off + cc + (lane < nch ? lane : 0);
+        for (int vv = wave; vv < PL_VERTS; vv += PL_WAVES) // (a wave reads one vertex's 64 channels per round)
+            tile[vv][lane] = (v0 + vv < a.nv && lane < nch) ? gi[(size_t)vv * a.ld] : 0.f;
         __syncthreads();
         float gx = 0.f, gy = 0.f;
-        if (live) {
-            for (int c = wave; c < nch; c += PL_WAVES) {
-                const size_t po = (size_t)(cc + c) * dim * dim;
-                const float g = tile[lane][c];
-                const float c11 = blk[po + t.i11], c12 = blk[po + t.i12], c21 = blk[po + t.i21], c22 = blk[po + t.i22];
-                gx += g * (((-c11 * t.G) - (t.H * c12)) + ((t.G * c21) + (c22 * t.H)));
-                gy += g * (((-t.A * c11) + (c12 * t.A)) + ((-c21 * t.B) + (t.B * c22)));
-            }
-        }
+        chunk_quads(a, ck, mesh, t, nch, [&](int c, const Quad &q) { // (a padding lane's sums are dropped below)
+            const float g = tile[lane][c];
+            const float c11 = q.c11, c12 = q.c12, c21 = q.c21, c22 = q.c22;
+            gx += g * (((-c11 * t.G) - (t.H * c12)) + ((t.G * c21) + (c22 * t.H)));
+            gy += g * (((-t.A * c11) + (c12 * t.A)) + ((-c21 * t.B) + (t.B * c22)));
+        });
         if (t.in_x) ax += gx * dim; // the clamp passes the gradient only inside the map
         if (t.in_y) ay += gy * dim;
         __syncthreads();
@@ -172,7 +267,7 @@ __global__ __launch_bounds__(PL_THREADS) void pool_bwd_verts_kernel(PoolArgs a, 
             sx += part[w][0][lane];
             sy += part[w][1][lane];
         }
-        float *o = partial + (((size_t)blockIdx.z * a.b + mesh) * a.nv + v) * 2;
+        float *o = partial + (((size_t)k.z * a.b + mesh) * a.nv + v) * 2;
         o[0] = sx, o[1] = sy;
     }
 }
@@ -476,10 +571,11 @@ int fill_args(PoolArgs &a, int b, int nv, const float *verts, const float *cam_m
 {
     if (b < 0 || nv < 0 || levels < 0 || levels > GEOM_POOL_MAX_LEVELS) return GEOM_EINVAL;
     if (!verts || !cam_mat || !cam_pos || (levels > 0 && (!blocks || !channels || !dims))) return GEOM_EINVAL;
-    if (b > 65535) return GEOM_ETOOBIG;
+    if (b > 65535 || (size_t)((nv + PL_VERTS - 1) / PL_VERTS) * b * PL_MAX_CHUNKS > (size_t)INT_MAX - 8) return GEOM_ETOOBIG;
     a.verts = verts, a.cam_mat = cam_mat, a.cam_pos = cam_pos, a.levels = levels, a.b = b, a.nv = nv, a.ctot = 0, a.chunks = 0;
     for (int l = 0; l < levels; ++l) {
         if (!blocks[l] || channels[l] <= 0 || dims[l] <= 0) return GEOM_EINVAL;
+        if ((size_t)channels[l] * dims[l] * dims[l] * 4 > (size_t)INT_MAX) return GEOM_ETOOBIG; // (a mesh's planes as one buffer)
         a.blocks[l] = blocks[l], a.grad_blocks[l] = nullptr, a.channels[l] = channels[l], a.dims[l] = dims[l];
         a.ctot += channels[l];
         a.chunks += (channels[l] + GEOM_WAVE - 1) / GEOM_WAVE;
@@ -504,8 +600,8 @@ extern "C" int geom_pool_features_fwd_ld_f32(int b, int nv, const float *verts, 
         if (out_ld < a.ctot || out_ld > INT_MAX) return GEOM_EINVAL;
         a.ld = (int)out_ld;
     }
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3((nv + PL_VERTS - 1) / PL_VERTS, b, a.chunks < PL_MAX_CHUNKS ? a.chunks : PL_MAX_CHUNKS),
-                       dim3(PL_THREADS), 0, static_cast<hipStream_t>(stream), a, out);
+    const int zc = a.chunks < PL_MAX_CHUNKS ? a.chunks : PL_MAX_CHUNKS;
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(pool_grid(nv, b, zc)), dim3(PL_THREADS), 0, static_cast<hipStream_t>(stream), a, out, zc);
     return geom::launch_status();
 }
 
@@ -517,8 +613,8 @@ extern "C" int geom_pool_features_fwd_f32(int b, int nv, const float *verts, con
     if (int rc = fill_args(a, b, nv, verts, cam_mat, cam_pos, levels, blocks, channels, dims)) return rc;
     if (b == 0 || nv == 0 || levels == 0) return 0;
     if (!out) return GEOM_EINVAL;
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3((nv + PL_VERTS - 1) / PL_VERTS, b, a.chunks < PL_MAX_CHUNKS ? a.chunks : PL_MAX_CHUNKS),
-                       dim3(PL_THREADS), 0, static_cast<hipStream_t>(stream), a, out);
+    const int zc = a.chunks < PL_MAX_CHUNKS ? a.chunks : PL_MAX_CHUNKS;
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(pool_grid(nv, b, zc)), dim3(PL_THREADS), 0, static_cast<hipStream_t>(stream), a, out, zc);
     return geom::launch_status();
 }
 
@@ -600,8 +696,7 @@ extern "C" int geom_pool_features_bwd_ld_f32(int b, int nv, const float *verts, 
     }
     if (grad_verts) {
         const int zc = a.chunks < PL_MAX_CHUNKS ? a.chunks : PL_MAX_CHUNKS;
-        hipLaunchKernelGGL(pool_bwd_verts_kernel, dim3((nv + PL_VERTS - 1) / PL_VERTS, b, zc), dim3(PL_THREADS), 0, s, a, grad_out,
-                           ws.vert_partial);
+        hipLaunchKernelGGL(pool_bwd_verts_kernel, dim3(pool_grid(nv, b, zc)), dim3(PL_THREADS), 0, s, a, grad_out, ws.vert_partial, zc);
         hipLaunchKernelGGL(pool_bwd_verts_finish_kernel, dim3((nv + 255) / 256, b), dim3(256), 0, s, a, ws.vert_partial, zc, grad_verts);
     }
     return geom::launch_status();

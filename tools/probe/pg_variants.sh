@@ -1,9 +1,9 @@
 #!/bin/bash
-# Ablation builds of csrc/pooling.hip (probe macros PG_PROBE_*): what the gradient-row reads, the stores and the bare launch
-# of pool_gather_kernel each cost.   usage: pg_variants.sh build | run
+# Ablation builds of csrc/pooling.hip (probe macros PG_PROBE_* / PL_PROBE_*): what the reads, the stores and the bare launch
+# of pool_gather_kernel / pool_fwd_kernel / pool_bwd_verts_kernel each cost.   usage: pg_variants.sh build | run
 set -e
 cd "$(dirname "$0")/../.."
-VARIANTS=("base:" "norows:-DPG_PROBE_NO_ROWS" "nostore:-DPG_PROBE_NO_STORE" "bare:-DPG_PROBE_BARE")
+VARIANTS=("base:" "norows:-DPG_PROBE_NO_ROWS -DPL_PROBE_NO_LOADS" "nostore:-DPG_PROBE_NO_STORE -DPL_PROBE_NO_STORE" "bare:-DPG_PROBE_BARE -DPL_PROBE_NO_LOADS -DPL_PROBE_NO_STORE")
 if [ "$1" = build ]; then
   mkdir -p tools/probe/bin
   for v in "${VARIANTS[@]}"; do
@@ -21,6 +21,6 @@ else
   for v in "${VARIANTS[@]}"; do
     name=${v%%:*}
     echo "== $name"
-    GEOM_ALLOW_STALE_LIB=1 GEOM_LIB_OVERRIDE=$PWD/tools/probe/bin/libgeom_pg_$name.so python tools/time_pool_gather.py 2>&1 | grep "bin + gather"
+    GEOM_ALLOW_STALE_LIB=1 GEOM_LIB_OVERRIDE=$PWD/tools/probe/bin/libgeom_pg_$name.so python tools/time_pool_gather.py 2>&1 | grep "per call"
   done
 fi

@@ -55,6 +55,24 @@ def t(fn, it=20):
 
 
 print("bin + gather: %.1f us per call (16 x %d vertices, gradient pitch %d)" % (t(run), nv, LD))
+
+out = torch.empty(B, nv, LD, device=dev)
+gverts = torch.empty_like(verts)
+no_maps = (ctypes.c_void_p * n)(*[None] * n)
+
+
+def run_fwd():
+    _lib.call("geom_pool_features_fwd_ld_f32", B, nv, verts.data_ptr(), cam_mat.data_ptr(), cam_pos.data_ptr(), n, ptrs, chans, dims,
+              out[..., 195:].data_ptr(), LD)
+
+
+def run_verts():
+    _lib.call("geom_pool_features_bwd_ld_f32", B, nv, verts.data_ptr(), cam_mat.data_ptr(), cam_pos.data_ptr(), n, ptrs, chans, dims,
+              g.data_ptr(), LD, no_maps, gverts.data_ptr(), ws.data_ptr(), ws_bytes)
+
+
+print("forward: %.1f us per call" % t(run_fwd))
+print("vertex gradient (two launches): %.1f us per call" % t(run_verts))
 # list lengths: pooling identity maps gives P; nonzeros per texel column
 for c, d in shapes:
     eye = torch.eye(d * d, device=dev).view(1, d * d, d, d).expand(B, -1, -1, -1).contiguous()
