@@ -41,6 +41,8 @@ V_LEVEL, S_PTS, G_PTS, FEAT, HID = 4, 3000, 3000, 963, 192
 # 3.6 us the culled tiles save), so the HEADLINE runs the brute-force tiles on a ground-truth tensor that may change every replay.
 # --gt-index: the culled route, for jobs whose ground-truth clouds are static (same results bit for bit).
 CULLED_CHAMFER = False
+# the driver step's three surface losses on a second stream, each beside the next deformation block (driver_step_times)
+DRIVER_STEP_OVERLAP = False
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector peak == f32 MFMA dense peak
 
@@ -874,7 +876,7 @@ def training_shape_times(dev, batch=16):
                                   if csr.ell_w else "generic CSR"}
 
 
-def driver_step_times(dev, batch=16, profile_replays=0, zero_edit=False):
+def driver_step_times(dev, batch=16, profile_replays=0, zero_edit=False, overlap_losses=None):
     """The step the reference's driver really runs (GEOMetrics.py:110-174) at its own sizes: batch 16 on the 482-vertex /
     960-face template (meshgen.uv_sphere: the size and the two 32-neighbour poles of 482.obj), three poolings from four
     feature maps each (64x56^2, 128x28^2, 256x14^2, 512x7^2 -- what the three VGG encoders return; they are inputs here: the
@@ -910,6 +912,22 @@ def driver_step_times(dev, batch=16, profile_replays=0, zero_edit=False):
     # own utils); these operators never write their inputs, so only the zero-edit step keeps the copies
     clone = (lambda t: t.clone()) if zero_edit else (lambda t: t)
 
+    # the surface loss of a stage needs only that stage's positions: issued on a second stream as soon as they exist, its scan
+    # (VALU-issue bound: brute-force Chamfer pairs) runs beside the next block's layer launches (latency / matrix-core bound);
+    # autograd runs a node's backward on its forward's stream, so the gathers of the backward overlap likewise.  All three
+    # losses on ONE side stream: their draws advance the same generator state, in stage order.
+    overlap = DRIVER_STEP_OVERLAP if overlap_losses is None else bool(overlap_losses)
+    overlap = overlap and not zero_edit
+    loss_stream = torch.cuda.Stream(device=dev) if overlap else None
+
+    def surface_term(p, wgt):
+        surf = lambda: utils.batch_point_to_surface(p, info, gt, num=S_PTS, gt_index=gt_index, weight=wgt)
+        if loss_stream is None:
+            return surf()
+        loss_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(loss_stream):
+            return surf()
+
     def predict():
         base = initial.unsqueeze(0).expand(batch, nv, 3)
         # (the edited driver tells the pooling how many columns will be concatenated in front of its features -- 3 coordinates,
@@ -923,22 +941,28 @@ def driver_step_times(dev, batch=16, profile_replays=0, zero_edit=False):
         f = utils.batched_pooling(maps[0], base, clone(img_info), headroom=room(3))
         f, p1 = blocks[0](base, f, info["adj"])
         p1 = fan(base + p1, 6)
+        s1 = None if zero_edit else surface_term(p1[3], .2)
         f = cat(f, utils.batched_pooling(maps[1], clone(p1[0]), clone(img_info), headroom=room(3 + HID)))
         f, p2 = blocks[1](clone(p1[1]), f, info["adj"])
         p2 = fan(p2 + p1[2], 6)
+        s2 = None if zero_edit else surface_term(p2[3], .2)
         f = cat(f, utils.batched_pooling(maps[2], clone(p2[0]), clone(img_info), headroom=room(3 + HID)))
         _, p3 = blocks[2](clone(p2[1]), f, info["adj"])
         p3 = fan(p3 + p2[2], 2)
-        return p1[3:], p2[3:], p3
+        s3 = None if zero_edit else surface_term(p3[0], 2.0)
+        if zero_edit:
+            return p1[3:], p2[3:], p3
+        if loss_stream is not None:
+            torch.cuda.current_stream().wait_stream(loss_stream)
+        return (s1,) + tuple(p1[4:]), (s2,) + tuple(p2[4:]), (s3,) + tuple(p3[1:])
 
     def losses(p1, p2, p3):
-        # GEOMetrics.py:134-161 with its weights folded into the operators: surface_loss_k * (.2, .2, 2); per stage
-        # 300 * edge(p_k) + .2 * (1500 * lap term [* .3 for stage 1] + 100 * displacement term) as ONE node per stage
-        # (utils.stage_regularisers; the zero-edit step below keeps the driver's own expressions)
-        # p1, p2: (surface-loss handle, regulariser handle as `cur`, regulariser handle as `prev`); p3: (surface, cur)
-        surf = lambda p, wgt: utils.batch_point_to_surface(p, info, gt, num=S_PTS, gt_index=gt_index, weight=wgt)
+        # GEOMetrics.py:134-161 with its weights folded into the operators: surface_loss_k * (.2, .2, 2) (formed in predict(),
+        # behind each stage); per stage 300 * edge(p_k) + .2 * (1500 * lap term [* .3 for stage 1] + 100 * displacement term)
+        # as ONE node per stage (utils.stage_regularisers; the zero-edit step below keeps the driver's own expressions)
+        # p1, p2: (surface loss, regulariser handle as `cur`, regulariser handle as `prev`); p3: (surface loss, cur)
         return utils.sum_losses(
-            surf(p1[0], .2), surf(p2[0], .2), surf(p3[0], 2.0),
+            p1[0], p2[0], p3[0],
             utils.stage_regularisers(initial, p1[1], info, lap_weight=.2 * .3 * 1500, edge_weight=300),
             utils.stage_regularisers(p1[2], p2[1], info, lap_weight=.2 * 1500, move_weight=.2 * 100, edge_weight=300),
             utils.stage_regularisers(p2[2], p3[1], info, lap_weight=.2 * 1500, move_weight=.2 * 100, edge_weight=300))

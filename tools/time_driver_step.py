@@ -13,5 +13,9 @@ for fused in (True, False, True):
     r = bench.driver_step_times(dev)
     print("fused hidden layers %-5s  ms_per_step %.4f  %s" % (fused, r["ms_per_step"], json.dumps(r["stages_us"])))
 deform.enabled = True
+if "--overlap" in sys.argv:
+    for ov in (False, True, False, True):
+        r = bench.driver_step_times(dev, overlap_losses=ov)
+        print("surface losses on a second stream %-5s  ms_per_step %.4f  final loss %.5f" % (ov, r["ms_per_step"], r["final_loss"]))
 if "--zero-edit" in sys.argv:
     print(json.dumps(bench.driver_step_times(dev, zero_edit=True)))
