@@ -1116,6 +1116,51 @@ def test_pooling_with_more_channel_chunks_than_grid_slices(gpu):
     close(gv_big.cpu().numpy(), gv_sum.cpu().numpy(), 2e-5)
 
 
+def _pooling_against_float64(gpu, verts, img_info, chans, dims, headrooms=(0,)):
+    """forward, map gradient and vertex gradient of batched_pooling against float64 built from the pooling operator itself:
+    pooling identity maps (channel t = the one-hot map of texel t) returns P [b, nv, texels] with the weights as the kernel
+    forms them, so feats = P maps and d maps = P^T g in float64, per element, bound 8 eps * sum |P||g| (|maps|)."""
+    b = verts.shape[0]
+    maps = [torch.randn(b, c, d, d, device=gpu, requires_grad=True) for c, d in zip(chans, dims)]
+    eps = np.finfo(np.float32).eps
+    Ps = []
+    for d in dims:
+        eye = torch.eye(d * d, device=gpu).view(1, d * d, d, d).expand(b, -1, -1, -1).contiguous()
+        Ps.append(utils.batched_pooling([eye], verts, img_info.clone()).double())                  # [b, nv, d*d]
+    for headroom in headrooms:
+        feats = utils.batched_pooling(maps, verts, img_info.clone(), headroom=headroom)
+        g = torch.randn_like(feats)
+        grads = torch.autograd.grad(feats, maps, g)
+        col = 0
+        for c, d, P, m, got in zip(chans, dims, Ps, maps, grads):
+            md = m.detach().double().view(b, c, d * d)
+            ref_f = torch.einsum("bvt,bct->bvc", P, md)
+            bound_f = 8 * eps * torch.einsum("bvt,bct->bvc", P.abs(), md.abs()) + 1e-30
+            err_f = (feats.detach()[..., col:col + c].double() - ref_f).abs()
+            assert bool((err_f <= bound_f).all()), "features of map %d x %d: err/bound up to %.3g" % (d, d, float((err_f / bound_f).max()))
+            gl = g[..., col:col + c].double()
+            ref = torch.einsum("bvt,bvc->bct", P, gl).view(b, c, d, d)
+            bound = 8 * eps * torch.einsum("bvt,bvc->bct", P.abs(), gl.abs()).view(b, c, d, d) + 1e-30
+            err = (got.double() - ref).abs()
+            assert bool((err <= bound).all()), "map %d x %d: err/bound up to %.3g" % (d, d, float((err / bound).max()))
+            col += c
+    return Ps
+
+
+def test_pooling_at_ragged_shapes_per_element(gpu):
+    """Channel counts that are no multiple of 64 (or of the lane vector: 70 -> 1, 130 -> 2, 260 -> 4 channels per lane, a
+    partial last slice each), map sizes 1 x 1 (every weight zero: integral coordinate), 2 x 2, odd sizes whose runs end
+    ragged, one map larger than a run's tile allows 64 texels for (260 channels x 40 x 40), a vertex count that is no
+    multiple of the 64-vertex tile, vertices that project outside the image (clamped)."""
+    torch.manual_seed(32)
+    V, _ = meshgen.icosphere(1)                                                     # 42 vertices
+    V = np.concatenate([V, 0.5 * V, 2.5 * V], 0)[:101]                              # (2.5 x: outside the image for some cameras)
+    verts = dev(meshgen.jittered_batch(V, 2), gpu)
+    img_info = torch.tensor([[35.0, 20.0, 1.2], [250.0, -30.0, 0.8]], device=gpu)
+    _pooling_against_float64(gpu, verts, img_info, chans=(70, 130, 260, 5), dims=(5, 9, 40, 1), headrooms=(0, 7))
+    _pooling_against_float64(gpu, verts, img_info, chans=(3, 64), dims=(2, 13))
+
+
 def test_pooling_map_gradient_per_element_at_the_training_shape(gpu):
     """d loss / d maps at the reference's training shape (482 vertices, the four VGG maps 64 x 56^2 ... 512 x 7^2), every
     element against float64.  The pooling is LINEAR in the maps: feats[b, v, c] = sum_t P_b[v, t] map[b, c, t], and pooling
