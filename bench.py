@@ -43,6 +43,8 @@ V_LEVEL, S_PTS, G_PTS, FEAT, HID = 4, 3000, 3000, 963, 192
 CULLED_CHAMFER = False
 # the driver step's three surface losses on a second stream, each beside the next deformation block (driver_step_times)
 DRIVER_STEP_OVERLAP = False
+# ... the three stages' surface losses as one call on the 48 stacked meshes with per-mesh weights
+DRIVER_STEP_STACKED_LOSSES = True
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector peak == f32 MFMA dense peak
 
@@ -920,6 +922,8 @@ def driver_step_times(dev, batch=16, profile_replays=0, zero_edit=False, overlap
     overlap = overlap and not zero_edit
     loss_stream = torch.cuda.Stream(device=dev) if overlap else None
 
+    stage_weights = torch.tensor([3 * .2] * batch + [3 * .2] * batch + [3 * 2.0] * batch, dtype=torch.float32, device=dev)
+
     def surface_term(p, wgt):
         surf = lambda: utils.batch_point_to_surface(p, info, gt, num=S_PTS, gt_index=gt_index, weight=wgt)
         if loss_stream is None:
@@ -941,15 +945,24 @@ def driver_step_times(dev, batch=16, profile_replays=0, zero_edit=False, overlap
         f = utils.batched_pooling(maps[0], base, clone(img_info), headroom=room(3))
         f, p1 = blocks[0](base, f, info["adj"])
         p1 = fan(base + p1, 6)
-        s1 = None if zero_edit else surface_term(p1[3], .2)
+        stacked = DRIVER_STEP_STACKED_LOSSES and not zero_edit and loss_stream is None
+        s1 = None if zero_edit or stacked else surface_term(p1[3], .2)
         f = cat(f, utils.batched_pooling(maps[1], clone(p1[0]), clone(img_info), headroom=room(3 + HID)))
         f, p2 = blocks[1](clone(p1[1]), f, info["adj"])
         p2 = fan(p2 + p1[2], 6)
-        s2 = None if zero_edit else surface_term(p2[3], .2)
+        s2 = None if zero_edit or stacked else surface_term(p2[3], .2)
         f = cat(f, utils.batched_pooling(maps[2], clone(p2[0]), clone(img_info), headroom=room(3 + HID)))
         _, p3 = blocks[2](clone(p2[1]), f, info["adj"])
         p3 = fan(p3 + p2[2], 2)
-        s3 = None if zero_edit else surface_term(p3[0], 2.0)
+        if stacked:
+            # the three stages' surface losses (GEOMetrics.py:134-138: weights .2 / .2 / 2, one ground truth) as ONE call on the 48
+            # stacked meshes with per-mesh factors -- the loss is a mean over the batch, so stage s enters with 3 x its weight:
+            # one draw / scan / finalize / gather launch instead of three each (the scan's pairs are the same; the fixed costs
+            # of the launches and the 17-workgroup finalize passes are not)
+            s3 = utils.batch_point_to_surface(torch.cat((p1[3], p2[3], p3[0])), info, torch.cat((gt, gt, gt)), num=S_PTS,
+                                              weight=stage_weights)
+        else:
+            s3 = None if zero_edit else surface_term(p3[0], 2.0)
         if zero_edit:
             return p1[3:], p2[3:], p3
         if loss_stream is not None:
@@ -962,7 +975,7 @@ def driver_step_times(dev, batch=16, profile_replays=0, zero_edit=False, overlap
         # as ONE node per stage (utils.stage_regularisers; the zero-edit step below keeps the driver's own expressions)
         # p1, p2: (surface loss, regulariser handle as `cur`, regulariser handle as `prev`); p3: (surface loss, cur)
         return utils.sum_losses(
-            p1[0], p2[0], p3[0],
+            *[t for t in (p1[0], p2[0], p3[0]) if t is not None],
             utils.stage_regularisers(initial, p1[1], info, lap_weight=.2 * .3 * 1500, edge_weight=300),
             utils.stage_regularisers(p1[2], p2[1], info, lap_weight=.2 * 1500, move_weight=.2 * 100, edge_weight=300),
             utils.stage_regularisers(p2[2], p3[1], info, lap_weight=.2 * 1500, move_weight=.2 * 100, edge_weight=300))

@@ -16,7 +16,7 @@ FLAG_FIX_REGION6 = 2
 FLAG_TRI_BRUTE_FORCE = 4
 FLAG_NN_FMA = 8
 FLAG_TRI_WS_READY = 16
-ABI_VERSION = 10
+ABI_VERSION = 11
 EUNSUPPORTED = -3
 ADAM_MAX_TENSORS = 64
 COLSUM_MAX_JOBS = 32
@@ -80,6 +80,9 @@ _SIGNATURES = {
     "geom_surface_scan_f32": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp, _f, _f, _vp, _u, _vp, ctypes.c_size_t, _vp, _vp, _vp, _vp],
     "geom_surface_gather_f32": [_i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "geom_surface_finalize_w_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i,
+                                    _i, _vp, _vp, _vp, _vp],
+    "geom_surface_gather_w_f32": [_i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_vertex_head_fwd_f32": [ctypes.c_int64, _i, _vp, _vp, _f, _vp, _vp],
     "geom_vertex_head_bwd_f32": [ctypes.c_int64, _i, _vp, _f, _vp, _vp],
     "geom_sample_faces_fwd_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],

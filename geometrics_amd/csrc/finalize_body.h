@@ -45,6 +45,7 @@ struct FinalizeArgs {
     float4 *rec;
     float *loss;
     int *status; // [b + 1] words of the scratch (surface_layout.h): 0 = this role's result is complete; null: no scratch
+    const float *mesh_weight; // [b] or null: loss = sum_m w[m] * (scale_sample * sum(sq_sample[m]) + scale_other * sum(sq_other[m]))
 };
 
 
@@ -123,11 +124,47 @@ __device__ __forceinline__ void surface_finalize_body(const FinalizeArgs &a, int
             for (int64_t i = 4 * n4 + vt; i < n; i += FIN_VIRTUAL) acc += x[i];
             return acc;
         };
+        // per-mesh weights (several equal-size batches stacked into one call, each with its own factor): the same walk over
+        // the flat array, every element times its mesh's weight -- the mesh of a thread's next element follows from the
+        // previous one (stride FIN_VIRTUAL elements), no division per element
+        auto weighted_sum = [&](const float *x, int per_mesh, int vt) {
+            float acc = 0.f;
+            if (per_mesh <= 0) return acc;
+            const int64_t n = (int64_t)a.b * per_mesh;
+            const bool vec = (((uintptr_t)x) & 15) == 0 && per_mesh % 4 == 0; // (a float4 then never straddles two meshes)
+            const int width = vec ? 4 : 1;
+            const int64_t units = n / width;
+            const float4 *x4 = reinterpret_cast<const float4 *>(x);
+            int mesh = (int)(((int64_t)vt * width) / per_mesh), rem = (int)(((int64_t)vt * width) % per_mesh);
+            for (int64_t base = 0; base < units; base += (int64_t)8 * FIN_VIRTUAL) {
+                float4 v[8];
+                float w[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int64_t i = base + vt + (int64_t)k * FIN_VIRTUAL;
+                    const bool in = i < units;
+                    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (in && vec) v[k] = x4[i];
+                    if (in && !vec) v[k].x = x[i];
+                    w[k] = in ? a.mesh_weight[mesh] : 0.f;
+                    rem += FIN_VIRTUAL * width;
+                    while (rem >= per_mesh) rem -= per_mesh, ++mesh;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += w[k] * ((v[k].x + v[k].y) + (v[k].z + v[k].w));
+            }
+            return acc;
+        };
         float s1[V], s2[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            s1[j] = virtual_sum(a.sq_sample, (int64_t)a.b * a.num, tid + j * THREADS);
-            s2[j] = virtual_sum(a.sq_other, (int64_t)a.b * a.n_gt, tid + j * THREADS);
+            if (a.mesh_weight) {
+                s1[j] = weighted_sum(a.sq_sample, a.num, tid + j * THREADS);
+                s2[j] = weighted_sum(a.sq_other, a.n_gt, tid + j * THREADS);
+            } else {
+                s1[j] = virtual_sum(a.sq_sample, (int64_t)a.b * a.num, tid + j * THREADS);
+                s2[j] = virtual_sum(a.sq_other, (int64_t)a.b * a.n_gt, tid + j * THREADS);
+            }
         }
         const float t1 = block_sum_virtual<THREADS>(s1, fsum, tid);
         const float t2 = block_sum_virtual<THREADS>(s2, fsum + FIN_VWAVES, tid);

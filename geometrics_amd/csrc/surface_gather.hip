@@ -274,6 +274,7 @@ struct VGatherArgs {
     int nv, nf, per;
     const int *status; // [b + 1] (surface_layout.h)
     int b;
+    const float *mesh_weight; // [b] or null: mesh m's gradient times w[m] (the loss was formed with the same weights)
 };
 
 // The backward: eight lanes per (mesh, vertex), one incident (face, corner) each; a face's segment is walked in its
@@ -319,7 +320,8 @@ __global__ __launch_bounds__(SGA_THREADS) void surface_vertex_gather_kernel(VGat
         total = total + other;
     }
     if (live && j == 0) {
-        const float s = broken ? __builtin_nanf("") : 2.f * (a.grad ? a.grad[0] : 1.f);
+        float s = broken ? __builtin_nanf("") : 2.f * (a.grad ? a.grad[0] : 1.f);
+        if (a.mesh_weight) s *= a.mesh_weight[mesh];
         float *G = a.grad_verts + ((int64_t)mesh * a.nv + vtx) * 3;
         G[0] = total.x * s;
         G[1] = total.y * s;
@@ -397,12 +399,34 @@ extern "C" int64_t geom_surface_order_words(int b, int nf, int num, int n_gt)
     return geom_surface_status_offset(b, nf, cap) + geom_surface_status_ints(b);
 }
 
+extern "C" int geom_surface_finalize_w_f32(int b, int nf, int num, const int64_t *choices, const float *u, const float *v,
+                                           const float *points, int n_gt, const float *gt, const int *idx_g,
+                                           const int *idx_p, const int *index, const float *closest, const float *weights,
+                                           const float *sq_sample, const float *sq_other, float scale_sample,
+                                           float scale_other, float coef_sample, float coef_other, int want_order,
+                                           int records_ready, int *order, float *loss, const float *mesh_weight, void *stream);
+
 extern "C" int geom_surface_finalize_f32(int b, int nf, int num, const int64_t *choices, const float *u, const float *v,
                                          const float *points, int n_gt, const float *gt, const int *idx_g,
                                          const int *idx_p, const int *index, const float *closest, const float *weights,
                                          const float *sq_sample, const float *sq_other, float scale_sample,
                                          float scale_other, float coef_sample, float coef_other, int want_order,
                                          int records_ready, int *order, float *loss, void *stream)
+{
+    return geom_surface_finalize_w_f32(b, nf, num, choices, u, v, points, n_gt, gt, idx_g, idx_p, index, closest, weights, sq_sample,
+                                       sq_other, scale_sample, scale_other, coef_sample, coef_other, want_order, records_ready, order,
+                                       loss, nullptr, stream);
+}
+
+// mesh_weight (may be NULL = all ones): [b] device floats; the loss becomes sum_m w[m] * (mesh m's two sums) -- several
+// equal-size batches (the stages of a cascade) stacked into ONE call, each with its own factor.  The gradient records do not
+// carry the weights: geom_surface_gather_w_f32 applies the same array.
+extern "C" int geom_surface_finalize_w_f32(int b, int nf, int num, const int64_t *choices, const float *u, const float *v,
+                                           const float *points, int n_gt, const float *gt, const int *idx_g,
+                                           const int *idx_p, const int *index, const float *closest, const float *weights,
+                                           const float *sq_sample, const float *sq_other, float scale_sample,
+                                           float scale_other, float coef_sample, float coef_other, int want_order,
+                                           int records_ready, int *order, float *loss, const float *mesh_weight, void *stream)
 {
     if (b < 0 || nf < 0 || num < 0 || n_gt < 0) return GEOM_EINVAL;
     if (!loss || !order || ((uintptr_t)order & 15)) return GEOM_EINVAL;
@@ -427,7 +451,7 @@ extern "C" int geom_surface_finalize_f32(int b, int nf, int num, const int64_t *
     float4 *rec = reinterpret_cast<float4 *>(order + geom_surface_order_ints(b, nf, cap));
     FinalizeArgs a{choices, u, v, points, gt, idx_g, idx_p, index, closest, weights, sq_sample, sq_other, scale_sample,
                    scale_other, coef_sample, coef_other, b, nf, num, n_gt, other, per, want_order ? 1 : 0, records_ready ? 1 : 0, off, seg, pface,
-                   slot, rec, loss, order + geom_surface_status_offset(b, nf, cap)};
+                   slot, rec, loss, order + geom_surface_status_offset(b, nf, cap), mesh_weight};
     hipStream_t s = static_cast<hipStream_t>(stream);
     // without ordering the single (loss) workgroup touches only its reduction scratch: independent of nf, so the
     // documented fallback beyond the ordering limit (want_order = 0 + scatter backward) really launches
@@ -446,8 +470,20 @@ extern "C" int geom_surface_finalize_f32(int b, int nf, int num, const int64_t *
     return geom::launch_status();
 }
 
+extern "C" int geom_surface_gather_w_f32(int b, int nv, int nf, const int *vf_ptr, const int *vf_item, int num, int n_gt,
+                                         int has_other, const int *order, const float *grad, const float *mesh_weight,
+                                         float *grad_verts, void *stream);
+
 extern "C" int geom_surface_gather_f32(int b, int nv, int nf, const int *vf_ptr, const int *vf_item, int num, int n_gt,
                                        int has_other, const int *order, const float *grad, float *grad_verts, void *stream)
+{
+    return geom_surface_gather_w_f32(b, nv, nf, vf_ptr, vf_item, num, n_gt, has_other, order, grad, nullptr, grad_verts, stream);
+}
+
+// mesh_weight (may be NULL): the per-mesh factors of geom_surface_finalize_w_f32; mesh m's gradient = w[m] * 2 * grad[0] * (...)
+extern "C" int geom_surface_gather_w_f32(int b, int nv, int nf, const int *vf_ptr, const int *vf_item, int num, int n_gt,
+                                         int has_other, const int *order, const float *grad, const float *mesh_weight,
+                                         float *grad_verts, void *stream)
 {
     if (b < 0 || nv < 0 || nf < 0 || num < 0 || n_gt < 0) return GEOM_EINVAL;
     if (b == 0 || nv == 0) return 0;
@@ -458,7 +494,8 @@ extern "C" int geom_surface_gather_f32(int b, int nv, int nf, const int *vf_ptr,
     const int *off = order;
     const int *seg = off + (int64_t)b * (nf + 1);
     const float4 *rec = reinterpret_cast<const float4 *>(order + geom_surface_order_ints(b, nf, cap));
-    VGatherArgs a{vf_ptr, vf_item, off, seg, rec, grad, grad_verts, nv, nf, per, order + geom_surface_status_offset(b, nf, cap), b};
+    VGatherArgs a{vf_ptr, vf_item, off, seg, rec, grad, grad_verts, nv, nf, per, order + geom_surface_status_offset(b, nf, cap), b,
+                  mesh_weight};
     hipLaunchKernelGGL(surface_vertex_gather_kernel, dim3(((int64_t)nv * VTX_LANES + SGA_THREADS - 1) / SGA_THREADS, b),
                        dim3(SGA_THREADS), 0, static_cast<hipStream_t>(stream), a);
     return geom::launch_status();

@@ -264,7 +264,10 @@ class SurfaceLoss(torch.autograd.Function):
     distances feed the F1 score and are not differentiable."""
 
     @staticmethod
-    def forward(ctx, verts, faces, gt, choices, u, v, two_sided, scale, points=None, tri_ws=None, loss_out=None, gt_index=None):
+    def forward(ctx, verts, faces, gt, choices, u, v, two_sided, scale, points=None, tri_ws=None, loss_out=None, gt_index=None,
+                mesh_weight=None):
+        """mesh_weight (optional, [B] fp32 on the meshes' device): per-mesh factors -- loss = sum_m w[m] * (mesh m's share of the
+        loss above), mesh m's gradient times w[m] (geom_surface_finalize_w_f32 / geom_surface_gather_w_f32)."""
         verts_c = _f32(verts.detach(), "verts", 3, 3)
         gt_c = _f32(gt.detach(), "gt_points", 3, 3)
         faces = _lib.require(faces, "faces", torch.int64, 2, 3)
@@ -275,6 +278,10 @@ class SurfaceLoss(torch.autograd.Function):
         num, n_gt, nf, dev = choices.shape[1], gt_c.shape[1], faces.shape[0], verts_c.device
         if gt_c.shape[0] != b:
             raise RuntimeError("gt_points and verts batch sizes differ")
+        if mesh_weight is not None:
+            mesh_weight = _f32(mesh_weight.detach(), "mesh_weight", 1)
+            if mesh_weight.shape[0] != b or mesh_weight.device != verts_c.device:
+                raise RuntimeError("mesh_weight must be [B] on the meshes' device")
         L = _lib.lib()
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
@@ -333,7 +340,7 @@ class SurfaceLoss(torch.autograd.Function):
             # the fused one and a mesh's faces + points fit its LDS (tail.finalized says so): each mesh is ordered as soon
             # as ITS triangle tiles are through instead of in a launch of its own behind the slowest tile
             tail = None
-            if not two_sided and scan_finalize_tail:
+            if not two_sided and scan_finalize_tail and mesh_weight is None:    # (the in-launch roles know no per-mesh factors)
                 tail = _lib.SurfaceTail(choices.data_ptr(), scale / sq_pred.numel(), scale / sq.numel(), int(want), out.data_ptr(), 0)
             _lib.check(L.geom_surface_scan_f32(
                 b, n_gt, gt_c.data_ptr(), num, points.data_ptr(), sq_gt.data_ptr(), idx_p.data_ptr(), sq_pred.data_ptr(),
@@ -349,11 +356,15 @@ class SurfaceLoss(torch.autograd.Function):
                     None if two_sided else closest.data_ptr(), None if two_sided else weights.data_ptr(),
                     sq_pred.data_ptr(), other_sq.data_ptr(), scale / sq_pred.numel(), scale / other_sq.numel(), coef_s, coef_o)
             if tail is None or not tail.finalized:
-                code = L.geom_surface_finalize_f32(*args, int(want), wrote.value, order.data_ptr(), out.data_ptr(), _lib.stream_ptr())
+                wptr = _lib.ptr(mesh_weight)
+                code = L.geom_surface_finalize_w_f32(*args, int(want), wrote.value, order.data_ptr(), out.data_ptr(), wptr,
+                                                     _lib.stream_ptr())
                 if code == _lib.EUNSUPPORTED:       # too many faces + points for the in-LDS ordering: loss only, scatter backward
+                    if mesh_weight is not None and want:
+                        raise RuntimeError("per-mesh weights need the ordered backward (faces + points of a mesh within ~38 000)")
                     want = False
-                    code = L.geom_surface_finalize_f32(*args, 0, 0, order.data_ptr(), out.data_ptr(), _lib.stream_ptr())
-                _lib.check(code, "geom_surface_finalize_f32")
+                    code = L.geom_surface_finalize_w_f32(*args, 0, 0, order.data_ptr(), out.data_ptr(), wptr, _lib.stream_ptr())
+                _lib.check(code, "geom_surface_finalize_w_f32")
             ctx.order = order if want else None
             if tail is not None and tail.finalized and want:
                 _watch_roles(order, b, nf, num + n_gt)
@@ -366,6 +377,7 @@ class SurfaceLoss(torch.autograd.Function):
             else:
                 ctx.save_for_backward(faces, choices, u, v, points, gt_c, idx_g, index, closest, weights)
         ctx.two_sided, ctx.scale, ctx.nv = two_sided, scale, nv
+        ctx.mesh_weight = mesh_weight
         ctx.mark_non_differentiable(sq_gt, sq_pred)
         ctx.set_materialize_grads(False)    # no zero tensors (two fill launches) for the two distance outputs
         return out, sq_gt, sq_pred
@@ -382,8 +394,10 @@ class SurfaceLoss(torch.autograd.Function):
             if ctx.order is not None:           # prepared by the forward's finalize launch: one gather, no atomics
                 vf_ptr, vf_item = vertex_faces(faces, nv)
                 grad_verts = torch.empty(b, nv, 3, dtype=torch.float32, device=dev)
-                _lib.call("geom_surface_gather_f32", b, nv, nf, vf_ptr.data_ptr(), vf_item.data_ptr(), num, n_gt, 1,
-                          ctx.order.data_ptr(), grad.data_ptr(), grad_verts.data_ptr())
+                _lib.call("geom_surface_gather_w_f32", b, nv, nf, vf_ptr.data_ptr(), vf_item.data_ptr(), num, n_gt, 1,
+                          ctx.order.data_ptr(), grad.data_ptr(), _lib.ptr(ctx.mesh_weight), grad_verts.data_ptr())
+            elif ctx.mesh_weight is not None:
+                raise RuntimeError("per-mesh weights need the ordered backward")
             else:
                 # a mesh whose faces + points do not fit the ordering pass's LDS (> ~38 000 together): scatter formulation
                 # (fp32 atomics into a zeroed gradient; same values up to summation order)
@@ -399,7 +413,7 @@ class SurfaceLoss(torch.autograd.Function):
                               u.data_ptr(), v.data_ptr(), points.data_ptr(), n_gt, gt.data_ptr(), saved[6].data_ptr(),
                               index.data_ptr(), closest.data_ptr(), weights.data_ptr(), grad.data_ptr(),
                               ctx.scale / (b * num), ctx.scale / (b * n_gt), grad_verts.data_ptr())
-        return grad_verts, None, None, None, None, None, None, None, None, None, None, None
+        return grad_verts, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class Laplacian(torch.autograd.Function):

@@ -88,8 +88,11 @@ def _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, two_sided, los
                                                              prepare_scan_for=gt_points.shape[1], gt_index=gt_index)
     else:
         choices, u, v = draws
+    mesh_weight = None
+    if isinstance(weight, torch.Tensor):      # per-mesh factors: the loss's own scale stays, the kernels apply the factors
+        mesh_weight, weight = weight, 1.0
     loss, sq_gt, sq_pred = ops.SurfaceLoss.apply(pred_vert, faces, gt_points, choices, u, v, two_sided, LOSS_SCALE * weight,
-                                                 points, tri_ws, loss_out, gt_index)
+                                                 points, tri_ws, loss_out, gt_index, mesh_weight)
     if f1:
         return loss, _f_score(sq_gt, sq_pred, num)
     return loss
@@ -109,7 +112,10 @@ def batch_point_to_surface(pred_vert, adj_info, gt_points, num=1000, f1=False, d
     the culled scan and the draw launch generates the samples in face-visiting order (other, equally distributed draws than
     without the index: sorted uniforms from exponential spacings); on the same draws loss and gradients are those of the plain
     route, bit for bit (tests/test_ops_parity_gpu.py).  weight (not a reference argument): a factor folded into the loss's
-    own scale -- `weight * loss` without the multiply launches forward and backward (GEOMetrics.py:138: .2 / .2 / 2)."""
+    own scale -- `weight * loss` without the multiply launches forward and backward (GEOMetrics.py:138: .2 / .2 / 2); or a
+    [B] fp32 tensor of PER-MESH factors: the result is (1/B) sum_m weight[m] * L_m with L_m the loss of mesh m alone -- the
+    three stages of the cascade stacked into one call (`torch.cat((p1, p2, p3))` against `torch.cat((gt, gt, gt))`, weights
+    3 x (.2, .2, 2) per stage: the mean is over the stacked batch): one draw / scan / finalize / gather launch instead of three."""
     return _surface_loss(pred_vert, adj_info, gt_points, num, f1, draws, False, loss_out, gt_index, weight)
 
 

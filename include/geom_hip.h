@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GEOM_ABI_VERSION 10
+#define GEOM_ABI_VERSION 11
 
 /* argument errors */
 #define GEOM_EINVAL   (-1) /* bad size / null pointer */
@@ -656,6 +656,20 @@ int geom_surface_finalize_f32(int b, int nf, int num, const int64_t *choices, co
                               void *stream);
 int geom_surface_gather_f32(int b, int nv, int nf, const int *vf_ptr, const int *vf_item, int num, int n_gt,
                             int has_other, const int *order, const float *grad, float *grad_verts, void *stream);
+/* The same two calls with PER-MESH factors mesh_weight[b] (device floats; NULL = the calls above): loss = sum_m w[m] *
+ * (scale_sample * sum(sq_sample[m]) + scale_other * sum(sq_other[m])), mesh m's gradient = w[m] * 2 * grad[0] * (...).
+ * The stages of the reference's cascade (GEOMetrics.py:134-138: three surface losses on meshes of one size against one
+ * ground truth, weights .2 / .2 / 2) stacked into ONE batch: one draw / scan / finalize / gather launch instead of
+ * three each.  The gradient records do not carry the weights (both calls must be given the same array). */
+int geom_surface_finalize_w_f32(int b, int nf, int num, const int64_t *choices, const float *u, const float *v,
+                                const float *points, int n_gt, const float *gt, const int *idx_g, const int *idx_p,
+                                const int *index, const float *closest, const float *weights, const float *sq_sample,
+                                const float *sq_other, float scale_sample, float scale_other, float coef_sample,
+                                float coef_other, int want_order, int records_ready, int *order, float *loss,
+                                const float *mesh_weight, void *stream);
+int geom_surface_gather_w_f32(int b, int nv, int nf, const int *vf_ptr, const int *vf_item, int num, int n_gt,
+                              int has_other, const int *order, const float *grad, const float *mesh_weight,
+                              float *grad_verts, void *stream);
 
 /* ---- ragged mesh batches (SURVEY 8f "next" row 4; auto_encoder.py:71-76, layers.py:78) ---------------
  * Meshes of different sizes are concatenated along the vertex axis; segment s owns rows

@@ -1116,6 +1116,50 @@ def test_pooling_with_more_channel_chunks_than_grid_slices(gpu):
     close(gv_big.cpu().numpy(), gv_sum.cpu().numpy(), 2e-5)
 
 
+def test_surface_loss_with_per_mesh_weights_equals_the_weighted_stages(gpu):
+    """batch_point_to_surface(weight=[B] tensor): three 'stages' of 5 meshes stacked into one call against one ground truth,
+    factors 3 x (.2, .2, 2) per stage (the mean runs over the stacked batch) -- loss and position gradients against the three
+    separate calls `w_s * batch_point_to_surface(stage s)` on the SAME draws (GEOMetrics.py:134-138).  The stacked call forms
+    the same per-point terms (the factor enters the loss's summation and, in the backward, scales the finished per-vertex
+    sum): agreement to fp32 round-off of the differently grouped sums."""
+    torch.manual_seed(41)
+    V, Fc = meshgen.icosphere(2)
+    nb, num = 5, 700
+    faces = dev(Fc, gpu)
+    info = utils.adj_init(faces)
+    stages = [dev(meshgen.jittered_batch(V, nb, first=10 * k), gpu, grad=True) for k in range(3)]
+    gt = dev(meshgen.gt_cloud(nb, 900, first=3), gpu)
+    ops.manual_seed(77, gpu)
+    draws = [ops.draw_samples(p.detach(), faces, num)[:3] for p in stages]
+    ws = (.2, .2, 2.0)
+    ref_loss = 0.0
+    for p, d, w in zip(stages, draws, ws):
+        term = w * utils.batch_point_to_surface(p, info, gt, num=num, draws=d)
+        term.backward()
+        ref_loss = ref_loss + term.detach().double()
+    ref_grads = [p.grad.clone() for p in stages]
+    for p in stages:
+        p.grad = None
+    stacked = torch.cat(stages).detach().requires_grad_(True)
+    weight = torch.tensor([3 * w for w in ws for _ in range(nb)], dtype=torch.float32, device=gpu)
+    all_draws = tuple(torch.cat([d[k] for d in draws]) for k in range(3))
+    loss = utils.batch_point_to_surface(stacked, info, torch.cat((gt, gt, gt)), num=num, draws=all_draws, weight=weight)
+    loss.backward()
+    assert abs(float(loss.detach().double() - ref_loss)) <= 2e-6 * abs(float(ref_loss))
+    for k in range(3):
+        close(stacked.grad[k * nb:(k + 1) * nb].cpu().numpy(), ref_grads[k].cpu().numpy(), 2e-6)
+    # an upstream factor and a constant weight vector: the scalar route's result
+    stacked.grad = None
+    ones = torch.full((3 * nb,), 1.5, device=gpu)
+    (2.0 * utils.batch_point_to_surface(stacked, info, torch.cat((gt, gt, gt)), num=num, draws=all_draws, weight=ones)).backward()
+    g_vec = stacked.grad.clone()
+    stacked.grad = None
+    (2.0 * utils.batch_point_to_surface(stacked, info, torch.cat((gt, gt, gt)), num=num, draws=all_draws, weight=1.5)).backward()
+    close(g_vec.cpu().numpy(), stacked.grad.cpu().numpy(), 2e-6)
+    with pytest.raises(RuntimeError):
+        utils.batch_point_to_surface(stacked, info, torch.cat((gt, gt, gt)), num=num, weight=weight[:4])
+
+
 def _pooling_against_float64(gpu, verts, img_info, chans, dims, headrooms=(0,)):
     """forward, map gradient and vertex gradient of batched_pooling against float64 built from the pooling operator itself:
     pooling identity maps (channel t = the one-hot map of texel t) returns P [b, nv, texels] with the weights as the kernel

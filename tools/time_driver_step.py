@@ -17,5 +17,10 @@ if "--overlap" in sys.argv:
     for ov in (False, True, False, True):
         r = bench.driver_step_times(dev, overlap_losses=ov)
         print("surface losses on a second stream %-5s  ms_per_step %.4f  final loss %.5f" % (ov, r["ms_per_step"], r["final_loss"]))
+if "--stacked" in sys.argv:
+    for st in (False, True, False, True):
+        bench.DRIVER_STEP_STACKED_LOSSES = st
+        r = bench.driver_step_times(dev)
+        print("the three surface losses in one call %-5s  ms_per_step %.4f  final loss %.5f" % (st, r["ms_per_step"], r["final_loss"]))
 if "--zero-edit" in sys.argv:
     print(json.dumps(bench.driver_step_times(dev, zero_edit=True)))
