@@ -173,10 +173,10 @@ struct PoolWork {
     bool live;
 };
 
-__device__ __forceinline__ PoolWork pool_work(const PoolArgs &a, int zc)
+__device__ __forceinline__ PoolWork pool_work(const PoolArgs &a, int zc, int bid, int nblocks)
 {
     const int tiles = (a.nv + PL_VERTS - 1) / PL_VERTS;
-    const int w = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    const int w = (bid & 7) * (nblocks >> 3) + (bid >> 3);
     PoolWork k;
     k.live = w < tiles * a.b * zc;
     const int r = w / tiles;
@@ -193,7 +193,7 @@ static inline unsigned pool_grid(int nv, int b, int zc)
 __global__ __launch_bounds__(PL_THREADS) void pool_fwd_kernel(PoolArgs a, float *out, int zc)
 {
     __shared__ float tile[PL_VERTS][GEOM_WAVE + 1];
-    const PoolWork k = pool_work(a, zc);
+    const PoolWork k = pool_work(a, zc, blockIdx.x, gridDim.x);
     if (!k.live) return;
     const int mesh = k.mesh, v0 = k.v0;
     const int lane = threadIdx.x & (GEOM_WAVE - 1);
@@ -224,13 +224,19 @@ __global__ __launch_bounds__(PL_THREADS) void pool_fwd_kernel(PoolArgs a, float 
 
 // d loss / d verts: vertex-tiled like the forward (the gradient w.r.t. a vertex sums over all channels).  A workgroup owns
 // one 64-channel chunk and leaves its share of d loss / d (xs, ys) per vertex in `partial` [chunk][mesh][vertex][2];
-// pool_bwd_verts_finish_kernel adds the chunks up in chunk order (fixed: bit-reproducible) and chains the sum through the
+// pool_bwd_verts_finish_body adds the chunks up in chunk order (fixed: bit-reproducible) and chains the sum through the
 // clamp, the perspective divide and the camera matrix.
-__global__ __launch_bounds__(PL_THREADS) void pool_bwd_verts_kernel(PoolArgs a, const float *grad_out, float *partial, int zc)
+struct VertsLds {
+    float tile[PL_VERTS][GEOM_WAVE + 1];
+    float part[PL_WAVES][2][PL_VERTS];
+};
+
+__device__ __forceinline__ void pool_bwd_verts_body(const PoolArgs &a, const float *grad_out, float *partial, int zc, int bid,
+                                                    int nblocks, VertsLds &L)
 {
-    __shared__ float tile[PL_VERTS][GEOM_WAVE + 1];
-    __shared__ float part[PL_WAVES][2][PL_VERTS];
-    const PoolWork k = pool_work(a, zc);
+    auto &tile = L.tile;
+    auto &part = L.part;
+    const PoolWork k = pool_work(a, zc, bid, nblocks);
     if (!k.live) return;
     const int mesh = k.mesh, v0 = k.v0;
     const int lane = threadIdx.x & (GEOM_WAVE - 1), wave = threadIdx.x >> 6;
@@ -272,9 +278,9 @@ __global__ __launch_bounds__(PL_THREADS) void pool_bwd_verts_kernel(PoolArgs a, 
     }
 }
 
-__global__ __launch_bounds__(256) void pool_bwd_verts_finish_kernel(PoolArgs a, const float *partial, int chunks, float *grad_verts)
+__device__ __forceinline__ void pool_bwd_verts_finish_body(const PoolArgs &a, const float *partial, int chunks, float *grad_verts,
+                                                           int mesh, int v)
 {
-    const int mesh = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
     if (v >= a.nv) return;
     const Projection pr = project(a, mesh, v);
     float sx = 0.f, sy = 0.f;
@@ -301,11 +307,11 @@ __global__ __launch_bounds__(256) void pool_bwd_verts_finish_kernel(PoolArgs a, 
 // 7x7, so global fp32 atomics from 2562 vertices pile up on a few addresses (4.4 ms per call measured),
 // LDS ds_add_f32 costs ~1700 cycles per wave instruction whatever the addresses (2 ms), and wave-private
 // LDS planes with plain adds are a serial walk over the vertices (0.8 ms).  So the scatter is inverted:
-//   1. pool_bin_kernel, one workgroup per (mesh, level): counts the contributions per texel (INTEGER LDS
+//   1. the binning role (pool_bin_body), one workgroup per (mesh, level): counts the contributions per texel (INTEGER LDS
 //      atomics), scans, and fills texel -> (vertex, weight) lists in the workspace;
-//   2. pool_gather_kernel: a wave owns one texel x 64 channels, lanes <-> channels, and sums
-//      w * grad_out[b, v, c] over the texel's list -- every read is a contiguous 256-byte run of the
-//      gradient row, every output is written exactly once (nothing to zero-initialise).
+//   2. the gather role (pg_run): a workgroup owns a run of texels x up to 256 channels and sums w * grad_out[b, v, c] over
+//      the texels' lists -- every read is a contiguous run of the gradient row, every output is written exactly once
+//      (nothing to zero-initialise).
 // The order inside a list follows the atomic cursor, so the fp32 summation order can differ between runs
 // (as with torch's own index_add backward); contributions with zero weight are dropped.
 constexpr int BIN_THREADS = 256;
@@ -320,11 +326,15 @@ struct BinSpace {
     float *vert_partial; // [PL_MAX_CHUNKS][b][nv][2]
 };
 
-__global__ __launch_bounds__(BIN_THREADS) void pool_bin_kernel(PoolArgs a, BinSpace ws)
+struct BinLds {
+    int counts[BIN_MAX_TEXELS + 1];
+    int wave_sum[BIN_THREADS / GEOM_WAVE];
+};
+
+__device__ __forceinline__ void pool_bin_body(const PoolArgs &a, const BinSpace &ws, int l, int mesh, BinLds &L)
 {
-    __shared__ int counts[BIN_MAX_TEXELS + 1];
-    __shared__ int wave_sum[BIN_THREADS / GEOM_WAVE];
-    const int l = blockIdx.x, mesh = blockIdx.y;
+    auto &counts = L.counts;
+    auto &wave_sum = L.wave_sum;
     const int dim = a.dims[l], texels = dim * dim;
     for (int i = threadIdx.x; i <= texels; i += BIN_THREADS) counts[i] = 0;
     __syncthreads();
@@ -377,6 +387,25 @@ __global__ __launch_bounds__(BIN_THREADS) void pool_bin_kernel(PoolArgs a, BinSp
         if (w21 != 0.f) { const int p = atomicAdd(&counts[t.i21], 1); ev[p] = v; ew[p] = w21; }
         if (w22 != 0.f) { const int p = atomicAdd(&counts[t.i22], 1); ev[p] = v; ew[p] = w22; }
     }
+}
+
+// The backward pass is TWO launches of two roles each (the four bodies were launches of their own until round 6: at the
+// training shape the 64-workgroup binning pass and the 32-workgroup finish pass each held the whole chip for 6-8 us):
+//   1. pool_bwd_lists_kernel: the texel lists (one workgroup per mesh and map) BESIDE the vertex tiles' per-chunk sums of
+//      d loss / d (xs, ys) -- neither reads what the other writes;
+//   2. pool_bwd_grads_kernel: the map gradient from the lists BESIDE the vertex gradient from the per-chunk sums.
+static_assert(BIN_THREADS == PL_THREADS, "the two roles of a launch share its workgroup size");
+
+__global__ __launch_bounds__(PL_THREADS) void pool_bwd_lists_kernel(PoolArgs a, BinSpace ws, const float *grad_out, int zc,
+                                                                    int bin_blocks, int verts_blocks)
+{
+    __shared__ union Lds {
+        BinLds bin;
+        VertsLds verts;
+        __device__ Lds() {}
+    } lds;
+    if ((int)blockIdx.x < bin_blocks) pool_bin_body(a, ws, (int)blockIdx.x % a.levels, (int)blockIdx.x / a.levels, lds.bin);
+    else pool_bwd_verts_body(a, grad_out, ws.vert_partial, zc, (int)blockIdx.x - bin_blocks, verts_blocks, lds.verts);
 }
 
 // What this kernel has to avoid is not traffic but INSTRUCTIONS and TAILS.  The lists are short and skewed: at the training
@@ -543,14 +572,22 @@ __device__ __forceinline__ void pg_run(const PoolArgs &a, const BinSpace &ws, co
     }
 }
 
-__global__ __launch_bounds__(PL_THREADS) void pool_gather_kernel(PoolArgs a, BinSpace ws, GatherPlan p, const float *grad_out)
+// finish_z >= 0: the workgroups of that grid.z slice chain the vertex tiles' sums to grad_verts (256 vertices each); gather_tasks
+// = the runs of all maps (0: no map wants a gradient)
+__global__ __launch_bounds__(PL_THREADS) void pool_bwd_grads_kernel(PoolArgs a, BinSpace ws, GatherPlan p, const float *grad_out,
+                                                                    int gather_tasks, int finish_z, int finish_chunks,
+                                                                    float *grad_verts)
 {
     __shared__ __attribute__((aligned(16))) float tile[PG_TILE + GEOM_WAVE];
+    if ((int)blockIdx.z == finish_z) {
+        pool_bwd_verts_finish_body(a, ws.vert_partial, finish_chunks, grad_verts, blockIdx.y, (int)blockIdx.x * PL_THREADS + (int)threadIdx.x);
+        return;
+    }
     // workgroups go to the eight XCDs round robin (gridDim.x is a multiple of 8: XCD = blockIdx.x % 8): give an XCD CONSECUTIVE
     // runs -- the 2 x 2 texels a vertex touches then meet in one L2 (its gradient row is fetched from HBM once, not per XCD),
     // and so do the short runs of a small map that share a 128-byte line of the output
     const int task = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
-    if (task >= p.first_task[a.levels]) return;
+    if (task >= gather_tasks) return;
     int l = 0;
     while (l + 1 < a.levels && task >= p.first_task[l + 1]) ++l;
     const int part = blockIdx.z;
@@ -636,7 +673,7 @@ static size_t pool_ws_layout(int b, int nv, int levels, const int *dims, BinSpac
     }
     const size_t lists = (off_bytes + ent * (sizeof(int) + sizeof(float)) + 15) / 16 * 16;
     if (ws) ws->vert_partial = reinterpret_cast<float *>(static_cast<char *>(base) + lists);
-    // + the per-chunk shares of d loss / d (xs, ys) of every vertex (pool_bwd_verts_kernel)
+    // + the per-chunk shares of d loss / d (xs, ys) of every vertex (pool_bwd_verts_body)
     return lists + (size_t)PL_MAX_CHUNKS * b * nv * 2 * sizeof(float);
 }
 
@@ -686,19 +723,20 @@ extern "C" int geom_pool_features_bwd_ld_f32(int b, int nv, const float *verts, 
     BinSpace ws;
     const size_t need = pool_ws_layout(b, nv, levels, dims, &ws, workspace);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return GEOM_EINVAL;
-    if (any_map) {
-        hipLaunchKernelGGL(pool_bin_kernel, dim3(levels, b), dim3(BIN_THREADS), 0, s, a, ws);
-        GatherPlan plan;
-        gather_plan(a, plan);
-        if (plan.max_parts > 65535 || (size_t)nv * a.ld * 4 > (size_t)INT_MAX) return GEOM_ETOOBIG;
-        hipLaunchKernelGGL(pool_gather_kernel, dim3((plan.first_task[levels] + 7) / 8 * 8, b, plan.max_parts), dim3(PL_THREADS), 0, s, a, ws, plan,
-                           grad_out);
-    }
-    if (grad_verts) {
-        const int zc = a.chunks < PL_MAX_CHUNKS ? a.chunks : PL_MAX_CHUNKS;
-        hipLaunchKernelGGL(pool_bwd_verts_kernel, dim3(pool_grid(nv, b, zc)), dim3(PL_THREADS), 0, s, a, grad_out, ws.vert_partial, zc);
-        hipLaunchKernelGGL(pool_bwd_verts_finish_kernel, dim3((nv + 255) / 256, b), dim3(256), 0, s, a, ws.vert_partial, zc, grad_verts);
-    }
+    GatherPlan plan;
+    gather_plan(a, plan);
+    if (plan.max_parts > 65534 || (size_t)nv * a.ld * 4 > (size_t)INT_MAX) return GEOM_ETOOBIG;
+    const int zc = a.chunks < PL_MAX_CHUNKS ? a.chunks : PL_MAX_CHUNKS;
+    const int bin_blocks = any_map ? levels * b : 0;
+    const unsigned verts_blocks = grad_verts ? pool_grid(nv, b, zc) : 0;
+    hipLaunchKernelGGL(pool_bwd_lists_kernel, dim3(bin_blocks + verts_blocks), dim3(PL_THREADS), 0, s, a, ws, grad_out, zc, bin_blocks,
+                       (int)verts_blocks);
+    const int gather_tasks = any_map ? plan.first_task[levels] : 0;
+    const int parts = any_map ? plan.max_parts : 0;
+    int gx = (gather_tasks + 7) / 8 * 8;
+    if (grad_verts && gx < (nv + PL_THREADS - 1) / PL_THREADS) gx = ((nv + PL_THREADS - 1) / PL_THREADS + 7) / 8 * 8;
+    hipLaunchKernelGGL(pool_bwd_grads_kernel, dim3(gx, b, parts + (grad_verts ? 1 : 0)), dim3(PL_THREADS), 0, s, a, ws, plan, grad_out,
+                       gather_tasks, grad_verts ? parts : -1, zc, grad_verts);
     return geom::launch_status();
 }
 

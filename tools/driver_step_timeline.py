@@ -65,11 +65,17 @@ if n:
     fl = 2.0 * rows_ * 192 * 192
     lines.append("#   db_bwd_kernel<true> (aggregation backward + input-gradient product + BatchNorm backward, %d launches): %.1f us; the "
                  "product alone = %.1f TFLOP/s = %.2f of the fp32 MFMA peak" % (n, us, fl / us / 1e6, fl / us / 1e6 / 157.3))
-n, us = per("pool_bwd_verts_kernel")
+n, us = per("pool_bwd_lists_kernel")
 if n:
     by = maps_bytes + rows_ * 960 * 4
-    lines.append("#   pool_bwd_verts_kernel (%d launches): %.1f us for %.1f MB (the four maps + the upstream gradient, each once) = %.2f TB/s = %.2f of "
-                 "HBM -- 16 texel reads per (vertex, channel) out of L2 and a per-vertex reduction over 960 channels: the largest single item"
+    lines.append("#   pool_bwd_lists_kernel (%d launches; texel lists beside the vertex tiles' sums): %.1f us for %.1f MB (the four maps + the "
+                 "upstream gradient, each once) = %.2f TB/s = %.2f of HBM -- VALU issue and gather latency, not bytes (LAB_NOTES 12.3)"
+                 % (n, us, by / 1e6, by / us / 1e6, by / us / 1e6 / 8.0))
+n, us = per("pool_bwd_grads_kernel")
+if n:
+    by = maps_bytes + rows_ * 960 * 4
+    lines.append("#   pool_bwd_grads_kernel (%d launches; map gradient from the lists beside the vertex gradient): %.1f us for %.1f MB (the "
+                 "gradient rows in, the four maps' gradients out) = %.2f TB/s = %.2f of HBM"
                  % (n, us, by / 1e6, by / us / 1e6, by / us / 1e6 / 8.0))
 text = "\n".join(lines) + "\n"
 if len(sys.argv) > 2:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Ablation builds of csrc/pooling.hip (probe macros PG_PROBE_* / PL_PROBE_*): what the reads, the stores and the bare launch
-# of pool_gather_kernel / pool_fwd_kernel / pool_bwd_verts_kernel each cost.   usage: pg_variants.sh build | run
+# of the pooling's gather / forward / vertex-sum bodies each cost.   usage: pg_variants.sh build | run
 set -e
 cd "$(dirname "$0")/../.."
 VARIANTS=("base:" "norows:-DPG_PROBE_NO_ROWS -DPL_PROBE_NO_LOADS" "nostore:-DPG_PROBE_NO_STORE -DPL_PROBE_NO_STORE" "bare:-DPG_PROBE_BARE -DPL_PROBE_NO_LOADS -DPL_PROBE_NO_STORE")

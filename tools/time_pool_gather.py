@@ -1,4 +1,4 @@
-"""Dev helper: the map gradient of batched_pooling alone (pool_bin_kernel + pool_gather_kernel through the C-ABI, no vertex
+"""Dev helper: the map gradient of batched_pooling alone (the binning + gather roles of the two backward launches through the C-ABI, no vertex
 gradient) at the driver step's shape -- 16 meshes x 482 vertices (meshgen.uv_sphere under the bench's cameras), the four VGG
 maps, the gradient read out of a 1155-wide buffer -- and how the texel lists are distributed (entries per texel, per level)."""
 import ctypes
