@@ -16,7 +16,7 @@ FLAG_FIX_REGION6 = 2
 FLAG_TRI_BRUTE_FORCE = 4
 FLAG_NN_FMA = 8
 FLAG_TRI_WS_READY = 16
-ABI_VERSION = 11
+ABI_VERSION = 12
 EUNSUPPORTED = -3
 ADAM_MAX_TENSORS = 64
 COLSUM_MAX_JOBS = 32
@@ -131,6 +131,9 @@ _SIGNATURES = {
     "geom_stage_regularisers_bwd_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "geom_deform_layer_fwd_f32": [_vp, _vp],
     "geom_deform_pack_weights_f32": [_i, _vp, _vp, _vp, _vp],
+    "geom_deform_pack_weights_zero_f32": [_i, _vp, _vp, _vp, _vp, _i, _vp],
+    "geom_deform_chain_fwd_f32": [_i, _vp, _vp, _vp],
+    "geom_deform_chain_fits": [_i],
     "geom_deform_layer_bwd_f32": [_vp, _vp],
 }
 

@@ -63,15 +63,40 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t db_rsrc(const void *p, int64_t
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, p ? (int)bytes : 0, 0x00020000);
 }
+// AGENT: the access of a chain launch that another workgroup of the SAME launch produces / consumes (sc1: through the XCD's L2
+// to the memory side, what an agent-scope atomic compiles to -- the eight L2s do not snoop each other)
+constexpr int DB_SC1 = 16;
+template <bool AGENT = false>
 __device__ __forceinline__ float4 db_ld4(__amdgpu_buffer_rsrc_t r, unsigned off)
 {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AGENT ? DB_SC1 : 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+template <bool AGENT = false>
 __device__ __forceinline__ void db_st4(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v)
 {
     __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)},
-                                           r, off, 0, 0);
+                                           r, off, 0, AGENT ? DB_SC1 : 0);
+}
+
+// ---- the layers of a block as ONE launch (db_fwd_chain_kernel): a vertex's workgroup runs layer after layer and waits, in front
+// of a layer's gathers, until the workgroups of its NEIGHBOURS have published the previous layer's support rows -- the only
+// cross-tile dependency of a layer (see the top of the file).  done[v * DB_CTR_STRIDE] = layers vertex v has published (a
+// 128-byte line each: pollers and publishers of different vertices never share one); zero on entry (the weight-packing launch of
+// the step zeroes it).  Every workgroup of the launch must be resident at once (the host checks; otherwise separate launches).
+constexpr int DB_CTR_STRIDE = 32;
+constexpr int DB_SPIN_LIMIT = 1 << 22; // polls before a wait gives up (seconds): the layer's outputs are then NaN, loudly
+
+// wave-wide wait: lane's `target` vertex (< 0: none) has published `need` layers.  false: gave up.
+__device__ __forceinline__ bool db_wait_published(const int *done, int target, int need)
+{
+    bool ok = target < 0;
+    for (int polls = 0;; ++polls) {
+        if (!ok) ok = __hip_atomic_load(done + (size_t)target * DB_CTR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+        if (__all(ok)) return true;
+        if (polls > DB_SPIN_LIMIT) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
 }
 
 // workgroup w -> vertex: contiguous vertex runs per XCD (workgroup w runs on XCD w % 8; a support row is gathered by its ~7
@@ -162,9 +187,16 @@ struct DbPackArgs {
     const float *w[GEOM_DEFORM_MAX_PACK];
     float *fwd, *bwd;
     int count;
+    int *zero;      // optional: words to clear (the chain launches' counters), by the workgroups behind the packing ones
+    int zero_words, pack_blocks;
 };
 __global__ __launch_bounds__(256) void db_pack_kernel(DbPackArgs a)
 {
+    if ((int)blockIdx.x >= a.pack_blocks) {
+        const int i = ((int)blockIdx.x - a.pack_blocks) * 256 + (int)threadIdx.x;
+        if (i < a.zero_words) a.zero[i] = 0;
+        return;
+    }
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int m = idx / (DB_C * DB_C), r = idx - m * (DB_C * DB_C);
     const int layer = m >> 1, dir = m & 1;
@@ -188,32 +220,62 @@ __global__ __launch_bounds__(256) void db_pack_kernel(DbPackArgs a)
 // scalar loads, so a pole's extra neighbour rows are requested TOGETHER with its table rows: the launch ends with its slowest
 // workgroup, and a pole that walked its tail eight entries per dependent round trip took 3 x the time of every other vertex
 // (26 000 cycles in the gather phase against 8 500: tools/probe/db_stamps.py).
-template <bool SLICE>
-__device__ __forceinline__ float4 db_aggregate(__amdgpu_buffer_rsrc_t r_src, bool mesh_on, unsigned rowbase, int v, int c0,
-                                               const int *ell_col, const float *ell_val, const int *tail_col, const float *tail_val,
-                                               float4 *own, DbSlice &bw, const float *packed, int wave, int lane)
+// a vertex's row of the neighbour table + its tail row (round trip 1 of a layer: scalar loads -- the same for every thread of
+// the workgroup -- and ONE vector load of the tail row); a chain launch fetches it once for all its layers
+struct DbTable {
+    int nb[DB_W];
+    float wv[DB_W];
+    int tcol;
+    float tval;
+    bool has_tail;
+};
+__device__ __forceinline__ DbTable db_table(int v, const int *ell_col, const float *ell_val, const int *tail_col, const float *tail_val,
+                                            int lane)
 {
-    // round trip 1: the vertex's table entries (scalar loads: the same for every thread of the workgroup) + its tail row
-    int tcol = -1;
-    float tval = 0.f;
+    DbTable t;
+    t.tcol = -1, t.tval = 0.f;
     if (tail_col) {
-        tcol = tail_col[(size_t)v * DB_TAIL + (lane & (DB_TAIL - 1))];
-        tval = tail_val[(size_t)v * DB_TAIL + (lane & (DB_TAIL - 1))];
+        t.tcol = tail_col[(size_t)v * DB_TAIL + (lane & (DB_TAIL - 1))];
+        t.tval = tail_val[(size_t)v * DB_TAIL + (lane & (DB_TAIL - 1))];
     }
     const int4 ci0 = *reinterpret_cast<const int4 *>(ell_col + (size_t)v * DB_W), ci1 = *reinterpret_cast<const int4 *>(ell_col + (size_t)v * DB_W + 4);
     const float4 wi0 = *reinterpret_cast<const float4 *>(ell_val + (size_t)v * DB_W), wi1 = *reinterpret_cast<const float4 *>(ell_val + (size_t)v * DB_W + 4);
-    const int nb[DB_W] = {ci0.x, ci0.y, ci0.z, ci0.w, ci1.x, ci1.y, ci1.z, ci1.w};
-    const float wv[DB_W] = {wi0.x, wi0.y, wi0.z, wi0.w, wi1.x, wi1.y, wi1.z, wi1.w};
+    t.nb[0] = ci0.x, t.nb[1] = ci0.y, t.nb[2] = ci0.z, t.nb[3] = ci0.w, t.nb[4] = ci1.x, t.nb[5] = ci1.y, t.nb[6] = ci1.z, t.nb[7] = ci1.w;
+    t.wv[0] = wi0.x, t.wv[1] = wi0.y, t.wv[2] = wi0.z, t.wv[3] = wi0.w, t.wv[4] = wi1.x, t.wv[5] = wi1.y, t.wv[6] = wi1.z, t.wv[7] = wi1.w;
+    t.has_tail = tail_col != nullptr;
+    return t;
+}
+
+// CHAIN (need > 0): the rows are another workgroup's output of the same launch -- wait until the neighbours have published
+// `need` layers (ok = false: the wait gave up), read with agent-scope loads.
+template <bool SLICE, bool CHAIN = false>
+__device__ __forceinline__ float4 db_aggregate(__amdgpu_buffer_rsrc_t r_src, bool mesh_on, unsigned rowbase, int v, int c0,
+                                               const DbTable &tb, float4 *own, DbSlice &bw, const float *packed, int wave, int lane,
+                                               const int *done = nullptr, int need = 0, bool *ok = nullptr)
+{
+    const int (&nb)[DB_W] = tb.nb;
+    const float (&wv)[DB_W] = tb.wv;
+    const int tcol = tb.tcol;
+    const float tval = tb.tval;
+    if (CHAIN && need > 0) { // lanes 0..7: the table's neighbours; lanes 8..39: the tail row's
+        int target = -1;
+#pragma unroll
+        for (int n = 0; n < DB_W; ++n) target = lane == n ? nb[n] : target;
+        const int from_tail = __shfl(tcol, (lane - DB_W) & (GEOM_WAVE - 1), GEOM_WAVE);
+        if (lane >= DB_W && lane < DB_W + DB_TAIL) target = from_tail;
+        const bool there = db_wait_published(done, target, need);
+        if (!there) *ok = false;
+    }
     // round trip 2: the neighbour rows + the thread's own pass-through elements
     float4 sv[DB_W];
 #pragma unroll
     for (int n = 0; n < DB_W; ++n) {
         const unsigned off = rowbase + (unsigned)(nb[n] >= 0 ? nb[n] : v) * (DB_C * 4) + 4 * c0;
-        sv[n] = db_ld4(r_src, mesh_on ? off : DB_OOB);
+        sv[n] = db_ld4<CHAIN>(r_src, mesh_on ? off : DB_OOB);
     }
     const unsigned own_off = rowbase + (unsigned)v * (DB_C * 4) + 4 * c0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) own[i] = db_ld4(r_src, mesh_on ? own_off + 4 * DB_K * (i + 1) : DB_OOB);
+    for (int i = 0; i < 2; ++i) own[i] = db_ld4<CHAIN>(r_src, mesh_on ? own_off + 4 * DB_K * (i + 1) : DB_OOB);
     float4 facc = make_float4(0.f, 0.f, 0.f, 0.f);
     auto table_terms = [&]() {
 #pragma unroll
@@ -224,7 +286,7 @@ __device__ __forceinline__ float4 db_aggregate(__amdgpu_buffer_rsrc_t r_src, boo
         }
     };
     __builtin_amdgcn_sched_barrier(0);
-    const bool has_tail = tail_col && __builtin_amdgcn_readfirstlane(tcol) >= 0; // (uniform: entry 0 of the tail row)
+    const bool has_tail = tb.has_tail && __builtin_amdgcn_readfirstlane(tcol) >= 0; // (uniform: entry 0 of the tail row)
     if (!has_tail) { // every vertex of an icosphere, all but the two poles of 482.obj
         if (SLICE) db_load_slice(bw, packed, wave, lane); // behind the gathers (in-order memory counter: see the callers)
         __builtin_amdgcn_sched_barrier(0);
@@ -236,7 +298,7 @@ __device__ __forceinline__ float4 db_aggregate(__amdgpu_buffer_rsrc_t r_src, boo
 #pragma unroll
     for (int n = 0; n < DB_TAIL; ++n) {
         const int col = __builtin_amdgcn_readlane(tcol, n);
-        tv[n] = db_ld4(r_src, (mesh_on && col >= 0) ? rowbase + (unsigned)col * (DB_C * 4) + 4 * c0 : DB_OOB);
+        tv[n] = db_ld4<CHAIN>(r_src, (mesh_on && col >= 0) ? rowbase + (unsigned)col * (DB_C * 4) + 4 * c0 : DB_OOB);
     }
     table_terms(); // summation order: the table's slots, then the tail, in CSR order
 #pragma unroll
@@ -261,12 +323,12 @@ __device__ __forceinline__ void db_to_panel(float *panel, int rl, int c0, const 
     }
 }
 
-template <bool PRODUCT>
-__global__ __launch_bounds__(DB_THREADS, 2) void db_fwd_kernel(geom_deform_fwd a)
+// One layer of vertex v.  CHAIN: layer `layer` (0-based) of a chain launch -- layer > 0 reads the previous layer's support
+// rows from the neighbours' workgroups (wait + agent-scope loads), a layer with a product publishes its rows.
+template <bool PRODUCT, bool CHAIN>
+__device__ __forceinline__ void db_fwd_body(const geom_deform_fwd &a, const int v, float *lds, int *done, const int layer,
+                                            const DbTable *table)
 {
-    __shared__ __attribute__((aligned(16))) float lds[DB_PANEL + DB_CST + DB_RED];
-    const int v = db_vertex(blockIdx.x, a.vpx, a.nv);
-    if (v < 0) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int x = lane & 15, g = lane >> 4; // matrix-core coordinates
     const int rl = tid >> 4, j = tid & 15;  // batch row (mesh) and float4 group of the gather / BatchNorm thread
@@ -298,7 +360,14 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_fwd_kernel(geom_deform_fwd a
     // have a counter of their own); in this order the statistics run while the slice is still on its way.
     DbSlice bw;
     float4 z[3];
-    z[0] = db_aggregate<PRODUCT>(r_src, mesh_on, rowbase, v, c0, a.ell_col, a.ell_val, a.tail_col, a.tail_val, &z[1], bw, a.w_next, wave, lane);
+    bool arrived = true; // (a chain launch: the neighbours' rows were published in time)
+    if (CHAIN) {
+        z[0] = db_aggregate<PRODUCT, true>(r_src, mesh_on, rowbase, v, c0, *table, &z[1], bw, a.w_next, wave, lane, done, layer, &arrived);
+    } else {
+        const DbTable tb = db_table(v, a.ell_col, a.ell_val, a.tail_col, a.tail_val, lane);
+        z[0] = db_aggregate<PRODUCT, false>(r_src, mesh_on, rowbase, v, c0, tb, &z[1], bw, a.w_next, wave, lane);
+    }
+    if (CHAIN && !arrived) z[0].x = __builtin_nanf(""); // poisons the vertex's statistics: every output of the layer is NaN
 #pragma unroll
     for (int i = 0; i < 3; ++i) z[i].x += bias4[i].x, z[i].y += bias4[i].y, z[i].z += bias4[i].z, z[i].w += bias4[i].w;
 
@@ -396,9 +465,42 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_fwd_kernel(geom_deform_fwd a
         const int idx = tid + DB_THREADS * t, r = idx / 48, c4 = idx % 48;
         const f32x4 val = *reinterpret_cast<const f32x4 *>(stage + r * DB_LDC + 4 * c4);
         const unsigned off = r < a.b ? ((unsigned)r * (unsigned)a.nv + (unsigned)v) * (DB_C * 4) + 16u * c4 : DB_OOB;
-        db_st4(r_s, off, make_float4(val[0], val[1], val[2], val[3]));
+        db_st4<CHAIN>(r_s, off, make_float4(val[0], val[1], val[2], val[3]));
     }
     DB_STAMP(8);
+    if (CHAIN) { // publish: every wave's stores are acknowledged (written through), then the vertex's count moves
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done + (size_t)v * DB_CTR_STRIDE, layer + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <bool PRODUCT>
+__global__ __launch_bounds__(DB_THREADS, 2) void db_fwd_kernel(geom_deform_fwd a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[DB_PANEL + DB_CST + DB_RED];
+    const int v = db_vertex(blockIdx.x, a.vpx, a.nv);
+    if (v < 0) return;
+    db_fwd_body<PRODUCT, false>(a, v, lds, nullptr, 0, nullptr);
+}
+
+struct DbFwdChain {
+    geom_deform_fwd layer[GEOM_DEFORM_CHAIN_MAX];
+    int count;
+    int *done;
+};
+
+__global__ __launch_bounds__(DB_THREADS, 2) void db_fwd_chain_kernel(DbFwdChain c)
+{
+    __shared__ __attribute__((aligned(16))) float lds[DB_PANEL + DB_CST + DB_RED];
+    const int v = db_vertex(blockIdx.x, c.layer[0].vpx, c.layer[0].nv);
+    if (v < 0) return;
+    const DbTable tb = db_table(v, c.layer[0].ell_col, c.layer[0].ell_val, c.layer[0].tail_col, c.layer[0].tail_val, threadIdx.x & 63);
+    for (int l = 0; l < c.count; ++l) {
+        if (c.layer[l].w_next) db_fwd_body<true, true>(c.layer[l], v, lds, c.done, l, &tb);
+        else db_fwd_body<false, true>(c.layer[l], v, lds, c.done, l, &tb);
+        __syncthreads(); // (the layer's LDS is free again)
+    }
 }
 
 template <bool PRODUCT>
@@ -481,7 +583,8 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_kernel(geom_deform_bwd a
         const __amdgpu_buffer_rsrc_t r_src = db_rsrc(a.dz_up, op_bytes), r_ds = db_rsrc(a.ds_up, op_bytes);
         float4 gs[3];
         DbSlice bw;
-        gs[0] = db_aggregate<true>(r_src, mesh_on, rowbase, v, c0, a.ell_col_t, a.ell_val_t, a.tail_col_t, a.tail_val_t, &gs[1], bw, a.wt_up, wave, lane);
+        const DbTable tb = db_table(v, a.ell_col_t, a.ell_val_t, a.tail_col_t, a.tail_val_t, lane);
+        gs[0] = db_aggregate<true>(r_src, mesh_on, rowbase, v, c0, tb, &gs[1], bw, a.wt_up, wave, lane);
 #pragma unroll
         for (int i = 0; i < 3; ++i) db_st4(r_ds, at(i), gs[i]); // the layer above's weight gradient reads it (X^T . G)
         db_to_panel(lds, rl, c0, gs);                           // (rows beyond the batch read zeros: zero rows of the tile)
@@ -637,9 +740,17 @@ extern "C" int geom_deform_layer_bwd_f32(const geom_deform_bwd *args, void *stre
 // device pointers to [192,192] row-major matrices.  One launch for all layers of a block, once per step.
 extern "C" int geom_deform_pack_weights_f32(int count, const float *const *w, float *fwd, float *bwd, void *stream)
 {
-    if (count < 0 || count > GEOM_DEFORM_MAX_PACK) return GEOM_EINVAL;
-    if (count == 0 || (!fwd && !bwd)) return 0;
-    if (!w || !db_aligned16(fwd) || !db_aligned16(bwd)) return GEOM_EINVAL;
+    return geom_deform_pack_weights_zero_f32(count, w, fwd, bwd, nullptr, 0, stream);
+}
+
+// ... and `zero_words` 4-byte words at `zero` cleared by the same launch (the counters of the step's chain launches)
+extern "C" int geom_deform_pack_weights_zero_f32(int count, const float *const *w, float *fwd, float *bwd, int *zero, int zero_words,
+                                                 void *stream)
+{
+    if (count < 0 || count > GEOM_DEFORM_MAX_PACK || zero_words < 0 || (zero_words > 0 && !zero)) return GEOM_EINVAL;
+    if (count == 0 || (!fwd && !bwd)) count = 0;
+    if (count == 0 && zero_words == 0) return 0;
+    if (count && (!w || !db_aligned16(fwd) || !db_aligned16(bwd))) return GEOM_EINVAL;
     DbPackArgs a{};
     for (int i = 0; i < count; ++i) {
         if (!w[i] || ((uintptr_t)w[i] & 3)) return GEOM_EINVAL;
@@ -647,6 +758,63 @@ extern "C" int geom_deform_pack_weights_f32(int count, const float *const *w, fl
     }
     a.fwd = fwd, a.bwd = bwd, a.count = count;
     const int total = count * 2 * DB_C * DB_C;
-    hipLaunchKernelGGL(db_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    a.pack_blocks = (total + 255) / 256, a.zero = zero, a.zero_words = zero_words;
+    hipLaunchKernelGGL(db_pack_kernel, dim3(a.pack_blocks + (zero_words + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return geom::launch_status();
+}
+
+// Whether a chain launch over nv vertices can run on the current device: every workgroup must be resident at once (a
+// workgroup waits for its neighbours' INSIDE the launch).
+extern "C" int geom_deform_chain_fits(int nv)
+{
+    if (nv <= 0) return 0;
+    static int slots[64] = {0}; // per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!slots[dev]) {
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, db_fwd_chain_kernel, DB_THREADS, 0) != hipSuccess ||
+            hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return 0;
+        slots[dev] = per_cu * prop.multiProcessorCount > 0 ? per_cu * prop.multiProcessorCount : -1;
+    }
+    return slots[dev] >= 8 * ((nv + 7) / 8);
+}
+
+// `count` consecutive layers (layers[l + 1].s_in == layers[l].s_out, all but possibly the last with a product) in ONE launch;
+// results = those of `count` geom_deform_layer_fwd_f32 calls, bit for bit.  done: nv * 32 ints, ZERO on entry
+// (geom_deform_pack_weights_zero_f32 of the same step), 128-byte aligned.  GEOM_EUNSUPPORTED when the launch does not fit the
+// device (geom_deform_chain_fits) -- the caller issues the layers one by one.
+extern "C" int geom_deform_chain_fwd_f32(int count, const geom_deform_fwd *layers, int *done, void *stream)
+{
+    if (count <= 0 || count > GEOM_DEFORM_CHAIN_MAX || !layers || !done || ((uintptr_t)done & 127)) return GEOM_EINVAL;
+    DbFwdChain c{};
+    for (int l = 0; l < count; ++l) {
+        geom_deform_fwd a = layers[l];
+        const int code = db_check_shape(a.b, a.nv, a.c, a.k, a.ell_w);
+        if (code) return code;
+        if (a.b != layers[0].b || a.nv != layers[0].nv || a.ell_col != layers[0].ell_col || a.ell_val != layers[0].ell_val ||
+            a.tail_col != layers[0].tail_col || a.tail_val != layers[0].tail_val)
+            return GEOM_EINVAL;
+        if (!a.s_in || !a.ell_col || !a.ell_val || !a.x_out) return GEOM_EINVAL;
+        if (a.training ? (!a.save_mean || !a.save_invstd) : (!a.run_mean || !a.run_var)) return GEOM_EINVAL;
+        if (a.w_next ? !a.s_out : l + 1 < count) return GEOM_EINVAL;                 // only the last layer may lack a product
+        if (l > 0 && a.s_in != layers[l - 1].s_out) return GEOM_EINVAL;              // a chain
+        if (l > 1 && a.s_out && a.s_out == layers[l - 1].s_out) return GEOM_EINVAL; // (ping-pong at least)
+        if ((a.w_head != nullptr) != (a.s_head != nullptr) || (a.w_head && a.w_next)) return GEOM_EINVAL;
+        if (a.tail_col && !a.tail_val) return GEOM_EINVAL;
+        if (a.res && a.res_ld < DB_C) return GEOM_EINVAL;
+        if (!db_aligned16(a.s_in) || !db_aligned16(a.ell_col) || !db_aligned16(a.ell_val) || !db_aligned16(a.x_out) || !db_aligned16(a.z_out) ||
+            !db_aligned16(a.s_out) || !db_aligned16(a.bias) || ((uintptr_t)a.res & 3) || !db_aligned16(a.w_next))
+            return GEOM_EINVAL;
+        if (!a.res) a.scale = 1.f;
+        a.vpx = (a.nv + 7) / 8;
+        c.layer[l] = a;
+    }
+    if (layers[0].b == 0 || layers[0].nv == 0) return 0;
+    if (!geom_deform_chain_fits(layers[0].nv)) return GEOM_EUNSUPPORTED;
+    c.count = count, c.done = done;
+    hipLaunchKernelGGL(db_fwd_chain_kernel, dim3(8 * c.layer[0].vpx), dim3(DB_THREADS), 0, static_cast<hipStream_t>(stream), c);
     return geom::launch_status();
 }

@@ -87,9 +87,10 @@ def _tail_tables(csr):
     return csr._deform_tail
 
 
-def pack_weights(weights):
+def pack_weights(weights, zero=None):
     """(fwd, bwd) [len(weights), 36864] each: every [192,192] weight (and its transpose) in the order a wave of the layer
-    launches keeps its slice in registers -- ONE launch for all layers of a block (geom_deform_pack_weights_f32)."""
+    launches keeps its slice in registers -- ONE launch for all layers of a block (geom_deform_pack_weights_zero_f32).
+    zero (optional int32 tensor): cleared by the same launch (the chain launches' counters)."""
     n = len(weights)
     w2 = [w.reshape(192, 192) if w.is_contiguous() else w.reshape(192, 192).contiguous() for w in weights]
     dev = w2[0].device
@@ -97,22 +98,48 @@ def pack_weights(weights):
     bwd = torch.empty(n, 192 * 192, dtype=torch.float32, device=dev)
     ptrs = (ctypes.c_void_p * n)(*[w.data_ptr() for w in w2])
     with torch.cuda.device(dev):
-        _lib.call("geom_deform_pack_weights_f32", n, ptrs, fwd.data_ptr(), bwd.data_ptr())
+        _lib.call("geom_deform_pack_weights_zero_f32", n, ptrs, fwd.data_ptr(), bwd.data_ptr(), _p(zero),
+                  0 if zero is None else zero.numel())
     return fwd, bwd
 
 
-def layer_forward(s_in, bias, csr, bn_w, bn_b, run_mean, run_var, training, momentum, eps, relu, res, scale, z_out, x_out,
+# The hidden layers of a block as ONE launch per direction (geom_deform_chain_fwd_f32: a vertex's workgroup waits for its
+# neighbours' rows inside the launch) where every workgroup of the launch is resident at once; False: one launch per layer.
+chain = True
+CTR_STRIDE = 32      # ints per vertex counter (one 128-byte line each)
+
+
+def chain_fits(nv, device):
+    if not chain:
+        return False
+    with torch.cuda.device(device):
+        return bool(_lib.lib().geom_deform_chain_fits(int(nv)))
+
+
+def _forward_args(s_in, bias, csr, bn_w, bn_b, run_mean, run_var, training, momentum, eps, relu, res, scale, z_out, x_out,
                   save_mean, save_invstd, w_next=None, s_out=None, w_head=None, s_head=None):
-    """One forward launch (geom_deform_layer_fwd_f32); w_next = the next layer's weight PACKED (pack_weights()[0][l]); see
-    include/geom_hip.h for the operands."""
     b, nv, c = s_in.shape
     tail = _tail_tables(csr)
-    a = _lib.DeformFwd(b, nv, c, 64, csr.ell_w, _p(s_in), _p(bias), _p(csr.ell_col), _p(csr.ell_val), _p(tail[0]), _p(tail[1]),
-                       _p(bn_w), _p(bn_b), _p(run_mean), _p(run_var), int(training), float(momentum), float(eps),
-                       int(relu), _p(res), res.stride(1) if res is not None else 0, float(scale), _p(z_out), _p(x_out),
-                       _p(save_mean), _p(save_invstd), _p(w_next), _p(s_out), _p(w_head), _p(s_head), 0)
+    return _lib.DeformFwd(b, nv, c, 64, csr.ell_w, _p(s_in), _p(bias), _p(csr.ell_col), _p(csr.ell_val), _p(tail[0]), _p(tail[1]),
+                          _p(bn_w), _p(bn_b), _p(run_mean), _p(run_var), int(training), float(momentum), float(eps),
+                          int(relu), _p(res), res.stride(1) if res is not None else 0, float(scale), _p(z_out), _p(x_out),
+                          _p(save_mean), _p(save_invstd), _p(w_next), _p(s_out), _p(w_head), _p(s_head), 0)
+
+
+def layer_forward(s_in, *args, **kwargs):
+    """One forward launch (geom_deform_layer_fwd_f32); w_next = the next layer's weight PACKED (pack_weights()[0][l]); see
+    include/geom_hip.h for the operands."""
+    a = _forward_args(s_in, *args, **kwargs)
     with torch.cuda.device(s_in.device):
         _lib.call("geom_deform_layer_fwd_f32", ctypes.addressof(a))
+
+
+def chain_forward(layers, done, device):
+    """`layers` (lists of layer_forward's arguments) as ONE launch (geom_deform_chain_fwd_f32); done: int32 [nv * CTR_STRIDE],
+    zero."""
+    structs = (_lib.DeformFwd * len(layers))(*[_forward_args(*a, **k) for a, k in layers])
+    with torch.cuda.device(device):
+        _lib.call("geom_deform_chain_fwd_f32", len(layers), ctypes.addressof(structs), done.data_ptr())
 
 
 def _rows192(t, shape):
@@ -169,7 +196,11 @@ class _HiddenChain(torch.autograd.Function):
         means, invstds = torch.empty(L, nv, **f32), torch.empty(L, nv, **f32)
         s_buf = (torch.empty(b, nv, c, **f32), torch.empty(b, nv, c, **f32))
         s_cur = s1
-        w2, wts = pack_weights(weights)               # w2[i - 1] / wts[i - 1] = W_{i+1} / its transpose, in register-slice order
+        as_chain = chain_fits(nv, dev)
+        # (counters of the forward and of the backward chain launch, cleared by the packing launch)
+        counters = torch.empty(2, nv * CTR_STRIDE, dtype=torch.int32, device=dev) if as_chain else None
+        w2, wts = pack_weights(weights, counters)     # w2[i - 1] / wts[i - 1] = W_{i+1} / its transpose, in register-slice order
+        calls = []
         for i in range(1, L + 1):
             src = RESIDUALS.get(i)
             res = None if src is None else (lead if src == "lead" else xs[src - 2])
@@ -179,11 +210,17 @@ class _HiddenChain(torch.autograd.Function):
                 wh = w_head.reshape(c, 3)
                 wh = wh if wh.is_contiguous() else wh.contiguous()
                 s_head = torch.empty(b, nv, 3, **f32)
-            layer_forward(s_cur, biases[i - 1], csr, bn_w[i - 1], bn_b[i - 1], stats[i - 1][0], stats[i - 1][1], True, momentum, eps,
-                          relu, res, 0.5, zs[i - 1], xs[i - 1], means[i - 1], invstds[i - 1],
-                          w_next=w2[i - 1] if nxt else None, s_out=s_buf[i & 1] if nxt else None,
-                          w_head=wh if head else None, s_head=s_head if head else None)
+            call = ((s_cur, biases[i - 1], csr, bn_w[i - 1], bn_b[i - 1], stats[i - 1][0], stats[i - 1][1], True, momentum, eps,
+                     relu, res, 0.5, zs[i - 1], xs[i - 1], means[i - 1], invstds[i - 1]),
+                    dict(w_next=w2[i - 1] if nxt else None, s_out=s_buf[i & 1] if nxt else None,
+                         w_head=wh if head else None, s_head=s_head if head else None))
+            if as_chain:
+                calls.append(call)
+            else:
+                layer_forward(*call[0], **call[1])
             s_cur = s_buf[i & 1]
+        if as_chain:
+            chain_forward(calls, counters[0], dev)
         ctx.csr, ctx.relu, ctx.head = csr, relu, w_head is not None
         ctx.head_shape = None if w_head is None else tuple(w_head.shape)
         ctx.set_materialize_grads(False)      # a handle nobody uses (the last block's features) arrives as None, not as 5.9 MB of zeros

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GEOM_ABI_VERSION 11
+#define GEOM_ABI_VERSION 12
 
 /* argument errors */
 #define GEOM_EINVAL   (-1) /* bad size / null pointer */
@@ -424,6 +424,20 @@ typedef struct geom_deform_bwd {
                                                                  * x_top^T . ds_head (x_top [b,nv,192]: the layer's output) */
     int vpx;
 } geom_deform_bwd;
+/* The hidden layers of a block as ONE launch: `count` <= GEOM_DEFORM_CHAIN_MAX consecutive geom_deform_layer_fwd_f32 layers
+ * (layers[l + 1].s_in == layers[l].s_out; only the last may lack a product), HOST array of their argument structs; results
+ * bit for bit those of the separate calls.  A vertex's workgroup runs layer after layer and waits, in front of a layer's
+ * gathers, for the workgroups of its neighbours to publish the previous layer's rows (the only cross-tile dependency of a
+ * layer: models.py:237-297 + layers.py:107-116) -- twelve kernel boundaries less per block and direction.
+ * done: nv * 32 ints of device scratch, 128-byte aligned, ZERO on entry (geom_deform_pack_weights_zero_f32 clears it in
+ * the step's packing launch).  Needs every workgroup of the launch resident at once: geom_deform_chain_fits(nv) != 0,
+ * otherwise GEOM_EUNSUPPORTED (issue the layers one by one).  A wait that gives up (seconds) turns the layer's outputs
+ * into NaN. */
+#define GEOM_DEFORM_CHAIN_MAX 13
+int geom_deform_chain_fits(int nv);
+int geom_deform_chain_fwd_f32(int count, const geom_deform_fwd *layers, int *done, void *stream);
+int geom_deform_pack_weights_zero_f32(int count, const float *const *w, float *fwd, float *bwd, int *zero, int zero_words,
+                                      void *stream);
 /* EXPERIMENT (csrc/dense_split_bf16.hip; on no default route): c [m, 192] = a [m, k] . w [k, 192] on the BF16 matrix cores with
  * exact fp32 products -- every fp32 operand is the exact sum of three bf16 numbers, the products a_i b_j are exact in fp32,
  * terms = 6 keeps those with i + j <= 2 (the rest is below 2^-24 of |a b|), 9 keeps all; fp32 accumulation, the leading
