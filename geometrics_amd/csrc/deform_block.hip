@@ -503,12 +503,12 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_fwd_chain_kernel(DbFwdChain 
     }
 }
 
-template <bool PRODUCT>
-__global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_kernel(geom_deform_bwd a)
+// One backward layer of vertex v.  CHAIN: step `step` of a chain launch (0 = the top layer) -- a step > 0 gathers the dZ rows
+// the neighbours' workgroups wrote in the step before (wait + agent-scope loads); every step publishes its dZ rows.
+template <bool PRODUCT, bool CHAIN>
+__device__ __forceinline__ void db_bwd_body(const geom_deform_bwd &a, const int v, float *lds, int *done, const int step,
+                                            const DbTable *table)
 {
-    __shared__ __attribute__((aligned(16))) float lds[DB_PANEL + DB_CST + DB_RED];
-    const int v = db_vertex(blockIdx.x, a.vpx, a.nv);
-    if (v < 0) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int x = lane & 15, g = lane >> 4;
     const int rl = tid >> 4, j = tid & 15;
@@ -583,8 +583,14 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_kernel(geom_deform_bwd a
         const __amdgpu_buffer_rsrc_t r_src = db_rsrc(a.dz_up, op_bytes), r_ds = db_rsrc(a.ds_up, op_bytes);
         float4 gs[3];
         DbSlice bw;
-        const DbTable tb = db_table(v, a.ell_col_t, a.ell_val_t, a.tail_col_t, a.tail_val_t, lane);
-        gs[0] = db_aggregate<true>(r_src, mesh_on, rowbase, v, c0, tb, &gs[1], bw, a.wt_up, wave, lane);
+        if (CHAIN) {
+            bool arrived = true;
+            gs[0] = db_aggregate<true, true>(r_src, mesh_on, rowbase, v, c0, *table, &gs[1], bw, a.wt_up, wave, lane, done, step, &arrived);
+            if (!arrived) gs[0].x = __builtin_nanf(""); // (the wait gave up: the layer's gradients are NaN, loudly)
+        } else {
+            const DbTable tb = db_table(v, a.ell_col_t, a.ell_val_t, a.tail_col_t, a.tail_val_t, lane);
+            gs[0] = db_aggregate<true, false>(r_src, mesh_on, rowbase, v, c0, tb, &gs[1], bw, a.wt_up, wave, lane);
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) db_st4(r_ds, at(i), gs[i]); // the layer above's weight gradient reads it (X^T . G)
         db_to_panel(lds, rl, c0, gs);                           // (rows beyond the batch read zeros: zero rows of the tile)
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_kernel(geom_deform_bwd a
         dz[i] = make_float4(kk * (go[i].x - mg - xh[i].x * mgx), kk * (go[i].y - mg - xh[i].y * mgx),
                             kk * (go[i].z - mg - xh[i].z * mgx), kk * (go[i].w - mg - xh[i].w * mgx));
         if (!mesh_on) dz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        db_st4(r_dz, at(i), dz[i]);
+        db_st4<CHAIN>(r_dz, at(i), dz[i]);
     }
     // ---- bias gradient of this layer: the vertex's column sums of dZ over its meshes, in mesh order (lanes 16 apart hold the
     // wave's four meshes, the four waves' sums through LDS); the host adds the vertices up
@@ -662,6 +668,40 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_kernel(geom_deform_bwd a
         if (tid < DB_C) a.colsum[(size_t)v * DB_C + tid] = ((stage[tid] + stage[DB_C + tid]) + stage[2 * DB_C + tid]) + stage[3 * DB_C + tid];
     }
     DB_STAMP(8);
+    if (CHAIN) { // publish the vertex's dZ rows (every wave's stores acknowledged first)
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done + (size_t)v * DB_CTR_STRIDE, step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <bool PRODUCT>
+__global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_kernel(geom_deform_bwd a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[DB_PANEL + DB_CST + DB_RED];
+    const int v = db_vertex(blockIdx.x, a.vpx, a.nv);
+    if (v < 0) return;
+    db_bwd_body<PRODUCT, false>(a, v, lds, nullptr, 0, nullptr);
+}
+
+struct DbBwdChain {
+    geom_deform_bwd layer[GEOM_DEFORM_CHAIN_MAX]; // in execution order: the top layer first
+    int count;
+    int *done;
+};
+
+__global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_chain_kernel(DbBwdChain c)
+{
+    __shared__ __attribute__((aligned(16))) float lds[DB_PANEL + DB_CST + DB_RED];
+    const int v = db_vertex(blockIdx.x, c.layer[0].vpx, c.layer[0].nv);
+    if (v < 0) return;
+    const geom_deform_bwd &t = c.layer[c.count > 1 ? 1 : 0]; // (the top layer may come without tables)
+    const DbTable tb = db_table(v, t.ell_col_t, t.ell_val_t, t.tail_col_t, t.tail_val_t, threadIdx.x & 63);
+    for (int l = 0; l < c.count; ++l) {
+        if (c.layer[l].dz_up) db_bwd_body<true, true>(c.layer[l], v, lds, c.done, l, &tb);
+        else db_bwd_body<false, true>(c.layer[l], v, lds, c.done, l, &tb);
+        __syncthreads();
+    }
 }
 
 inline bool db_aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
@@ -735,6 +775,47 @@ extern "C" int geom_deform_layer_bwd_f32(const geom_deform_bwd *args, void *stre
     return geom::launch_status();
 }
 
+// `count` backward layers in execution order (layers[0] = the top layer, read from memory: dz_up == NULL; layers[t].dz_up ==
+// layers[t - 1].dz for t >= 1) in ONE launch; results = those of the separate geom_deform_layer_bwd_f32 calls, bit for bit.
+// done: as for geom_deform_chain_fwd_f32 (its own nv * 32 zeroed ints).
+extern "C" int geom_deform_chain_bwd_f32(int count, const geom_deform_bwd *layers, int *done, void *stream)
+{
+    if (count <= 0 || count > GEOM_DEFORM_CHAIN_MAX || !layers || !done || ((uintptr_t)done & 127)) return GEOM_EINVAL;
+    DbBwdChain c{};
+    for (int l = 0; l < count; ++l) {
+        geom_deform_bwd a = layers[l];
+        const int code = db_check_shape(a.b, a.nv, a.c, a.k, a.ell_w);
+        if (code) return code;
+        if (a.b != layers[0].b || a.nv != layers[0].nv) return GEOM_EINVAL;
+        if (!a.z || !a.save_mean || !a.save_invstd || !a.dz) return GEOM_EINVAL;
+        const bool product = a.dz_up != nullptr;
+        if (product != (l > 0)) return GEOM_EINVAL;                                   // only the top layer reads its gradient from memory
+        if (product && a.dz_up != layers[l - 1].dz) return GEOM_EINVAL;               // a chain
+        if (product && l > 1 && (a.ell_col_t != layers[1].ell_col_t || a.ell_val_t != layers[1].ell_val_t ||
+                                 a.tail_col_t != layers[1].tail_col_t || a.tail_val_t != layers[1].tail_val_t))
+            return GEOM_EINVAL;
+        if (product ? (!a.ell_col_t || !a.ell_val_t || !a.ds_up || !a.wt_up) : (!a.g && !a.ds_head)) return GEOM_EINVAL;
+        if (a.ds_head && (product || !a.w_head || (a.dw_head && !a.x_top) || !db_aligned16(a.x_top))) return GEOM_EINVAL;
+        if (a.tail_col_t && !a.tail_val_t) return GEOM_EINVAL;
+        if ((a.g_ld && a.g_ld < DB_C) || (a.g2_ld && a.g2_ld < DB_C)) return GEOM_EINVAL;
+        if ((int64_t)a.b * a.nv * (a.g_ld > a.g2_ld ? a.g_ld : a.g2_ld) >= (1LL << 29)) return GEOM_EUNSUPPORTED;
+        if (!db_aligned16(a.dz_up) || !db_aligned16(a.ell_col_t) || !db_aligned16(a.ell_val_t) || !db_aligned16(a.ds_up) || ((uintptr_t)a.g & 3) ||
+            ((uintptr_t)a.g2 & 3) || !db_aligned16(a.z) || !db_aligned16(a.grad_res) || !db_aligned16(a.dz) || !db_aligned16(a.colsum) ||
+            !db_aligned16(a.wt_up))
+            return GEOM_EINVAL;
+        for (int e = 0; e < l; ++e)
+            if (layers[e].dz == a.dz) return GEOM_EINVAL;                              // (every step its own dZ: neighbours read it a step later)
+        if (!a.has_res) a.scale = 1.f;
+        a.vpx = (a.nv + 7) / 8;
+        c.layer[l] = a;
+    }
+    if (layers[0].b == 0 || layers[0].nv == 0) return 0;
+    if (!geom_deform_chain_fits(layers[0].nv)) return GEOM_EUNSUPPORTED;
+    c.count = count, c.done = done;
+    hipLaunchKernelGGL(db_bwd_chain_kernel, dim3(8 * c.layer[0].vpx), dim3(DB_THREADS), 0, static_cast<hipStream_t>(stream), c);
+    return geom::launch_status();
+}
+
 // fwd[l] / bwd[l] (each count x 36 864 floats, either may be NULL) = the register-slice order of w[l] / w[l]^T that
 // geom_deform_layer_fwd_f32 (w_next) / geom_deform_layer_bwd_f32 (wt_up) read; w = HOST array of count <= GEOM_DEFORM_MAX_PACK
 // device pointers to [192,192] row-major matrices.  One launch for all layers of a block, once per step.
@@ -774,9 +855,12 @@ extern "C" int geom_deform_chain_fits(int nv)
     if (!slots[dev]) {
         int per_cu = 0;
         hipDeviceProp_t prop;
+        int per_cu_b = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, db_fwd_chain_kernel, DB_THREADS, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, db_bwd_chain_kernel, DB_THREADS, 0) != hipSuccess ||
             hipGetDeviceProperties(&prop, dev) != hipSuccess)
             return 0;
+        per_cu = per_cu < per_cu_b ? per_cu : per_cu_b;
         slots[dev] = per_cu * prop.multiProcessorCount > 0 ? per_cu * prop.multiProcessorCount : -1;
     }
     return slots[dev] >= 8 * ((nv + 7) / 8);

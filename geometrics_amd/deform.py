@@ -155,11 +155,10 @@ def _rows192(t, shape):
     return t, t.stride(1)
 
 
-def layer_backward(shape, csr, z, bn_w, bn_b, save_mean, save_invstd, relu, has_res, scale, dz, grad_bn_w, grad_bn_b,
+def _backward_args(shape, csr, z, bn_w, bn_b, save_mean, save_invstd, relu, has_res, scale, dz, grad_bn_w, grad_bn_b,
                    dz_up=None, ds_up=None, wt_up=None, g=None, g2=None, grad_res=None, colsum=None, ds_head=None, w_head=None,
                    x_top=None, dw_head=None):
-    """One backward launch (geom_deform_layer_bwd_f32); wt_up = the layer above's weight, TRANSPOSED and packed
-    (pack_weights()[1][l])."""
+    """(struct, tensors it points into that were made here: the caller keeps them alive until the launch is issued)"""
     b, nv, c = shape
     tail = _tail_tables(csr)
     g, g_ld = _rows192(g, shape)
@@ -168,8 +167,23 @@ def layer_backward(shape, csr, z, bn_w, bn_b, save_mean, save_invstd, relu, has_
                        _p(ds_up), _p(wt_up), _p(g), _p(g2), g_ld, g2_ld, _p(z), _p(bn_w), _p(bn_b), _p(save_mean),
                        _p(save_invstd), int(relu), int(has_res), float(scale), _p(grad_res), _p(dz), _p(grad_bn_w),
                        _p(grad_bn_b), _p(colsum), _p(ds_head), _p(w_head), _p(x_top), _p(dw_head), 0)
+    return a, (g, g2)
+
+
+def layer_backward(shape, csr, z, *args, **kwargs):
+    """One backward launch (geom_deform_layer_bwd_f32); wt_up = the layer above's weight, TRANSPOSED and packed
+    (pack_weights()[1][l])."""
+    a, _keep = _backward_args(shape, csr, z, *args, **kwargs)
     with torch.cuda.device(z.device):
         _lib.call("geom_deform_layer_bwd_f32", ctypes.addressof(a))
+
+
+def chain_backward(layers, done, device):
+    """`layers` (lists of layer_backward's arguments, the top layer first) as ONE launch (geom_deform_chain_bwd_f32)."""
+    built = [_backward_args(*a, **k) for a, k in layers]
+    structs = (_lib.DeformBwd * len(built))(*[b[0] for b in built])
+    with torch.cuda.device(device):
+        _lib.call("geom_deform_chain_bwd_f32", len(built), ctypes.addressof(structs), done.data_ptr())
 
 
 class _HiddenChain(torch.autograd.Function):
@@ -221,6 +235,7 @@ class _HiddenChain(torch.autograd.Function):
             s_cur = s_buf[i & 1]
         if as_chain:
             chain_forward(calls, counters[0], dev)
+        ctx.counters = counters[1] if as_chain else None
         ctx.csr, ctx.relu, ctx.head = csr, relu, w_head is not None
         ctx.head_shape = None if w_head is None else tuple(w_head.shape)
         ctx.set_materialize_grads(False)      # a handle nobody uses (the last block's features) arrives as None, not as 5.9 MB of zeros
@@ -258,26 +273,34 @@ class _HiddenChain(torch.autograd.Function):
         colsum = torch.empty(L, nv, c, **f32)
         pending = {}                                   # j -> gradient that reaches X_j through a residual average
         g_lead = None
+        calls = [] if ctx.counters is not None else None   # (the forward ran as one launch: so does the backward)
         for i in range(L, 0, -1):
             src = RESIDUALS.get(i)
             grad_res = torch.empty(b, nv, c, **f32) if src is not None else None
             common = dict(relu=ctx.relu, has_res=src is not None, scale=0.5, dz=dzs[i - 1], grad_bn_w=g_bnw[i - 1], grad_bn_b=g_bnb[i - 1],
                           grad_res=grad_res, colsum=colsum[i - 1])
+            where = ((b, nv, c), csr, zs[i - 1], bn_w[i - 1], bn_b[i - 1], means[i - 1], invstds[i - 1])
             if i == L:
-                layer_backward((b, nv, c), csr, zs[i - 1], bn_w[i - 1], bn_b[i - 1], means[i - 1], invstds[i - 1], g=g_top, g2=g_top2,
-                               ds_head=ds_head, w_head=w_head if ds_head is not None else None, x_top=xs[L - 1] if dw_head is not None else None,
-                               dw_head=dw_head, **common)
+                what = dict(g=g_top, g2=g_top2, ds_head=ds_head, w_head=w_head if ds_head is not None else None,
+                            x_top=xs[L - 1] if dw_head is not None else None, dw_head=dw_head, **common)
             else:
-                layer_backward((b, nv, c), csr, zs[i - 1], bn_w[i - 1], bn_b[i - 1], means[i - 1], invstds[i - 1], dz_up=dzs[i],
-                               ds_up=dss[i - 1], wt_up=wts[i - 1], g2=pending.pop(i + 1, None), **common)
+                what = dict(dz_up=dzs[i], ds_up=dss[i - 1], wt_up=wts[i - 1], g2=pending.pop(i + 1, None), **common)
+            if calls is None:
+                layer_backward(*where, **what)
+            else:
+                calls.append((where, what))
             if src == "lead":
                 g_lead = grad_res
             elif src is not None:
                 if src in pending:
+                    if calls is not None:
+                        raise RuntimeError("two residual gradients for one layer: not expressible inside one launch")
                     pending[src] = pending[src] + grad_res
                 else:
                     pending[src] = grad_res
         assert not pending, "a residual gradient was left without its layer"
+        if calls is not None:
+            chain_backward(calls, ctx.counters, dev)
         # dS_1 = aggregation backward of the first layer: the existing operator (no activation between S_1 and Z_1)
         g_s1, _ = _layers.aggregate_backward(dzs[0], csr, 64, _layers._ACT_NONE, None, None, False)
         rows = b * nv

@@ -436,6 +436,9 @@ typedef struct geom_deform_bwd {
 #define GEOM_DEFORM_CHAIN_MAX 13
 int geom_deform_chain_fits(int nv);
 int geom_deform_chain_fwd_f32(int count, const geom_deform_fwd *layers, int *done, void *stream);
+/* ... and the backward layers, in execution order: layers[0] = the top layer (dz_up == NULL: its gradient comes from memory),
+ * layers[t].dz_up == layers[t - 1].dz; every step its own dz array; `done` = its own nv * 32 zeroed ints. */
+int geom_deform_chain_bwd_f32(int count, const geom_deform_bwd *layers, int *done, void *stream);
 int geom_deform_pack_weights_zero_f32(int count, const float *const *w, float *fwd, float *bwd, int *zero, int zero_words,
                                       void *stream);
 /* EXPERIMENT (csrc/dense_split_bf16.hip; on no default route): c [m, 192] = a [m, k] . w [k, 192] on the BF16 matrix cores with
