@@ -85,7 +85,7 @@ __device__ __forceinline__ void db_st4(__amdgpu_buffer_rsrc_t r, unsigned off, f
 // 128-byte line each: pollers and publishers of different vertices never share one); zero on entry (the weight-packing launch of
 // the step zeroes it).  Every workgroup of the launch must be resident at once (the host checks; otherwise separate launches).
 constexpr int DB_CTR_STRIDE = 32;
-constexpr int DB_SPIN_LIMIT = 1 << 22; // polls before a wait gives up (seconds): the layer's outputs are then NaN, loudly
+constexpr int DB_SPIN_LIMIT = 1 << 20; // polls before a wait gives up (seconds): the layer's outputs are then NaN, loudly
 
 // wave-wide wait: lane's `target` vertex (< 0: none) has published `need` layers.  false: gave up.
 __device__ __forceinline__ bool db_wait_published(const int *done, int target, int need)

@@ -13,10 +13,14 @@ its gradients stay with layers._dense), its output the block's final features X_
 existing layer.  Weight gradients of the twelve equal layers: one strided-batched product over the stacked activations and
 support gradients; bias gradients: per-vertex column sums out of the backward launches, added up by one reduction.
 
+Where every workgroup of a launch is resident at once (482 vertices on an MI355X: yes) the thirteen launches of a direction
+are ONE (`chain`): a vertex's workgroup runs layer after layer and waits for its neighbours' rows inside the launch.
+
 `serves()` says when the launches apply (192-wide block, k = 64, b <= 16, bounded-degree table of width 8, training mode,
 local BatchNorm statistics, fp32 on a HIP device); everything else takes the separate operators (models.py).
 """
 import ctypes
+import threading
 
 import torch
 
@@ -105,15 +109,40 @@ def pack_weights(weights, zero=None):
 
 # The hidden layers of a block as ONE launch per direction (geom_deform_chain_fwd_f32: a vertex's workgroup waits for its
 # neighbours' rows inside the launch) where every workgroup of the launch is resident at once; False: one launch per layer.
+#
+# ONE chain launch at a time per device: a chain launch needs all its workgroups resident, and two of them that start together
+# on two streams can each hold half of the chip and wait for the other half (the waits give up after seconds and the outputs
+# are NaN -- loud, but a lost step).  A process therefore gives the chain launches of a device to ONE stream at a time: the
+# stream that asks first owns them until it is idle, other streams issue the layers one by one meanwhile.  A stream that is being
+# captured always records chain launches.  (Not covered: two PROCESSES sharing a GPU, and captured graphs replayed concurrently
+# with other chain work -- set deform.chain = False there.)
 chain = True
 CTR_STRIDE = 32      # ints per vertex counter (one 128-byte line each)
+_chain_owner = {}    # device index -> the torch stream that issues chain launches
+_chain_lock = threading.Lock()
 
 
 def chain_fits(nv, device):
     if not chain:
         return False
     with torch.cuda.device(device):
-        return bool(_lib.lib().geom_deform_chain_fits(int(nv)))
+        if not _lib.lib().geom_deform_chain_fits(int(nv)):
+            return False
+        mine = torch.cuda.current_stream(device)
+        if torch.cuda.is_current_stream_capturing():
+            return True      # (nothing runs now; whoever replays the graph keeps other chain work off the device meanwhile)
+    with _chain_lock:
+        owner = _chain_owner.get(device.index)
+        if owner is None or owner == mine:
+            _chain_owner[device.index] = mine
+            return True
+        try:                          # the owner has nothing in flight any more: the launches move to this stream
+            idle = owner.query()
+        except RuntimeError:          # (it is being captured)
+            idle = False
+        if idle:
+            _chain_owner[device.index] = mine
+        return idle
 
 
 def _forward_args(s_in, bias, csr, bn_w, bn_b, run_mean, run_var, training, momentum, eps, relu, res, scale, z_out, x_out,
@@ -273,7 +302,8 @@ class _HiddenChain(torch.autograd.Function):
         colsum = torch.empty(L, nv, c, **f32)
         pending = {}                                   # j -> gradient that reaches X_j through a residual average
         g_lead = None
-        calls = [] if ctx.counters is not None else None   # (the forward ran as one launch: so does the backward)
+        # (the forward ran as one launch: so does the backward, if this stream still owns the device's chain launches)
+        calls = [] if ctx.counters is not None and chain_fits(nv, dev) else None
         for i in range(L, 0, -1):
             src = RESIDUALS.get(i)
             grad_res = torch.empty(b, nv, c, **f32) if src is not None else None

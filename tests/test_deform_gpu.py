@@ -7,7 +7,10 @@ geometrics_amd/deform.py; reference models.py:237-297 on layers.py:107-116).
   coordinates, running statistics, every parameter gradient and both input gradients;
 * the same against the block on the separate operators (`deform.enabled = False`), batch 16 on the 482-vertex template with its
   two 33-entry poles (table + CSR tail) and batch 5 on a pole-free icosphere (rows beyond the batch are zero rows of the tile);
-* the step inside a HIP graph; shapes the launches do not serve fall back to the separate operators."""
+* the step inside a HIP graph; shapes the launches do not serve fall back to the separate operators;
+* the thirteen launches of a direction as ONE (a vertex's workgroup waits for its neighbours' rows inside the launch): bit for
+  bit the layer-by-layer launches; only the stream that owns a device's chain launches issues them; a mesh whose workgroups are
+  not all resident at once takes the layer-by-layer launches."""
 import numpy as np
 import pytest
 import torch
@@ -326,3 +329,77 @@ def test_block_input_assembled_in_place_equals_the_concatenations(gpu):
     utils.batched_pooling(ms2, p2, img).backward(g_wide[..., 5:].contiguous())
     assert torch.equal(p.grad, p2.grad)
     assert all(float((x.grad - y.grad).abs().max()) <= 1e-5 * float(y.grad.abs().max()) for x, y in zip(ms, ms2))
+
+
+def _block_step(block, feats, pooled, adj):
+    for p in block.parameters():
+        p.grad = None
+    feats.grad = pooled.grad = None
+    for i in range(1, 14):
+        getattr(block, "bn%d" % i).running_mean.zero_(), getattr(block, "bn%d" % i).running_var.fill_(1.0)
+    f, c = block(feats, pooled, adj)
+    (f * torch.linspace(-1, 1, f.shape[-1], device=f.device)).sum().add((c * c).sum()).backward()
+    out = [f.detach().clone(), c.detach().clone(), feats.grad.clone(), pooled.grad.clone()]
+    out += [p.grad.clone() for p in block.parameters() if p.grad is not None]
+    out += [getattr(block, "bn%d" % i).running_var.clone() for i in range(1, 14)]
+    return out
+
+
+@pytest.mark.parametrize("mesh,batch", [("uv_sphere_482", 16), ("icosphere_162", 5)])
+def test_one_launch_per_direction_equals_the_launch_per_layer(gpu, mesh, batch):
+    """deform.chain: forward and backward of the block's thirteen hidden layers as ONE launch each against the thirteen launches
+    (same bodies, the rows between layers travel through memory with agent-scope accesses behind per-vertex counters): every
+    output, gradient and running statistic bit for bit, five times over (a race would not repeat)."""
+    nv, adj, csr = _mesh(mesh, gpu)
+    from geometrics_amd import _lib
+    assert _lib.lib().geom_deform_chain_fits(nv) == 1
+    torch.manual_seed(16)
+    block = models.BatchMeshDeformationBlock(3 + 197, nv).to(gpu).train()
+    feats = torch.randn(batch, nv, 3, device=gpu, requires_grad=True)
+    pooled = torch.randn(batch, nv, 197, device=gpu, requires_grad=True)
+    try:
+        deform.chain = False
+        ref = _block_step(block, feats, pooled, adj)
+        deform.chain = True
+        for _ in range(5):
+            got = _block_step(block, feats, pooled, adj)
+            assert len(got) == len(ref)
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b)
+    finally:
+        deform.chain = True
+
+
+def test_chain_launches_belong_to_one_stream_and_need_a_resident_grid(gpu):
+    nv, adj, csr = _mesh("uv_sphere_482", gpu)
+    from geometrics_amd import _lib
+    lib = _lib.lib()
+    assert lib.geom_deform_chain_fits(482) == 1 and lib.geom_deform_chain_fits(100000) == 0 and lib.geom_deform_chain_fits(0) == 0
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(a):
+        assert deform.chain_fits(nv, gpu)                    # (everything idle: the launches move to stream a)
+        busy = torch.empty(1 << 28, device=gpu)
+        for _ in range(20):
+            busy.fill_(1.0)                                   # stream a has work in flight ...
+        with torch.cuda.stream(b):
+            assert not deform.chain_fits(nv, gpu)            # ... so stream b issues its layers one by one
+        assert deform.chain_fits(nv, gpu)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(b):
+        assert deform.chain_fits(nv, gpu)                    # the owner is idle: the launches move
+    # a mesh with more vertices than workgroups fit the chip: the block runs on the layer-by-layer launches, same results as ever
+    V, Fc = meshgen.icosphere(3)                              # 642 vertices
+    assert lib.geom_deform_chain_fits(V.shape[0]) == 0
+    adj642 = utils.adj_init(torch.from_numpy(Fc).to(gpu))["adj"]
+    torch.manual_seed(17)
+    block = models.BatchMeshDeformationBlock(3 + 197, V.shape[0]).to(gpu).train()
+    feats = torch.randn(4, V.shape[0], 3, device=gpu, requires_grad=True)
+    pooled = torch.randn(4, V.shape[0], 197, device=gpu, requires_grad=True)
+    got = _block_step(block, feats, pooled, adj642)
+    try:
+        deform.enabled = False
+        ref = _block_step(block, feats, pooled, adj642)
+    finally:
+        deform.enabled = True
+    assert _maxrel(got[0], ref[0]) < 5e-5 and _maxrel(got[1], ref[1]) < 5e-5
