@@ -65,6 +65,18 @@ if n:
     fl = 2.0 * rows_ * 192 * 192
     lines.append("#   db_bwd_kernel<true> (aggregation backward + input-gradient product + BatchNorm backward, %d launches): %.1f us; the "
                  "product alone = %.1f TFLOP/s = %.2f of the fp32 MFMA peak" % (n, us, fl / us / 1e6, fl / us / 1e6 / 157.3))
+n, us = per("db_fwd_chain_kernel")
+if n:
+    fl, by = 12 * 2.0 * rows_ * 192 * 192, 13 * rows_ * 192 * 4 * 3 + 12 * 192 * 192 * 4
+    lines.append("#   db_fwd_chain_kernel (the 13 hidden layers of a block forward -- aggregation + BatchNorm1d(verts) + ReLU + residual + next "
+                 "product each -- in ONE launch, %d launches): %.1f us = %.1f per layer; the 12 products alone = %.1f TFLOP/s = %.2f of the "
+                 "fp32 MFMA peak; %.0f MB of tensors = %.2f TB/s -- a chain of 13 neighbour hand-offs, not a throughput kernel"
+                 % (n, us, us / 13, fl / us / 1e6, fl / us / 1e6 / 157.3, by / 1e6, by / us / 1e6))
+n, us = per("db_bwd_chain_kernel")
+if n:
+    fl = 12 * 2.0 * rows_ * 192 * 192
+    lines.append("#   db_bwd_chain_kernel (the 13 backward layers of a block in ONE launch, %d launches): %.1f us = %.1f per layer; the 12 "
+                 "input-gradient products alone = %.1f TFLOP/s = %.2f of the fp32 MFMA peak" % (n, us, us / 13, fl / us / 1e6, fl / us / 1e6 / 157.3))
 n, us = per("pool_bwd_lists_kernel")
 if n:
     by = maps_bytes + rows_ * 960 * 4
