@@ -303,7 +303,11 @@ class _HiddenChain(torch.autograd.Function):
         pending = {}                                   # j -> gradient that reaches X_j through a residual average
         g_lead = None
         # (the forward ran as one launch: so does the backward, if this stream still owns the device's chain launches)
+        counters = ctx.counters
+        # (its counters are good for ONE pass: a second backward over a retained graph takes the launches per layer)
         calls = [] if ctx.counters is not None and chain_fits(nv, dev) else None
+        if calls is not None:
+            ctx.counters = None
         for i in range(L, 0, -1):
             src = RESIDUALS.get(i)
             grad_res = torch.empty(b, nv, c, **f32) if src is not None else None
@@ -330,7 +334,7 @@ class _HiddenChain(torch.autograd.Function):
                     pending[src] = grad_res
         assert not pending, "a residual gradient was left without its layer"
         if calls is not None:
-            chain_backward(calls, ctx.counters, dev)
+            chain_backward(calls, counters, dev)
         # dS_1 = aggregation backward of the first layer: the existing operator (no activation between S_1 and Z_1)
         g_s1, _ = _layers.aggregate_backward(dzs[0], csr, 64, _layers._ACT_NONE, None, None, False)
         rows = b * nv

@@ -403,3 +403,24 @@ def test_chain_launches_belong_to_one_stream_and_need_a_resident_grid(gpu):
     finally:
         deform.enabled = True
     assert _maxrel(got[0], ref[0]) < 5e-5 and _maxrel(got[1], ref[1]) < 5e-5
+
+
+def test_a_second_backward_over_a_retained_graph_takes_the_launches_per_layer(gpu):
+    """The chain launch's counters are good for one pass (they count up from zero): backward(retain_graph=True) twice gives
+    the gradients of one pass twice -- the second pass on the launches per layer, bit for bit the same."""
+    nv, adj, csr = _mesh("uv_sphere_482", gpu)
+    torch.manual_seed(18)
+    block = models.BatchMeshDeformationBlock(3 + 197, nv).to(gpu).train()
+    feats = torch.randn(16, nv, 3, device=gpu, requires_grad=True)
+    pooled = torch.randn(16, nv, 197, device=gpu, requires_grad=True)
+    f, c = block(feats, pooled, adj)
+    loss = (f * f).sum() + c.sum()
+    loss.backward(retain_graph=True)
+    once = [p.grad.clone() for p in block.parameters() if p.grad is not None] + [pooled.grad.clone()]
+    for p in block.parameters():
+        p.grad = None
+    pooled.grad = feats.grad = None
+    loss.backward()
+    again = [p.grad for p in block.parameters() if p.grad is not None] + [pooled.grad]
+    for a, b in zip(once, again):
+        assert torch.equal(a, b)
