@@ -133,7 +133,7 @@ _SIGNATURES = {
     "geom_deform_pack_weights_f32": [_i, _vp, _vp, _vp, _vp],
     "geom_deform_pack_weights_zero_f32": [_i, _vp, _vp, _vp, _vp, _i, _vp],
     "geom_deform_chain_fwd_f32": [_i, _vp, _vp, _vp],
-    "geom_deform_chain_bwd_f32": [_i, _vp, _vp, _vp],
+    "geom_deform_chain_bwd_f32": [_i, _vp, _vp, _vp, _vp],
     "geom_deform_chain_fits": [_i],
     "geom_deform_layer_bwd_f32": [_vp, _vp],
 }

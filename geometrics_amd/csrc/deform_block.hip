@@ -688,6 +688,7 @@ struct DbBwdChain {
     geom_deform_bwd layer[GEOM_DEFORM_CHAIN_MAX]; // in execution order: the top layer first
     int count;
     int *done;
+    float *ds_first; // optional: [A^T . dZ[:, :64] | dZ[:, 64:]] of the LAST step's dZ (the first layer's support gradient)
 };
 
 __global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_chain_kernel(DbBwdChain c)
@@ -701,6 +702,25 @@ __global__ __launch_bounds__(DB_THREADS, 2) void db_bwd_chain_kernel(DbBwdChain 
         if (c.layer[l].dz_up) db_bwd_body<true, true>(c.layer[l], v, lds, c.done, l, &tb);
         else db_bwd_body<false, true>(c.layer[l], v, lds, c.done, l, &tb);
         __syncthreads();
+    }
+    if (c.ds_first) {
+        // one more hand-off instead of one more launch: the aggregation backward of the chain's first layer (no activation, no
+        // product behind it: the first layer's products stay with the caller) -- the bits of geom_zn_gcn_aggregate_ell_bwd_f32
+        const geom_deform_bwd &a = c.layer[c.count - 1];
+        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+        const int rl = tid >> 4, c0 = 4 * (tid & 15);
+        const bool mesh_on = rl < a.b;
+        const int64_t op_bytes = (int64_t)a.b * a.nv * DB_C * 4;
+        const unsigned rowbase = (unsigned)rl * (unsigned)a.nv * (DB_C * 4);
+        const __amdgpu_buffer_rsrc_t r_src = db_rsrc(a.dz, op_bytes), r_ds = db_rsrc(c.ds_first, op_bytes);
+        float4 gs[3];
+        DbSlice none;
+        bool arrived = true;
+        gs[0] = db_aggregate<false, true>(r_src, mesh_on, rowbase, v, c0, tb, &gs[1], none, nullptr, wave, lane, c.done, c.count, &arrived);
+        if (!arrived) gs[0].x = __builtin_nanf("");
+        const unsigned own_off = mesh_on ? rowbase + (unsigned)v * (DB_C * 4) + 4 * c0 : DB_OOB;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) db_st4(r_ds, own_off == DB_OOB ? DB_OOB : own_off + 4 * DB_K * i, gs[i]);
     }
 }
 
@@ -777,10 +797,13 @@ extern "C" int geom_deform_layer_bwd_f32(const geom_deform_bwd *args, void *stre
 
 // `count` backward layers in execution order (layers[0] = the top layer, read from memory: dz_up == NULL; layers[t].dz_up ==
 // layers[t - 1].dz for t >= 1) in ONE launch; results = those of the separate geom_deform_layer_bwd_f32 calls, bit for bit.
-// done: as for geom_deform_chain_fwd_f32 (its own nv * 32 zeroed ints).
-extern "C" int geom_deform_chain_bwd_f32(int count, const geom_deform_bwd *layers, int *done, void *stream)
+// done: as for geom_deform_chain_fwd_f32 (its own nv * 32 zeroed ints).  ds_first (may be NULL): also the aggregation backward of
+// the last step's dZ, [A^T . dZ[:, :64] | dZ[:, 64:]] -> ds_first [b,nv,192] (the support gradient of the chain's first layer;
+// the bits of geom_zn_gcn_aggregate_ell_bwd_f32 without activation), as a last hand-off of the same launch.
+extern "C" int geom_deform_chain_bwd_f32(int count, const geom_deform_bwd *layers, int *done, float *ds_first, void *stream)
 {
     if (count <= 0 || count > GEOM_DEFORM_CHAIN_MAX || !layers || !done || ((uintptr_t)done & 127)) return GEOM_EINVAL;
+    if (ds_first && (count < 2 || !db_aligned16(ds_first))) return GEOM_EINVAL; // (the transposed tables come with layers[1])
     DbBwdChain c{};
     for (int l = 0; l < count; ++l) {
         geom_deform_bwd a = layers[l];
@@ -811,7 +834,7 @@ extern "C" int geom_deform_chain_bwd_f32(int count, const geom_deform_bwd *layer
     }
     if (layers[0].b == 0 || layers[0].nv == 0) return 0;
     if (!geom_deform_chain_fits(layers[0].nv)) return GEOM_EUNSUPPORTED;
-    c.count = count, c.done = done;
+    c.count = count, c.done = done, c.ds_first = ds_first;
     hipLaunchKernelGGL(db_bwd_chain_kernel, dim3(8 * c.layer[0].vpx), dim3(DB_THREADS), 0, static_cast<hipStream_t>(stream), c);
     return geom::launch_status();
 }

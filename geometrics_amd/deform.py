@@ -207,12 +207,13 @@ def layer_backward(shape, csr, z, *args, **kwargs):
         _lib.call("geom_deform_layer_bwd_f32", ctypes.addressof(a))
 
 
-def chain_backward(layers, done, device):
-    """`layers` (lists of layer_backward's arguments, the top layer first) as ONE launch (geom_deform_chain_bwd_f32)."""
+def chain_backward(layers, done, device, ds_first=None):
+    """`layers` (lists of layer_backward's arguments, the top layer first) as ONE launch (geom_deform_chain_bwd_f32); ds_first:
+    receives the aggregation backward of the last layer's dZ (the chain's first layer has no activation behind its support)."""
     built = [_backward_args(*a, **k) for a, k in layers]
     structs = (_lib.DeformBwd * len(built))(*[b[0] for b in built])
     with torch.cuda.device(device):
-        _lib.call("geom_deform_chain_bwd_f32", len(built), ctypes.addressof(structs), done.data_ptr())
+        _lib.call("geom_deform_chain_bwd_f32", len(built), ctypes.addressof(structs), done.data_ptr(), _p(ds_first))
 
 
 class _HiddenChain(torch.autograd.Function):
@@ -333,10 +334,13 @@ class _HiddenChain(torch.autograd.Function):
                 else:
                     pending[src] = grad_res
         assert not pending, "a residual gradient was left without its layer"
+        # dS_1 = aggregation backward of the first layer (no activation between S_1 and Z_1): a last step of the chain launch, or
+        # the existing operator
         if calls is not None:
-            chain_backward(calls, counters, dev)
-        # dS_1 = aggregation backward of the first layer: the existing operator (no activation between S_1 and Z_1)
-        g_s1, _ = _layers.aggregate_backward(dzs[0], csr, 64, _layers._ACT_NONE, None, None, False)
+            g_s1 = torch.empty(b, nv, c, **f32)
+            chain_backward(calls, counters, dev, ds_first=g_s1)
+        else:
+            g_s1, _ = _layers.aggregate_backward(dzs[0], csr, 64, _layers._ACT_NONE, None, None, False)
         rows = b * nv
         g_w = torch.bmm(xs[:L - 1].view(L - 1, rows, c).transpose(1, 2), dss.view(L - 1, rows, c))     # dW_i = X_i^T . dS_i, i = 2..L
         # bias gradients: the vertices' column sums added up in vertex order, all 13 layers in ONE launch (torch's reduction over

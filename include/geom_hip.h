@@ -437,8 +437,10 @@ typedef struct geom_deform_bwd {
 int geom_deform_chain_fits(int nv);
 int geom_deform_chain_fwd_f32(int count, const geom_deform_fwd *layers, int *done, void *stream);
 /* ... and the backward layers, in execution order: layers[0] = the top layer (dz_up == NULL: its gradient comes from memory),
- * layers[t].dz_up == layers[t - 1].dz; every step its own dz array; `done` = its own nv * 32 zeroed ints. */
-int geom_deform_chain_bwd_f32(int count, const geom_deform_bwd *layers, int *done, void *stream);
+ * layers[t].dz_up == layers[t - 1].dz; every step its own dz array; `done` = its own nv * 32 zeroed ints.  ds_first (may be
+ * NULL; needs count >= 2): [b,nv,192] = [A^T . dz[:, :k] | dz[:, k:]] of the LAST step's dz -- the aggregation backward of the
+ * chain's first layer (geom_zn_gcn_aggregate_ell_bwd_f32 without activation, same bits) as one more step of the launch. */
+int geom_deform_chain_bwd_f32(int count, const geom_deform_bwd *layers, int *done, float *ds_first, void *stream);
 int geom_deform_pack_weights_zero_f32(int count, const float *const *w, float *fwd, float *bwd, int *zero, int zero_words,
                                       void *stream);
 /* EXPERIMENT (csrc/dense_split_bf16.hip; on no default route): c [m, 192] = a [m, k] . w [k, 192] on the BF16 matrix cores with
