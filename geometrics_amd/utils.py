@@ -233,7 +233,9 @@ def batched_pooling(blocks, verts_pos, img_info, headroom=0):
     headroom (not a reference argument): how many columns the caller is going to concatenate IN FRONT of the result
     (GEOMetrics.py:123,128: the previous features; models.py:241: the 3 coordinates) -- the features are then written as the
     trailing columns of a buffer that wide and `concat_features` / the deformation block fill the front in place of torch.cat."""
-    cam_mat, cam_pos = batch_camera_info(img_info)
+    # img_info: the camera parameters [B,3], or -- a driver that pools three times per step with the same cameras
+    # (GEOMetrics.py:118-128) -- the (cam_mat, cam_pos) pair batch_camera_info(img_info) returned once
+    cam_mat, cam_pos = img_info if isinstance(img_info, (tuple, list)) else batch_camera_info(img_info)
     return ops.PoolFeatures.apply(verts_pos, cam_mat.detach(), cam_pos.detach(), int(headroom), *blocks)
 
 

@@ -1062,6 +1062,8 @@ def test_batched_pooling_matches_reference_fixture(gpu):
     # the pixel coordinate is scaled by the map resolution (up to 56), which amplifies the fp32 round-off of
     # the projection (the reference's own matmul order is BLAS-dependent); the maps here are white noise
     close(feats.detach().cpu().numpy(), g["features"], 3e-5)
+    # the camera formed once and handed over (a driver that pools several times per step with the same cameras): same bits
+    assert torch.equal(utils.batched_pooling(blocks, verts, (cam_mat, cam_pos)), feats)
     feats.backward(dev(g["grad_out"], gpu))
     for i, blk in enumerate(blocks):
         close(blk.grad.cpu().numpy(), g["grad_block%d" % i], 3e-5)
