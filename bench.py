@@ -932,8 +932,12 @@ def driver_step_times(dev, batch=16, profile_replays=0, zero_edit=False, overlap
         with torch.cuda.stream(loss_stream):
             return surf()
 
+    # (the template expanded over the batch is a constant of the run: the edited driver materialises it once, the zero-edit
+    # step keeps GEOMetrics.py:116's expand in front of every step)
+    base_const = initial.unsqueeze(0).expand(batch, nv, 3).contiguous()
+
     def predict():
-        base = initial.unsqueeze(0).expand(batch, nv, 3)
+        base = initial.unsqueeze(0).expand(batch, nv, 3) if zero_edit else base_const
         # (the edited driver tells the pooling how many columns will be concatenated in front of its features -- 3 coordinates,
         # + the 192 previous features -- and uses utils.concat_features: no torch.cat of the 35 MB input, no slicing copies of its
         # gradient; the zero-edit step keeps torch.cat)
