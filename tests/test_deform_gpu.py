@@ -424,3 +424,32 @@ def test_a_second_backward_over_a_retained_graph_takes_the_launches_per_layer(gp
     again = [p.grad for p in block.parameters() if p.grad is not None] + [pooled.grad]
     for a, b in zip(once, again):
         assert torch.equal(a, b)
+
+
+def test_chain_launches_under_a_busy_neighbour_stream(gpu):
+    """The chain launches while another stream keeps the chip busy with ordinary kernels (their workgroups come and go, so the
+    chain's are not all resident from the first cycle: late workgroups are waited for, never deadlocked on), forty steps:
+    every step's outputs and gradients bit for bit those of the launches per layer."""
+    nv, adj, csr = _mesh("uv_sphere_482", gpu)
+    torch.manual_seed(19)
+    block = models.BatchMeshDeformationBlock(3 + 197, nv).to(gpu).train()
+    feats = torch.randn(16, nv, 3, device=gpu, requires_grad=True)
+    pooled = torch.randn(16, nv, 197, device=gpu, requires_grad=True)
+    try:
+        deform.chain = False
+        ref = _block_step(block, feats, pooled, adj)
+    finally:
+        deform.chain = True
+    torch.cuda.synchronize()
+    noise = torch.cuda.Stream()
+    junk = torch.empty(1 << 26, device=gpu)
+    a, b = torch.randn(2048, 2048, device=gpu), torch.randn(2048, 2048, device=gpu)
+    for step in range(40):
+        with torch.cuda.stream(noise):
+            for _ in range(6):
+                junk.fill_(float(step))
+                torch.mm(a, b)
+        got = _block_step(block, feats, pooled, adj)
+        for x, y in zip(got, ref):
+            assert torch.equal(x, y), "step %d" % step
+    torch.cuda.synchronize()
