@@ -20,6 +20,7 @@ are ONE (`chain`): a vertex's workgroup runs layer after layer and waits for its
 local BatchNorm statistics, fp32 on a HIP device); everything else takes the separate operators (models.py).
 """
 import ctypes
+import os
 import threading
 
 import torch
@@ -115,8 +116,8 @@ def pack_weights(weights, zero=None):
 # are NaN -- loud, but a lost step).  A process therefore gives the chain launches of a device to ONE stream at a time: the
 # stream that asks first owns them until it is idle, other streams issue the layers one by one meanwhile.  A stream that is being
 # captured always records chain launches.  (Not covered: two PROCESSES sharing a GPU, and captured graphs replayed concurrently
-# with other chain work -- set deform.chain = False there.)
-chain = True
+# with other chain work -- set deform.chain = False (or GEOM_DEFORM_CHAIN=0 in the environment) there.)
+chain = os.environ.get("GEOM_DEFORM_CHAIN", "1") != "0"
 CTR_STRIDE = 32      # ints per vertex counter (one 128-byte line each)
 _chain_owner = {}    # device index -> the torch stream that issues chain launches
 _chain_lock = threading.Lock()
