@@ -948,16 +948,19 @@ def driver_step_times(dev, batch=16, profile_replays=0, zero_edit=False, overlap
         fan = (lambda t, n: (t,) * n) if zero_edit else utils.fan_out
         # (the cameras of the three poolings are the same: the edited driver forms them once)
         cam = img_info if zero_edit else utils.batch_camera_info(img_info)
-        f = utils.batched_pooling(maps[0], base, clone(cam), headroom=room(3))
+        # ... and hands the pooling what will stand in front of its features (the coordinates, the previous features): the
+        # pooling launch copies them into place, the concatenations below find them there
+        fr = (lambda *t: None) if zero_edit else (lambda *t: t)
+        f = utils.batched_pooling(maps[0], base, clone(cam), headroom=room(3), fronts=fr(base))
         f, p1 = blocks[0](base, f, info["adj"])
         p1 = fan(base + p1, 6)
         stacked = DRIVER_STEP_STACKED_LOSSES and not zero_edit and loss_stream is None
         s1 = None if zero_edit or stacked else surface_term(p1[3], .2)
-        f = cat(f, utils.batched_pooling(maps[1], clone(p1[0]), clone(cam), headroom=room(3 + HID)))
+        f = cat(f, utils.batched_pooling(maps[1], clone(p1[0]), clone(cam), headroom=room(3 + HID), fronts=fr(p1[1], f)))
         f, p2 = blocks[1](clone(p1[1]), f, info["adj"])
         p2 = fan(p2 + p1[2], 6)
         s2 = None if zero_edit or stacked else surface_term(p2[3], .2)
-        f = cat(f, utils.batched_pooling(maps[2], clone(p2[0]), clone(cam), headroom=room(3 + HID)))
+        f = cat(f, utils.batched_pooling(maps[2], clone(p2[0]), clone(cam), headroom=room(3 + HID), fronts=fr(p2[1], f)))
         _, p3 = blocks[2](clone(p2[1]), f, info["adj"])
         p3 = fan(p3 + p2[2], 2)
         if stacked:

@@ -16,7 +16,7 @@ FLAG_FIX_REGION6 = 2
 FLAG_TRI_BRUTE_FORCE = 4
 FLAG_NN_FMA = 8
 FLAG_TRI_WS_READY = 16
-ABI_VERSION = 12
+ABI_VERSION = 13
 EUNSUPPORTED = -3
 ADAM_MAX_TENSORS = 64
 COLSUM_MAX_JOBS = 32
@@ -103,6 +103,7 @@ _SIGNATURES = {
     "geom_pool_features_fwd_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_pool_features_bwd_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "geom_pool_features_fwd_ld_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp],
+    "geom_pool_features_fwd_fronts_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp, _vp, _vp, _vp, _vp],
     "geom_pool_features_bwd_ld_f32": [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "geom_colsum_batch_f32": [_i, _vp, _vp, _vp, _vp, _vp],
     "geom_adam_step_f32": [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _vp, _i, _vp],

@@ -190,10 +190,36 @@ static inline unsigned pool_grid(int nv, int b, int zc)
     return (unsigned)((n + 7) / 8 * 8);
 }
 
-__global__ __launch_bounds__(PL_THREADS) void pool_fwd_kernel(PoolArgs a, float *out, int zc)
+// What the caller is going to concatenate IN FRONT of the pooled features (GEOMetrics.py:123,128: the previous features;
+// models.py:241: the coordinates), copied into the free columns of the wide buffer by workgroups BESIDE the pooling ones -- the
+// narrow copies were launches of their own (and 5.9 MB each for the previous features).
+constexpr int PL_MAX_FRONTS = 2;
+struct PoolFronts {
+    const float *src[PL_MAX_FRONTS]; // [b * nv, width] contiguous
+    int width[PL_MAX_FRONTS], col[PL_MAX_FRONTS], first_block[PL_MAX_FRONTS + 1];
+    int count;
+    float *dst;     // the wide buffer (row pitch a.ld)
+    int work_blocks; // the pooling workgroups in front of the copying ones
+};
+
+__global__ __launch_bounds__(PL_THREADS) void pool_fwd_kernel(PoolArgs a, float *out, int zc, PoolFronts fr)
 {
     __shared__ float tile[PL_VERTS][GEOM_WAVE + 1];
-    const PoolWork k = pool_work(a, zc, blockIdx.x, gridDim.x);
+    if ((int)blockIdx.x >= fr.work_blocks) {
+        const int fb = (int)blockIdx.x - fr.work_blocks;
+        const int f = (fr.count > 1 && fb >= fr.first_block[1]) ? 1 : 0;
+        const int64_t total = (int64_t)a.b * a.nv * fr.width[f];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t idx = ((int64_t)(fb - fr.first_block[f]) * 4 + q) * PL_THREADS + threadIdx.x;
+            if (idx < total) {
+                const int64_t row = idx / fr.width[f];
+                fr.dst[row * a.ld + fr.col[f] + (int)(idx - row * fr.width[f])] = fr.src[f][idx];
+            }
+        }
+        return;
+    }
+    const PoolWork k = pool_work(a, zc, blockIdx.x, fr.work_blocks);
     if (!k.live) return;
     const int mesh = k.mesh, v0 = k.v0;
     const int lane = threadIdx.x & (GEOM_WAVE - 1);
@@ -623,6 +649,31 @@ int fill_args(PoolArgs &a, int b, int nv, const float *verts, const float *cam_m
 
 } // namespace
 
+static int pool_fwd_launch(PoolArgs &a, int b, int nv, float *out, int64_t out_ld, int n_fronts, const float *const *fronts,
+                           const int *widths, const int *cols, float *buf, void *stream)
+{
+    if (!out) return GEOM_EINVAL;
+    if (out_ld) {
+        if (out_ld < a.ctot || out_ld > INT_MAX) return GEOM_EINVAL;
+        a.ld = (int)out_ld;
+    }
+    PoolFronts fr{};
+    const int zc = a.chunks < PL_MAX_CHUNKS ? a.chunks : PL_MAX_CHUNKS;
+    fr.work_blocks = (int)pool_grid(nv, b, zc);
+    if (n_fronts < 0 || n_fronts > PL_MAX_FRONTS || (n_fronts && (!fronts || !widths || !cols || !buf))) return GEOM_EINVAL;
+    int extra = 0;
+    for (int f = 0; f < n_fronts; ++f) {
+        if (!fronts[f] || widths[f] <= 0 || cols[f] < 0 || cols[f] + widths[f] > a.ld) return GEOM_EINVAL;
+        fr.src[f] = fronts[f], fr.width[f] = widths[f], fr.col[f] = cols[f], fr.first_block[f] = extra;
+        const int64_t blocks = ((int64_t)b * nv * widths[f] + 4 * PL_THREADS - 1) / (4 * PL_THREADS);
+        if (blocks > (1 << 24)) return GEOM_ETOOBIG;
+        extra += (int)blocks;
+    }
+    fr.first_block[n_fronts] = extra, fr.count = n_fronts, fr.dst = buf;
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(fr.work_blocks + extra), dim3(PL_THREADS), 0, static_cast<hipStream_t>(stream), a, out, zc, fr);
+    return geom::launch_status();
+}
+
 // out_ld: floats between two vertex rows of `out` (0 = the pooled width: a contiguous [b,nv,sum channels] tensor; larger: the
 // features are written as a column slice of a wider row-major buffer -- the deformation block's concatenated input)
 extern "C" int geom_pool_features_fwd_ld_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos,
@@ -632,27 +683,28 @@ extern "C" int geom_pool_features_fwd_ld_f32(int b, int nv, const float *verts, 
     PoolArgs a;
     if (int rc = fill_args(a, b, nv, verts, cam_mat, cam_pos, levels, blocks, channels, dims)) return rc;
     if (b == 0 || nv == 0 || levels == 0) return 0;
-    if (!out) return GEOM_EINVAL;
-    if (out_ld) {
-        if (out_ld < a.ctot || out_ld > INT_MAX) return GEOM_EINVAL;
-        a.ld = (int)out_ld;
-    }
-    const int zc = a.chunks < PL_MAX_CHUNKS ? a.chunks : PL_MAX_CHUNKS;
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3(pool_grid(nv, b, zc)), dim3(PL_THREADS), 0, static_cast<hipStream_t>(stream), a, out, zc);
-    return geom::launch_status();
+    return pool_fwd_launch(a, b, nv, out, out_ld, 0, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+// ... and up to two tensors fronts[f] [b, nv, widths[f]] (contiguous) copied into columns [cols[f], cols[f] + widths[f]) of the
+// wide buffer `buf` (row pitch out_ld, `out` = buf + the pooled features' first column) by the same launch: what the caller
+// concatenates in front of the pooled features (GEOMetrics.py:123,128; models.py:241)
+extern "C" int geom_pool_features_fwd_fronts_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos,
+                                                 int levels, const float *const *blocks, const int *channels, const int *dims,
+                                                 float *out, int64_t out_ld, int n_fronts, const float *const *fronts,
+                                                 const int *widths, const int *cols, float *buf, void *stream)
+{
+    PoolArgs a;
+    if (int rc = fill_args(a, b, nv, verts, cam_mat, cam_pos, levels, blocks, channels, dims)) return rc;
+    if (b == 0 || nv == 0 || levels == 0) return 0;
+    return pool_fwd_launch(a, b, nv, out, out_ld, n_fronts, fronts, widths, cols, buf, stream);
 }
 
 extern "C" int geom_pool_features_fwd_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos,
                                           int levels, const float *const *blocks, const int *channels, const int *dims,
                                           float *out, void *stream)
 {
-    PoolArgs a;
-    if (int rc = fill_args(a, b, nv, verts, cam_mat, cam_pos, levels, blocks, channels, dims)) return rc;
-    if (b == 0 || nv == 0 || levels == 0) return 0;
-    if (!out) return GEOM_EINVAL;
-    const int zc = a.chunks < PL_MAX_CHUNKS ? a.chunks : PL_MAX_CHUNKS;
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3(pool_grid(nv, b, zc)), dim3(PL_THREADS), 0, static_cast<hipStream_t>(stream), a, out, zc);
-    return geom::launch_status();
+    return geom_pool_features_fwd_ld_f32(b, nv, verts, cam_mat, cam_pos, levels, blocks, channels, dims, out, 0, stream);
 }
 
 static size_t pool_ws_layout(int b, int nv, int levels, const int *dims, BinSpace *ws, void *base)

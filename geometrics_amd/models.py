@@ -105,7 +105,8 @@ class _InputTap(torch.autograd.Function):
                         and features.shape[:2] == pooled.shape[:2] and _ops.headroom_of(pooled) == nf)
         if ctx.in_place:
             buf = _ops._headroom[pooled.untyped_storage().data_ptr()][0]()
-            buf[..., :nf].copy_(features)
+            if not _ops._already_placed(buf, 0, features):      # (the pooling launch may have copied them: batched_pooling(fronts=))
+                buf[..., :nf].copy_(features)
             _ops._register_headroom(buf, 0)
             full = buf
         else:

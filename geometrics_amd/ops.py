@@ -584,13 +584,23 @@ class StageRegularisers(torch.autograd.Function):
 # (`headroom`) allocates the wide buffer itself and writes its features at that column offset (geom_pool_features_fwd_ld_f32); the
 # later "concatenations" (`concat_in_front`) only copy the narrow operand into the free columns and widen the view, and in the
 # backward pass every consumer reads its column slice of the ONE wide gradient in place.
-_headroom = {}     # storage address -> (weak reference to the wide buffer, columns still free in front of the view handed out)
+_headroom = {}     # storage address -> (weak reference to the wide buffer, columns still free in front of the view handed out,
+#                      {first column: (address, version, width) of a tensor the pooling launch already copied there})
 
 
-def _register_headroom(buf, free):
+def _register_headroom(buf, free, placed=None):
     import weakref
     key = buf.untyped_storage().data_ptr()
-    _headroom[key] = (weakref.ref(buf, lambda _r, k=key: _headroom.pop(k, None)), free)
+    if placed is None:
+        old = _headroom.get(key)
+        placed = old[2] if old is not None and old[0]() is buf else {}
+    _headroom[key] = (weakref.ref(buf, lambda _r, k=key: _headroom.pop(k, None)), free, placed)
+
+
+def _already_placed(buf, col, t):
+    """Whether columns [col, col + width) of the wide buffer already hold `t` (PoolFeatures(fronts=...) copied it there)."""
+    hit = _headroom.get(buf.untyped_storage().data_ptr())
+    return hit is not None and hit[0]() is buf and hit[2].get(col) == (t.data_ptr(), t._version, t.shape[2])
 
 
 def headroom_of(t):
@@ -617,7 +627,8 @@ class _ConcatInFront(torch.autograd.Function):
         hit = _headroom[view.untyped_storage().data_ptr()]
         buf, free = hit[0](), hit[1]
         cf = front.shape[2]
-        buf[..., free - cf:free].copy_(front)
+        if not _already_placed(buf, free - cf, front):
+            buf[..., free - cf:free].copy_(front)
         out = buf[..., free - cf:]
         _register_headroom(buf, free - cf)
         ctx.cf = cf
@@ -644,7 +655,13 @@ class PoolFeatures(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, verts, cam_mat, cam_pos, headroom, *blocks):
-        """headroom: columns left free IN FRONT of the pooled features (0: a plain contiguous result; see concat_in_front)."""
+        """headroom: columns left free IN FRONT of the pooled features (0: a plain contiguous result; see concat_in_front), or
+        (headroom, fronts): also up to two [B,V,*] tensors, left to right as they will stand in front of the features (their
+        widths add up to the headroom), which the launch copies there -- concat_in_front / the deformation block then find them
+        in place (the gradient still flows through those nodes: the tensors are not inputs of this one)."""
+        fronts = ()
+        if isinstance(headroom, (tuple, list)):
+            headroom, fronts = headroom
         headroom = int(headroom or 0)
         import ctypes
         v = _f32(verts, "verts_pos", 3, 3)
@@ -660,15 +677,35 @@ class PoolFeatures(torch.autograd.Function):
         chans = (ctypes.c_int * n)(*[t.shape[1] for t in blks])
         dims = (ctypes.c_int * n)(*[t.shape[2] for t in blks])
         ctot = sum(t.shape[1] for t in blks)
+        placed, srcs = {}, []
+        if fronts:
+            col = 0
+            for t in fronts:
+                if not (torch.is_tensor(t) and t.dim() == 3 and tuple(t.shape[:2]) == (b, nv) and t.is_cuda and t.device == v.device
+                        and t.dtype == torch.float32):
+                    raise RuntimeError("fronts must be fp32 [B,V,*] tensors on the meshes' device")
+                c = t.detach().contiguous()
+                srcs.append((c, col))
+                if c.data_ptr() == t.data_ptr():       # (a copy made here is not what the caller will hand to the concatenation)
+                    placed[col] = (t.data_ptr(), t._version, t.shape[2])
+                col += t.shape[2]
+            if col != headroom or len(srcs) > 2:
+                raise RuntimeError("at most two fronts, whose widths add up to the headroom")
         if headroom > 0:      # the features as the trailing columns of a wider buffer: see concat_in_front
             buf = torch.empty(b, nv, headroom + ctot, dtype=torch.float32, device=v.device)
             out = buf[..., headroom:]
-            _register_headroom(buf, headroom)
+            _register_headroom(buf, headroom, placed)
         else:
             out = torch.empty(b, nv, ctot, dtype=torch.float32, device=v.device)
         with torch.cuda.device(v.device):
-            _lib.call("geom_pool_features_fwd_ld_f32", b, nv, v.data_ptr(), cam_mat.data_ptr(), cam_pos.data_ptr(), n,
-                      ptrs, chans, dims, out.data_ptr(), headroom + ctot if headroom > 0 else 0)
+            if srcs:
+                m = len(srcs)
+                _lib.call("geom_pool_features_fwd_fronts_f32", b, nv, v.data_ptr(), cam_mat.data_ptr(), cam_pos.data_ptr(), n,
+                          ptrs, chans, dims, out.data_ptr(), headroom + ctot, m, (ctypes.c_void_p * m)(*[t.data_ptr() for t, _ in srcs]),
+                          (ctypes.c_int * m)(*[t.shape[2] for t, _ in srcs]), (ctypes.c_int * m)(*[c for _, c in srcs]), buf.data_ptr())
+            else:
+                _lib.call("geom_pool_features_fwd_ld_f32", b, nv, v.data_ptr(), cam_mat.data_ptr(), cam_pos.data_ptr(), n,
+                          ptrs, chans, dims, out.data_ptr(), headroom + ctot if headroom > 0 else 0)
         ctx.save_for_backward(v, cam_mat, cam_pos, *blks)
         ctx.meta = (ptrs, chans, dims, n)
         return out

@@ -226,17 +226,21 @@ def batch_camera_info(param):
     return torch.stack(rows, dim=1), cam_pos
 
 
-def batched_pooling(blocks, verts_pos, img_info, headroom=0):
+def batched_pooling(blocks, verts_pos, img_info, headroom=0, fronts=None):
     """[B,V,sum C] image features bilinearly pooled from the encoder maps `blocks` (each [B,C,d,d]) at the
     pixels the vertices project to (reference utils.py:316-389).  Differentiable in the maps and in the
     vertex positions; one HIP kernel per direction instead of ~40 eager ops per call.
     headroom (not a reference argument): how many columns the caller is going to concatenate IN FRONT of the result
     (GEOMetrics.py:123,128: the previous features; models.py:241: the 3 coordinates) -- the features are then written as the
-    trailing columns of a buffer that wide and `concat_features` / the deformation block fill the front in place of torch.cat."""
+    trailing columns of a buffer that wide and `concat_features` / the deformation block fill the front in place of torch.cat.
+    fronts (with headroom; not a reference argument): those very tensors, left to right as they will stand in front of the
+    features -- e.g. (positions, previous_features) -- which the pooling launch then copies into place itself (the later
+    concatenations find them there and copy nothing; gradients flow as before)."""
     # img_info: the camera parameters [B,3], or -- a driver that pools three times per step with the same cameras
     # (GEOMetrics.py:118-128) -- the (cam_mat, cam_pos) pair batch_camera_info(img_info) returned once
     cam_mat, cam_pos = img_info if isinstance(img_info, (tuple, list)) else batch_camera_info(img_info)
-    return ops.PoolFeatures.apply(verts_pos, cam_mat.detach(), cam_pos.detach(), int(headroom), *blocks)
+    room = int(headroom) if not fronts else (int(headroom), tuple(fronts))
+    return ops.PoolFeatures.apply(verts_pos, cam_mat.detach(), cam_pos.detach(), room, *blocks)
 
 
 def fan_out(x, n):

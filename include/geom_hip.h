@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GEOM_ABI_VERSION 12
+#define GEOM_ABI_VERSION 13
 
 /* argument errors */
 #define GEOM_EINVAL   (-1) /* bad size / null pointer */
@@ -573,6 +573,14 @@ int geom_pool_features_bwd_f32(int b, int nv, const float *verts, const float *c
 int geom_pool_features_fwd_ld_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos, int levels,
                                   const float *const *blocks, const int *channels, const int *dims, float *out, int64_t out_ld,
                                   void *stream);
+/* ... with up to two tensors fronts[f] [b, nv, widths[f]] (contiguous) copied into columns [cols[f], cols[f] + widths[f]) of the
+ * wide buffer buf (row pitch out_ld; out = buf + the pooled features' first column) by workgroups of the same launch: what the
+ * caller concatenates in front of the pooled features (GEOMetrics.py:123,128: the previous features; models.py:241: the
+ * coordinates) -- the narrow copies were launches of their own. */
+int geom_pool_features_fwd_fronts_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos, int levels,
+                                      const float *const *blocks, const int *channels, const int *dims, float *out,
+                                      int64_t out_ld, int n_fronts, const float *const *fronts, const int *widths,
+                                      const int *cols, float *buf, void *stream);
 int geom_pool_features_bwd_ld_f32(int b, int nv, const float *verts, const float *cam_mat, const float *cam_pos, int levels,
                                   const float *const *blocks, const int *channels, const int *dims, const float *grad_out,
                                   int64_t grad_ld, float *const *grad_blocks, float *grad_verts, void *workspace,

@@ -298,24 +298,31 @@ def test_block_input_assembled_in_place_equals_the_concatenations(gpu):
     img = torch.tensor([[30.0 + 7 * i, 20.0, 1.2] for i in range(b)], device=gpu)
     g_f, g_c = torch.randn(b, nv, 192, device=gpu), torch.randn(b, nv, 3, device=gpu)
 
-    def run(blk, in_place):
+    def run(blk, in_place, fronts=False):
         ms = [m.clone().requires_grad_(True) for m in maps]
         p, f_prev = pos.clone().requires_grad_(True), prev.clone().requires_grad_(True)
-        pooled = utils.batched_pooling(ms, p, img, headroom=3 + 192 if in_place else 0)
+        pooled = utils.batched_pooling(ms, p, img, headroom=3 + 192 if in_place else 0, fronts=(p, f_prev) if fronts else None)
+        if fronts:      # the pooling launch placed both: the concatenations below copy nothing
+            buf = ops._headroom[pooled.untyped_storage().data_ptr()][0]()
+            assert ops._already_placed(buf, 0, p) and ops._already_placed(buf, 3, f_prev)
+            assert torch.equal(buf[..., :3], p.detach()) and torch.equal(buf[..., 3:195], f_prev.detach())
         assert (ops.headroom_of(pooled) == 195) == in_place
         f = utils.concat_features(f_prev, pooled) if in_place else torch.cat((f_prev, pooled), dim=-1)
         assert f.shape == (b, nv, 192 + 96) and (ops.headroom_of(f) == 3) == in_place
         out_f, coords = blk(p, f, adj)
         ((out_f * g_f).sum() + (coords * g_c).sum()).backward()
         return [out_f.detach(), coords.detach(), p.grad, f_prev.grad] + [m.grad for m in ms] + [q.grad for q in blk.parameters() if q.grad is not None]
-    got = run(block, True)
     want = run(twin, False)
-    assert len(got) == len(want) and len(got) >= 55
-    for i, (a, w) in enumerate(zip(got, want)):
-        if i in (4, 5):     # the maps' gradients: per-texel lists are filled in ticket order (same terms, fp32 order may differ: DESIGN 5)
-            assert float((a - w).abs().max()) <= 1e-5 * float(w.abs().max())
-        else:
-            assert torch.equal(a, w), i
+    for fronts in (False, True):     # (True: positions and previous features copied into place by the pooling launch itself)
+        got = run(copy.deepcopy(twin), True, fronts)
+        assert len(got) == len(want) and len(got) >= 55
+        for i, (a, w) in enumerate(zip(got, want)):
+            if i in (4, 5):     # the maps' gradients: per-texel lists are filled in ticket order (same terms, fp32 order may differ: DESIGN 5)
+                assert float((a - w).abs().max()) <= 1e-5 * float(w.abs().max())
+            else:
+                assert torch.equal(a, w), i
+    with pytest.raises(RuntimeError):
+        utils.batched_pooling([m.clone() for m in maps], pos, img, headroom=10, fronts=(pos,))      # widths must add up
     # pooling alone: the pitched forward and a pitched upstream gradient give the plain call's bits
     ms = [m.clone().requires_grad_(True) for m in maps]
     p = pos.clone().requires_grad_(True)
