@@ -16,7 +16,7 @@ FLAG_FIX_REGION6 = 2
 FLAG_TRI_BRUTE_FORCE = 4
 FLAG_NN_FMA = 8
 FLAG_TRI_WS_READY = 16
-ABI_VERSION = 13
+ABI_VERSION = 14
 EUNSUPPORTED = -3
 ADAM_MAX_TENSORS = 64
 COLSUM_MAX_JOBS = 32
@@ -126,6 +126,7 @@ _SIGNATURES = {
     "geom_zn_layer_bwd_f32": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp],
     "geom_camera_info_f32": [_i, _vp, _vp, _vp, _vp],
     "geom_sum_tensors_f32": [_i, _vp, ctypes.c_int64, _vp, _vp],
+    "geom_sum_tensors_rows_f32": [_i, _vp, _vp, ctypes.c_int64, _i, _vp, _vp],
     "geom_split_bf16_planes_f32": [_i, _i, _vp, _vp, _vp],
     "geom_gemm_split_bf16_f32": [_i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "geom_stage_regularisers_fwd_f32": [_i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp],

@@ -295,6 +295,44 @@ __global__ __launch_bounds__(RG_THREADS) void sum_tensors_kernel(SumArgs a, int6
 }
 } // namespace
 
+namespace {
+struct SumRowsArgs {
+    const float *t[GEOM_SUM_MAX_TENSORS];
+    int64_t ld[GEOM_SUM_MAX_TENSORS];
+    int count, width;
+};
+__global__ __launch_bounds__(RG_THREADS) void sum_rows_kernel(SumRowsArgs a, int64_t n, float *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * RG_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = i / a.width;
+    const int c = (int)(i - r * a.width);
+    float s = a.t[0][r * a.ld[0] + c];
+#pragma unroll
+    for (int k = 1; k < GEOM_SUM_MAX_TENSORS; ++k)
+        if (k < a.count) s += a.t[k][r * a.ld[k] + c];
+    out[i] = s;
+}
+} // namespace
+
+// the same sum for [rows, width] operands of which some are column slices of wider row-major buffers: lds[k] = floats between
+// two rows of tensors[k] (>= width); out is contiguous
+extern "C" int geom_sum_tensors_rows_f32(int count, const float *const *tensors, const int64_t *lds, int64_t rows, int width, float *out,
+                                         void *stream)
+{
+    if (count <= 0 || count > GEOM_SUM_MAX_TENSORS || rows < 0 || width <= 0) return GEOM_EINVAL;
+    if (rows == 0) return 0;
+    if (!tensors || !lds || !out) return GEOM_EINVAL;
+    SumRowsArgs a{};
+    for (int k = 0; k < count; ++k) {
+        if (!tensors[k] || lds[k] < width) return GEOM_EINVAL;
+        a.t[k] = tensors[k], a.ld[k] = lds[k];
+    }
+    a.count = count, a.width = width;
+    hipLaunchKernelGGL(sum_rows_kernel, rg_grid(rows * width), dim3(RG_THREADS), 0, static_cast<hipStream_t>(stream), a, rows * width, out);
+    return geom::launch_status();
+}
+
 extern "C" int geom_sum_tensors_f32(int count, const float *const *tensors, int64_t n, float *out, void *stream)
 {
     if (count <= 0 || count > GEOM_SUM_MAX_TENSORS || n < 0) return GEOM_EINVAL;

@@ -125,21 +125,21 @@ class _InputTap(torch.autograd.Function):
         nf, width = ctx.nf, ctx.width
         lead = min(nf, width)
         gf = gp = None
+        if g_full is not None and ctx.in_place and g_full.is_contiguous() and ctx.needs_input_grad[1]:
+            # the consumers (pooling backward, the previous block's last layer, the sum of the coordinates' gradients) read their
+            # column slices of the ONE input gradient in place; the residual's share is added into it with one launch
+            # (nothing else reads g_full)
+            if g_res is not None:
+                g_full[..., :width].add_(g_res)
+            return (g_full[..., :nf] if ctx.needs_input_grad[0] else None), g_full[..., nf:], None, None
         if ctx.needs_input_grad[0]:
             gf = g_full[..., :nf].clone() if g_full is not None else g_res.new_zeros(ctx.shapes[0])
             if g_res is not None and lead:
                 gf[..., :lead] += g_res[..., :lead]
         if ctx.needs_input_grad[1]:
-            if g_full is not None and ctx.in_place and g_full.is_contiguous():
-                # the consumers (pooling backward, the previous block's last layer) read their column slices of the ONE input
-                # gradient in place; the residual's share is added into it (nothing else reads g_full)
-                gp = g_full[..., nf:]
-                if g_res is not None and width > nf:
-                    gp[..., :width - nf].add_(g_res[..., nf:width])
-            else:
-                gp = g_full[..., nf:].contiguous() if g_full is not None else g_res.new_zeros(ctx.shapes[1])
-                if g_res is not None and width > nf:
-                    gp[..., :width - nf] += g_res[..., nf:width]
+            gp = g_full[..., nf:].contiguous() if g_full is not None else g_res.new_zeros(ctx.shapes[1])
+            if g_res is not None and width > nf:
+                gp[..., :width - nf] += g_res[..., nf:width]
         return gf, gp, None, None
 
 

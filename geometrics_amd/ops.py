@@ -486,20 +486,33 @@ class FanOut(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         import ctypes
-        given = [g.contiguous() for g in grads if g is not None]
+
+        def rows(g):      # a [.., width] column slice of a wider row-major buffer is read in place
+            if g.is_contiguous():
+                return g, g.shape[-1]
+            if g.dim() >= 2 and g.stride(-1) == 1 and g.stride(-2) >= g.shape[-1] and \
+                    all(g.stride(d) == g.stride(d + 1) * g.shape[d + 1] for d in range(g.dim() - 2)):
+                return g, g.stride(-2)
+            return g.contiguous(), g.shape[-1]
+        given = [rows(g) for g in grads if g is not None]
         if not given:
             return None, None
-        if len(given) == 1:
-            return given[0], None
-        out = torch.empty_like(given[0])
-        if not (out.is_cuda and out.dtype == torch.float32) or len(given) > 8:
-            total = given[0]
-            for g in given[1:]:
+        first = given[0][0]
+        fast = first.is_cuda and first.dtype == torch.float32 and len(given) <= 8 and first.dim() >= 1
+        if len(given) == 1 or not fast:
+            total = first.contiguous()
+            for g, _ in given[1:]:
                 total = total + g
             return total, None
-        ptrs = (ctypes.c_void_p * len(given))(*[g.data_ptr() for g in given])
+        out = torch.empty(first.shape, dtype=torch.float32, device=first.device)
+        ptrs = (ctypes.c_void_p * len(given))(*[g.data_ptr() for g, _ in given])
+        width = first.shape[-1]
         with torch.cuda.device(out.device):
-            _lib.call("geom_sum_tensors_f32", len(given), ptrs, out.numel(), out.data_ptr())
+            if all(ld == width for _, ld in given):
+                _lib.call("geom_sum_tensors_f32", len(given), ptrs, out.numel(), out.data_ptr())
+            else:
+                lds = (ctypes.c_int64 * len(given))(*[ld for _, ld in given])
+                _lib.call("geom_sum_tensors_rows_f32", len(given), ptrs, lds, out.numel() // width, width, out.data_ptr())
         return out, None
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GEOM_ABI_VERSION 13
+#define GEOM_ABI_VERSION 14
 
 /* argument errors */
 #define GEOM_EINVAL   (-1) /* bad size / null pointer */
@@ -474,6 +474,11 @@ int geom_stage_regularisers_bwd_f32(int b, int nv, const float *prev, int prev_b
  * instead of one accumulation launch per consumer (python: utils.fan_out). */
 #define GEOM_SUM_MAX_TENSORS 8
 int geom_sum_tensors_f32(int count, const float *const *tensors, int64_t n, float *out, void *stream);
+/* ... for [rows, width] operands some of which are column slices of wider row-major buffers: lds[k] = floats between two rows
+ * of tensors[k] (>= width; == width: contiguous); out contiguous.  (The gradient of a block's coordinate input is the
+ * leading three columns of the 1155-wide input gradient: read in place.) */
+int geom_sum_tensors_rows_f32(int count, const float *const *tensors, const int64_t *lds, int64_t rows, int width, float *out,
+                              void *stream);
 
 /* Camera of every image from param [b,3] = (azimuth deg, elevation deg, distance) (reference utils.py:286-313: ~35 tiny
  * torch launches per call, three calls per training step): cam_mat [b,3,3] (rows = the camera's normalised x, y, z axes),

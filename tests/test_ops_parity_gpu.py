@@ -1876,6 +1876,13 @@ def test_fan_out_sums_its_handles_gradients_in_one_launch(gpu):
     x.grad = None
     ((hs[0] * ws[0]).sum() + (hs[2] * ws[2]).sum()).backward()
     assert torch.equal(x.grad, ws[0] + ws[2])
+    # a gradient that arrives as a column slice of a wider buffer (the coordinates' share of a block's 1155-wide input gradient)
+    # is read in place (geom_sum_tensors_rows_f32): same sum
+    wide = torch.randn(16, 482, 1155, device=gpu)
+    hs = utils.fan_out(x, 3)
+    x.grad = None
+    torch.autograd.backward(hs, [ws[0], wide[..., :3], ws[1]])
+    assert torch.equal(x.grad, (ws[0] + wide[..., :3]) + ws[1])
 
 
 def test_sum_losses_is_one_launch_and_the_same_sum(gpu):
